@@ -1,0 +1,148 @@
+"""Independent float64 numpy restatement of the WaveNet / LSTM math -- TEST INFRASTRUCTURE ONLY.
+
+Written from the algorithm description, NOT from oracle/na_oracle.c:
+whole-signal (non-streaming, no rings, no chunks), vectorised over time, float64 accumulate.
+It exists so the C oracle's ring / chunk / prewarm bookkeeping is checked by something that
+has none of it.  The initial state is emulated by a zero lead-in longer than the receptive
+field, which is what the reference's analytic Prewarm (WaveNet.h:746-766) is equivalent to.
+"""
+import numpy as np
+
+
+def fast_tanh(x):
+    """Activation.h:83-91 in float64 (rational approximation, not libm)."""
+    ax = np.abs(x)
+    x2 = x * x
+    return (x * (2.45550750702956 + 2.45550750702956 * ax + (0.893229853513558 + 0.821226666969744 * ax) * x2)
+            / (2.44506634652299 + (2.44506634652299 + x2) * np.abs(x + 0.814642734961073 * x * ax)))
+
+
+def fast_sigmoid(x):
+    return 0.5 * (fast_tanh(0.5 * x) + 1.0)
+
+
+def leaky_relu(x):
+    return np.where(x > 0, x, 0.01 * x)
+
+
+def _shift(h, s):
+    """h[:, t] -> h[:, t - s] with zeros flowing in (s >= 0)."""
+    if s == 0:
+        return h
+    out = np.zeros_like(h)
+    if s < h.shape[1]:
+        out[:, s:] = h[:, :-s]
+    return out
+
+
+def wavenet_forward(arrays, weights, x, lead_in=None, tanh=fast_tanh):
+    """Returns y for signal x assuming the model was prewarmed (zero-input steady state) before x."""
+    w = np.asarray(weights, dtype=np.float64)
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        v = w[pos:pos + n]
+        assert v.size == n, "ran out of weights"
+        pos += n
+        return v
+
+    rf = sum((k - 1) * d for a in arrays for k, d in zip(a["kernel_sizes"], a["dilations"]))
+    rf += sum((a["head_kernel_size"] - 1) * a["head_dilation"] for a in arrays)
+    if lead_in is None:
+        lead_in = rf + 8
+    sig = np.concatenate([np.zeros(lead_in), np.asarray(x, dtype=np.float64)])
+    T = sig.size
+    cond = sig[None, :]
+    layer_in = cond
+    head = None
+    for a in arrays:
+        c = a["channels"]
+        act = leaky_relu if a["activation"] == 1 else tanh
+        w_re = take(c * a["input_size"]).reshape(c, a["input_size"])
+        h = w_re @ layer_in
+        if head is None:
+            head = np.zeros((c, T))
+        for k, d in zip(a["kernel_sizes"], a["dilations"]):
+            wc = take(c * c * k).reshape(c, c, k)
+            bc = take(c)
+            wm = take(c * a["condition_size"]).reshape(c, a["condition_size"])
+            w1 = take(c * c).reshape(c, c)
+            b1 = take(c)
+            z = bc[:, None] + wm @ cond
+            for tap in range(k):
+                z = z + wc[:, :, tap] @ _shift(h, d * (k - 1 - tap))
+            z = act(z)
+            head = head + z
+            h = w1 @ z + b1[:, None] + h
+        kh = a["head_kernel_size"]
+        wh = take(a["head_size"] * c * kh).reshape(a["head_size"], c, kh)
+        out = np.zeros((a["head_size"], T))
+        for tap in range(kh):
+            out = out + wh[:, :, tap] @ _shift(head, a["head_dilation"] * (kh - 1 - tap))
+        if a["has_head_bias"]:
+            out = out + take(a["head_size"])[:, None]
+        head = out
+        layer_in = h
+    scale = take(1)[0]
+    assert pos == w.size, "weights left over"
+    return (scale * head[0])[lead_in:], rf
+
+
+def lstm_forward_nam(num_layers, hidden, weights, x, prewarm=2048, tanh=fast_tanh, sigmoid=fast_sigmoid):
+    w = np.asarray(weights, dtype=np.float64)
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        v = w[pos:pos + n]
+        pos += n
+        return v
+
+    layers = []
+    for l in range(num_layers):
+        i = 1 if l == 0 else hidden
+        W = take(4 * hidden * (i + hidden)).reshape(4 * hidden, i + hidden)
+        b = take(4 * hidden)
+        h0 = take(hidden).copy()
+        c0 = take(hidden).copy()
+        layers.append([W, b, h0, c0])
+    wh = take(hidden)
+    bh = take(1)[0]
+    assert pos == w.size
+    return _lstm_run(layers, wh, bh, hidden, x, prewarm, tanh, sigmoid)
+
+
+def lstm_forward_keras(model_json, x, prewarm=2048, tanh=fast_tanh, sigmoid=fast_sigmoid):
+    ls = model_json["layers"]
+    hidden = int(ls[0]["shape"][-1])
+    layers = []
+    for l in ls[:-1]:
+        kernel = np.array(l["weights"][0], dtype=np.float64)      # [I][4H]
+        recurrent = np.array(l["weights"][1], dtype=np.float64)   # [H][4H]
+        bias = np.array(l["weights"][2], dtype=np.float64).ravel()
+        W = np.concatenate([kernel.T, recurrent.T], axis=1)
+        layers.append([W, bias, np.zeros(hidden), np.zeros(hidden)])
+    wh = np.array(ls[-1]["weights"][0], dtype=np.float64).ravel()
+    bh = float(ls[-1]["weights"][1][0])
+    return _lstm_run(layers, wh, bh, hidden, x, prewarm, tanh, sigmoid)
+
+
+def _lstm_run(layers, wh, bh, H, x, prewarm, tanh, sigmoid):
+    sig = np.concatenate([np.zeros(prewarm), np.asarray(x, dtype=np.float64)])
+    y = np.empty(sig.size)
+    for t in range(sig.size):
+        inp = np.array([sig[t]])
+        for L in layers:
+            W, b, h, c = L
+            g = W @ np.concatenate([inp, h]) + b
+            c = sigmoid(g[H:2 * H]) * c + sigmoid(g[0:H]) * tanh(g[2 * H:3 * H])
+            h = sigmoid(g[3 * H:4 * H]) * tanh(c)
+            L[2], L[3] = h, c
+            inp = h
+        y[t] = wh @ inp + bh
+    return y[prewarm:]
+
+
+def std_sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
