@@ -1,0 +1,69 @@
+/*
+ * neuralaudio_amd.h -- additive C ABI of the MI355X-native library: the many-stream batch engine the
+ * reference lacks, plus C access to the NeuralModel virtuals the legacy C API never exported.
+ *
+ * Plain pointers and sizes only (no C++/torch types).  Every function returning int returns 0 on success
+ * and a negative value on failure; the failure text is available from NA_GetLastError() (thread-local).
+ *
+ * The batch is the data-parallel drop-in for "N hosts each calling NeuralModel::Process"
+ * (NeuralAudio/NeuralModel.h:127): stream s of the batch is bit-for-bit what a single NeuralModel created
+ * from the same file computes, so row s of `in`/`out` replaces the s-th host's Process(input, output, n).
+ */
+#ifndef NEURALAUDIO_AMD_H
+#define NEURALAUDIO_AMD_H
+
+#include "NeuralAudioCApi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct NA_Batch NA_Batch;
+
+/* ---- library / device ------------------------------------------------------------------------- */
+NA_EXTERN const char* NA_GetLastError(void);
+NA_EXTERN int NA_GetDeviceCount(void);                 /* 0 when no HIP device / driver is present */
+NA_EXTERN const char* NA_GetVersion(void);
+
+/* ---- loader / model extras (NeuralModelLoader setters NeuralModel.h:155-221, virtuals :40-134) -- */
+NA_EXTERN NeuralModel* NA_CreateModelFromFileUtf8(NeuralModelLoader* loader, const char* utf8Path, int doPrewarm);
+NA_EXTERN NeuralModel* NA_CreateModelFromString(NeuralModelLoader* loader, const char* jsonText, const char* extension, int doPrewarm);
+NA_EXTERN void NA_SetDevice(NeuralModelLoader* loader, int device);
+NA_EXTERN void NA_SetDefaultQualityScaleFactor(NeuralModelLoader* loader, float quality);
+NA_EXTERN void NA_SetExternalSampleRate(NeuralModelLoader* loader, int sampleRate);
+NA_EXTERN int NA_HasQualityScaling(NeuralModel* model);
+NA_EXTERN float NA_GetQualityScaleFactor(NeuralModel* model);
+NA_EXTERN void NA_SetQualityScaleFactor(NeuralModel* model, float quality);
+NA_EXTERN int NA_GetReceptiveFieldSize(NeuralModel* model);
+NA_EXTERN int NA_Prewarm(NeuralModel* model);
+/* copies the JSON text of a metadata field into buf (NUL-terminated, truncated); returns its full length */
+NA_EXTERN int NA_GetMetadata(NeuralModel* model, const char* fieldName, char* buf, int bufSize);
+NA_EXTERN int NA_GetModelVersion(NeuralModel* model, char* buf, int bufSize);
+
+/* ---- batch engine -------------------------------------------------------------------------------- */
+/* One batch == one GPU.  hipStream: NULL -> the batch creates its own non-blocking HIP stream;
+ * otherwise the caller's hipStream_t is borrowed (e.g. torch.cuda.current_stream().cuda_stream). */
+NA_EXTERN NA_Batch* NA_BatchCreate(int device, void* hipStream);
+NA_EXTERN void NA_BatchDestroy(NA_Batch* batch);
+/* Adds `count` streams running `model` (weights are shared on the device); returns the id (= row) of the
+ * first one, ids are consecutive; negative on failure.  quality is used by SlimmableContainer models. */
+NA_EXTERN int NA_BatchAddStreams(NA_Batch* batch, NeuralModel* model, float quality, int count, int doPrewarm);
+NA_EXTERN int NA_BatchNumStreams(NA_Batch* batch);
+NA_EXTERN int NA_BatchSetQuality(NA_Batch* batch, int stream, float quality);
+NA_EXTERN int NA_BatchGetActiveSubModel(NA_Batch* batch, int stream);
+NA_EXTERN int NA_BatchPrewarm(NA_Batch* batch, int stream); /* stream < 0: all */
+/* host pointers, layout [streams][n]; synchronous */
+NA_EXTERN int NA_BatchProcess(NA_Batch* batch, const float* in, float* out, size_t n);
+/* DEVICE pointers, row s = stream s, rows `stride` floats apart; asynchronous on the batch's stream */
+NA_EXTERN int NA_BatchProcessDevice(NA_Batch* batch, const float* dIn, float* dOut, size_t n, long inStride, long outStride);
+NA_EXTERN int NA_BatchSynchronize(NA_Batch* batch);
+NA_EXTERN void* NA_BatchGetHipStream(NA_Batch* batch);
+/* roofline bookkeeping (stream-weighted means): compulsory HBM bytes and multiply-accumulates per sample */
+NA_EXTERN double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames);
+NA_EXTERN double NA_BatchMacsPerSample(NA_Batch* batch);
+NA_EXTERN double NA_BatchStateBytes(NA_Batch* batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

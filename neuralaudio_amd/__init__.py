@@ -1,0 +1,241 @@
+"""neuralaudio_amd -- MI355X-native NeuralAudio hot path (NAM WaveNet / LSTM per-sample inference).
+
+Thin, pythonic mirror of the reference's host interface for this path:
+  NeuralModelLoader / NeuralModel  <->  NeuralAudio/NeuralModel.h:33-231 (same method names and meaning)
+  Batch                            <->  new: many independent streams per GPU (include/neuralaudio_amd.h)
+All compute happens in libNeuralAudioCAPI.so (C++ host code + hand-written gfx950 HIP kernels) through
+its C ABI; numpy arrays are only the host-side containers.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+__all__ = ["NeuralModelLoader", "NeuralModel", "Batch", "EModelLoadMode", "device_count", "NeuralAudioError"]
+
+
+class NeuralAudioError(RuntimeError):
+    pass
+
+
+class EModelLoadMode:
+    Internal = 0
+    RTNeural = 1
+    NAMCore = 2
+
+
+def device_count():
+    return capi.device_count()
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class NeuralModel:
+    """One mono audio stream (NeuralAudio::NeuralModel). Created by NeuralModelLoader."""
+
+    def __init__(self, handle):
+        self._lib = capi.load_library()
+        self._h = handle
+
+    # -- reference API -------------------------------------------------------------------------
+    def GetLoadMode(self):
+        return self._lib.GetLoadMode(self._h)
+
+    def IsStatic(self):
+        return bool(self._lib.IsStatic(self._h))
+
+    def SetMaxAudioBufferSize(self, max_size):
+        self._lib.SetMaxAudioBufferSize(self._h, int(max_size))
+
+    def GetRecommendedInputDBAdjustment(self):
+        return float(self._lib.GetRecommendedInputDBAdjustment(self._h))
+
+    def GetRecommendedOutputDBAdjustment(self):
+        return float(self._lib.GetRecommendedOutputDBAdjustment(self._h))
+
+    def GetSampleRate(self):
+        return float(self._lib.GetSampleRate(self._h))
+
+    def GetReceptiveFieldSize(self):
+        return int(self._lib.NA_GetReceptiveFieldSize(self._h))
+
+    def HasQualityScaling(self):
+        return bool(self._lib.NA_HasQualityScaling(self._h))
+
+    def GetQualityScaleFactor(self):
+        return float(self._lib.NA_GetQualityScaleFactor(self._h))
+
+    def SetQualityScaleFactor(self, q):
+        self._lib.NA_SetQualityScaleFactor(self._h, float(q))
+
+    def GetModelVersion(self):
+        buf = C.create_string_buffer(256)
+        self._lib.NA_GetModelVersion(self._h, buf, 256)
+        return buf.value.decode()
+
+    def GetMetadata(self, field):
+        buf = C.create_string_buffer(65536)
+        self._lib.NA_GetMetadata(self._h, field.encode(), buf, 65536)
+        return buf.value.decode()
+
+    def Prewarm(self):
+        if self._lib.NA_Prewarm(self._h) != 0:
+            raise NeuralAudioError(capi.last_error())
+
+    def Process(self, x):
+        """input -> output (same length), any number of samples; runs on the GPU."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty_like(x)
+        self._lib.NA_GetLastError()
+        self._lib.Process(self._h, _fptr(x), _fptr(y), x.size)
+        return y
+
+    def close(self):
+        if self._h:
+            self._lib.DeleteModel(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NeuralModelLoader:
+    """NeuralAudio::NeuralModelLoader (settings + factories)."""
+
+    def __init__(self):
+        self._lib = capi.load_library()
+        self._h = self._lib.CreateLoader()
+        if not self._h:
+            raise NeuralAudioError(capi.last_error())
+
+    def SetLSTMLoadMode(self, mode):
+        self._lib.SetLSTMLoadMode(self._h, int(mode))
+
+    def SetWaveNetLoadMode(self, mode):
+        self._lib.SetWaveNetLoadMode(self._h, int(mode))
+
+    def SetAudioInputLevelDBu(self, dbu):
+        self._lib.SetAudioInputLevelDBu(self._h, float(dbu))
+
+    def SetDefaultMaxAudioBufferSize(self, n):
+        self._lib.SetDefaultMaxAudioBufferSize(self._h, int(n))
+
+    def SetDefaultQualityScaleFactor(self, q):
+        self._lib.NA_SetDefaultQualityScaleFactor(self._h, float(q))
+
+    def SetExternalSampleRate(self, sr):
+        self._lib.NA_SetExternalSampleRate(self._h, int(sr))
+
+    def SetDevice(self, device):
+        self._lib.NA_SetDevice(self._h, int(device))
+
+    def CreateFromFile(self, path, doPrewarm=True, use_wchar_entry=False):
+        """Returns None when the file is missing / unsupported (reference: nullptr); raises on malformed files."""
+        if use_wchar_entry:
+            h = self._lib.CreateModelFromFile(self._h, str(path))
+        else:
+            h = self._lib.NA_CreateModelFromFileUtf8(self._h, str(path).encode(), 1 if doPrewarm else 0)
+        if not h:
+            err = capi.last_error()
+            if "not found or not supported" in err or "model not supported" in err:
+                return None
+            raise NeuralAudioError(err)
+        return NeuralModel(h)
+
+    def CreateFromString(self, text, extension, doPrewarm=True):
+        h = self._lib.NA_CreateModelFromString(self._h, text.encode(), extension.encode(), 1 if doPrewarm else 0)
+        if not h:
+            err = capi.last_error()
+            if "model not supported" in err:
+                return None
+            raise NeuralAudioError(err)
+        return NeuralModel(h)
+
+    def close(self):
+        if self._h:
+            self._lib.DeleteLoader(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """Many independent streams on one GPU; row s of the [streams][n] arrays is stream s."""
+
+    def __init__(self, device=0, hip_stream=None):
+        self._lib = capi.load_library()
+        self._h = self._lib.NA_BatchCreate(int(device), C.c_void_p(hip_stream) if hip_stream else None)
+        if not self._h:
+            raise NeuralAudioError(capi.last_error())
+
+    def AddStreams(self, model, count=1, quality=1.0, doPrewarm=True):
+        first = self._lib.NA_BatchAddStreams(self._h, model._h, float(quality), int(count), 1 if doPrewarm else 0)
+        if first < 0:
+            raise NeuralAudioError(capi.last_error())
+        return first
+
+    def NumStreams(self):
+        return int(self._lib.NA_BatchNumStreams(self._h))
+
+    def SetQuality(self, stream, q):
+        if self._lib.NA_BatchSetQuality(self._h, int(stream), float(q)) != 0:
+            raise NeuralAudioError(capi.last_error())
+
+    def GetActiveSubModel(self, stream):
+        return int(self._lib.NA_BatchGetActiveSubModel(self._h, int(stream)))
+
+    def Prewarm(self, stream=-1):
+        if self._lib.NA_BatchPrewarm(self._h, int(stream)) != 0:
+            raise NeuralAudioError(capi.last_error())
+
+    def Process(self, x):
+        """x: host array [streams, n] -> host array [streams, n] (synchronous)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.ndim == 2 and x.shape[0] == self.NumStreams(), "expected [streams, n]"
+        y = np.empty_like(x)
+        if self._lib.NA_BatchProcess(self._h, _fptr(x), _fptr(y), x.shape[1]) != 0:
+            raise NeuralAudioError(capi.last_error())
+        return y
+
+    def ProcessDevice(self, d_in, d_out, n, in_stride=None, out_stride=None):
+        """d_in / d_out: raw device pointers (ints); asynchronous on the batch's HIP stream."""
+        rc = self._lib.NA_BatchProcessDevice(self._h, C.c_void_p(d_in), C.c_void_p(d_out), int(n),
+                                             int(in_stride if in_stride is not None else n),
+                                             int(out_stride if out_stride is not None else n))
+        if rc != 0:
+            raise NeuralAudioError(capi.last_error())
+
+    def Synchronize(self):
+        if self._lib.NA_BatchSynchronize(self._h) != 0:
+            raise NeuralAudioError(capi.last_error())
+
+    def AlgorithmicBytesPerSample(self, block_frames=128):
+        return float(self._lib.NA_BatchAlgorithmicBytesPerSample(self._h, int(block_frames)))
+
+    def MacsPerSample(self):
+        return float(self._lib.NA_BatchMacsPerSample(self._h))
+
+    def StateBytes(self):
+        return float(self._lib.NA_BatchStateBytes(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.NA_BatchDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,353 @@
+// capi.cpp -- extern "C" surface of libNeuralAudioCAPI.so: the 15 legacy symbols of the reference's
+// NeuralAudioCAPI (NeuralAudioCAPI/NeuralAudioCApi.cpp:4-97) plus the additive NA_* batch API
+// (include/neuralaudio_amd.h).  No exception crosses this boundary.
+#include <cstring>
+#include <cwchar>
+#include <string>
+
+#include "neuralaudio_amd.h"
+#include "neural_model_impl.h"
+
+struct NeuralModel
+{
+	NeuralAudio::NeuralModel* model;
+};
+
+struct NeuralModelLoader
+{
+	NeuralAudio::NeuralModelLoader* loader;
+};
+
+struct NA_Batch
+{
+	na::GpuBatch* batch;
+};
+
+namespace
+{
+	thread_local std::string g_lastError;
+
+	void SetError(const char* what) { g_lastError = what ? what : "unknown error"; }
+
+	template <typename F>
+	int Guard(F&& f)
+	{
+		try
+		{
+			f();
+			return 0;
+		}
+		catch (const std::exception& e)
+		{
+			SetError(e.what());
+		}
+		catch (...)
+		{
+			SetError("unknown exception");
+		}
+		return -1;
+	}
+
+	// wchar_t is UTF-32 on Linux and UTF-16 on Windows (the C# caller marshals LPWStr, NativeApi.cs:17)
+	std::string WideToUtf8(const wchar_t* w)
+	{
+		std::string out;
+		if (!w) return out;
+		for (; *w; ++w)
+		{
+			unsigned long cp = (unsigned long)*w;
+			if (sizeof(wchar_t) == 2 && cp >= 0xD800 && cp <= 0xDBFF && w[1] >= 0xDC00 && w[1] <= 0xDFFF)
+			{
+				cp = 0x10000 + ((cp - 0xD800) << 10) + ((unsigned long)w[1] - 0xDC00);
+				++w;
+			}
+			if (cp < 0x80) out.push_back((char)cp);
+			else if (cp < 0x800)
+			{
+				out.push_back((char)(0xC0 | (cp >> 6)));
+				out.push_back((char)(0x80 | (cp & 0x3F)));
+			}
+			else if (cp < 0x10000)
+			{
+				out.push_back((char)(0xE0 | (cp >> 12)));
+				out.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+				out.push_back((char)(0x80 | (cp & 0x3F)));
+			}
+			else
+			{
+				out.push_back((char)(0xF0 | (cp >> 18)));
+				out.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+				out.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+				out.push_back((char)(0x80 | (cp & 0x3F)));
+			}
+		}
+		return out;
+	}
+
+	NeuralModel* Wrap(NeuralAudio::NeuralModel* m)
+	{
+		if (!m) return nullptr;
+		NeuralModel* w = new NeuralModel();
+		w->model = m;
+		return w;
+	}
+
+	int CopyOut(const std::string& s, char* buf, int bufSize)
+	{
+		if (buf && bufSize > 0)
+		{
+			const size_t n = std::min((size_t)bufSize - 1, s.size());
+			memcpy(buf, s.data(), n);
+			buf[n] = 0;
+		}
+		return (int)s.size();
+	}
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------- legacy symbols (reference NeuralAudioCApi.h:18-46)
+
+NeuralModelLoader* CreateLoader(void)
+{
+	NeuralModelLoader* loader = nullptr;
+	Guard([&] {
+		loader = new NeuralModelLoader();
+		loader->loader = new NeuralAudio::NeuralModelLoader();
+	});
+	return loader;
+}
+
+void DeleteLoader(NeuralModelLoader* loader)
+{
+	if (!loader) return;
+	delete loader->loader;
+	delete loader;
+}
+
+NeuralModel* CreateModelFromFile(NeuralModelLoader* loader, const wchar_t* modelPath)
+{
+	NeuralModel* result = nullptr;
+	Guard([&] {
+		if (!loader || !modelPath) throw std::runtime_error("CreateModelFromFile: null argument");
+		NeuralAudio::NeuralModel* m = loader->loader->CreateFromFile(std::filesystem::path(WideToUtf8(modelPath)));
+		if (!m) SetError("model file not found or not supported");
+		result = Wrap(m);
+	});
+	return result;
+}
+
+void DeleteModel(NeuralModel* model)
+{
+	if (!model) return;
+	delete model->model;
+	delete model;
+}
+
+void SetLSTMLoadMode(NeuralModelLoader* loader, int loadMode)
+{
+	if (loader) loader->loader->SetLSTMLoadMode((NeuralAudio::EModelLoadMode)loadMode);
+}
+
+void SetWaveNetLoadMode(NeuralModelLoader* loader, int loadMode)
+{
+	if (loader) loader->loader->SetWaveNetLoadMode((NeuralAudio::EModelLoadMode)loadMode);
+}
+
+void SetAudioInputLevelDBu(NeuralModelLoader* loader, float audioDBu)
+{
+	if (loader) loader->loader->SetAudioInputLevelDBu(audioDBu);
+}
+
+void SetDefaultMaxAudioBufferSize(NeuralModelLoader* loader, int maxSize)
+{
+	if (loader) loader->loader->SetDefaultMaxAudioBufferSize(maxSize);
+}
+
+int GetLoadMode(NeuralModel* model) { return model ? (int)model->model->GetLoadMode() : 0; }
+
+bool IsStatic(NeuralModel* model) { return model ? model->model->IsStatic() : false; }
+
+void SetMaxAudioBufferSize(NeuralModel* model, int maxSize)
+{
+	if (model) model->model->SetMaxAudioBufferSize(maxSize);
+}
+
+float GetRecommendedInputDBAdjustment(NeuralModel* model) { return model ? model->model->GetRecommendedInputDBAdjustment() : 0.0f; }
+
+float GetRecommendedOutputDBAdjustment(NeuralModel* model) { return model ? model->model->GetRecommendedOutputDBAdjustment() : 0.0f; }
+
+float GetSampleRate(NeuralModel* model) { return model ? model->model->GetSampleRate() : 0.0f; }
+
+void Process(NeuralModel* model, float* input, float* output, size_t numSamples)
+{
+	if (!model) return;
+	Guard([&] { model->model->Process(input, output, numSamples); });
+}
+
+// ---------------------------------------------------------------- additive API (include/neuralaudio_amd.h)
+
+const char* NA_GetLastError(void) { return g_lastError.c_str(); }
+
+int NA_GetDeviceCount(void) { return na::VisibleDeviceCount(); }
+
+const char* NA_GetVersion(void) { return "neuralaudio_amd 0.1.0 (gfx950)"; }
+
+NeuralModel* NA_CreateModelFromFileUtf8(NeuralModelLoader* loader, const char* utf8Path, int doPrewarm)
+{
+	NeuralModel* result = nullptr;
+	Guard([&] {
+		if (!loader || !utf8Path) throw std::runtime_error("NA_CreateModelFromFileUtf8: null argument");
+		NeuralAudio::NeuralModel* m = loader->loader->CreateFromFile(std::filesystem::path(std::string(utf8Path)), doPrewarm != 0);
+		if (!m) SetError("model file not found or not supported");
+		result = Wrap(m);
+	});
+	return result;
+}
+
+NeuralModel* NA_CreateModelFromString(NeuralModelLoader* loader, const char* jsonText, const char* extension, int doPrewarm)
+{
+	NeuralModel* result = nullptr;
+	Guard([&] {
+		if (!loader || !jsonText || !extension) throw std::runtime_error("NA_CreateModelFromString: null argument");
+		NeuralAudio::NeuralModel* m = loader->loader->CreateFromString(jsonText, std::filesystem::path(std::string(extension)), doPrewarm != 0);
+		if (!m) SetError("model not supported");
+		result = Wrap(m);
+	});
+	return result;
+}
+
+void NA_SetDevice(NeuralModelLoader* loader, int device)
+{
+	if (loader) loader->loader->SetDevice(device);
+}
+
+void NA_SetDefaultQualityScaleFactor(NeuralModelLoader* loader, float quality)
+{
+	if (loader) loader->loader->SetDefaultQualityScaleFactor(quality);
+}
+
+void NA_SetExternalSampleRate(NeuralModelLoader* loader, int sampleRate)
+{
+	if (loader) loader->loader->SetExternalSampleRate(sampleRate);
+}
+
+int NA_HasQualityScaling(NeuralModel* model) { return (model && model->model->HasQualityScaling()) ? 1 : 0; }
+
+float NA_GetQualityScaleFactor(NeuralModel* model) { return model ? model->model->GetQualityScaleFactor() : 1.0f; }
+
+void NA_SetQualityScaleFactor(NeuralModel* model, float quality)
+{
+	if (model) Guard([&] { model->model->SetQualityScaleFactor(quality); });
+}
+
+int NA_GetReceptiveFieldSize(NeuralModel* model) { return model ? model->model->GetReceptiveFieldSize() : -1; }
+
+int NA_Prewarm(NeuralModel* model)
+{
+	if (!model) return -1;
+	return Guard([&] { model->model->Prewarm(); });
+}
+
+int NA_GetMetadata(NeuralModel* model, const char* fieldName, char* buf, int bufSize)
+{
+	if (!model || !fieldName) return -1;
+	return CopyOut(model->model->GetMetadata(fieldName), buf, bufSize);
+}
+
+int NA_GetModelVersion(NeuralModel* model, char* buf, int bufSize)
+{
+	if (!model) return -1;
+	return CopyOut(model->model->GetModelVersion(), buf, bufSize);
+}
+
+NA_Batch* NA_BatchCreate(int device, void* hipStream)
+{
+	NA_Batch* b = nullptr;
+	Guard([&] {
+		na::GpuBatch* gb = new na::GpuBatch(device, reinterpret_cast<hipStream_t>(hipStream));
+		b = new NA_Batch();
+		b->batch = gb;
+	});
+	return b;
+}
+
+void NA_BatchDestroy(NA_Batch* batch)
+{
+	if (!batch) return;
+	Guard([&] { delete batch->batch; });
+	delete batch;
+}
+
+int NA_BatchAddStreams(NA_Batch* batch, NeuralModel* model, float quality, int count, int doPrewarm)
+{
+	int first = -1;
+	const int rc = Guard([&] {
+		if (!batch || !model || count < 1) throw std::runtime_error("NA_BatchAddStreams: bad argument");
+		NeuralAudio::GpuModel* gm = dynamic_cast<NeuralAudio::GpuModel*>(model->model);
+		if (!gm) throw std::runtime_error("NA_BatchAddStreams: model was not created by this library");
+		for (int i = 0; i < count; i++)
+		{
+			const int id = batch->batch->AddStream(gm->GetLoadedModel(), quality, doPrewarm != 0);
+			if (i == 0) first = id;
+		}
+	});
+	return rc == 0 ? first : -1;
+}
+
+int NA_BatchNumStreams(NA_Batch* batch) { return batch ? batch->batch->NumStreams() : -1; }
+
+int NA_BatchSetQuality(NA_Batch* batch, int stream, float quality)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->SetQuality(stream, quality); });
+}
+
+int NA_BatchGetActiveSubModel(NA_Batch* batch, int stream)
+{
+	int idx = -1;
+	if (!batch) return -1;
+	Guard([&] { idx = batch->batch->GetActiveSubModel(stream); });
+	return idx;
+}
+
+int NA_BatchPrewarm(NA_Batch* batch, int stream)
+{
+	if (!batch) return -1;
+	return Guard([&] {
+		if (stream >= 0) batch->batch->Prewarm(stream);
+		else
+			for (int s = 0; s < batch->batch->NumStreams(); s++) batch->batch->Prewarm(s);
+	});
+}
+
+int NA_BatchProcess(NA_Batch* batch, const float* in, float* out, size_t n)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->ProcessHost(in, out, n); });
+}
+
+int NA_BatchProcessDevice(NA_Batch* batch, const float* dIn, float* dOut, size_t n, long inStride, long outStride)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->ProcessDevice(dIn, dOut, n, inStride, outStride); });
+}
+
+int NA_BatchSynchronize(NA_Batch* batch)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->Synchronize(); });
+}
+
+void* NA_BatchGetHipStream(NA_Batch* batch) { return batch ? reinterpret_cast<void*>(batch->batch->GetStream()) : nullptr; }
+
+double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames)
+{
+	return batch ? batch->batch->AlgorithmicBytesPerSample(blockFrames) : 0.0;
+}
+
+double NA_BatchMacsPerSample(NA_Batch* batch) { return batch ? batch->batch->MacsPerSample() : 0.0; }
+
+double NA_BatchStateBytes(NA_Batch* batch) { return batch ? (double)batch->batch->StateBytes() : 0.0; }
+
+} // extern "C"

@@ -1,0 +1,540 @@
+// gpu_batch.cpp -- see gpu_batch.h.  Host side only: device memory, tables, launches.
+#include "gpu_batch.h"
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+#include <hip/hip_runtime.h>
+
+#include "lstm_launch.h"
+#include "wavenet_launch.h"
+#include "wavenet_plan.h"
+
+namespace na
+{
+	void CheckHip(hipError_t e, const char* what)
+	{
+		if (e != hipSuccess) throw HipError(e, what);
+	}
+
+	int VisibleDeviceCount()
+	{
+		int count = 0;
+		const hipError_t e = hipGetDeviceCount(&count);
+		if (e != hipSuccess)
+		{
+			(void)hipGetLastError();
+			return 0;
+		}
+		return count;
+	}
+
+	namespace
+	{
+		template <typename T>
+		class DevArray
+		{
+		public:
+			DevArray() = default;
+			~DevArray() { Free(); }
+			DevArray(const DevArray&) = delete;
+			DevArray& operator=(const DevArray&) = delete;
+
+			void Alloc(size_t n)
+			{
+				Free();
+				if (n == 0) return;
+				CheckHip(hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)), "hipMalloc");
+				count = n;
+			}
+
+			void Upload(const std::vector<T>& host, hipStream_t s)
+			{
+				if (host.size() > count) Alloc(std::max(host.size(), count * 2));
+				if (!host.empty())
+				{
+					CheckHip(hipMemcpyAsync(ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, s), "hipMemcpyAsync H2D");
+					// host vectors are pageable and may be reused right away
+					CheckHip(hipStreamSynchronize(s), "hipStreamSynchronize");
+				}
+			}
+
+			void Free()
+			{
+				if (ptr) (void)hipFree(ptr);
+				ptr = nullptr;
+				count = 0;
+			}
+
+			void Swap(DevArray& o)
+			{
+				std::swap(ptr, o.ptr);
+				std::swap(count, o.count);
+			}
+
+			T* Get() const { return ptr; }
+			size_t Count() const { return count; }
+
+		private:
+			T* ptr = nullptr;
+			size_t count = 0;
+		};
+	}
+
+	// ------------------------------------------------------------------------------------------ groups
+
+	class ModelGroup
+	{
+	public:
+		ModelGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s) : desc(d), stream(s) {}
+		virtual ~ModelGroup() = default;
+
+		const std::shared_ptr<const ModelDesc> desc;
+
+		int AddMember()
+		{
+			const int member = (int)memberRow.size();
+			EnsureCapacity(member + 1);
+			memberRow.push_back(-1);
+			return member;
+		}
+
+		// row >= 0: active, reads/writes that row of the batch arrays; row < 0: inactive (state frozen)
+		void SetActive(int member, int row)
+		{
+			memberRow[(size_t)member] = row;
+			activeDirty = true;
+		}
+
+		int NumMembers() const { return (int)memberRow.size(); }
+
+		// fresh (never prewarmed) state: zero history / the model's initial h,c
+		virtual void Reset(const std::vector<int>& members) = 0;
+		virtual void Prewarm(const std::vector<int>& members) = 0;
+		virtual void Process(const float* dIn, float* dOut, long inStride, long outStride, size_t n) = 0;
+		virtual double AlgorithmicBytesPerSample(int blockFrames) const = 0;
+		virtual double MacsPerSample() const = 0;
+		virtual size_t StateBytesPerStream() const = 0;
+
+		int NumActive() const
+		{
+			int c = 0;
+			for (int r : memberRow) c += (r >= 0);
+			return c;
+		}
+
+	protected:
+		virtual void EnsureCapacity(int members) = 0;
+
+		void SyncActiveLists()
+		{
+			if (!activeDirty) return;
+			hSlots.clear();
+			hRows.clear();
+			for (size_t m = 0; m < memberRow.size(); m++)
+			{
+				if (memberRow[m] >= 0)
+				{
+					hSlots.push_back((int)m);
+					hRows.push_back(memberRow[m]);
+				}
+			}
+			dSlots.Upload(hSlots, stream);
+			dRows.Upload(hRows, stream);
+			activeDirty = false;
+		}
+
+		hipStream_t stream;
+		std::vector<int> memberRow; // member == state slot
+		std::vector<int> hSlots, hRows;
+		DevArray<int> dSlots, dRows;
+		bool activeDirty = true;
+	};
+
+	namespace
+	{
+		class WaveNetGroup : public ModelGroup
+		{
+		public:
+			WaveNetGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s) : ModelGroup(d, s), plan(BuildWaveNetPlan(d->wavenet))
+			{
+				dStages.Upload(plan.stages, stream);
+				dWpack.Upload(plan.wpack, stream);
+				dQdesc.Upload(plan.qdesc, stream);
+				dPrewarm.Upload(plan.prewarm, stream);
+				dWeights.Upload(d->wavenet.weights, stream);
+
+				std::vector<int> ringOff, ringFrames, ringG;
+				for (const auto& r : plan.rings)
+				{
+					ringOff.push_back(r.offF4);
+					ringFrames.push_back(r.frames);
+					ringG.push_back(r.G);
+				}
+				dRingOff.Upload(ringOff, stream);
+				dRingFrames.Upload(ringFrames, stream);
+				dRingG.Upload(ringG, stream);
+
+				// steady-state columns: once per model (WaveNet.h:746-766)
+				dCols.Alloc(plan.rings.size() * 16);
+				CheckHip(LaunchWaveNetPrewarmColumns(dPrewarm.Get(), (int)plan.prewarm.size(), dWeights.Get(), dCols.Get(), stream),
+					"WaveNetPrewarmColumnsKernel");
+
+				dev.stages = dStages.Get();
+				dev.wpack = dWpack.Get();
+				dev.qdesc = dQdesc.Get();
+				dev.ring_frames = dRingFrames.Get();
+				dev.nstages = (int)plan.stages.size();
+				dev.nrings = (int)plan.rings.size();
+				dev.state_f4 = plan.stateF4;
+				dev.head_scale = plan.headScale;
+			}
+
+			// ChannelHistoryBuffer::AllocBuffer zero-fills (WaveNet.h:38-40)
+			void Reset(const std::vector<int>& members) override
+			{
+				for (int m : members)
+					CheckHip(hipMemsetAsync(state.Get() + (size_t)m * (size_t)plan.stateF4 * 4, 0, (size_t)plan.stateF4 * 16, stream), "hipMemsetAsync");
+			}
+
+			void Prewarm(const std::vector<int>& members) override
+			{
+				if (members.empty()) return;
+				DevArray<int> list;
+				list.Upload(members, stream);
+				CheckHip(LaunchWaveNetFillRings(state.Get(), plan.stateF4, list.Get(), (int)members.size(), (int)plan.rings.size(),
+					dRingOff.Get(), dRingFrames.Get(), dRingG.Get(), dCols.Get(), stream), "WaveNetFillRingsKernel");
+				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize"); // `list` is freed on return
+			}
+
+			void Process(const float* dIn, float* dOut, long inStride, long outStride, size_t n) override
+			{
+				SyncActiveLists();
+				const int numActive = (int)hSlots.size();
+				if (numActive == 0) return;
+				// any n: chunks of <= 128 frames per launch (the reference chunks at 64, InternalModel.h:104-117;
+				// results do not depend on the chunking)
+				size_t offset = 0;
+				while (n > 0)
+				{
+					const int chunk = (int)std::min<size_t>(n, (size_t)WN_MAX_FRAMES);
+					CheckHip(LaunchWaveNetBlock(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
+						outStride, chunk, stream), "WaveNetBlockKernel");
+					offset += (size_t)chunk;
+					n -= (size_t)chunk;
+				}
+			}
+
+			double AlgorithmicBytesPerSample(int blockFrames) const override { return plan.AlgorithmicBytesPerSample(blockFrames); }
+			double MacsPerSample() const override { return plan.MacsPerSample(); }
+			size_t StateBytesPerStream() const override { return (size_t)plan.stateF4 * 16; }
+
+		protected:
+			void EnsureCapacity(int members) override
+			{
+				if ((size_t)members <= capacity) return;
+				const size_t newCap = std::max<size_t>((size_t)members, std::max<size_t>(capacity * 2, 16));
+				DevArray<float> bigger;
+				bigger.Alloc(newCap * (size_t)plan.stateF4 * 4);
+				if (capacity > 0)
+				{
+					CheckHip(hipMemcpyAsync(bigger.Get(), state.Get(), capacity * (size_t)plan.stateF4 * 16, hipMemcpyDeviceToDevice, stream),
+						"hipMemcpyAsync D2D");
+					CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+				}
+				state.Swap(bigger);
+				capacity = newCap;
+			}
+
+		private:
+			WaveNetPlan plan;
+			WnModelDev dev = {};
+			DevArray<WnStage> dStages;
+			DevArray<float> dWpack;
+			DevArray<WnQuad> dQdesc;
+			DevArray<WnPrewarmLayer> dPrewarm;
+			DevArray<float> dWeights;
+			DevArray<int> dRingOff, dRingFrames, dRingG;
+			DevArray<float> dCols;
+			DevArray<float> state;
+			size_t capacity = 0;
+		};
+
+		class LstmGroup : public ModelGroup
+		{
+		public:
+			LstmGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s) : ModelGroup(d, s)
+			{
+				const LSTMDesc& lstm = d->lstm;
+				if (lstm.numLayers < 1 || lstm.numLayers > LSTM_MAX_LAYERS) throw std::runtime_error("LSTM: unsupported number of layers");
+				if (!LstmHiddenSizeSupported(lstm.hiddenSize))
+					throw std::runtime_error("LSTM: hidden size " + std::to_string(lstm.hiddenSize) + " has no gfx950 kernel instance");
+				std::vector<float> w;
+				for (int l = 0; l < lstm.numLayers; l++)
+				{
+					dev.layerOff[l] = (int)w.size();
+					w.insert(w.end(), lstm.layers[(size_t)l].w.begin(), lstm.layers[(size_t)l].w.end());
+					w.insert(w.end(), lstm.layers[(size_t)l].bias.begin(), lstm.layers[(size_t)l].bias.end());
+					init.insert(init.end(), lstm.layers[(size_t)l].h0.begin(), lstm.layers[(size_t)l].h0.end());
+					init.insert(init.end(), lstm.layers[(size_t)l].c0.begin(), lstm.layers[(size_t)l].c0.end());
+				}
+				dev.headOff = (int)w.size();
+				w.insert(w.end(), lstm.headWeights.begin(), lstm.headWeights.begin() + lstm.hiddenSize);
+				w.push_back(lstm.headBias);
+				dW.Upload(w, stream);
+				dInit.Upload(init, stream);
+				dev.w = dW.Get();
+				dev.numLayers = lstm.numLayers;
+				dev.hidden = lstm.hiddenSize;
+				numElems = lstm.numLayers * 2 * lstm.hiddenSize;
+				dZeros.Alloc(LSTM_MAX_FRAMES);
+				CheckHip(hipMemsetAsync(dZeros.Get(), 0, LSTM_MAX_FRAMES * sizeof(float), stream), "hipMemsetAsync");
+			}
+
+			// InternalLSTMModelT::Prewarm -> NeuralModelImpl::Prewarm(2048, 64) (InternalModel.h:368-371):
+			// run 2048 zeros through the recurrence from the CURRENT state (the initial h/c right after load;
+			// a later Prewarm() call continues from wherever the stream is, exactly like the reference).
+			void Reset(const std::vector<int>& members) override
+			{
+				if (members.empty()) return;
+				DevArray<int> list;
+				list.Upload(members, stream);
+				CheckHip(LaunchLstmInitState(state.Get(), (int)capacity, list.Get(), (int)members.size(), dInit.Get(), numElems, stream),
+					"LstmInitStateKernel");
+				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+			}
+
+			void Prewarm(const std::vector<int>& members) override
+			{
+				if (members.empty()) return;
+				DevArray<int> list, rows;
+				list.Upload(members, stream);
+				std::vector<int> zeroRows(members.size(), 0);
+				rows.Upload(zeroRows, stream);
+				DevArray<float> sink;
+				sink.Alloc(LSTM_MAX_FRAMES);
+				for (int done = 0; done < 2048; done += LSTM_MAX_FRAMES)
+					CheckHip(LaunchLstmBlock(dev, state.Get(), (int)capacity, list.Get(), rows.Get(), (int)members.size(), dZeros.Get(), sink.Get(),
+						0, 0, LSTM_MAX_FRAMES, stream), "LstmBlockKernel (prewarm)");
+				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+			}
+
+			void Process(const float* dIn, float* dOut, long inStride, long outStride, size_t n) override
+			{
+				SyncActiveLists();
+				const int numActive = (int)hSlots.size();
+				if (numActive == 0) return;
+				size_t offset = 0;
+				while (n > 0)
+				{
+					const int chunk = (int)std::min<size_t>(n, (size_t)LSTM_MAX_FRAMES);
+					CheckHip(LaunchLstmBlock(dev, state.Get(), (int)capacity, dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset,
+						inStride, outStride, chunk, stream), "LstmBlockKernel");
+					offset += (size_t)chunk;
+					n -= (size_t)chunk;
+				}
+			}
+
+			// 8 + 2*4*(state floats)/N bytes per sample
+			double AlgorithmicBytesPerSample(int blockFrames) const override { return 8.0 + 8.0 * numElems / blockFrames; }
+
+			double MacsPerSample() const override
+			{
+				const LSTMDesc& lstm = desc->lstm;
+				double macs = 0.0;
+				for (int l = 0; l < lstm.numLayers; l++) macs += 4.0 * lstm.hiddenSize * ((l == 0 ? 1 : lstm.hiddenSize) + lstm.hiddenSize);
+				return macs + lstm.hiddenSize;
+			}
+
+			size_t StateBytesPerStream() const override { return (size_t)numElems * sizeof(float); }
+
+		protected:
+			void EnsureCapacity(int members) override
+			{
+				if ((size_t)members <= capacity) return;
+				const size_t newCap = std::max<size_t>((size_t)members, std::max<size_t>(capacity * 2, 64));
+				DevArray<float> bigger;
+				bigger.Alloc(newCap * (size_t)numElems);
+				if (capacity > 0)
+				{
+					// [elem][capacity] -> [elem][newCap]
+					CheckHip(hipMemcpy2DAsync(bigger.Get(), newCap * sizeof(float), state.Get(), capacity * sizeof(float), capacity * sizeof(float),
+						(size_t)numElems, hipMemcpyDeviceToDevice, stream), "hipMemcpy2DAsync");
+					CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+				}
+				state.Swap(bigger);
+				capacity = newCap;
+			}
+
+		private:
+			LstmModelDev dev = {};
+			DevArray<float> dW, dInit, dZeros;
+			DevArray<float> state;
+			std::vector<float> init;
+			int numElems = 0;
+			size_t capacity = 0;
+		};
+	}
+}
+
+namespace na
+{
+	// ------------------------------------------------------------------------------------------ GpuBatch
+
+	GpuBatch::GpuBatch(int dev, hipStream_t borrowedStream) : device(dev)
+	{
+		const int count = VisibleDeviceCount();
+		if (count <= 0) throw std::runtime_error("neuralaudio_amd: no HIP device is visible; this library has no CPU fallback");
+		if (dev < 0 || dev >= count) throw std::runtime_error("neuralaudio_amd: invalid HIP device index");
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		if (borrowedStream)
+		{
+			stream = borrowedStream;
+			ownsStream = false;
+		}
+		else
+		{
+			CheckHip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+		}
+	}
+
+	GpuBatch::~GpuBatch()
+	{
+		(void)hipSetDevice(device);
+		if (stream) (void)hipStreamSynchronize(stream);
+		groups.clear();
+		if (hostStage) (void)hipHostFree(hostStage);
+		if (devStage) (void)hipFree(devStage);
+		if (stream && ownsStream) (void)hipStreamDestroy(stream);
+	}
+
+	ModelGroup* GpuBatch::GroupFor(const std::shared_ptr<const ModelDesc>& desc)
+	{
+		for (auto& g : groups)
+			if (g->desc.get() == desc.get()) return g.get();
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		std::unique_ptr<ModelGroup> g;
+		if (desc->kind == MODEL_WAVENET) g.reset(new WaveNetGroup(desc, stream));
+		else if (desc->kind == MODEL_LSTM) g.reset(new LstmGroup(desc, stream));
+		else throw std::runtime_error("neuralaudio_amd: unsupported model kind");
+		groups.push_back(std::move(g));
+		return groups.back().get();
+	}
+
+	int GpuBatch::AddStream(const std::shared_ptr<const LoadedModel>& model, float quality, bool prewarm)
+	{
+		if (!model || model->subModels.empty()) throw std::runtime_error("neuralaudio_amd: AddStream with an empty model");
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		StreamRef ref;
+		ref.model = model;
+		ref.quality = quality;
+		const int row = (int)streams.size();
+		for (const auto& sm : model->subModels)
+		{
+			ModelGroup* g = GroupFor(sm.desc);
+			const int member = g->AddMember();
+			g->Reset({ member });
+			ref.members.push_back({ g, member });
+		}
+		ref.active = model->isComposite ? model->ModelIndexFromQuality(quality) : 0;
+		ref.members[(size_t)ref.active].first->SetActive(ref.members[(size_t)ref.active].second, row);
+		streams.push_back(ref);
+		if (prewarm) Prewarm(row);
+		return row;
+	}
+
+	void GpuBatch::SetQuality(int s, float quality)
+	{
+		StreamRef& ref = streams.at((size_t)s);
+		ref.quality = quality;
+		if (!ref.model->isComposite) return;
+		const int idx = ref.model->ModelIndexFromQuality(quality);
+		if (idx == ref.active) return;
+		ref.members[(size_t)ref.active].first->SetActive(ref.members[(size_t)ref.active].second, -1);
+		ref.active = idx;
+		ref.members[(size_t)idx].first->SetActive(ref.members[(size_t)idx].second, s);
+	}
+
+	float GpuBatch::GetQuality(int s) const { return streams.at((size_t)s).quality; }
+	int GpuBatch::GetActiveSubModel(int s) const { return streams.at((size_t)s).active; }
+
+	void GpuBatch::Prewarm(int s)
+	{
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		StreamRef& ref = streams.at((size_t)s);
+		// LoadAll semantics (CompositeModel.h:111-118): every submodel is prewarmed
+		for (auto& m : ref.members) m.first->Prewarm({ m.second });
+	}
+
+	void GpuBatch::ProcessDevice(const float* dIn, float* dOut, size_t n, long inStride, long outStride)
+	{
+		if (n == 0 || streams.empty()) return;
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		for (auto& g : groups) g->Process(dIn, dOut, inStride, outStride, n);
+	}
+
+	void GpuBatch::EnsureStaging(size_t floats)
+	{
+		if (floats <= stageFloats) return;
+		if (hostStage) (void)hipHostFree(hostStage);
+		if (devStage) (void)hipFree(devStage);
+		hostStage = nullptr;
+		devStage = nullptr;
+		stageFloats = 0;
+		CheckHip(hipHostMalloc(reinterpret_cast<void**>(&hostStage), floats * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+		CheckHip(hipMalloc(reinterpret_cast<void**>(&devStage), floats * sizeof(float)), "hipMalloc");
+		stageFloats = floats;
+	}
+
+	void GpuBatch::ProcessHost(const float* in, float* out, size_t n)
+	{
+		if (n == 0 || streams.empty()) return;
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		const size_t total = streams.size() * n;
+		EnsureStaging(total);
+		memcpy(hostStage, in, total * sizeof(float));
+		CheckHip(hipMemcpyAsync(devStage, hostStage, total * sizeof(float), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+		ProcessDevice(devStage, devStage, n, (long)n, (long)n);
+		CheckHip(hipMemcpyAsync(hostStage, devStage, total * sizeof(float), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H");
+		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		memcpy(out, hostStage, total * sizeof(float));
+	}
+
+	void GpuBatch::Synchronize()
+	{
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+	}
+
+	double GpuBatch::AlgorithmicBytesPerSample(int blockFrames) const
+	{
+		double sum = 0.0;
+		int n = 0;
+		for (const auto& g : groups)
+		{
+			sum += g->AlgorithmicBytesPerSample(blockFrames) * g->NumActive();
+			n += g->NumActive();
+		}
+		return n ? sum / n : 0.0;
+	}
+
+	double GpuBatch::MacsPerSample() const
+	{
+		double sum = 0.0;
+		int n = 0;
+		for (const auto& g : groups)
+		{
+			sum += g->MacsPerSample() * g->NumActive();
+			n += g->NumActive();
+		}
+		return n ? sum / n : 0.0;
+	}
+
+	size_t GpuBatch::StateBytes() const
+	{
+		size_t total = 0;
+		for (const auto& g : groups) total += g->StateBytesPerStream() * (size_t)g->NumMembers();
+		return total;
+	}
+}

@@ -1,0 +1,99 @@
+// gpu_batch.h -- the batched multi-stream engine: owns device state for many independent audio
+// streams on ONE GPU and runs the WaveNet / LSTM kernels over them, one launch per model group
+// and block of <= 128 frames.
+//
+// The reference has no counterpart (it processes one stream per NeuralModel instance on the caller's
+// thread, NeuralAudio/NeuralModel.h:127); this is the data-parallel axis the GPU path adds.  A
+// single-stream NeuralModel (neural_model.cpp) is a GpuBatch with one stream.
+#pragma once
+
+#include <cstddef>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "model_loader.h"
+
+namespace na
+{
+	class HipError : public std::runtime_error
+	{
+	public:
+		HipError(hipError_t e, const char* what) : std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)), code(e) {}
+		hipError_t code;
+	};
+
+	void CheckHip(hipError_t e, const char* what);
+
+	// returns the number of visible HIP devices (0 when there is no GPU / no driver); never throws
+	int VisibleDeviceCount();
+
+	class ModelGroup; // one per distinct ModelDesc: packed weights + state of all its streams
+
+	class GpuBatch
+	{
+	public:
+		// throws std::runtime_error if `device` is not a usable HIP device -- there is no CPU fallback
+		// `borrowedStream` != nullptr: launch on the caller's HIP stream instead of creating one
+		explicit GpuBatch(int device, hipStream_t borrowedStream = nullptr);
+		~GpuBatch();
+
+		GpuBatch(const GpuBatch&) = delete;
+		GpuBatch& operator=(const GpuBatch&) = delete;
+
+		// Adds a stream running `model`; its row in the [streams][n] input/output arrays is the returned id.
+		// For a SlimmableContainer every submodel gets state, `quality` picks the active one.
+		int AddStream(const std::shared_ptr<const LoadedModel>& model, float quality, bool prewarm);
+
+		int NumStreams() const { return (int)streams.size(); }
+
+		// ScalableCompositeModel::SetQualityScaleFactor (CompositeModel.h:176-181): switches the active submodel,
+		// the inactive one keeps its state untouched.
+		void SetQuality(int stream, float quality);
+		float GetQuality(int stream) const;
+		int GetActiveSubModel(int stream) const;
+
+		// Re-establish the zero-input steady state of every submodel of `stream` (NeuralModel::Prewarm)
+		void Prewarm(int stream);
+
+		// in/out are DEVICE pointers, row s = stream s, `n` samples per row, rows `stride` floats apart.
+		// Asynchronous on GetStream(). in == out is allowed.
+		void ProcessDevice(const float* dIn, float* dOut, size_t n, long inStride, long outStride);
+
+		// in/out are HOST pointers laid out [streams][n]; stages through pinned buffers; synchronous.
+		void ProcessHost(const float* in, float* out, size_t n);
+
+		void Synchronize();
+		hipStream_t GetStream() const { return stream; }
+		int GetDevice() const { return device; }
+
+		// roofline bookkeeping for bench.py: stream-weighted algorithmic bytes / MACs per sample
+		double AlgorithmicBytesPerSample(int blockFrames) const;
+		double MacsPerSample() const;
+		size_t StateBytes() const;
+
+	private:
+		struct StreamRef
+		{
+			std::shared_ptr<const LoadedModel> model;
+			std::vector<std::pair<ModelGroup*, int>> members; // per submodel: (group, member index)
+			int active = 0;
+			float quality = 1.0f;
+		};
+
+		ModelGroup* GroupFor(const std::shared_ptr<const ModelDesc>& desc);
+		void EnsureStaging(size_t floats);
+
+		int device;
+		hipStream_t stream = nullptr;
+		bool ownsStream = true;
+		std::vector<std::unique_ptr<ModelGroup>> groups;
+		std::vector<StreamRef> streams;
+
+		float* hostStage = nullptr; // pinned
+		float* devStage = nullptr;
+		size_t stageFloats = 0;
+	};
+}

@@ -1,0 +1,201 @@
+// lstm_kernels.hip -- gfx950 kernels for the LSTM recurrent gate loop.
+//
+// Replaces, for many independent streams at once:
+//   LSTMModelT::Process   NeuralAudio/LSTM.h:164-191   (sample loop, layer chain, dense head)
+//   LSTMLayerT::Process   NeuralAudio/LSTM.h:87-100    (g = W[4H x (I+H)] [x;h] + b; i,f,g,o gates)
+//   LSTMLayer::Process    NeuralAudio/LSTMDynamic.h:95-108 (same arithmetic, runtime shaped)
+//   FastMath Tanh/Sigmoid NeuralAudio/Activation.h:83-96
+#include <hip/hip_runtime.h>
+
+#include "lstm_dev.h"
+#include "lstm_launch.h"
+
+namespace na
+{
+	// Activation.h:83-91
+	__device__ __forceinline__ float LstmFastTanh(float x)
+	{
+		const float ax = fabsf(x);
+		const float x2 = x * x;
+		const float num = x * (2.45550750702956f + 2.45550750702956f * ax + (0.893229853513558f + 0.821226666969744f * ax) * x2);
+		const float den = 2.44506634652299f + (2.44506634652299f + x2) * fabsf(x + 0.814642734961073f * x * ax);
+		return num / den;
+	}
+
+	// Activation.h:93-96
+	__device__ __forceinline__ float LstmFastSigmoid(float x) { return 0.5f * (LstmFastTanh(x * 0.5f) + 1.0f); }
+
+	// One layer step for one stream (lane).  state = [x (I values); h (H values)] in registers.
+	//   cell/hidden columns live in LDS: hc[k * 64 + lane]
+	template <int H, int I>
+	__device__ __forceinline__ void LstmLayerStep(const float* __restrict__ w, const float (&xin)[I], float* hc, int lane)
+	{
+		constexpr int W = I + H;
+		float s[W];
+#pragma unroll
+		for (int k = 0; k < I; k++) s[k] = xin[k];
+#pragma unroll
+		for (int k = 0; k < H; k++) s[I + k] = hc[k * 64 + lane];
+
+		const float* bias = w + 4 * H * W;
+		// s[] holds the pre-update hidden state, so h/c can be updated in place unit by unit
+#pragma unroll 4
+		for (int i = 0; i < H; i++)
+		{
+			float gi = 0.0f, gf = 0.0f, gg = 0.0f, go = 0.0f;
+			const float* ri = w + (size_t)(0 * H + i) * W;
+			const float* rf = w + (size_t)(1 * H + i) * W;
+			const float* rg = w + (size_t)(2 * H + i) * W;
+			const float* ro = w + (size_t)(3 * H + i) * W;
+#pragma unroll
+			for (int k = 0; k < W; k++)
+			{
+				gi += ri[k] * s[k];
+				gf += rf[k] * s[k];
+				gg += rg[k] * s[k];
+				go += ro[k] * s[k];
+			}
+			gi += bias[0 * H + i];
+			gf += bias[1 * H + i];
+			gg += bias[2 * H + i];
+			go += bias[3 * H + i];
+			// LSTM.h:94-99
+			const float c = (LstmFastSigmoid(gf) * hc[(H + i) * 64 + lane]) + (LstmFastSigmoid(gi) * LstmFastTanh(gg));
+			hc[(H + i) * 64 + lane] = c;
+			hc[i * 64 + lane] = LstmFastSigmoid(go) * LstmFastTanh(c);
+		}
+	}
+
+	// grid = ceil(active/64), block = 64.  lane = stream.
+	template <int H>
+	__global__ void __launch_bounds__(64) LstmBlockKernel(LstmModelDev m, float* __restrict__ state, int capacity,
+		const int* __restrict__ slots, const int* __restrict__ rows, int numStreams, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n)
+	{
+		extern __shared__ __attribute__((aligned(16))) float lds[];
+		// lds: io[64][n + 1] then hc[numLayers][2H][64]
+		float* io = lds;
+		const int ioStride = n + 1;
+		float* hcAll = lds + 64 * ioStride;
+
+		const int lane = threadIdx.x;
+		const int idx = blockIdx.x * 64 + lane;
+		const bool active = idx < numStreams;
+		const int slot = active ? slots[idx] : 0;
+
+		// stage the input tile [64 streams][n] through LDS so global reads are row-contiguous
+		for (int r = 0; r < 64; r++)
+		{
+			const int ridx = blockIdx.x * 64 + r;
+			if (ridx < numStreams)
+			{
+				const float* src = in + (size_t)rows[ridx] * inStride;
+				for (int f = lane; f < n; f += 64) io[r * ioStride + f] = src[f];
+			}
+		}
+		// load h, c
+		for (int l = 0; l < m.numLayers; l++)
+			for (int k = 0; k < 2 * H; k++)
+				hcAll[(l * 2 * H + k) * 64 + lane] = active ? state[(size_t)(l * 2 * H + k) * capacity + slot] : 0.0f;
+		__syncthreads();
+
+		const float* headW = m.w + m.headOff;
+		for (int f = 0; f < n; f++)
+		{
+			float x1[1] = { io[lane * ioStride + f] };
+			LstmLayerStep<H, 1>(m.w + m.layerOff[0], x1, hcAll, lane); // LSTM.h:168
+			for (int l = 1; l < m.numLayers; l++)
+			{
+				float xh[H];
+#pragma unroll
+				for (int k = 0; k < H; k++) xh[k] = hcAll[((l - 1) * 2 * H + k) * 64 + lane];
+				LstmLayerStep<H, H>(m.w + m.layerOff[l], xh, hcAll + (size_t)l * 2 * H * 64, lane); // LSTM.h:170-180
+			}
+			const float* hl = hcAll + (size_t)(m.numLayers - 1) * 2 * H * 64;
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < H; k++) acc += headW[k] * hl[k * 64 + lane];
+			io[lane * ioStride + f] = acc + headW[H]; // LSTM.h:182-189
+		}
+		__syncthreads();
+
+		for (int l = 0; l < m.numLayers; l++)
+			for (int k = 0; k < 2 * H; k++)
+				if (active) state[(size_t)(l * 2 * H + k) * capacity + slot] = hcAll[(l * 2 * H + k) * 64 + lane];
+		for (int r = 0; r < 64; r++)
+		{
+			const int ridx = blockIdx.x * 64 + r;
+			if (ridx < numStreams)
+			{
+				float* dst = out + (size_t)rows[ridx] * outStride;
+				for (int f = lane; f < n; f += 64) dst[f] = io[r * ioStride + f];
+			}
+		}
+	}
+
+	// initial hidden / cell state of the listed slots (NAM: stored in the weights, LSTM.h:51-55; keras: zeros)
+	__global__ void LstmInitStateKernel(float* __restrict__ state, int capacity, const int* __restrict__ slots, int numStreams,
+		const float* __restrict__ init /* [numLayers*2H] */, int numElems)
+	{
+		const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+		if (idx >= numStreams) return;
+		const int slot = slots[idx];
+		for (int k = 0; k < numElems; k++) state[(size_t)k * capacity + slot] = init[k];
+	}
+
+	template <int H>
+	static hipError_t LaunchH(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
+		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream)
+	{
+		const size_t ldsBytes = ((size_t)64 * (n + 1) + (size_t)m.numLayers * 2 * H * 64) * sizeof(float);
+		if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
+		static bool attrSet = false;
+		if (!attrSet)
+		{
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&LstmBlockKernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			attrSet = true;
+		}
+		hipLaunchKernelGGL(LstmBlockKernel<H>, dim3((unsigned)((numStreams + 63) / 64)), dim3(64), ldsBytes, stream, m, state, capacity,
+			slots, rows, numStreams, in, out, inStride, outStride, n);
+		return hipGetLastError();
+	}
+
+	bool LstmHiddenSizeSupported(int hidden)
+	{
+		switch (hidden)
+		{
+		case 4: case 8: case 12: case 16: case 20: case 24: case 32: case 40: return true;
+		default: return false;
+		}
+	}
+
+	hipError_t LaunchLstmBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
+		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream)
+	{
+		if (numStreams <= 0 || n <= 0) return hipSuccess;
+		if (n > LSTM_MAX_FRAMES) return hipErrorInvalidValue;
+#define NA_LSTM_CASE(HH) case HH: return LaunchH<HH>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream)
+		switch (m.hidden)
+		{
+			NA_LSTM_CASE(4);
+			NA_LSTM_CASE(8);
+			NA_LSTM_CASE(12);
+			NA_LSTM_CASE(16);
+			NA_LSTM_CASE(20);
+			NA_LSTM_CASE(24);
+			NA_LSTM_CASE(32);
+			NA_LSTM_CASE(40);
+		default: return hipErrorInvalidValue;
+		}
+#undef NA_LSTM_CASE
+	}
+
+	hipError_t LaunchLstmInitState(float* state, int capacity, const int* slots, int numStreams, const float* init, int numElems,
+		hipStream_t stream)
+	{
+		if (numStreams <= 0) return hipSuccess;
+		hipLaunchKernelGGL(LstmInitStateKernel, dim3((unsigned)((numStreams + 255) / 256)), dim3(256), 0, stream, state, capacity, slots,
+			numStreams, init, numElems);
+		return hipGetLastError();
+	}
+}

@@ -1,0 +1,19 @@
+// lstm_launch.h -- host-callable launchers for the kernels in lstm_kernels.hip
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include "lstm_dev.h"
+
+namespace na
+{
+	bool LstmHiddenSizeSupported(int hidden);
+
+	// One block of n <= 128 samples for `numStreams` streams of one model (lane = stream).
+	hipError_t LaunchLstmBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
+		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream);
+
+	// state[k*capacity + slot] = init[k] for the listed slots
+	hipError_t LaunchLstmInitState(float* state, int capacity, const int* slots, int numStreams, const float* init, int numElems,
+		hipStream_t stream);
+}

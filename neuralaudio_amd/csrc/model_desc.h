@@ -1,0 +1,67 @@
+// model_desc.h -- host-side description of a loaded model, independent of any device.
+//
+// Produced by the loader (model_loader.cpp, mirrors NeuralAudio/NeuralModel.cpp:338-581) and
+// consumed by the plan builders that lower it to device tables.
+#pragma once
+
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace na
+{
+	enum ActivationType { ACT_TANH = 0, ACT_LEAKYRELU = 1 };
+
+	// Template parameters of WaveNetLayerArrayT (NeuralAudio/WaveNet.h:503)
+	struct WnArrayCfg
+	{
+		int inputSize = 1;
+		int conditionSize = 1;
+		int headSize = 1;
+		int headKernelSize = 1;
+		int headDilation = 1;
+		int channels = 0;
+		bool hasHeadBias = false;
+		int activation = ACT_TANH;
+		std::vector<int> kernelSizes;
+		std::vector<int> dilations;
+	};
+
+	struct WaveNetDesc
+	{
+		std::vector<WnArrayCfg> arrays;
+		std::vector<float> weights; // flat, reference order (WaveNet.h:700-719)
+		bool isStatic = false;      // matched one of the official architectures (InternalModel.h:12-20)
+
+		size_t ExpectedNumWeights() const;
+		int ReceptiveFieldSize() const; // WaveNet.h:534-542,674-684
+	};
+
+	struct LSTMLayerDesc
+	{
+		int inputSize = 1;
+		std::vector<float> w;    // row-major [4H][I+H]  (LSTM.h:27)
+		std::vector<float> bias; // [4H]
+		std::vector<float> h0;   // [H] initial hidden (NAM files carry it, LSTM.h:51-55; keras: zeros)
+		std::vector<float> c0;   // [H]
+	};
+
+	struct LSTMDesc
+	{
+		int numLayers = 0;
+		int hiddenSize = 0;
+		std::vector<LSTMLayerDesc> layers;
+		std::vector<float> headWeights; // [H]
+		float headBias = 0.0f;
+		bool isStatic = false;
+	};
+
+	enum ModelKind { MODEL_NONE = 0, MODEL_WAVENET = 1, MODEL_LSTM = 2 };
+
+	struct ModelDesc
+	{
+		ModelKind kind = MODEL_NONE;
+		WaveNetDesc wavenet;
+		LSTMDesc lstm;
+	};
+}

@@ -1,0 +1,352 @@
+// model_loader.cpp -- see model_loader.h.
+#include "model_loader.h"
+
+#include <algorithm>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace na
+{
+	int LoadedModel::ModelIndexFromQuality(float quality) const
+	{
+		int modelIndex = 0;
+		for (const auto& level : qualityLevels)
+		{
+			modelIndex = level.second;
+			if (quality <= level.first) break;
+		}
+		return modelIndex;
+	}
+
+	namespace
+	{
+		const std::vector<int> kStdDilations = { 1, 2, 4, 8, 16, 32, 64, 128, 256, 512 };              // NeuralModel.cpp:71
+		const std::vector<int> kLiteDilations = { 1, 2, 4, 8, 16, 32, 64 };                            // :72
+		const std::vector<int> kLiteDilations2 = { 128, 256, 512, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512 }; // :73
+		const std::vector<int> kA2KernelSizes = { 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 15, 15, 6, 6, 6, 6, 6, 6, 6 }; // :75
+		const std::vector<int> kA2Dilations = { 1, 3, 7, 17, 41, 101, 239, 1, 3, 7, 17, 41, 101, 239, 1, 13, 1, 3, 7, 17, 41, 101, 239 }; // :76
+
+		std::vector<int> IntArray(const Json& j)
+		{
+			std::vector<int> v;
+			for (size_t i = 0; i < j.Size(); i++) v.push_back(j.At(i).AsInt());
+			return v;
+		}
+
+		bool Truthy(const Json& j)
+		{
+			if (j.IsBool()) return j.AsBool();
+			if (j.IsNumber()) return j.AsDouble() != 0.0;
+			return !j.IsNull();
+		}
+
+		// NeuralModelImpl.h:30-60
+		void ReadNAMConfig(const Json& modelJson, ModelInfo& info)
+		{
+			info.modelVersion = modelJson.At("version").AsString();
+			if (modelJson.Contains("sample_rate") && modelJson.At("sample_rate").IsNumber())
+				info.sampleRate = modelJson.At("sample_rate").AsFloat();
+			if (modelJson.Contains("metadata") && modelJson.At("metadata").IsObject())
+			{
+				const Json& md = modelJson.At("metadata");
+				for (const auto& key : md.Keys())
+				{
+					const Json& value = md.At(key);
+					if (!value.IsNull()) info.metadata.push_back({ key, value.Dump() }); // :85-94
+				}
+				if (md.Contains("loudness") && md.At("loudness").IsNumber()) info.modelLoudnessDB = md.At("loudness").AsFloat();
+				if (md.Contains("input_level_dbu") && md.At("input_level_dbu").IsNumber())
+					info.modelInputLevelDBu = md.At("input_level_dbu").AsFloat();
+				if (md.Contains("output_level_dbu") && md.At("output_level_dbu").IsNumber())
+					info.modelOutputLevelDBu = md.At("output_level_dbu").AsFloat();
+			}
+		}
+
+		// NeuralModelImpl.h:62-78
+		void ReadKerasConfig(const Json& modelJson, ModelInfo& info)
+		{
+			if (modelJson.Contains("samplerate") && modelJson.At("samplerate").IsNumber())
+				info.sampleRate = modelJson.At("samplerate").AsFloat();
+			if (modelJson.Contains("in_gain") && modelJson.At("in_gain").IsNumber())
+				info.modelInputLevelDBu = modelJson.At("in_gain").AsFloat();
+			if (modelJson.Contains("out_gain") && modelJson.At("out_gain").IsNumber())
+				info.modelLoudnessDB = -18.0f - modelJson.At("out_gain").AsFloat();
+		}
+
+		int ActivationFromJson(const Json& act)
+		{
+			// A1: "Tanh"; A2: [{type:"LeakyReLU", negative_slope:0.01}, ...] (one per layer, all equal in supported files)
+			const Json* a = &act;
+			if (act.IsArray())
+			{
+				if (act.Size() == 0) return ACT_TANH;
+				a = &act.At(0);
+			}
+			std::string name;
+			if (a->IsString()) name = a->AsString();
+			else if (a->IsObject() && a->Contains("type")) name = a->At("type").AsString();
+			if (name == "Tanh") return ACT_TANH;
+			if (name == "LeakyReLU") return ACT_LEAKYRELU;
+			throw std::runtime_error("WaveNet activation '" + name + "' is not supported by the Internal path");
+		}
+
+		// One "layers" entry of a WaveNet config -> WnArrayCfg.
+		// A1 keys (InternalModel.h:204-209): input_size, condition_size, head_size, channels, kernel_size, head_bias, dilations
+		// A2 keys: kernel_sizes[], head{out_channels,kernel_size,bias}, activation[] ...
+		WnArrayCfg ReadLayerArray(const Json& lc, int headDilationOverride)
+		{
+			WnArrayCfg cfg;
+			cfg.inputSize = lc.At("input_size").AsInt();
+			cfg.conditionSize = lc.At("condition_size").AsInt();
+			cfg.channels = lc.At("channels").AsInt();
+			cfg.dilations = IntArray(lc.At("dilations"));
+			if (lc.Contains("gated") && Truthy(lc.At("gated")))
+				throw std::runtime_error("gated WaveNet layers are not supported by the Internal path");
+			if (lc.Contains("activation")) cfg.activation = ActivationFromJson(lc.At("activation"));
+			if (lc.Contains("kernel_sizes"))
+			{
+				cfg.kernelSizes = IntArray(lc.At("kernel_sizes"));
+				const Json& head = lc.At("head");
+				cfg.headSize = head.At("out_channels").AsInt();
+				cfg.headKernelSize = head.At("kernel_size").AsInt();
+				cfg.hasHeadBias = Truthy(head.At("bias"));
+				cfg.headDilation = headDilationOverride; // OversampleNAMConfig sets head["head_dilation"], :124-127
+			}
+			else
+			{
+				const int k = lc.At("kernel_size").AsInt();
+				cfg.kernelSizes.assign(cfg.dilations.size(), k);
+				cfg.headSize = lc.At("head_size").AsInt();
+				cfg.headKernelSize = 1;
+				cfg.hasHeadBias = Truthy(lc.At("head_bias"));
+				cfg.headDilation = 1;
+			}
+			if (cfg.kernelSizes.size() != cfg.dilations.size()) throw std::runtime_error("kernel_sizes / dilations length mismatch");
+			return cfg;
+		}
+
+		// NeuralModel.cpp:389-465: which configurations the reference runs on its static (templated) engines
+		bool IsOfficialArchitecture(const std::vector<WnArrayCfg>& arrays)
+		{
+			if (arrays.size() == 1)
+			{
+				const WnArrayCfg& a = arrays[0];
+				return a.dilations == kA2Dilations && a.kernelSizes == kA2KernelSizes && (a.channels == 3 || a.channels == 8) &&
+					a.headKernelSize == 16 && a.headSize == 1 && a.hasHeadBias && a.activation == ACT_LEAKYRELU;
+			}
+			if (arrays.size() == 2)
+			{
+				const WnArrayCfg& a = arrays[0];
+				const WnArrayCfg& b = arrays[1];
+				if (a.hasHeadBias || !b.hasHeadBias) return false;
+				if (a.headKernelSize != 1 || b.headKernelSize != 1) return false;
+				bool dil = false;
+				if (a.channels == 16) dil = (a.dilations == kStdDilations && b.dilations == kStdDilations);
+				else dil = (a.dilations == kLiteDilations && b.dilations == kLiteDilations2);
+				if (!dil) return false;
+				// InternalA1WaveNetDefinitionT<16,8> / <12,6> / <8,4> / <4,2> (NeuralModel.cpp:25-28)
+				const int c = a.channels, h = a.headSize;
+				return (c == 16 && h == 8) || (c == 12 && h == 6) || (c == 8 && h == 4) || (c == 4 && h == 2);
+			}
+			return false;
+		}
+
+		std::shared_ptr<ModelDesc> ReadNAMWaveNet(const Json& modelJson, int oversampleFactor)
+		{
+			auto desc = std::make_shared<ModelDesc>();
+			desc->kind = MODEL_WAVENET;
+			const Json& config = modelJson.At("config");
+			const Json& layers = config.At("layers");
+			for (size_t i = 0; i < layers.Size(); i++)
+			{
+				WnArrayCfg cfg = ReadLayerArray(layers.At(i), oversampleFactor);
+				// OversampleNAMConfig (NeuralModel.cpp:92-130): integer oversampling multiplies every dilation
+				if (oversampleFactor != 1)
+					for (auto& d : cfg.dilations) d *= oversampleFactor;
+				desc->wavenet.arrays.push_back(cfg);
+			}
+			modelJson.At("weights").FlattenNumbers(desc->wavenet.weights);
+			desc->wavenet.isStatic = (oversampleFactor == 1) && IsOfficialArchitecture(desc->wavenet.arrays);
+			return desc;
+		}
+
+		// LSTM.h:42-56,130-147
+		std::shared_ptr<ModelDesc> ReadNAMLSTM(const Json& modelJson)
+		{
+			auto desc = std::make_shared<ModelDesc>();
+			desc->kind = MODEL_LSTM;
+			const Json& config = modelJson.At("config");
+			LSTMDesc& lstm = desc->lstm;
+			lstm.numLayers = config.At("num_layers").AsInt();
+			lstm.hiddenSize = config.At("hidden_size").AsInt();
+			if (config.Contains("input_size") && config.At("input_size").AsInt() != 1)
+				throw std::runtime_error("LSTM input_size != 1 is not supported");
+			std::vector<float> w;
+			modelJson.At("weights").FlattenNumbers(w);
+			const int H = lstm.hiddenSize;
+			size_t expected = 0;
+			for (int l = 0; l < lstm.numLayers; l++) expected += (size_t)4 * H * ((l == 0 ? 1 : H) + H) + 4 * H + 2 * H;
+			expected += (size_t)H + 1;
+			if (expected != w.size())
+			{
+				std::stringstream str;
+				str << "Wrong number of weights. Expected " << expected << " but got " << w.size();
+				throw std::runtime_error(str.str());
+			}
+			size_t it = 0;
+			for (int l = 0; l < lstm.numLayers; l++)
+			{
+				LSTMLayerDesc layer;
+				layer.inputSize = (l == 0) ? 1 : H;
+				const size_t nW = (size_t)4 * H * (layer.inputSize + H);
+				layer.w.assign(w.begin() + it, w.begin() + it + nW); it += nW;
+				layer.bias.assign(w.begin() + it, w.begin() + it + 4 * H); it += (size_t)4 * H;
+				layer.h0.assign(w.begin() + it, w.begin() + it + H); it += (size_t)H;
+				layer.c0.assign(w.begin() + it, w.begin() + it + H); it += (size_t)H;
+				lstm.layers.push_back(std::move(layer));
+			}
+			lstm.headWeights.assign(w.begin() + it, w.begin() + it + H); it += (size_t)H;
+			lstm.headBias = w[it++];
+			// InternalLSTMDefinitionT list, NeuralModel.cpp:31-38 (only when BUILD_INTERNAL_STATIC_LSTM)
+			lstm.isStatic = false;
+			return desc;
+		}
+
+		// InternalModel.h:311-356 / :473-519 and LSTM.h:58-85
+		std::shared_ptr<ModelDesc> ReadKerasLSTM(const Json& modelJson)
+		{
+			const Json& layers = modelJson.At("layers");
+			const size_t numLayers = layers.Size();
+			if (numLayers < 2) return nullptr;
+			const Json& lastLayer = layers.At(numLayers - 1);
+			if (lastLayer.At("type").AsString() != "dense") return nullptr;
+
+			auto desc = std::make_shared<ModelDesc>();
+			desc->kind = MODEL_LSTM;
+			LSTMDesc& lstm = desc->lstm;
+			lstm.numLayers = (int)numLayers - 1;
+			lstm.hiddenSize = layers.At(0).At("shape").Back().AsInt();
+			const int H = lstm.hiddenSize;
+
+			lastLayer.At("weights").At(0).FlattenNumbers(lstm.headWeights);
+			lstm.headBias = lastLayer.At("weights").At(1).At(0).AsFloat();
+			if ((int)lstm.headWeights.size() < H) throw std::runtime_error("keras dense head has too few weights");
+
+			for (int l = 0; l < lstm.numLayers; l++)
+			{
+				const Json& layer = layers.At((size_t)l);
+				if (layer.At("type").AsString() != "lstm") return nullptr;
+				std::vector<float> kernel, recurrent, bias;
+				layer.At("weights").At(0).FlattenNumbers(kernel);    // [I][4H]
+				layer.At("weights").At(1).FlattenNumbers(recurrent); // [H][4H]
+				layer.At("weights").At(2).FlattenNumbers(bias);      // [4H]
+				LSTMLayerDesc ld;
+				ld.inputSize = (l == 0) ? 1 : H;
+				const int I = ld.inputSize, W = I + H, R = 4 * H;
+				if ((int)kernel.size() != I * R || (int)recurrent.size() != H * R || (int)bias.size() < R)
+					throw std::runtime_error("keras lstm layer has unexpected weight shapes");
+				ld.w.assign((size_t)R * W, 0.0f);
+				for (int j = 0; j < I; j++)
+					for (int i = 0; i < R; i++) ld.w[(size_t)i * W + j] = kernel[(size_t)j * R + i];
+				for (int j = 0; j < H; j++)
+					for (int i = 0; i < R; i++) ld.w[(size_t)i * W + I + j] = recurrent[(size_t)j * R + i];
+				ld.bias.assign(bias.begin(), bias.begin() + R);
+				ld.h0.assign((size_t)H, 0.0f);
+				ld.c0.assign((size_t)H, 0.0f);
+				lstm.layers.push_back(std::move(ld));
+			}
+			return desc;
+		}
+
+		int OversampleFactor(const Json& modelJson, int externalSampleRate)
+		{
+			// NeuralModel.cpp:92-114
+			if (modelJson.At("architecture").AsString() != "WaveNet") return 1;
+			int modelSampleRate = 48000;
+			if (modelJson.Contains("sample_rate") && modelJson.At("sample_rate").IsNumber())
+				modelSampleRate = (int)modelJson.At("sample_rate").AsFloat();
+			if (modelSampleRate == externalSampleRate || modelSampleRate <= 0) return 1;
+			if ((externalSampleRate % modelSampleRate) != 0) return 1;
+			return externalSampleRate / modelSampleRate;
+		}
+	}
+
+	std::shared_ptr<LoadedModel> LoadModelFromJson(const Json& modelJson, const std::string& extension, const LoaderOptions& opts)
+	{
+		auto model = std::make_shared<LoadedModel>();
+
+		if (extension == ".nam")
+		{
+			const std::string arch = modelJson.At("architecture").AsString();
+			ReadNAMConfig(modelJson, model->info);
+
+			if (arch == "SlimmableContainer")
+			{
+				// ScalableCompositeModel::CreateModelFromNAMJson, CompositeModel.h:137-159
+				model->isComposite = true;
+				const Json& subModels = modelJson.At("config").At("submodels");
+				for (size_t i = 0; i < subModels.Size(); i++)
+				{
+					const Json& sub = subModels.At(i);
+					auto loaded = LoadModelFromJson(sub.At("model"), ".nam", opts);
+					if (!loaded || loaded->isComposite || loaded->subModels.size() != 1)
+						throw std::runtime_error("SlimmableContainer submodel could not be loaded");
+					SubModel sm = loaded->subModels[0];
+					sm.maxValue = sub.At("max_value").AsFloat();
+					sm.info = loaded->info;
+					model->subModels.push_back(sm);
+					model->qualityLevels.push_back({ sm.maxValue, (int)model->subModels.size() - 1 });
+					std::stable_sort(model->qualityLevels.begin(), model->qualityLevels.end(),
+						[](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+				}
+				if (model->subModels.empty()) throw std::runtime_error("SlimmableContainer without submodels");
+				return model;
+			}
+
+			SubModel sm;
+			sm.info = model->info;
+			if (arch == "WaveNet") sm.desc = ReadNAMWaveNet(modelJson, OversampleFactor(modelJson, opts.externalSampleRate));
+			else if (arch == "LSTM") sm.desc = ReadNAMLSTM(modelJson);
+			else return nullptr;
+			model->subModels.push_back(sm);
+			model->qualityLevels.push_back({ 1.0f, 0 });
+			return model;
+		}
+		else if (extension == ".json" || extension == ".aidax")
+		{
+			ReadKerasConfig(modelJson, model->info);
+			const Json& layers = modelJson.At("layers");
+			const std::string modelType = layers.At(0).At("type").AsString();
+			if (modelType != "lstm") return nullptr; // GRU & co. run on RTNeural in the reference (NeuralModel.cpp:565-572)
+			SubModel sm;
+			sm.info = model->info;
+			sm.desc = ReadKerasLSTM(modelJson);
+			if (!sm.desc) return nullptr;
+			model->subModels.push_back(sm);
+			model->qualityLevels.push_back({ 1.0f, 0 });
+			return model;
+		}
+
+		return nullptr;
+	}
+
+	std::shared_ptr<LoadedModel> LoadModelFromText(const std::string& text, const std::string& extension, const LoaderOptions& opts)
+	{
+		const Json j = Json::Parse(text);
+		return LoadModelFromJson(j, extension, opts);
+	}
+
+	std::shared_ptr<LoadedModel> LoadModelFromFile(const std::string& path, const LoaderOptions& opts)
+	{
+		std::ifstream f(path, std::ifstream::binary);
+		if (!f.good()) return nullptr;
+		std::stringstream ss;
+		ss << f.rdbuf();
+		std::string ext;
+		const size_t dot = path.find_last_of('.');
+		const size_t slash = path.find_last_of("/\\");
+		if (dot != std::string::npos && (slash == std::string::npos || dot > slash)) ext = path.substr(dot);
+		return LoadModelFromText(ss.str(), ext, opts);
+	}
+}

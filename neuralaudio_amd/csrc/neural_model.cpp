@@ -1,0 +1,141 @@
+// neural_model.cpp -- NeuralAudio::NeuralModel / NeuralModelLoader on top of na::GpuBatch.
+//
+// Counterpart of the reference's L2 adapters + loader entry points:
+//   InternalWaveNetModelT / InternalLSTMModelT / *Dyn   NeuralAudio/InternalModel.h:54-126,251-375,177-248,417-538
+//   ScalableCompositeModel                              NeuralAudio/CompositeModel.h:127-214
+//   NeuralModelLoader::CreateFromFile/Stream/Json       NeuralAudio/NeuralModel.cpp:319-581
+// One GpuModel is one stream; its device state is created lazily on the first Process()/Prewarm() so
+// that a model can be loaded (and used as a template for a many-stream na::GpuBatch) without a GPU.
+#include "neural_model_impl.h"
+
+#include <fstream>
+#include <sstream>
+
+namespace NeuralAudio
+{
+	GpuModel::GpuModel(std::shared_ptr<const na::LoadedModel> loaded, NeuralModelLoader* loader, bool doPrewarm)
+		: model(std::move(loaded)), device(loader->GetDevice()), prewarmPending(doPrewarm)
+	{
+		// NeuralModelImpl::SetModelLoader (NeuralModelImpl.h:12-17)
+		SetAudioInputLevelDBu(loader->GetAudioInputLevelDBu());
+
+		const na::ModelInfo& info = model->info;
+		modelInputLevelDBu = info.modelInputLevelDBu;
+		modelOutputLevelDBu = info.modelOutputLevelDBu;
+		modelLoudnessDB = info.modelLoudnessDB;
+		sampleRate = info.sampleRate;
+		modelVersion = info.modelVersion;
+		metadata = info.metadata;
+
+		// ScalableCompositeModel::CreateModelFromNAMJson ends with SetQualityScaleFactor(default) (CompositeModel.h:155)
+		quality = model->isComposite ? loader->GetDefaultQualityScaleFactor() : 1.0f;
+		activeIndex = model->isComposite ? model->ModelIndexFromQuality(quality) : 0;
+	}
+
+	GpuModel::~GpuModel() {}
+
+	void GpuModel::EnsureDeviceState()
+	{
+		if (batch) return;
+		batch.reset(new na::GpuBatch(device));
+		batch->AddStream(model, quality, prewarmPending);
+		prewarmPending = false;
+	}
+
+	bool GpuModel::HasQualityScaling() { return model->isComposite; }
+
+	float GpuModel::GetQualityScaleFactor() { return model->isComposite ? quality : 1.0f; }
+
+	bool GpuModel::IsQualityChangeRealtimeSafe(float newScaleFactor)
+	{
+		// LoadAll semantics: every submodel has state and was prewarmed (CompositeModel.h:44-50); what a switch
+		// costs here is one small host->device index-list upload on the next Process().
+		(void)newScaleFactor;
+		return true;
+	}
+
+	void GpuModel::SetQualityScaleFactor(float scaleFactor)
+	{
+		if (!model->isComposite) return;
+		quality = scaleFactor;
+		activeIndex = model->ModelIndexFromQuality(scaleFactor);
+		if (batch) batch->SetQuality(0, scaleFactor);
+	}
+
+	bool GpuModel::IsStatic()
+	{
+		const na::ModelDesc& d = *model->subModels[(size_t)activeIndex].desc;
+		return d.kind == na::MODEL_WAVENET ? d.wavenet.isStatic : d.lstm.isStatic;
+	}
+
+	int GpuModel::GetReceptiveFieldSize()
+	{
+		const na::ModelDesc& d = *model->subModels[(size_t)activeIndex].desc;
+		return d.kind == na::MODEL_WAVENET ? d.wavenet.ReceptiveFieldSize() : -1;
+	}
+
+	void GpuModel::Process(float* input, float* output, size_t numSamples)
+	{
+		if (numSamples == 0) return;
+		EnsureDeviceState();
+		batch->ProcessHost(input, output, numSamples);
+	}
+
+	void GpuModel::Prewarm()
+	{
+		if (!batch)
+		{
+			prewarmPending = true;
+			EnsureDeviceState();
+			return;
+		}
+		batch->Prewarm(0);
+	}
+
+	// ------------------------------------------------------------------------------------------ loader
+
+	bool NeuralModelLoader::SupportsWaveNetLoadMode(EModelLoadMode mode) { return mode == EModelLoadMode::Internal; }
+
+	bool NeuralModelLoader::SupportsLSTMLoadMode(EModelLoadMode mode) { return mode == EModelLoadMode::Internal; }
+
+	NeuralModel* NeuralModelLoader::CreateFromFile(const std::filesystem::path& modelPath, bool doPrewarm)
+	{
+		if (!std::filesystem::exists(modelPath)) return nullptr; // ref NeuralModel.cpp:321-322
+		std::ifstream jsonStream(modelPath, std::ifstream::binary);
+		return CreateFromStream(jsonStream, modelPath.extension(), doPrewarm);
+	}
+
+	NeuralModel* NeuralModelLoader::CreateFromStream(std::basic_istream<char>& stream, const std::filesystem::path& extension, bool doPrewarm)
+	{
+		std::stringstream ss;
+		ss << stream.rdbuf();
+		return CreateFromString(ss.str(), extension, doPrewarm);
+	}
+
+	NeuralModel* NeuralModelLoader::CreateFromString(const std::string& jsonText, const std::filesystem::path& extension, bool doPrewarm)
+	{
+		na::LoaderOptions opts;
+		opts.externalSampleRate = externalSampleRate;
+		std::shared_ptr<na::LoadedModel> loaded = na::LoadModelFromText(jsonText, extension.string(), opts);
+		if (!loaded) return nullptr;
+		GpuModel* m = new GpuModel(loaded, this, doPrewarm);
+		if (doPrewarm)
+		{
+			// the reference prewarms inside the factory (NeuralModel.cpp:575-578); do the same when a device is present so
+			// the first Process() call is real-time safe.  Without a device the model stays a host-side template.
+			if (na::VisibleDeviceCount() > 0)
+			{
+				try
+				{
+					m->Prewarm();
+				}
+				catch (...)
+				{
+					delete m;
+					throw;
+				}
+			}
+		}
+		return m;
+	}
+}

@@ -1,0 +1,109 @@
+// wavenet_dev.h -- device-side data model shared by the host packer (wavenet_plan.cpp) and the
+// gfx950 kernels (wavenet_kernels.hip).
+//
+// A WaveNet model (reference: NeuralAudio/WaveNet.h) is lowered at load time into a short
+// "stage program".  One wave64 executes the whole program for one audio stream and one block of
+// up to 128 frames; every mat-mul in it is issued as v_mfma_f32_16x16x4_f32 with
+//     M = output channels (padded to 16), N = 16 frames (one "tile"), K = 4 input channels.
+//
+// Register / memory tile layout ("D layout", identical for registers, LDS and the HBM rings):
+//     a tile is 16 frames x 4*G channels; lane (g = lane>>4, j = lane&15) owns the float4 holding
+//     channels 4g..4g+3 of frame j.  That is exactly the C/D fragment of the 16x16x4 MFMA
+//     (row = 4*(lane>>4)+reg, col = lane&15), and with weights permuted on the host it is also a
+//     valid B fragment for the next mat-mul (k-slot = lane group, one MFMA per float4 element),
+//     so activations never need a cross-lane shuffle.
+//     Memory image of a tile: float4 index (tile*G + g)*16 + j  -> one coalesced 1 KB (G=4) store.
+//
+// HBM state per stream (float4 units):
+//     [0, 16)            header: 64 ints, header[r] = write cursor (frame index) of ring r
+//     ring r             ring_frames[r]/16 tiles of G[r] channel groups, true modulo ring of the
+//                        INPUT of conv layer r (what ChannelHistoryBuffer holds in the reference,
+//                        WaveNet.h:30-83), ring_frames = roundup16((K-1)*dilation) + 128.
+#pragma once
+
+#include <cstdint>
+
+namespace na
+{
+	constexpr int WN_TILE = 16;            // frames per MFMA tile
+	constexpr int WN_MAX_TILES = 8;        // tiles per launch
+	constexpr int WN_MAX_FRAMES = WN_TILE * WN_MAX_TILES; // 128 frames per launch
+	constexpr int WN_MAX_RINGS = 64;
+	constexpr int WN_HEADER_F4 = WN_MAX_RINGS / 4; // header size in float4 units
+
+	enum WnStageType : int
+	{
+		WN_ST_RECHANNEL_COND = 0, // x = w_re * cond                   (array 0 rechannel, WaveNet.h:637)
+		WN_ST_LAYER = 1,          // WaveNetLayerT::Process             (WaveNet.h:462-494)
+		WN_ST_ARRAY_LINK = 2,     // head = Wh*head (+b); x = Wre*x     (A1 array i -> i+1, WaveNet.h:658-660,637)
+		WN_ST_HEAD_DENSE_OUT = 3, // out = scale*(Wh*head + b)[0]       (A1 last array head, K=1)
+		WN_ST_HEAD_CONV_OUT = 4,  // out = scale*(conv_K(head) + b)[0]  (A2 head, K=16)
+	};
+
+	enum WnStageFlags : int
+	{
+		WN_FLAG_LEAKY = 1,       // LeakyReLU(0.01) instead of FastMath tanh (Activation.h:83-118)
+		WN_FLAG_NEED_OUTPUT = 2, // compute the 1x1 + residual (NeedOutput, WaveNet.h:486-491)
+		WN_FLAG_PUBLISH = 4,     // write the layer output to LDS + the next layer's ring
+		WN_FLAG_BIAS = 8,        // dense/head stage has a bias
+	};
+
+	struct WnStage
+	{
+		int type;
+		int flags;
+		int G;               // channel groups of this stage's conv input
+		int nrounds;         // conv rounds (4 k-quads = 4 MFMAs x 4 lane groups each)
+		int wconv_off;       // float4 index into wpack: [round][64 lanes]
+		int qdesc_off;       // int4 index into qdesc: [round][4 lane groups] = {shift, channel group, valid, 0}
+		int vec_off;         // float4 index: [0..3] conv/dense bias, [4..7] mix-in w, [8..11] 1x1 bias, [12..15] aux
+		int w1_off;          // float4 index: [64 lanes] 1x1 (layer) / head dense
+		int w2_off;          // float4 index: [64 lanes] second dense of WN_ST_ARRAY_LINK (rechannel)
+		int ring_id;         // ring read by this stage's conv (-1: none)
+		int ring_off;        // float4 offset of that ring in the stream state
+		int ring_frames;
+		int out_ring_id;     // ring receiving this stage's output block (-1: none)
+		int out_ring_off;
+		int out_ring_frames;
+		int out_G;
+	};
+
+	struct WnQuad
+	{
+		int shift;  // frames back: dilation * (K - 1 - tap)
+		int cg;     // channel group fetched by this lane group
+		int valid;
+		int pad;
+	};
+
+	// Natural-layout tensor table used by the prewarm kernel (one entry per conv ring).
+	struct WnPrewarmLayer
+	{
+		int kind;       // 0: layer, 1: head conv (K may be 1)
+		int cin, cout, ksize;
+		int act;        // 0 tanh, 1 leaky
+		int wconv;      // offsets into the flat reference-order weight array
+		int bconv;      // -1 if none
+		int wmix;       // -1 for head
+		int w1, b1;     // -1 for head
+		int ring_id;    // ring whose steady-state column is the INPUT of this conv (-1: K==1 head, no ring)
+		int need_output;
+		int last_of_array;
+		int rechannel;  // >=0: before this layer apply rechannel weights at this offset (first layer of an array)
+		int rech_in;
+		int pad0;
+	};
+
+	// Everything the kernels need about one model; passed by value.
+	struct WnModelDev
+	{
+		const WnStage* stages;
+		const float* wpack;   // float4-aligned packed weights
+		const WnQuad* qdesc;
+		const int* ring_frames; // [nrings]
+		int nstages;
+		int nrings;
+		int state_f4;         // per-stream state size in float4 units (header + rings)
+		float head_scale;
+	};
+}

@@ -1,0 +1,421 @@
+// wavenet_kernels.hip -- gfx950 (CDNA4) kernels for the NAM WaveNet hot path.
+//
+// Replaces the CPU inner loops of the reference's Internal WaveNet engine for MANY independent
+// audio streams at once:
+//   WaveNetModelT::Process          NeuralAudio/WaveNet.h:768-799
+//   WaveNetLayerArrayT::Process     NeuralAudio/WaveNet.h:632-661
+//   WaveNetLayerT::Process          NeuralAudio/WaveNet.h:462-494
+//   Conv1DT::Process                NeuralAudio/WaveNet.h:139-290
+//   DenseLayerT::Process/ProcessAcc NeuralAudio/WaveNet.h:336-383
+//   FastMath::Tanh / LeakyReLU      NeuralAudio/Activation.h:83-91,110-118
+//   WaveNetModelT::Prewarm          NeuralAudio/WaveNet.h:746-766 (+ :607-630, :74-82)
+//
+// Mapping (see wavenet_dev.h): one wave64 = one stream x one block of <= 128 frames.  The wave
+// walks the stage program; every mat-mul is v_mfma_f32_16x16x4_f32 (exact f32, M = out channels,
+// N = 16 frames, K = 4 input channels).  Activations stay in the MFMA C/D fragment layout, which
+// is also the layout of the LDS block buffer and of the per-layer HBM history rings, so a tile
+// is stored/loaded as one float4 per lane (1 KB coalesced per 16 frames x 16 channels).
+// History taps that fall inside the current block come from LDS, older ones from the HBM ring.
+#include <hip/hip_runtime.h>
+
+#include "wavenet_dev.h"
+#include "wavenet_launch.h"
+
+namespace na
+{
+	typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+	// Activation.h:83-91 -- same association as the reference; IEEE division.
+	__device__ __forceinline__ float FastTanh(float x)
+	{
+		const float ax = fabsf(x);
+		const float x2 = x * x;
+		const float num = x * (2.45550750702956f + 2.45550750702956f * ax + (0.893229853513558f + 0.821226666969744f * ax) * x2);
+		const float den = 2.44506634652299f + (2.44506634652299f + x2) * fabsf(x + 0.814642734961073f * x * ax);
+		return num / den;
+	}
+
+	// Activation.h:110-118
+	__device__ __forceinline__ float LeakyReLU(float x) { return x > 0.0f ? x : 0.01f * x; }
+
+	__device__ __forceinline__ f32x4 Activate(f32x4 v, bool leaky)
+	{
+		f32x4 r;
+		if (leaky)
+		{
+			r.x = LeakyReLU(v.x); r.y = LeakyReLU(v.y); r.z = LeakyReLU(v.z); r.w = LeakyReLU(v.w);
+		}
+		else
+		{
+			r.x = FastTanh(v.x); r.y = FastTanh(v.y); r.z = FastTanh(v.z); r.w = FastTanh(v.w);
+		}
+		return r;
+	}
+
+	__device__ __forceinline__ f32x4 Mfma4(f32x4 a, f32x4 b, f32x4 c)
+	{
+		// four k-steps: element kk of the A/B float4s is k-slot (lane group, kk)
+		c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+		c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+		c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+		c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+		return c;
+	}
+
+	// One B fragment: frame (block-relative) `off`, channel group `cg`.
+	// off >= 0: current block, from LDS.  off < 0: history, from the HBM ring (true modulo ring).
+	// The LDS read is unconditional (clamped) and the ring read predicated, so the two address spaces
+	// never meet in one pointer (a merged pointer would degrade both to flat loads).
+	__device__ __forceinline__ f32x4 FetchTile(const f32x4* xb, const f32x4* __restrict__ ring, int off, int G, int cg, int pos0, int R)
+	{
+		const int offc = off < 0 ? 0 : off;
+		f32x4 v = xb[((offc >> 4) * G + cg) * 16 + (offc & 15)];
+		if (off < 0)
+		{
+			int p = pos0 + off;
+			if (p < 0) p += R;
+			v = ring[((p >> 4) * G + cg) * 16 + (p & 15)];
+		}
+		return v;
+	}
+
+	template <int NT>
+	__device__ __forceinline__ void Publish(const f32x4 (&x)[NT], f32x4* xb, f32x4* __restrict__ ring, int G, int pos0, int R, int n,
+		int g, int j)
+	{
+		if (g < G)
+		{
+#pragma unroll
+			for (int t = 0; t < NT; t++)
+			{
+				xb[(t * G + g) * 16 + j] = x[t];
+				const int f = t * 16 + j;
+				if (f < n)
+				{
+					int p = pos0 + f;
+					if (p >= R) p -= R;
+					ring[((p >> 4) * G + g) * 16 + (p & 15)] = x[t];
+				}
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+
+	template <int NT>
+	__device__ __forceinline__ void ConvRounds(f32x4 (&acc)[NT], const WnStage& sd, const WnModelDev& m, const f32x4* wp, const f32x4* xb,
+		const f32x4* __restrict__ ring, int pos0, int lane, int g, int j)
+	{
+		const int G = sd.G;
+		const int R = sd.ring_frames;
+		for (int r = 0; r < sd.nrounds; r++)
+		{
+			const f32x4 a = wp[sd.wconv_off + r * 64 + lane];
+			const WnQuad qd = m.qdesc[sd.qdesc_off + r * 4 + g];
+			const int base = j - qd.shift;
+			f32x4 b[NT];
+#pragma unroll
+			for (int t = 0; t < NT; t++)
+			{
+				b[t] = FetchTile(xb, ring, base + t * 16, G, qd.cg, pos0, R);
+			}
+#pragma unroll
+			for (int t = 0; t < NT; t++)
+				acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+			for (int t = 0; t < NT; t++)
+				acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+			for (int t = 0; t < NT; t++)
+				acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+			for (int t = 0; t < NT; t++)
+				acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+		}
+	}
+
+	__device__ __forceinline__ WnStage LoadStage(const WnStage* p)
+	{
+		// the stage table is wave-uniform: pin every field into an SGPR so control flow stays scalar
+		WnStage s;
+		const int* src = reinterpret_cast<const int*>(p);
+		int* dst = reinterpret_cast<int*>(&s);
+#pragma unroll
+		for (int i = 0; i < (int)(sizeof(WnStage) / sizeof(int)); i++) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
+		return s;
+	}
+
+	// grid = active streams of one model, block = 64 (one wave per stream)
+	template <int NT>
+	__global__ void __launch_bounds__(64) WaveNetBlockKernel(WnModelDev m, f32x4* __restrict__ state, const int* __restrict__ slots,
+		const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
+	{
+		__shared__ f32x4 xbuf[2][NT * 64];
+
+		const int lane = threadIdx.x;
+		const int g = lane >> 4;
+		const int j = lane & 15;
+		const int slot = slots[blockIdx.x];
+		const int row = rows[blockIdx.x];
+		f32x4* st = state + (size_t)slot * (size_t)m.state_f4;
+		int* header = reinterpret_cast<int*>(st);
+		const int myPos = header[lane]; // lane r holds the write cursor of ring r
+		const f32x4* wp = reinterpret_cast<const f32x4*>(m.wpack);
+		const float* inRow = in + (size_t)row * inStride;
+		float* outRow = out + (size_t)row * outStride;
+
+		float cond[NT];
+		f32x4 xcur[NT];
+		f32x4 head[NT];
+#pragma unroll
+		for (int t = 0; t < NT; t++)
+		{
+			const int f = t * 16 + j;
+			cond[t] = (f < n) ? inRow[f] : 0.0f; // WaveNet.h:770 (input -> condition)
+			xcur[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+			head[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
+		}
+
+		int cur = 0;
+
+		for (int s = 0; s < m.nstages; s++)
+		{
+			const WnStage sd = LoadStage(m.stages + s);
+			const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
+			const int inPos0 = (sd.ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.ring_id) : 0;
+
+			if (sd.type == WN_ST_LAYER)
+			{
+				// acc = conv bias + W_mix * cond   (bias WaveNet.h:288-289, mix-in :471)
+				const f32x4 bias4 = wp[sd.vec_off + g];
+				const f32x4 wm4 = wp[sd.vec_off + 4 + g];
+				f32x4 acc[NT];
+#pragma unroll
+				for (int t = 0; t < NT; t++) acc[t] = bias4 + wm4 * cond[t];
+
+				ConvRounds<NT>(acc, sd, m, wp, xbuf[cur], st + sd.ring_off, inPos0, lane, g, j); // :468
+
+				const bool leaky = (sd.flags & WN_FLAG_LEAKY) != 0;
+				const bool needOutput = (sd.flags & WN_FLAG_NEED_OUTPUT) != 0;
+				const f32x4 w1 = wp[sd.w1_off + lane];
+				const f32x4 b14 = wp[sd.vec_off + 8 + g];
+#pragma unroll
+				for (int t = 0; t < NT; t++)
+				{
+										{
+						const f32x4 z = Activate(acc[t], leaky); // :473-480
+						head[t] += z;                           // :482
+						if (needOutput)
+						{
+							// 1x1 + bias + residual (:486-491); z in D layout is already a B fragment
+							xcur[t] = Mfma4(w1, z, xcur[t] + b14);
+						}
+					}
+				}
+
+				if (sd.flags & WN_FLAG_PUBLISH)
+				{
+					Publish<NT>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, g, j);
+					cur ^= 1;
+				}
+			}
+			else if (sd.type == WN_ST_RECHANNEL_COND)
+			{
+				const f32x4 wre4 = wp[sd.vec_off + 12 + g];
+#pragma unroll
+				for (int t = 0; t < NT; t++) xcur[t] = wre4 * cond[t]; // :637 with InputSize == 1
+				Publish<NT>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, g, j);
+				cur ^= 1;
+			}
+			else if (sd.type == WN_ST_ARRAY_LINK)
+			{
+				// previous array's headRechannel (K=1, :658-660) and this array's rechannel (:637)
+				const f32x4 w1 = wp[sd.w1_off + lane];
+				const f32x4 w2 = wp[sd.w2_off + lane];
+				f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
+				if (sd.flags & WN_FLAG_BIAS) hb = wp[sd.vec_off + g];
+#pragma unroll
+				for (int t = 0; t < NT; t++)
+				{
+										{
+						head[t] = Mfma4(w1, head[t], hb);
+						xcur[t] = Mfma4(w2, xcur[t], f32x4{ 0.0f, 0.0f, 0.0f, 0.0f });
+					}
+				}
+				Publish<NT>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, g, j);
+				cur ^= 1;
+			}
+			else if (sd.type == WN_ST_HEAD_DENSE_OUT)
+			{
+				const f32x4 w1 = wp[sd.w1_off + lane];
+				f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
+				if (sd.flags & WN_FLAG_BIAS) hb = wp[sd.vec_off + g];
+#pragma unroll
+				for (int t = 0; t < NT; t++)
+				{
+										{
+						const f32x4 o = Mfma4(w1, head[t], hb);
+						const int f = t * 16 + j;
+						if (g == 0 && f < n) outRow[f] = m.head_scale * o.x; // :793-798
+					}
+				}
+			}
+			else if (sd.type == WN_ST_HEAD_CONV_OUT)
+			{
+				// A2 head: Conv1D(C -> 1, K = 16) over the accumulated head signal (:658-660)
+				Publish<NT>(head, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, g, j);
+				cur ^= 1;
+				f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
+				if (sd.flags & WN_FLAG_BIAS) hb = wp[sd.vec_off + g];
+				f32x4 acc[NT];
+#pragma unroll
+				for (int t = 0; t < NT; t++) acc[t] = hb;
+				ConvRounds<NT>(acc, sd, m, wp, xbuf[cur], st + sd.ring_off, inPos0, lane, g, j);
+#pragma unroll
+				for (int t = 0; t < NT; t++)
+				{
+					const int f = t * 16 + j;
+					if (g == 0 && f < n) outRow[f] = m.head_scale * acc[t].x;
+				}
+			}
+		}
+
+		// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
+		if (lane < m.nrings)
+		{
+			const int R = m.ring_frames[lane];
+			int p = myPos + n;
+			if (p >= R) p -= R;
+			header[lane] = p;
+		}
+	}
+
+	// ------------------------------------------------------------------------------------------
+	// Prewarm (WaveNet.h:746-766): zero-input steady state.  Every layer input is a constant column
+	// that depends only on the weights, so it is computed once per MODEL by one wave (lane = channel),
+	// in the reference's natural weight layout, then broadcast into every stream's rings.
+	// ------------------------------------------------------------------------------------------
+	__global__ void __launch_bounds__(64) WaveNetPrewarmColumnsKernel(const WnPrewarmLayer* __restrict__ layers, int numLayers,
+		const float* __restrict__ w, float* __restrict__ cols /* [ring][16] */)
+	{
+		__shared__ float x[16], z[16], head[16], lin[16];
+		const int i = threadIdx.x;
+		if (i < 16)
+		{
+			x[i] = 0.0f; z[i] = 0.0f; head[i] = 0.0f; lin[i] = 0.0f; // condition = 0 (:748), headArray zero (:750)
+		}
+		__syncthreads();
+
+		for (int li = 0; li < numLayers; li++)
+		{
+			const WnPrewarmLayer L = layers[li];
+			if (L.kind == 0)
+			{
+				if (L.rechannel >= 0)
+				{
+					// rechannel.Process (:609): x = W_re * layer_inputs
+					float v = 0.0f;
+					if (i < L.cin)
+						for (int c = 0; c < L.rech_in; c++) v += w[L.rechannel + i * L.rech_in + c] * lin[c];
+					__syncthreads();
+					if (i < 16) x[i] = (i < L.cin) ? v : 0.0f;
+					__syncthreads();
+				}
+				if (i < 16) cols[L.ring_id * 16 + i] = x[i]; // CopyBuffer (:74-82): the whole receptive field holds this column
+
+				float acc = 0.0f;
+				if (i < L.cout)
+				{
+					for (int k = 0; k < L.ksize; k++)
+						for (int c = 0; c < L.cin; c++) acc += w[L.wconv + (i * L.cin + c) * L.ksize + k] * x[c];
+					acc += w[L.bconv + i];
+					// mix-in * condition(0) adds nothing
+					acc = (L.act == 1) ? LeakyReLU(acc) : FastTanh(acc);
+				}
+				__syncthreads();
+				if (i < 16)
+				{
+					z[i] = (i < L.cout) ? acc : 0.0f;
+					head[i] += z[i];
+				}
+				__syncthreads();
+				float y = 0.0f;
+				if (i < L.cout)
+				{
+					for (int c = 0; c < L.cin; c++) y += w[L.w1 + i * L.cin + c] * z[c];
+					y += w[L.b1 + i];
+					y += x[i];
+				}
+				__syncthreads();
+				if (i < 16)
+				{
+					if (L.last_of_array) lin[i] = (i < L.cout) ? y : 0.0f; // arrayOutputs feeds the next array's rechannel
+					else x[i] = (i < L.cout) ? y : 0.0f;
+				}
+				__syncthreads();
+			}
+			else
+			{
+				// head rechannel (:625-629): steady-state head column, then conv over a constant history
+				if (L.ring_id >= 0 && i < 16) cols[L.ring_id * 16 + i] = (i < L.cin) ? head[i] : 0.0f;
+				float acc = 0.0f;
+				if (i < L.cout)
+				{
+					for (int k = 0; k < L.ksize; k++)
+						for (int c = 0; c < L.cin; c++) acc += w[L.wconv + (i * L.cin + c) * L.ksize + k] * head[c];
+					if (L.bconv >= 0) acc += w[L.bconv + i];
+				}
+				__syncthreads();
+				if (i < 16) head[i] = (i < L.cout) ? acc : 0.0f; // becomes the next array's head accumulator (:785-789)
+				__syncthreads();
+			}
+		}
+	}
+
+	// grid = (streams to fill, rings), block = 256: fill ring r of stream slot with its steady-state column
+	__global__ void __launch_bounds__(256) WaveNetFillRingsKernel(f32x4* __restrict__ state, int stateF4, const int* __restrict__ slots,
+		const int* __restrict__ ringOffF4, const int* __restrict__ ringFrames, const int* __restrict__ ringG, const float* __restrict__ cols)
+	{
+		const int slot = slots[blockIdx.x];
+		const int r = blockIdx.y;
+		f32x4* st = state + (size_t)slot * (size_t)stateF4;
+		const int G = ringG[r];
+		const int nF4 = (ringFrames[r] / 16) * G * 16;
+		f32x4* ring = st + ringOffF4[r];
+		for (int idx = threadIdx.x; idx < nF4; idx += blockDim.x)
+		{
+			const int cg = (idx >> 4) % G;
+			const float* c = cols + r * 16 + cg * 4;
+			ring[idx] = f32x4{ c[0], c[1], c[2], c[3] };
+		}
+		if (r == 0 && threadIdx.x < WN_MAX_RINGS) reinterpret_cast<int*>(st)[threadIdx.x] = 0; // cursors
+	}
+
+	// ------------------------------------------------------------------------------------------ launchers
+
+	hipError_t LaunchWaveNetBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
+		float* out, long inStride, long outStride, int n, hipStream_t stream)
+	{
+		if (numStreams <= 0 || n <= 0) return hipSuccess;
+		if (n > WN_MAX_FRAMES) return hipErrorInvalidValue;
+		hipLaunchKernelGGL(WaveNetBlockKernel<WN_MAX_TILES>, dim3((unsigned)numStreams), dim3(64), 0, stream, m,
+			reinterpret_cast<f32x4*>(state), slots, rows, in, out, inStride, outStride, n);
+		return hipGetLastError();
+	}
+
+	hipError_t LaunchWaveNetPrewarmColumns(const WnPrewarmLayer* layers, int numLayers, const float* weights, float* cols,
+		hipStream_t stream)
+	{
+		hipLaunchKernelGGL(WaveNetPrewarmColumnsKernel, dim3(1), dim3(64), 0, stream, layers, numLayers, weights, cols);
+		return hipGetLastError();
+	}
+
+	hipError_t LaunchWaveNetFillRings(float* state, int stateF4, const int* slots, int numStreams, int numRings, const int* ringOffF4,
+		const int* ringFrames, const int* ringG, const float* cols, hipStream_t stream)
+	{
+		if (numStreams <= 0) return hipSuccess;
+		hipLaunchKernelGGL(WaveNetFillRingsKernel, dim3((unsigned)numStreams, (unsigned)numRings), dim3(256), 0, stream,
+			reinterpret_cast<f32x4*>(state), stateF4, slots, ringOffF4, ringFrames, ringG, cols);
+		return hipGetLastError();
+	}
+}

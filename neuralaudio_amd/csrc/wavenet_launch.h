@@ -1,0 +1,22 @@
+// wavenet_launch.h -- host-callable launchers for the kernels in wavenet_kernels.hip
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include "wavenet_dev.h"
+
+namespace na
+{
+	// One block of n <= 128 frames for `numStreams` streams of one model.
+	//   slots[i]: state slot of active stream i; rows[i]: its row in `in`/`out` (row stride in floats)
+	hipError_t LaunchWaveNetBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
+		float* out, long inStride, long outStride, int n, hipStream_t stream);
+
+	// Zero-input steady-state columns per ring (once per model), cols = [nrings][16] floats.
+	hipError_t LaunchWaveNetPrewarmColumns(const WnPrewarmLayer* layers, int numLayers, const float* weights, float* cols,
+		hipStream_t stream);
+
+	// Broadcast the columns into the rings of the listed stream slots and zero their cursors.
+	hipError_t LaunchWaveNetFillRings(float* state, int stateF4, const int* slots, int numStreams, int numRings, const int* ringOffF4,
+		const int* ringFrames, const int* ringG, const float* cols, hipStream_t stream);
+}

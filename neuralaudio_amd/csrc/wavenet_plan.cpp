@@ -1,0 +1,400 @@
+// wavenet_plan.cpp -- WaveNetDesc -> stage program + packed MFMA operand tables.
+//
+// Weight walk order follows the reference's SetWeights chain exactly:
+//   WaveNetModelT::SetWeights (WaveNet.h:700-719) -> per array WaveNetLayerArrayT::SetWeights (:570-580):
+//   rechannel [out][in]; per layer (:420-425) conv [out][in][k] + bias, input mix-in [out][cond],
+//   1x1 [out][in] + bias; head conv [out][in][k] (+ bias); last float = head scale.
+#include "wavenet_plan.h"
+
+#include <algorithm>
+#include <sstream>
+#include <stdexcept>
+
+namespace na
+{
+	static int CeilDiv(int a, int b) { return (a + b - 1) / b; }
+
+	size_t WaveNetDesc::ExpectedNumWeights() const
+	{
+		size_t n = 0;
+		for (const auto& a : arrays)
+		{
+			const size_t c = (size_t)a.channels;
+			n += c * a.inputSize;
+			for (size_t l = 0; l < a.kernelSizes.size(); l++)
+			{
+				n += c * c * a.kernelSizes[l] + c; // conv + bias
+				n += c * a.conditionSize;         // mix-in
+				n += c * c + c;                   // 1x1 + bias
+			}
+			n += (size_t)a.headSize * c * a.headKernelSize + (a.hasHeadBias ? a.headSize : 0);
+		}
+		return n + 1; // head scale
+	}
+
+	int WaveNetDesc::ReceptiveFieldSize() const
+	{
+		int rf = 0;
+		for (const auto& a : arrays)
+		{
+			for (size_t l = 0; l < a.kernelSizes.size(); l++) rf += (a.kernelSizes[l] - 1) * a.dilations[l];
+			rf += (a.headKernelSize - 1) * a.headDilation;
+		}
+		return rf;
+	}
+
+	namespace
+	{
+		struct Builder
+		{
+			const WaveNetDesc& desc;
+			WaveNetPlan plan;
+			size_t cursor = 0; // into desc.weights
+
+			explicit Builder(const WaveNetDesc& d) : desc(d) {}
+
+			int Take(size_t n)
+			{
+				const size_t off = cursor;
+				cursor += n;
+				return (int)off;
+			}
+
+			float W(int off) const { return desc.weights[(size_t)off]; }
+
+			// reserve `nF4` float4 slots in wpack, zero-filled; returns float4 index
+			int AllocF4(int nF4)
+			{
+				const int off = (int)(plan.wpack.size() / 4);
+				plan.wpack.resize(plan.wpack.size() + (size_t)nF4 * 4, 0.0f);
+				return off;
+			}
+
+			int AddRing(int channels, int history)
+			{
+				WnRingInfo r;
+				r.channels = channels;
+				r.G = CeilDiv(channels, 4);
+				r.frames = CeilDiv(history, WN_TILE) * WN_TILE + WN_MAX_FRAMES;
+				r.offF4 = plan.stateF4;
+				plan.stateF4 += (r.frames / WN_TILE) * r.G * WN_TILE; // tiles * G * 16 float4
+				plan.rings.push_back(r);
+				if ((int)plan.rings.size() > WN_MAX_RINGS) throw std::runtime_error("WaveNet has more than 64 conv layers (unsupported)");
+				return (int)plan.rings.size() - 1;
+			}
+
+			// conv operand table: [round][lane] float4, lane (g,i): quad q = round*4+g -> (tap = q/G, cg = q%G),
+			// element kk -> input channel 4cg+kk, output channel i.  Flat conv weights: [(i*cin + c)*K + tap].
+			void PackConv(WnStage& st, int wOff, int cin, int cout, int ksize, int dilation)
+			{
+				const int G = CeilDiv(cin, 4);
+				const int nquads = ksize * G;
+				st.nrounds = CeilDiv(nquads, 4);
+				st.wconv_off = AllocF4(st.nrounds * 64);
+				st.qdesc_off = (int)plan.qdesc.size();
+				for (int r = 0; r < st.nrounds; r++)
+				{
+					for (int g = 0; g < 4; g++)
+					{
+						const int q = r * 4 + g;
+						WnQuad qd = { 0, 0, 0, 0 };
+						if (q < nquads)
+						{
+							const int tap = q / G;
+							qd.cg = q % G;
+							qd.shift = dilation * (ksize - 1 - tap); // tap k reads t - d*(K-1-k), WaveNet.h:160,255
+							qd.valid = 1;
+							for (int i = 0; i < 16; i++)
+							{
+								for (int kk = 0; kk < 4; kk++)
+								{
+									const int c = 4 * qd.cg + kk;
+									float v = 0.0f;
+									if (i < cout && c < cin) v = W(wOff + (i * cin + c) * ksize + tap);
+									plan.wpack[((size_t)st.wconv_off + (size_t)r * 64 + (size_t)(g * 16 + i)) * 4 + kk] = v;
+								}
+							}
+						}
+						plan.qdesc.push_back(qd);
+					}
+				}
+			}
+
+			// dense-from-registers operand table: lane (g,i), element kk -> input channel 4g+kk. Flat [i*cin + c].
+			int PackDense(int wOff, int cin, int cout)
+			{
+				if (cin > 16 || cout > 16) throw std::runtime_error("WaveNet channels > 16 are not supported by the gfx950 MFMA kernel");
+				const int off = AllocF4(64);
+				for (int g = 0; g < 4; g++)
+					for (int i = 0; i < 16; i++)
+						for (int kk = 0; kk < 4; kk++)
+						{
+							const int c = 4 * g + kk;
+							float v = 0.0f;
+							if (i < cout && c < cin) v = W(wOff + i * cin + c);
+							plan.wpack[((size_t)off + (size_t)(g * 16 + i)) * 4 + kk] = v;
+						}
+				return off;
+			}
+
+			void SetVec(const WnStage& st, int slot, int wOff, int n)
+			{
+				for (int i = 0; i < n && i < 16; i++) plan.wpack[((size_t)st.vec_off + (size_t)slot * 4) * 4 + i] = W(wOff + i);
+			}
+
+			static WnStage EmptyStage(int type)
+			{
+				WnStage st = {};
+				st.type = type;
+				st.ring_id = -1;
+				st.out_ring_id = -1;
+				return st;
+			}
+
+			void SetRing(WnStage& st, int ringId)
+			{
+				st.ring_id = ringId;
+				st.ring_off = plan.rings[ringId].offF4;
+				st.ring_frames = plan.rings[ringId].frames;
+			}
+
+			void SetOutRing(WnStage& st, int ringId)
+			{
+				st.out_ring_id = ringId;
+				st.out_ring_off = plan.rings[ringId].offF4;
+				st.out_ring_frames = plan.rings[ringId].frames;
+				st.out_G = plan.rings[ringId].G;
+			}
+
+			void Build()
+			{
+				const size_t expected = desc.ExpectedNumWeights();
+				if (expected != desc.weights.size())
+				{
+					std::stringstream str;
+					str << "Wrong number of weights. Expected " << expected << " but got " << desc.weights.size();
+					throw std::runtime_error(str.str());
+				}
+				if (desc.arrays.empty()) throw std::runtime_error("WaveNet without layer arrays");
+
+				plan.arrays = desc.arrays;
+				plan.receptiveField = desc.ReceptiveFieldSize();
+				plan.stateF4 = WN_HEADER_F4;
+
+				const int numArrays = (int)desc.arrays.size();
+
+				// Pass 1: rings (one per conv layer, plus a head ring when the head conv has K > 1)
+				std::vector<std::vector<int>> layerRing(numArrays);
+				std::vector<int> headRing(numArrays, -1);
+				for (int a = 0; a < numArrays; a++)
+				{
+					const WnArrayCfg& cfg = desc.arrays[a];
+					if (cfg.channels > 16 || cfg.headSize > 16 || cfg.inputSize > 16)
+						throw std::runtime_error("WaveNet channels > 16 are not supported by the gfx950 MFMA kernel");
+					if (cfg.conditionSize != 1) throw std::runtime_error("WaveNet condition_size != 1 is not supported");
+					if (cfg.kernelSizes.size() != cfg.dilations.size() || cfg.kernelSizes.empty())
+						throw std::runtime_error("WaveNet kernel_sizes/dilations mismatch");
+					for (size_t l = 0; l < cfg.kernelSizes.size(); l++)
+						layerRing[a].push_back(AddRing(cfg.channels, (cfg.kernelSizes[l] - 1) * cfg.dilations[l]));
+					if (cfg.headKernelSize > 1)
+						headRing[a] = AddRing(cfg.channels, (cfg.headKernelSize - 1) * cfg.headDilation);
+					if (a > 0)
+					{
+						// head accumulation continues in place in the previous array's head outputs (WaveNet.h:785-789)
+						if (desc.arrays[a - 1].headSize != cfg.channels || cfg.inputSize != desc.arrays[a - 1].channels)
+							throw std::runtime_error("WaveNet layer arrays do not chain (head_size/input_size mismatch)");
+						if (desc.arrays[a - 1].headKernelSize != 1)
+							throw std::runtime_error("WaveNet: head kernel > 1 is only supported on the last layer array");
+					}
+				}
+				if (desc.arrays[0].inputSize != 1) throw std::runtime_error("WaveNet first layer array must have input_size 1");
+
+				// Pass 2: walk the flat weights and emit stages
+				int prevHeadW = -1, prevHeadB = -1;
+				for (int a = 0; a < numArrays; a++)
+				{
+					const WnArrayCfg& cfg = desc.arrays[a];
+					const int C = cfg.channels;
+					const int numLayers = (int)cfg.kernelSizes.size();
+					const bool lastArray = (a == numArrays - 1);
+
+					const int rechOff = Take((size_t)C * cfg.inputSize);
+
+					if (a == 0)
+					{
+						WnStage st = EmptyStage(WN_ST_RECHANNEL_COND);
+						st.vec_off = AllocF4(16);
+						SetVec(st, 3, rechOff, C); // aux slot: w_re[c] (input_size == 1)
+						SetOutRing(st, layerRing[a][0]);
+						st.flags = WN_FLAG_PUBLISH;
+						plan.stages.push_back(st);
+					}
+					else
+					{
+						const WnArrayCfg& prev = desc.arrays[a - 1];
+						WnStage st = EmptyStage(WN_ST_ARRAY_LINK);
+						st.vec_off = AllocF4(16);
+						st.w1_off = PackDense(prevHeadW, prev.channels, prev.headSize);
+						if (prev.hasHeadBias)
+						{
+							st.flags |= WN_FLAG_BIAS;
+							SetVec(st, 0, prevHeadB, prev.headSize);
+						}
+						st.w2_off = PackDense(rechOff, cfg.inputSize, C);
+						SetOutRing(st, layerRing[a][0]);
+						st.flags |= WN_FLAG_PUBLISH;
+						plan.stages.push_back(st);
+					}
+
+					for (int l = 0; l < numLayers; l++)
+					{
+						const int K = cfg.kernelSizes[l];
+						const int d = cfg.dilations[l];
+						const int wconv = Take((size_t)C * C * K);
+						const int bconv = Take((size_t)C);
+						const int wmix = Take((size_t)C * cfg.conditionSize);
+						const int w1 = Take((size_t)C * C);
+						const int b1 = Take((size_t)C);
+
+						const bool lastLayer = (l == numLayers - 1);
+						WnStage st = EmptyStage(WN_ST_LAYER);
+						st.G = CeilDiv(C, 4);
+						st.vec_off = AllocF4(16);
+						SetVec(st, 0, bconv, C);
+						SetVec(st, 1, wmix, C);
+						SetVec(st, 2, b1, C);
+						PackConv(st, wconv, C, C, K, d);
+						st.w1_off = PackDense(w1, C, C);
+						SetRing(st, layerRing[a][l]);
+						if (cfg.activation == ACT_LEAKYRELU) st.flags |= WN_FLAG_LEAKY;
+						// NeedOutput=false for the very last layer (WaveNet.h:643,785); for a single-array model the
+						// reference still computes it but nothing reads it.
+						if (!(lastLayer && lastArray)) st.flags |= WN_FLAG_NEED_OUTPUT;
+						if (!lastLayer)
+						{
+							st.flags |= WN_FLAG_PUBLISH;
+							SetOutRing(st, layerRing[a][l + 1]);
+						}
+						plan.stages.push_back(st);
+
+						WnPrewarmLayer pw = {};
+						pw.kind = 0;
+						pw.cin = C; pw.cout = C; pw.ksize = K;
+						pw.act = cfg.activation;
+						pw.wconv = wconv; pw.bconv = bconv; pw.wmix = wmix; pw.w1 = w1; pw.b1 = b1;
+						pw.ring_id = layerRing[a][l];
+						pw.need_output = 1;
+						pw.last_of_array = lastLayer ? 1 : 0;
+						pw.rechannel = (l == 0) ? rechOff : -1;
+						pw.rech_in = cfg.inputSize;
+						plan.prewarm.push_back(pw);
+					}
+
+					const int wh = Take((size_t)cfg.headSize * C * cfg.headKernelSize);
+					const int bh = cfg.hasHeadBias ? Take((size_t)cfg.headSize) : -1;
+
+					WnPrewarmLayer pw = {};
+					pw.kind = 1;
+					pw.cin = C; pw.cout = cfg.headSize; pw.ksize = cfg.headKernelSize;
+					pw.wconv = wh; pw.bconv = bh; pw.wmix = -1; pw.w1 = -1; pw.b1 = -1;
+					pw.ring_id = headRing[a];
+					pw.rechannel = -1;
+					plan.prewarm.push_back(pw);
+
+					if (lastArray)
+					{
+						if (cfg.headKernelSize == 1)
+						{
+							WnStage st = EmptyStage(WN_ST_HEAD_DENSE_OUT);
+							st.vec_off = AllocF4(16);
+							st.w1_off = PackDense(wh, C, cfg.headSize);
+							if (cfg.hasHeadBias)
+							{
+								st.flags |= WN_FLAG_BIAS;
+								SetVec(st, 0, bh, cfg.headSize);
+							}
+							plan.stages.push_back(st);
+						}
+						else
+						{
+							WnStage st = EmptyStage(WN_ST_HEAD_CONV_OUT);
+							st.G = CeilDiv(C, 4);
+							st.vec_off = AllocF4(16);
+							PackConv(st, wh, C, cfg.headSize, cfg.headKernelSize, cfg.headDilation);
+							if (cfg.hasHeadBias)
+							{
+								st.flags |= WN_FLAG_BIAS;
+								SetVec(st, 0, bh, cfg.headSize);
+							}
+							SetRing(st, headRing[a]);
+							SetOutRing(st, headRing[a]);
+							plan.stages.push_back(st);
+						}
+					}
+					else
+					{
+						prevHeadW = wh;
+						prevHeadB = bh;
+					}
+				}
+
+				plan.headScale = W(Take(1));
+				// round the state up to a 256-byte multiple so every stream's state starts float4/line aligned
+				plan.stateF4 = CeilDiv(plan.stateF4, 16) * 16;
+			}
+		};
+	}
+
+	WaveNetPlan BuildWaveNetPlan(const WaveNetDesc& desc)
+	{
+		Builder b(desc);
+		b.Build();
+		return std::move(b.plan);
+	}
+
+	// B(arch) = 8 + (4/N) * sum_layers C_l * [ sum_{j=1}^{K_l-1} min(j*d_l, N) + min(N, (K_l-1)*d_l) ]
+	// (compulsory ring traffic with perfect in-block reuse, weights amortised; includes a head conv with K > 1)
+	double WaveNetPlan::AlgorithmicBytesPerSample(int N) const
+	{
+		double sum = 0.0;
+		for (const auto& a : arrays)
+		{
+			for (size_t l = 0; l < a.kernelSizes.size(); l++)
+			{
+				const int K = a.kernelSizes[l], d = a.dilations[l];
+				double t = 0.0;
+				for (int j = 1; j <= K - 1; j++) t += std::min(j * d, N);
+				t += std::min(N, (K - 1) * d);
+				sum += a.channels * t;
+			}
+			if (a.headKernelSize > 1)
+			{
+				const int K = a.headKernelSize, d = a.headDilation;
+				double t = 0.0;
+				for (int j = 1; j <= K - 1; j++) t += std::min(j * d, N);
+				t += std::min(N, (K - 1) * d);
+				sum += a.channels * t;
+			}
+		}
+		return 8.0 + 4.0 * sum / N;
+	}
+
+	double WaveNetPlan::MacsPerSample() const
+	{
+		double macs = 0.0;
+		const int numArrays = (int)arrays.size();
+		for (int ai = 0; ai < numArrays; ai++)
+		{
+			const auto& a = arrays[ai];
+			const double c = a.channels;
+			macs += c * a.inputSize;
+			for (size_t l = 0; l < a.kernelSizes.size(); l++)
+			{
+				const bool last = (ai == numArrays - 1) && (l == a.kernelSizes.size() - 1) && numArrays > 1;
+				macs += c * c * a.kernelSizes[l] + c * a.conditionSize + (last ? 0.0 : c * c);
+			}
+			macs += (double)a.headSize * c * a.headKernelSize;
+		}
+		return macs;
+	}
+}

@@ -1,0 +1,40 @@
+// wavenet_plan.h -- lowers a WaveNetDesc into the stage program + packed MFMA operand tables
+// consumed by the gfx950 kernels (see wavenet_dev.h for the layouts).
+#pragma once
+
+#include <vector>
+
+#include "model_desc.h"
+#include "wavenet_dev.h"
+
+namespace na
+{
+	struct WnRingInfo
+	{
+		int G;          // channel groups
+		int frames;     // ring length in frames (multiple of 16)
+		int offF4;      // float4 offset within the stream state
+		int channels;   // real channel count
+	};
+
+	struct WaveNetPlan
+	{
+		std::vector<WnStage> stages;
+		std::vector<float> wpack;   // size multiple of 4
+		std::vector<WnQuad> qdesc;
+		std::vector<WnRingInfo> rings;
+		std::vector<WnPrewarmLayer> prewarm;
+		int stateF4 = 0;            // per-stream state in float4 units
+		float headScale = 0.0f;
+		int receptiveField = 0;
+
+		// roofline bookkeeping: compulsory HBM bytes and MACs per sample at block N
+		double AlgorithmicBytesPerSample(int blockFrames) const;
+		double MacsPerSample() const;
+
+		std::vector<WnArrayCfg> arrays;
+	};
+
+	// throws std::runtime_error("Wrong number of weights...") like WaveNet.h:704-709
+	WaveNetPlan BuildWaveNetPlan(const WaveNetDesc& desc);
+}
