@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the NeuralModel::Process hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): NAM A1 WaveNet 'Standard', 1024 batched streams per GPU,
+128-sample buffers, FP32.  One "step" = one pass of the hot path over one buffer of every stream
+(one WaveNetBlockKernel launch over 1024 streams x 128 samples), inputs already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
+   one rank per GPU; streams are independent so ranks share nothing on the data path: weak scaling)
+
+Prints ONE JSON line (rank 0).  PyTorch is plumbing only: device buffers, the stream/event used for
+timing, and torch.distributed (RCCL) for the barrier + max-over-ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+STREAMS_PER_GPU = 1024
+BLOCK = 128
+MODEL_FILE = os.path.join(ROOT, "tests", "golden", "models", "BossWN-standard.nam")
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA peak
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, q // int(f2.read())))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The oracle ('port' of the reference's Internal CPU path) timed on this box's host cores,
+    ModelTest protocol (blocks of zeros after prewarm, Utils/ModelTest/ModelTest.cpp:59-79)."""
+    import ctypes as C
+    import numpy as np
+    import na_oracle as O  # cpu_baseline leg only
+
+    lib = O.load_native_lib()
+    j = O.load_json("BossWN-standard.nam")
+    arrays = O.wavenet_arrays_from_nam(j)
+    cfgs = O._cfgs(arrays)
+    w = np.ascontiguousarray(j["weights"], dtype=np.float32)
+    wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    cores = usable_cores()
+    # calibrate on a short all-core run, then size the timed run to ~seconds_target of wall time
+    t1 = lib.na_oracle_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, 32, 1)
+    single = 32 * BLOCK / t1
+    tc = lib.na_oracle_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, 16, cores)
+    per_thread = 16 * BLOCK / tc
+    blocks = max(16, min(int(seconds_target * per_thread / BLOCK), 200000))
+    t = lib.na_oracle_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, blocks, cores)
+    total = cores * blocks * BLOCK
+    return {
+        "value": total / t / 1e6,
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d threads x %d buffers of %d zero samples each after prewarm (ModelTest protocol), %.1f s wall; "
+                  "single-thread %.3f Msamples/s (%.1fx real-time)" % (cores, blocks, BLOCK, t, single / 1e6, single / 48000.0),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    import neuralaudio_amd as na
+
+    S = args.streams
+    loader = na.NeuralModelLoader()
+    loader.SetDevice(local_rank)
+    model = loader.CreateFromFile(MODEL_FILE, doPrewarm=False)
+    if model is None:
+        raise SystemExit("could not load " + MODEL_FILE)
+    # run on torch's current stream so torch.cuda.Event brackets exactly the kernels we launch
+    tstream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream handle
+    torch.cuda.set_stream(tstream)
+    batch = na.Batch(local_rank, hip_stream=tstream.cuda_stream)
+    batch.AddStreams(model, S)
+
+    # synthetic 48 kHz buffers (bench-C of SURVEY 8d): clip(0.25*N(0,1), +-1), per-rank seed; a ring of 8 distinct buffers
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    nbuf = 8
+    x = torch.clamp(0.25 * torch.randn(nbuf, S, BLOCK, generator=g), -1.0, 1.0).to(dev)
+    y = torch.empty(S, BLOCK, device=dev)
+
+    def step(i):
+        batch.ProcessDevice(x[i % nbuf].data_ptr(), y.data_ptr(), BLOCK, BLOCK, BLOCK)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+
+    # per-launch kernel duration from events on the launch stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev[0].record(tstream)
+    for i in range(args.steps):
+        step(i)
+        ev[i + 1].record(tstream)
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+
+    finite = bool(torch.isfinite(y).all().item())
+
+    if rank == 0:
+        samples_per_step = S * BLOCK
+        total_samples = samples_per_step * args.steps * world
+        value = total_samples / elapsed / 1e6  # Msamples/s, whole job
+        bytes_per_sample = batch.AlgorithmicBytesPerSample(BLOCK)
+        flops_per_sample = 2.0 * batch.MacsPerSample()
+        alg_bytes_per_launch = bytes_per_sample * samples_per_step
+        achieved_gbs = alg_bytes_per_launch / (kernel_ms_avg * 1e-3) / 1e9
+        achieved_tflops = flops_per_sample * samples_per_step / (kernel_ms_avg * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "concurrent 48 kHz real-time streams + Msamples/s/GPU, NAM WaveNet Standard",
+            "value": value,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "NAM A1 WaveNet 'Standard' (BossWN-standard.nam weights), %d batched streams per GPU, "
+                            "128-sample buffers, 48 kHz, inputs resident in HBM" % S,
+                "streams_per_gpu": S,
+                "block": BLOCK,
+                "parallelism": "independent streams sharded across %d GPU(s), no data-path collective" % world,
+            },
+            "realtime_streams_48k": value * 1e6 / 48000.0,
+            "msamples_per_s_per_gpu": value / world,
+            "kernel_ms_avg": kernel_ms_avg,
+            "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
+            "output_finite": finite,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_sample": bytes_per_sample,
+                "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                "kernel": "WaveNetBlockKernel",
+            },
+            "roofline_mfma_f32": {
+                "achieved": achieved_tflops,
+                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tflops / FP32_MFMA_PEAK_TFLOPS,
+                "algorithmic_flops_per_sample": flops_per_sample,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+
+    batch.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
