@@ -79,17 +79,20 @@ namespace na
 		return v;
 	}
 
-	template <int NT>
-	__device__ __forceinline__ void Publish(const f32x4 (&x)[NT], f32x4* xb, f32x4* __restrict__ ring, int G, int pos0, int R, int n,
-		int g, int j)
+	// Store this wave's TPW tiles (block tiles tb .. tb+TPW-1) of a layer output: to the LDS block buffer
+	// (for in-block taps of the next layer) and to the next layer's HBM ring (history for later blocks).
+	template <int TPW, int WPS>
+	__device__ __forceinline__ void Publish(const f32x4 (&x)[TPW], f32x4* xb, f32x4* __restrict__ ring, int G, int pos0, int R, int n,
+		int tb, int g, int j)
 	{
 		if (g < G)
 		{
 #pragma unroll
-			for (int t = 0; t < NT; t++)
+			for (int t = 0; t < TPW; t++)
 			{
-				xb[(t * G + g) * 16 + j] = x[t];
-				const int f = t * 16 + j;
+				const int T = tb + t;
+				xb[(T * G + g) * 16 + j] = x[t];
+				const int f = T * 16 + j;
 				if (f < n)
 				{
 					int p = pos0 + f;
@@ -98,43 +101,43 @@ namespace na
 				}
 			}
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
+		if (WPS > 1)
+		{
+			__syncthreads(); // the waves of a stream exchange their tiles through LDS
+		}
+		else
+		{
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
 	}
 
-	template <int NT>
-	__device__ __forceinline__ void ConvRounds(f32x4 (&acc)[NT], const WnStage& sd, const WnModelDev& m, const f32x4* wp, const f32x4* xb,
-		const f32x4* __restrict__ ring, int pos0, int lane, int g, int j)
+	template <int TPW>
+	__device__ __forceinline__ void ConvRounds(f32x4 (&acc)[TPW], const WnStage& sd, const WnQuad* __restrict__ qdesc, const f32x4* __restrict__ wp,
+		const f32x4* xb, const f32x4* __restrict__ ring, int pos0, int tb, int lane, int g, int j)
 	{
 		const int G = sd.G;
 		const int R = sd.ring_frames;
 		for (int r = 0; r < sd.nrounds; r++)
 		{
 			const f32x4 a = wp[sd.wconv_off + r * 64 + lane];
-			const WnQuad qd = m.qdesc[sd.qdesc_off + r * 4 + g];
-			const int base = j - qd.shift;
-			f32x4 b[NT];
+			const WnQuad qd = qdesc[sd.qdesc_off + r * 4 + g];
+			const int base = j - qd.shift + tb * 16;
+			f32x4 b[TPW];
 #pragma unroll
-			for (int t = 0; t < NT; t++)
-			{
-				b[t] = FetchTile(xb, ring, base + t * 16, G, qd.cg, pos0, R);
-			}
+			for (int t = 0; t < TPW; t++) b[t] = FetchTile(xb, ring, base + t * 16, G, qd.cg, pos0, R);
 #pragma unroll
-			for (int t = 0; t < NT; t++)
-				acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+			for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-			for (int t = 0; t < NT; t++)
-				acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+			for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
 #pragma unroll
-			for (int t = 0; t < NT; t++)
-				acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+			for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
 #pragma unroll
-			for (int t = 0; t < NT; t++)
-				acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+			for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
 		}
 	}
 
-	__device__ __forceinline__ WnStage LoadStage(const WnStage* p)
+	__device__ __forceinline__ WnStage LoadStage(const WnStage* __restrict__ p)
 	{
 		// the stage table is wave-uniform: pin every field into an SGPR so control flow stays scalar
 		WnStage s;
@@ -145,32 +148,38 @@ namespace na
 		return s;
 	}
 
-	// grid = active streams of one model, block = 64 (one wave per stream)
-	template <int NT>
-	__global__ void __launch_bounds__(64) WaveNetBlockKernel(WnModelDev m, f32x4* __restrict__ state, const int* __restrict__ slots,
-		const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
+	// grid = active streams of one model; block = WPS waves: the WPS waves of a workgroup split the stream's block
+	// of TPW*WPS tiles (16 frames each) along time and meet at one barrier per layer.
+	template <int TPW, int WPS>
+	__global__ void __launch_bounds__(64 * WPS) WaveNetBlockKernel(const WnStage* __restrict__ stages, const float* __restrict__ wpack,
+		const WnQuad* __restrict__ qdesc, const int* __restrict__ ringFrames, int nstages, int nrings, int stateF4, float headScale,
+		f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n)
 	{
-		__shared__ f32x4 xbuf[2][NT * 64];
+		constexpr int NTB = TPW * WPS;
+		__shared__ f32x4 xbuf[2][NTB * 64];
 
-		const int lane = threadIdx.x;
+		const int lane = threadIdx.x & 63;
+		const int wave = threadIdx.x >> 6;
+		const int tb = wave * TPW; // first block tile owned by this wave
 		const int g = lane >> 4;
 		const int j = lane & 15;
 		const int slot = slots[blockIdx.x];
 		const int row = rows[blockIdx.x];
-		f32x4* st = state + (size_t)slot * (size_t)m.state_f4;
+		f32x4* st = state + (size_t)slot * (size_t)stateF4;
 		int* header = reinterpret_cast<int*>(st);
 		const int myPos = header[lane]; // lane r holds the write cursor of ring r
-		const f32x4* wp = reinterpret_cast<const f32x4*>(m.wpack);
+		const f32x4* wp = reinterpret_cast<const f32x4*>(wpack);
 		const float* inRow = in + (size_t)row * inStride;
 		float* outRow = out + (size_t)row * outStride;
 
-		float cond[NT];
-		f32x4 xcur[NT];
-		f32x4 head[NT];
+		float cond[TPW];
+		f32x4 xcur[TPW];
+		f32x4 head[TPW];
 #pragma unroll
-		for (int t = 0; t < NT; t++)
+		for (int t = 0; t < TPW; t++)
 		{
-			const int f = t * 16 + j;
+			const int f = (tb + t) * 16 + j;
 			cond[t] = (f < n) ? inRow[f] : 0.0f; // WaveNet.h:770 (input -> condition)
 			xcur[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 			head[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
@@ -178,9 +187,9 @@ namespace na
 
 		int cur = 0;
 
-		for (int s = 0; s < m.nstages; s++)
+		for (int s = 0; s < nstages; s++)
 		{
-			const WnStage sd = LoadStage(m.stages + s);
+			const WnStage sd = LoadStage(stages + s);
 			const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
 			const int inPos0 = (sd.ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.ring_id) : 0;
 
@@ -189,33 +198,28 @@ namespace na
 				// acc = conv bias + W_mix * cond   (bias WaveNet.h:288-289, mix-in :471)
 				const f32x4 bias4 = wp[sd.vec_off + g];
 				const f32x4 wm4 = wp[sd.vec_off + 4 + g];
-				f32x4 acc[NT];
+				f32x4 acc[TPW];
 #pragma unroll
-				for (int t = 0; t < NT; t++) acc[t] = bias4 + wm4 * cond[t];
+				for (int t = 0; t < TPW; t++) acc[t] = bias4 + wm4 * cond[t];
 
-				ConvRounds<NT>(acc, sd, m, wp, xbuf[cur], st + sd.ring_off, inPos0, lane, g, j); // :468
+				ConvRounds<TPW>(acc, sd, qdesc, wp, xbuf[cur], st + sd.ring_off, inPos0, tb, lane, g, j); // :468
 
 				const bool leaky = (sd.flags & WN_FLAG_LEAKY) != 0;
 				const bool needOutput = (sd.flags & WN_FLAG_NEED_OUTPUT) != 0;
 				const f32x4 w1 = wp[sd.w1_off + lane];
 				const f32x4 b14 = wp[sd.vec_off + 8 + g];
 #pragma unroll
-				for (int t = 0; t < NT; t++)
+				for (int t = 0; t < TPW; t++)
 				{
-										{
-						const f32x4 z = Activate(acc[t], leaky); // :473-480
-						head[t] += z;                           // :482
-						if (needOutput)
-						{
-							// 1x1 + bias + residual (:486-491); z in D layout is already a B fragment
-							xcur[t] = Mfma4(w1, z, xcur[t] + b14);
-						}
-					}
+					const f32x4 z = Activate(acc[t], leaky); // :473-480
+					head[t] += z;                           // :482
+					// 1x1 + bias + residual (:486-491); z in D layout is already a B fragment
+					if (needOutput) xcur[t] = Mfma4(w1, z, xcur[t] + b14);
 				}
 
 				if (sd.flags & WN_FLAG_PUBLISH)
 				{
-					Publish<NT>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, g, j);
+					Publish<TPW, WPS>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
 					cur ^= 1;
 				}
 			}
@@ -223,8 +227,8 @@ namespace na
 			{
 				const f32x4 wre4 = wp[sd.vec_off + 12 + g];
 #pragma unroll
-				for (int t = 0; t < NT; t++) xcur[t] = wre4 * cond[t]; // :637 with InputSize == 1
-				Publish<NT>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, g, j);
+				for (int t = 0; t < TPW; t++) xcur[t] = wre4 * cond[t]; // :637 with InputSize == 1
+				Publish<TPW, WPS>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
 				cur ^= 1;
 			}
 			else if (sd.type == WN_ST_ARRAY_LINK)
@@ -235,14 +239,12 @@ namespace na
 				f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
 				if (sd.flags & WN_FLAG_BIAS) hb = wp[sd.vec_off + g];
 #pragma unroll
-				for (int t = 0; t < NT; t++)
+				for (int t = 0; t < TPW; t++)
 				{
-										{
-						head[t] = Mfma4(w1, head[t], hb);
-						xcur[t] = Mfma4(w2, xcur[t], f32x4{ 0.0f, 0.0f, 0.0f, 0.0f });
-					}
+					head[t] = Mfma4(w1, head[t], hb);
+					xcur[t] = Mfma4(w2, xcur[t], f32x4{ 0.0f, 0.0f, 0.0f, 0.0f });
 				}
-				Publish<NT>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, g, j);
+				Publish<TPW, WPS>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
 				cur ^= 1;
 			}
 			else if (sd.type == WN_ST_HEAD_DENSE_OUT)
@@ -251,39 +253,37 @@ namespace na
 				f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
 				if (sd.flags & WN_FLAG_BIAS) hb = wp[sd.vec_off + g];
 #pragma unroll
-				for (int t = 0; t < NT; t++)
+				for (int t = 0; t < TPW; t++)
 				{
-										{
-						const f32x4 o = Mfma4(w1, head[t], hb);
-						const int f = t * 16 + j;
-						if (g == 0 && f < n) outRow[f] = m.head_scale * o.x; // :793-798
-					}
+					const f32x4 o = Mfma4(w1, head[t], hb);
+					const int f = (tb + t) * 16 + j;
+					if (g == 0 && f < n) outRow[f] = headScale * o.x; // :793-798
 				}
 			}
 			else if (sd.type == WN_ST_HEAD_CONV_OUT)
 			{
 				// A2 head: Conv1D(C -> 1, K = 16) over the accumulated head signal (:658-660)
-				Publish<NT>(head, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, g, j);
+				Publish<TPW, WPS>(head, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
 				cur ^= 1;
 				f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
 				if (sd.flags & WN_FLAG_BIAS) hb = wp[sd.vec_off + g];
-				f32x4 acc[NT];
+				f32x4 acc[TPW];
 #pragma unroll
-				for (int t = 0; t < NT; t++) acc[t] = hb;
-				ConvRounds<NT>(acc, sd, m, wp, xbuf[cur], st + sd.ring_off, inPos0, lane, g, j);
+				for (int t = 0; t < TPW; t++) acc[t] = hb;
+				ConvRounds<TPW>(acc, sd, qdesc, wp, xbuf[cur], st + sd.ring_off, inPos0, tb, lane, g, j);
 #pragma unroll
-				for (int t = 0; t < NT; t++)
+				for (int t = 0; t < TPW; t++)
 				{
-					const int f = t * 16 + j;
-					if (g == 0 && f < n) outRow[f] = m.head_scale * acc[t].x;
+					const int f = (tb + t) * 16 + j;
+					if (g == 0 && f < n) outRow[f] = headScale * acc[t].x;
 				}
 			}
 		}
 
 		// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
-		if (lane < m.nrings)
+		if (wave == 0 && lane < nrings)
 		{
-			const int R = m.ring_frames[lane];
+			const int R = ringFrames[lane];
 			int p = myPos + n;
 			if (p >= R) p -= R;
 			header[lane] = p;
@@ -393,13 +393,25 @@ namespace na
 
 	// ------------------------------------------------------------------------------------------ launchers
 
+	template <int TPW, int WPS>
+	static void LaunchBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
+		long inStride, long outStride, int n, hipStream_t stream)
+	{
+		hipLaunchKernelGGL((WaveNetBlockKernel<TPW, WPS>), dim3((unsigned)numStreams), dim3(64 * WPS), 0, stream, m.stages, m.wpack, m.qdesc,
+			m.ring_frames, m.nstages, m.nrings, m.state_f4, m.head_scale, reinterpret_cast<f32x4*>(state), slots, rows, in, out, inStride,
+			outStride, n);
+	}
+
 	hipError_t LaunchWaveNetBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
 		float* out, long inStride, long outStride, int n, hipStream_t stream)
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > WN_MAX_FRAMES) return hipErrorInvalidValue;
-		hipLaunchKernelGGL(WaveNetBlockKernel<WN_MAX_TILES>, dim3((unsigned)numStreams), dim3(64), 0, stream, m,
-			reinterpret_cast<f32x4*>(state), slots, rows, in, out, inStride, outStride, n);
+		// smallest tile grid that covers n frames: (tiles per wave) x (waves per stream)
+		if (n > 64) LaunchBlock<2, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		else if (n > 32) LaunchBlock<1, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		else if (n > 16) LaunchBlock<1, 2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		else LaunchBlock<1, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 		return hipGetLastError();
 	}
 
