@@ -186,6 +186,7 @@ namespace na
 				dev.qdesc = dQdesc.Get();
 				dev.ring_frames = dRingFrames.Get();
 				dev.nstages = (int)plan.stages.size();
+				dev.nqdesc = (int)plan.qdesc.size();
 				dev.nrings = (int)plan.rings.size();
 				dev.state_f4 = plan.stateF4;
 				dev.head_scale = plan.headScale;

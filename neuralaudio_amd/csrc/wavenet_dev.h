@@ -66,6 +66,8 @@ namespace na
 		int out_ring_off;
 		int out_ring_frames;
 		int out_G;
+		int hist_rounds;     // leading conv rounds that may read history (shift > 0); later rounds are in-block only
+		int pad;
 	};
 
 	struct WnQuad
@@ -102,6 +104,7 @@ namespace na
 		const WnQuad* qdesc;
 		const int* ring_frames; // [nrings]
 		int nstages;
+		int nqdesc;           // total WnQuad entries
 		int nrings;
 		int state_f4;         // per-stream state size in float4 units (header + rings)
 		float head_scale;

@@ -85,6 +85,8 @@ namespace na
 	__device__ __forceinline__ void Publish(const f32x4 (&x)[TPW], f32x4* xb, f32x4* __restrict__ ring, int G, int pos0, int R, int n,
 		int tb, int g, int j)
 	{
+		// only the last R-128 = roundup16((K-1)*dilation) frames of a block can ever be read back as history
+		const int firstKept = n - (R - WN_MAX_FRAMES);
 		if (g < G)
 		{
 #pragma unroll
@@ -93,7 +95,7 @@ namespace na
 				const int T = tb + t;
 				xb[(T * G + g) * 16 + j] = x[t];
 				const int f = T * 16 + j;
-				if (f < n)
+				if (f < n && f >= firstKept)
 				{
 					int p = pos0 + f;
 					if (p >= R) p -= R;
@@ -103,11 +105,14 @@ namespace na
 		}
 		if (WPS > 1)
 		{
-			__syncthreads(); // the waves of a stream exchange their tiles through LDS
+			// LDS-only workgroup barrier: the ring stores above stay in flight (nobody reads them in this launch)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+			__builtin_amdgcn_s_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 		}
 		else
 		{
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
 			__builtin_amdgcn_wave_barrier();
 		}
 	}

@@ -90,6 +90,7 @@ namespace na
 				const int G = CeilDiv(cin, 4);
 				const int nquads = ksize * G;
 				st.nrounds = CeilDiv(nquads, 4);
+				st.hist_rounds = CeilDiv((ksize - 1) * G, 4); // quads are tap-major, the last tap (shift 0) comes last
 				st.wconv_off = AllocF4(st.nrounds * 64);
 				st.qdesc_off = (int)plan.qdesc.size();
 				for (int r = 0; r < st.nrounds; r++)
