@@ -105,12 +105,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
-
     import neuralaudio_amd as na
+    from neuralaudio_amd import dist as nd
+
+    if distributed:
+        nd.init(backend="nccl", device=dev)  # nccl == RCCL on ROCm; one rank per GPU
 
     S = args.streams
     loader = na.NeuralModelLoader()
@@ -139,8 +138,7 @@ def main():
 
     # per-launch kernel duration from events on the launch stream
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    if distributed:
-        dist.barrier()
+    nd.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev[0].record(tstream)
@@ -148,15 +146,9 @@ def main():
         step(i)
         ev[i + 1].record(tstream)
     torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
+    nd.barrier()
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-
-    if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = nd.max_over_ranks(time.perf_counter() - t0, device=dev)
 
     kernel_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
@@ -232,8 +224,7 @@ def main():
         print(json.dumps(out))
 
     batch.close()
-    if distributed:
-        dist.destroy_process_group()
+    nd.shutdown()
 
 
 if __name__ == "__main__":

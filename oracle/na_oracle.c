@@ -201,6 +201,20 @@ static void dense_process(const dense* d, const float* in, float* out, int frame
 	}
 }
 
+/* Test hook: the oracle's 1x1 / conv-tap arithmetic on caller-supplied column-major weights (W(i,j) = w[j*cout+i],
+ * the reference's ChannelBuffer<T,Out,In> layout), so it can be pinned against the reference's MatMul.h vectors.
+ * acc == 0: out = W*in (+bias);  acc == 1: out += W*in (+bias). */
+void na_oracle_test_dense(int cin, int cout, const float* w_colmajor, const float* bias_or_null, const float* in, float* out,
+	int frames, int acc)
+{
+	dense d;
+	dense_init(&d, cin, cout, bias_or_null != NULL);
+	memcpy(d.w, w_colmajor, (size_t)cin * cout * sizeof(float));
+	if (bias_or_null) memcpy(d.bias, bias_or_null, (size_t)cout * sizeof(float));
+	dense_process(&d, in, out, frames, acc);
+	dense_free(&d);
+}
+
 /* ---------------------------------------------------------------- WaveNetLayerT (WaveNet.h:391-494) */
 
 typedef struct {

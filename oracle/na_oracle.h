@@ -70,6 +70,10 @@ float na_oracle_fast_tanh(float x);
 float na_oracle_fast_sigmoid(float x);
 float na_oracle_leaky_relu(float x);
 
+/* test hook: W column-major [cin][cout]; see na_oracle.c */
+void na_oracle_test_dense(int cin, int cout, const float* w_colmajor, const float* bias_or_null, const float* in, float* out,
+	int frames, int acc);
+
 /* number of weights the architecture consumes (incl. trailing head_scale) */
 size_t na_oracle_wavenet_num_weights(int num_arrays, const na_oracle_wn_array_cfg* cfgs);
 

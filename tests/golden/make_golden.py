@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Regenerates the committed golden fixtures.  Run in the build container (where /root/reference exists).
+
+  matmul_ref.npz      REFERENCE OUTPUTS: the reference's own NeuralAudio/MatMul.h (compiled unmodified into
+                      oracle/_ref/libna_ref_matmul.so by `make -C oracle ref`) applied to seeded inputs.
+                      These pin the oracle's tiny mat-mul / conv-tap arithmetic against the reference itself.
+  oracle_outputs.npz  ORACLE REGRESSION VECTORS (not reference outputs): first 1024 output samples of the C
+                      oracle for every sample model on sin(0.01 n) after prewarm.  They make the oracle's
+                      behaviour reproducible on the GPU box and catch accidental edits; they do not pin parity
+                      (see oracle/na_oracle.h for what does).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import na_oracle as O  # noqa: E402
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def make_matmul():
+    ref = C.CDLL(os.path.join(O.ORACLE_DIR, "_ref", "libna_ref_matmul.so"))
+    rng = np.random.default_rng(20260928)
+    out = {}
+    frames = 37
+    for cin, cout in [(3, 3), (8, 1), (3, 1), (1, 3)]:
+        x = rng.uniform(-1, 1, size=(frames, cin)).astype(np.float32)
+        w = rng.uniform(-1, 1, size=(cin * cout,)).astype(np.float32)   # column-major W(i,j) = w[j*cout + i]
+        w2 = rng.uniform(-1, 1, size=(cin * cout,)).astype(np.float32)
+        init = rng.uniform(-1, 1, size=(cout,)).astype(np.float32)
+        tag = "%d_%d" % (cin, cout)
+        y0 = np.zeros((frames, cout), np.float32)
+        getattr(ref, "na_ref_matmul_init_zero_" + tag)(fptr(x), fptr(y0), fptr(w), C.c_size_t(frames))
+        y1 = np.zeros((frames, cout), np.float32)
+        getattr(ref, "na_ref_matmul_init_colwise_" + tag)(fptr(x), fptr(y1), fptr(w), fptr(init), C.c_size_t(frames))
+        y2 = y1.copy()
+        getattr(ref, "na_ref_matmul_accumulate_" + tag)(fptr(x), fptr(y2), fptr(w2), C.c_size_t(frames))
+        out.update({"x_" + tag: x, "w_" + tag: w, "w2_" + tag: w2, "init_" + tag: init, "zero_" + tag: y0,
+                    "colwise_" + tag: y1, "acc_" + tag: y2})
+    np.savez_compressed(os.path.join(HERE, "matmul_ref.npz"), **out)
+
+
+def make_oracle_outputs():
+    x = O.signal_sine(1024)
+    out = {"input": x}
+    for name, q in [("BossWN-standard.nam", 1.0), ("BossWN-feather.nam", 1.0), ("BossWN-nano.nam", 1.0),
+                    ("BossWN-a2.nam", 0.0), ("BossWN-a2.nam", 1.0), ("BossLSTM-1x16.nam", 1.0), ("BossLSTM-2x8.nam", 1.0),
+                    ("tw40_blues_deluxe_deerinkstudios.json", 1.0)]:
+        m = O.oracle_from_file(name, quality=q)
+        out["%s@q%.1f" % (name, q)] = m.process(x)
+    np.savez_compressed(os.path.join(HERE, "oracle_outputs.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_matmul()
+    make_oracle_outputs()
+    print("golden fixtures written")

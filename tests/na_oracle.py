@@ -56,6 +56,8 @@ def _bind(lib):
     lib.na_oracle_fast_sigmoid.argtypes = [C.c_float]
     lib.na_oracle_leaky_relu.restype = C.c_float
     lib.na_oracle_leaky_relu.argtypes = [C.c_float]
+    lib.na_oracle_test_dense.restype = None
+    lib.na_oracle_test_dense.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, C.c_int, C.c_int]
     lib.na_oracle_wavenet_num_weights.restype = C.c_size_t
     lib.na_oracle_wavenet_num_weights.argtypes = [C.c_int, C.POINTER(WnArrayCfg)]
     lib.na_oracle_wavenet_create.restype = C.c_void_p
@@ -104,6 +106,19 @@ def load_native_lib():
 
 def _fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def test_dense(w_colmajor, bias, x, out=None):
+    """oracle 1x1: x [frames][cin] -> [frames][cout]; out given -> accumulate into it"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    frames, cin = x.shape
+    w = np.ascontiguousarray(w_colmajor, dtype=np.float32)
+    cout = w.size // cin
+    acc = out is not None
+    y = np.ascontiguousarray(out, dtype=np.float32).copy() if acc else np.zeros((frames, cout), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    lib().na_oracle_test_dense(cin, cout, _fptr(w), None if b is None else _fptr(b), _fptr(x), _fptr(y), frames, 1 if acc else 0)
+    return y
 
 
 # ----------------------------------------------------------------------------- model-file reading
