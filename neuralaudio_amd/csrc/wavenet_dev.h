@@ -105,6 +105,7 @@ namespace na
 		const int* ring_frames; // [nrings]
 		int nstages;
 		int nqdesc;           // total WnQuad entries
+		int wpack_f4;         // size of wpack in float4 units
 		int nrings;
 		int state_f4;         // per-stream state size in float4 units (header + rings)
 		float head_scale;

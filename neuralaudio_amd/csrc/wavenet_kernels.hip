@@ -25,7 +25,9 @@ namespace na
 {
 	typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-	// Activation.h:83-91 -- same association as the reference; IEEE division.
+	typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+	// Activation.h:83-91 -- same association as the reference; IEEE division.  (prewarm kernel, once per model)
 	__device__ __forceinline__ float FastTanh(float x)
 	{
 		const float ax = fabsf(x);
@@ -38,6 +40,28 @@ namespace na
 	// Activation.h:110-118
 	__device__ __forceinline__ float LeakyReLU(float x) { return x > 0.0f ? x : 0.01f * x; }
 
+	__device__ __forceinline__ f32x2 Abs2(f32x2 v)
+	{
+		f32x2 r;
+		r.x = __builtin_fabsf(v.x);
+		r.y = __builtin_fabsf(v.y);
+		return r;
+	}
+
+	// Hot-path form of Activation.h:83-91 on two lanes' worth of data: same association, packed f32 math
+	// (v_pk_fma/v_pk_mul), division as num * v_rcp_f32(den) (1 ulp; the north-star tolerance is 1e-4 RMS).
+	__device__ __forceinline__ f32x2 FastTanh2(f32x2 x)
+	{
+		const f32x2 ax = Abs2(x);
+		const f32x2 x2 = x * x;
+		const f32x2 num = x * (2.45550750702956f + 2.45550750702956f * ax + (0.893229853513558f + 0.821226666969744f * ax) * x2);
+		const f32x2 den = 2.44506634652299f + (2.44506634652299f + x2) * Abs2(x + 0.814642734961073f * x * ax);
+		f32x2 r;
+		r.x = __builtin_amdgcn_rcpf(den.x);
+		r.y = __builtin_amdgcn_rcpf(den.y);
+		return num * r;
+	}
+
 	__device__ __forceinline__ f32x4 Activate(f32x4 v, bool leaky)
 	{
 		f32x4 r;
@@ -47,7 +71,9 @@ namespace na
 		}
 		else
 		{
-			r.x = FastTanh(v.x); r.y = FastTanh(v.y); r.z = FastTanh(v.z); r.w = FastTanh(v.w);
+			const f32x2 lo = FastTanh2(f32x2{ v.x, v.y });
+			const f32x2 hi = FastTanh2(f32x2{ v.z, v.w });
+			r = f32x4{ lo.x, lo.y, hi.x, hi.y };
 		}
 		return r;
 	}
@@ -62,50 +88,33 @@ namespace na
 		return c;
 	}
 
-	// One B fragment: frame (block-relative) `off`, channel group `cg`.
-	// off >= 0: current block, from LDS.  off < 0: history, from the HBM ring (true modulo ring).
-	// The LDS read is unconditional (clamped) and the ring read predicated, so the two address spaces
-	// never meet in one pointer (a merged pointer would degrade both to flat loads).
-	__device__ __forceinline__ f32x4 FetchTile(const f32x4* xb, const f32x4* __restrict__ ring, int off, int G, int cg, int pos0, int R)
+	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+	constexpr int WN_OOB = (int)0x80000000; // buffer offset that is always out of range: loads return 0, stores are dropped
+
+	// Raw buffer access: SGPR resource (base + size) + 32-bit per-lane byte offset + SGPR offset.  No 64-bit
+	// per-lane address math, and out-of-range lanes are predicated off by the hardware bounds check.
+	__device__ __forceinline__ __amdgpu_buffer_rsrc_t MakeRsrc(const void* base, unsigned bytes)
 	{
-		const int offc = off < 0 ? 0 : off;
-		f32x4 v = xb[((offc >> 4) * G + cg) * 16 + (offc & 15)];
-		if (off < 0)
-		{
-			int p = pos0 + off;
-			if (p < 0) p += R;
-			v = ring[((p >> 4) * G + cg) * 16 + (p & 15)];
-		}
-		return v;
+		return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 	}
 
-	// Store this wave's TPW tiles (block tiles tb .. tb+TPW-1) of a layer output: to the LDS block buffer
-	// (for in-block taps of the next layer) and to the next layer's HBM ring (history for later blocks).
-	template <int TPW, int WPS>
-	__device__ __forceinline__ void Publish(const f32x4 (&x)[TPW], f32x4* xb, f32x4* __restrict__ ring, int G, int pos0, int R, int n,
-		int tb, int g, int j)
+	__device__ __forceinline__ f32x4 BufLoad(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 	{
-		// only the last R-128 = roundup16((K-1)*dilation) frames of a block can ever be read back as history
-		const int firstKept = n - (R - WN_MAX_FRAMES);
-		if (g < G)
-		{
-#pragma unroll
-			for (int t = 0; t < TPW; t++)
-			{
-				const int T = tb + t;
-				xb[(T * G + g) * 16 + j] = x[t];
-				const int f = T * 16 + j;
-				if (f < n && f >= firstKept)
-				{
-					int p = pos0 + f;
-					if (p >= R) p -= R;
-					ring[((p >> 4) * G + g) * 16 + (p & 15)] = x[t];
-				}
-			}
-		}
+		return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+	}
+
+	__device__ __forceinline__ void BufStore(__amdgpu_buffer_rsrc_t r, f32x4 v, int voff)
+	{
+		__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+	}
+
+	// Workgroup barrier that orders LDS traffic only: global stores in flight (this layer's ring stores, which
+	// nobody reads back inside the launch) are NOT drained, unlike __syncthreads().
+	template <int WPS>
+	__device__ __forceinline__ void BlockBarrier()
+	{
 		if (WPS > 1)
 		{
-			// LDS-only workgroup barrier: the ring stores above stay in flight (nobody reads them in this launch)
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 			__builtin_amdgcn_s_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -117,20 +126,87 @@ namespace na
 		}
 	}
 
+	// Store this wave's TPW tiles (block tiles tb .. tb+TPW-1) of a layer output: to the LDS block buffer
+	// (in-block taps of the next layer) and to the next layer's HBM ring (history for LATER blocks: only the
+	// last R-128 = roundup16((K-1)*dilation) frames of a block can ever be read back).
+	template <int TPW, int WPS>
+	__device__ __forceinline__ void Publish(const f32x4 (&x)[TPW], f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int G, int pos0, int R,
+		int n, int tb, int g, int j)
+	{
+		if (g < G)
+		{
+			const int step = G * 16;
+			const int idx0 = (tb * G + g) * 16 + j;
+			const int f0 = tb * 16 + j;
+			const int firstKept = n - (R - WN_MAX_FRAMES);
+			int p = pos0 + f0;
+			if (p >= R) p -= R;
+#pragma unroll
+			for (int t = 0; t < TPW; t++)
+			{
+				xb[idx0 + t * step] = x[t];
+				const int f = f0 + t * 16;
+				const int voff = (ringOff + ((p >> 4) * G + g) * 16 + (p & 15)) * 16;
+				BufStore(srsrc, x[t], (f < n && f >= firstKept) ? voff : WN_OOB);
+				p += 16;
+				if (p >= R) p -= R;
+			}
+		}
+		BlockBarrier<WPS>();
+	}
+
+	// acc += conv(x) for this wave's tiles (Conv1DT::Process, WaveNet.h:139-290).
+	// B fragment of (round, tile): frame off = 16*(tb+t) + j - shift of channel group cg, per lane group.
+	// The source is classified per (round, tile) with SCALAR compares on the min/max shift of the four lane groups:
+	//   whole tile inside the current block -> one LDS read;  whole tile in the past -> one ring read from HBM;
+	//   straddling the block start -> both + select.
 	template <int TPW>
-	__device__ __forceinline__ void ConvRounds(f32x4 (&acc)[TPW], const WnStage& sd, const WnQuad* __restrict__ qdesc, const f32x4* __restrict__ wp,
-		const f32x4* xb, const f32x4* __restrict__ ring, int pos0, int tb, int lane, int g, int j)
+	__device__ __forceinline__ void ConvRounds(f32x4 (&acc)[TPW], const WnStage& sd, const WnQuad* sQ, __amdgpu_buffer_rsrc_t wrsrc,
+		const f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int pos0, int tb, int lane, int g, int j)
 	{
 		const int G = sd.G;
 		const int R = sd.ring_frames;
+		const int step = G * 16;
 		for (int r = 0; r < sd.nrounds; r++)
 		{
-			const f32x4 a = wp[sd.wconv_off + r * 64 + lane];
-			const WnQuad qd = qdesc[sd.qdesc_off + r * 4 + g];
-			const int base = j - qd.shift + tb * 16;
+			const f32x4 a = BufLoad(wrsrc, lane * 16, (sd.wconv_off + r * 64) * 16);
+			const WnQuad qd = sQ[sd.qdesc_off + r * 4 + g];
+			const int s0 = __builtin_amdgcn_readlane(qd.shift, 0), s1 = __builtin_amdgcn_readlane(qd.shift, 16);
+			const int s2 = __builtin_amdgcn_readlane(qd.shift, 32), s3 = __builtin_amdgcn_readlane(qd.shift, 48);
+			const int smin = min(min(s0, s1), min(s2, s3));
+			const int smax = max(max(s0, s1), max(s2, s3));
+			const int off0 = tb * 16 + j - qd.shift;
+			const int idx0 = ((off0 >> 4) * G + qd.cg) * 16 + (off0 & 15);
+			int p0 = pos0 + off0;
+			if (p0 < 0) p0 += R;
 			f32x4 b[TPW];
 #pragma unroll
-			for (int t = 0; t < TPW; t++) b[t] = FetchTile(xb, ring, base + t * 16, G, qd.cg, pos0, R);
+			for (int t = 0; t < TPW; t++)
+			{
+				const int base = (tb + t) * 16;
+				if (base - smax >= 0)
+				{
+					b[t] = xb[idx0 + t * step];
+				}
+				else
+				{
+					int p = p0 + t * 16;
+					if (p >= R) p -= R;
+					const int voff = (sd.ring_off + ((p >> 4) * G + qd.cg) * 16 + (p & 15)) * 16;
+					if (base + 15 - smin < 0)
+					{
+						b[t] = BufLoad(srsrc, voff, 0);
+					}
+					else
+					{
+						const int off = off0 + t * 16;
+						const int idx = idx0 + t * step;
+						const f32x4 l = xb[idx < 0 ? 0 : idx];
+						const f32x4 h = BufLoad(srsrc, off < 0 ? voff : WN_OOB, 0);
+						b[t] = (off < 0) ? h : l;
+					}
+				}
+			}
 #pragma unroll
 			for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -142,39 +218,56 @@ namespace na
 		}
 	}
 
-	__device__ __forceinline__ WnStage LoadStage(const WnStage* __restrict__ p)
+	constexpr int WN_STAGE_INTS = (int)(sizeof(WnStage) / sizeof(int));
+
+	__device__ __forceinline__ WnStage LoadStageLds(const int* sStages, int s)
 	{
 		// the stage table is wave-uniform: pin every field into an SGPR so control flow stays scalar
-		WnStage s;
-		const int* src = reinterpret_cast<const int*>(p);
-		int* dst = reinterpret_cast<int*>(&s);
+		WnStage sd;
+		int* dst = reinterpret_cast<int*>(&sd);
 #pragma unroll
-		for (int i = 0; i < (int)(sizeof(WnStage) / sizeof(int)); i++) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
-		return s;
+		for (int i = 0; i < WN_STAGE_INTS; i++) dst[i] = __builtin_amdgcn_readfirstlane(sStages[s * WN_STAGE_INTS + i]);
+		return sd;
 	}
 
 	// grid = active streams of one model; block = WPS waves: the WPS waves of a workgroup split the stream's block
-	// of TPW*WPS tiles (16 frames each) along time and meet at one barrier per layer.
+	// of TPW*WPS tiles (16 frames each) along time and meet at one LDS barrier per layer.
+	// dynamic LDS: xbuf[2][NTB*64] float4 | stage table | quad table
 	template <int TPW, int WPS>
 	__global__ void __launch_bounds__(64 * WPS) WaveNetBlockKernel(const WnStage* __restrict__ stages, const float* __restrict__ wpack,
-		const WnQuad* __restrict__ qdesc, const int* __restrict__ ringFrames, int nstages, int nrings, int stateF4, float headScale,
-		f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows, const float* __restrict__ in,
-		float* __restrict__ out, long inStride, long outStride, int n)
+		const WnQuad* __restrict__ qdesc, const int* __restrict__ ringFrames, int nstages, int nqdesc, int wpackF4, int nrings, int stateF4,
+		float headScale, f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows,
+		const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
 	{
 		constexpr int NTB = TPW * WPS;
-		__shared__ f32x4 xbuf[2][NTB * 64];
+		extern __shared__ __attribute__((aligned(16))) char smem[];
+		f32x4* xbuf = reinterpret_cast<f32x4*>(smem);                       // [2][NTB*64]
+		int* sStages = reinterpret_cast<int*>(smem + 2 * NTB * 64 * 16);    // [nstages][WN_STAGE_INTS]
+		WnQuad* sQ = reinterpret_cast<WnQuad*>(sStages + ((nstages * WN_STAGE_INTS + 3) & ~3)); // [nqdesc]
 
 		const int lane = threadIdx.x & 63;
-		const int wave = threadIdx.x >> 6;
+		const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform by construction: keep it in an SGPR
 		const int tb = wave * TPW; // first block tile owned by this wave
 		const int g = lane >> 4;
 		const int j = lane & 15;
+
+		// model tables -> LDS (a few KB, L2-resident): takes their latency off every layer's critical path
+		{
+			const int* src = reinterpret_cast<const int*>(stages);
+			for (int i = threadIdx.x; i < nstages * WN_STAGE_INTS; i += 64 * WPS) sStages[i] = src[i];
+			const f32x4* qsrc = reinterpret_cast<const f32x4*>(qdesc);
+			f32x4* qdst = reinterpret_cast<f32x4*>(sQ);
+			for (int i = threadIdx.x; i < nqdesc; i += 64 * WPS) qdst[i] = qsrc[i];
+		}
+
 		const int slot = slots[blockIdx.x];
 		const int row = rows[blockIdx.x];
 		f32x4* st = state + (size_t)slot * (size_t)stateF4;
 		int* header = reinterpret_cast<int*>(st);
 		const int myPos = header[lane]; // lane r holds the write cursor of ring r
 		const f32x4* wp = reinterpret_cast<const f32x4*>(wpack);
+		const __amdgpu_buffer_rsrc_t wrsrc = MakeRsrc(wpack, (unsigned)wpackF4 * 16u);
+		const __amdgpu_buffer_rsrc_t srsrc = MakeRsrc(st, (unsigned)stateF4 * 16u);
 		const float* inRow = in + (size_t)row * inStride;
 		float* outRow = out + (size_t)row * outStride;
 
@@ -190,41 +283,46 @@ namespace na
 			head[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
 		}
 
+		if (WPS > 1) __syncthreads();
+		else __builtin_amdgcn_wave_barrier();
+
 		int cur = 0;
 
 		for (int s = 0; s < nstages; s++)
 		{
-			const WnStage sd = LoadStage(stages + s);
+			const WnStage sd = LoadStageLds(sStages, s);
 			const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
 			const int inPos0 = (sd.ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.ring_id) : 0;
+			f32x4* xbCur = xbuf + cur * (NTB * 64);
+			f32x4* xbNext = xbuf + (cur ^ 1) * (NTB * 64);
 
 			if (sd.type == WN_ST_LAYER)
 			{
-				// acc = conv bias + W_mix * cond   (bias WaveNet.h:288-289, mix-in :471)
+				const f32x4 w1 = wp[sd.w1_off + lane];
 				const f32x4 bias4 = wp[sd.vec_off + g];
 				const f32x4 wm4 = wp[sd.vec_off + 4 + g];
+				const f32x4 b14 = wp[sd.vec_off + 8 + g];
+
 				f32x4 acc[TPW];
 #pragma unroll
-				for (int t = 0; t < TPW; t++) acc[t] = bias4 + wm4 * cond[t];
-
-				ConvRounds<TPW>(acc, sd, qdesc, wp, xbuf[cur], st + sd.ring_off, inPos0, tb, lane, g, j); // :468
+				for (int t = 0; t < TPW; t++) acc[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+				ConvRounds<TPW>(acc, sd, sQ, wrsrc, xbCur, srsrc, inPos0, tb, lane, g, j); // WaveNet.h:468
 
 				const bool leaky = (sd.flags & WN_FLAG_LEAKY) != 0;
 				const bool needOutput = (sd.flags & WN_FLAG_NEED_OUTPUT) != 0;
-				const f32x4 w1 = wp[sd.w1_off + lane];
-				const f32x4 b14 = wp[sd.vec_off + 8 + g];
 #pragma unroll
 				for (int t = 0; t < TPW; t++)
 				{
-					const f32x4 z = Activate(acc[t], leaky); // :473-480
-					head[t] += z;                           // :482
+					// + conv bias (:288-289) + W_mix * cond (:471), then activation (:473-480)
+					const f32x4 z = Activate(acc[t] + (bias4 + wm4 * cond[t]), leaky);
+					head[t] += z; // :482
 					// 1x1 + bias + residual (:486-491); z in D layout is already a B fragment
 					if (needOutput) xcur[t] = Mfma4(w1, z, xcur[t] + b14);
 				}
 
 				if (sd.flags & WN_FLAG_PUBLISH)
 				{
-					Publish<TPW, WPS>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
+					Publish<TPW, WPS>(xcur, xbNext, srsrc, sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
 					cur ^= 1;
 				}
 			}
@@ -233,7 +331,7 @@ namespace na
 				const f32x4 wre4 = wp[sd.vec_off + 12 + g];
 #pragma unroll
 				for (int t = 0; t < TPW; t++) xcur[t] = wre4 * cond[t]; // :637 with InputSize == 1
-				Publish<TPW, WPS>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
+				Publish<TPW, WPS>(xcur, xbNext, srsrc, sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
 				cur ^= 1;
 			}
 			else if (sd.type == WN_ST_ARRAY_LINK)
@@ -249,7 +347,7 @@ namespace na
 					head[t] = Mfma4(w1, head[t], hb);
 					xcur[t] = Mfma4(w2, xcur[t], f32x4{ 0.0f, 0.0f, 0.0f, 0.0f });
 				}
-				Publish<TPW, WPS>(xcur, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
+				Publish<TPW, WPS>(xcur, xbNext, srsrc, sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
 				cur ^= 1;
 			}
 			else if (sd.type == WN_ST_HEAD_DENSE_OUT)
@@ -265,17 +363,17 @@ namespace na
 					if (g == 0 && f < n) outRow[f] = headScale * o.x; // :793-798
 				}
 			}
-			else if (sd.type == WN_ST_HEAD_CONV_OUT)
+			else // WN_ST_HEAD_CONV_OUT
 			{
 				// A2 head: Conv1D(C -> 1, K = 16) over the accumulated head signal (:658-660)
-				Publish<TPW, WPS>(head, xbuf[cur ^ 1], st + sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
+				Publish<TPW, WPS>(head, xbNext, srsrc, sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
 				cur ^= 1;
 				f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
 				if (sd.flags & WN_FLAG_BIAS) hb = wp[sd.vec_off + g];
 				f32x4 acc[TPW];
 #pragma unroll
 				for (int t = 0; t < TPW; t++) acc[t] = hb;
-				ConvRounds<TPW>(acc, sd, qdesc, wp, xbuf[cur], st + sd.ring_off, inPos0, tb, lane, g, j);
+				ConvRounds<TPW>(acc, sd, sQ, wrsrc, xbNext, srsrc, inPos0, tb, lane, g, j);
 #pragma unroll
 				for (int t = 0; t < TPW; t++)
 				{
@@ -402,9 +500,11 @@ namespace na
 	static void LaunchBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
 		long inStride, long outStride, int n, hipStream_t stream)
 	{
-		hipLaunchKernelGGL((WaveNetBlockKernel<TPW, WPS>), dim3((unsigned)numStreams), dim3(64 * WPS), 0, stream, m.stages, m.wpack, m.qdesc,
-			m.ring_frames, m.nstages, m.nrings, m.state_f4, m.head_scale, reinterpret_cast<f32x4*>(state), slots, rows, in, out, inStride,
-			outStride, n);
+		const size_t lds = (size_t)2 * TPW * WPS * 64 * 16 + (size_t)((m.nstages * WN_STAGE_INTS + 3) & ~3) * sizeof(int) +
+			(size_t)m.nqdesc * sizeof(WnQuad);
+		hipLaunchKernelGGL((WaveNetBlockKernel<TPW, WPS>), dim3((unsigned)numStreams), dim3(64 * WPS), lds, stream, m.stages, m.wpack, m.qdesc,
+			m.ring_frames, m.nstages, m.nqdesc, m.wpack_f4, m.nrings, m.state_f4, m.head_scale, reinterpret_cast<f32x4*>(state), slots, rows, in, out,
+			inStride, outStride, n);
 	}
 
 	hipError_t LaunchWaveNetBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
