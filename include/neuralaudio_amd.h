@@ -62,6 +62,8 @@ NA_EXTERN void* NA_BatchGetHipStream(NA_Batch* batch);
 NA_EXTERN double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames);
 NA_EXTERN double NA_BatchMacsPerSample(NA_Batch* batch);
 NA_EXTERN double NA_BatchStateBytes(NA_Batch* batch);
+/* tuning aid: device buffer (long long[stages*4*waves]) that workgroup 0 of the WaveNet kernel stamps with the shader clock; NULL = off */
+NA_EXTERN void NA_DebugSetTraceBuffer(void* deviceBuffer);
 
 #ifdef __cplusplus
 }

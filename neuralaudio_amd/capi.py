@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libNeuralAudioCAPI.so")
+# NA_LIB_SUFFIX selects a tuning build (tools/ablate.sh); unset in normal use
+LIB_PATH = os.path.join(_HERE, "libNeuralAudioCAPI%s.so" % os.environ.get("NA_LIB_SUFFIX", ""))
 
 LEGACY_SYMBOLS = [
     "CreateLoader", "DeleteLoader", "CreateModelFromFile", "DeleteModel", "SetLSTMLoadMode", "SetWaveNetLoadMode",
@@ -24,7 +25,7 @@ NA_SYMBOLS = [
     "NA_GetModelVersion", "NA_BatchCreate", "NA_BatchDestroy", "NA_BatchAddStreams", "NA_BatchNumStreams",
     "NA_BatchSetQuality", "NA_BatchGetActiveSubModel", "NA_BatchPrewarm", "NA_BatchProcess", "NA_BatchProcessDevice",
     "NA_BatchSynchronize", "NA_BatchGetHipStream", "NA_BatchAlgorithmicBytesPerSample", "NA_BatchMacsPerSample",
-    "NA_BatchStateBytes",
+    "NA_BatchStateBytes", "NA_DebugSetTraceBuffer",
 ]
 
 _lib = None
@@ -86,6 +87,7 @@ def load_library():
         "NA_BatchAlgorithmicBytesPerSample": (C.c_double, [vp, C.c_int]),
         "NA_BatchMacsPerSample": (C.c_double, [vp]),
         "NA_BatchStateBytes": (C.c_double, [vp]),
+        "NA_DebugSetTraceBuffer": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -7,6 +7,7 @@
 
 #include "neuralaudio_amd.h"
 #include "neural_model_impl.h"
+#include "wavenet_launch.h"
 
 struct NeuralModel
 {
@@ -347,6 +348,8 @@ double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames)
 }
 
 double NA_BatchMacsPerSample(NA_Batch* batch) { return batch ? batch->batch->MacsPerSample() : 0.0; }
+
+void NA_DebugSetTraceBuffer(void* deviceBuffer) { na::SetWaveNetTraceBuffer(reinterpret_cast<long long*>(deviceBuffer)); }
 
 double NA_BatchStateBytes(NA_Batch* batch) { return batch ? (double)batch->batch->StateBytes() : 0.0; }
 

@@ -188,6 +188,7 @@ namespace na
 				dev.nstages = (int)plan.stages.size();
 				dev.nqdesc = (int)plan.qdesc.size();
 				dev.wpack_f4 = (int)(plan.wpack.size() / 4);
+				dev.max_stage_f4 = plan.maxStageF4;
 				dev.nrings = (int)plan.rings.size();
 				dev.state_f4 = plan.stateF4;
 				dev.head_scale = plan.headScale;

@@ -67,6 +67,10 @@ namespace na
 		int out_ring_frames;
 		int out_G;
 		int hist_rounds;     // leading conv rounds that may read history (shift > 0); later rounds are in-block only
+		int wblk_off;        // float4 index: this stage's weights are ONE contiguous block [wblk_off, wblk_off + wblk_f4)
+		int wblk_f4;         // (vec | conv rounds | w1 | w2), staged into LDS one stage ahead
+		int ksize;           // conv kernel size / dilation of this stage (0 for stages without a conv)
+		int dilation;
 		int pad;
 	};
 
@@ -74,8 +78,8 @@ namespace na
 	{
 		int shift;  // frames back: dilation * (K - 1 - tap)
 		int cg;     // channel group fetched by this lane group
-		int valid;
-		int pad;
+		int smin;   // min / max shift over the four lane groups of this round (same value in all four entries):
+		int smax;   // lets the kernel classify a (round, tile) as in-block / history / straddling with scalar compares
 	};
 
 	// Natural-layout tensor table used by the prewarm kernel (one entry per conv ring).
@@ -106,6 +110,7 @@ namespace na
 		int nstages;
 		int nqdesc;           // total WnQuad entries
 		int wpack_f4;         // size of wpack in float4 units
+		int max_stage_f4;     // largest per-stage weight block in float4 units
 		int nrings;
 		int state_f4;         // per-stream state size in float4 units (header + rings)
 		float head_scale;

@@ -12,6 +12,9 @@ namespace na
 	hipError_t LaunchWaveNetBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
 		float* out, long inStride, long outStride, int n, hipStream_t stream);
 
+	// tuning aid: device buffer of long long[stages*4*waves] that workgroup 0 stamps with the shader clock (nullptr: off)
+	void SetWaveNetTraceBuffer(long long* deviceBuffer);
+
 	// Zero-input steady-state columns per ring (once per model), cols = [nrings][16] floats.
 	hipError_t LaunchWaveNetPrewarmColumns(const WnPrewarmLayer* layers, int numLayers, const float* weights, float* cols,
 		hipStream_t stream);

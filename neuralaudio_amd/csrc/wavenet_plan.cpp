@@ -91,20 +91,22 @@ namespace na
 				const int nquads = ksize * G;
 				st.nrounds = CeilDiv(nquads, 4);
 				st.hist_rounds = CeilDiv((ksize - 1) * G, 4); // quads are tap-major, the last tap (shift 0) comes last
+				st.ksize = ksize;
+				st.dilation = dilation;
 				st.wconv_off = AllocF4(st.nrounds * 64);
 				st.qdesc_off = (int)plan.qdesc.size();
 				for (int r = 0; r < st.nrounds; r++)
 				{
+					WnQuad round[4];
 					for (int g = 0; g < 4; g++)
 					{
 						const int q = r * 4 + g;
-						WnQuad qd = { 0, 0, 0, 0 };
+						WnQuad qd = { 0, 0, 0, 0 }; // idle quad: zero weights, reads (shift 0, group 0) = always valid in-block data
 						if (q < nquads)
 						{
 							const int tap = q / G;
 							qd.cg = q % G;
 							qd.shift = dilation * (ksize - 1 - tap); // tap k reads t - d*(K-1-k), WaveNet.h:160,255
-							qd.valid = 1;
 							for (int i = 0; i < 16; i++)
 							{
 								for (int kk = 0; kk < 4; kk++)
@@ -116,7 +118,19 @@ namespace na
 								}
 							}
 						}
-						plan.qdesc.push_back(qd);
+						round[g] = qd;
+					}
+					int smin = round[0].shift, smax = round[0].shift;
+					for (int g = 1; g < 4; g++)
+					{
+						smin = std::min(smin, round[g].shift);
+						smax = std::max(smax, round[g].shift);
+					}
+					for (int g = 0; g < 4; g++)
+					{
+						round[g].smin = smin;
+						round[g].smax = smax;
+						plan.qdesc.push_back(round[g]);
 					}
 				}
 			}
@@ -340,6 +354,15 @@ namespace na
 				}
 
 				plan.headScale = W(Take(1));
+				// every stage's weights were allocated back to back starting with its vec block
+				for (size_t i = 0; i < plan.stages.size(); i++)
+				{
+					WnStage& st = plan.stages[i];
+					const int end = (i + 1 < plan.stages.size()) ? plan.stages[i + 1].vec_off : (int)(plan.wpack.size() / 4);
+					st.wblk_off = st.vec_off;
+					st.wblk_f4 = end - st.vec_off;
+					plan.maxStageF4 = std::max(plan.maxStageF4, st.wblk_f4);
+				}
 				// round the state up to a 256-byte multiple so every stream's state starts float4/line aligned
 				plan.stateF4 = CeilDiv(plan.stateF4, 16) * 16;
 			}

@@ -25,6 +25,7 @@ namespace na
 		std::vector<WnRingInfo> rings;
 		std::vector<WnPrewarmLayer> prewarm;
 		int stateF4 = 0;            // per-stream state in float4 units
+		int maxStageF4 = 0;         // largest per-stage weight block (float4), sizes the LDS staging buffers
 		float headScale = 0.0f;
 		int receptiveField = 0;
 
