@@ -166,8 +166,7 @@ namespace na
 	}
 
 	constexpr int WN_STAGE_INTS = (int)(sizeof(WnStage) / sizeof(int));
-	constexpr int WN_HPF = 2;   // conv rounds whose history taps are prefetched one stage ahead (registers)
-	constexpr int WN_WCOPY = 4; // float4 per thread kept in flight while staging the next stage's weights
+	constexpr int WN_APF = 3; // conv rounds whose weight fragments are prefetched one stage ahead (A1: K = 3 -> all of them)
 
 	// The stage table is wave-uniform and read-only: read it through the constant address space so the compiler
 	// emits scalar loads (s_load_dwordx*) and every field lives in an SGPR -- control flow stays scalar, no VALU.
@@ -183,146 +182,103 @@ namespace na
 		return sd;
 	}
 
-	// History part of one B fragment (round r of stage sd, this wave's tile t): frames that precede the current
-	// block come from the stage's HBM ring.  Returns 0 for lanes (or whole tiles) that are inside the block.
 	template <int TPW>
-	__device__ __forceinline__ void HistFetch(f32x4 (&h)[TPW], const WnStage& sd, const WnQuad* sQ, int r, __amdgpu_buffer_rsrc_t srsrc,
-		int pos0, int tb, int g, int j)
+	__device__ __forceinline__ void MfmaRound(f32x4 (&acc)[TPW], f32x4 a, const f32x4 (&b)[TPW])
 	{
-		const WnQuad qd = sQ[sd.qdesc_off + r * 4 + g];
-		const int smax = __builtin_amdgcn_readfirstlane(qd.smax);
-		const int G = sd.G;
-		const int R = sd.ring_frames;
-		const int off0 = tb * 16 + j - qd.shift;
-		int p = pos0 + off0;
-		if (p < 0) p += R;
+		// element kk of the A/B float4s is k-slot (lane group, kk); tiles interleaved so no MFMA waits on its predecessor
 #pragma unroll
-		for (int t = 0; t < TPW; t++)
-		{
-			h[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-			if (!(NA_ABL & 2) && (tb + t) * 16 - smax < 0) // scalar: some lane of this tile reaches back before the block
-			{
-				const int voff = (sd.ring_off + ((p >> 4) * G + qd.cg) * 16 + (p & 15)) * 16;
-				h[t] = BufLoad(srsrc, (off0 + t * 16 < 0) ? voff : WN_OOB, 0);
-			}
-			p += 16;
-			if (p >= R) p -= R;
-		}
+		for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+		for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+		for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+		for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.w, b[t].w, acc[t], 0, 0, 0);
 	}
 
-	// acc += conv(x) for this wave's tiles (Conv1DT::Process, WaveNet.h:139-290).
-	// B fragment of (round, tile): frame off = 16*(tb+t) + j - shift of channel group cg, per lane group;
-	// off >= 0 -> LDS copy of the current block, off < 0 -> ring history (rounds < WN_HPF: prefetched in `hpre`).
-	// Weights (A fragments) are read from the LDS-staged block of this stage.
+	// Generic conv (any channel-group count; tap / channel group of every lane group from the quad table in LDS).
+	// B fragment of (round, tile): frame off = 16*(tb+t) + j - shift; off >= 0 -> LDS copy of the current block,
+	// off < 0 -> ring history in HBM; classified per (round, tile) with scalar compares on the round's min/max shift.
 	template <int TPW>
-	__device__ __forceinline__ void ConvRounds(f32x4 (&acc)[TPW], const f32x4 (&hpre)[WN_HPF][TPW], const WnStage& sd, const WnQuad* sQ,
-		const f32x4* wl, const f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int pos0, int tb, int lane, int g, int j)
+	__device__ __forceinline__ void ConvRounds(f32x4 (&acc)[TPW], const f32x4 (&apf)[WN_APF], const WnStage& sd, const WnQuad* sQ,
+		__amdgpu_buffer_rsrc_t wrsrc, const f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int pos0, int tb, int lane, int g, int j)
 	{
 		const int G = sd.G;
+		const int R = sd.ring_frames;
 		const int step = G * 16;
-		const f32x4* wconv = wl + (sd.wconv_off - sd.wblk_off) + lane;
-#pragma unroll
-		for (int r = 0; r < WN_HPF; r++)
+		for (int r = 0; r < sd.nrounds; r++)
 		{
-			if (r < sd.nrounds)
-			{
-				const f32x4 a = wconv[r * 64];
-				const WnQuad qd = sQ[sd.qdesc_off + r * 4 + g];
-				const int smin = __builtin_amdgcn_readfirstlane(qd.smin);
-				const int off0 = tb * 16 + j - qd.shift;
-				const int idx0 = ((off0 >> 4) * G + qd.cg) * 16 + (off0 & 15);
-				f32x4 b[TPW];
-#pragma unroll
-				for (int t = 0; t < TPW; t++)
-				{
-					if ((tb + t) * 16 + 15 - smin < 0)
-					{
-						b[t] = hpre[r][t]; // scalar: the whole tile is history
-					}
-					else
-					{
-						const int idx = idx0 + t * step;
-						const f32x4 l = xb[idx < 0 ? 0 : idx];
-						b[t] = (off0 + t * 16 < 0) ? hpre[r][t] : l;
-					}
-				}
-#pragma unroll
-				for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-				for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-				for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-				for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.w, b[t].w, acc[t], 0, 0, 0);
-			}
-		}
-		for (int r = WN_HPF; r < sd.nrounds; r++)
-		{
-			const f32x4 a = wconv[r * 64];
+			f32x4 a;
+			if (r == 0) a = apf[0];
+			else if (r == 1) a = apf[1];
+			else if (r == 2) a = apf[2];
+			else a = BufLoad(wrsrc, lane * 16, (sd.wconv_off + r * 64) * 16);
 			const WnQuad qd = sQ[sd.qdesc_off + r * 4 + g];
+			const int smin = __builtin_amdgcn_readfirstlane(qd.smin);
+			const int smax = __builtin_amdgcn_readfirstlane(qd.smax);
 			const int off0 = tb * 16 + j - qd.shift;
 			const int idx0 = ((off0 >> 4) * G + qd.cg) * 16 + (off0 & 15);
-			f32x4 h[TPW];
-			HistFetch<TPW>(h, sd, sQ, r, srsrc, pos0, tb, g, j);
+			int p = pos0 + off0;
+			if (p < 0) p += R;
 			f32x4 b[TPW];
 #pragma unroll
 			for (int t = 0; t < TPW; t++)
 			{
-				const int idx = idx0 + t * step;
-				const f32x4 l = xb[idx < 0 ? 0 : idx];
-				b[t] = (off0 + t * 16 < 0) ? h[t] : l;
+				const int base = (tb + t) * 16;
+				if (base - smax >= 0)
+				{
+					b[t] = xb[idx0 + t * step];
+				}
+				else
+				{
+					const int voff = (sd.ring_off + ((p >> 4) * G + qd.cg) * 16 + (p & 15)) * 16;
+					if ((NA_ABL & 2)) b[t] = xb[0];
+					else if (base + 15 - smin < 0) b[t] = BufLoad(srsrc, voff, 0);
+					else
+					{
+						const int off = off0 + t * 16;
+						const int idx = idx0 + t * step;
+						const f32x4 l = xb[idx < 0 ? 0 : idx];
+						const f32x4 h = BufLoad(srsrc, off < 0 ? voff : WN_OOB, 0);
+						b[t] = (off < 0) ? h : l;
+					}
+				}
+				p += 16;
+				if (p >= R) p -= R;
 			}
-#pragma unroll
-			for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-			for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-			for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-			for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.w, b[t].w, acc[t], 0, 0, 0);
+			MfmaRound<TPW>(acc, a, b);
 		}
 	}
 
-	// D = W * X (+ init) on every tile, the four k-steps of all tiles interleaved so no MFMA waits on its predecessor
-	template <int TPW>
-	__device__ __forceinline__ void DenseTiles(f32x4 (&d)[TPW], f32x4 w, const f32x4 (&x)[TPW])
-	{
-#pragma unroll
-		for (int t = 0; t < TPW; t++) d[t] = NA_MFMA(w.x, x[t].x, d[t], 0, 0, 0);
-#pragma unroll
-		for (int t = 0; t < TPW; t++) d[t] = NA_MFMA(w.y, x[t].y, d[t], 0, 0, 0);
-#pragma unroll
-		for (int t = 0; t < TPW; t++) d[t] = NA_MFMA(w.z, x[t].z, d[t], 0, 0, 0);
-#pragma unroll
-		for (int t = 0; t < TPW; t++) d[t] = NA_MFMA(w.w, x[t].w, d[t], 0, 0, 0);
-	}
-
-	// Conv of one layer for channel-group counts that divide 4 (C = 4, 8, 16 -> G = 1, 2, 4): a round then holds
-	// 4/G whole taps, so tap / channel group / shift of a lane group follow from (round, lane group) arithmetically
-	// and the in-block / history classification of a tile needs only SCALAR compares -- no quad-table lookups.
-	// Same packing as PackConv (quad q = 4r + g -> tap q / G, channel group q % G), same results as ConvRounds.
+	// Conv for channel-group counts that divide 4 (C = 4, 8, 16 -> G = 1, 2, 4): a round then holds 4/G whole taps, so
+	// tap / channel group / shift of a lane group follow from (round, lane group) arithmetically and the in-block /
+	// history classification of a tile needs only SCALAR compares -- no quad-table lookups.  Same packing as PackConv
+	// (quad q = 4r + g -> tap q / G, channel group q % G), same results as ConvRounds.
 	template <int G, int TPW>
-	__device__ __forceinline__ void ConvFast(f32x4 (&acc)[TPW], const WnStage& sd, const f32x4* wl, const f32x4* xb,
-		__amdgpu_buffer_rsrc_t srsrc, int pos0, int tb, int lane, int g, int j)
+	__device__ __forceinline__ void ConvFast(f32x4 (&acc)[TPW], const f32x4 (&apf)[WN_APF], const WnStage& sd, __amdgpu_buffer_rsrc_t wrsrc,
+		const f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int pos0, int tb, int lane, int g, int j)
 	{
 		constexpr int TPR = 4 / G; // taps per round
 		const int K = sd.ksize;
 		const int d = sd.dilation;
 		const int R = sd.ring_frames;
 		const int tg = g / G;
-		const int cgj = (g % G) * 16 + j;
-		const f32x4* wconv = wl + (sd.wconv_off - sd.wblk_off) + lane;
-		const int ringBase = sd.ring_off + (g % G) * 16;
+		const int cg16 = (g % G) * 16;
+		const int ringBase = sd.ring_off + cg16;
 		for (int r = 0; r < sd.nrounds; r++)
 		{
+			f32x4 a;
+			if (r == 0) a = apf[0];
+			else if (r == 1) a = apf[1];
+			else if (r == 2) a = apf[2];
+			else a = BufLoad(wrsrc, lane * 16, (sd.wconv_off + r * 64) * 16);
 			const int tapLo = r * TPR;                               // scalar; <= K-1 because r < nrounds
 			const int smax = d * (K - 1 - tapLo);                    // largest shift in this round
 			const int smin = d * max(K - 1 - (tapLo + TPR - 1), 0);  // smallest (idle quads read shift 0)
 			int shift = smax;
 			if (TPR > 1) shift = d * max(K - 1 - (tapLo + tg), 0);
-			const f32x4 a = wconv[r * 64];
 			const int off0 = tb * 16 + j - shift;
-			const int idx0 = (off0 >> 4) * (G * 16) + (off0 & 15) + (cgj - j);
+			const int idx0 = (off0 >> 4) * (G * 16) + (off0 & 15) + cg16;
 			f32x4 b[TPW];
 #pragma unroll
 			for (int t = 0; t < TPW; t++)
@@ -337,7 +293,8 @@ namespace na
 					int p = pos0 + off0 + t * 16;
 					if (p < 0) p += R;
 					const int voff = (ringBase + (p >> 4) * (G * 16) + (p & 15)) * 16;
-					if (base + 15 - smin < 0)
+					if ((NA_ABL & 2)) b[t] = xb[0];
+					else if (base + 15 - smin < 0)
 					{
 						b[t] = BufLoad(srsrc, voff, 0); // whole tile is history
 					}
@@ -351,72 +308,55 @@ namespace na
 					}
 				}
 			}
-#pragma unroll
-			for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-			for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-			for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-			for (int t = 0; t < TPW; t++) acc[t] = NA_MFMA(a.w, b[t].w, acc[t], 0, 0, 0);
+			MfmaRound<TPW>(acc, a, b);
 		}
 	}
 
 	// Tuning aid: when a trace buffer is installed (NA_DebugSetTraceBuffer), workgroup 0 stamps the shader clock at four
 	// points of every stage: trace[((stage * 4 + point) * waves + wave)].  Null in normal use (one scalar branch).
 #define NA_TRACE(point) \
-	if (trace != nullptr && blockIdx.x == 0 && lane == 0) trace[((s * 4 + (point)) * (WPS * SPW)) + wave] = (long long)__builtin_readcyclecounter()
+	if (trace != nullptr && (int)blockIdx.x == traceBlock && lane == 0) trace[((s * 4 + (point)) * WPS) + wave] = (long long)__builtin_readcyclecounter()
 
-	// grid = ceil(active streams / SPW); block = SPW*WPS waves.  A workgroup runs SPW streams of one model in lock step:
-	// the WPS waves of a stream split its block of TPW*WPS tiles (16 frames each) along time; all waves meet at one
-	// LDS-only barrier per stage.  Sharing the workgroup lets the streams share ONE LDS copy of each layer's weights,
-	// staged one stage ahead, so no L2/HBM latency sits between two layers:
-	//   stage s:  [issue loads: weights of stage s+1, history taps of stage s+1]  compute stage s  [weights -> LDS]  barrier
-	// dynamic LDS: xbuf[SPW][2][NTB*64] f4 | wbuf[2][maxStageF4] f4 | quad table
-	template <int TPW, int WPS, int SPW>
-	__global__ void __launch_bounds__(64 * WPS * SPW) WaveNetBlockKernel(const WnStage* __restrict__ stages, const float* __restrict__ wpack,
-		const WnQuad* __restrict__ qdesc, const int* __restrict__ ringFrames, int nstages, int nqdesc, int wpackF4, int maxStageF4,
-		int nrings, int stateF4, float headScale, f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows,
-		int numStreams, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n,
-		long long* __restrict__ trace)
+	// grid = active streams of one model; block = WPS waves: the WPS waves of a workgroup split the stream's block of
+	// TPW*WPS tiles (16 frames each) along time and meet at one LDS-only barrier per layer.  4 workgroups per CU
+	// (1024 streams = 4 per CU) need 4 waves per SIMD, i.e. <= 128 registers per lane.
+	// Per stage the wave first issues the loads whose latency it can hide -- the NEXT stage's weight fragments --
+	// BEFORE its own ring stores: gfx950 has one vmcnt for loads and stores, so a load issued after a store would
+	// otherwise wait for that store's acknowledgement.
+	// dynamic LDS: xbuf[2][NTB*64] float4 | quad table
+	template <int TPW, int WPS>
+	__global__ void __launch_bounds__(64 * WPS) __attribute__((amdgpu_waves_per_eu(4, 4))) WaveNetBlockKernel(
+		const WnStage* __restrict__ stages, const float* __restrict__ wpack, const WnQuad* __restrict__ qdesc,
+		const int* __restrict__ ringFrames, int nstages, int nqdesc, int wpackF4, int nrings, int stateF4, float headScale,
+		f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n, long long* __restrict__ trace, int traceBlock)
 	{
 		constexpr int NTB = TPW * WPS;
-		constexpr int NTHREADS = 64 * WPS * SPW;
 		extern __shared__ __attribute__((aligned(16))) char smem[];
-		f32x4* xbufAll = reinterpret_cast<f32x4*>(smem);                       // [SPW][2][NTB*64]
-		f32x4* wbuf = xbufAll + SPW * 2 * NTB * 64;                            // [2][maxStageF4]
-		WnQuad* sQ = reinterpret_cast<WnQuad*>(wbuf + 2 * maxStageF4);         // [nqdesc]
+		f32x4* xbuf = reinterpret_cast<f32x4*>(smem);                           // [2][NTB*64]
+		WnQuad* sQ = reinterpret_cast<WnQuad*>(smem + 2 * NTB * 64 * 16);       // [nqdesc]
 
-		const int tid = threadIdx.x;
-		const int lane = tid & 63;
-		const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
-		const int sidx = wave / WPS;          // stream within the workgroup
-		const int tb = (wave % WPS) * TPW;    // first block tile owned by this wave
+		const int lane = threadIdx.x & 63;
+		const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform by construction: keep it in an SGPR
+		const int tb = wave * TPW; // first block tile owned by this wave
 		const int g = lane >> 4;
 		const int j = lane & 15;
-		const f32x4* wp = reinterpret_cast<const f32x4*>(wpack);
 
-		// model tables -> LDS, and the first stage's weights
 		{
 			const f32x4* qsrc = reinterpret_cast<const f32x4*>(qdesc);
 			f32x4* qdst = reinterpret_cast<f32x4*>(sQ);
-			for (int i = tid; i < nqdesc; i += NTHREADS) qdst[i] = qsrc[i];
-			const WnStage first = LoadStage(stages, 0);
-			const int off0 = first.wblk_off, cnt0 = first.wblk_f4;
-			for (int i = tid; i < cnt0; i += NTHREADS) wbuf[i] = wp[off0 + i];
+			for (int i = threadIdx.x; i < nqdesc; i += 64 * WPS) qdst[i] = qsrc[i];
 		}
 
-		const int streamIdx = blockIdx.x * SPW + sidx;
-		const bool active = streamIdx < numStreams; // the last workgroup may carry idle streams: same control flow, no memory effects
-		const int slot = active ? slots[streamIdx] : 0;
-		const int row = active ? rows[streamIdx] : 0;
+		const int slot = slots[blockIdx.x];
+		const int row = rows[blockIdx.x];
 		f32x4* st = state + (size_t)slot * (size_t)stateF4;
 		int* header = reinterpret_cast<int*>(st);
-		const int myPos = active ? header[lane] : 0; // lane r holds the write cursor of ring r
-		const __amdgpu_buffer_rsrc_t srsrc = MakeRsrc(st, active ? (unsigned)stateF4 * 16u : 0u);
+		const int myPos = header[lane]; // lane r holds the write cursor of ring r
+		const __amdgpu_buffer_rsrc_t wrsrc = MakeRsrc(wpack, (unsigned)wpackF4 * 16u);
+		const __amdgpu_buffer_rsrc_t srsrc = MakeRsrc(st, (unsigned)stateF4 * 16u);
 		const float* inRow = in + (size_t)row * inStride;
 		float* outRow = out + (size_t)row * outStride;
-		f32x4* xbuf = xbufAll + sidx * (2 * NTB * 64);
 
 		float cond[TPW];
 		f32x4 xcur[TPW];
@@ -425,74 +365,53 @@ namespace na
 		for (int t = 0; t < TPW; t++)
 		{
 			const int f = (tb + t) * 16 + j;
-			cond[t] = (active && f < n) ? inRow[f] : 0.0f; // WaveNet.h:770 (input -> condition)
+			cond[t] = (f < n) ? inRow[f] : 0.0f; // WaveNet.h:770 (input -> condition)
 			xcur[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 			head[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
 		}
 
-		__syncthreads();
+		BlockBarrier<WPS>();
 
 		int cur = 0;
 		WnStage sd = LoadStage(stages, 0);
-		f32x4 hpre[WN_HPF][TPW];
+		f32x4 apf[WN_APF];
 #pragma unroll
-		for (int r = 0; r < WN_HPF; r++)
-#pragma unroll
-			for (int t = 0; t < TPW; t++) hpre[r][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+		for (int r = 0; r < WN_APF; r++) apf[r] = BufLoad(wrsrc, lane * 16, (sd.wconv_off + r * 64) * 16);
 
 		for (int s = 0; s < nstages; s++)
 		{
-			const f32x4* wl = wbuf + (s & 1) * maxStageF4;      // this stage's weights (LDS)
-			f32x4* wlNext = wbuf + ((s + 1) & 1) * maxStageF4;
-
-			// ---- issue the loads of the NEXT stage: its weight block (-> registers -> LDS at the end of this stage)
-			//      and the history taps of its first conv rounds (-> registers)
-			WnStage sdn = sd;
-			sdn.nrounds = 0;
-			sdn.wblk_f4 = 0;
-			if (s + 1 < nstages) sdn = LoadStage(stages, s + 1);
-			f32x4 wcopy[WN_WCOPY];
-#pragma unroll
-			for (int c = 0; c < WN_WCOPY; c++)
-			{
-				const int i = tid + c * NTHREADS;
-				wcopy[c] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-				if (!(NA_ABL & 32) && c * NTHREADS < sdn.wblk_f4 && i < sdn.wblk_f4) wcopy[c] = wp[sdn.wblk_off + i];
-			}
-			f32x4 hnext[WN_HPF][TPW];
-			{
-				const int nextPos0 = (sdn.ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sdn.ring_id) : 0;
-#pragma unroll
-				for (int r = 0; r < WN_HPF; r++)
-				{
-#pragma unroll
-					for (int t = 0; t < TPW; t++) hnext[r][t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-					const bool generic = (sdn.type != WN_ST_LAYER) || (sdn.G == 3);
-					if (generic && r < sdn.hist_rounds) HistFetch<TPW>(hnext[r], sdn, sQ, r, srsrc, nextPos0, tb, g, j);
-				}
-			}
-
 			NA_TRACE(0);
+			WnStage sdn = sd;
+			if (s + 1 < nstages) sdn = LoadStage(stages, s + 1);
+
 			const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
 			const int inPos0 = (sd.ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.ring_id) : 0;
 			f32x4* xbCur = xbuf + cur * (NTB * 64);
 			f32x4* xbNext = xbuf + (cur ^ 1) * (NTB * 64);
-			const f32x4* vec = wl; // [0..3] conv/dense bias, [4..7] mix-in w, [8..11] 1x1 bias, [12..15] aux  (block starts with vec)
+			const int vecOff = (sd.vec_off + g) * 16; // [0..3] conv/dense bias, [4..7] mix-in w, [8..11] 1x1 bias, [12..15] aux
 
 			if (sd.type == WN_ST_LAYER)
 			{
+				// this stage's small operands: needed only after the conv, their L2 latency hides behind it
+				const f32x4 w1 = BufLoad(wrsrc, lane * 16, sd.w1_off * 16);
+				const f32x4 bias4 = BufLoad(wrsrc, vecOff, 0);
+				const f32x4 wm4 = BufLoad(wrsrc, vecOff, 4 * 16);
+				const f32x4 b14 = BufLoad(wrsrc, vecOff, 8 * 16);
+
 				f32x4 acc[TPW];
 #pragma unroll
 				for (int t = 0; t < TPW; t++) acc[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 				// WaveNet.h:468
-				if (sd.G == 4) ConvFast<4, TPW>(acc, sd, wl, xbCur, srsrc, inPos0, tb, lane, g, j);
-				else if (sd.G == 2) ConvFast<2, TPW>(acc, sd, wl, xbCur, srsrc, inPos0, tb, lane, g, j);
-				else if (sd.G == 1) ConvFast<1, TPW>(acc, sd, wl, xbCur, srsrc, inPos0, tb, lane, g, j);
-				else ConvRounds<TPW>(acc, hpre, sd, sQ, wl, xbCur, srsrc, inPos0, tb, lane, g, j);
-
+				if (sd.G == 4) ConvFast<4, TPW>(acc, apf, sd, wrsrc, xbCur, srsrc, inPos0, tb, lane, g, j);
+				else if (sd.G == 2) ConvFast<2, TPW>(acc, apf, sd, wrsrc, xbCur, srsrc, inPos0, tb, lane, g, j);
+				else if (sd.G == 1) ConvFast<1, TPW>(acc, apf, sd, wrsrc, xbCur, srsrc, inPos0, tb, lane, g, j);
+				else ConvRounds<TPW>(acc, apf, sd, sQ, wrsrc, xbCur, srsrc, inPos0, tb, lane, g, j);
 				NA_TRACE(1);
-				const f32x4 bias4 = vec[g];
-				const f32x4 wm4 = vec[4 + g];
+
+				// next stage's weight fragments: issued BEFORE this stage's ring stores (see kernel comment)
+#pragma unroll
+				for (int r = 0; r < WN_APF; r++) apf[r] = BufLoad(wrsrc, lane * 16, (sdn.wconv_off + r * 64) * 16);
+
 				const bool leaky = (sd.flags & WN_FLAG_LEAKY) != 0;
 				f32x4 z[TPW];
 #pragma unroll
@@ -505,11 +424,9 @@ namespace na
 				if (sd.flags & WN_FLAG_NEED_OUTPUT)
 				{
 					// 1x1 + bias + residual (:486-491); z in D layout is already a B fragment
-					const f32x4 w1 = wl[(sd.w1_off - sd.wblk_off) + lane];
-					const f32x4 b14 = vec[8 + g];
 #pragma unroll
 					for (int t = 0; t < TPW; t++) xcur[t] += b14;
-					DenseTiles<TPW>(xcur, w1, z);
+					MfmaRound<TPW>(xcur, w1, z);
 				}
 				if (sd.flags & WN_FLAG_PUBLISH)
 				{
@@ -517,96 +434,90 @@ namespace na
 					cur ^= 1;
 				}
 			}
-			else if (sd.type == WN_ST_RECHANNEL_COND)
+			else
 			{
-				const f32x4 wre4 = vec[12 + g];
 #pragma unroll
-				for (int t = 0; t < TPW; t++) xcur[t] = wre4 * cond[t]; // :637 with InputSize == 1
-				Publish<TPW>(xcur, xbNext, srsrc, sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
-				cur ^= 1;
-			}
-			else if (sd.type == WN_ST_ARRAY_LINK)
-			{
-				// previous array's headRechannel (K=1, :658-660) and this array's rechannel (:637)
-				const f32x4 w1 = wl[(sd.w1_off - sd.wblk_off) + lane];
-				const f32x4 w2 = wl[(sd.w2_off - sd.wblk_off) + lane];
-				f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
-				if (sd.flags & WN_FLAG_BIAS) hb = vec[g];
-				f32x4 hnew[TPW], xnew[TPW];
-#pragma unroll
-				for (int t = 0; t < TPW; t++)
+				for (int r = 0; r < WN_APF; r++) apf[r] = BufLoad(wrsrc, lane * 16, (sdn.wconv_off + r * 64) * 16);
+				if (sd.type == WN_ST_RECHANNEL_COND)
 				{
-					hnew[t] = hb;
-					xnew[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-				}
-				DenseTiles<TPW>(hnew, w1, head);
-				DenseTiles<TPW>(xnew, w2, xcur);
+					const f32x4 wre4 = BufLoad(wrsrc, vecOff, 12 * 16);
 #pragma unroll
-				for (int t = 0; t < TPW; t++)
+					for (int t = 0; t < TPW; t++) xcur[t] = wre4 * cond[t]; // :637 with InputSize == 1
+					Publish<TPW>(xcur, xbNext, srsrc, sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
+					cur ^= 1;
+				}
+				else if (sd.type == WN_ST_ARRAY_LINK)
 				{
-					head[t] = hnew[t];
-					xcur[t] = xnew[t];
+					// previous array's headRechannel (K=1, :658-660) and this array's rechannel (:637)
+					const f32x4 w1 = BufLoad(wrsrc, lane * 16, sd.w1_off * 16);
+					const f32x4 w2 = BufLoad(wrsrc, lane * 16, sd.w2_off * 16);
+					f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
+					if (sd.flags & WN_FLAG_BIAS) hb = BufLoad(wrsrc, vecOff, 0);
+					f32x4 hnew[TPW], xnew[TPW];
+#pragma unroll
+					for (int t = 0; t < TPW; t++)
+					{
+						hnew[t] = hb;
+						xnew[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+					}
+					MfmaRound<TPW>(hnew, w1, head);
+					MfmaRound<TPW>(xnew, w2, xcur);
+#pragma unroll
+					for (int t = 0; t < TPW; t++)
+					{
+						head[t] = hnew[t];
+						xcur[t] = xnew[t];
+					}
+					Publish<TPW>(xcur, xbNext, srsrc, sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
+					cur ^= 1;
 				}
-				Publish<TPW>(xcur, xbNext, srsrc, sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
-				cur ^= 1;
-			}
-			else if (sd.type == WN_ST_HEAD_DENSE_OUT)
-			{
-				const f32x4 w1 = wl[(sd.w1_off - sd.wblk_off) + lane];
-				f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
-				if (sd.flags & WN_FLAG_BIAS) hb = vec[g];
-				f32x4 o[TPW];
-#pragma unroll
-				for (int t = 0; t < TPW; t++) o[t] = hb;
-				DenseTiles<TPW>(o, w1, head);
-#pragma unroll
-				for (int t = 0; t < TPW; t++)
+				else if (sd.type == WN_ST_HEAD_DENSE_OUT)
 				{
-					const int f = (tb + t) * 16 + j;
-					if (active && g == 0 && f < n) outRow[f] = headScale * o[t].x; // :793-798
+					const f32x4 w1 = BufLoad(wrsrc, lane * 16, sd.w1_off * 16);
+					f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
+					if (sd.flags & WN_FLAG_BIAS) hb = BufLoad(wrsrc, vecOff, 0);
+					f32x4 o[TPW];
+#pragma unroll
+					for (int t = 0; t < TPW; t++) o[t] = hb;
+					MfmaRound<TPW>(o, w1, head);
+#pragma unroll
+					for (int t = 0; t < TPW; t++)
+					{
+						const int f = (tb + t) * 16 + j;
+						if (g == 0 && f < n) outRow[f] = headScale * o[t].x; // :793-798
+					}
 				}
-			}
-			else // WN_ST_HEAD_CONV_OUT
-			{
-				// A2 head: Conv1D(C -> 1, K = 16) over the accumulated head signal (:658-660)
-				Publish<TPW>(head, xbNext, srsrc, sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
-				cur ^= 1;
-				BlockBarrier<WPS * SPW>();
-				f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
-				if (sd.flags & WN_FLAG_BIAS) hb = vec[g];
-				f32x4 acc[TPW];
-#pragma unroll
-				for (int t = 0; t < TPW; t++) acc[t] = hb;
-				ConvRounds<TPW>(acc, hpre, sd, sQ, wl, xbNext, srsrc, inPos0, tb, lane, g, j);
-#pragma unroll
-				for (int t = 0; t < TPW; t++)
+				else // WN_ST_HEAD_CONV_OUT
 				{
-					const int f = (tb + t) * 16 + j;
-					if (active && g == 0 && f < n) outRow[f] = headScale * acc[t].x;
+					// A2 head: Conv1D(C -> 1, K = 16) over the accumulated head signal (:658-660)
+					f32x4 wh[WN_APF];
+#pragma unroll
+					for (int r = 0; r < WN_APF; r++) wh[r] = BufLoad(wrsrc, lane * 16, (sd.wconv_off + r * 64) * 16);
+					f32x4 hb = { 0.0f, 0.0f, 0.0f, 0.0f };
+					if (sd.flags & WN_FLAG_BIAS) hb = BufLoad(wrsrc, vecOff, 0);
+					Publish<TPW>(head, xbNext, srsrc, sd.out_ring_off, sd.out_G, outPos0, sd.out_ring_frames, n, tb, g, j);
+					cur ^= 1;
+					BlockBarrier<WPS>();
+					f32x4 acc[TPW];
+#pragma unroll
+					for (int t = 0; t < TPW; t++) acc[t] = hb;
+					ConvRounds<TPW>(acc, wh, sd, sQ, wrsrc, xbNext, srsrc, inPos0, tb, lane, g, j);
+#pragma unroll
+					for (int t = 0; t < TPW; t++)
+					{
+						const int f = (tb + t) * 16 + j;
+						if (g == 0 && f < n) outRow[f] = headScale * acc[t].x;
+					}
 				}
 			}
-
 			NA_TRACE(2);
-			// ---- stage the next stage's weights into the other LDS buffer, then meet
-#pragma unroll
-			for (int c = 0; c < WN_WCOPY; c++)
-			{
-				const int i = tid + c * NTHREADS;
-				if (c * NTHREADS < sdn.wblk_f4 && i < sdn.wblk_f4) wlNext[i] = wcopy[c];
-			}
-			for (int i = tid + WN_WCOPY * NTHREADS; i < sdn.wblk_f4; i += NTHREADS) wlNext[i] = wp[sdn.wblk_off + i]; // oversized blocks (rare)
-			BlockBarrier<WPS * SPW>();
+			BlockBarrier<WPS>();
 			NA_TRACE(3);
-
 			sd = sdn;
-#pragma unroll
-			for (int r = 0; r < WN_HPF; r++)
-#pragma unroll
-				for (int t = 0; t < TPW; t++) hpre[r][t] = hnext[r][t];
 		}
 
 		// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
-		if (active && (wave % WPS) == 0 && lane < nrings)
+		if (wave == 0 && lane < nrings)
 		{
 			const int R = ringFrames[lane];
 			int p = myPos + n;
@@ -721,23 +632,16 @@ namespace na
 	static long long* g_traceBuffer = nullptr;
 	void SetWaveNetTraceBuffer(long long* p) { g_traceBuffer = p; }
 
-	template <int TPW, int WPS, int SPW>
+	template <int TPW, int WPS>
 	static hipError_t LaunchBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
 		float* out, long inStride, long outStride, int n, hipStream_t stream)
 	{
-		const size_t lds = (size_t)SPW * 2 * TPW * WPS * 64 * 16 + (size_t)2 * m.max_stage_f4 * 16 + (size_t)m.nqdesc * sizeof(WnQuad);
-		if (lds > 160 * 1024) return hipErrorInvalidValue;
-		static bool attrSet = false;
-		if (!attrSet)
-		{
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&WaveNetBlockKernel<TPW, WPS, SPW>),
-				hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			attrSet = true;
-		}
-		const unsigned grid = (unsigned)((numStreams + SPW - 1) / SPW);
-		hipLaunchKernelGGL((WaveNetBlockKernel<TPW, WPS, SPW>), dim3(grid), dim3(64 * WPS * SPW), lds, stream, m.stages, m.wpack, m.qdesc,
-			m.ring_frames, m.nstages, m.nqdesc, m.wpack_f4, m.max_stage_f4, m.nrings, m.state_f4, m.head_scale,
-			reinterpret_cast<f32x4*>(state), slots, rows, numStreams, in, out, inStride, outStride, n, g_traceBuffer);
+		const size_t lds = (size_t)2 * TPW * WPS * 64 * 16 + (size_t)m.nqdesc * sizeof(WnQuad);
+		if (lds > 64 * 1024) return hipErrorInvalidValue;
+		hipLaunchKernelGGL((WaveNetBlockKernel<TPW, WPS>), dim3((unsigned)numStreams), dim3(64 * WPS), lds, stream, m.stages, m.wpack, m.qdesc,
+			m.ring_frames, m.nstages, m.nqdesc, m.wpack_f4, m.nrings, m.state_f4, m.head_scale, reinterpret_cast<f32x4*>(state), slots, rows,
+			in, out, inStride, outStride, n, g_traceBuffer,
+			[]() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
 		return hipGetLastError();
 	}
 
@@ -746,21 +650,11 @@ namespace na
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > WN_MAX_FRAMES) return hipErrorInvalidValue;
-		// tile grid that covers n frames: (tiles per wave) x (waves per stream); streams per workgroup by batch size
-		if (n > 64)
-		{
-			static const int cfg = []() { const char* e = getenv("NA_WN_CFG"); return e ? atoi(e) : 244; }(); // tuning knob: TPW WPS SPW
-			if (cfg == 811) return LaunchBlock<8, 1, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			if (cfg == 421) return LaunchBlock<4, 2, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			if (cfg == 422 && numStreams >= 4) return LaunchBlock<4, 2, 2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			if (cfg == 424 && numStreams >= 8) return LaunchBlock<4, 2, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			if (numStreams >= 8 && cfg == 244) return LaunchBlock<2, 4, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			if (numStreams >= 4 && cfg == 242) return LaunchBlock<2, 4, 2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			return LaunchBlock<2, 4, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-		}
-		if (n > 32) return LaunchBlock<1, 4, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-		if (n > 16) return LaunchBlock<1, 2, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-		return LaunchBlock<1, 1, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		// smallest tile grid that covers n frames: (tiles per wave) x (waves per stream)
+		if (n > 64) return LaunchBlock<2, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		if (n > 32) return LaunchBlock<1, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		if (n > 16) return LaunchBlock<1, 2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		return LaunchBlock<1, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 	}
 
 	hipError_t LaunchWaveNetPrewarmColumns(const WnPrewarmLayer* layers, int numLayers, const float* weights, float* cols,
