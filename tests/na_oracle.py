@@ -367,3 +367,24 @@ def synth_lstm_weights(num_layers, hidden, seed):
 def rms(a):
     a = np.asarray(a, dtype=np.float64)
     return float(np.sqrt(np.mean(a * a)))
+
+
+# ----------------------------------------------------------------------------- synthetic .nam documents
+
+def nam_json_wavenet_a1(channels, head_size, weights, lite=None):
+    """A .nam document for an official A1 architecture with the given flat weights (loader input)."""
+    arrays = a1_arrays(channels, head_size, lite)
+    layers = []
+    for a in arrays:
+        layers.append({"input_size": a["input_size"], "condition_size": 1, "head_size": a["head_size"], "channels": a["channels"],
+                       "kernel_size": 3, "dilations": list(a["dilations"]), "activation": "Tanh", "gated": False,
+                       "head_bias": bool(a["has_head_bias"])})
+    return json.dumps({"version": "0.5.4", "architecture": "WaveNet", "metadata": {"loudness": -10.0},
+                       "config": {"layers": layers, "head": None, "head_scale": 0.02},
+                       "weights": [float(w) for w in weights], "sample_rate": 48000})
+
+
+def nam_json_lstm(num_layers, hidden, weights):
+    return json.dumps({"version": "0.5.4", "architecture": "LSTM", "metadata": {"loudness": -12.0},
+                       "config": {"input_size": 1, "hidden_size": hidden, "num_layers": num_layers},
+                       "weights": [float(w) for w in weights]})
