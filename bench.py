@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="standard",
+                    help="standard (default = the BASELINE metric's config) | feather | nano | a2full | a2lite | lstm1x16 | lstm2x8 | mixed3 "
+                         "(other BASELINE configs, for DESIGN.md numbers; the driver uses the default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -114,14 +117,20 @@ def main():
     S = args.streams
     loader = na.NeuralModelLoader()
     loader.SetDevice(local_rank)
-    model = loader.CreateFromFile(MODEL_FILE, doPrewarm=False)
-    if model is None:
-        raise SystemExit("could not load " + MODEL_FILE)
+    mdir = os.path.dirname(MODEL_FILE)
+    files = {"standard": ["BossWN-standard.nam"], "feather": ["BossWN-feather.nam"], "nano": ["BossWN-nano.nam"],
+             "a2full": ["BossWN-a2.nam"], "a2lite": ["BossWN-a2.nam"], "lstm1x16": ["BossLSTM-1x16.nam"], "lstm2x8": ["BossLSTM-2x8.nam"],
+             "mixed3": ["BossWN-standard.nam", "BossWN-feather.nam", "BossWN-nano.nam"]}[args.workload]
+    quality = 0.0 if args.workload == "a2lite" else 1.0
+    models = [loader.CreateFromFile(os.path.join(mdir, f), doPrewarm=False) for f in files]
+    if any(m is None for m in models):
+        raise SystemExit("could not load " + str(files))
     # run on torch's current stream so torch.cuda.Event brackets exactly the kernels we launch
     tstream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream handle
     torch.cuda.set_stream(tstream)
     batch = na.Batch(local_rank, hip_stream=tstream.cuda_stream)
-    batch.AddStreams(model, S)
+    for k, mdl in enumerate(models):
+        batch.AddStreams(mdl, S // len(models) + (1 if k < S % len(models) else 0), quality=quality)
 
     # synthetic 48 kHz buffers (bench-C of SURVEY 8d): clip(0.25*N(0,1), +-1), per-rank seed; a ring of 8 distinct buffers
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -166,7 +175,7 @@ def main():
         achieved_tflops = flops_per_sample * samples_per_step / (kernel_ms_avg * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "standard" and S == STREAMS_PER_GPU:
             try:
                 with open(tpath) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
@@ -186,8 +195,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "NAM A1 WaveNet 'Standard' (BossWN-standard.nam weights), %d batched streams per GPU, "
-                            "128-sample buffers, 48 kHz, inputs resident in HBM" % S,
+                "workload": ("NAM A1 WaveNet 'Standard' (BossWN-standard.nam weights), %d batched streams per GPU, "
+                             "128-sample buffers, 48 kHz, inputs resident in HBM" % S) if args.workload == "standard" else
+                            ("%s (%s, quality %.1f), %d batched streams per GPU, 128-sample buffers" % (args.workload, "+".join(files), quality, S)),
                 "streams_per_gpu": S,
                 "block": BLOCK,
                 "parallelism": "independent streams sharded across %d GPU(s), no data-path collective" % world,
@@ -206,7 +216,7 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_sample": bytes_per_sample,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "kernel": "WaveNetBlockKernel",
+                "kernel": "LstmBlockKernel" if args.workload.startswith("lstm") else "WaveNetBlockKernel",
             },
             "roofline_mfma_f32": {
                 "achieved": achieved_tflops,
@@ -216,7 +226,7 @@ def main():
                 "algorithmic_flops_per_sample": flops_per_sample,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "standard":
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline is reported, never required for the GPU number

@@ -287,11 +287,7 @@ int NA_BatchAddStreams(NA_Batch* batch, NeuralModel* model, float quality, int c
 		if (!batch || !model || count < 1) throw std::runtime_error("NA_BatchAddStreams: bad argument");
 		NeuralAudio::GpuModel* gm = dynamic_cast<NeuralAudio::GpuModel*>(model->model);
 		if (!gm) throw std::runtime_error("NA_BatchAddStreams: model was not created by this library");
-		for (int i = 0; i < count; i++)
-		{
-			const int id = batch->batch->AddStream(gm->GetLoadedModel(), quality, doPrewarm != 0);
-			if (i == 0) first = id;
-		}
+		first = batch->batch->AddStreams(gm->GetLoadedModel(), quality, count, doPrewarm != 0);
 	});
 	return rc == 0 ? first : -1;
 }

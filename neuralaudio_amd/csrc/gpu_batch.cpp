@@ -197,8 +197,15 @@ namespace na
 			// ChannelHistoryBuffer::AllocBuffer zero-fills (WaveNet.h:38-40)
 			void Reset(const std::vector<int>& members) override
 			{
-				for (int m : members)
-					CheckHip(hipMemsetAsync(state.Get() + (size_t)m * (size_t)plan.stateF4 * 4, 0, (size_t)plan.stateF4 * 16, stream), "hipMemsetAsync");
+				// one memset per run of consecutive slots (a batch add is a single run)
+				for (size_t i = 0; i < members.size();)
+				{
+					size_t k = i + 1;
+					while (k < members.size() && members[k] == members[k - 1] + 1) k++;
+					CheckHip(hipMemsetAsync(state.Get() + (size_t)members[i] * (size_t)plan.stateF4 * 4, 0, (k - i) * (size_t)plan.stateF4 * 16, stream),
+						"hipMemsetAsync");
+					i = k;
+				}
 			}
 
 			void Prewarm(const std::vector<int>& members) override
@@ -427,24 +434,43 @@ namespace na
 
 	int GpuBatch::AddStream(const std::shared_ptr<const LoadedModel>& model, float quality, bool prewarm)
 	{
+		return AddStreams(model, quality, 1, prewarm);
+	}
+
+	int GpuBatch::AddStreams(const std::shared_ptr<const LoadedModel>& model, float quality, int count, bool prewarm)
+	{
 		if (!model || model->subModels.empty()) throw std::runtime_error("neuralaudio_amd: AddStream with an empty model");
+		if (count < 1) throw std::runtime_error("neuralaudio_amd: AddStreams with count < 1");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
-		StreamRef ref;
-		ref.model = model;
-		ref.quality = quality;
-		const int row = (int)streams.size();
-		for (const auto& sm : model->subModels)
+		const int first = (int)streams.size();
+		const int active = model->isComposite ? model->ModelIndexFromQuality(quality) : 0;
+		const size_t numSub = model->subModels.size();
+		std::vector<ModelGroup*> subGroups(numSub);
+		std::vector<std::vector<int>> newMembers(numSub);
+		for (size_t k = 0; k < numSub; k++) subGroups[k] = GroupFor(model->subModels[k].desc);
+		for (int i = 0; i < count; i++)
 		{
-			ModelGroup* g = GroupFor(sm.desc);
-			const int member = g->AddMember();
-			g->Reset({ member });
-			ref.members.push_back({ g, member });
+			StreamRef ref;
+			ref.model = model;
+			ref.quality = quality;
+			ref.active = active;
+			const int row = first + i;
+			for (size_t k = 0; k < numSub; k++)
+			{
+				const int member = subGroups[k]->AddMember();
+				newMembers[k].push_back(member);
+				ref.members.push_back({ subGroups[k], member });
+			}
+			ref.members[(size_t)active].first->SetActive(ref.members[(size_t)active].second, row);
+			streams.push_back(ref);
 		}
-		ref.active = model->isComposite ? model->ModelIndexFromQuality(quality) : 0;
-		ref.members[(size_t)ref.active].first->SetActive(ref.members[(size_t)ref.active].second, row);
-		streams.push_back(ref);
-		if (prewarm) Prewarm(row);
-		return row;
+		// fresh state for every new member, then (LoadAll semantics, CompositeModel.h:111-118) prewarm every submodel
+		for (size_t k = 0; k < numSub; k++)
+		{
+			subGroups[k]->Reset(newMembers[k]);
+			if (prewarm) subGroups[k]->Prewarm(newMembers[k]);
+		}
+		return first;
 	}
 
 	void GpuBatch::SetQuality(int s, float quality)

@@ -46,6 +46,8 @@ namespace na
 		// Adds a stream running `model`; its row in the [streams][n] input/output arrays is the returned id.
 		// For a SlimmableContainer every submodel gets state, `quality` picks the active one.
 		int AddStream(const std::shared_ptr<const LoadedModel>& model, float quality, bool prewarm);
+		// `count` streams of the same model at once (one state reset / prewarm launch per model group); returns the first id
+		int AddStreams(const std::shared_ptr<const LoadedModel>& model, float quality, int count, bool prewarm);
 
 		int NumStreams() const { return (int)streams.size(); }
 
