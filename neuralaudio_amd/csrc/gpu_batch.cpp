@@ -88,7 +88,24 @@ namespace na
 	{
 	public:
 		ModelGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s) : desc(d), stream(s) {}
-		virtual ~ModelGroup() = default;
+		virtual ~ModelGroup()
+		{
+			if (sideStream) (void)hipStreamDestroy(sideStream);
+			if (doneEvent) (void)hipEventDestroy(doneEvent);
+		}
+
+		// created on first use: lets independent model groups of a mixed batch run concurrently
+		hipStream_t SideStream()
+		{
+			if (!sideStream) CheckHip(hipStreamCreateWithFlags(&sideStream, hipStreamNonBlocking), "hipStreamCreate");
+			return sideStream;
+		}
+
+		hipEvent_t DoneEvent()
+		{
+			if (!doneEvent) CheckHip(hipEventCreateWithFlags(&doneEvent, hipEventDisableTiming), "hipEventCreate");
+			return doneEvent;
+		}
 
 		const std::shared_ptr<const ModelDesc> desc;
 
@@ -112,7 +129,8 @@ namespace na
 		// fresh (never prewarmed) state: zero history / the model's initial h,c
 		virtual void Reset(const std::vector<int>& members) = 0;
 		virtual void Prewarm(const std::vector<int>& members) = 0;
-		virtual void Process(const float* dIn, float* dOut, long inStride, long outStride, size_t n) = 0;
+		// launches on `launchStream` (the batch's main stream, or this group's side stream when several groups run concurrently)
+		virtual void Process(const float* dIn, float* dOut, long inStride, long outStride, size_t n, hipStream_t launchStream) = 0;
 		virtual double AlgorithmicBytesPerSample(int blockFrames) const = 0;
 		virtual double MacsPerSample() const = 0;
 		virtual size_t StateBytesPerStream() const = 0;
@@ -124,9 +142,7 @@ namespace na
 			return c;
 		}
 
-	protected:
-		virtual void EnsureCapacity(int members) = 0;
-
+		// upload the active-stream lists if they changed (host -> device copy + sync: never inside a graph capture)
 		void SyncActiveLists()
 		{
 			if (!activeDirty) return;
@@ -145,7 +161,12 @@ namespace na
 			activeDirty = false;
 		}
 
+	protected:
+		virtual void EnsureCapacity(int members) = 0;
+
 		hipStream_t stream;
+		hipStream_t sideStream = nullptr;
+		hipEvent_t doneEvent = nullptr;
 		std::vector<int> memberRow; // member == state slot
 		std::vector<int> hSlots, hRows;
 		DevArray<int> dSlots, dRows;
@@ -218,7 +239,7 @@ namespace na
 				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize"); // `list` is freed on return
 			}
 
-			void Process(const float* dIn, float* dOut, long inStride, long outStride, size_t n) override
+			void Process(const float* dIn, float* dOut, long inStride, long outStride, size_t n, hipStream_t launchStream) override
 			{
 				SyncActiveLists();
 				const int numActive = (int)hSlots.size();
@@ -230,7 +251,7 @@ namespace na
 				{
 					const int chunk = (int)std::min<size_t>(n, (size_t)WN_MAX_FRAMES);
 					CheckHip(LaunchWaveNetBlock(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
-						outStride, chunk, stream), "WaveNetBlockKernel");
+						outStride, chunk, launchStream), "WaveNetBlockKernel");
 					offset += (size_t)chunk;
 					n -= (size_t)chunk;
 				}
@@ -330,7 +351,7 @@ namespace na
 				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 			}
 
-			void Process(const float* dIn, float* dOut, long inStride, long outStride, size_t n) override
+			void Process(const float* dIn, float* dOut, long inStride, long outStride, size_t n, hipStream_t launchStream) override
 			{
 				SyncActiveLists();
 				const int numActive = (int)hSlots.size();
@@ -340,7 +361,7 @@ namespace na
 				{
 					const int chunk = (int)std::min<size_t>(n, (size_t)LSTM_MAX_FRAMES);
 					CheckHip(LaunchLstmBlock(dev, state.Get(), (int)capacity, dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset,
-						inStride, outStride, chunk, stream), "LstmBlockKernel");
+						inStride, outStride, chunk, launchStream), "LstmBlockKernel");
 					offset += (size_t)chunk;
 					n -= (size_t)chunk;
 				}
@@ -416,6 +437,8 @@ namespace na
 		groups.clear();
 		if (hostStage) (void)hipHostFree(hostStage);
 		if (devStage) (void)hipFree(devStage);
+		for (auto& e : graphCache) (void)hipGraphExecDestroy(e.exec);
+		if (forkEvent) (void)hipEventDestroy(forkEvent);
 		if (stream && ownsStream) (void)hipStreamDestroy(stream);
 	}
 
@@ -442,6 +465,7 @@ namespace na
 		if (!model || model->subModels.empty()) throw std::runtime_error("neuralaudio_amd: AddStream with an empty model");
 		if (count < 1) throw std::runtime_error("neuralaudio_amd: AddStreams with count < 1");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
+		topologyVersion++;
 		const int first = (int)streams.size();
 		const int active = model->isComposite ? model->ModelIndexFromQuality(quality) : 0;
 		const size_t numSub = model->subModels.size();
@@ -483,6 +507,7 @@ namespace na
 		ref.members[(size_t)ref.active].first->SetActive(ref.members[(size_t)ref.active].second, -1);
 		ref.active = idx;
 		ref.members[(size_t)idx].first->SetActive(ref.members[(size_t)idx].second, s);
+		topologyVersion++;
 	}
 
 	float GpuBatch::GetQuality(int s) const { return streams.at((size_t)s).quality; }
@@ -500,7 +525,62 @@ namespace na
 	{
 		if (n == 0 || streams.empty()) return;
 		CheckHip(hipSetDevice(device), "hipSetDevice");
-		for (auto& g : groups) g->Process(dIn, dOut, inStride, outStride, n);
+		int activeGroups = 0;
+		for (auto& g : groups) activeGroups += (g->NumActive() > 0);
+		if (activeGroups <= 1)
+		{
+			for (auto& g : groups) g->Process(dIn, dOut, inStride, outStride, n, stream);
+			return;
+		}
+		// mixed batch: the model groups are independent (disjoint rows, disjoint state) -> fork onto per-group side streams
+		// so their kernels share the GPU, then join back into the batch stream.  The fork/join costs ~5 HIP calls per group,
+		// which would make a buffer host-bound, so the sequence is captured once into a hipGraph and replayed while the call
+		// signature (pointers, n, strides) and the active-stream lists stay the same -- the steady state of a real-time host.
+		for (auto& g : groups) g->SyncActiveLists();
+		if (!graphCache.empty() && graphCache.front().key.version != topologyVersion)
+		{
+			for (auto& e : graphCache) (void)hipGraphExecDestroy(e.exec);
+			graphCache.clear();
+		}
+		hipGraphExec_t graphExec = nullptr;
+		for (auto& e : graphCache)
+			if (e.key.dIn == dIn && e.key.dOut == dOut && e.key.n == n && e.key.inStride == inStride && e.key.outStride == outStride) graphExec = e.exec;
+		if (!graphExec)
+		{
+			if (graphCache.size() >= 16)
+			{
+				(void)hipGraphExecDestroy(graphCache.front().exec);
+				graphCache.erase(graphCache.begin());
+			}
+			hipGraph_t graph = nullptr;
+			CheckHip(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed), "hipStreamBeginCapture");
+			try
+			{
+				if (!forkEvent) CheckHip(hipEventCreateWithFlags(&forkEvent, hipEventDisableTiming), "hipEventCreate");
+				CheckHip(hipEventRecord(forkEvent, stream), "hipEventRecord");
+				for (auto& g : groups)
+				{
+					if (g->NumActive() == 0) continue;
+					hipStream_t side = g->SideStream();
+					CheckHip(hipStreamWaitEvent(side, forkEvent, 0), "hipStreamWaitEvent");
+					g->Process(dIn, dOut, inStride, outStride, n, side);
+					CheckHip(hipEventRecord(g->DoneEvent(), side), "hipEventRecord");
+					CheckHip(hipStreamWaitEvent(stream, g->DoneEvent(), 0), "hipStreamWaitEvent");
+				}
+			}
+			catch (...)
+			{
+				(void)hipStreamEndCapture(stream, &graph);
+				if (graph) (void)hipGraphDestroy(graph);
+				throw;
+			}
+			CheckHip(hipStreamEndCapture(stream, &graph), "hipStreamEndCapture");
+			const hipError_t e = hipGraphInstantiate(&graphExec, graph, nullptr, nullptr, 0);
+			(void)hipGraphDestroy(graph);
+			CheckHip(e, "hipGraphInstantiate");
+			graphCache.push_back({ { dIn, dOut, n, inStride, outStride, topologyVersion }, graphExec });
+		}
+		CheckHip(hipGraphLaunch(graphExec, stream), "hipGraphLaunch");
 	}
 
 	void GpuBatch::EnsureStaging(size_t floats)

@@ -91,6 +91,24 @@ namespace na
 		int device;
 		hipStream_t stream = nullptr;
 		bool ownsStream = true;
+		hipEvent_t forkEvent = nullptr;
+
+		// cached hipGraph of the multi-group fork/launch/join sequence (see ProcessDevice)
+		struct GraphKey
+		{
+			const float* dIn;
+			float* dOut;
+			size_t n;
+			long inStride, outStride;
+			unsigned long version;
+		};
+		struct GraphEntry
+		{
+			GraphKey key;
+			hipGraphExec_t exec;
+		};
+		std::vector<GraphEntry> graphCache; // a handful of call signatures (hosts cycle through a few fixed buffers)
+		unsigned long topologyVersion = 0;
 		std::vector<std::unique_ptr<ModelGroup>> groups;
 		std::vector<StreamRef> streams;
 

@@ -5,6 +5,8 @@
 //   LSTMLayerT::Process   NeuralAudio/LSTM.h:87-100    (g = W[4H x (I+H)] [x;h] + b; i,f,g,o gates)
 //   LSTMLayer::Process    NeuralAudio/LSTMDynamic.h:95-108 (same arithmetic, runtime shaped)
 //   FastMath Tanh/Sigmoid NeuralAudio/Activation.h:83-96
+#include <cstdlib>
+
 #include <hip/hip_runtime.h>
 
 #include "lstm_dev.h"
@@ -133,6 +135,178 @@ namespace na
 		}
 	}
 
+	// ------------------------------------------------------------------------------------------------------------
+	// Fast path: ONE WAVE PER STREAM, the 4H gate rows of a layer spread over the 64 lanes (lane r owns rows r, r+64, ..),
+	// each lane keeps its rows of W (and bias) in VGPRs for the whole block, the state vector [x; h] is broadcast from
+	// LDS, gates are exchanged through LDS, lanes i < H own unit i (cell state in a register).  The dense head is
+	// taken off the serial path: h_last[t] is parked in LDS and all outputs are computed after the sample loop.
+	// Same arithmetic and summation order as LstmLayerStep (and the reference, LSTM.h:87-100).
+	// ------------------------------------------------------------------------------------------------------------
+	template <int H, int I>
+	struct LstmRows
+	{
+		static constexpr int RPL = (4 * H + 63) / 64; // rows per lane
+		float w[RPL][I + H];
+		float b[RPL];
+	};
+
+	template <int H, int I>
+	__device__ __forceinline__ void LoadRows(LstmRows<H, I>& rows, const float* __restrict__ w, int lane)
+	{
+		constexpr int W = I + H;
+#pragma unroll
+		for (int q = 0; q < LstmRows<H, I>::RPL; q++)
+		{
+			const int r = lane + 64 * q;
+			const bool valid = r < 4 * H;
+#pragma unroll
+			for (int k = 0; k < W; k++) rows.w[q][k] = valid ? w[(size_t)r * W + k] : 0.0f;
+			rows.b[q] = valid ? w[(size_t)4 * H * W + r] : 0.0f;
+		}
+	}
+
+	// gates of one layer for this sample: s = [x (I values from `xin`), h (H values from `hvec`)] broadcast from LDS
+	template <int H, int I>
+	__device__ __forceinline__ void GateRows(const LstmRows<H, I>& rows, const float* xin, const float* hvec, float* gates, int lane)
+	{
+		constexpr int W = I + H;
+		float sv[W];
+#pragma unroll
+		for (int k = 0; k < I; k++) sv[k] = xin[k];
+#pragma unroll
+		for (int k = 0; k < H; k++) sv[I + k] = hvec[k];
+#pragma unroll
+		for (int q = 0; q < LstmRows<H, I>::RPL; q++)
+		{
+			const int r = lane + 64 * q;
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < W; k++) acc += rows.w[q][k] * sv[k];
+			acc += rows.b[q];
+			// rows [2H, 3H) are the cell candidate (tanh), the others sigmoid = 0.5*(tanh(0.5 x) + 1)  (LSTM.h:33-36,94-99)
+			const bool isG = (r >= 2 * H) && (r < 3 * H);
+			const float t = LstmFastTanh(isG ? acc : acc * 0.5f);
+			if (r < 4 * H) gates[r] = isG ? t : 0.5f * (t + 1.0f);
+		}
+	}
+
+	__device__ __forceinline__ void LstmWaveSync()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+	}
+
+	// grid = active streams, block = 64 (one wave per stream).  L in {1, 2}.
+	template <int H, int L>
+	__global__ void __launch_bounds__(64) LstmWaveKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
+		const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
+	{
+		constexpr int HP = H + 1; // padded row of the parked hidden states
+		__shared__ float xin[LSTM_MAX_FRAMES];
+		__shared__ float hvec[L][H];
+		__shared__ float gates[4 * H];
+		__shared__ float hout[LSTM_MAX_FRAMES * HP];
+
+		const int lane = threadIdx.x;
+		const int slot = slots[blockIdx.x];
+		const int row = rows[blockIdx.x];
+		const float* inRow = in + (size_t)row * inStride;
+		float* outRow = out + (size_t)row * outStride;
+
+		LstmRows<H, 1> rows0;
+		LoadRows<H, 1>(rows0, m.w + m.layerOff[0], lane);
+		LstmRows<H, H> rows1;
+		if (L > 1) LoadRows<H, H>(rows1, m.w + m.layerOff[L > 1 ? 1 : 0], lane);
+
+		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
+		float c[L];
+#pragma unroll
+		for (int l = 0; l < L; l++)
+		{
+			c[l] = 0.0f;
+			if (lane < H)
+			{
+				hvec[l][lane] = state[(size_t)(l * 2 * H + lane) * capacity + slot];
+				c[l] = state[(size_t)(l * 2 * H + H + lane) * capacity + slot];
+			}
+		}
+		LstmWaveSync();
+
+		for (int f = 0; f < n; f++)
+		{
+			GateRows<H, 1>(rows0, xin + f, hvec[0], gates, lane); // LSTM.h:168
+			LstmWaveSync();
+			if (lane < H)
+			{
+				// LSTM.h:94-99
+				c[0] = (gates[H + lane] * c[0]) + (gates[lane] * gates[2 * H + lane]);
+				const float h = gates[3 * H + lane] * LstmFastTanh(c[0]);
+				hvec[0][lane] = h;
+				if (L == 1) hout[f * HP + lane] = h;
+			}
+			LstmWaveSync();
+			if (L > 1)
+			{
+				GateRows<H, H>(rows1, hvec[0], hvec[L > 1 ? 1 : 0], gates, lane); // LSTM.h:170-180
+				LstmWaveSync();
+				if (lane < H)
+				{
+					c[L - 1] = (gates[H + lane] * c[L - 1]) + (gates[lane] * gates[2 * H + lane]);
+					const float h = gates[3 * H + lane] * LstmFastTanh(c[L - 1]);
+					hvec[L > 1 ? 1 : 0][lane] = h;
+					hout[f * HP + lane] = h;
+				}
+				LstmWaveSync();
+			}
+		}
+
+		// dense head for the whole block, lane = sample (LSTM.h:182-189)
+		const float* headW = m.w + m.headOff;
+		for (int f = lane; f < n; f += 64)
+		{
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < H; k++) acc += headW[k] * hout[f * HP + k];
+			outRow[f] = acc + headW[H];
+		}
+#pragma unroll
+		for (int l = 0; l < L; l++)
+		{
+			if (lane < H)
+			{
+				state[(size_t)(l * 2 * H + lane) * capacity + slot] = hvec[l][lane];
+				state[(size_t)(l * 2 * H + H + lane) * capacity + slot] = c[l];
+			}
+		}
+	}
+
+	template <int H, int L>
+	static hipError_t LaunchWaveHL(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
+		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream)
+	{
+		hipLaunchKernelGGL((LstmWaveKernel<H, L>), dim3((unsigned)numStreams), dim3(64), 0, stream, m, state, capacity, slots, rows, in, out,
+			inStride, outStride, n);
+		return hipGetLastError();
+	}
+
+	// returns false when (H, layers) has no wave-per-stream instance (the lane-per-stream kernel is used instead)
+	static bool LaunchLstmWave(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
+		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err)
+	{
+#define NA_LSTM_WAVE(HH) \
+	if (m.hidden == HH && m.numLayers == 1) { err = LaunchWaveHL<HH, 1>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream); return true; } \
+	if (m.hidden == HH && m.numLayers == 2) { err = LaunchWaveHL<HH, 2>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream); return true; }
+		NA_LSTM_WAVE(8)
+		NA_LSTM_WAVE(12)
+		NA_LSTM_WAVE(16)
+		NA_LSTM_WAVE(20)
+		NA_LSTM_WAVE(24)
+		NA_LSTM_WAVE(32)
+#undef NA_LSTM_WAVE
+		return false;
+	}
+
 	// initial hidden / cell state of the listed slots (NAM: stored in the weights, LSTM.h:51-55; keras: zeros)
 	__global__ void LstmInitStateKernel(float* __restrict__ state, int capacity, const int* __restrict__ slots, int numStreams,
 		const float* __restrict__ init /* [numLayers*2H] */, int numElems)
@@ -174,6 +348,11 @@ namespace na
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > LSTM_MAX_FRAMES) return hipErrorInvalidValue;
+		{
+			static const bool forceLaneKernel = getenv("NA_LSTM_LANE_KERNEL") != nullptr; // tuning knob
+			hipError_t err = hipSuccess;
+			if (!forceLaneKernel && LaunchLstmWave(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
+		}
 #define NA_LSTM_CASE(HH) case HH: return LaunchH<HH>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream)
 		switch (m.hidden)
 		{
