@@ -325,7 +325,7 @@ namespace na
 	// otherwise wait for that store's acknowledgement.
 	// dynamic LDS: xbuf[2][NTB*64] float4 | quad table
 	template <int TPW, int WPS>
-	__global__ void __launch_bounds__(64 * WPS) __attribute__((amdgpu_waves_per_eu(4, 4))) WaveNetBlockKernel(
+	__global__ void __launch_bounds__(64 * WPS) __attribute__((amdgpu_waves_per_eu(WPS >= 8 ? 8 : (WPS >= 4 ? 4 : (WPS == 2 ? 2 : 1)), WPS >= 8 ? 8 : (WPS >= 4 ? 4 : (WPS == 2 ? 2 : 1))))) WaveNetBlockKernel(
 		const WnStage* __restrict__ stages, const float* __restrict__ wpack, const WnQuad* __restrict__ qdesc,
 		const int* __restrict__ ringFrames, int nstages, int nqdesc, int wpackF4, int nrings, int stateF4, float headScale,
 		f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows, const float* __restrict__ in,
@@ -651,7 +651,14 @@ namespace na
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > WN_MAX_FRAMES) return hipErrorInvalidValue;
 		// smallest tile grid that covers n frames: (tiles per wave) x (waves per stream)
-		if (n > 64) return LaunchBlock<2, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		if (n > 64)
+		{
+			static const int cfg = []() { const char* e = getenv("NA_WN_CFG"); return e ? atoi(e) : 24; }(); // tuning knob: TPW WPS
+			if (cfg == 18) return LaunchBlock<1, 8>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			if (cfg == 42) return LaunchBlock<4, 2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			if (cfg == 81) return LaunchBlock<8, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			return LaunchBlock<2, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		}
 		if (n > 32) return LaunchBlock<1, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 		if (n > 16) return LaunchBlock<1, 2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 		return LaunchBlock<1, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
