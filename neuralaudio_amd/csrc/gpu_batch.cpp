@@ -2,6 +2,7 @@
 #include "gpu_batch.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -183,6 +184,7 @@ namespace na
 				dStages.Upload(plan.stages, stream);
 				dWpack.Upload(plan.wpack, stream);
 				dQdesc.Upload(plan.qdesc, stream);
+				dWpk.Upload(plan.wpk, stream);
 				dPrewarm.Upload(plan.prewarm, stream);
 				dWeights.Upload(d->wavenet.weights, stream);
 
@@ -205,11 +207,14 @@ namespace na
 				dev.stages = dStages.Get();
 				dev.wpack = dWpack.Get();
 				dev.qdesc = dQdesc.Get();
+				dev.wpk = dWpk.Get();
 				dev.ring_frames = dRingFrames.Get();
 				dev.nstages = (int)plan.stages.size();
 				dev.nqdesc = (int)plan.qdesc.size();
 				dev.wpack_f4 = (int)(plan.wpack.size() / 4);
 				dev.max_stage_f4 = plan.maxStageF4;
+				dev.max_a4_floats = plan.maxA4Floats;
+				dev.wpk_floats = (int)plan.wpk.size();
 				dev.nrings = (int)plan.rings.size();
 				dev.state_f4 = plan.stateF4;
 				dev.head_scale = plan.headScale;
@@ -250,8 +255,16 @@ namespace na
 				while (n > 0)
 				{
 					const int chunk = (int)std::min<size_t>(n, (size_t)WN_MAX_FRAMES);
-					CheckHip(LaunchWaveNetBlock(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
-						outStride, chunk, launchStream), "WaveNetBlockKernel");
+					static const std::string which = getenv("NA_WN_KERNEL") ? getenv("NA_WN_KERNEL") : "tile"; // tuning knob: tile | frame | pk
+					if (which == "frame")
+						CheckHip(LaunchWaveNetFrame(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
+							outStride, chunk, launchStream), "WaveNetFrameKernel");
+					else if (which != "pk")
+						CheckHip(LaunchWaveNetBlock(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
+							outStride, chunk, launchStream), "WaveNetBlockKernel");
+					else
+						CheckHip(LaunchWaveNetPk(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
+							outStride, chunk, launchStream), "WaveNetPkKernel");
 					offset += (size_t)chunk;
 					n -= (size_t)chunk;
 				}
@@ -284,6 +297,7 @@ namespace na
 			DevArray<WnStage> dStages;
 			DevArray<float> dWpack;
 			DevArray<WnQuad> dQdesc;
+			DevArray<float> dWpk;
 			DevArray<WnPrewarmLayer> dPrewarm;
 			DevArray<float> dWeights;
 			DevArray<int> dRingOff, dRingFrames, dRingG;

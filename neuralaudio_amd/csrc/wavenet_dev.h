@@ -71,7 +71,13 @@ namespace na
 		int wblk_f4;         // (vec | conv rounds | w1 | w2), staged into LDS one stage ahead
 		int ksize;           // conv kernel size / dilation of this stage (0 for stages without a conv)
 		int dilation;
-		int pad;
+		// packed-FMA (lane = frame) kernel: float offsets into wpk, all blocks padded to C = 4*G (link stages: 16)
+		int pk_conv_off;     // conv [tap][in c][out o]  (head conv: [tap][in c])
+		int pk_w1_off;       // 1x1 / head dense [in c][out o]
+		int pk_w2_off;       // rechannel of WN_ST_ARRAY_LINK [in c][out o]
+		// frame kernel (lane = frame, v_mfma_f32_4x4x1_16b_f32): this stage's A-operand block in wpk, staged into LDS one stage ahead
+		int a4_off;          // float offset into wpk ([conv taps | 1x1] or [head dense | rechannel])
+		int a4_floats;       // 0: stage has no MFMA weights
 	};
 
 	struct WnQuad
@@ -106,11 +112,14 @@ namespace na
 		const WnStage* stages;
 		const float* wpack;   // float4-aligned packed weights
 		const WnQuad* qdesc;
+		const float* wpk;       // weights in the packed-FMA kernel's layout (scalar-load friendly)
 		const int* ring_frames; // [nrings]
 		int nstages;
 		int nqdesc;           // total WnQuad entries
 		int wpack_f4;         // size of wpack in float4 units
 		int max_stage_f4;     // largest per-stage weight block in float4 units
+		int max_a4_floats;    // largest per-stage A-operand block of the frame kernel
+		int wpk_floats;
 		int nrings;
 		int state_f4;         // per-stream state size in float4 units (header + rings)
 		float head_scale;

@@ -1,0 +1,530 @@
+// wavenet_frame_kernels.hip -- the "lane = frame" WaveNet block kernel for gfx950 (v_mfma_f32_4x4x1_16b_f32).
+//
+// Same path, same HBM/LDS data layout and same stage program as wavenet_kernels.hip (reference functions:
+// WaveNetModelT/LayerArrayT/LayerT::Process, Conv1DT::Process, DenseLayerT::Process -- NeuralAudio/WaveNet.h:768-799,
+// 632-661,462-494,139-290,336-383; FastMath -- NeuralAudio/Activation.h:83-118), different mapping of the arithmetic:
+//
+//   * lane = one audio frame, a wave = 64 consecutive frames, a workgroup = the 1-2 waves of one stream's block;
+//   * every lane holds ALL channels of its frame in registers; mat-muls are chains of v_mfma_f32_4x4x1_16b_f32:
+//     16 independent 4x4 outer products per instruction, block b = lanes 4b..4b+3 = frames 4b..4b+3.  B operand = one
+//     input channel of the lane's frame (a plain VGPR), A operand = W[4*og + (lane&3)][c] (the same 4 weights in every
+//     block), result = 4 output channels of the lane's own frame.  Operands and results are in the SAME lane = frame layout,
+//     so a layer runs conv -> activation -> 1x1 -> residual entirely in registers, with no padding: an 8-channel layer
+//     issues exactly half the MFMAs of a 16-channel one and the activation only touches real channels.
+//   * the A operands of a stage (4.3 KB for a 16-channel layer) are staged into LDS one stage ahead and read back as
+//     broadcast float4s.
+//
+// Why not the 16x16x4 tile mapping (wavenet_kernels.hip) everywhere: measured on MI355X (tools/microbench/mfma_valu_overlap.hip)
+// f32 MFMA runs at the f32 VALU rate and does NOT overlap with VALU work on the same SIMD, so every padded MFMA row and
+// every activation evaluated on a padding lane is pure loss; the tile mapping pads 8-channel layers to 16 rows.
+#include <cstdlib>
+
+#include <hip/hip_runtime.h>
+
+#include "wavenet_dev.h"
+#include "wavenet_launch.h"
+
+namespace na
+{
+	namespace fr
+	{
+		typedef float f32x2 __attribute__((ext_vector_type(2)));
+		typedef float f32x4 __attribute__((ext_vector_type(4)));
+		typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+		typedef const float __attribute__((address_space(4)))* CFloat; // wave-uniform read-only data -> scalar loads
+		typedef const int __attribute__((address_space(4)))* CInt;
+
+		constexpr int OOB = (int)0x80000000;
+		constexpr int STAGE_INTS = (int)(sizeof(WnStage) / sizeof(int));
+		constexpr int MAXC = 16;
+
+		__device__ __forceinline__ __amdgpu_buffer_rsrc_t MakeRsrc(const void* base, unsigned bytes)
+		{
+			return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+		}
+
+		__device__ __forceinline__ f32x4 BufLoad(__amdgpu_buffer_rsrc_t r, int voff)
+		{
+			return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+		}
+
+		__device__ __forceinline__ void BufStore(__amdgpu_buffer_rsrc_t r, f32x4 v, int voff)
+		{
+			__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+		}
+
+		__device__ __forceinline__ WnStage LoadStage(const WnStage* __restrict__ stages, int s)
+		{
+			WnStage sd;
+			CInt src = (CInt)(const int*)(stages + s);
+			int* dst = reinterpret_cast<int*>(&sd);
+#pragma unroll
+			for (int i = 0; i < STAGE_INTS; i++) dst[i] = src[i];
+			return sd;
+		}
+
+		__device__ __forceinline__ f32x2 Abs2(f32x2 v)
+		{
+			f32x2 r;
+			r.x = __builtin_fabsf(v.x);
+			r.y = __builtin_fabsf(v.y);
+			return r;
+		}
+
+		// Activation.h:83-91 on two channels: same association, packed math, division = num * v_rcp_f32(den)
+		__device__ __forceinline__ f32x2 FastTanh2(f32x2 x)
+		{
+			const f32x2 ax = Abs2(x);
+			const f32x2 x2 = x * x;
+			const f32x2 num = x * (2.45550750702956f + 2.45550750702956f * ax + (0.893229853513558f + 0.821226666969744f * ax) * x2);
+			const f32x2 den = 2.44506634652299f + (2.44506634652299f + x2) * Abs2(x + 0.814642734961073f * x * ax);
+			f32x2 r;
+			r.x = __builtin_amdgcn_rcpf(den.x);
+			r.y = __builtin_amdgcn_rcpf(den.y);
+			return num * r;
+		}
+
+		// Activation.h:110-118
+		__device__ __forceinline__ f32x2 LeakyReLU2(f32x2 v)
+		{
+			f32x2 r;
+			r.x = v.x > 0.0f ? v.x : 0.01f * v.x;
+			r.y = v.y > 0.0f ? v.y : 0.01f * v.y;
+			return r;
+		}
+
+		template <int WPS>
+		__device__ __forceinline__ void BlockBarrier()
+		{
+			if (WPS > 1)
+			{
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+				__builtin_amdgcn_s_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+			}
+			else
+			{
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+
+		// float4 index of (frame, channel group) in a tiled image with G groups: ((frame>>4)*G + cg)*16 + (frame&15)
+		__device__ __forceinline__ int TileIdx(int frame, int G, int cg) { return ((frame >> 4) * G + cg) * 16 + (frame & 15); }
+
+		// Channels [4*cg, 4*cg+4) of the frame `off` frames from the block start (off < 0: history) for this lane.
+		// lo/hi: range of `off` over the wave (scalar) -> whole wave in block / whole wave in history / mixed.
+		template <int G>
+		__device__ __forceinline__ void FetchFrame(float (&x)[4 * G], const f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int off, int lo, int hi,
+			int pos0, int R)
+		{
+			f32x4 v[G];
+			if (lo >= 0)
+			{
+				// whole wave inside the current block: LDS only
+				const int base = TileIdx(off, G, 0);
+#pragma unroll
+				for (int cg = 0; cg < G; cg++) v[cg] = xb[base + cg * 16];
+			}
+			else
+			{
+				int p = pos0 + off;
+				if (p < 0) p += R;
+				if (p >= R) p -= R;
+				const int vbase = (ringOff + TileIdx(p, G, 0)) * 16;
+				if (hi < 0)
+				{
+					// whole wave in the past: ring only
+#pragma unroll
+					for (int cg = 0; cg < G; cg++) v[cg] = BufLoad(srsrc, vbase + cg * 256);
+				}
+				else
+				{
+					// the wave straddles the block start: both, all loads issued before any is consumed
+					const int base = TileIdx(off < 0 ? 0 : off, G, 0);
+					const int hoff = (off < 0) ? vbase : OOB;
+					f32x4 l[G], h[G];
+#pragma unroll
+					for (int cg = 0; cg < G; cg++)
+					{
+						l[cg] = xb[base + cg * 16];
+						h[cg] = BufLoad(srsrc, hoff + cg * 256);
+					}
+#pragma unroll
+					for (int cg = 0; cg < G; cg++) v[cg] = (off < 0) ? h[cg] : l[cg];
+				}
+			}
+#pragma unroll
+			for (int cg = 0; cg < G; cg++)
+			{
+				x[4 * cg] = v[cg].x; x[4 * cg + 1] = v[cg].y; x[4 * cg + 2] = v[cg].z; x[4 * cg + 3] = v[cg].w;
+			}
+		}
+
+		// acc[og] += W[4og..4og+3][0..CIN) * x   for this lane's frame.  wl: LDS image [og][cq][row i][4 c] (see PackConvA4);
+		// a4 = &wl[... + (lane & 3)] so that lane reads its row; one float4 = the weights of 4 consecutive input channels.
+		template <int CIN, int COUT>
+		__device__ __forceinline__ void DenseMfma(f32x4 (&acc)[COUT / 4], const f32x4* a4, const float (&x)[CIN])
+		{
+			constexpr int NCQ = CIN / 4;
+#pragma unroll
+			for (int cq = 0; cq < NCQ; cq++)
+			{
+				f32x4 w[COUT / 4];
+#pragma unroll
+				for (int og = 0; og < COUT / 4; og++) w[og] = a4[(og * NCQ + cq) * 4];
+#pragma unroll
+				for (int og = 0; og < COUT / 4; og++) acc[og] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[og].x, x[4 * cq + 0], acc[og], 0, 0, 0);
+#pragma unroll
+				for (int og = 0; og < COUT / 4; og++) acc[og] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[og].y, x[4 * cq + 1], acc[og], 0, 0, 0);
+#pragma unroll
+				for (int og = 0; og < COUT / 4; og++) acc[og] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[og].z, x[4 * cq + 2], acc[og], 0, 0, 0);
+#pragma unroll
+				for (int og = 0; og < COUT / 4; og++) acc[og] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[og].w, x[4 * cq + 3], acc[og], 0, 0, 0);
+			}
+		}
+
+		// this lane's frame of a layer output -> LDS block image (in-block taps of the next layer) and the next layer's
+		// HBM ring (history for LATER blocks: only the last R-128 frames of a block can ever be read back)
+		template <int G>
+		__device__ __forceinline__ void PublishFrame(const float (&x)[MAXC], f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int pos0, int R,
+			int n, int f)
+		{
+			const int firstKept = n - (R - WN_MAX_FRAMES);
+			int p = pos0 + f;
+			if (p >= R) p -= R;
+			const bool keep = (f < n) && (f >= firstKept);
+#pragma unroll
+			for (int cg = 0; cg < G; cg++)
+			{
+				const f32x4 v = f32x4{ x[4 * cg], x[4 * cg + 1], x[4 * cg + 2], x[4 * cg + 3] };
+				xb[TileIdx(f, G, cg)] = v;
+				BufStore(srsrc, v, keep ? (ringOff + TileIdx(p, G, cg)) * 16 : OOB);
+			}
+		}
+
+		// WaveNetLayerT::Process (WaveNet.h:462-494) for one frame per lane
+		template <int G, int WPS>
+		__device__ __forceinline__ void LayerFr(const WnStage& sd, const f32x4* wl, CFloat vec, const f32x4* xbCur, f32x4* xbNext,
+			__amdgpu_buffer_rsrc_t srsrc, int inPos0, int outPos0, int n, int f, int wave, int lane, float cond, float (&xc)[MAXC], float (&hd)[MAXC])
+		{
+			constexpr int C = 4 * G;
+			const int K = sd.ksize;
+			const int d = sd.dilation;
+			const f32x4* a4 = wl + (lane & 3);
+
+			// acc = conv bias (:288-289) + W_mix * cond (:471)
+			f32x4 acc[G];
+#pragma unroll
+			for (int og = 0; og < G; og++)
+			{
+				const f32x4 b = f32x4{ vec[4 * og], vec[4 * og + 1], vec[4 * og + 2], vec[4 * og + 3] };
+				const f32x4 wm = f32x4{ vec[16 + 4 * og], vec[16 + 4 * og + 1], vec[16 + 4 * og + 2], vec[16 + 4 * og + 3] };
+				acc[og] = b + wm * cond;
+			}
+
+			// dilated conv (:139-290): tap k reads the frame d*(K-1-k) back; the last tap is the layer input itself (registers)
+			for (int k = 0; k < K - 1; k++)
+			{
+				const int shift = d * (K - 1 - k);
+				const int lo = wave * 64 - shift;
+				float x[C];
+				FetchFrame<G>(x, xbCur, srsrc, sd.ring_off, f - shift, lo, lo + 63, inPos0, sd.ring_frames);
+				DenseMfma<C, C>(acc, a4 + k * (C * C / 4), x);
+			}
+			{
+				float x[C];
+#pragma unroll
+				for (int c = 0; c < C; c++) x[c] = xc[c];
+				DenseMfma<C, C>(acc, a4 + (K - 1) * (C * C / 4), x);
+			}
+
+			// activation (:473-480), head accumulate (:482)
+			float z[C];
+			const bool leaky = (sd.flags & WN_FLAG_LEAKY) != 0;
+#pragma unroll
+			for (int og = 0; og < G; og++)
+			{
+				const f32x2 lo2 = leaky ? LeakyReLU2(f32x2{ acc[og].x, acc[og].y }) : FastTanh2(f32x2{ acc[og].x, acc[og].y });
+				const f32x2 hi2 = leaky ? LeakyReLU2(f32x2{ acc[og].z, acc[og].w }) : FastTanh2(f32x2{ acc[og].z, acc[og].w });
+				z[4 * og] = lo2.x; z[4 * og + 1] = lo2.y; z[4 * og + 2] = hi2.x; z[4 * og + 3] = hi2.y;
+				hd[4 * og] += lo2.x; hd[4 * og + 1] += lo2.y; hd[4 * og + 2] += hi2.x; hd[4 * og + 3] += hi2.y;
+			}
+
+			if (sd.flags & WN_FLAG_NEED_OUTPUT)
+			{
+				// 1x1 + bias + residual (:486-491)
+				f32x4 y[G];
+#pragma unroll
+				for (int og = 0; og < G; og++)
+					y[og] = f32x4{ vec[32 + 4 * og] + xc[4 * og], vec[32 + 4 * og + 1] + xc[4 * og + 1], vec[32 + 4 * og + 2] + xc[4 * og + 2],
+						vec[32 + 4 * og + 3] + xc[4 * og + 3] };
+				DenseMfma<C, C>(y, a4 + K * (C * C / 4), z);
+#pragma unroll
+				for (int og = 0; og < G; og++)
+				{
+					xc[4 * og] = y[og].x; xc[4 * og + 1] = y[og].y; xc[4 * og + 2] = y[og].z; xc[4 * og + 3] = y[og].w;
+				}
+			}
+			if (sd.flags & WN_FLAG_PUBLISH) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, n, f);
+		}
+
+		__device__ __forceinline__ void PublishAny(int G, const float (&x)[MAXC], f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int pos0, int R,
+			int n, int f)
+		{
+			if (G == 4) PublishFrame<4>(x, xb, srsrc, ringOff, pos0, R, n, f);
+			else if (G == 3) PublishFrame<3>(x, xb, srsrc, ringOff, pos0, R, n, f);
+			else if (G == 2) PublishFrame<2>(x, xb, srsrc, ringOff, pos0, R, n, f);
+			else PublishFrame<1>(x, xb, srsrc, ringOff, pos0, R, n, f);
+		}
+
+		// A2 head: out = scale * (bias + sum_k sum_c w[k][c] * head[t - (K-1-k)*dil][c])   (WaveNet.h:658-660, Conv1D C -> 1, K = 16)
+		template <int G>
+		__device__ __forceinline__ float HeadConvPk(const WnStage& sd, CFloat wpk, const f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int pos0, int f,
+			int wave, float bias)
+		{
+			constexpr int C = 4 * G;
+			float acc = bias;
+			CFloat w = wpk + sd.pk_conv_off;
+			for (int k = 0; k < sd.ksize; k++)
+			{
+				const int shift = sd.dilation * (sd.ksize - 1 - k);
+				const int lo = wave * 64 - shift;
+				float x[C];
+				FetchFrame<G>(x, xb, srsrc, sd.ring_off, f - shift, lo, lo + 63, pos0, sd.ring_frames);
+#pragma unroll
+				for (int c = 0; c < C; c++) acc = __builtin_fmaf(w[k * C + c], x[c], acc);
+			}
+			return acc;
+		}
+
+		// Stages the NEXT stage's A-operand block: global -> registers at the start of a stage (before the stage's ring stores:
+		// gfx950 has one vmcnt for loads and stores), registers -> the other LDS weight buffer at its end.
+		template <int WPS>
+		struct WeightStager
+		{
+			static constexpr int NTHREADS = 64 * WPS;
+			static constexpr int WCOPY = 3; // float4 per thread in flight (3 * 128 * 16 B = 6 KB >= any official stage; larger blocks use the tail loop)
+			f32x4 w[WCOPY];
+
+			__device__ __forceinline__ void Begin(__amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn)
+			{
+				const int nextF4 = sdn.a4_floats / 4;
+#pragma unroll
+				for (int c = 0; c < WCOPY; c++)
+				{
+					const int i = (int)threadIdx.x + c * NTHREADS;
+					w[c] = BufLoad(wrsrc, (c * NTHREADS < nextF4 && i < nextF4) ? (sdn.a4_off / 4 + i) * 16 : OOB);
+				}
+			}
+
+			__device__ __forceinline__ void End(f32x4* wlNext, __amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn)
+			{
+				const int nextF4 = sdn.a4_floats / 4;
+#pragma unroll
+				for (int c = 0; c < WCOPY; c++)
+				{
+					const int i = (int)threadIdx.x + c * NTHREADS;
+					if (c * NTHREADS < nextF4 && i < nextF4) wlNext[i] = w[c];
+				}
+				for (int i = (int)threadIdx.x + WCOPY * NTHREADS; i < nextF4; i += NTHREADS) wlNext[i] = BufLoad(wrsrc, (sdn.a4_off / 4 + i) * 16); // oversized (A2 K=15)
+			}
+		};
+
+		// tuning aid (see NA_DebugSetTraceBuffer): trace[((stage * 4 + point) * WPS) + wave] = shader clock, workgroup `traceBlock` only
+#define FR_TRACE(point) \
+	if (trace != nullptr && (int)blockIdx.x == traceBlock && lane == 0) trace[((s * 4 + (point)) * WPS) + wave] = (long long)__builtin_readcyclecounter()
+
+		// consecutive WaveNet layer stages with the same channel-group count
+		template <int G, int WPS>
+		__device__ __forceinline__ void RunLayers(int& s, WnStage& sd, int& cur, const WnStage* __restrict__ stages, int nstages, f32x4* wbuf, int maxA4F4,
+			__amdgpu_buffer_rsrc_t wrsrc, CFloat wvec, f32x4* xbuf, __amdgpu_buffer_rsrc_t srsrc, int myPos, int n, int f, int wave, int lane, float cond,
+			float (&xc)[MAXC], float (&hd)[MAXC], long long* __restrict__ trace, int traceBlock)
+		{
+			constexpr int NTB = WPS * 4;
+			do
+			{
+				FR_TRACE(0);
+				WnStage sdn = sd;
+				sdn.a4_floats = 0;
+				sdn.type = -1;
+				if (s + 1 < nstages) sdn = LoadStage(stages, s + 1);
+				const f32x4* wl = wbuf + (s & 1) * maxA4F4;
+				f32x4* wlNext = wbuf + ((s + 1) & 1) * maxA4F4;
+				WeightStager<WPS> stager;
+				stager.Begin(wrsrc, sdn);
+				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
+				const int inPos0 = __builtin_amdgcn_readlane(myPos, sd.ring_id);
+				LayerFr<G, WPS>(sd, wl, wvec + sd.vec_off * 4, xbuf + cur * (NTB * 64), xbuf + (cur ^ 1) * (NTB * 64), srsrc, inPos0, outPos0, n, f, wave,
+					lane, cond, xc, hd);
+				if (sd.flags & WN_FLAG_PUBLISH) cur ^= 1;
+				FR_TRACE(1);
+				stager.End(wlNext, wrsrc, sdn);
+				FR_TRACE(2);
+				BlockBarrier<WPS>();
+				FR_TRACE(3);
+				sd = sdn;
+				s++;
+			} while (s < nstages && sd.type == WN_ST_LAYER && sd.G == G);
+		}
+
+		// grid = active streams of one model; block = WPS waves of 64 frames (WPS = 2: 128-frame blocks).
+		// Per stage: issue the loads of the NEXT stage's A-operand block first (before this stage's ring stores: gfx950 has one
+		// vmcnt for loads and stores), compute, park the block in the other LDS weight buffer, meet at an LDS-only barrier.
+		// dynamic LDS: xbuf[2][WPS*4 tiles * 64] float4 | wbuf[2][maxA4Floats/4] float4
+		template <int WPS>
+		__global__ void __launch_bounds__(64 * WPS) WaveNetFrameKernel(const WnStage* __restrict__ stages, const float* __restrict__ wpack,
+			const float* __restrict__ wpkGlobal, const int* __restrict__ ringFrames, int nstages, int nrings, int stateF4, int maxA4F4, int wpkFloats, float headScale,
+			f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows, const float* __restrict__ in,
+			float* __restrict__ out, long inStride, long outStride, int n, long long* __restrict__ trace, int traceBlock)
+		{
+			constexpr int NTB = WPS * 4; // tiles in the block
+			extern __shared__ __attribute__((aligned(16))) char smem[];
+			f32x4* xbuf = reinterpret_cast<f32x4*>(smem); // [2][NTB*64]
+			f32x4* wbuf = xbuf + 2 * NTB * 64;            // [2][maxA4F4]
+			constexpr int NTHREADS = 64 * WPS;
+
+			const int lane = threadIdx.x & 63;
+			const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int f = wave * 64 + lane; // this lane's frame in the block
+
+			const int slot = slots[blockIdx.x];
+			const int row = rows[blockIdx.x];
+			f32x4* st = state + (size_t)slot * (size_t)stateF4;
+			int* header = reinterpret_cast<int*>(st);
+			const int myPos = header[lane]; // lane r holds the write cursor of ring r
+			const __amdgpu_buffer_rsrc_t srsrc = MakeRsrc(st, (unsigned)stateF4 * 16u);
+			CFloat wpk = (CFloat)wpkGlobal;
+			CFloat wvec = (CFloat)wpack;
+
+			const float cond = (f < n) ? in[(size_t)row * inStride + f] : 0.0f; // WaveNet.h:770 (input -> condition)
+			float xc[MAXC], hd[MAXC];
+#pragma unroll
+			for (int c = 0; c < MAXC; c++)
+			{
+				xc[c] = 0.0f;
+				hd[c] = 0.0f; // WaveNet.h:772 headArray.SetZero()
+			}
+
+			const __amdgpu_buffer_rsrc_t wrsrc = MakeRsrc(wpkGlobal, (unsigned)wpkFloats * 4u);
+			WnStage sd = LoadStage(stages, 0);
+			for (int i = threadIdx.x; i < sd.a4_floats / 4; i += NTHREADS) wbuf[i] = BufLoad(wrsrc, (sd.a4_off / 4 + i) * 16);
+			BlockBarrier<WPS>();
+
+			int cur = 0;
+			int s = 0;
+			while (s < nstages)
+			{
+				// Hot path: runs of WaveNet layers with the same channel-group count execute in their own tight loop, so the
+				// per-frame state (xc, hd) stays in fixed registers across layers (no phi copies at the stage-type branches).
+				if (sd.type == WN_ST_LAYER)
+				{
+					if (sd.G == 4) RunLayers<4, WPS>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
+					else if (sd.G == 3) RunLayers<3, WPS>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
+					else if (sd.G == 2) RunLayers<2, WPS>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
+					else RunLayers<1, WPS>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
+					continue;
+				}
+
+				WnStage sdn = sd;
+				sdn.a4_floats = 0;
+				if (s + 1 < nstages) sdn = LoadStage(stages, s + 1);
+				const f32x4* wl = wbuf + (s & 1) * maxA4F4;
+				f32x4* wlNext = wbuf + ((s + 1) & 1) * maxA4F4;
+				WeightStager<WPS> stager;
+				stager.Begin(wrsrc, sdn);
+				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
+				const int inPos0 = (sd.ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.ring_id) : 0;
+				f32x4* xbCur = xbuf + cur * (NTB * 64);
+				f32x4* xbNext = xbuf + (cur ^ 1) * (NTB * 64);
+				(void)xbCur;
+				CFloat vec = wvec + sd.vec_off * 4; // [0..15] conv/dense bias, [16..31] mix-in w, [32..47] 1x1 bias, [48..63] aux
+
+				if (sd.type == WN_ST_RECHANNEL_COND)
+				{
+#pragma unroll
+					for (int c = 0; c < MAXC; c++) xc[c] = vec[48 + c] * cond; // :637 with InputSize == 1
+					PublishAny(sd.out_G, xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, n, f);
+					cur ^= 1;
+				}
+				else if (sd.type == WN_ST_ARRAY_LINK)
+				{
+					// previous array's headRechannel (K=1, :658-660) and this array's rechannel (:637); weights padded to 16x16
+					f32x4 hn[4], xn[4];
+#pragma unroll
+					for (int og = 0; og < 4; og++)
+					{
+						hn[og] = (sd.flags & WN_FLAG_BIAS) ? f32x4{ vec[4 * og], vec[4 * og + 1], vec[4 * og + 2], vec[4 * og + 3] } : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+						xn[og] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+					}
+					DenseMfma<MAXC, MAXC>(hn, wl + (lane & 3), hd);
+					DenseMfma<MAXC, MAXC>(xn, wl + 64 + (lane & 3), xc);
+#pragma unroll
+					for (int og = 0; og < 4; og++)
+					{
+						hd[4 * og] = hn[og].x; hd[4 * og + 1] = hn[og].y; hd[4 * og + 2] = hn[og].z; hd[4 * og + 3] = hn[og].w;
+						xc[4 * og] = xn[og].x; xc[4 * og + 1] = xn[og].y; xc[4 * og + 2] = xn[og].z; xc[4 * og + 3] = xn[og].w;
+					}
+					PublishAny(sd.out_G, xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, n, f);
+					cur ^= 1;
+				}
+				else if (sd.type == WN_ST_HEAD_DENSE_OUT)
+				{
+					float o = (sd.flags & WN_FLAG_BIAS) ? vec[0] : 0.0f;
+					CFloat wh = wpk + sd.pk_w1_off;
+#pragma unroll
+					for (int c = 0; c < MAXC; c++) o = __builtin_fmaf(wh[c], hd[c], o);
+					if (f < n) out[(size_t)row * outStride + f] = headScale * o; // :793-798
+				}
+				else // WN_ST_HEAD_CONV_OUT
+				{
+					PublishAny(sd.out_G, hd, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, n, f);
+					cur ^= 1;
+					BlockBarrier<WPS>();
+					const float bias = (sd.flags & WN_FLAG_BIAS) ? vec[0] : 0.0f;
+					float o;
+					if (sd.G == 4) o = HeadConvPk<4>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
+					else if (sd.G == 3) o = HeadConvPk<3>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
+					else if (sd.G == 2) o = HeadConvPk<2>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
+					else o = HeadConvPk<1>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
+					if (f < n) out[(size_t)row * outStride + f] = headScale * o;
+				}
+				stager.End(wlNext, wrsrc, sdn);
+				BlockBarrier<WPS>();
+				sd = sdn;
+				s++;
+			}
+
+			// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
+			if (wave == 0 && lane < nrings)
+			{
+				const int R = ringFrames[lane];
+				int p = myPos + n;
+				if (p >= R) p -= R;
+				header[lane] = p;
+			}
+		}
+
+		template <int WPS>
+		static hipError_t Launch(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
+			long inStride, long outStride, int n, hipStream_t stream)
+		{
+			const int maxA4F4 = (m.max_a4_floats + 3) / 4;
+			const size_t lds = (size_t)2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16;
+			if (lds > 64 * 1024) return hipErrorInvalidValue;
+			hipLaunchKernelGGL((WaveNetFrameKernel<WPS>), dim3((unsigned)numStreams), dim3(64 * WPS), lds, stream, m.stages, m.wpack, m.wpk, m.ring_frames,
+				m.nstages, m.nrings, m.state_f4, maxA4F4, m.wpk_floats, m.head_scale, reinterpret_cast<f32x4*>(state), slots, rows, in, out, inStride, outStride, n, GetWaveNetTraceBuffer(),
+				[]() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
+			return hipGetLastError();
+		}
+	}
+
+	hipError_t LaunchWaveNetFrame(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
+		long inStride, long outStride, int n, hipStream_t stream)
+	{
+		if (numStreams <= 0 || n <= 0) return hipSuccess;
+		if (n > WN_MAX_FRAMES) return hipErrorInvalidValue;
+		if (n > 64) return fr::Launch<2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		return fr::Launch<1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+	}
+}

@@ -631,6 +631,7 @@ namespace na
 
 	static long long* g_traceBuffer = nullptr;
 	void SetWaveNetTraceBuffer(long long* p) { g_traceBuffer = p; }
+	long long* GetWaveNetTraceBuffer() { return g_traceBuffer; }
 
 	template <int TPW, int WPS>
 	static hipError_t LaunchBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,

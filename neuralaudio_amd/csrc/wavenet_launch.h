@@ -12,8 +12,17 @@ namespace na
 	hipError_t LaunchWaveNetBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
 		float* out, long inStride, long outStride, int n, hipStream_t stream);
 
+	// Same contract as LaunchWaveNetBlock, packed-FMA (lane = frame) kernel (wavenet_pk_kernels.hip)
+	hipError_t LaunchWaveNetPk(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
+		float* out, long inStride, long outStride, int n, hipStream_t stream);
+
+	// Same contract, lane = frame kernel on v_mfma_f32_4x4x1_16b_f32 (wavenet_frame_kernels.hip)
+	hipError_t LaunchWaveNetFrame(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
+		float* out, long inStride, long outStride, int n, hipStream_t stream);
+
 	// tuning aid: device buffer of long long[stages*4*waves] that workgroup 0 stamps with the shader clock (nullptr: off)
 	void SetWaveNetTraceBuffer(long long* deviceBuffer);
+	long long* GetWaveNetTraceBuffer();
 
 	// Zero-input steady-state columns per ring (once per model), cols = [nrings][16] floats.
 	hipError_t LaunchWaveNetPrewarmColumns(const WnPrewarmLayer* layers, int numLayers, const float* weights, float* cols,

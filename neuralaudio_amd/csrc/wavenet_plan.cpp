@@ -152,6 +152,62 @@ namespace na
 				return off;
 			}
 
+			int AllocPk(int nFloats)
+			{
+				const int off = (int)plan.wpk.size();
+				plan.wpk.resize(plan.wpk.size() + (size_t)((nFloats + 15) & ~15), 0.0f); // 64-byte granules: s_load_dwordx16 friendly
+				return off;
+			}
+
+			// conv for the packed-FMA kernel: [tap][in c][out o], both channel counts padded to CP; flat source [(o*cin + c)*K + tap]
+			int PackConvPk(int wOff, int cin, int cout, int ksize, int CPin, int CPout)
+			{
+				const int off = AllocPk(ksize * CPin * CPout);
+				for (int k = 0; k < ksize; k++)
+					for (int c = 0; c < cin; c++)
+						for (int o = 0; o < cout; o++) plan.wpk[(size_t)off + ((size_t)k * CPin + c) * CPout + o] = W(wOff + (o * cin + c) * ksize + k);
+				return off;
+			}
+
+			// dense [in c][out o] padded; flat source [o*cin + c]
+			int PackDensePk(int wOff, int cin, int cout, int CPin, int CPout)
+			{
+				const int off = AllocPk(CPin * CPout);
+				for (int c = 0; c < cin; c++)
+					for (int o = 0; o < cout; o++) plan.wpk[(size_t)off + (size_t)c * CPout + o] = W(wOff + o * cin + c);
+				return off;
+			}
+
+			// A operands of v_mfma_f32_4x4x1_16b_f32 for the frame kernel: lane l of every 4-lane block supplies row (l & 3), so
+			// the image is [tap][out group og][in quad cq][row i][4 in channels]: lane reads one float4 at index
+			// ((tap*NOG + og)*NCQ + cq)*4 + (l & 3).  Flat source conv [(o*cin + c)*K + tap], dense [o*cin + c].
+			int PackConvA4(int wOff, int cin, int cout, int ksize, int CPin, int CPout)
+			{
+				const int nog = CPout / 4, ncq = CPin / 4;
+				const int off = AllocPk(ksize * CPin * CPout);
+				for (int k = 0; k < ksize; k++)
+					for (int o = 0; o < cout; o++)
+						for (int c = 0; c < cin; c++)
+						{
+							const size_t idx = ((((size_t)k * nog + o / 4) * ncq + c / 4) * 4 + (o % 4)) * 4 + (c % 4);
+							plan.wpk[(size_t)off + idx] = W(wOff + (o * cin + c) * ksize + k);
+						}
+				return off;
+			}
+
+			int PackDenseA4(int wOff, int cin, int cout, int CPin, int CPout)
+			{
+				const int ncq = CPin / 4;
+				const int off = AllocPk(CPin * CPout);
+				for (int o = 0; o < cout; o++)
+					for (int c = 0; c < cin; c++)
+					{
+						const size_t idx = ((((size_t)(o / 4)) * ncq + c / 4) * 4 + (o % 4)) * 4 + (c % 4);
+						plan.wpk[(size_t)off + idx] = W(wOff + o * cin + c);
+					}
+				return off;
+			}
+
 			void SetVec(const WnStage& st, int slot, int wOff, int n)
 			{
 				for (int i = 0; i < n && i < 16; i++) plan.wpack[((size_t)st.vec_off + (size_t)slot * 4) * 4 + i] = W(wOff + i);
@@ -256,6 +312,11 @@ namespace na
 							SetVec(st, 0, prevHeadB, prev.headSize);
 						}
 						st.w2_off = PackDense(rechOff, cfg.inputSize, C);
+						st.pk_w1_off = PackDensePk(prevHeadW, prev.channels, prev.headSize, 16, 16);
+						st.pk_w2_off = PackDensePk(rechOff, cfg.inputSize, C, 16, 16);
+						st.a4_off = PackDenseA4(prevHeadW, prev.channels, prev.headSize, 16, 16); // [head dense | rechannel], 16x16 each
+						PackDenseA4(rechOff, cfg.inputSize, C, 16, 16);
+						st.a4_floats = 2 * 256;
 						SetOutRing(st, layerRing[a][0]);
 						st.flags |= WN_FLAG_PUBLISH;
 						plan.stages.push_back(st);
@@ -280,6 +341,11 @@ namespace na
 						SetVec(st, 2, b1, C);
 						PackConv(st, wconv, C, C, K, d);
 						st.w1_off = PackDense(w1, C, C);
+						st.pk_conv_off = PackConvPk(wconv, C, C, K, 4 * st.G, 4 * st.G);
+						st.pk_w1_off = PackDensePk(w1, C, C, 4 * st.G, 4 * st.G);
+						st.a4_off = PackConvA4(wconv, C, C, K, 4 * st.G, 4 * st.G);       // [conv taps | 1x1], one contiguous block
+						PackDenseA4(w1, C, C, 4 * st.G, 4 * st.G);
+						st.a4_floats = (K + 1) * (4 * st.G) * (4 * st.G);
 						SetRing(st, layerRing[a][l]);
 						if (cfg.activation == ACT_LEAKYRELU) st.flags |= WN_FLAG_LEAKY;
 						// NeedOutput=false for the very last layer (WaveNet.h:643,785); for a single-array model the
@@ -323,6 +389,8 @@ namespace na
 							WnStage st = EmptyStage(WN_ST_HEAD_DENSE_OUT);
 							st.vec_off = AllocF4(16);
 							st.w1_off = PackDense(wh, C, cfg.headSize);
+							st.G = CeilDiv(C, 4);
+							st.pk_w1_off = PackDensePk(wh, C, 1, 16, 1); // only head channel 0 reaches the output (WaveNet.h:793-798)
 							if (cfg.hasHeadBias)
 							{
 								st.flags |= WN_FLAG_BIAS;
@@ -336,6 +404,7 @@ namespace na
 							st.G = CeilDiv(C, 4);
 							st.vec_off = AllocF4(16);
 							PackConv(st, wh, C, cfg.headSize, cfg.headKernelSize, cfg.headDilation);
+							st.pk_conv_off = PackConvPk(wh, C, 1, cfg.headKernelSize, 4 * st.G, 1);
 							if (cfg.hasHeadBias)
 							{
 								st.flags |= WN_FLAG_BIAS;
@@ -362,6 +431,7 @@ namespace na
 					st.wblk_off = st.vec_off;
 					st.wblk_f4 = end - st.vec_off;
 					plan.maxStageF4 = std::max(plan.maxStageF4, st.wblk_f4);
+					plan.maxA4Floats = std::max(plan.maxA4Floats, st.a4_floats);
 				}
 				// round the state up to a 256-byte multiple so every stream's state starts float4/line aligned
 				plan.stateF4 = CeilDiv(plan.stateF4, 16) * 16;
