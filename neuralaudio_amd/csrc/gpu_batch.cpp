@@ -255,7 +255,7 @@ namespace na
 				while (n > 0)
 				{
 					const int chunk = (int)std::min<size_t>(n, (size_t)WN_MAX_FRAMES);
-					static const std::string which = getenv("NA_WN_KERNEL") ? getenv("NA_WN_KERNEL") : "tile"; // tuning knob: tile | frame | pk
+					static const std::string which = getenv("NA_WN_KERNEL") ? getenv("NA_WN_KERNEL") : "frame"; // tuning knob: frame | tile | pk
 					if (which == "frame")
 						CheckHip(LaunchWaveNetFrame(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
 							outStride, chunk, launchStream), "WaveNetFrameKernel");

@@ -114,6 +114,36 @@ namespace na
 
 		// Channels [4*cg, 4*cg+4) of the frame `off` frames from the block start (off < 0: history) for this lane.
 		// lo/hi: range of `off` over the wave (scalar) -> whole wave in block / whole wave in history / mixed.
+		constexpr int HPF = 2; // shifted taps (most shifted first) whose history can be prefetched one layer ahead
+
+		// history part of one tap for this lane's frame: channels of frame (pos0 + off) from the ring (lanes inside the block: nothing)
+		template <int G>
+		__device__ __forceinline__ void LoadHistory(f32x4 (&h)[G], __amdgpu_buffer_rsrc_t srsrc, int ringOff, int off, int pos0, int R)
+		{
+			int p = pos0 + off;
+			if (p < 0) p += R;
+			if (p >= R) p -= R;
+			const int hoff = (off < 0) ? (ringOff + TileIdx(p, G, 0)) * 16 : OOB;
+#pragma unroll
+			for (int cg = 0; cg < G; cg++) h[cg] = BufLoad(srsrc, hoff + cg * 256);
+		}
+
+		// FetchFrame with the history part already in registers.  Branch-free on purpose: with a fixed number of VMEM operations per
+		// layer on every path the compiler can place COUNTED vmcnt waits; a conditional load anywhere in the loop makes it wait for
+		// the youngest loads too, which would expose the very HBM latency the prefetch is meant to hide.
+		template <int G>
+		__device__ __forceinline__ void FetchFramePre(float (&x)[4 * G], const f32x4* xb, int off, const f32x4 (&hpre)[G])
+		{
+			const int base = TileIdx(off < 0 ? 0 : off, G, 0);
+#pragma unroll
+			for (int cg = 0; cg < G; cg++)
+			{
+				const f32x4 l = xb[base + cg * 16];
+				const f32x4 v = (off < 0) ? hpre[cg] : l;
+				x[4 * cg] = v.x; x[4 * cg + 1] = v.y; x[4 * cg + 2] = v.z; x[4 * cg + 3] = v.w;
+			}
+		}
+
 		template <int G>
 		__device__ __forceinline__ void FetchFrame(float (&x)[4 * G], const f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int off, int lo, int hi,
 			int pos0, int R)
@@ -204,9 +234,10 @@ namespace na
 		}
 
 		// WaveNetLayerT::Process (WaveNet.h:462-494) for one frame per lane
-		template <int G, int WPS>
+		template <int G, int WPS, bool PF>
 		__device__ __forceinline__ void LayerFr(const WnStage& sd, const f32x4* wl, CFloat vec, const f32x4* xbCur, f32x4* xbNext,
-			__amdgpu_buffer_rsrc_t srsrc, int inPos0, int outPos0, int n, int f, int wave, int lane, float cond, float (&xc)[MAXC], float (&hd)[MAXC])
+			__amdgpu_buffer_rsrc_t srsrc, int inPos0, int outPos0, int n, int f, int wave, int lane, float cond, float (&xc)[MAXC], float (&hd)[MAXC],
+			const f32x4 (&hcur)[HPF][G], bool haveCur)
 		{
 			constexpr int C = 4 * G;
 			const int K = sd.ksize;
@@ -223,8 +254,26 @@ namespace na
 				acc[og] = b + wm * cond;
 			}
 
-			// dilated conv (:139-290): tap k reads the frame d*(K-1-k) back; the last tap is the layer input itself (registers)
-			for (int k = 0; k < K - 1; k++)
+			// dilated conv (:139-290): tap k reads the frame d*(K-1-k) back; the last tap is the layer input itself (registers).
+			// With PF the history of the first HPF taps was loaded during the previous layer (hcur); those taps are peeled so that each
+			// names its registers statically.
+			int kFirst = 0;
+			if (PF)
+			{
+#pragma unroll
+				for (int k = 0; k < HPF; k++)
+				{
+					if (k < K - 1)
+					{
+						const int shift = d * (K - 1 - k);
+						float x[C];
+						FetchFramePre<G>(x, xbCur, f - shift, hcur[k]);
+						DenseMfma<C, C>(acc, a4 + k * (C * C / 4), x);
+					}
+				}
+				kFirst = HPF;
+			}
+			for (int k = kFirst; k < K - 1; k++)
 			{
 				const int shift = d * (K - 1 - k);
 				const int lo = wave * 64 - shift;
@@ -241,15 +290,28 @@ namespace na
 
 			// activation (:473-480), head accumulate (:482)
 			float z[C];
-			const bool leaky = (sd.flags & WN_FLAG_LEAKY) != 0;
-#pragma unroll
-			for (int og = 0; og < G; og++)
+			if (sd.flags & WN_FLAG_LEAKY) // one uniform branch per layer, not one per channel pair
 			{
-				const f32x2 lo2 = leaky ? LeakyReLU2(f32x2{ acc[og].x, acc[og].y }) : FastTanh2(f32x2{ acc[og].x, acc[og].y });
-				const f32x2 hi2 = leaky ? LeakyReLU2(f32x2{ acc[og].z, acc[og].w }) : FastTanh2(f32x2{ acc[og].z, acc[og].w });
-				z[4 * og] = lo2.x; z[4 * og + 1] = lo2.y; z[4 * og + 2] = hi2.x; z[4 * og + 3] = hi2.y;
-				hd[4 * og] += lo2.x; hd[4 * og + 1] += lo2.y; hd[4 * og + 2] += hi2.x; hd[4 * og + 3] += hi2.y;
+#pragma unroll
+				for (int og = 0; og < G; og++)
+				{
+					const f32x2 lo2 = LeakyReLU2(f32x2{ acc[og].x, acc[og].y });
+					const f32x2 hi2 = LeakyReLU2(f32x2{ acc[og].z, acc[og].w });
+					z[4 * og] = lo2.x; z[4 * og + 1] = lo2.y; z[4 * og + 2] = hi2.x; z[4 * og + 3] = hi2.y;
+				}
 			}
+			else
+			{
+#pragma unroll
+				for (int og = 0; og < G; og++)
+				{
+					const f32x2 lo2 = FastTanh2(f32x2{ acc[og].x, acc[og].y });
+					const f32x2 hi2 = FastTanh2(f32x2{ acc[og].z, acc[og].w });
+					z[4 * og] = lo2.x; z[4 * og + 1] = lo2.y; z[4 * og + 2] = hi2.x; z[4 * og + 3] = hi2.y;
+				}
+			}
+#pragma unroll
+			for (int c = 0; c < C; c++) hd[c] += z[c];
 
 			if (sd.flags & WN_FLAG_NEED_OUTPUT)
 			{
@@ -266,7 +328,8 @@ namespace na
 					xc[4 * og] = y[og].x; xc[4 * og + 1] = y[og].y; xc[4 * og + 2] = y[og].z; xc[4 * og + 3] = y[og].w;
 				}
 			}
-			if (sd.flags & WN_FLAG_PUBLISH) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, n, f);
+			if (PF) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, (sd.flags & WN_FLAG_PUBLISH) ? n : 0, f);
+			else if (sd.flags & WN_FLAG_PUBLISH) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, n, f);
 		}
 
 		__device__ __forceinline__ void PublishAny(int G, const float (&x)[MAXC], f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int pos0, int R,
@@ -336,12 +399,22 @@ namespace na
 	if (trace != nullptr && (int)blockIdx.x == traceBlock && lane == 0) trace[((s * 4 + (point)) * WPS) + wave] = (long long)__builtin_readcyclecounter()
 
 		// consecutive WaveNet layer stages with the same channel-group count
-		template <int G, int WPS>
+		template <int G, int WPS, bool PF>
 		__device__ __forceinline__ void RunLayers(int& s, WnStage& sd, int& cur, const WnStage* __restrict__ stages, int nstages, f32x4* wbuf, int maxA4F4,
 			__amdgpu_buffer_rsrc_t wrsrc, CFloat wvec, f32x4* xbuf, __amdgpu_buffer_rsrc_t srsrc, int myPos, int n, int f, int wave, int lane, float cond,
 			float (&xc)[MAXC], float (&hd)[MAXC], long long* __restrict__ trace, int traceBlock)
 		{
 			constexpr int NTB = WPS * 4;
+			// history of the first HPF taps of the current layer; loaded once here for the first layer of the run, afterwards one layer ahead
+			f32x4 hcur[HPF][G];
+#pragma unroll
+			for (int t = 0; t < HPF; t++)
+			{
+				const int shift0 = sd.dilation * (sd.ksize - 1 - t);
+				const int off = (PF && t < sd.ksize - 1) ? f - shift0 : 0; // off >= 0 -> nothing is loaded
+				LoadHistory<G>(hcur[t], srsrc, sd.ring_off, off, __builtin_amdgcn_readlane(myPos, sd.ring_id), sd.ring_frames);
+			}
+			const bool haveCur = true;
 			do
 			{
 				FR_TRACE(0);
@@ -355,8 +428,25 @@ namespace na
 				stager.Begin(wrsrc, sdn);
 				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
 				const int inPos0 = __builtin_amdgcn_readlane(myPos, sd.ring_id);
-				LayerFr<G, WPS>(sd, wl, wvec + sd.vec_off * 4, xbuf + cur * (NTB * 64), xbuf + (cur ^ 1) * (NTB * 64), srsrc, inPos0, outPos0, n, f, wave,
-					lane, cond, xc, hd);
+				// history of the NEXT layer's first HPF taps: issued at the start of this layer (before its ring stores), consumed a layer
+				// later.  Always HPF*G loads, predicated through the offset, so the VMEM count per layer is the same on every path.
+				f32x4 hnext[HPF][G];
+				const bool haveNext = PF && (s + 1 < nstages) && sdn.type == WN_ST_LAYER && sdn.G == G;
+				const int nextPos0 = __builtin_amdgcn_readlane(myPos, haveNext ? sdn.ring_id : 0);
+#pragma unroll
+				for (int t = 0; t < HPF; t++)
+				{
+					const int shiftN = sdn.dilation * (sdn.ksize - 1 - t);
+					const int off = (haveNext && t < sdn.ksize - 1) ? f - shiftN : 0;
+					if (PF) LoadHistory<G>(hnext[t], srsrc, sdn.ring_off, off, nextPos0, sdn.ring_frames);
+				}
+				LayerFr<G, WPS, PF>(sd, wl, wvec + sd.vec_off * 4, xbuf + cur * (NTB * 64), xbuf + (cur ^ 1) * (NTB * 64), srsrc, inPos0, outPos0, n, f, wave,
+					lane, cond, xc, hd, hcur, haveCur);
+#pragma unroll
+				for (int t = 0; t < HPF; t++)
+#pragma unroll
+					for (int cg = 0; cg < G; cg++)
+						if (PF) hcur[t][cg] = hnext[t][cg];
 				if (sd.flags & WN_FLAG_PUBLISH) cur ^= 1;
 				FR_TRACE(1);
 				stager.End(wlNext, wrsrc, sdn);
@@ -372,7 +462,7 @@ namespace na
 		// Per stage: issue the loads of the NEXT stage's A-operand block first (before this stage's ring stores: gfx950 has one
 		// vmcnt for loads and stores), compute, park the block in the other LDS weight buffer, meet at an LDS-only barrier.
 		// dynamic LDS: xbuf[2][WPS*4 tiles * 64] float4 | wbuf[2][maxA4Floats/4] float4
-		template <int WPS>
+		template <int WPS, bool PF>
 		__global__ void __launch_bounds__(64 * WPS) WaveNetFrameKernel(const WnStage* __restrict__ stages, const float* __restrict__ wpack,
 			const float* __restrict__ wpkGlobal, const int* __restrict__ ringFrames, int nstages, int nrings, int stateF4, int maxA4F4, int wpkFloats, float headScale,
 			f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows, const float* __restrict__ in,
@@ -419,10 +509,10 @@ namespace na
 				// per-frame state (xc, hd) stays in fixed registers across layers (no phi copies at the stage-type branches).
 				if (sd.type == WN_ST_LAYER)
 				{
-					if (sd.G == 4) RunLayers<4, WPS>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
-					else if (sd.G == 3) RunLayers<3, WPS>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
-					else if (sd.G == 2) RunLayers<2, WPS>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
-					else RunLayers<1, WPS>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
+					if (sd.G == 4) RunLayers<4, WPS, PF>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
+					else if (sd.G == 3) RunLayers<3, WPS, PF>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
+					else if (sd.G == 2) RunLayers<2, WPS, PF>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
+					else RunLayers<1, WPS, PF>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
 					continue;
 				}
 
@@ -505,14 +595,14 @@ namespace na
 			}
 		}
 
-		template <int WPS>
+		template <int WPS, bool PF>
 		static hipError_t Launch(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
 			long inStride, long outStride, int n, hipStream_t stream)
 		{
 			const int maxA4F4 = (m.max_a4_floats + 3) / 4;
 			const size_t lds = (size_t)2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16;
 			if (lds > 64 * 1024) return hipErrorInvalidValue;
-			hipLaunchKernelGGL((WaveNetFrameKernel<WPS>), dim3((unsigned)numStreams), dim3(64 * WPS), lds, stream, m.stages, m.wpack, m.wpk, m.ring_frames,
+			hipLaunchKernelGGL((WaveNetFrameKernel<WPS, PF>), dim3((unsigned)numStreams), dim3(64 * WPS), lds, stream, m.stages, m.wpack, m.wpk, m.ring_frames,
 				m.nstages, m.nrings, m.state_f4, maxA4F4, m.wpk_floats, m.head_scale, reinterpret_cast<f32x4*>(state), slots, rows, in, out, inStride, outStride, n, GetWaveNetTraceBuffer(),
 				[]() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
 			return hipGetLastError();
@@ -524,7 +614,12 @@ namespace na
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > WN_MAX_FRAMES) return hipErrorInvalidValue;
-		if (n > 64) return fr::Launch<2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-		return fr::Launch<1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		static const bool prefetch = getenv("NA_FR_PF") ? atoi(getenv("NA_FR_PF")) != 0 : true; // tuning knob: cross-layer history prefetch
+		if (n > 64)
+		{
+			if (prefetch) return fr::Launch<2, true>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			return fr::Launch<2, false>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		}
+		return fr::Launch<1, false>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 	}
 }
