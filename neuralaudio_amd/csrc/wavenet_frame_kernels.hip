@@ -34,6 +34,10 @@ namespace na
 		typedef const float __attribute__((address_space(4)))* CFloat; // wave-uniform read-only data -> scalar loads
 		typedef const int __attribute__((address_space(4)))* CInt;
 
+#ifndef NA_ABL
+#define NA_ABL 0 // ablation bit mask for tuning builds only (tools/ablate.sh); 0 in the product.  1: no activation math, 2: no MFMA,
+                 // 4: no history loads / ring stores, 8: no barrier, 16: no weight staging
+#endif
 		constexpr int OOB = (int)0x80000000;
 		constexpr int STAGE_INTS = (int)(sizeof(WnStage) / sizeof(int));
 		constexpr int MAXC = 16;
@@ -71,13 +75,15 @@ namespace na
 			return r;
 		}
 
-		// Activation.h:83-91 on two channels: same association, packed math, division = num * v_rcp_f32(den)
+		// Activation.h:83-91 on two channels, packed math, division = num * v_rcp_f32(den)
 		__device__ __forceinline__ f32x2 FastTanh2(f32x2 x)
 		{
+			if (NA_ABL & 1) return x * 0.5f;
 			const f32x2 ax = Abs2(x);
 			const f32x2 x2 = x * x;
 			const f32x2 num = x * (2.45550750702956f + 2.45550750702956f * ax + (0.893229853513558f + 0.821226666969744f * ax) * x2);
-			const f32x2 den = 2.44506634652299f + (2.44506634652299f + x2) * Abs2(x + 0.814642734961073f * x * ax);
+			// |x + e*x*|x|| == |x| + e*x^2 (1 + e|x| > 0): three packed ops for the denominator instead of six
+			const f32x2 den = 2.44506634652299f + (2.44506634652299f + x2) * (ax + 0.814642734961073f * x2);
 			f32x2 r;
 			r.x = __builtin_amdgcn_rcpf(den.x);
 			r.y = __builtin_amdgcn_rcpf(den.y);
@@ -96,6 +102,7 @@ namespace na
 		template <int WPS>
 		__device__ __forceinline__ void BlockBarrier()
 		{
+			if (NA_ABL & 8) return;
 			if (WPS > 1)
 			{
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -120,6 +127,12 @@ namespace na
 		template <int G>
 		__device__ __forceinline__ void LoadHistory(f32x4 (&h)[G], __amdgpu_buffer_rsrc_t srsrc, int ringOff, int off, int pos0, int R)
 		{
+			if (NA_ABL & 4)
+			{
+#pragma unroll
+				for (int cg = 0; cg < G; cg++) h[cg] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+				return;
+			}
 			int p = pos0 + off;
 			if (p < 0) p += R;
 			if (p >= R) p -= R;
@@ -197,6 +210,12 @@ namespace na
 		__device__ __forceinline__ void DenseMfma(f32x4 (&acc)[COUT / 4], const f32x4* a4, const float (&x)[CIN])
 		{
 			constexpr int NCQ = CIN / 4;
+			if (NA_ABL & 2)
+			{
+#pragma unroll
+				for (int og = 0; og < COUT / 4; og++) acc[og].x += x[og];
+				return;
+			}
 #pragma unroll
 			for (int cq = 0; cq < NCQ; cq++)
 			{
@@ -229,7 +248,7 @@ namespace na
 			{
 				const f32x4 v = f32x4{ x[4 * cg], x[4 * cg + 1], x[4 * cg + 2], x[4 * cg + 3] };
 				xb[TileIdx(f, G, cg)] = v;
-				BufStore(srsrc, v, keep ? (ringOff + TileIdx(p, G, cg)) * 16 : OOB);
+				if (!(NA_ABL & 4)) BufStore(srsrc, v, keep ? (ringOff + TileIdx(p, G, cg)) * 16 : OOB);
 			}
 		}
 
@@ -243,15 +262,14 @@ namespace na
 			const int K = sd.ksize;
 			const int d = sd.dilation;
 			const f32x4* a4 = wl + (lane & 3);
+			const f32x4* vl = wl + (K + 1) * (C * C / 4); // conv bias | mixin | 1x1 bias (tail of the staged block, see BuildWaveNetPlan)
 
 			// acc = conv bias (:288-289) + W_mix * cond (:471)
 			f32x4 acc[G];
 #pragma unroll
 			for (int og = 0; og < G; og++)
 			{
-				const f32x4 b = f32x4{ vec[4 * og], vec[4 * og + 1], vec[4 * og + 2], vec[4 * og + 3] };
-				const f32x4 wm = f32x4{ vec[16 + 4 * og], vec[16 + 4 * og + 1], vec[16 + 4 * og + 2], vec[16 + 4 * og + 3] };
-				acc[og] = b + wm * cond;
+				acc[og] = vl[og] + vl[G + og] * cond;
 			}
 
 			// dilated conv (:139-290): tap k reads the frame d*(K-1-k) back; the last tap is the layer input itself (registers).
@@ -319,8 +337,7 @@ namespace na
 				f32x4 y[G];
 #pragma unroll
 				for (int og = 0; og < G; og++)
-					y[og] = f32x4{ vec[32 + 4 * og] + xc[4 * og], vec[32 + 4 * og + 1] + xc[4 * og + 1], vec[32 + 4 * og + 2] + xc[4 * og + 2],
-						vec[32 + 4 * og + 3] + xc[4 * og + 3] };
+					y[og] = vl[2 * G + og] + f32x4{ xc[4 * og], xc[4 * og + 1], xc[4 * og + 2], xc[4 * og + 3] };
 				DenseMfma<C, C>(y, a4 + K * (C * C / 4), z);
 #pragma unroll
 				for (int og = 0; og < G; og++)
@@ -372,6 +389,7 @@ namespace na
 
 			__device__ __forceinline__ void Begin(__amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn)
 			{
+				if (NA_ABL & 16) return;
 				const int nextF4 = sdn.a4_floats / 4;
 #pragma unroll
 				for (int c = 0; c < WCOPY; c++)
@@ -383,6 +401,7 @@ namespace na
 
 			__device__ __forceinline__ void End(f32x4* wlNext, __amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn)
 			{
+				if (NA_ABL & 16) return;
 				const int nextF4 = sdn.a4_floats / 4;
 #pragma unroll
 				for (int c = 0; c < WCOPY; c++)

@@ -345,7 +345,18 @@ namespace na
 						st.pk_w1_off = PackDensePk(w1, C, C, 4 * st.G, 4 * st.G);
 						st.a4_off = PackConvA4(wconv, C, C, K, 4 * st.G, 4 * st.G);       // [conv taps | 1x1], one contiguous block
 						PackDenseA4(w1, C, C, 4 * st.G, 4 * st.G);
-						st.a4_floats = (K + 1) * (4 * st.G) * (4 * st.G);
+						{
+							// tail of the block: conv bias | mixin | 1x1 bias, 4G floats each, read back from LDS as broadcast float4s
+							const int CP = 4 * st.G;
+							const int tail = AllocPk(3 * CP);
+							for (int c = 0; c < C; c++)
+							{
+								plan.wpk[(size_t)tail + c] = W(bconv + c);
+								plan.wpk[(size_t)tail + CP + c] = W(wmix + c);
+								plan.wpk[(size_t)tail + 2 * CP + c] = W(b1 + c);
+							}
+						}
+						st.a4_floats = (K + 1) * (4 * st.G) * (4 * st.G) + 12 * st.G;
 						SetRing(st, layerRing[a][l]);
 						if (cfg.activation == ACT_LEAKYRELU) st.flags |= WN_FLAG_LEAKY;
 						// NeedOutput=false for the very last layer (WaveNet.h:643,785); for a single-array model the

@@ -20,10 +20,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define VD "v_fma_f32 %5, %5, %9, %8\n"
 #define PK "v_pk_fma_f32 %6, %6, %7, %7\n"
 
+#define DS "ds_read_b128 v[100:103], %10\n"
+#define DSW "s_waitcnt lgkmcnt(0)\n"
+#define SA "s_add_u32 s20, s20, 1\n"
 #define BODY(name, text)                                                                                                              \
-	__device__ __forceinline__ void name(f32x4& c0, f32x4& c1, float& v0, float& v1, float& v2, float& v3, float2& p0, float2& p1, float a, float b) \
+	__device__ __forceinline__ void name(f32x4& c0, f32x4& c1, float& v0, float& v1, float& v2, float& v3, float2& p0, float2& p1, float a, float b, unsigned ldsAddr) \
 	{                                                                                                                                  \
-		asm volatile(REP8(text) : "+v"(c0), "+v"(c1), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(p0), "+v"(p1) : "v"(a), "v"(b));                \
+		asm volatile(REP8(text) : "+v"(c0), "+v"(c1), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(p0), "+v"(p1) : "v"(a), "v"(b), "v"(ldsAddr) : "v100", "v101", "v102", "v103", "s20");                \
 	}
 
 // 16x16x4 (8 passes = 32 cycles) + n VALU
@@ -39,6 +42,10 @@ BODY(pk8_only, PK PK PK PK PK PK PK PK)
 BODY(m4_v0, MF4 MF4B MF4 MF4B MF4 MF4B MF4 MF4B)
 BODY(m4_v8, MF4 VA MF4B VB MF4 VC MF4B VD MF4 VA MF4B VB MF4 VC MF4B VD)
 BODY(m4_v16, MF4 VA VB MF4B VC VD MF4 VA VB MF4B VC VD MF4 VA VB MF4B VC VD MF4 VA VB MF4B VC VD)
+BODY(m4_ds8, MF4 DS MF4B DS MF4 DS MF4B DS MF4 DS MF4B DS MF4 DS MF4B DS DSW)
+BODY(m4_ds2, MF4 DS MF4B MF4 MF4B MF4 DS MF4B MF4 MF4B DSW)
+BODY(m4_sa8, MF4 SA MF4B SA MF4 SA MF4B SA MF4 SA MF4B SA MF4 SA MF4B SA)
+BODY(ds8_only, DS DS DS DS DS DS DS DS DSW)
 BODY(m4_pk8, MF4 PK MF4B PK MF4 PK MF4B PK MF4 PK MF4B PK MF4 PK MF4B PK)
 
 template <int MODE>
@@ -49,6 +56,9 @@ __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters, 
 	f32x4 c0 = {0, 0, 0, 0}, c1 = c0;
 	float v0 = a, v1 = a + 1, v2 = a + 2, v3 = a + 3;
 	float2 p0 = {a, a}, p1 = {b, b};
+	__shared__ float lds[4096];
+	lds[threadIdx.x] = a;
+	const unsigned ldsAddr = (threadIdx.x & 3) * 16;
 	unsigned hwid;
 	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
 	const int simd = (hwid >> 4) & 3;
@@ -58,27 +68,31 @@ __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters, 
 	const long long t0 = __builtin_readcyclecounter();
 	for (int i = 0; i < iters; i++)
 	{
-		if (MODE == 0) m16_v0(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 1) m16_v4(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 2) m16_v8(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 3) m16_v12(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 4) m16_v16(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 5) m16_v24(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 6) v8_only(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 7) pk8_only(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 8) m4_v0(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 9) m4_v8(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 10) m4_v16(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-		if (MODE == 11) m4_pk8(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
+		if (MODE == 0) m16_v0(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 1) m16_v4(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 2) m16_v8(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 3) m16_v12(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 4) m16_v16(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 5) m16_v24(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 6) v8_only(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 7) pk8_only(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 8) m4_v0(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 9) m4_v8(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 10) m4_v16(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 11) m4_pk8(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 14) m4_ds8(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 15) m4_ds2(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 16) m4_sa8(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+		if (MODE == 17) ds8_only(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
 		if (MODE == 12) // two waves per SIMD: role 0 = 2x MFMA16 per iter, role 1 = 8 VALU per iter
 		{
-			if (role == 0) m16_v0(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-			else v8_only(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
+			if (role == 0) m16_v0(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+			else v8_only(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
 		}
 		if (MODE == 13) // role 0 = 8x MFMA4, role 1 = 8 VALU
 		{
-			if (role == 0) m4_v0(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
-			else v8_only(c0, c1, v0, v1, v2, v3, p0, p1, a, b);
+			if (role == 0) m4_v0(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
+			else v8_only(c0, c1, v0, v1, v2, v3, p0, p1, a, b, ldsAddr);
 		}
 	}
 	const long long t1 = __builtin_readcyclecounter();
@@ -117,6 +131,11 @@ int main()
 	run<9>("8x mfma4 + 8 valu", 64, 0, d, dc);
 	run<10>("8x mfma4 + 16 valu", 64, 0, d, dc);
 	run<11>("8x mfma4 + 8 pk_fma", 64, 0, d, dc);
+	run<14>("8x mfma4 + 8 ds_read_b128 (broadcast)", 64, 0, d, dc);
+	run<15>("8x mfma4 + 2 ds_read_b128", 64, 0, d, dc);
+	run<16>("8x mfma4 + 8 salu", 64, 0, d, dc);
+	run<17>("8 ds_read_b128 only", 64, 0, d, dc);
+	run<14>("8x mfma4 + 8 ds_read, 8 waves", 512, 0, d, dc);
 	run<0>("2x mfma16, 8 waves (2/SIMD)", 512, 0, d, dc);
 	run<6>("8 valu, 8 waves (2/SIMD)", 512, 0, d, dc);
 	run<12>("split: mfma16 wave + valu wave per SIMD", 512, 1, d, dc);
