@@ -36,7 +36,7 @@ namespace na
 
 #ifndef NA_ABL
 #define NA_ABL 0 // ablation bit mask for tuning builds only (tools/ablate.sh); 0 in the product.  1: no activation math, 2: no MFMA,
-                 // 4: no history loads / ring stores, 8: no barrier, 16: no weight staging
+                 // 4: no history loads / ring stores, 8: no barrier, 16: no weight staging, 32: staging loads but no LDS writes, 64: LDS writes but no loads
 #endif
 		constexpr int OOB = (int)0x80000000;
 		constexpr int STAGE_INTS = (int)(sizeof(WnStage) / sizeof(int));
@@ -255,7 +255,7 @@ namespace na
 		// WaveNetLayerT::Process (WaveNet.h:462-494) for one frame per lane
 		template <int G, int WPS, bool PF>
 		__device__ __forceinline__ void LayerFr(const WnStage& sd, const f32x4* wl, CFloat vec, const f32x4* xbCur, f32x4* xbNext,
-			__amdgpu_buffer_rsrc_t srsrc, int inPos0, int outPos0, int n, int f, int wave, int lane, float cond, float (&xc)[MAXC], float (&hd)[MAXC],
+			__amdgpu_buffer_rsrc_t srsrc, int inPos0, int outPos0, int n, int nSt, int f, int wave, int lane, float cond, float (&xc)[MAXC], float (&hd)[MAXC],
 			const f32x4 (&hcur)[HPF][G], bool haveCur)
 		{
 			constexpr int C = 4 * G;
@@ -345,8 +345,8 @@ namespace na
 					xc[4 * og] = y[og].x; xc[4 * og + 1] = y[og].y; xc[4 * og + 2] = y[og].z; xc[4 * og + 3] = y[og].w;
 				}
 			}
-			if (PF) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, (sd.flags & WN_FLAG_PUBLISH) ? n : 0, f);
-			else if (sd.flags & WN_FLAG_PUBLISH) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, n, f);
+			if (PF) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, (sd.flags & WN_FLAG_PUBLISH) ? nSt : 0, f);
+			else if (sd.flags & WN_FLAG_PUBLISH) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, nSt, f);
 		}
 
 		__device__ __forceinline__ void PublishAny(int G, const float (&x)[MAXC], f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int pos0, int R,
@@ -380,16 +380,21 @@ namespace na
 
 		// Stages the NEXT stage's A-operand block: global -> registers at the start of a stage (before the stage's ring stores:
 		// gfx950 has one vmcnt for loads and stores), registers -> the other LDS weight buffer at its end.
-		template <int WPS>
+		template <int NWAVES>
 		struct WeightStager
 		{
-			static constexpr int NTHREADS = 64 * WPS;
-			static constexpr int WCOPY = 3; // float4 per thread in flight (3 * 128 * 16 B = 6 KB >= any official stage; larger blocks use the tail loop)
+			static constexpr int NTHREADS = 64 * NWAVES;
+			static constexpr int WCOPY = (384 + NTHREADS - 1) / NTHREADS; // float4 per thread in flight (>= 6 KB per workgroup >= any official stage; larger blocks use the tail loop)
 			f32x4 w[WCOPY];
 
 			__device__ __forceinline__ void Begin(__amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn)
 			{
-				if (NA_ABL & 16) return;
+				if (NA_ABL & (16 | 64))
+				{
+#pragma unroll
+					for (int c = 0; c < WCOPY; c++) w[c] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+					return;
+				}
 				const int nextF4 = sdn.a4_floats / 4;
 #pragma unroll
 				for (int c = 0; c < WCOPY; c++)
@@ -401,7 +406,11 @@ namespace na
 
 			__device__ __forceinline__ void End(f32x4* wlNext, __amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn)
 			{
-				if (NA_ABL & 16) return;
+				if (NA_ABL & (16 | 32))
+				{
+					if (NA_ABL & 32) asm volatile("" :: "v"(w[0]), "v"(w[WCOPY - 1]));
+					return;
+				}
 				const int nextF4 = sdn.a4_floats / 4;
 #pragma unroll
 				for (int c = 0; c < WCOPY; c++)
@@ -413,14 +422,20 @@ namespace na
 			}
 		};
 
-		// tuning aid (see NA_DebugSetTraceBuffer): trace[((stage * 4 + point) * WPS) + wave] = shader clock, workgroup `traceBlock` only
+		// tuning aid (see NA_DebugSetTraceBuffer): trace[((stage * 4 + point) * waves) + wave] = shader clock, workgroup `traceBlock` only.
+		// Compiled in only with -DNA_FR_TRACE (make SUFFIX=_trace EXTRA=-DNA_FR_TRACE): a conditional store inside the layer loop makes
+		// the compiler's vmcnt waits conservative.
+#ifdef NA_FR_TRACE
 #define FR_TRACE(point) \
-	if (trace != nullptr && (int)blockIdx.x == traceBlock && lane == 0) trace[((s * 4 + (point)) * WPS) + wave] = (long long)__builtin_readcyclecounter()
+	if (trace != nullptr && (int)blockIdx.x == traceBlock && lane == 0) trace[((s * 4 + (point)) * (WPS * SPB)) + waveAll] = (long long)__builtin_readcyclecounter()
+#else
+#define FR_TRACE(point) (void)0
+#endif
 
 		// consecutive WaveNet layer stages with the same channel-group count
-		template <int G, int WPS, bool PF>
+		template <int G, int WPS, bool PF, int SPB>
 		__device__ __forceinline__ void RunLayers(int& s, WnStage& sd, int& cur, const WnStage* __restrict__ stages, int nstages, f32x4* wbuf, int maxA4F4,
-			__amdgpu_buffer_rsrc_t wrsrc, CFloat wvec, f32x4* xbuf, __amdgpu_buffer_rsrc_t srsrc, int myPos, int n, int f, int wave, int lane, float cond,
+			__amdgpu_buffer_rsrc_t wrsrc, CFloat wvec, f32x4* xbuf, __amdgpu_buffer_rsrc_t srsrc, int myPos, int n, int nSt, int f, int wave, int waveAll, int lane, float cond,
 			float (&xc)[MAXC], float (&hd)[MAXC], long long* __restrict__ trace, int traceBlock)
 		{
 			constexpr int NTB = WPS * 4;
@@ -443,7 +458,7 @@ namespace na
 				if (s + 1 < nstages) sdn = LoadStage(stages, s + 1);
 				const f32x4* wl = wbuf + (s & 1) * maxA4F4;
 				f32x4* wlNext = wbuf + ((s + 1) & 1) * maxA4F4;
-				WeightStager<WPS> stager;
+				WeightStager<WPS * SPB> stager;
 				stager.Begin(wrsrc, sdn);
 				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
 				const int inPos0 = __builtin_amdgcn_readlane(myPos, sd.ring_id);
@@ -459,7 +474,7 @@ namespace na
 					const int off = (haveNext && t < sdn.ksize - 1) ? f - shiftN : 0;
 					if (PF) LoadHistory<G>(hnext[t], srsrc, sdn.ring_off, off, nextPos0, sdn.ring_frames);
 				}
-				LayerFr<G, WPS, PF>(sd, wl, wvec + sd.vec_off * 4, xbuf + cur * (NTB * 64), xbuf + (cur ^ 1) * (NTB * 64), srsrc, inPos0, outPos0, n, f, wave,
+				LayerFr<G, WPS, PF>(sd, wl, wvec + sd.vec_off * 4, xbuf + cur * (NTB * 64), xbuf + (cur ^ 1) * (NTB * 64), srsrc, inPos0, outPos0, n, nSt, f, wave,
 					lane, cond, xc, hd, hcur, haveCur);
 #pragma unroll
 				for (int t = 0; t < HPF; t++)
@@ -470,35 +485,44 @@ namespace na
 				FR_TRACE(1);
 				stager.End(wlNext, wrsrc, sdn);
 				FR_TRACE(2);
-				BlockBarrier<WPS>();
+				BlockBarrier<WPS * SPB>();
 				FR_TRACE(3);
 				sd = sdn;
 				s++;
 			} while (s < nstages && sd.type == WN_ST_LAYER && sd.G == G);
 		}
 
-		// grid = active streams of one model; block = WPS waves of 64 frames (WPS = 2: 128-frame blocks).
+		// grid = active streams of one model / SPB; workgroup = SPB streams x WPS waves of 64 frames (WPS = 2: 128-frame blocks).  The SPB
+		// streams of a workgroup share one staged copy of the weights (4x less L2->LDS traffic and staging work per wave at SPB = 4).
 		// Per stage: issue the loads of the NEXT stage's A-operand block first (before this stage's ring stores: gfx950 has one
 		// vmcnt for loads and stores), compute, park the block in the other LDS weight buffer, meet at an LDS-only barrier.
-		// dynamic LDS: xbuf[2][WPS*4 tiles * 64] float4 | wbuf[2][maxA4Floats/4] float4
-		template <int WPS, bool PF>
-		__global__ void __launch_bounds__(64 * WPS) WaveNetFrameKernel(const WnStage* __restrict__ stages, const float* __restrict__ wpack,
+		// dynamic LDS: xbuf[SPB][2][WPS*4 tiles * 64] float4 | wbuf[2][maxA4Floats/4] float4
+		template <int WPS, bool PF, int SPB>
+		__global__ void __launch_bounds__(64 * WPS * SPB) WaveNetFrameKernel(const WnStage* __restrict__ stages, const float* __restrict__ wpack,
 			const float* __restrict__ wpkGlobal, const int* __restrict__ ringFrames, int nstages, int nrings, int stateF4, int maxA4F4, int wpkFloats, float headScale,
 			f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows, const float* __restrict__ in,
-			float* __restrict__ out, long inStride, long outStride, int n, long long* __restrict__ trace, int traceBlock)
+			float* __restrict__ out, long inStride, long outStride, int n, int numStreams, long long* __restrict__ trace, int traceBlock)
 		{
-			constexpr int NTB = WPS * 4; // tiles in the block
+			constexpr int NTB = WPS * 4; // tiles in one stream's block
 			extern __shared__ __attribute__((aligned(16))) char smem[];
-			f32x4* xbuf = reinterpret_cast<f32x4*>(smem); // [2][NTB*64]
-			f32x4* wbuf = xbuf + 2 * NTB * 64;            // [2][maxA4F4]
-			constexpr int NTHREADS = 64 * WPS;
+			constexpr int NTHREADS = 64 * WPS * SPB;
 
 			const int lane = threadIdx.x & 63;
-			const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int waveAll = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int sub = waveAll / WPS;  // stream within the workgroup
+			const int wave = waveAll % WPS; // 64-frame part of the stream's block
 			const int f = wave * 64 + lane; // this lane's frame in the block
+			f32x4* xbuf = reinterpret_cast<f32x4*>(smem) + sub * (2 * NTB * 64);  // [2][NTB*64] per stream
+			f32x4* wbuf = reinterpret_cast<f32x4*>(smem) + SPB * (2 * NTB * 64);  // [2][maxA4F4], shared
 
-			const int slot = slots[blockIdx.x];
-			const int row = rows[blockIdx.x];
+			// a partial last workgroup: the surplus waves shadow the last stream (they must keep staging weights and meeting barriers)
+			// but write nothing
+			int sidx = (int)blockIdx.x * SPB + sub;
+			const bool live = sidx < numStreams;
+			if (!live) sidx = numStreams - 1;
+			const int nSt = live ? n : 0;
+			const int slot = slots[sidx];
+			const int row = rows[sidx];
 			f32x4* st = state + (size_t)slot * (size_t)stateF4;
 			int* header = reinterpret_cast<int*>(st);
 			const int myPos = header[lane]; // lane r holds the write cursor of ring r
@@ -518,7 +542,7 @@ namespace na
 			const __amdgpu_buffer_rsrc_t wrsrc = MakeRsrc(wpkGlobal, (unsigned)wpkFloats * 4u);
 			WnStage sd = LoadStage(stages, 0);
 			for (int i = threadIdx.x; i < sd.a4_floats / 4; i += NTHREADS) wbuf[i] = BufLoad(wrsrc, (sd.a4_off / 4 + i) * 16);
-			BlockBarrier<WPS>();
+			BlockBarrier<WPS * SPB>();
 
 			int cur = 0;
 			int s = 0;
@@ -528,10 +552,10 @@ namespace na
 				// per-frame state (xc, hd) stays in fixed registers across layers (no phi copies at the stage-type branches).
 				if (sd.type == WN_ST_LAYER)
 				{
-					if (sd.G == 4) RunLayers<4, WPS, PF>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
-					else if (sd.G == 3) RunLayers<3, WPS, PF>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
-					else if (sd.G == 2) RunLayers<2, WPS, PF>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
-					else RunLayers<1, WPS, PF>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, f, wave, lane, cond, xc, hd, trace, traceBlock);
+					if (sd.G == 4) RunLayers<4, WPS, PF, SPB>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, nSt, f, wave, waveAll, lane, cond, xc, hd, trace, traceBlock);
+					else if (sd.G == 3) RunLayers<3, WPS, PF, SPB>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, nSt, f, wave, waveAll, lane, cond, xc, hd, trace, traceBlock);
+					else if (sd.G == 2) RunLayers<2, WPS, PF, SPB>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, nSt, f, wave, waveAll, lane, cond, xc, hd, trace, traceBlock);
+					else RunLayers<1, WPS, PF, SPB>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, nSt, f, wave, waveAll, lane, cond, xc, hd, trace, traceBlock);
 					continue;
 				}
 
@@ -540,7 +564,7 @@ namespace na
 				if (s + 1 < nstages) sdn = LoadStage(stages, s + 1);
 				const f32x4* wl = wbuf + (s & 1) * maxA4F4;
 				f32x4* wlNext = wbuf + ((s + 1) & 1) * maxA4F4;
-				WeightStager<WPS> stager;
+				WeightStager<WPS * SPB> stager;
 				stager.Begin(wrsrc, sdn);
 				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
 				const int inPos0 = (sd.ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.ring_id) : 0;
@@ -553,7 +577,7 @@ namespace na
 				{
 #pragma unroll
 					for (int c = 0; c < MAXC; c++) xc[c] = vec[48 + c] * cond; // :637 with InputSize == 1
-					PublishAny(sd.out_G, xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, n, f);
+					PublishAny(sd.out_G, xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, nSt, f);
 					cur ^= 1;
 				}
 				else if (sd.type == WN_ST_ARRAY_LINK)
@@ -574,7 +598,7 @@ namespace na
 						hd[4 * og] = hn[og].x; hd[4 * og + 1] = hn[og].y; hd[4 * og + 2] = hn[og].z; hd[4 * og + 3] = hn[og].w;
 						xc[4 * og] = xn[og].x; xc[4 * og + 1] = xn[og].y; xc[4 * og + 2] = xn[og].z; xc[4 * og + 3] = xn[og].w;
 					}
-					PublishAny(sd.out_G, xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, n, f);
+					PublishAny(sd.out_G, xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, nSt, f);
 					cur ^= 1;
 				}
 				else if (sd.type == WN_ST_HEAD_DENSE_OUT)
@@ -583,29 +607,29 @@ namespace na
 					CFloat wh = wpk + sd.pk_w1_off;
 #pragma unroll
 					for (int c = 0; c < MAXC; c++) o = __builtin_fmaf(wh[c], hd[c], o);
-					if (f < n) out[(size_t)row * outStride + f] = headScale * o; // :793-798
+					if (f < nSt) out[(size_t)row * outStride + f] = headScale * o; // :793-798
 				}
 				else // WN_ST_HEAD_CONV_OUT
 				{
-					PublishAny(sd.out_G, hd, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, n, f);
+					PublishAny(sd.out_G, hd, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, nSt, f);
 					cur ^= 1;
-					BlockBarrier<WPS>();
+					BlockBarrier<WPS * SPB>();
 					const float bias = (sd.flags & WN_FLAG_BIAS) ? vec[0] : 0.0f;
 					float o;
 					if (sd.G == 4) o = HeadConvPk<4>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
 					else if (sd.G == 3) o = HeadConvPk<3>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
 					else if (sd.G == 2) o = HeadConvPk<2>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
 					else o = HeadConvPk<1>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
-					if (f < n) out[(size_t)row * outStride + f] = headScale * o;
+					if (f < nSt) out[(size_t)row * outStride + f] = headScale * o;
 				}
 				stager.End(wlNext, wrsrc, sdn);
-				BlockBarrier<WPS>();
+				BlockBarrier<WPS * SPB>();
 				sd = sdn;
 				s++;
 			}
 
 			// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
-			if (wave == 0 && lane < nrings)
+			if (wave == 0 && live && lane < nrings)
 			{
 				const int R = ringFrames[lane];
 				int p = myPos + n;
@@ -614,16 +638,27 @@ namespace na
 			}
 		}
 
-		template <int WPS, bool PF>
+		template <int WPS, bool PF, int SPB>
 		static hipError_t Launch(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
 			long inStride, long outStride, int n, hipStream_t stream)
 		{
 			const int maxA4F4 = (m.max_a4_floats + 3) / 4;
-			const size_t lds = (size_t)2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16;
-			if (lds > 64 * 1024) return hipErrorInvalidValue;
-			hipLaunchKernelGGL((WaveNetFrameKernel<WPS, PF>), dim3((unsigned)numStreams), dim3(64 * WPS), lds, stream, m.stages, m.wpack, m.wpk, m.ring_frames,
-				m.nstages, m.nrings, m.state_f4, maxA4F4, m.wpk_floats, m.head_scale, reinterpret_cast<f32x4*>(state), slots, rows, in, out, inStride, outStride, n, GetWaveNetTraceBuffer(),
-				[]() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
+			const size_t lds = (size_t)SPB * 2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16;
+			if (lds > 160 * 1024) return hipErrorInvalidValue;
+			auto kernel = WaveNetFrameKernel<WPS, PF, SPB>;
+			if (lds > 64 * 1024)
+			{
+				static size_t granted = 0; // per instantiation
+				if (lds > granted)
+				{
+					const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+					if (e != hipSuccess) return e;
+					granted = lds;
+				}
+			}
+			hipLaunchKernelGGL(kernel, dim3((unsigned)((numStreams + SPB - 1) / SPB)), dim3(64 * WPS * SPB), lds, stream, m.stages, m.wpack, m.wpk, m.ring_frames,
+				m.nstages, m.nrings, m.state_f4, maxA4F4, m.wpk_floats, m.head_scale, reinterpret_cast<f32x4*>(state), slots, rows, in, out, inStride, outStride, n,
+				numStreams, GetWaveNetTraceBuffer(), []() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
 			return hipGetLastError();
 		}
 	}
@@ -634,11 +669,18 @@ namespace na
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > WN_MAX_FRAMES) return hipErrorInvalidValue;
 		static const bool prefetch = getenv("NA_FR_PF") ? atoi(getenv("NA_FR_PF")) != 0 : true; // tuning knob: cross-layer history prefetch
+		static const int spbEnv = getenv("NA_FR_SPB") ? atoi(getenv("NA_FR_SPB")) : 0;            // tuning knob: streams per workgroup (1, 2, 4)
+		// streams per workgroup: two streams share one staged copy of the weights once there are enough streams to cover all 256 CUs
+		// (measured 1024 x Standard: SPB 1 / 2 / 4 = 74.8 / 73.6 / 75.1 us -- at 4 the 8-wave barrier skew eats the saving)
+		const int spb = spbEnv > 0 ? spbEnv : (numStreams >= 512 ? 2 : 1);
+		const size_t ldsWeights = (size_t)2 * ((m.max_a4_floats + 3) / 4) * 16;
 		if (n > 64)
 		{
-			if (prefetch) return fr::Launch<2, true>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			return fr::Launch<2, false>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			if (!prefetch) return fr::Launch<2, false, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			if (spb >= 4 && ldsWeights + 4 * 16384 <= 160 * 1024) return fr::Launch<2, true, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			if (spb >= 2) return fr::Launch<2, true, 2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			return fr::Launch<2, true, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 		}
-		return fr::Launch<1, false>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		return fr::Launch<1, false, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 	}
 }
