@@ -7,12 +7,14 @@
 //   * lane = one audio frame, a wave = 64 consecutive frames, a workgroup = the 1-2 waves of one stream's block;
 //   * every lane holds ALL channels of its frame in registers; mat-muls are chains of v_mfma_f32_4x4x1_16b_f32:
 //     16 independent 4x4 outer products per instruction, block b = lanes 4b..4b+3 = frames 4b..4b+3.  B operand = one
-//     input channel of the lane's frame (a plain VGPR), A operand = W[4*og + (lane&3)][c] (the same 4 weights in every
-//     block), result = 4 output channels of the lane's own frame.  Operands and results are in the SAME lane = frame layout,
-//     so a layer runs conv -> activation -> 1x1 -> residual entirely in registers, with no padding: an 8-channel layer
-//     issues exactly half the MFMAs of a 16-channel one and the activation only touches real channels.
-//   * the A operands of a stage (4.3 KB for a 16-channel layer) are staged into LDS one stage ahead and read back as
-//     broadcast float4s.
+//     input channel of the lane's frame (a plain VGPR).  A operand: register w[og] holds W[4*og + (lane&3)][c = lane>>2],
+//     i.e. the weights of 16 input channels spread over the 16 blocks, and MFMA number c is issued with CBSZ=4 / ABID=c so
+//     that block c's four A values are broadcast to every block (probe: tools/microbench/mfma_cbsz_probe.hip).  Result = 4
+//     output channels of the lane's own frame.  Operands and results are in the SAME lane = frame layout, so a layer runs
+//     conv -> activation -> 1x1 -> residual entirely in registers, with no padding: an 8-channel layer issues exactly half
+//     the MFMAs of a 16-channel one and the activation only touches real channels.
+//   * the A operands of a stage (4.3 KB for a 16-channel layer) are staged into LDS one stage ahead; a tap costs ONE LDS read
+//     per lane (16 B for 16 channels) for its C*C/4 MFMAs.
 //
 // Why not the 16x16x4 tile mapping (wavenet_kernels.hip) everywhere: measured on MI355X (tools/microbench/mfma_valu_overlap.hip)
 // f32 MFMA runs at the f32 VALU rate and does NOT overlap with VALU work on the same SIMD, so every padded MFMA row and
@@ -204,33 +206,49 @@ namespace na
 			}
 		}
 
-		// acc[og] += W[4og..4og+3][0..CIN) * x   for this lane's frame.  wl: LDS image [og][cq][row i][4 c] (see PackConvA4);
-		// a4 = &wl[... + (lane & 3)] so that lane reads its row; one float4 = the weights of 4 consecutive input channels.
-		template <int CIN, int COUT>
-		__device__ __forceinline__ void DenseMfma(f32x4 (&acc)[COUT / 4], const f32x4* a4, const float (&x)[CIN])
+		// the ABID field is an immediate: unroll over the input channel at compile time
+		template <int CIN, int COUT, int CI>
+		__device__ __forceinline__ void DenseMfmaRegs(f32x4 (&acc)[COUT / 4], const float (&w)[COUT / 4], const float (&x)[CIN])
 		{
-			constexpr int NCQ = CIN / 4;
+			if constexpr (CI < CIN)
+			{
+#pragma unroll
+				for (int og = 0; og < COUT / 4; og++) acc[og] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[og], x[CI], acc[og], 4, CI, 0);
+				DenseMfmaRegs<CIN, COUT, CI + 1>(acc, w, x);
+			}
+		}
+
+		// acc[og] += W[4og..4og+3][0..CIN) * x   for this lane's frame.  a: this lane's COUT/4 floats of the tap's LDS image (see
+		// PackConvA4): register w[og] holds W[4og + (lane&3)][c = lane>>2]; MFMA number c broadcasts block c's A operand to all 16
+		// blocks (CBSZ=4, ABID=c), so one LDS read per tap feeds all CIN*COUT/4 MFMAs of the tap.
+		template <int CIN, int COUT>
+		__device__ __forceinline__ void DenseMfma(f32x4 (&acc)[COUT / 4], const float* a, const float (&x)[CIN])
+		{
+			constexpr int NOG = COUT / 4;
+			static_assert(CIN <= 16, "one A register covers at most 16 input channels");
 			if (NA_ABL & 2)
 			{
 #pragma unroll
-				for (int og = 0; og < COUT / 4; og++) acc[og].x += x[og];
+				for (int og = 0; og < NOG; og++) acc[og].x += x[og];
 				return;
 			}
-#pragma unroll
-			for (int cq = 0; cq < NCQ; cq++)
+			float w[NOG];
+			if constexpr (NOG == 4)
 			{
-				f32x4 w[COUT / 4];
-#pragma unroll
-				for (int og = 0; og < COUT / 4; og++) w[og] = a4[(og * NCQ + cq) * 4];
-#pragma unroll
-				for (int og = 0; og < COUT / 4; og++) acc[og] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[og].x, x[4 * cq + 0], acc[og], 0, 0, 0);
-#pragma unroll
-				for (int og = 0; og < COUT / 4; og++) acc[og] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[og].y, x[4 * cq + 1], acc[og], 0, 0, 0);
-#pragma unroll
-				for (int og = 0; og < COUT / 4; og++) acc[og] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[og].z, x[4 * cq + 2], acc[og], 0, 0, 0);
-#pragma unroll
-				for (int og = 0; og < COUT / 4; og++) acc[og] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[og].w, x[4 * cq + 3], acc[og], 0, 0, 0);
+				const f32x4 v = *reinterpret_cast<const f32x4*>(a);
+				w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 			}
+			else if constexpr (NOG == 2)
+			{
+				const f32x2 v = *reinterpret_cast<const f32x2*>(a);
+				w[0] = v.x; w[1] = v.y;
+			}
+			else
+			{
+#pragma unroll
+				for (int og = 0; og < NOG; og++) w[og] = a[og];
+			}
+			DenseMfmaRegs<CIN, COUT, 0>(acc, w, x);
 		}
 
 		// this lane's frame of a layer output -> LDS block image (in-block taps of the next layer) and the next layer's
@@ -261,8 +279,8 @@ namespace na
 			constexpr int C = 4 * G;
 			const int K = sd.ksize;
 			const int d = sd.dilation;
-			const f32x4* a4 = wl + (lane & 3);
-			const f32x4* vl = wl + (K + 1) * (C * C / 4); // conv bias | mixin | 1x1 bias (tail of the staged block, see BuildWaveNetPlan)
+			const float* a4 = reinterpret_cast<const float*>(wl) + lane * G; // this lane's A operands, tap stride 64*G floats
+			const f32x4* vl = wl + (K + 1) * (16 * G);                       // conv bias | mixin | 1x1 bias (tail of the staged block, see BuildWaveNetPlan)
 
 			// acc = conv bias (:288-289) + W_mix * cond (:471)
 			f32x4 acc[G];
@@ -286,7 +304,7 @@ namespace na
 						const int shift = d * (K - 1 - k);
 						float x[C];
 						FetchFramePre<G>(x, xbCur, f - shift, hcur[k]);
-						DenseMfma<C, C>(acc, a4 + k * (C * C / 4), x);
+						DenseMfma<C, C>(acc, a4 + k * (64 * G), x);
 					}
 				}
 				kFirst = HPF;
@@ -297,13 +315,13 @@ namespace na
 				const int lo = wave * 64 - shift;
 				float x[C];
 				FetchFrame<G>(x, xbCur, srsrc, sd.ring_off, f - shift, lo, lo + 63, inPos0, sd.ring_frames);
-				DenseMfma<C, C>(acc, a4 + k * (C * C / 4), x);
+				DenseMfma<C, C>(acc, a4 + k * (64 * G), x);
 			}
 			{
 				float x[C];
 #pragma unroll
 				for (int c = 0; c < C; c++) x[c] = xc[c];
-				DenseMfma<C, C>(acc, a4 + (K - 1) * (C * C / 4), x);
+				DenseMfma<C, C>(acc, a4 + (K - 1) * (64 * G), x);
 			}
 
 			// activation (:473-480), head accumulate (:482)
@@ -338,7 +356,7 @@ namespace na
 #pragma unroll
 				for (int og = 0; og < G; og++)
 					y[og] = vl[2 * G + og] + f32x4{ xc[4 * og], xc[4 * og + 1], xc[4 * og + 2], xc[4 * og + 3] };
-				DenseMfma<C, C>(y, a4 + K * (C * C / 4), z);
+				DenseMfma<C, C>(y, a4 + K * (64 * G), z);
 #pragma unroll
 				for (int og = 0; og < G; og++)
 				{
@@ -590,8 +608,8 @@ namespace na
 						hn[og] = (sd.flags & WN_FLAG_BIAS) ? f32x4{ vec[4 * og], vec[4 * og + 1], vec[4 * og + 2], vec[4 * og + 3] } : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 						xn[og] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 					}
-					DenseMfma<MAXC, MAXC>(hn, wl + (lane & 3), hd);
-					DenseMfma<MAXC, MAXC>(xn, wl + 64 + (lane & 3), xc);
+					DenseMfma<MAXC, MAXC>(hn, reinterpret_cast<const float*>(wl) + lane * 4, hd);
+					DenseMfma<MAXC, MAXC>(xn, reinterpret_cast<const float*>(wl) + 256 + lane * 4, xc);
 #pragma unroll
 					for (int og = 0; og < 4; og++)
 					{

@@ -178,32 +178,31 @@ namespace na
 				return off;
 			}
 
-			// A operands of v_mfma_f32_4x4x1_16b_f32 for the frame kernel: lane l of every 4-lane block supplies row (l & 3), so
-			// the image is [tap][out group og][in quad cq][row i][4 in channels]: lane reads one float4 at index
-			// ((tap*NOG + og)*NCQ + cq)*4 + (l & 3).  Flat source conv [(o*cin + c)*K + tap], dense [o*cin + c].
-			int PackConvA4(int wOff, int cin, int cout, int ksize, int CPin, int CPout)
+			// A operands of v_mfma_f32_4x4x1_16b_f32 for the frame kernel.  The kernel issues the MFMA with CBSZ=4 / ABID=c: the 4 lanes of
+			// block c supply the A operand of ALL 16 blocks, so ONE register per (tap, out group) carries the weights of 16 input channels:
+			// lane l holds W[4*og + (l & 3)][c = l >> 2].  Image: [tap][lane 0..63][og 0..G-1] floats (a lane reads its G floats as one
+			// ds_read_b128/b64/b32).  Flat source conv [(o*cin + c)*K + tap], dense [o*cin + c].
+			int PackConvA4(int wOff, int cin, int cout, int ksize, int G)
 			{
-				const int nog = CPout / 4, ncq = CPin / 4;
-				const int off = AllocPk(ksize * CPin * CPout);
+				const int off = AllocPk(ksize * 64 * G);
 				for (int k = 0; k < ksize; k++)
-					for (int o = 0; o < cout; o++)
-						for (int c = 0; c < cin; c++)
+					for (int lane = 0; lane < 64; lane++)
+						for (int og = 0; og < G; og++)
 						{
-							const size_t idx = ((((size_t)k * nog + o / 4) * ncq + c / 4) * 4 + (o % 4)) * 4 + (c % 4);
-							plan.wpk[(size_t)off + idx] = W(wOff + (o * cin + c) * ksize + k);
+							const int o = 4 * og + (lane & 3), c = lane >> 2;
+							if (o < cout && c < cin) plan.wpk[(size_t)off + ((size_t)k * 64 + lane) * G + og] = W(wOff + (o * cin + c) * ksize + k);
 						}
 				return off;
 			}
 
-			int PackDenseA4(int wOff, int cin, int cout, int CPin, int CPout)
+			int PackDenseA4(int wOff, int cin, int cout, int G)
 			{
-				const int ncq = CPin / 4;
-				const int off = AllocPk(CPin * CPout);
-				for (int o = 0; o < cout; o++)
-					for (int c = 0; c < cin; c++)
+				const int off = AllocPk(64 * G);
+				for (int lane = 0; lane < 64; lane++)
+					for (int og = 0; og < G; og++)
 					{
-						const size_t idx = ((((size_t)(o / 4)) * ncq + c / 4) * 4 + (o % 4)) * 4 + (c % 4);
-						plan.wpk[(size_t)off + idx] = W(wOff + o * cin + c);
+						const int o = 4 * og + (lane & 3), c = lane >> 2;
+						if (o < cout && c < cin) plan.wpk[(size_t)off + (size_t)lane * G + og] = W(wOff + o * cin + c);
 					}
 				return off;
 			}
@@ -314,8 +313,8 @@ namespace na
 						st.w2_off = PackDense(rechOff, cfg.inputSize, C);
 						st.pk_w1_off = PackDensePk(prevHeadW, prev.channels, prev.headSize, 16, 16);
 						st.pk_w2_off = PackDensePk(rechOff, cfg.inputSize, C, 16, 16);
-						st.a4_off = PackDenseA4(prevHeadW, prev.channels, prev.headSize, 16, 16); // [head dense | rechannel], 16x16 each
-						PackDenseA4(rechOff, cfg.inputSize, C, 16, 16);
+						st.a4_off = PackDenseA4(prevHeadW, prev.channels, prev.headSize, 4); // [head dense | rechannel], padded to 16x16 each
+						PackDenseA4(rechOff, cfg.inputSize, C, 4);
 						st.a4_floats = 2 * 256;
 						SetOutRing(st, layerRing[a][0]);
 						st.flags |= WN_FLAG_PUBLISH;
@@ -343,8 +342,8 @@ namespace na
 						st.w1_off = PackDense(w1, C, C);
 						st.pk_conv_off = PackConvPk(wconv, C, C, K, 4 * st.G, 4 * st.G);
 						st.pk_w1_off = PackDensePk(w1, C, C, 4 * st.G, 4 * st.G);
-						st.a4_off = PackConvA4(wconv, C, C, K, 4 * st.G, 4 * st.G);       // [conv taps | 1x1], one contiguous block
-						PackDenseA4(w1, C, C, 4 * st.G, 4 * st.G);
+						st.a4_off = PackConvA4(wconv, C, C, K, st.G);       // [conv taps | 1x1 | vectors], one contiguous block
+						PackDenseA4(w1, C, C, st.G);
 						{
 							// tail of the block: conv bias | mixin | 1x1 bias, 4G floats each, read back from LDS as broadcast float4s
 							const int CP = 4 * st.G;
@@ -356,7 +355,7 @@ namespace na
 								plan.wpk[(size_t)tail + 2 * CP + c] = W(b1 + c);
 							}
 						}
-						st.a4_floats = (K + 1) * (4 * st.G) * (4 * st.G) + 12 * st.G;
+						st.a4_floats = (K + 1) * 64 * st.G + 12 * st.G;
 						SetRing(st, layerRing[a][l]);
 						if (cfg.activation == ACT_LEAKYRELU) st.flags |= WN_FLAG_LEAKY;
 						// NeedOutput=false for the very last layer (WaveNet.h:643,785); for a single-array model the
