@@ -3,7 +3,7 @@
 
 Workload (BASELINE.json configs[1]): NAM A1 WaveNet 'Standard', 1024 batched streams per GPU,
 128-sample buffers, FP32.  One "step" = one pass of the hot path over one buffer of every stream
-(one WaveNetBlockKernel launch over 1024 streams x 128 samples), inputs already resident in HBM.
+(one WaveNetFrameKernel launch over 1024 streams x 128 samples), inputs already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
@@ -216,7 +216,7 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_sample": bytes_per_sample,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "kernel": "LstmBlockKernel" if args.workload.startswith("lstm") else "WaveNetBlockKernel",
+                "kernel": "LstmWaveKernel" if args.workload.startswith("lstm") else "WaveNetFrameKernel",
             },
             "roofline_mfma_f32": {
                 "achieved": achieved_tflops,
