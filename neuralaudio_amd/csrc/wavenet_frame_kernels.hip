@@ -450,22 +450,127 @@ namespace na
 #define FR_TRACE(point) (void)0
 #endif
 
-		// consecutive WaveNet layer stages with the same channel-group count
-		template <int G, int WPS, bool PF, int SPB>
-		__device__ __forceinline__ void RunLayers(int& s, WnStage& sd, int& cur, const WnStage* __restrict__ stages, int nstages, f32x4* wbuf, int maxA4F4,
-			__amdgpu_buffer_rsrc_t wrsrc, CFloat wvec, f32x4* xbuf, __amdgpu_buffer_rsrc_t srsrc, int myPos, int n, int nSt, int f, int wave, int waveAll, int lane, float cond,
-			float (&xc)[MAXC], float (&hd)[MAXC], long long* __restrict__ trace, int traceBlock)
+		// everything a stage needs that does not change from stage to stage
+		struct FrCtx
+		{
+			const WnStage* __restrict__ stages;
+			int nstages;
+			f32x4* wbuf;   // [2][maxA4F4] staged A images
+			int maxA4F4;
+			__amdgpu_buffer_rsrc_t wrsrc; // wpk as a buffer (weight staging)
+			CFloat wvec;   // wpack (bias vectors of the non-layer stages), scalar loads
+			CFloat wpk;    // wpk, scalar loads (head weights)
+			f32x4* xbuf;   // this stream's [2][NTB*64] block images
+			__amdgpu_buffer_rsrc_t srsrc; // this stream's state
+			int myPos;     // lane r: write cursor of ring r
+			int n, nSt;    // frames in the block; frames this wave may store (0 for a shadow wave)
+			int f, wave, waveAll, lane;
+			float cond;
+			float* __restrict__ out;
+			size_t outBase;
+			float headScale;
+			long long* __restrict__ trace;
+			int traceBlock;
+		};
+
+		// One non-layer stage (rechannel / array link / head), including the staging of the next stage's weights and the closing barrier.
+		template <int WPS, int SPB, bool HEADS>
+		__device__ __forceinline__ void OtherStage(const FrCtx& cx, int& s, WnStage& sd, const WnStage& sdn, int& cur, float (&xc)[MAXC], float (&hd)[MAXC])
 		{
 			constexpr int NTB = WPS * 4;
-			// history of the first HPF taps of the current layer; loaded once here for the first layer of the run, afterwards one layer ahead
+			const int lane = cx.lane, waveAll = cx.waveAll, f = cx.f;
+			long long* __restrict__ trace = cx.trace;
+			const int traceBlock = cx.traceBlock;
+			(void)waveAll; (void)trace; (void)traceBlock;
+			FR_TRACE(0);
+			const f32x4* wl = cx.wbuf + (s & 1) * cx.maxA4F4;
+			f32x4* wlNext = cx.wbuf + ((s + 1) & 1) * cx.maxA4F4;
+			WeightStager<WPS * SPB> stager;
+			stager.Begin(cx.wrsrc, sdn);
+			const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id) : 0;
+			const int inPos0 = (sd.ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.ring_id) : 0;
+			f32x4* xbNext = cx.xbuf + (cur ^ 1) * (NTB * 64);
+			CFloat vec = cx.wvec + sd.vec_off * 4; // [0..15] conv/dense bias, [48..63] aux
+
+			if (sd.type == WN_ST_RECHANNEL_COND)
+			{
+#pragma unroll
+				for (int c = 0; c < MAXC; c++) xc[c] = vec[48 + c] * cx.cond; // :637 with InputSize == 1
+				PublishAny(sd.out_G, xc, xbNext, cx.srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, cx.nSt, f);
+				cur ^= 1;
+			}
+			else if (sd.type == WN_ST_ARRAY_LINK)
+			{
+				// previous array's headRechannel (K=1, :658-660) and this array's rechannel (:637); weights padded to 16x16
+				f32x4 hn[4], xn[4];
+#pragma unroll
+				for (int og = 0; og < 4; og++)
+				{
+					hn[og] = (sd.flags & WN_FLAG_BIAS) ? f32x4{ vec[4 * og], vec[4 * og + 1], vec[4 * og + 2], vec[4 * og + 3] } : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+					xn[og] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+				}
+				DenseMfma<MAXC, MAXC>(hn, reinterpret_cast<const float*>(wl) + lane * 4, hd);
+				DenseMfma<MAXC, MAXC>(xn, reinterpret_cast<const float*>(wl) + 256 + lane * 4, xc);
+#pragma unroll
+				for (int og = 0; og < 4; og++)
+				{
+					hd[4 * og] = hn[og].x; hd[4 * og + 1] = hn[og].y; hd[4 * og + 2] = hn[og].z; hd[4 * og + 3] = hn[og].w;
+					xc[4 * og] = xn[og].x; xc[4 * og + 1] = xn[og].y; xc[4 * og + 2] = xn[og].z; xc[4 * og + 3] = xn[og].w;
+				}
+				PublishAny(sd.out_G, xc, xbNext, cx.srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, cx.nSt, f);
+				cur ^= 1;
+			}
+			else if (HEADS && sd.type == WN_ST_HEAD_DENSE_OUT)
+			{
+				float o = (sd.flags & WN_FLAG_BIAS) ? vec[0] : 0.0f;
+				CFloat wh = cx.wpk + sd.pk_w1_off;
+#pragma unroll
+				for (int c = 0; c < MAXC; c++) o = __builtin_fmaf(wh[c], hd[c], o);
+				if (f < cx.nSt) cx.out[cx.outBase + f] = cx.headScale * o; // :793-798
+			}
+			else if (HEADS) // WN_ST_HEAD_CONV_OUT
+			{
+				PublishAny(sd.out_G, hd, xbNext, cx.srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, cx.nSt, f);
+				cur ^= 1;
+				BlockBarrier<WPS * SPB>();
+				const float bias = (sd.flags & WN_FLAG_BIAS) ? vec[0] : 0.0f;
+				float o;
+				if (sd.G == 4) o = HeadConvPk<4>(sd, cx.wpk, xbNext, cx.srsrc, inPos0, f, cx.wave, bias);
+				else if (sd.G == 3) o = HeadConvPk<3>(sd, cx.wpk, xbNext, cx.srsrc, inPos0, f, cx.wave, bias);
+				else if (sd.G == 2) o = HeadConvPk<2>(sd, cx.wpk, xbNext, cx.srsrc, inPos0, f, cx.wave, bias);
+				else o = HeadConvPk<1>(sd, cx.wpk, xbNext, cx.srsrc, inPos0, f, cx.wave, bias);
+				if (f < cx.nSt) cx.out[cx.outBase + f] = cx.headScale * o;
+			}
+			FR_TRACE(1);
+			stager.End(wlNext, cx.wrsrc, sdn);
+			FR_TRACE(2);
+			BlockBarrier<WPS * SPB>();
+			FR_TRACE(3);
+			sd = sdn;
+			s++;
+		}
+
+		// A run of consecutive WaveNet layer stages with the same channel-group count G.  With `pre`, sd is the rechannel / array-link
+		// stage in front of the run and sdFirst its first layer: the ring history of that layer is requested BEFORE the pre-stage
+		// computes, so its HBM latency hides behind it (the per-frame state stays in registers typed by G either way).
+		template <int G, int WPS, bool PF, int SPB>
+		__device__ __forceinline__ void RunLayers(const FrCtx& cx, int& s, WnStage& sd, const WnStage& sdFirst, bool pre, int& cur, float (&xc)[MAXC], float (&hd)[MAXC])
+		{
+			constexpr int NTB = WPS * 4;
+			const int lane = cx.lane, waveAll = cx.waveAll, f = cx.f;
+			long long* __restrict__ trace = cx.trace;
+			const int traceBlock = cx.traceBlock;
+			(void)waveAll; (void)trace; (void)traceBlock; (void)lane;
+			// history of the first HPF taps of the current layer; loaded here for the first layer of the run, afterwards one layer ahead
 			f32x4 hcur[HPF][G];
 #pragma unroll
 			for (int t = 0; t < HPF; t++)
 			{
-				const int shift0 = sd.dilation * (sd.ksize - 1 - t);
-				const int off = (PF && t < sd.ksize - 1) ? f - shift0 : 0; // off >= 0 -> nothing is loaded
-				LoadHistory<G>(hcur[t], srsrc, sd.ring_off, off, __builtin_amdgcn_readlane(myPos, sd.ring_id), sd.ring_frames);
+				const int shift0 = sdFirst.dilation * (sdFirst.ksize - 1 - t);
+				const int off = (PF && t < sdFirst.ksize - 1) ? f - shift0 : 0; // off >= 0 -> nothing is loaded
+				LoadHistory<G>(hcur[t], cx.srsrc, sdFirst.ring_off, off, __builtin_amdgcn_readlane(cx.myPos, sdFirst.ring_id), sdFirst.ring_frames);
 			}
+			if (pre) OtherStage<WPS, SPB, false>(cx, s, sd, sdFirst, cur, xc, hd);
 			const bool haveCur = true;
 			do
 			{
@@ -473,27 +578,27 @@ namespace na
 				WnStage sdn = sd;
 				sdn.a4_floats = 0;
 				sdn.type = -1;
-				if (s + 1 < nstages) sdn = LoadStage(stages, s + 1);
-				const f32x4* wl = wbuf + (s & 1) * maxA4F4;
-				f32x4* wlNext = wbuf + ((s + 1) & 1) * maxA4F4;
+				if (s + 1 < cx.nstages) sdn = LoadStage(cx.stages, s + 1);
+				const f32x4* wl = cx.wbuf + (s & 1) * cx.maxA4F4;
+				f32x4* wlNext = cx.wbuf + ((s + 1) & 1) * cx.maxA4F4;
 				WeightStager<WPS * SPB> stager;
-				stager.Begin(wrsrc, sdn);
-				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
-				const int inPos0 = __builtin_amdgcn_readlane(myPos, sd.ring_id);
+				stager.Begin(cx.wrsrc, sdn);
+				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id) : 0;
+				const int inPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
 				// history of the NEXT layer's first HPF taps: issued at the start of this layer (before its ring stores), consumed a layer
 				// later.  Always HPF*G loads, predicated through the offset, so the VMEM count per layer is the same on every path.
 				f32x4 hnext[HPF][G];
-				const bool haveNext = PF && (s + 1 < nstages) && sdn.type == WN_ST_LAYER && sdn.G == G;
-				const int nextPos0 = __builtin_amdgcn_readlane(myPos, haveNext ? sdn.ring_id : 0);
+				const bool haveNext = PF && (s + 1 < cx.nstages) && sdn.type == WN_ST_LAYER && sdn.G == G;
+				const int nextPos0 = __builtin_amdgcn_readlane(cx.myPos, haveNext ? sdn.ring_id : 0);
 #pragma unroll
 				for (int t = 0; t < HPF; t++)
 				{
 					const int shiftN = sdn.dilation * (sdn.ksize - 1 - t);
 					const int off = (haveNext && t < sdn.ksize - 1) ? f - shiftN : 0;
-					if (PF) LoadHistory<G>(hnext[t], srsrc, sdn.ring_off, off, nextPos0, sdn.ring_frames);
+					if (PF) LoadHistory<G>(hnext[t], cx.srsrc, sdn.ring_off, off, nextPos0, sdn.ring_frames);
 				}
-				LayerFr<G, WPS, PF>(sd, wl, wvec + sd.vec_off * 4, xbuf + cur * (NTB * 64), xbuf + (cur ^ 1) * (NTB * 64), srsrc, inPos0, outPos0, n, nSt, f, wave,
-					lane, cond, xc, hd, hcur, haveCur);
+				LayerFr<G, WPS, PF>(sd, wl, cx.wvec + sd.vec_off * 4, cx.xbuf + cur * (NTB * 64), cx.xbuf + (cur ^ 1) * (NTB * 64), cx.srsrc, inPos0, outPos0, cx.n,
+					cx.nSt, f, cx.wave, lane, cx.cond, xc, hd, hcur, haveCur);
 #pragma unroll
 				for (int t = 0; t < HPF; t++)
 #pragma unroll
@@ -501,17 +606,17 @@ namespace na
 						if (PF) hcur[t][cg] = hnext[t][cg];
 				if (sd.flags & WN_FLAG_PUBLISH) cur ^= 1;
 				FR_TRACE(1);
-				stager.End(wlNext, wrsrc, sdn);
+				stager.End(wlNext, cx.wrsrc, sdn);
 				FR_TRACE(2);
 				BlockBarrier<WPS * SPB>();
 				FR_TRACE(3);
 				sd = sdn;
 				s++;
-			} while (s < nstages && sd.type == WN_ST_LAYER && sd.G == G);
+			} while (s < cx.nstages && sd.type == WN_ST_LAYER && sd.G == G);
 		}
 
 		// grid = active streams of one model / SPB; workgroup = SPB streams x WPS waves of 64 frames (WPS = 2: 128-frame blocks).  The SPB
-		// streams of a workgroup share one staged copy of the weights (4x less L2->LDS traffic and staging work per wave at SPB = 4).
+		// streams of a workgroup share one staged copy of the weights.
 		// Per stage: issue the loads of the NEXT stage's A-operand block first (before this stage's ring stores: gfx950 has one
 		// vmcnt for loads and stores), compute, park the block in the other LDS weight buffer, meet at an LDS-only barrier.
 		// dynamic LDS: xbuf[SPB][2][WPS*4 tiles * 64] float4 | wbuf[2][maxA4Floats/4] float4
@@ -527,6 +632,9 @@ namespace na
 
 			const int lane = threadIdx.x & 63;
 			const int waveAll = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef NA_FR_TRACE
+			const long long tEntry = (long long)__builtin_readcyclecounter();
+#endif
 			const int sub = waveAll / WPS;  // stream within the workgroup
 			const int wave = waveAll % WPS; // 64-frame part of the stream's block
 			const int f = wave * 64 + lane; // this lane's frame in the block
@@ -544,10 +652,6 @@ namespace na
 			f32x4* st = state + (size_t)slot * (size_t)stateF4;
 			int* header = reinterpret_cast<int*>(st);
 			const int myPos = header[lane]; // lane r holds the write cursor of ring r
-			const __amdgpu_buffer_rsrc_t srsrc = MakeRsrc(st, (unsigned)stateF4 * 16u);
-			CFloat wpk = (CFloat)wpkGlobal;
-			CFloat wvec = (CFloat)wpack;
-
 			const float cond = (f < n) ? in[(size_t)row * inStride + f] : 0.0f; // WaveNet.h:770 (input -> condition)
 			float xc[MAXC], hd[MAXC];
 #pragma unroll
@@ -557,95 +661,68 @@ namespace na
 				hd[c] = 0.0f; // WaveNet.h:772 headArray.SetZero()
 			}
 
-			const __amdgpu_buffer_rsrc_t wrsrc = MakeRsrc(wpkGlobal, (unsigned)wpkFloats * 4u);
+			FrCtx cx;
+			cx.stages = stages;
+			cx.nstages = nstages;
+			cx.wbuf = wbuf;
+			cx.maxA4F4 = maxA4F4;
+			cx.wrsrc = MakeRsrc(wpkGlobal, (unsigned)wpkFloats * 4u);
+			cx.wvec = (CFloat)wpack;
+			cx.wpk = (CFloat)wpkGlobal;
+			cx.xbuf = xbuf;
+			cx.srsrc = MakeRsrc(st, (unsigned)stateF4 * 16u);
+			cx.myPos = myPos;
+			cx.n = n;
+			cx.nSt = nSt;
+			cx.f = f;
+			cx.wave = wave;
+			cx.waveAll = waveAll;
+			cx.lane = lane;
+			cx.cond = cond;
+			cx.out = out;
+			cx.outBase = (size_t)row * outStride;
+			cx.headScale = headScale;
+			cx.trace = trace;
+			cx.traceBlock = traceBlock;
+
 			WnStage sd = LoadStage(stages, 0);
-			for (int i = threadIdx.x; i < sd.a4_floats / 4; i += NTHREADS) wbuf[i] = BufLoad(wrsrc, (sd.a4_off / 4 + i) * 16);
+			for (int i = threadIdx.x; i < sd.a4_floats / 4; i += NTHREADS) wbuf[i] = BufLoad(cx.wrsrc, (sd.a4_off / 4 + i) * 16);
 			BlockBarrier<WPS * SPB>();
 
 			int cur = 0;
 			int s = 0;
 			while (s < nstages)
 			{
-				// Hot path: runs of WaveNet layers with the same channel-group count execute in their own tight loop, so the
-				// per-frame state (xc, hd) stays in fixed registers across layers (no phi copies at the stage-type branches).
-				if (sd.type == WN_ST_LAYER)
-				{
-					if (sd.G == 4) RunLayers<4, WPS, PF, SPB>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, nSt, f, wave, waveAll, lane, cond, xc, hd, trace, traceBlock);
-					else if (sd.G == 3) RunLayers<3, WPS, PF, SPB>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, nSt, f, wave, waveAll, lane, cond, xc, hd, trace, traceBlock);
-					else if (sd.G == 2) RunLayers<2, WPS, PF, SPB>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, nSt, f, wave, waveAll, lane, cond, xc, hd, trace, traceBlock);
-					else RunLayers<1, WPS, PF, SPB>(s, sd, cur, stages, nstages, wbuf, maxA4F4, wrsrc, wvec, xbuf, srsrc, myPos, n, nSt, f, wave, waveAll, lane, cond, xc, hd, trace, traceBlock);
-					continue;
-				}
-
+				// Hot path: runs of WaveNet layers with the same channel-group count execute in their own tight loop, so the per-frame
+				// state (xc, hd) stays in fixed registers across layers (no phi copies at the stage-type branches).  The rechannel /
+				// array-link stage in front of a run executes inside it (see RunLayers).
 				WnStage sdn = sd;
 				sdn.a4_floats = 0;
+				sdn.type = -1;
 				if (s + 1 < nstages) sdn = LoadStage(stages, s + 1);
-				const f32x4* wl = wbuf + (s & 1) * maxA4F4;
-				f32x4* wlNext = wbuf + ((s + 1) & 1) * maxA4F4;
-				WeightStager<WPS * SPB> stager;
-				stager.Begin(wrsrc, sdn);
-				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.out_ring_id) : 0;
-				const int inPos0 = (sd.ring_id >= 0) ? __builtin_amdgcn_readlane(myPos, sd.ring_id) : 0;
-				f32x4* xbCur = xbuf + cur * (NTB * 64);
-				f32x4* xbNext = xbuf + (cur ^ 1) * (NTB * 64);
-				(void)xbCur;
-				CFloat vec = wvec + sd.vec_off * 4; // [0..15] conv/dense bias, [16..31] mix-in w, [32..47] 1x1 bias, [48..63] aux
-
-				if (sd.type == WN_ST_RECHANNEL_COND)
+				const bool pre = (sd.type == WN_ST_RECHANNEL_COND || sd.type == WN_ST_ARRAY_LINK) && sdn.type == WN_ST_LAYER;
+				if (pre || sd.type == WN_ST_LAYER)
 				{
-#pragma unroll
-					for (int c = 0; c < MAXC; c++) xc[c] = vec[48 + c] * cond; // :637 with InputSize == 1
-					PublishAny(sd.out_G, xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, nSt, f);
-					cur ^= 1;
+					const WnStage& first = pre ? sdn : sd;
+					if (first.G == 4) RunLayers<4, WPS, PF, SPB>(cx, s, sd, first, pre, cur, xc, hd);
+					else if (first.G == 3) RunLayers<3, WPS, PF, SPB>(cx, s, sd, first, pre, cur, xc, hd);
+					else if (first.G == 2) RunLayers<2, WPS, PF, SPB>(cx, s, sd, first, pre, cur, xc, hd);
+					else RunLayers<1, WPS, PF, SPB>(cx, s, sd, first, pre, cur, xc, hd);
+					continue;
 				}
-				else if (sd.type == WN_ST_ARRAY_LINK)
-				{
-					// previous array's headRechannel (K=1, :658-660) and this array's rechannel (:637); weights padded to 16x16
-					f32x4 hn[4], xn[4];
-#pragma unroll
-					for (int og = 0; og < 4; og++)
-					{
-						hn[og] = (sd.flags & WN_FLAG_BIAS) ? f32x4{ vec[4 * og], vec[4 * og + 1], vec[4 * og + 2], vec[4 * og + 3] } : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-						xn[og] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-					}
-					DenseMfma<MAXC, MAXC>(hn, reinterpret_cast<const float*>(wl) + lane * 4, hd);
-					DenseMfma<MAXC, MAXC>(xn, reinterpret_cast<const float*>(wl) + 256 + lane * 4, xc);
-#pragma unroll
-					for (int og = 0; og < 4; og++)
-					{
-						hd[4 * og] = hn[og].x; hd[4 * og + 1] = hn[og].y; hd[4 * og + 2] = hn[og].z; hd[4 * og + 3] = hn[og].w;
-						xc[4 * og] = xn[og].x; xc[4 * og + 1] = xn[og].y; xc[4 * og + 2] = xn[og].z; xc[4 * og + 3] = xn[og].w;
-					}
-					PublishAny(sd.out_G, xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, nSt, f);
-					cur ^= 1;
-				}
-				else if (sd.type == WN_ST_HEAD_DENSE_OUT)
-				{
-					float o = (sd.flags & WN_FLAG_BIAS) ? vec[0] : 0.0f;
-					CFloat wh = wpk + sd.pk_w1_off;
-#pragma unroll
-					for (int c = 0; c < MAXC; c++) o = __builtin_fmaf(wh[c], hd[c], o);
-					if (f < nSt) out[(size_t)row * outStride + f] = headScale * o; // :793-798
-				}
-				else // WN_ST_HEAD_CONV_OUT
-				{
-					PublishAny(sd.out_G, hd, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, nSt, f);
-					cur ^= 1;
-					BlockBarrier<WPS * SPB>();
-					const float bias = (sd.flags & WN_FLAG_BIAS) ? vec[0] : 0.0f;
-					float o;
-					if (sd.G == 4) o = HeadConvPk<4>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
-					else if (sd.G == 3) o = HeadConvPk<3>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
-					else if (sd.G == 2) o = HeadConvPk<2>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
-					else o = HeadConvPk<1>(sd, wpk, xbNext, srsrc, inPos0, f, wave, bias);
-					if (f < nSt) out[(size_t)row * outStride + f] = headScale * o;
-				}
-				stager.End(wlNext, wrsrc, sdn);
-				BlockBarrier<WPS * SPB>();
-				sd = sdn;
-				s++;
+				OtherStage<WPS, SPB, true>(cx, s, sd, sdn, cur, xc, hd);
 			}
 
+#ifdef NA_FR_TRACE
+			{
+				const int s = nstages; // slot after the last stage: [0] = kernel entry, [1] = after the stage loop
+				if (trace != nullptr && (int)blockIdx.x == traceBlock && lane == 0)
+				{
+					trace[((s * 4 + 0) * (WPS * SPB)) + waveAll] = tEntry;
+					trace[((s * 4 + 1) * (WPS * SPB)) + waveAll] = (long long)__builtin_readcyclecounter();
+				}
+			}
+#endif
 			// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
 			if (wave == 0 && live && lane < nrings)
 			{

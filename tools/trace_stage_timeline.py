@@ -18,17 +18,18 @@ x = torch.clamp(0.25 * torch.randn(S, n), -1, 1).to(dev); y = torch.empty_like(x
 for _ in range(5):
     batch.ProcessDevice(x.data_ptr(), y.data_ptr(), n)
 torch.cuda.synchronize()
-nst, waves = 23, int(os.environ.get("NA_TRACE_WAVES", "16"))
+nst, waves = 24, int(os.environ.get("NA_TRACE_WAVES", "4"))  # 23 stages of Standard + 1 slot for kernel entry / exit
 trace = torch.zeros(nst * 4 * waves, dtype=torch.int64, device=dev)
 capi.load_library().NA_DebugSetTraceBuffer(trace.data_ptr())
 batch.ProcessDevice(x.data_ptr(), y.data_ptr(), n)
 torch.cuda.synchronize()
 capi.load_library().NA_DebugSetTraceBuffer(None)
 t = trace.cpu().numpy().reshape(nst, 4, waves).astype(np.float64)
-t0 = t[0, 0].min()
-print("stage  start(min..max)   conv   epi+pub  barrier-wait | per-wave mean cycles; total %.0f cycles" % (t[-1, 3].max() - t0))
-for s in range(nst):
+t0 = t[-1, 0].min()
+print("kernel entry -> exit: %.0f cycles; entry -> stage 0: %.0f; last barrier -> exit: %.0f" % (t[-1, 1].max() - t0, t[0, 0].min() - t0, t[-1, 1].max() - t[-2, 3].max()))
+print("stage  start(min..max)   conv   epi+pub  barrier-wait | per-wave mean cycles")
+for s in range(nst - 1):
     st, cv, ep, br = t[s, 0], t[s, 1], t[s, 2], t[s, 3]
     conv = np.where(cv > 0, cv - st, 0)
     epi = np.where(cv > 0, ep - cv, ep - st)
-    print("%2d  %7.0f..%7.0f  %6.0f  %6.0f  %6.0f   (wave spread at barrier exit %.0f)" % (s, st.min() - t0, st.max() - t0, conv.mean(), epi.mean(), (br - ep).mean(), br.max() - br.min()))
+    print("%2d  %7.0f..%7.0f  %6.0f  %6.0f  %6.0f   stage total %6.0f" % (s, st.min() - t0, st.max() - t0, conv.mean(), epi.mean(), (br - ep).mean(), br.max() - st.min()))
