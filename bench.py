@@ -145,22 +145,32 @@ def main():
         step(i)
     torch.cuda.synchronize(dev)
 
-    # per-launch kernel duration from events on the launch stream
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # Average launch duration from two HIP events on the launch stream bracketing the K timed launches (an event per step would put an
+    # extra timestamp packet between every two launches and stretch the very gaps it measures).
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
     nd.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    ev[0].record(tstream)
+    ev0.record(tstream)
     for i in range(args.steps):
         step(i)
-        ev[i + 1].record(tstream)
+    ev1.record(tstream)
     torch.cuda.synchronize(dev)
     nd.barrier()
     torch.cuda.synchronize(dev)
     elapsed = nd.max_over_ranks(time.perf_counter() - t0, device=dev)
+    kernel_ms_avg = ev0.elapsed_time(ev1) / args.steps
 
-    kernel_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
-    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    # diagnostic only (outside the timed region): per-launch spread from one event per launch
+    nprobe = min(32, args.steps)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(nprobe + 1)]
+    ev[0].record(tstream)
+    for i in range(nprobe):
+        step(i)
+        ev[i + 1].record(tstream)
+    torch.cuda.synchronize(dev)
+    kernel_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(nprobe))
 
     finite = bool(torch.isfinite(y).all().item())
 
