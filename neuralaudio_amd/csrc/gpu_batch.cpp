@@ -159,6 +159,9 @@ namespace na
 			}
 			dSlots.Upload(hSlots, stream);
 			dRows.Upload(hRows, stream);
+			contiguous = !hSlots.empty();
+			for (size_t i = 1; i < hSlots.size() && contiguous; i++)
+				contiguous = hSlots[i] == hSlots[0] + (int)i && hRows[i] == hRows[0] + (int)i;
 			activeDirty = false;
 		}
 
@@ -171,6 +174,7 @@ namespace na
 		std::vector<int> memberRow; // member == state slot
 		std::vector<int> hSlots, hRows;
 		DevArray<int> dSlots, dRows;
+		bool contiguous = false; // active streams are slot0+i / row0+i: kernels may skip the index arrays
 		bool activeDirty = true;
 	};
 
@@ -257,8 +261,8 @@ namespace na
 					const int chunk = (int)std::min<size_t>(n, (size_t)WN_MAX_FRAMES);
 					static const std::string which = getenv("NA_WN_KERNEL") ? getenv("NA_WN_KERNEL") : "frame"; // tuning knob: frame | tile | pk
 					if (which == "frame")
-						CheckHip(LaunchWaveNetFrame(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
-							outStride, chunk, launchStream), "WaveNetFrameKernel");
+						CheckHip(LaunchWaveNetFrame(dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset,
+							inStride, outStride, chunk, launchStream, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0), "WaveNetFrameKernel");
 					else if (which != "pk")
 						CheckHip(LaunchWaveNetBlock(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
 							outStride, chunk, launchStream), "WaveNetBlockKernel");

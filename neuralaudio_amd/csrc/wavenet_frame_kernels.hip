@@ -624,7 +624,7 @@ namespace na
 		__global__ void __launch_bounds__(64 * WPS * SPB) WaveNetFrameKernel(const WnStage* __restrict__ stages, const float* __restrict__ wpack,
 			const float* __restrict__ wpkGlobal, const int* __restrict__ ringFrames, int nstages, int nrings, int stateF4, int maxA4F4, int wpkFloats, float headScale,
 			f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows, const float* __restrict__ in,
-			float* __restrict__ out, long inStride, long outStride, int n, int numStreams, long long* __restrict__ trace, int traceBlock)
+			float* __restrict__ out, long inStride, long outStride, int n, int numStreams, int slot0, int row0, long long* __restrict__ trace, int traceBlock)
 		{
 			constexpr int NTB = WPS * 4; // tiles in one stream's block
 			extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -647,8 +647,8 @@ namespace na
 			const bool live = sidx < numStreams;
 			if (!live) sidx = numStreams - 1;
 			const int nSt = live ? n : 0;
-			const int slot = slots[sidx];
-			const int row = rows[sidx];
+			const int slot = slots ? slots[sidx] : slot0 + sidx;
+			const int row = slots ? rows[sidx] : row0 + sidx;
 			f32x4* st = state + (size_t)slot * (size_t)stateF4;
 			int* header = reinterpret_cast<int*>(st);
 			const int myPos = header[lane]; // lane r holds the write cursor of ring r
@@ -735,7 +735,7 @@ namespace na
 
 		template <int WPS, bool PF, int SPB>
 		static hipError_t Launch(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
-			long inStride, long outStride, int n, hipStream_t stream)
+			long inStride, long outStride, int n, hipStream_t stream, int slot0, int row0)
 		{
 			const int maxA4F4 = (m.max_a4_floats + 3) / 4;
 			const size_t lds = (size_t)SPB * 2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16;
@@ -753,13 +753,13 @@ namespace na
 			}
 			hipLaunchKernelGGL(kernel, dim3((unsigned)((numStreams + SPB - 1) / SPB)), dim3(64 * WPS * SPB), lds, stream, m.stages, m.wpack, m.wpk, m.ring_frames,
 				m.nstages, m.nrings, m.state_f4, maxA4F4, m.wpk_floats, m.head_scale, reinterpret_cast<f32x4*>(state), slots, rows, in, out, inStride, outStride, n,
-				numStreams, GetWaveNetTraceBuffer(), []() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
+				numStreams, slot0, row0, GetWaveNetTraceBuffer(), []() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
 			return hipGetLastError();
 		}
 	}
 
 	hipError_t LaunchWaveNetFrame(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
-		long inStride, long outStride, int n, hipStream_t stream)
+		long inStride, long outStride, int n, hipStream_t stream, int slot0, int row0)
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > WN_MAX_FRAMES) return hipErrorInvalidValue;
@@ -771,11 +771,11 @@ namespace na
 		const size_t ldsWeights = (size_t)2 * ((m.max_a4_floats + 3) / 4) * 16;
 		if (n > 64)
 		{
-			if (!prefetch) return fr::Launch<2, false, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			if (spb >= 4 && ldsWeights + 4 * 16384 <= 160 * 1024) return fr::Launch<2, true, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			if (spb >= 2) return fr::Launch<2, true, 2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			return fr::Launch<2, true, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			if (!prefetch) return fr::Launch<2, false, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream, slot0, row0);
+			if (spb >= 4 && ldsWeights + 4 * 16384 <= 160 * 1024) return fr::Launch<2, true, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream, slot0, row0);
+			if (spb >= 2) return fr::Launch<2, true, 2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream, slot0, row0);
+			return fr::Launch<2, true, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream, slot0, row0);
 		}
-		return fr::Launch<1, false, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		return fr::Launch<1, false, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream, slot0, row0);
 	}
 }

@@ -17,8 +17,10 @@ namespace na
 		float* out, long inStride, long outStride, int n, hipStream_t stream);
 
 	// Same contract, lane = frame kernel on v_mfma_f32_4x4x1_16b_f32 (wavenet_frame_kernels.hip)
+	// slots == nullptr: the active streams are contiguous -- stream i uses state slot slot0 + i and matrix row row0 + i (saves the
+	// kernel a dependent global load before it can touch the stream's state)
 	hipError_t LaunchWaveNetFrame(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
-		float* out, long inStride, long outStride, int n, hipStream_t stream);
+		float* out, long inStride, long outStride, int n, hipStream_t stream, int slot0 = 0, int row0 = 0);
 
 	// tuning aid: device buffer of long long[stages*4*waves] that workgroup 0 stamps with the shader clock (nullptr: off)
 	void SetWaveNetTraceBuffer(long long* deviceBuffer);
