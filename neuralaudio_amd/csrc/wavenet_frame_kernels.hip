@@ -38,7 +38,7 @@ namespace na
 
 #ifndef NA_ABL
 #define NA_ABL 0 // ablation bit mask for tuning builds only (tools/ablate.sh); 0 in the product.  1: no activation math, 2: no MFMA,
-                 // 4: no history loads / ring stores, 8: no barrier, 16: no weight staging, 32: staging loads but no LDS writes, 64: LDS writes but no loads
+                 // 4: no history loads / ring stores, 8: no barrier, 16: no weight staging, 32: staging loads but no LDS writes, 64: LDS writes but no loads, 128: history loads from cache-resident slots, 256: no ring stores
 #endif
 		constexpr int OOB = (int)0x80000000;
 		constexpr int STAGE_INTS = (int)(sizeof(WnStage) / sizeof(int));
@@ -255,12 +255,20 @@ namespace na
 			DenseMfmaRegs<CIN, COUT, 0>(acc, w, x);
 		}
 
-		// this lane's frame of a layer output -> LDS block image (in-block taps of the next layer) and the next layer's
-		// HBM ring (history for LATER blocks: only the last R-128 frames of a block can ever be read back)
+		// this lane's frame of a layer output -> LDS block image (in-block taps of the next layer)
 		template <int G>
-		__device__ __forceinline__ void PublishFrame(const float (&x)[MAXC], f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int pos0, int R,
-			int n, int f)
+		__device__ __forceinline__ void PublishLds(const float (&x)[MAXC], f32x4* xb, int f)
 		{
+#pragma unroll
+			for (int cg = 0; cg < G; cg++) xb[TileIdx(f, G, cg)] = f32x4{ x[4 * cg], x[4 * cg + 1], x[4 * cg + 2], x[4 * cg + 3] };
+		}
+
+		// ... and -> the next layer's HBM ring (history for LATER blocks: only the last R-128 frames of a block can ever be read back).
+		// Always G store instructions (predicated through the offset) so that the VMEM count per layer is fixed.
+		template <int G>
+		__device__ __forceinline__ void StoreRing(const float (&x)[MAXC], __amdgpu_buffer_rsrc_t srsrc, int ringOff, int pos0, int R, int n, int f)
+		{
+			if (NA_ABL & (4 | 256)) return;
 			const int firstKept = n - (R - WN_MAX_FRAMES);
 			unsigned p = (unsigned)(pos0 + f);
 			p = __builtin_elementwise_min(p, p - (unsigned)R); // p >= R ? p - R : p
@@ -268,12 +276,15 @@ namespace na
 			const int addr = (int)((p >> 4) * (unsigned)(G * 256) + (unsigned)(ringOff * 16)) + (int)((p & 15u) << 4);
 			const int soff = keep ? addr : OOB;
 #pragma unroll
-			for (int cg = 0; cg < G; cg++)
-			{
-				const f32x4 v = f32x4{ x[4 * cg], x[4 * cg + 1], x[4 * cg + 2], x[4 * cg + 3] };
-				xb[TileIdx(f, G, cg)] = v;
-				if (!(NA_ABL & 4)) BufStore(srsrc, v, soff + cg * 256);
-			}
+			for (int cg = 0; cg < G; cg++) BufStore(srsrc, f32x4{ x[4 * cg], x[4 * cg + 1], x[4 * cg + 2], x[4 * cg + 3] }, soff + cg * 256);
+		}
+
+		template <int G>
+		__device__ __forceinline__ void PublishFrame(const float (&x)[MAXC], f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int pos0, int R,
+			int n, int f)
+		{
+			PublishLds<G>(x, xb, f);
+			StoreRing<G>(x, srsrc, ringOff, pos0, R, n, f);
 		}
 
 		// WaveNetLayerT::Process (WaveNet.h:462-494) for one frame per lane
@@ -369,6 +380,7 @@ namespace na
 					xc[4 * og] = y[og].x; xc[4 * og + 1] = y[og].y; xc[4 * og + 2] = y[og].z; xc[4 * og + 3] = y[og].w;
 				}
 			}
+			// (deferring the ring store to the start of the next layer was tried: no gain, the cost is the store instructions themselves)
 			if (PF) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, (sd.flags & WN_FLAG_PUBLISH) ? nSt : 0, f);
 			else if (sd.flags & WN_FLAG_PUBLISH) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, nSt, f);
 		}
@@ -468,6 +480,7 @@ namespace na
 			CFloat wpk;    // wpk, scalar loads (head weights)
 			f32x4* xbuf;   // this stream's [2][NTB*64] block images
 			__amdgpu_buffer_rsrc_t srsrc; // this stream's state
+			__amdgpu_buffer_rsrc_t lrsrc; // = srsrc (tuning builds: NA_ABL & 128 redirects the history loads)
 			int myPos;     // lane r: write cursor of ring r
 			int n, nSt;    // frames in the block; frames this wave may store (0 for a shadow wave)
 			int f, wave, waveAll, lane;
@@ -573,7 +586,7 @@ namespace na
 			for (int t = 0; t < HPF; t++)
 			{
 				const int shift0 = sdFirst.dilation * (sdFirst.ksize - 1 - t);
-				LoadHistory<G>(hcur[t], cx.srsrc, sdFirst.ring_off, f, shift0, PF && t < sdFirst.ksize - 1, __builtin_amdgcn_readlane(cx.myPos, sdFirst.ring_id),
+				LoadHistory<G>(hcur[t], cx.lrsrc, sdFirst.ring_off, f, shift0, PF && t < sdFirst.ksize - 1, __builtin_amdgcn_readlane(cx.myPos, sdFirst.ring_id),
 					sdFirst.ring_frames);
 			}
 			if (pre) OtherStage<WPS, SPB, false>(cx, s, sd, sdFirst, cur, xc, hd);
@@ -600,8 +613,9 @@ namespace na
 				for (int t = 0; t < HPF; t++)
 				{
 					const int shiftN = sdn.dilation * (sdn.ksize - 1 - t);
-					if (PF) LoadHistory<G>(hnext[t], cx.srsrc, sdn.ring_off, f, shiftN, haveNext && t < sdn.ksize - 1, nextPos0, sdn.ring_frames);
+					if (PF) LoadHistory<G>(hnext[t], cx.lrsrc, sdn.ring_off, f, shiftN, haveNext && t < sdn.ksize - 1, nextPos0, sdn.ring_frames);
 				}
+
 				LayerFr<G, WPS, PF>(sd, wl, cx.wvec + sd.vec_off * 4, cx.xbuf + cur * (NTB * 64), cx.xbuf + (cur ^ 1) * (NTB * 64), cx.srsrc, inPos0, outPos0, cx.n,
 					cx.nSt, f, cx.wave, lane, cx.cond, xc, hd, hcur, haveCur);
 #pragma unroll
@@ -676,6 +690,7 @@ namespace na
 			cx.wpk = (CFloat)wpkGlobal;
 			cx.xbuf = xbuf;
 			cx.srsrc = MakeRsrc(st, (unsigned)stateF4 * 16u);
+			cx.lrsrc = (NA_ABL & 128) ? MakeRsrc(state + (size_t)(blockIdx.x & 7) * (size_t)stateF4, (unsigned)stateF4 * 16u) : cx.srsrc; // 128: history loads hit 8 hot slots
 			cx.myPos = myPos;
 			cx.n = n;
 			cx.nSt = nSt;
