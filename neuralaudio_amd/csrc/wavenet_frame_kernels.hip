@@ -19,6 +19,7 @@
 // Why not the 16x16x4 tile mapping (wavenet_kernels.hip) everywhere: measured on MI355X (tools/microbench/mfma_valu_overlap.hip)
 // f32 MFMA runs at the f32 VALU rate and does NOT overlap with VALU work on the same SIMD, so every padded MFMA row and
 // every activation evaluated on a padding lane is pure loss; the tile mapping pads 8-channel layers to 16 rows.
+#include <algorithm>
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
@@ -414,47 +415,39 @@ namespace na
 			return acc;
 		}
 
-		// Stages the NEXT stage's A-operand block: global -> registers at the start of a stage (before the stage's ring stores:
-		// gfx950 has one vmcnt for loads and stores), registers -> the other LDS weight buffer at its end.
+		// Stages the NEXT stage's A-operand block into the other LDS weight buffer with LDS-DMA loads (buffer_load_dwordx4 ... lds: lane l's
+		// 16 bytes land at ldsBase + 16 l, no VGPRs, no ds_write), issued at the start of a stage -- before the stage's ring stores, gfx950
+		// has one vmcnt for loads and stores -- and awaited just before the closing barrier.
 		template <int NWAVES>
 		struct WeightStager
 		{
 			static constexpr int NTHREADS = 64 * NWAVES;
-			static constexpr int WCOPY = (384 + NTHREADS - 1) / NTHREADS; // float4 per thread in flight (>= 6 KB per workgroup >= any official stage; larger blocks use the tail loop)
-			f32x4 w[WCOPY];
+			static constexpr int WCOPY = (384 + NTHREADS - 1) / NTHREADS; // float4 per thread (>= 6 KB per workgroup >= any official stage; larger blocks use the tail loop)
 
-			__device__ __forceinline__ void Begin(__amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn)
+			__device__ __forceinline__ void Begin(f32x4* wlNext, __amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn, int waveAll)
 			{
-				if (NA_ABL & (16 | 64))
-				{
-#pragma unroll
-					for (int c = 0; c < WCOPY; c++) w[c] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-					return;
-				}
+				if (NA_ABL & 16) return;
 				const int nextF4 = sdn.a4_floats / 4;
+				const int lane = (int)threadIdx.x & 63;
 #pragma unroll
 				for (int c = 0; c < WCOPY; c++)
 				{
-					const int i = (int)threadIdx.x + c * NTHREADS;
-					w[c] = BufLoad(wrsrc, (c * NTHREADS < nextF4 && i < nextF4) ? (sdn.a4_off / 4 + i) * 16 : OOB);
+					const int i0 = c * NTHREADS + waveAll * 64; // first float4 of this wave's 1 KB slice (wave-uniform)
+					const int i = i0 + lane;
+					__builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(wlNext + i0), 16, (i < nextF4) ? (sdn.a4_off / 4 + i) * 16 : OOB, 0, 0, 0);
 				}
 			}
 
+			// LATER = number of VMEM instructions this wave issued after Begin() on every path (they may stay in flight), or 0
+			template <int LATER>
 			__device__ __forceinline__ void End(f32x4* wlNext, __amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn)
 			{
-				if (NA_ABL & (16 | 32))
-				{
-					if (NA_ABL & 32) asm volatile("" :: "v"(w[0]), "v"(w[WCOPY - 1]));
-					return;
-				}
+				if (NA_ABL & 16) return;
 				const int nextF4 = sdn.a4_floats / 4;
-#pragma unroll
-				for (int c = 0; c < WCOPY; c++)
-				{
-					const int i = (int)threadIdx.x + c * NTHREADS;
-					if (c * NTHREADS < nextF4 && i < nextF4) wlNext[i] = w[c];
-				}
 				for (int i = (int)threadIdx.x + WCOPY * NTHREADS; i < nextF4; i += NTHREADS) wlNext[i] = BufLoad(wrsrc, (sdn.a4_off / 4 + i) * 16); // oversized (A2 K=15)
+				// the DMA data must be in LDS before the closing barrier lets other waves read it; the workgroup release fence only covers
+				// lgkmcnt, so wait on vmcnt here (gfx9 s_waitcnt: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at "don't wait")
+				__builtin_amdgcn_s_waitcnt((LATER & 15) | ((LATER >> 4) << 14) | (7 << 4) | (15 << 8));
 			}
 		};
 
@@ -505,7 +498,7 @@ namespace na
 			const f32x4* wl = cx.wbuf + (s & 1) * cx.maxA4F4;
 			f32x4* wlNext = cx.wbuf + ((s + 1) & 1) * cx.maxA4F4;
 			WeightStager<WPS * SPB> stager;
-			stager.Begin(cx.wrsrc, sdn);
+			stager.Begin(wlNext, cx.wrsrc, sdn, cx.waveAll);
 			const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id) : 0;
 			const int inPos0 = (sd.ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.ring_id) : 0;
 			f32x4* xbNext = cx.xbuf + (cur ^ 1) * (NTB * 64);
@@ -561,7 +554,7 @@ namespace na
 				if (f < cx.nSt) cx.out[cx.outBase + f] = cx.headScale * o;
 			}
 			FR_TRACE(1);
-			stager.End(wlNext, cx.wrsrc, sdn);
+			stager.template End<0>(wlNext, cx.wrsrc, sdn);
 			FR_TRACE(2);
 			BlockBarrier<WPS * SPB>();
 			FR_TRACE(3);
@@ -601,7 +594,7 @@ namespace na
 				const f32x4* wl = cx.wbuf + (s & 1) * cx.maxA4F4;
 				f32x4* wlNext = cx.wbuf + ((s + 1) & 1) * cx.maxA4F4;
 				WeightStager<WPS * SPB> stager;
-				stager.Begin(cx.wrsrc, sdn);
+				stager.Begin(wlNext, cx.wrsrc, sdn, cx.waveAll);
 				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id) : 0;
 				const int inPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
 				// history of the NEXT layer's first HPF taps: issued at the start of this layer (before its ring stores), consumed a layer
@@ -625,7 +618,7 @@ namespace na
 						if (PF) hcur[t][cg] = hnext[t][cg];
 				if (sd.flags & WN_FLAG_PUBLISH) cur ^= 1;
 				FR_TRACE(1);
-				stager.End(wlNext, cx.wrsrc, sdn);
+				stager.template End<PF ? 3 * G : 0>(wlNext, cx.wrsrc, sdn); // PF: 2G history loads + G ring stores follow Begin() on every path
 				FR_TRACE(2);
 				BlockBarrier<WPS * SPB>();
 				FR_TRACE(3);
@@ -757,7 +750,9 @@ namespace na
 		static hipError_t Launch(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
 			long inStride, long outStride, int n, hipStream_t stream, int slot0, int row0)
 		{
-			const int maxA4F4 = (m.max_a4_floats + 3) / 4;
+			// stride of the two LDS weight buffers: the LDS-DMA staging always writes WCOPY * NTHREADS float4 slots (zeros past the block)
+			constexpr int NT = 64 * WPS * SPB;
+			const int maxA4F4 = std::max((m.max_a4_floats + 3) / 4, WeightStager<WPS * SPB>::WCOPY * NT);
 			const size_t lds = (size_t)SPB * 2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16;
 			if (lds > 160 * 1024) return hipErrorInvalidValue;
 			auto kernel = WaveNetFrameKernel<WPS, PF, SPB>;
