@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <fstream>
+#include <cmath>
 #include <sstream>
 #include <stdexcept>
 
@@ -91,6 +92,55 @@ namespace na
 			throw std::runtime_error("WaveNet activation '" + name + "' is not supported by the Internal path");
 		}
 
+		// A2-format features the Internal path has no arithmetic for.  The reference tests them in NAMIsA2Standard
+		// (NeuralModel.cpp:188-317) and hands such files to the NAM Core back-end; without that back-end they cannot be evaluated, so
+		// they are rejected loudly here instead of being mis-evaluated.  (Unlike the reference, a MISSING optional block counts as
+		// inactive: a block that is not described has no weights in the file either.)
+		bool BlockActive(const Json& lc, const char* name)
+		{
+			if (!lc.Contains(name) || !lc.At(name).IsObject()) return false;
+			const Json& b = lc.At(name);
+			return b.Contains("active") && Truthy(b.At("active"));
+		}
+
+		void RejectUnsupportedA2Features(const Json& lc, int channels)
+		{
+			auto fail = [](const std::string& what) {
+				throw std::runtime_error("WaveNet feature not supported by the Internal path (needs the NAM Core back-end): " + what);
+			};
+			if (lc.Contains("bottleneck") && lc.At("bottleneck").IsNumber() && lc.At("bottleneck").AsInt() != channels) fail("bottleneck != channels");
+			if (lc.Contains("secondary_activation") && lc.At("secondary_activation").IsArray())
+				for (size_t i = 0; i < lc.At("secondary_activation").Size(); i++)
+					if (!lc.At("secondary_activation").At(i).IsNull()) fail("secondary_activation");
+			if (lc.Contains("gating_mode") && lc.At("gating_mode").IsArray())
+				for (size_t i = 0; i < lc.At("gating_mode").Size(); i++)
+				{
+					const Json& g = lc.At("gating_mode").At(i);
+					if (!g.IsNull() && !(g.IsString() && g.AsString() == "none")) fail("gating_mode");
+				}
+			if (lc.Contains("layer1x1") && lc.At("layer1x1").IsObject())
+			{
+				const Json& l = lc.At("layer1x1");
+				if (l.Contains("active") && !Truthy(l.At("active"))) fail("layer1x1 inactive");
+				if (l.Contains("groups") && l.At("groups").AsInt() != 1) fail("layer1x1 groups != 1");
+			}
+			for (const char* key : { "head1x1", "conv_pre_film", "conv_post_film", "input_mixin_pre_film", "input_mixin_post_film", "activation_pre_film",
+					 "activation_post_film", "layer1x1_post_film", "head1x1_post_film" })
+				if (BlockActive(lc, key)) fail(key);
+			if (lc.Contains("groups_input") && lc.At("groups_input").AsInt() != 1) fail("groups_input != 1");
+			if (lc.Contains("groups_input_mixin") && lc.At("groups_input_mixin").AsInt() != 1) fail("groups_input_mixin != 1");
+			if (lc.Contains("slimmable") && !lc.At("slimmable").IsNull()) fail("slimmable layers");
+			if (lc.Contains("activation") && lc.At("activation").IsArray())
+				for (size_t i = 0; i < lc.At("activation").Size(); i++)
+				{
+					const Json& a = lc.At("activation").At(i);
+					if (!a.IsObject()) continue;
+					if (a.Contains("type") && a.At("type").AsString() != lc.At("activation").At(0).At("type").AsString()) fail("per-layer activation types differ");
+					// the kernels hard-wire Activation.h:110-118 (slope 0.01)
+					if (a.Contains("negative_slope") && std::fabs(a.At("negative_slope").AsFloat() - 0.01f) > 1e-5f) fail("LeakyReLU negative_slope != 0.01");
+				}
+		}
+
 		// One "layers" entry of a WaveNet config -> WnArrayCfg.
 		// A1 keys (InternalModel.h:204-209): input_size, condition_size, head_size, channels, kernel_size, head_bias, dilations
 		// A2 keys: kernel_sizes[], head{out_channels,kernel_size,bias}, activation[] ...
@@ -106,6 +156,7 @@ namespace na
 			if (lc.Contains("activation")) cfg.activation = ActivationFromJson(lc.At("activation"));
 			if (lc.Contains("kernel_sizes"))
 			{
+				RejectUnsupportedA2Features(lc, cfg.channels);
 				cfg.kernelSizes = IntArray(lc.At("kernel_sizes"));
 				const Json& head = lc.At("head");
 				cfg.headSize = head.At("out_channels").AsInt();
@@ -157,6 +208,13 @@ namespace na
 			auto desc = std::make_shared<ModelDesc>();
 			desc->kind = MODEL_WAVENET;
 			const Json& config = modelJson.At("config");
+			// model-level blocks of the A2 format that only the NAM Core back-end evaluates (NeuralModel.cpp:200-207)
+			if (config.Contains("head") && !config.At("head").IsNull())
+				throw std::runtime_error("WaveNet feature not supported by the Internal path (needs the NAM Core back-end): model-level head");
+			if (config.Contains("condition_dsp"))
+				throw std::runtime_error("WaveNet feature not supported by the Internal path (needs the NAM Core back-end): condition_dsp");
+			if (config.Contains("in_channels") && config.At("in_channels").IsNumber() && config.At("in_channels").AsInt() != 1)
+				throw std::runtime_error("WaveNet feature not supported by the Internal path (needs the NAM Core back-end): in_channels != 1");
 			const Json& layers = config.At("layers");
 			for (size_t i = 0; i < layers.Size(); i++)
 			{

@@ -6,6 +6,7 @@
   * the product never touches oracle/ and fails loudly without a GPU
 """
 import ctypes as C
+import copy
 import json
 import os
 import re
@@ -126,6 +127,40 @@ def test_missing_and_malformed_files(na, tmp_path):
     gru.write_text(json.dumps({"in_shape": [None, None, 1], "layers": [{"type": "gru", "shape": [None, None, 8], "weights": []},
                                                                        {"type": "dense", "shape": [None, None, 1], "weights": []}]}))
     assert loader.CreateFromFile(str(gru)) is None  # keras GRU is RTNeural-only in the reference (NeuralModel.cpp:565-572)
+
+
+def test_a2_features_outside_the_internal_path_are_rejected(na, tmp_path):
+    """NAMIsA2Standard (NeuralModel.cpp:188-317) sends such files to NAM Core; without that back-end they must not load silently."""
+    loader = na.NeuralModelLoader()
+    base = O.load_json("BossWN-a2.nam")["config"]["submodels"][1]["model"]  # a plain A2 WaveNet (ch8)
+
+    def variant(edit):
+        j = copy.deepcopy(base)
+        edit(j["config"]["layers"][0], j["config"])
+        path = tmp_path / "v.nam"
+        path.write_text(json.dumps(j))
+        return str(path)
+
+    assert loader.CreateFromFile(variant(lambda lc, c: None), doPrewarm=False) is not None
+    # optional blocks that are simply absent are fine (they have no weights either)
+    assert loader.CreateFromFile(variant(lambda lc, c: [lc.pop(k) for k in ("conv_pre_film", "head1x1", "slimmable")]), doPrewarm=False) is not None
+    edits = {
+        "head1x1": lambda lc, c: lc["head1x1"].update(active=True),
+        "conv_post_film": lambda lc, c: lc["conv_post_film"].update(active=True),
+        "gating_mode": lambda lc, c: lc.update(gating_mode=["gated"] * len(lc["dilations"])),
+        "secondary_activation": lambda lc, c: lc.update(secondary_activation=[{"type": "Sigmoid"}] * len(lc["dilations"])),
+        "bottleneck": lambda lc, c: lc.update(bottleneck=4),
+        "layer1x1": lambda lc, c: lc["layer1x1"].update(active=False),
+        "groups_input": lambda lc, c: lc.update(groups_input=2),
+        "negative_slope": lambda lc, c: lc["activation"][3].update(negative_slope=0.2),
+        "slimmable": lambda lc, c: lc.update(slimmable={"method": "slice_channels_uniform"}),
+        "model-level head": lambda lc, c: c.update(head={"channels": 8}),
+        "condition_dsp": lambda lc, c: c.update(condition_dsp={"architecture": "WaveNet"}),
+        "in_channels": lambda lc, c: c.update(in_channels=2),
+    }
+    for what, edit in edits.items():
+        with pytest.raises(na.NeuralAudioError, match="NAM Core"):
+            loader.CreateFromFile(variant(edit), doPrewarm=False)
 
 
 def test_unicode_path_through_wchar_entry(na, tmp_path):
