@@ -624,6 +624,104 @@ void na_oracle_lstm_prewarm(na_oracle_lstm* m)
 	for (int b = 0; b < 2048 / 64; b++) na_oracle_lstm_process(m, in, out, 64);
 }
 
+/* ---------------------------------------------------------------- keras GRU (config 4; third-party arithmetic)
+ *
+ * PARITY UNPINNED.  In the reference a keras "gru" model is not evaluated by NeuralAudio's own code but by RTNeural
+ * (deps/RTNeural, an empty submodule here; call sites NeuralAudio/NeuralModel.cpp:565-572 -> RTNeuralModel.h:300,
+ * 417-429: json_parser::parseJson<float, FastMathsProvider>, model->forward per sample, 2048-zero prewarm).  This is a
+ * restatement of the PUBLISHED algorithm of RTNeural's GRULayer / Keras GRU(reset_after=True):
+ *     z = sigma(W_z x + U_z h + b_z0 + b_z1)            kernel [I][3H] and recurrent [H][3H] hold the gate column
+ *     r = sigma(W_r x + U_r h + b_r0 + b_r1)            blocks z | r | c, bias [2][3H] = input row, recurrent row
+ *     c = tanh (W_c x + b_c0 + r o (U_c h + b_c1))
+ *     h = (1 - z) o c + z o h                           zero initial state
+ * with the reference's FastMathsProvider (RTNeuralModel.h:10-31): tanh = Eigen array tanh (an accurate float tanh; libm
+ * tanhf here), sigmoid(x) = (tanh(x/2) + 1) / 2.  tests/test_oracle.py cross-checks it against torch.nn.GRU.
+ */
+struct na_oracle_gru {
+	int num_layers, hidden;
+	float** wi;   /* per layer: row-major [3H][I]  */
+	float** wh;   /* per layer: row-major [3H][H]  */
+	float** bi;   /* per layer: [3H] input bias    */
+	float** bh;   /* per layer: [3H] recurrent bias */
+	float** h;    /* per layer: [H] */
+	float* head_w; float head_b;
+};
+
+static float gru_sigmoid(float x) { return (tanhf(x / 2.0f) + 1.0f) / 2.0f; }
+
+na_oracle_gru* na_oracle_gru_create_keras(int num_layers, int hidden, const float* const* kernels, const float* const* recurrents,
+	const float* const* biases, const float* head_weights, float head_bias)
+{
+	na_oracle_gru* m = (na_oracle_gru*)calloc(1, sizeof(*m));
+	const int H = hidden, R = 3 * hidden;
+	m->num_layers = num_layers; m->hidden = hidden;
+	m->wi = (float**)calloc((size_t)num_layers, sizeof(float*)); m->wh = (float**)calloc((size_t)num_layers, sizeof(float*));
+	m->bi = (float**)calloc((size_t)num_layers, sizeof(float*)); m->bh = (float**)calloc((size_t)num_layers, sizeof(float*));
+	m->h = (float**)calloc((size_t)num_layers, sizeof(float*));
+	for (int l = 0; l < num_layers; l++) {
+		const int I = (l == 0) ? 1 : H;
+		m->wi[l] = (float*)calloc((size_t)R * I, sizeof(float)); m->wh[l] = (float*)calloc((size_t)R * H, sizeof(float));
+		m->bi[l] = (float*)calloc((size_t)R, sizeof(float)); m->bh[l] = (float*)calloc((size_t)R, sizeof(float));
+		m->h[l] = (float*)calloc((size_t)H, sizeof(float));
+		for (int j = 0; j < I; j++) for (int i = 0; i < R; i++) m->wi[l][(size_t)i * I + j] = kernels[l][(size_t)j * R + i];
+		for (int j = 0; j < H; j++) for (int i = 0; i < R; i++) m->wh[l][(size_t)i * H + j] = recurrents[l][(size_t)j * R + i];
+		for (int i = 0; i < R; i++) { m->bi[l][i] = biases[l][i]; m->bh[l][i] = biases[l][R + i]; }
+	}
+	m->head_w = (float*)calloc((size_t)H, sizeof(float));
+	for (int i = 0; i < H; i++) m->head_w[i] = head_weights[i];
+	m->head_b = head_bias;
+	return m;
+}
+
+void na_oracle_gru_free(na_oracle_gru* m)
+{
+	if (!m) return;
+	for (int l = 0; l < m->num_layers; l++) { free(m->wi[l]); free(m->wh[l]); free(m->bi[l]); free(m->bh[l]); free(m->h[l]); }
+	free(m->wi); free(m->wh); free(m->bi); free(m->bh); free(m->h); free(m->head_w); free(m);
+}
+
+static void gru_layer_step(na_oracle_gru* m, int l, const float* x)
+{
+	const int H = m->hidden, I = (l == 0) ? 1 : H;
+	float ai[3 * 64], ah[3 * 64]; /* H <= 64 */
+	float* h = m->h[l];
+	for (int r = 0; r < 3 * H; r++) {
+		float a = 0.0f, b = 0.0f;
+		for (int k = 0; k < I; k++) a += m->wi[l][(size_t)r * I + k] * x[k];
+		for (int k = 0; k < H; k++) b += m->wh[l][(size_t)r * H + k] * h[k];
+		ai[r] = a + m->bi[l][r];
+		ah[r] = b + m->bh[l][r];
+	}
+	for (int u = 0; u < H; u++) {
+		const float z = gru_sigmoid(ai[u] + ah[u]);
+		const float rg = gru_sigmoid(ai[H + u] + ah[H + u]);
+		const float c = tanhf(ai[2 * H + u] + rg * ah[2 * H + u]);
+		ai[u] = (1.0f - z) * c + z * h[u]; /* new h, parked until every unit has read the old one */
+	}
+	for (int u = 0; u < H; u++) h[u] = ai[u];
+}
+
+void na_oracle_gru_process(na_oracle_gru* m, const float* in, float* out, size_t num_samples)
+{
+	const int H = m->hidden;
+	for (size_t s = 0; s < num_samples; s++) {
+		gru_layer_step(m, 0, in + s);
+		for (int l = 1; l < m->num_layers; l++) gru_layer_step(m, l, m->h[l - 1]);
+		const float* h = m->h[m->num_layers - 1];
+		float acc = 0.0f;
+		for (int i = 0; i < H; i++) acc += m->head_w[i] * h[i];
+		out[s] = acc + m->head_b;
+	}
+}
+
+/* RTNeuralModel.h:423-429 */
+void na_oracle_gru_prewarm(na_oracle_gru* m)
+{
+	float in[64], out[64];
+	memset(in, 0, sizeof(in));
+	for (int b = 0; b < 2048 / 64; b++) na_oracle_gru_process(m, in, out, 64);
+}
+
 /* ---------------------------------------------------------------- ModelTest-style timing (cpu_baseline only) */
 
 typedef struct {

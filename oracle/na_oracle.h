@@ -31,6 +31,8 @@
  *     external library that is absent; no stand-in headers are written).  They are covered by
  *     an independent float64 restatement (tests/ref_np.py) and by structural properties
  *     (chunk-size invariance, prewarm == long zero lead-in).
+ *   - keras GRU: **parity unpinned** -- evaluated by RTNeural in the reference (submodule absent); restated from the published
+ *     algorithm and cross-checked against torch.nn.GRU.
  */
 #ifndef NA_ORACLE_H
 #define NA_ORACLE_H
@@ -64,6 +66,7 @@ typedef struct na_oracle_wn_array_cfg {
 
 typedef struct na_oracle_wavenet na_oracle_wavenet;
 typedef struct na_oracle_lstm na_oracle_lstm;
+typedef struct na_oracle_gru na_oracle_gru;
 
 /* scalar math, exposed for unit tests */
 float na_oracle_fast_tanh(float x);
@@ -100,6 +103,14 @@ na_oracle_lstm* na_oracle_lstm_create_keras(int num_layers, int hidden_size, con
 void na_oracle_lstm_free(na_oracle_lstm* m);
 void na_oracle_lstm_prewarm(na_oracle_lstm* m); /* 2048 zeros */
 void na_oracle_lstm_process(na_oracle_lstm* m, const float* in, float* out, size_t num_samples);
+
+/* keras GRU, reset_after form (RTNeural's arithmetic -- absent from the reference tree: PARITY UNPINNED, see na_oracle.c).
+ * kernels[l]: [I][3H], recurrents[l]: [H][3H], biases[l]: [2][3H]; gate column blocks z | r | c; hidden <= 64. */
+na_oracle_gru* na_oracle_gru_create_keras(int num_layers, int hidden_size, const float* const* kernels,
+	const float* const* recurrents, const float* const* biases, const float* head_weights, float head_bias);
+void na_oracle_gru_free(na_oracle_gru* m);
+void na_oracle_gru_prewarm(na_oracle_gru* m); /* 2048 zeros */
+void na_oracle_gru_process(na_oracle_gru* m, const float* in, float* out, size_t num_samples);
 
 /* ModelTest-style timing helpers (Utils/ModelTest/ModelTest.cpp:59-79): run `num_blocks` blocks
  * of `block_size` zeros through `threads` independent copies (one per thread, pthreads);

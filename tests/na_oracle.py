@@ -279,6 +279,59 @@ class OracleLSTM:
             self._h = None
 
 
+class OracleGRU:
+    """keras GRU (reset_after form); RTNeural's arithmetic in the reference -- parity unpinned (see oracle/na_oracle.c)."""
+
+    def __init__(self, model_json, prewarm=True):
+        layers = model_json["layers"]
+        nl = len(layers) - 1
+        hidden = int(layers[0]["shape"][-1])
+        fp = C.POINTER(C.c_float)
+        self._keep = [[np.ascontiguousarray(np.array(layers[i]["weights"][k], dtype=np.float32).ravel()) for i in range(nl)] for k in range(3)]
+        hw = np.ascontiguousarray(np.array(layers[-1]["weights"][0], dtype=np.float32).ravel())
+        hb = float(layers[-1]["weights"][1][0])
+        ptrs = [(fp * nl)(*[_fptr(a) for a in self._keep[k]]) for k in range(3)]
+        L = lib()
+        L.na_oracle_gru_create_keras.restype = C.c_void_p
+        L.na_oracle_gru_create_keras.argtypes = [C.c_int, C.c_int, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), fp, C.c_float]
+        L.na_oracle_gru_process.argtypes = [C.c_void_p, fp, fp, C.c_size_t]
+        L.na_oracle_gru_prewarm.argtypes = [C.c_void_p]
+        L.na_oracle_gru_free.argtypes = [C.c_void_p]
+        self._h = L.na_oracle_gru_create_keras(nl, hidden, ptrs[0], ptrs[1], ptrs[2], _fptr(hw), hb)
+        if prewarm:
+            self.prewarm()
+
+    def prewarm(self):
+        lib().na_oracle_gru_prewarm(self._h)
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty_like(x)
+        lib().na_oracle_gru_process(self._h, _fptr(x), _fptr(y), x.size)
+        return y
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().na_oracle_gru_free(self._h)
+            self._h = None
+
+
+def synth_keras_gru(num_layers, hidden, seed):
+    """A keras/AIDA-X style GRU model json with seeded U(-a, a) weights, a = 1/sqrt(hidden) (no GRU file ships with the reference)."""
+    rng = np.random.default_rng(seed)
+    a = 1.0 / np.sqrt(hidden)
+    layers = []
+    for l in range(num_layers):
+        i = 1 if l == 0 else hidden
+        layers.append({"type": "gru", "activation": "", "shape": [None, None, hidden],
+                       "weights": [rng.uniform(-a, a, (i, 3 * hidden)).round(7).tolist(),
+                                   rng.uniform(-a, a, (hidden, 3 * hidden)).round(7).tolist(),
+                                   rng.uniform(-a, a, (2, 3 * hidden)).round(7).tolist()]})
+    layers.append({"type": "dense", "activation": "", "shape": [None, None, 1],
+                   "weights": [rng.uniform(-a, a, (hidden, 1)).round(7).tolist(), [float(np.round(rng.uniform(-a, a), 7))]]})
+    return {"in_shape": [None, None, 1], "in_skip": 0, "samplerate": 48000.0, "layers": layers}
+
+
 def load_json(name):
     path = name if os.path.isabs(name) else os.path.join(MODELS_DIR, name)
     with open(path) as f:
@@ -309,6 +362,8 @@ def oracle_from_file(name, quality=1.0, math_mode=MATH_FAST, prewarm=True):
             c = j["config"]
             return OracleLSTM.from_nam(int(c["num_layers"]), int(c["hidden_size"]), j["weights"], math_mode, prewarm)
         raise ValueError("unsupported architecture " + j["architecture"])
+    if j["layers"][0]["type"] == "gru":
+        return OracleGRU(j, prewarm)
     return OracleLSTM.from_keras(j, math_mode, prewarm)
 
 

@@ -146,3 +146,31 @@ def _lstm_run(layers, wh, bh, H, x, prewarm, tanh, sigmoid):
 
 def std_sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
+
+
+def gru_forward_keras(model_json, x, prewarm=2048):
+    """keras GRU(reset_after=True) / RTNeural GRULayer in float64 with exact tanh; zero initial state, `prewarm` zeros first."""
+    layers = model_json["layers"]
+    nl = len(layers) - 1
+    H = int(layers[0]["shape"][-1])
+    K = [np.array(layers[i]["weights"][0], dtype=np.float64) for i in range(nl)]  # [I][3H]
+    U = [np.array(layers[i]["weights"][1], dtype=np.float64) for i in range(nl)]  # [H][3H]
+    B = [np.array(layers[i]["weights"][2], dtype=np.float64) for i in range(nl)]  # [2][3H]
+    wh = np.array(layers[-1]["weights"][0], dtype=np.float64).ravel()
+    bh = float(layers[-1]["weights"][1][0])
+    h = [np.zeros(H) for _ in range(nl)]
+    xs = np.concatenate([np.zeros(prewarm), np.asarray(x, dtype=np.float64)])
+    out = np.empty(xs.size)
+    sig = lambda v: 0.5 * (np.tanh(0.5 * v) + 1.0)
+    for t, xv in enumerate(xs):
+        inp = np.array([xv])
+        for l in range(nl):
+            ai = inp @ K[l] + B[l][0]
+            ah = h[l] @ U[l] + B[l][1]
+            z = sig(ai[:H] + ah[:H])
+            r = sig(ai[H:2 * H] + ah[H:2 * H])
+            c = np.tanh(ai[2 * H:] + r * ah[2 * H:])
+            h[l] = (1.0 - z) * c + z * h[l]
+            inp = h[l]
+        out[t] = wh @ h[-1] + bh
+    return out[prewarm:]

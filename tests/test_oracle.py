@@ -226,3 +226,44 @@ def test_oracle_regression_vectors():
             assert np.max(np.abs(y - g[key])) < 1e-6, key
         else:
             assert np.array_equal(y, g[key]), key
+
+
+# ----------------------------------------------------------------------------- keras GRU (RTNeural arithmetic; parity unpinned)
+
+@pytest.mark.parametrize("layers,hidden", [(1, 16), (2, 8), (1, 12)])
+def test_gru_oracle_matches_float64_restatement_and_torch(layers, hidden):
+    import torch
+    j = O.synth_keras_gru(layers, hidden, seed=100 + 10 * layers + hidden)
+    x = O.signal_noise(1024, seed=7)
+    yo = O.OracleGRU(j, prewarm=True).process(x)
+    yr = R.gru_forward_keras(j, x, prewarm=2048)
+    assert O.rms(yo - yr) < 1e-6
+
+    # independent implementation: torch.nn.GRU is the same reset-after cell with gate order (r, z, n) instead of keras' (z, r, c)
+    H = hidden
+    gru = torch.nn.GRU(1, H, num_layers=layers, batch_first=True).double()
+    perm = np.concatenate([np.arange(H, 2 * H), np.arange(0, H), np.arange(2 * H, 3 * H)])
+    with torch.no_grad():
+        for l in range(layers):
+            k, u, b = (np.array(j["layers"][l]["weights"][i], dtype=np.float64) for i in range(3))
+            getattr(gru, "weight_ih_l%d" % l).copy_(torch.from_numpy(k.T[perm].copy()))
+            getattr(gru, "weight_hh_l%d" % l).copy_(torch.from_numpy(u.T[perm].copy()))
+            getattr(gru, "bias_ih_l%d" % l).copy_(torch.from_numpy(b[0][perm].copy()))
+            getattr(gru, "bias_hh_l%d" % l).copy_(torch.from_numpy(b[1][perm].copy()))
+        xs = torch.from_numpy(np.concatenate([np.zeros(2048), x.astype(np.float64)])).reshape(1, -1, 1)
+        hs, _ = gru(xs)
+        wh = torch.from_numpy(np.array(j["layers"][-1]["weights"][0], dtype=np.float64).ravel())
+        yt = (hs[0] @ wh + float(j["layers"][-1]["weights"][1][0])).numpy()[2048:]
+    assert O.rms(yo - yt) < 1e-6
+
+
+def test_gru_oracle_chunking_and_prewarm():
+    j = O.synth_keras_gru(1, 16, seed=5)
+    x = O.signal_sine(700)
+    a = O.OracleGRU(j, prewarm=True).process(x)
+    m = O.OracleGRU(j, prewarm=True)
+    b = np.concatenate([m.process(x[i:i + 37]) for i in range(0, x.size, 37)])
+    assert np.array_equal(a, b)
+    c = O.OracleGRU(j, prewarm=False)
+    c.process(np.zeros(2048, dtype=np.float32))
+    assert np.array_equal(a, c.process(x))
