@@ -317,7 +317,12 @@ namespace na
 			{
 				const LSTMDesc& lstm = d->lstm;
 				if (lstm.numLayers < 1 || lstm.numLayers > LSTM_MAX_LAYERS) throw std::runtime_error("LSTM: unsupported number of layers");
-				if (!LstmHiddenSizeSupported(lstm.hiddenSize))
+				if (lstm.cell == CELL_GRU)
+				{
+					if (!GruShapeSupported(lstm.hiddenSize, lstm.numLayers))
+						throw std::runtime_error("GRU: " + std::to_string(lstm.numLayers) + "x" + std::to_string(lstm.hiddenSize) + " has no gfx950 kernel instance");
+				}
+				else if (!LstmHiddenSizeSupported(lstm.hiddenSize))
 					throw std::runtime_error("LSTM: hidden size " + std::to_string(lstm.hiddenSize) + " has no gfx950 kernel instance");
 				std::vector<float> w;
 				for (int l = 0; l < lstm.numLayers; l++)
@@ -334,6 +339,7 @@ namespace na
 				dW.Upload(w, stream);
 				dInit.Upload(init, stream);
 				dev.w = dW.Get();
+				dev.cell = (lstm.cell == CELL_GRU) ? LSTM_CELL_GRU : LSTM_CELL_LSTM;
 				dev.numLayers = lstm.numLayers;
 				dev.hidden = lstm.hiddenSize;
 				numElems = lstm.numLayers * 2 * lstm.hiddenSize;
@@ -364,8 +370,7 @@ namespace na
 				DevArray<float> sink;
 				sink.Alloc(LSTM_MAX_FRAMES);
 				for (int done = 0; done < 2048; done += LSTM_MAX_FRAMES)
-					CheckHip(LaunchLstmBlock(dev, state.Get(), (int)capacity, list.Get(), rows.Get(), (int)members.size(), dZeros.Get(), sink.Get(),
-						0, 0, LSTM_MAX_FRAMES, stream), "LstmBlockKernel (prewarm)");
+					CheckHip(Launch(list.Get(), rows.Get(), (int)members.size(), dZeros.Get(), sink.Get(), 0, 0, LSTM_MAX_FRAMES, stream), "recurrent kernel (prewarm)");
 				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 			}
 
@@ -378,21 +383,30 @@ namespace na
 				while (n > 0)
 				{
 					const int chunk = (int)std::min<size_t>(n, (size_t)LSTM_MAX_FRAMES);
-					CheckHip(LaunchLstmBlock(dev, state.Get(), (int)capacity, dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset,
-						inStride, outStride, chunk, launchStream), "LstmBlockKernel");
+					CheckHip(Launch(dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "recurrent kernel");
 					offset += (size_t)chunk;
 					n -= (size_t)chunk;
 				}
 			}
 
-			// 8 + 2*4*(state floats)/N bytes per sample
-			double AlgorithmicBytesPerSample(int blockFrames) const override { return 8.0 + 8.0 * numElems / blockFrames; }
+			hipError_t Launch(const int* slots, const int* rows, int count, const float* dIn, float* dOut, long inStride, long outStride, int n, hipStream_t s)
+			{
+				if (dev.cell == LSTM_CELL_GRU) return LaunchGruBlock(dev, state.Get(), (int)capacity, slots, rows, count, dIn, dOut, inStride, outStride, n, s);
+				return LaunchLstmBlock(dev, state.Get(), (int)capacity, slots, rows, count, dIn, dOut, inStride, outStride, n, s);
+			}
+
+			// 8 + 2*4*(state floats)/N bytes per sample (a GRU has no cell state: half of it)
+			double AlgorithmicBytesPerSample(int blockFrames) const override
+			{
+				return 8.0 + 8.0 * (dev.cell == LSTM_CELL_GRU ? numElems / 2 : numElems) / blockFrames;
+			}
 
 			double MacsPerSample() const override
 			{
 				const LSTMDesc& lstm = desc->lstm;
 				double macs = 0.0;
-				for (int l = 0; l < lstm.numLayers; l++) macs += 4.0 * lstm.hiddenSize * ((l == 0 ? 1 : lstm.hiddenSize) + lstm.hiddenSize);
+				const double gates = (lstm.cell == CELL_GRU) ? 3.0 : 4.0;
+				for (int l = 0; l < lstm.numLayers; l++) macs += gates * lstm.hiddenSize * ((l == 0 ? 1 : lstm.hiddenSize) + lstm.hiddenSize);
 				return macs + lstm.hiddenSize;
 			}
 

@@ -1,0 +1,152 @@
+// gru_kernels.hip -- gfx950 kernel for keras GRU models (BASELINE config 4).
+//
+// In the reference a keras "gru" model is evaluated by RTNeural, not by NeuralAudio's own code
+// (NeuralAudio/NeuralModel.cpp:565-572 -> NeuralAudio/RTNeuralModel.h:300, 417-429; the RTNeural submodule is an empty
+// directory in the reference tree).  The arithmetic here is the published GRU(reset_after=True) of Keras / RTNeural's
+// GRULayer with the reference's FastMathsProvider (RTNeuralModel.h:10-31: accurate tanh, sigmoid(x) = (tanh(x/2)+1)/2):
+//     z = sigma(W_z x + U_z h + b_z0 + b_z1);  r = sigma(W_r x + U_r h + b_r0 + b_r1)
+//     c = tanh(W_c x + b_c0 + r o (U_c h + b_c1));  h = (1 - z) o c + z o h
+// PARITY UNPINNED against the reference; the tests check it against a CPU restatement and torch.nn.GRU.
+//
+// Mapping: one wave per stream, lane r owns gate row r of every layer (3H <= 64 rows: z | r | c), weights in VGPRs for
+// the whole block, [x; h] broadcast from LDS, the z / r gates meet the c rows through LDS, the dense head is computed for
+// the whole block after the sample loop (same structure as LstmWaveKernel).
+#include <hip/hip_runtime.h>
+
+#include "lstm_dev.h"
+#include "lstm_launch.h"
+
+namespace na
+{
+	namespace
+	{
+		__device__ __forceinline__ float GruSigmoid(float x) { return (tanhf(x * 0.5f) + 1.0f) * 0.5f; }
+
+		__device__ __forceinline__ void GruWaveSync()
+		{
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+		}
+
+		// this lane's row of one layer: packed per layer as W row-major [3H][I + H], then b_in[3H], then b_rec[3H]
+		template <int H, int I>
+		struct GruRow
+		{
+			float wi[I], wh[H], bi, bh;
+
+			__device__ __forceinline__ void Load(const float* __restrict__ w, int r)
+			{
+				const bool valid = r < 3 * H;
+#pragma unroll
+				for (int k = 0; k < I; k++) wi[k] = valid ? w[(size_t)r * (I + H) + k] : 0.0f;
+#pragma unroll
+				for (int k = 0; k < H; k++) wh[k] = valid ? w[(size_t)r * (I + H) + I + k] : 0.0f;
+				bi = valid ? w[(size_t)3 * H * (I + H) + r] : 0.0f;
+				bh = valid ? w[(size_t)3 * H * (I + H) + 3 * H + r] : 0.0f;
+			}
+		};
+
+		// one layer, one sample: xin[I] and h[H] are LDS vectors, zr[2H] an LDS scratch; h is updated in place
+		template <int H, int I>
+		__device__ __forceinline__ void GruLayerStep(const GruRow<H, I>& row, const float* xin, float* h, float* zr, int lane)
+		{
+			float ai = row.bi, ah = row.bh;
+#pragma unroll
+			for (int k = 0; k < I; k++) ai += row.wi[k] * xin[k];
+#pragma unroll
+			for (int k = 0; k < H; k++) ah += row.wh[k] * h[k];
+			if (lane < 2 * H) zr[lane] = GruSigmoid(ai + ah);
+			GruWaveSync(); // every lane has read the old h; z and r are visible
+			if (lane >= 2 * H && lane < 3 * H)
+			{
+				const int u = lane - 2 * H;
+				const float c = tanhf(ai + zr[H + u] * ah);
+				const float z = zr[u];
+				h[u] = (1.0f - z) * c + z * h[u];
+			}
+			GruWaveSync();
+		}
+
+		// grid = active streams, block = 64 (one wave per stream).  L in {1, 2}; 3H <= 64.
+		template <int H, int L>
+		__global__ void __launch_bounds__(64) GruWaveKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
+			const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
+		{
+			static_assert(3 * H <= 64, "one gate row per lane");
+			constexpr int HP = H + 1;
+			__shared__ float xin[LSTM_MAX_FRAMES];
+			__shared__ float hvec[L][H];
+			__shared__ float zr[2 * H];
+			__shared__ float hout[LSTM_MAX_FRAMES * HP];
+
+			const int lane = threadIdx.x;
+			const int slot = slots[blockIdx.x];
+			const int row = rows[blockIdx.x];
+			const float* inRow = in + (size_t)row * inStride;
+			float* outRow = out + (size_t)row * outStride;
+
+			GruRow<H, 1> row0;
+			row0.Load(m.w + m.layerOff[0], lane);
+			GruRow<H, H> row1;
+			if (L > 1) row1.Load(m.w + m.layerOff[L > 1 ? 1 : 0], lane);
+
+			for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
+#pragma unroll
+			for (int l = 0; l < L; l++)
+				if (lane < H) hvec[l][lane] = state[(size_t)(l * 2 * H + lane) * capacity + slot];
+			GruWaveSync();
+
+			for (int f = 0; f < n; f++)
+			{
+				GruLayerStep<H, 1>(row0, xin + f, hvec[0], zr, lane);
+				if (L > 1) GruLayerStep<H, H>(row1, hvec[0], hvec[L > 1 ? 1 : 0], zr, lane);
+				if (lane < H) hout[f * HP + lane] = hvec[L - 1][lane];
+			}
+			GruWaveSync();
+
+			// dense head for the whole block, lane = sample
+			const float* headW = m.w + m.headOff;
+			for (int f = lane; f < n; f += 64)
+			{
+				float acc = 0.0f;
+#pragma unroll
+				for (int k = 0; k < H; k++) acc += headW[k] * hout[f * HP + k];
+				outRow[f] = acc + headW[H];
+			}
+#pragma unroll
+			for (int l = 0; l < L; l++)
+				if (lane < H) state[(size_t)(l * 2 * H + lane) * capacity + slot] = hvec[l][lane];
+		}
+
+		template <int H, int L>
+		hipError_t LaunchHL(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams, const float* in,
+			float* out, long inStride, long outStride, int n, hipStream_t stream)
+		{
+			hipLaunchKernelGGL((GruWaveKernel<H, L>), dim3((unsigned)numStreams), dim3(64), 0, stream, m, state, capacity, slots, rows, in, out, inStride,
+				outStride, n);
+			return hipGetLastError();
+		}
+	}
+
+	bool GruShapeSupported(int hidden, int numLayers)
+	{
+		return (hidden == 8 || hidden == 12 || hidden == 16 || hidden == 20) && (numLayers == 1 || numLayers == 2);
+	}
+
+	hipError_t LaunchGruBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams, const float* in,
+		float* out, long inStride, long outStride, int n, hipStream_t stream)
+	{
+		if (numStreams <= 0 || n <= 0) return hipSuccess;
+		if (n > LSTM_MAX_FRAMES || !GruShapeSupported(m.hidden, m.numLayers)) return hipErrorInvalidValue;
+#define NA_GRU_CASE(HH) \
+	if (m.hidden == HH) return m.numLayers == 1 ? LaunchHL<HH, 1>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream) \
+												: LaunchHL<HH, 2>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		NA_GRU_CASE(8)
+		NA_GRU_CASE(12)
+		NA_GRU_CASE(16)
+		NA_GRU_CASE(20)
+#undef NA_GRU_CASE
+		return hipErrorInvalidValue;
+	}
+}

@@ -15,11 +15,15 @@ namespace na
 	constexpr int LSTM_MAX_LAYERS = 8;
 	constexpr int LSTM_MAX_FRAMES = 128;
 
+	enum { LSTM_CELL_LSTM = 0, LSTM_CELL_GRU = 1 };
+
 	struct LstmModelDev
 	{
 		// packed per layer l: W row-major [4H][I_l + H] (gate row blocks i,f,g,o -- LSTM.h:33-36), then bias[4H];
 		// after the last layer: head weights [H], head bias [1]
+		// GRU (cell == LSTM_CELL_GRU): per layer W row-major [3H][I_l + H] (gate row blocks z,r,c), then b_in[3H], b_rec[3H]
 		const float* w;
+		int cell;
 		int numLayers;
 		int hidden;
 		int layerOff[LSTM_MAX_LAYERS]; // float offset of layer l's W

@@ -13,6 +13,11 @@ namespace na
 	hipError_t LaunchLstmBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream);
 
+	// keras GRU (gru_kernels.hip): same state layout (only the h half of every layer is used), m.cell == LSTM_CELL_GRU
+	bool GruShapeSupported(int hidden, int numLayers);
+	hipError_t LaunchGruBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
+		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream);
+
 	// state[k*capacity + slot] = init[k] for the listed slots
 	hipError_t LaunchLstmInitState(float* state, int capacity, const int* slots, int numStreams, const float* init, int numElems,
 		hipStream_t stream);

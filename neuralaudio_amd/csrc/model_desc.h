@@ -40,19 +40,23 @@ namespace na
 	struct LSTMLayerDesc
 	{
 		int inputSize = 1;
-		std::vector<float> w;    // row-major [4H][I+H]  (LSTM.h:27)
-		std::vector<float> bias; // [4H]
+		std::vector<float> w;    // row-major [4H][I+H]  (LSTM.h:27); GRU: [3H][I+H], gate row blocks z,r,c
+		std::vector<float> bias; // [4H]; GRU: [6H] = input bias | recurrent bias
 		std::vector<float> h0;   // [H] initial hidden (NAM files carry it, LSTM.h:51-55; keras: zeros)
 		std::vector<float> c0;   // [H]
 	};
 
+	enum RecurrentCell { CELL_LSTM = 0, CELL_GRU = 1 };
+
 	struct LSTMDesc
 	{
+		int cell = CELL_LSTM; // CELL_GRU: keras GRU (RTNeural's arithmetic in the reference, NeuralModel.cpp:565-572)
 		int numLayers = 0;
 		int hiddenSize = 0;
 		std::vector<LSTMLayerDesc> layers;
 		std::vector<float> headWeights; // [H]
 		float headBias = 0.0f;
+		std::vector<float> headBiasVec; // scratch of the keras readers
 		bool isStatic = false;
 	};
 

@@ -317,6 +317,56 @@ namespace na
 			return desc;
 		}
 
+		// keras "gru" stacks + dense head.  The reference runs these on RTNeural (NeuralModel.cpp:565-572, RTNeuralModel.h:300);
+		// weights per layer: kernel [I][3H], recurrent [H][3H], bias [2][3H], gate column blocks z | r | c (Keras reset_after form).
+		std::shared_ptr<ModelDesc> ReadKerasGRU(const Json& modelJson)
+		{
+			const Json& layers = modelJson.At("layers");
+			const size_t numLayers = layers.Size();
+			if (numLayers < 2) return nullptr;
+			const Json& lastLayer = layers.At(numLayers - 1);
+			if (lastLayer.At("type").AsString() != "dense") return nullptr;
+
+			auto desc = std::make_shared<ModelDesc>();
+			desc->kind = MODEL_LSTM;
+			LSTMDesc& gru = desc->lstm;
+			gru.cell = CELL_GRU;
+			gru.numLayers = (int)numLayers - 1;
+			gru.hiddenSize = layers.At(0).At("shape").Back().AsInt();
+			const int H = gru.hiddenSize;
+
+			lastLayer.At("weights").At(0).FlattenNumbers(gru.headWeights);
+			lastLayer.At("weights").At(1).FlattenNumbers(gru.headBiasVec);
+			if ((int)gru.headWeights.size() != H || gru.headBiasVec.size() != 1) return nullptr; // a wider dense head is a generic RTNeural model
+			gru.headBias = gru.headBiasVec[0];
+
+			for (int l = 0; l < gru.numLayers; l++)
+			{
+				const Json& layer = layers.At((size_t)l);
+				if (layer.At("type").AsString() != "gru") return nullptr;
+				if (layer.At("shape").Back().AsInt() != H) return nullptr;
+				std::vector<float> kernel, recurrent, bias;
+				layer.At("weights").At(0).FlattenNumbers(kernel);    // [I][3H]
+				layer.At("weights").At(1).FlattenNumbers(recurrent); // [H][3H]
+				layer.At("weights").At(2).FlattenNumbers(bias);      // [2][3H]
+				LSTMLayerDesc ld;
+				ld.inputSize = (l == 0) ? 1 : H;
+				const int I = ld.inputSize, W = I + H, R = 3 * H;
+				if ((int)kernel.size() != I * R || (int)recurrent.size() != H * R || (int)bias.size() != 2 * R)
+					throw std::runtime_error("keras gru layer has unexpected weight shapes");
+				ld.w.assign((size_t)R * W, 0.0f);
+				for (int j = 0; j < I; j++)
+					for (int i = 0; i < R; i++) ld.w[(size_t)i * W + j] = kernel[(size_t)j * R + i];
+				for (int j = 0; j < H; j++)
+					for (int i = 0; i < R; i++) ld.w[(size_t)i * W + I + j] = recurrent[(size_t)j * R + i];
+				ld.bias = bias;
+				ld.h0.assign((size_t)H, 0.0f);
+				ld.c0.assign((size_t)H, 0.0f);
+				gru.layers.push_back(std::move(ld));
+			}
+			return desc;
+		}
+
 		int OversampleFactor(const Json& modelJson, int externalSampleRate)
 		{
 			// NeuralModel.cpp:92-114
@@ -376,10 +426,12 @@ namespace na
 			ReadKerasConfig(modelJson, model->info);
 			const Json& layers = modelJson.At("layers");
 			const std::string modelType = layers.At(0).At("type").AsString();
-			if (modelType != "lstm") return nullptr; // GRU & co. run on RTNeural in the reference (NeuralModel.cpp:565-572)
+			// "lstm": Internal path (NeuralModel.cpp:526-563); "gru": RTNeural in the reference (:565-572), restated here (parity
+			// unpinned); anything else (conv1d, activations, wider dense stacks ...) needs the generic RTNeural engine
+			if (modelType != "lstm" && modelType != "gru") return nullptr;
 			SubModel sm;
 			sm.info = model->info;
-			sm.desc = ReadKerasLSTM(modelJson);
+			sm.desc = (modelType == "gru") ? ReadKerasGRU(modelJson) : ReadKerasLSTM(modelJson);
 			if (!sm.desc) return nullptr;
 			model->subModels.push_back(sm);
 			model->qualityLevels.push_back({ 1.0f, 0 });

@@ -104,6 +104,37 @@ def test_config4_lstm_2x16_many_streams_and_mixed_with_wavenet(na, loader):
         assert O.rms(y[s] - O.oracle_from_file("BossWN-nano.nam").process(x[s])) < TOL_RMS, s
 
 
+def test_config4_keras_gru_next_to_lstm_2x16(na, loader):
+    """BASELINE configs[3]: LSTM 2x16 + keras GRU (H=16) streams, half/half, in one batch.  GRU = RTNeural's arithmetic in the
+    reference (parity unpinned): checked against the oracle restatement (which test_oracle.py checks against torch.nn.GRU)."""
+    import json
+    w = O.synth_lstm_weights(2, 16, seed=8)
+    lstm = loader.CreateFromString(O.nam_json_lstm(2, 16, w), ".nam", doPrewarm=True)
+    gj = O.synth_keras_gru(1, 16, seed=21)
+    gru = loader.CreateFromString(json.dumps(gj), ".json", doPrewarm=True)
+    assert gru is not None and gru.GetReceptiveFieldSize() == -1
+    b = na.Batch(0)
+    b.AddStreams(lstm, 70)
+    b.AddStreams(gru, 70)
+    n, blocks = 128, 3
+    x = np.stack([O.signal_noise(n * blocks, 300 + s) for s in range(140)])
+    y = _run_blocks(b, x, n)
+    for s in (0, 69):
+        assert O.rms(y[s] - O.OracleLSTM.from_nam(2, 16, w).process(x[s])) < 5e-6, s
+    for s in (70, 100, 139):
+        assert O.rms(y[s] - O.OracleGRU(gj).process(x[s])) < 5e-6, s
+
+
+@pytest.mark.parametrize("layers,hidden", [(1, 16), (2, 8), (1, 12), (2, 20)])
+def test_keras_gru_single_stream_shapes(na, loader, layers, hidden):
+    import json
+    gj = O.synth_keras_gru(layers, hidden, seed=40 + hidden + layers)
+    m = loader.CreateFromString(json.dumps(gj), ".aidax", doPrewarm=True)
+    x = O.signal_sine(1000)
+    y = np.concatenate([m.Process(x[i:i + 100]) for i in range(0, x.size, 100)])
+    assert O.rms(y - O.OracleGRU(gj).process(x)) < 5e-6
+
+
 @pytest.mark.parametrize("sizes", [[1, 15, 16, 17, 63, 64, 65, 127, 128], [300, 5, 129, 128, 1]])
 def test_ragged_buffer_sizes(na, loader, sizes):
     """Any n per call (the reference chunks at 64, InternalModel.h:104-117): 1, tile-straddling, > 128 (multi-launch)."""

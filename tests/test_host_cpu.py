@@ -123,10 +123,18 @@ def test_missing_and_malformed_files(na, tmp_path):
     short.write_text(json.dumps(j))
     m = loader.CreateFromFile(str(short), doPrewarm=False)  # loads; the weight count is checked when device tables are built
     assert m is not None
+    conv = tmp_path / "conv.json"
+    conv.write_text(json.dumps({"in_shape": [None, None, 1], "layers": [{"type": "conv1d", "shape": [None, None, 8], "weights": []},
+                                                                        {"type": "dense", "shape": [None, None, 1], "weights": []}]}))
+    assert loader.CreateFromFile(str(conv)) is None  # generic keras stacks need the RTNeural engine (NeuralModel.cpp:565-572)
     gru = tmp_path / "gru.json"
-    gru.write_text(json.dumps({"in_shape": [None, None, 1], "layers": [{"type": "gru", "shape": [None, None, 8], "weights": []},
-                                                                       {"type": "dense", "shape": [None, None, 1], "weights": []}]}))
-    assert loader.CreateFromFile(str(gru)) is None  # keras GRU is RTNeural-only in the reference (NeuralModel.cpp:565-572)
+    gru.write_text(json.dumps(O.synth_keras_gru(1, 16, seed=3)))
+    g = loader.CreateFromFile(str(gru), doPrewarm=False)  # keras GRU: RTNeural's arithmetic in the reference, restated here
+    assert g is not None and g.GetSampleRate() == 48000.0 and g.GetReceptiveFieldSize() == -1
+    wide = O.synth_keras_gru(1, 16, seed=3)
+    wide["layers"][-1]["weights"] = [[[0.1, 0.2]] * 16, [0.0, 0.0]]  # dense head with 2 outputs: not this path
+    gru.write_text(json.dumps(wide))
+    assert loader.CreateFromFile(str(gru), doPrewarm=False) is None
 
 
 def test_a2_features_outside_the_internal_path_are_rejected(na, tmp_path):
