@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed sustained load before warm-up so the shader clock reaches steady state")
     ap.add_argument("--workload", default="standard",
-                    help="standard (default = the BASELINE metric's config) | feather | nano | a2full | a2lite | lstm1x16 | lstm2x8 | mixed3 "
+                    help="standard (default = the BASELINE metric's config) | feather | nano | a2full | a2lite | lstm1x16 | lstm2x8 | mixed3 | config4 "
                          "(other BASELINE configs, for DESIGN.md numbers; the driver uses the default)")
     args = ap.parse_args()
 
@@ -121,9 +121,21 @@ def main():
     mdir = os.path.dirname(MODEL_FILE)
     files = {"standard": ["BossWN-standard.nam"], "feather": ["BossWN-feather.nam"], "nano": ["BossWN-nano.nam"],
              "a2full": ["BossWN-a2.nam"], "a2lite": ["BossWN-a2.nam"], "lstm1x16": ["BossLSTM-1x16.nam"], "lstm2x8": ["BossLSTM-2x8.nam"],
-             "mixed3": ["BossWN-standard.nam", "BossWN-feather.nam", "BossWN-nano.nam"]}[args.workload]
+             "mixed3": ["BossWN-standard.nam", "BossWN-feather.nam", "BossWN-nano.nam"], "config4": []}[args.workload]
     quality = 0.0 if args.workload == "a2lite" else 1.0
     models = [loader.CreateFromFile(os.path.join(mdir, f), doPrewarm=False) for f in files]
+    if args.workload == "config4":
+        # BASELINE configs[3]: LSTM 2x16 + keras GRU (H=16), half/half; no such files ship with the reference -> seeded U(-a, a) weights
+        rng = np.random.default_rng(4)
+        H, a = 16, 0.25
+        lw = np.concatenate([rng.uniform(-a, a, 4 * H * (1 + H) + 4 * H + 2 * H), rng.uniform(-a, a, 4 * H * 2 * H + 4 * H + 2 * H), rng.uniform(-a, a, H + 1)])
+        lstm = json.dumps({"version": "0.5.4", "architecture": "LSTM", "config": {"input_size": 1, "hidden_size": H, "num_layers": 2},
+                           "weights": [float(v) for v in lw]})
+        gru = json.dumps({"in_shape": [None, None, 1], "layers": [
+            {"type": "gru", "shape": [None, None, H], "weights": [rng.uniform(-a, a, (1, 3 * H)).tolist(), rng.uniform(-a, a, (H, 3 * H)).tolist(),
+                                                                  rng.uniform(-a, a, (2, 3 * H)).tolist()]},
+            {"type": "dense", "shape": [None, None, 1], "weights": [rng.uniform(-a, a, (H, 1)).tolist(), [0.0]]}]})
+        models = [loader.CreateFromString(lstm, ".nam", doPrewarm=False), loader.CreateFromString(gru, ".json", doPrewarm=False)]
     if any(m is None for m in models):
         raise SystemExit("could not load " + str(files))
     # run on torch's current stream so torch.cuda.Event brackets exactly the kernels we launch
@@ -238,7 +250,7 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_sample": bytes_per_sample,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "kernel": "LstmWaveKernel" if args.workload.startswith("lstm") else "WaveNetFrameKernel",
+                "kernel": "LstmDppKernel" if args.workload.startswith("lstm") else ("LstmDppKernel+GruWaveKernel" if args.workload == "config4" else "WaveNetFrameKernel"),
             },
             "roofline_mfma_f32": {
                 "achieved": achieved_tflops,
