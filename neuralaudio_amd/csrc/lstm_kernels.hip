@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "dpp_recurrent.h"
 #include "lstm_dev.h"
 #include "lstm_launch.h"
 
@@ -290,22 +291,6 @@ namespace na
 	//   Each lane sums its row starting at column `unit` and walking down instead of 0..H-1: same products, different rounding order than
 	//   LSTM.h:87-100 (observed difference vs the oracle ~1e-7 RMS, tolerance 5e-6).  tanh divides with v_rcp_f32 like the WaveNet path.
 	// ------------------------------------------------------------------------------------------------------------
-	// acc += sum_n w[n] * h[lane - n within its 16-lane row]: v_fmac_f32 with a DPP row_ror:n source, one instruction per term.
-	// (Written as asm: the compiler keeps a separate v_mov_b32_dpp per term otherwise.  The leading s_nop covers the VALU-write ->
-	// DPP-read hazard on h, which the hazard recognizer cannot see inside an asm block.)
-#define NA_DPP_TERM(N, OP) "v_fmac_f32_dpp %0, %1, %" #OP " row_ror:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-	template <int H>
-	__device__ __forceinline__ void DppDot(float& acc, const float (&w)[H], float h)
-	{
-		static_assert(H == 8 || H == 16, "");
-		acc = __builtin_fmaf(w[0], h, acc);
-		if constexpr (H == 8)
-			asm volatile("s_nop 1\n" NA_DPP_TERM(1, 2) NA_DPP_TERM(2, 3) NA_DPP_TERM(3, 4) NA_DPP_TERM(4, 5) NA_DPP_TERM(5, 6) NA_DPP_TERM(6, 7) NA_DPP_TERM(7, 8) : "+v"(acc) : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
-		else
-			asm volatile("s_nop 1\n" NA_DPP_TERM(1, 2) NA_DPP_TERM(2, 3) NA_DPP_TERM(3, 4) NA_DPP_TERM(4, 5) NA_DPP_TERM(5, 6) NA_DPP_TERM(6, 7) NA_DPP_TERM(7, 8) NA_DPP_TERM(8, 9) NA_DPP_TERM(9, 10) NA_DPP_TERM(10, 11) NA_DPP_TERM(11, 12) NA_DPP_TERM(12, 13) NA_DPP_TERM(13, 14) NA_DPP_TERM(14, 15) NA_DPP_TERM(15, 16) : "+v"(acc) : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
-	}
-#undef NA_DPP_TERM
-
 	__device__ __forceinline__ float LstmRcpTanh(float x)
 	{
 		const float ax = fabsf(x);
@@ -321,16 +306,14 @@ namespace na
 	template <int H>
 	__device__ __forceinline__ void GatherGates(float gv, float& gi, float& gf, float& gg, float& go)
 	{
-		// The swaps are written as asm with both registers in-out: the builtin's second result is mis-folded by this compiler (ROCm 7.2)
-		// when the operands derive from one value (tools/microbench/permlane_probe2.hip stores a[0] twice).  s_nop: VALU write ->
-		// permlane read needs 2 wait states and the hazard recognizer does not look inside asm.
 		int x = __builtin_bit_cast(int, gv);
 		int y = x;
 		if constexpr (H == 16)
 		{
-			asm volatile("s_nop 1\nv_permlane32_swap_b32 %0, %1\n" : "+v"(x), "+v"(y)); // x: rows g0 g1 g0 g1, y: rows g2 g3 g2 g3
+			LaneSwap32(x, y); // x: rows g0 g1 g0 g1, y: rows g2 g3 g2 g3
 			int x2 = x, y2 = y;
-			asm volatile("s_nop 1\nv_permlane16_swap_b32 %0, %1\nv_permlane16_swap_b32 %2, %3\ns_nop 1\n" : "+v"(x), "+v"(x2), "+v"(y), "+v"(y2));
+			LaneSwap16(x, x2); // x: g0 everywhere, x2: g1 everywhere
+			LaneSwap16(y, y2);
 			gi = __builtin_bit_cast(float, x);
 			gf = __builtin_bit_cast(float, x2);
 			gg = __builtin_bit_cast(float, y);
@@ -338,11 +321,11 @@ namespace na
 		}
 		else
 		{
-			asm volatile("s_nop 1\nv_permlane16_swap_b32 %0, %1\ns_nop 1\n" : "+v"(x), "+v"(y)); // x: every row = [g0 | g1], y: every row = [g2 | g3]
-			gi = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xC, false)); // lanes 8..15 of a row <- lanes 0..7
-			gf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0x3, false)); // lanes 0..7 <- lanes 8..15
-			gg = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(y, y, 0x128, 0xF, 0xC, false));
-			go = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(y, y, 0x128, 0xF, 0x3, false));
+			LaneSwap16(x, y); // x: every row = [g0 | g1], y: every row = [g2 | g3]
+			gi = __builtin_bit_cast(float, RowLowHalf(x));
+			gf = __builtin_bit_cast(float, RowHighHalf(x));
+			gg = __builtin_bit_cast(float, RowLowHalf(y));
+			go = __builtin_bit_cast(float, RowHighHalf(y));
 		}
 	}
 
