@@ -135,6 +135,13 @@ namespace na
 		virtual double AlgorithmicBytesPerSample(int blockFrames) const = 0;
 		virtual double MacsPerSample() const = 0;
 		virtual size_t StateBytesPerStream() const = 0;
+		// WaveNet groups on the frame kernel can share ONE launch with other such groups (a heterogeneous batch without stream
+		// fork/join); fills `out` with this group's part of that launch.  Other groups return false.
+		virtual bool FusedLaunchArgs(WnFrameGroup& out)
+		{
+			(void)out;
+			return false;
+		}
 
 		int NumActive() const
 		{
@@ -272,6 +279,21 @@ namespace na
 					offset += (size_t)chunk;
 					n -= (size_t)chunk;
 				}
+			}
+
+			bool FusedLaunchArgs(WnFrameGroup& out) override
+			{
+				static const bool frame = !getenv("NA_WN_KERNEL") || std::string(getenv("NA_WN_KERNEL")) == "frame";
+				if (!frame) return false;
+				SyncActiveLists();
+				out.model = &dev;
+				out.state = state.Get();
+				out.slots = contiguous ? nullptr : dSlots.Get();
+				out.rows = dRows.Get();
+				out.numStreams = (int)hSlots.size();
+				out.slot0 = contiguous ? hSlots[0] : 0;
+				out.row0 = contiguous ? hRows[0] : 0;
+				return out.numStreams > 0;
 			}
 
 			double AlgorithmicBytesPerSample(int blockFrames) const override { return plan.AlgorithmicBytesPerSample(blockFrames); }
@@ -564,7 +586,37 @@ namespace na
 			for (auto& g : groups) g->Process(dIn, dOut, inStride, outStride, n, stream);
 			return;
 		}
-		// mixed batch: the model groups are independent (disjoint rows, disjoint state) -> fork onto per-group side streams
+		// mixed batch, step 1: every WaveNet group on the frame kernel goes into ONE fused launch per <= 128-frame chunk (the
+		// workgroups of all architectures share the chip, no fork/join).  If that covers all active groups we are done.
+		{
+			std::vector<WnFrameGroup> fused;
+			bool all = true;
+			for (auto& g : groups)
+			{
+				if (g->NumActive() == 0) continue;
+				WnFrameGroup a;
+				if (g->FusedLaunchArgs(a)) fused.push_back(a);
+				else all = false;
+			}
+			if (all && !fused.empty())
+			{
+				size_t offset = 0, left = n;
+				while (left > 0)
+				{
+					const int chunk = (int)std::min<size_t>(left, (size_t)WN_MAX_FRAMES);
+					for (size_t first = 0; first < fused.size(); first += WN_FRAME_MAX_GROUPS)
+					{
+						const int count = (int)std::min<size_t>(fused.size() - first, (size_t)WN_FRAME_MAX_GROUPS);
+						CheckHip(LaunchWaveNetFrameFused(fused.data() + first, count, dIn + offset, dOut + offset, inStride, outStride, chunk, stream),
+							"WaveNetFrameKernel (fused)");
+					}
+					offset += (size_t)chunk;
+					left -= (size_t)chunk;
+				}
+				return;
+			}
+		}
+		// step 2 (batches that also hold LSTM / GRU groups): the model groups are independent (disjoint rows, disjoint state) -> fork onto per-group side streams
 		// so their kernels share the GPU, then join back into the batch stream.  The fork/join costs ~5 HIP calls per group,
 		// which would make a buffer host-bound, so the sequence is captured once into a hipGraph and replayed while the call
 		// signature (pointers, n, strides) and the active-stream lists stay the same -- the steady state of a real-time host.

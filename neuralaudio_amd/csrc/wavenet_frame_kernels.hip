@@ -632,12 +632,49 @@ namespace na
 		// Per stage: issue the loads of the NEXT stage's A-operand block first (before this stage's ring stores: gfx950 has one
 		// vmcnt for loads and stores), compute, park the block in the other LDS weight buffer, meet at an LDS-only barrier.
 		// dynamic LDS: xbuf[SPB][2][WPS*4 tiles * 64] float4 | wbuf[2][maxA4Floats/4] float4
-		template <int WPS, bool PF, int SPB>
-		__global__ void __launch_bounds__(64 * WPS * SPB) WaveNetFrameKernel(const WnStage* __restrict__ stages, const float* __restrict__ wpack,
-			const float* __restrict__ wpkGlobal, const int* __restrict__ ringFrames, int nstages, int nrings, int stateF4, int maxA4F4, int wpkFloats, float headScale,
-			f32x4* __restrict__ state, const int* __restrict__ slots, const int* __restrict__ rows, const float* __restrict__ in,
-			float* __restrict__ out, long inStride, long outStride, int n, int numStreams, int slot0, int row0, long long* __restrict__ trace, int traceBlock)
+		// per model group of one (possibly fused) launch; passed by value in the kernarg segment
+		struct FrGroupArgs
 		{
+			const WnStage* stages;
+			const float* wpack;
+			const float* wpk;
+			const int* ringFrames;
+			f32x4* state;
+			const int* slots; // nullptr: contiguous, stream i uses slot0 + i / row0 + i
+			const int* rows;
+			int nstages, nrings, stateF4, wpkFloats;
+			float headScale;
+			int numStreams, slot0, row0;
+			int firstBlock; // workgroups [firstBlock, next group's firstBlock) belong to this group
+		};
+
+		struct FrLaunchArgs
+		{
+			FrGroupArgs g[WN_FRAME_MAX_GROUPS];
+			int numGroups;
+		};
+
+		template <int WPS, bool PF, int SPB>
+		__global__ void __launch_bounds__(64 * WPS * SPB) WaveNetFrameKernel(const FrLaunchArgs args, int maxA4F4, const float* __restrict__ in,
+			float* __restrict__ out, long inStride, long outStride, int n, long long* __restrict__ trace, int traceBlock)
+		{
+			// which model group this workgroup serves (heterogeneous batches run as ONE launch: no stream fork/join, and the
+			// workgroups of all architectures share the chip)
+			int gi = 0;
+			for (int i = 1; i < args.numGroups; i++)
+				if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
+			const FrGroupArgs& ga = args.g[gi];
+			const WnStage* __restrict__ stages = ga.stages;
+			const float* __restrict__ wpack = ga.wpack;
+			const float* __restrict__ wpkGlobal = ga.wpk;
+			const int* __restrict__ ringFrames = ga.ringFrames;
+			f32x4* __restrict__ state = ga.state;
+			const int* __restrict__ slots = ga.slots;
+			const int* __restrict__ rows = ga.rows;
+			const int nstages = ga.nstages, nrings = ga.nrings, stateF4 = ga.stateF4, wpkFloats = ga.wpkFloats;
+			const float headScale = ga.headScale;
+			const int numStreams = ga.numStreams, slot0 = ga.slot0, row0 = ga.row0;
+			const int groupBlock = (int)blockIdx.x - ga.firstBlock;
 			constexpr int NTB = WPS * 4; // tiles in one stream's block
 			extern __shared__ __attribute__((aligned(16))) char smem[];
 			constexpr int NTHREADS = 64 * WPS * SPB;
@@ -655,7 +692,7 @@ namespace na
 
 			// a partial last workgroup: the surplus waves shadow the last stream (they must keep staging weights and meeting barriers)
 			// but write nothing
-			int sidx = (int)blockIdx.x * SPB + sub;
+			int sidx = groupBlock * SPB + sub;
 			const bool live = sidx < numStreams;
 			if (!live) sidx = numStreams - 1;
 			const int nSt = live ? n : 0;
@@ -683,7 +720,7 @@ namespace na
 			cx.wpk = (CFloat)wpkGlobal;
 			cx.xbuf = xbuf;
 			cx.srsrc = MakeRsrc(st, (unsigned)stateF4 * 16u);
-			cx.lrsrc = (NA_ABL & 128) ? MakeRsrc(state + (size_t)(blockIdx.x & 7) * (size_t)stateF4, (unsigned)stateF4 * 16u) : cx.srsrc; // 128: history loads hit 8 hot slots
+			cx.lrsrc = (NA_ABL & 128) ? MakeRsrc(state + (size_t)(groupBlock & 7) * (size_t)stateF4, (unsigned)stateF4 * 16u) : cx.srsrc; // 128: history loads hit 8 hot slots
 			cx.myPos = myPos;
 			cx.n = n;
 			cx.nSt = nSt;
@@ -747,12 +784,28 @@ namespace na
 		}
 
 		template <int WPS, bool PF, int SPB>
-		static hipError_t Launch(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
-			long inStride, long outStride, int n, hipStream_t stream, int slot0, int row0)
+		static hipError_t Launch(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream)
 		{
 			// stride of the two LDS weight buffers: the LDS-DMA staging always writes WCOPY * NTHREADS float4 slots (zeros past the block)
 			constexpr int NT = 64 * WPS * SPB;
-			const int maxA4F4 = std::max((m.max_a4_floats + 3) / 4, WeightStager<WPS * SPB>::WCOPY * NT);
+			FrLaunchArgs args = {};
+			args.numGroups = numGroups;
+			int maxA4F4 = WeightStager<WPS * SPB>::WCOPY * NT;
+			int blocks = 0;
+			for (int i = 0; i < numGroups; i++)
+			{
+				const WnFrameGroup& g = groups[i];
+				const WnModelDev& m = *g.model;
+				FrGroupArgs& a = args.g[i];
+				a.stages = m.stages; a.wpack = m.wpack; a.wpk = m.wpk; a.ringFrames = m.ring_frames;
+				a.state = reinterpret_cast<f32x4*>(g.state); a.slots = g.slots; a.rows = g.rows;
+				a.nstages = m.nstages; a.nrings = m.nrings; a.stateF4 = m.state_f4; a.wpkFloats = m.wpk_floats;
+				a.headScale = m.head_scale;
+				a.numStreams = g.numStreams; a.slot0 = g.slot0; a.row0 = g.row0;
+				a.firstBlock = blocks;
+				blocks += (g.numStreams + SPB - 1) / SPB;
+				maxA4F4 = std::max(maxA4F4, (m.max_a4_floats + 3) / 4);
+			}
 			const size_t lds = (size_t)SPB * 2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16;
 			if (lds > 160 * 1024) return hipErrorInvalidValue;
 			auto kernel = WaveNetFrameKernel<WPS, PF, SPB>;
@@ -766,31 +819,45 @@ namespace na
 					granted = lds;
 				}
 			}
-			hipLaunchKernelGGL(kernel, dim3((unsigned)((numStreams + SPB - 1) / SPB)), dim3(64 * WPS * SPB), lds, stream, m.stages, m.wpack, m.wpk, m.ring_frames,
-				m.nstages, m.nrings, m.state_f4, maxA4F4, m.wpk_floats, m.head_scale, reinterpret_cast<f32x4*>(state), slots, rows, in, out, inStride, outStride, n,
-				numStreams, slot0, row0, GetWaveNetTraceBuffer(), []() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
+			hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WPS * SPB), lds, stream, args, maxA4F4, in, out, inStride, outStride, n,
+				GetWaveNetTraceBuffer(), []() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
 			return hipGetLastError();
 		}
+	}
+
+	hipError_t LaunchWaveNetFrameFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream)
+	{
+		if (n <= 0 || numGroups <= 0) return hipSuccess;
+		if (n > WN_MAX_FRAMES || numGroups > WN_FRAME_MAX_GROUPS) return hipErrorInvalidValue;
+		int total = 0;
+		size_t ldsWeights = 0;
+		for (int i = 0; i < numGroups; i++)
+		{
+			if (groups[i].numStreams <= 0) return hipErrorInvalidValue;
+			total += groups[i].numStreams;
+			ldsWeights = std::max(ldsWeights, (size_t)2 * ((groups[i].model->max_a4_floats + 3) / 4) * 16);
+		}
+		static const bool prefetch = getenv("NA_FR_PF") ? atoi(getenv("NA_FR_PF")) != 0 : true; // tuning knob: cross-layer history prefetch
+		static const int spbEnv = getenv("NA_FR_SPB") ? atoi(getenv("NA_FR_SPB")) : 0;            // tuning knob: streams per workgroup (1, 2, 4)
+		// streams per workgroup: two streams share one staged copy of the weights once there are enough streams to cover all 256 CUs
+		// (measured 1024 x Standard: SPB 1 / 2 / 4 = 61.5 / 61.3 / 65.0 us -- at 4 the 8-wave barrier skew eats the saving)
+		const int spb = spbEnv > 0 ? spbEnv : (total >= 512 ? 2 : 1);
+		if (n > 64)
+		{
+			if (!prefetch) return fr::Launch<2, false, 1>(groups, numGroups, in, out, inStride, outStride, n, stream);
+			if (spb >= 4 && ldsWeights + 4 * 16384 <= 160 * 1024) return fr::Launch<2, true, 4>(groups, numGroups, in, out, inStride, outStride, n, stream);
+			if (spb >= 2) return fr::Launch<2, true, 2>(groups, numGroups, in, out, inStride, outStride, n, stream);
+			return fr::Launch<2, true, 1>(groups, numGroups, in, out, inStride, outStride, n, stream);
+		}
+		return fr::Launch<1, false, 1>(groups, numGroups, in, out, inStride, outStride, n, stream);
 	}
 
 	hipError_t LaunchWaveNetFrame(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
 		long inStride, long outStride, int n, hipStream_t stream, int slot0, int row0)
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
-		if (n > WN_MAX_FRAMES) return hipErrorInvalidValue;
-		static const bool prefetch = getenv("NA_FR_PF") ? atoi(getenv("NA_FR_PF")) != 0 : true; // tuning knob: cross-layer history prefetch
-		static const int spbEnv = getenv("NA_FR_SPB") ? atoi(getenv("NA_FR_SPB")) : 0;            // tuning knob: streams per workgroup (1, 2, 4)
-		// streams per workgroup: two streams share one staged copy of the weights once there are enough streams to cover all 256 CUs
-		// (measured 1024 x Standard: SPB 1 / 2 / 4 = 74.8 / 73.6 / 75.1 us -- at 4 the 8-wave barrier skew eats the saving)
-		const int spb = spbEnv > 0 ? spbEnv : (numStreams >= 512 ? 2 : 1);
-		const size_t ldsWeights = (size_t)2 * ((m.max_a4_floats + 3) / 4) * 16;
-		if (n > 64)
-		{
-			if (!prefetch) return fr::Launch<2, false, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream, slot0, row0);
-			if (spb >= 4 && ldsWeights + 4 * 16384 <= 160 * 1024) return fr::Launch<2, true, 4>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream, slot0, row0);
-			if (spb >= 2) return fr::Launch<2, true, 2>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream, slot0, row0);
-			return fr::Launch<2, true, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream, slot0, row0);
-		}
-		return fr::Launch<1, false, 1>(m, state, slots, rows, numStreams, in, out, inStride, outStride, n, stream, slot0, row0);
+		WnFrameGroup g = { &m, state, slots, rows, numStreams, slot0, row0 };
+		return LaunchWaveNetFrameFused(&g, 1, in, out, inStride, outStride, n, stream);
 	}
 }

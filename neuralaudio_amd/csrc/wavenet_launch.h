@@ -17,6 +17,19 @@ namespace na
 		float* out, long inStride, long outStride, int n, hipStream_t stream);
 
 	// Same contract, lane = frame kernel on v_mfma_f32_4x4x1_16b_f32 (wavenet_frame_kernels.hip)
+	// One launch over several model groups (a heterogeneous batch): workgroups are assigned to the groups in order.
+	constexpr int WN_FRAME_MAX_GROUPS = 8;
+	struct WnFrameGroup
+	{
+		const WnModelDev* model;
+		float* state;
+		const int* slots; // nullptr: contiguous (slot0 + i, row0 + i)
+		const int* rows;
+		int numStreams, slot0, row0;
+	};
+	hipError_t LaunchWaveNetFrameFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream);
+
 	// slots == nullptr: the active streams are contiguous -- stream i uses state slot slot0 + i and matrix row row0 + i (saves the
 	// kernel a dependent global load before it can touch the stream's state)
 	hipError_t LaunchWaveNetFrame(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
