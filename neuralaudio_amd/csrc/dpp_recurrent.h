@@ -35,4 +35,14 @@ namespace na
 	// H = 8: a row is [lo half | hi half]; copy one half over the other (DPP row_ror:8 with a bank mask)
 	__device__ __forceinline__ int RowLowHalf(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xC, false); }  // lanes 8..15 <- lanes 0..7
 	__device__ __forceinline__ int RowHighHalf(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0x3, false); } // lanes 0..7 <- lanes 8..15
+
+	// tanh(x) = 1 - 2 / (e^(2x) + 1) on the hardware exp2 / rcp units: absolute error ~1e-7 (the reference's Eigen tanh is itself a
+	// few-ulp rational approximation), saturates correctly (e^(2x) -> inf: 1, -> 0: -1), 6 instructions instead of libm's ~30
+	__device__ __forceinline__ float GruTanh(float x)
+	{
+		const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f); // 2 * log2(e)
+		return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+	}
+
+	__device__ __forceinline__ float GruSigmoid(float x) { return (GruTanh(x * 0.5f) + 1.0f) * 0.5f; }
 }

@@ -2,6 +2,7 @@
 #include "gpu_batch.h"
 
 #include <algorithm>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -138,6 +139,13 @@ namespace na
 		// WaveNet groups on the frame kernel can share ONE launch with other such groups (a heterogeneous batch without stream
 		// fork/join); fills `out` with this group's part of that launch.  Other groups return false.
 		virtual bool FusedLaunchArgs(WnFrameGroup& out)
+		{
+			(void)out;
+			return false;
+		}
+
+		// LSTM / GRU groups with an LDS-free kernel instance likewise share one launch (recurrent_dpp_kernels.hip)
+		virtual bool FusedRecurrentArgs(RecurrentGroup& out)
 		{
 			(void)out;
 			return false;
@@ -411,6 +419,20 @@ namespace na
 				}
 			}
 
+			bool FusedRecurrentArgs(RecurrentGroup& out) override
+			{
+				static const bool noDpp = getenv("NA_LSTM_NO_DPP") != nullptr || getenv("NA_GRU_NO_DPP") != nullptr || getenv("NA_LSTM_LANE_KERNEL") != nullptr;
+				if (noDpp || !RecurrentDppSupported(dev)) return false;
+				SyncActiveLists();
+				out.model = dev;
+				out.state = state.Get();
+				out.capacity = (int)capacity;
+				out.slots = dSlots.Get();
+				out.rows = dRows.Get();
+				out.numStreams = (int)hSlots.size();
+				return out.numStreams > 0;
+			}
+
 			hipError_t Launch(const int* slots, const int* rows, int count, const float* dIn, float* dOut, long inStride, long outStride, int n, hipStream_t s)
 			{
 				if (dev.cell == LSTM_CELL_GRU) return LaunchGruBlock(dev, state.Get(), (int)capacity, slots, rows, count, dIn, dOut, inStride, outStride, n, s);
@@ -586,41 +608,71 @@ namespace na
 			for (auto& g : groups) g->Process(dIn, dOut, inStride, outStride, n, stream);
 			return;
 		}
-		// mixed batch, step 1: every WaveNet group on the frame kernel goes into ONE fused launch per <= 128-frame chunk (the
-		// workgroups of all architectures share the chip, no fork/join).  If that covers all active groups we are done.
+		// Mixed batch.  Groups that can share a launch are fused: all WaveNet groups on the frame kernel into one launch, all LSTM / GRU
+		// groups with an LDS-free kernel instance into another (the workgroups of all architectures share the chip, no fork/join per
+		// group).  What remains are independent "units" (disjoint rows, disjoint state); one unit runs directly on the batch stream.
+		std::vector<WnFrameGroup> fusedWn;
+		std::vector<RecurrentGroup> fusedRec;
+		std::vector<ModelGroup*> singles;
+		ModelGroup* wnOwner = nullptr;  // lends its side stream / event to the fused unit
+		ModelGroup* recOwner = nullptr;
+		for (auto& g : groups)
 		{
-			std::vector<WnFrameGroup> fused;
-			bool all = true;
-			for (auto& g : groups)
+			if (g->NumActive() == 0) continue;
+			WnFrameGroup a;
+			RecurrentGroup r;
+			if (g->FusedLaunchArgs(a))
 			{
-				if (g->NumActive() == 0) continue;
-				WnFrameGroup a;
-				if (g->FusedLaunchArgs(a)) fused.push_back(a);
-				else all = false;
+				fusedWn.push_back(a);
+				if (!wnOwner) wnOwner = g.get();
 			}
-			if (all && !fused.empty())
+			else if (g->FusedRecurrentArgs(r))
 			{
-				size_t offset = 0, left = n;
-				while (left > 0)
-				{
-					const int chunk = (int)std::min<size_t>(left, (size_t)WN_MAX_FRAMES);
-					for (size_t first = 0; first < fused.size(); first += WN_FRAME_MAX_GROUPS)
-					{
-						const int count = (int)std::min<size_t>(fused.size() - first, (size_t)WN_FRAME_MAX_GROUPS);
-						CheckHip(LaunchWaveNetFrameFused(fused.data() + first, count, dIn + offset, dOut + offset, inStride, outStride, chunk, stream),
-							"WaveNetFrameKernel (fused)");
-					}
-					offset += (size_t)chunk;
-					left -= (size_t)chunk;
-				}
-				return;
+				fusedRec.push_back(r);
+				if (!recOwner) recOwner = g.get();
+			}
+			else
+			{
+				g->SyncActiveLists();
+				singles.push_back(g.get());
 			}
 		}
-		// step 2 (batches that also hold LSTM / GRU groups): the model groups are independent (disjoint rows, disjoint state) -> fork onto per-group side streams
-		// so their kernels share the GPU, then join back into the batch stream.  The fork/join costs ~5 HIP calls per group,
-		// which would make a buffer host-bound, so the sequence is captured once into a hipGraph and replayed while the call
-		// signature (pointers, n, strides) and the active-stream lists stay the same -- the steady state of a real-time host.
-		for (auto& g : groups) g->SyncActiveLists();
+		auto launchWn = [&](hipStream_t s) {
+			size_t offset = 0, left = n;
+			while (left > 0)
+			{
+				const int chunk = (int)std::min<size_t>(left, (size_t)WN_MAX_FRAMES);
+				for (size_t first = 0; first < fusedWn.size(); first += WN_FRAME_MAX_GROUPS)
+					CheckHip(LaunchWaveNetFrameFused(fusedWn.data() + first, (int)std::min<size_t>(fusedWn.size() - first, (size_t)WN_FRAME_MAX_GROUPS),
+						dIn + offset, dOut + offset, inStride, outStride, chunk, s), "WaveNetFrameKernel (fused)");
+				offset += (size_t)chunk;
+				left -= (size_t)chunk;
+			}
+		};
+		auto launchRec = [&](hipStream_t s) {
+			size_t offset = 0, left = n;
+			while (left > 0)
+			{
+				const int chunk = (int)std::min<size_t>(left, (size_t)LSTM_MAX_FRAMES);
+				for (size_t first = 0; first < fusedRec.size(); first += RECURRENT_MAX_GROUPS)
+					CheckHip(LaunchRecurrentDpp(fusedRec.data() + first, (int)std::min<size_t>(fusedRec.size() - first, (size_t)RECURRENT_MAX_GROUPS),
+						dIn + offset, dOut + offset, inStride, outStride, chunk, s), "RecurrentDppKernel (fused)");
+				offset += (size_t)chunk;
+				left -= (size_t)chunk;
+			}
+		};
+		const size_t units = (fusedWn.empty() ? 0 : 1) + (fusedRec.empty() ? 0 : 1) + singles.size();
+		if (units == 1)
+		{
+			if (!fusedWn.empty()) launchWn(stream);
+			else if (!fusedRec.empty()) launchRec(stream);
+			else singles[0]->Process(dIn, dOut, inStride, outStride, n, stream);
+			return;
+		}
+		// Several units: fork onto side streams so their kernels share the GPU, then join back into the batch stream.  The fork/join
+		// costs ~5 HIP calls per unit, which would make a buffer host-bound, so the sequence is captured once into a hipGraph and
+		// replayed while the call signature (pointers, n, strides) and the active-stream lists stay the same -- the steady state of a
+		// real-time host.
 		if (!graphCache.empty() && graphCache.front().key.version != topologyVersion)
 		{
 			for (auto& e : graphCache) (void)hipGraphExecDestroy(e.exec);
@@ -642,15 +694,16 @@ namespace na
 			{
 				if (!forkEvent) CheckHip(hipEventCreateWithFlags(&forkEvent, hipEventDisableTiming), "hipEventCreate");
 				CheckHip(hipEventRecord(forkEvent, stream), "hipEventRecord");
-				for (auto& g : groups)
-				{
-					if (g->NumActive() == 0) continue;
-					hipStream_t side = g->SideStream();
+				auto branch = [&](ModelGroup* owner, const std::function<void(hipStream_t)>& work) {
+					hipStream_t side = owner->SideStream();
 					CheckHip(hipStreamWaitEvent(side, forkEvent, 0), "hipStreamWaitEvent");
-					g->Process(dIn, dOut, inStride, outStride, n, side);
-					CheckHip(hipEventRecord(g->DoneEvent(), side), "hipEventRecord");
-					CheckHip(hipStreamWaitEvent(stream, g->DoneEvent(), 0), "hipStreamWaitEvent");
-				}
+					work(side);
+					CheckHip(hipEventRecord(owner->DoneEvent(), side), "hipEventRecord");
+					CheckHip(hipStreamWaitEvent(stream, owner->DoneEvent(), 0), "hipStreamWaitEvent");
+				};
+				if (!fusedWn.empty()) branch(wnOwner, launchWn);
+				if (!fusedRec.empty()) branch(recOwner, launchRec);
+				for (ModelGroup* g : singles) branch(g, [&](hipStream_t s) { g->Process(dIn, dOut, inStride, outStride, n, s); });
 			}
 			catch (...)
 			{

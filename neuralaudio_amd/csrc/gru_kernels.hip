@@ -23,7 +23,6 @@ namespace na
 {
 	namespace
 	{
-		__device__ __forceinline__ float GruSigmoid(float x) { return (tanhf(x * 0.5f) + 1.0f) * 0.5f; }
 
 		__device__ __forceinline__ void GruWaveSync()
 		{
@@ -64,7 +63,7 @@ namespace na
 			if (lane >= 2 * H && lane < 3 * H)
 			{
 				const int u = lane - 2 * H;
-				const float c = tanhf(ai + zr[H + u] * ah);
+				const float c = GruTanh(ai + zr[H + u] * ah);
 				const float z = zr[u];
 				h[u] = (1.0f - z) * c + z * h[u];
 			}
@@ -122,130 +121,6 @@ namespace na
 				if (lane < H) state[(size_t)(l * 2 * H + lane) * capacity + slot] = hvec[l][lane];
 		}
 
-		// ------------------------------------------------------------------------------------------------------------
-		// H = 8 / 16: nothing on the recurrence touches LDS (same idea as LstmDppKernel).  lane = H*gate + unit with gate rows z, r, c
-		// and the fourth row duplicating c (for H = 8 the upper 32 lanes mirror the lower 32); every lane keeps h[unit].  The mat-vec
-		// reads h[(unit - n) mod H] with DPP row_ror:n against weights rotated at load time; z and r reach every lane through two
-		// lane swaps, c through one.  Each lane sums its row starting at column `unit` (different rounding order than the plain
-		// kernel; ~1e-7 RMS).
-		// ------------------------------------------------------------------------------------------------------------
-		template <int H>
-		__device__ __forceinline__ float GruDppCell(float ai, float ah, float h)
-		{
-			int zr = __builtin_bit_cast(int, GruSigmoid(ai + ah)); // meaningful on the z and r rows
-			int zr2 = zr;
-			float z, r;
-			if constexpr (H == 16)
-			{
-				LaneSwap32(zr, zr2); // zr: rows z r z r
-				int rr = zr;
-				LaneSwap16(zr, rr);  // zr: z everywhere, rr: r everywhere
-				z = __builtin_bit_cast(float, zr);
-				r = __builtin_bit_cast(float, rr);
-			}
-			else
-			{
-				LaneSwap16(zr, zr2); // zr: every row = [z | r]  (rows 0 and 2 hold it, the upper half of the wave mirrors the lower)
-				z = __builtin_bit_cast(float, RowLowHalf(zr));
-				r = __builtin_bit_cast(float, RowHighHalf(zr));
-			}
-			int c = __builtin_bit_cast(int, tanhf(ai + r * ah)); // meaningful on the c rows (2 and 3 for H = 16; 1 and 3 for H = 8)
-			int c2 = c;
-			if constexpr (H == 16) LaneSwap32(c, c2); // c2: rows c c c c
-			else LaneSwap16(c, c2);                   // c2: rows 1 1 3 3 = c everywhere
-			const float cv = __builtin_bit_cast(float, c2);
-			return (1.0f - z) * cv + z * h;
-		}
-
-		template <int H, int L>
-		__global__ void __launch_bounds__(64) GruDppKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
-			const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
-		{
-			static_assert(H == 8 || H == 16, "a 16-lane DPP row must hold the units a whole number of times");
-			constexpr int HP = H + 1;
-			__shared__ float xin[LSTM_MAX_FRAMES];
-			__shared__ float hout[LSTM_MAX_FRAMES * HP];
-
-			const int lane = threadIdx.x;
-			const int unit = lane % H;
-			const int gate = min((lane / H) & 3, 2); // rows z, r, c, c
-			const int r = gate * H + unit;
-			const int slot = slots[blockIdx.x];
-			const int row = rows[blockIdx.x];
-			const float* inRow = in + (size_t)row * inStride;
-			float* outRow = out + (size_t)row * outStride;
-
-			// layer 0: W row-major [3H][1 + H], b_in[3H], b_rec[3H]; h weights rotated so that row_ror:k pairs wh0[k] with h[(unit - k) mod H]
-			const float* w0 = m.w + m.layerOff[0];
-			const float wx0 = w0[(size_t)r * (1 + H)];
-			float wh0[H];
-#pragma unroll
-			for (int k = 0; k < H; k++) wh0[k] = w0[(size_t)r * (1 + H) + 1 + ((unit - k + H) % H)];
-			const float bi0 = w0[(size_t)3 * H * (1 + H) + r], bh0 = w0[(size_t)3 * H * (1 + H) + 3 * H + r];
-			float wi1[H], wh1[H];
-			float bi1 = 0.0f, bh1 = 0.0f;
-			if (L > 1)
-			{
-				const float* w1 = m.w + m.layerOff[L > 1 ? 1 : 0];
-#pragma unroll
-				for (int k = 0; k < H; k++)
-				{
-					wi1[k] = w1[(size_t)r * (2 * H) + ((unit - k + H) % H)];
-					wh1[k] = w1[(size_t)r * (2 * H) + H + ((unit - k + H) % H)];
-				}
-				bi1 = w1[(size_t)3 * H * (2 * H) + r];
-				bh1 = w1[(size_t)3 * H * (2 * H) + 3 * H + r];
-			}
-
-			for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
-			float h[L];
-#pragma unroll
-			for (int l = 0; l < L; l++) h[l] = state[(size_t)(l * 2 * H + unit) * capacity + slot];
-			GruWaveSync();
-
-			float x = xin[0];
-			for (int f = 0; f < n; f++)
-			{
-				const float xNext = xin[(f + 1 < n) ? f + 1 : f]; // off the recurrence: fetched a step ahead
-				float ah = bh0;
-				DppDot<H>(ah, wh0, h[0]);
-				h[0] = GruDppCell<H>(wx0 * x + bi0, ah, h[0]);
-				if (L > 1)
-				{
-					float ai1 = bi1, ah1 = bh1;
-					DppDot<H>(ai1, wi1, h[0]);
-					DppDot<H>(ah1, wh1, h[L > 1 ? 1 : 0]);
-					h[L > 1 ? 1 : 0] = GruDppCell<H>(ai1, ah1, h[L > 1 ? 1 : 0]);
-				}
-				if (lane < H) hout[f * HP + lane] = h[L - 1];
-				x = xNext;
-			}
-			GruWaveSync();
-
-			const float* headW = m.w + m.headOff;
-			for (int f = lane; f < n; f += 64)
-			{
-				float acc = 0.0f;
-#pragma unroll
-				for (int k = 0; k < H; k++) acc += headW[k] * hout[f * HP + k];
-				outRow[f] = acc + headW[H];
-			}
-			if (lane < H)
-			{
-#pragma unroll
-				for (int l = 0; l < L; l++) state[(size_t)(l * 2 * H + lane) * capacity + slot] = h[l];
-			}
-		}
-
-		template <int H, int L>
-		hipError_t LaunchDppHL(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams, const float* in,
-			float* out, long inStride, long outStride, int n, hipStream_t stream)
-		{
-			hipLaunchKernelGGL((GruDppKernel<H, L>), dim3((unsigned)numStreams), dim3(64), 0, stream, m, state, capacity, slots, rows, in, out, inStride,
-				outStride, n);
-			return hipGetLastError();
-		}
-
 		template <int H, int L>
 		hipError_t LaunchHL(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams, const float* in,
 			float* out, long inStride, long outStride, int n, hipStream_t stream)
@@ -267,13 +142,10 @@ namespace na
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > LSTM_MAX_FRAMES || !GruShapeSupported(m.hidden, m.numLayers)) return hipErrorInvalidValue;
 		static const bool noDpp = getenv("NA_GRU_NO_DPP") != nullptr; // tuning knob: the LDS-broadcast kernel for every shape
-		if (!noDpp && (m.hidden == 8 || m.hidden == 16))
+		if (!noDpp && RecurrentDppSupported(m))
 		{
-			if (m.hidden == 8)
-				return m.numLayers == 1 ? LaunchDppHL<8, 1>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream)
-										: LaunchDppHL<8, 2>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			return m.numLayers == 1 ? LaunchDppHL<16, 1>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream)
-									: LaunchDppHL<16, 2>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			const RecurrentGroup g = { m, state, capacity, slots, rows, numStreams };
+			return LaunchRecurrentDpp(&g, 1, in, out, inStride, outStride, n, stream);
 		}
 #define NA_GRU_CASE(HH) \
 	if (m.hidden == HH) return m.numLayers == 1 ? LaunchHL<HH, 1>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream) \

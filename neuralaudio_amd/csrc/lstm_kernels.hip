@@ -282,166 +282,6 @@ namespace na
 		}
 	}
 
-	// ------------------------------------------------------------------------------------------------------------
-	// Fastest path (H = 8 or 16): one wave per stream, NO LDS on the recurrence.
-	//   lane = H*gate + unit (gate order i,f,g,o; for H = 8 the upper 32 lanes mirror the lower 32), every lane keeps h[unit] and c[unit]
-	//   (replicated across the gate rows).  The mat-vec reads h[(unit - n) mod H] from a neighbour lane with DPP row_ror:n (a 16-lane row
-	//   holds the H units once or twice), against weights that were rotated the same way when they were loaded -- 1 instruction per
-	//   term, no broadcast through LDS or SGPRs.  The four gates of a unit meet through gfx950 lane swaps (GatherGates).
-	//   Each lane sums its row starting at column `unit` and walking down instead of 0..H-1: same products, different rounding order than
-	//   LSTM.h:87-100 (observed difference vs the oracle ~1e-7 RMS, tolerance 5e-6).  tanh divides with v_rcp_f32 like the WaveNet path.
-	// ------------------------------------------------------------------------------------------------------------
-	__device__ __forceinline__ float LstmRcpTanh(float x)
-	{
-		const float ax = fabsf(x);
-		const float x2 = x * x;
-		const float num = x * (2.45550750702956f + 2.45550750702956f * ax + (0.893229853513558f + 0.821226666969744f * ax) * x2);
-		const float den = 2.44506634652299f + (2.44506634652299f + x2) * (ax + 0.814642734961073f * x2); // |x + e x|x|| == |x| + e x^2
-		return num * __builtin_amdgcn_rcpf(den);
-	}
-
-	// All four gates of this lane's unit, from the lanes that computed them (lane = H*gate + unit), without touching LDS:
-	// gfx950 lane swaps (v_permlane32_swap: a.hi <-> b.lo; v_permlane16_swap: odd rows of a <-> even rows of b; probed on the box)
-	// replicate each 16-lane row into all four rows; for H = 8 a row holds two gates and DPP row_ror:8 with a bank mask merges halves.
-	template <int H>
-	__device__ __forceinline__ void GatherGates(float gv, float& gi, float& gf, float& gg, float& go)
-	{
-		int x = __builtin_bit_cast(int, gv);
-		int y = x;
-		if constexpr (H == 16)
-		{
-			LaneSwap32(x, y); // x: rows g0 g1 g0 g1, y: rows g2 g3 g2 g3
-			int x2 = x, y2 = y;
-			LaneSwap16(x, x2); // x: g0 everywhere, x2: g1 everywhere
-			LaneSwap16(y, y2);
-			gi = __builtin_bit_cast(float, x);
-			gf = __builtin_bit_cast(float, x2);
-			gg = __builtin_bit_cast(float, y);
-			go = __builtin_bit_cast(float, y2);
-		}
-		else
-		{
-			LaneSwap16(x, y); // x: every row = [g0 | g1], y: every row = [g2 | g3]
-			gi = __builtin_bit_cast(float, RowLowHalf(x));
-			gf = __builtin_bit_cast(float, RowHighHalf(x));
-			gg = __builtin_bit_cast(float, RowLowHalf(y));
-			go = __builtin_bit_cast(float, RowHighHalf(y));
-		}
-	}
-
-	// gate pre-activation -> (c, h) update for this lane's unit; returns the new h
-	template <int H>
-	__device__ __forceinline__ float DppCellUpdate(float acc, int gate, int unit, float& c)
-	{
-		const bool isG = gate == 2;
-		const float t = LstmRcpTanh(isG ? acc : acc * 0.5f);
-		const float gv = isG ? t : 0.5f * (t + 1.0f); // LSTM.h:33-36,94-99
-		float gi, gf, gg, go;
-		GatherGates<H>(gv, gi, gf, gg, go);
-		c = (gf * c) + (gi * gg);
-		return go * LstmRcpTanh(c);
-	}
-
-	template <int H, int L>
-	__global__ void __launch_bounds__(64) LstmDppKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
-		const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
-	{
-		static_assert(H == 8 || H == 16, "a 16-lane DPP row must hold the units a whole number of times");
-		constexpr int HP = H + 1;
-		__shared__ float xin[LSTM_MAX_FRAMES];
-		__shared__ float hout[LSTM_MAX_FRAMES * HP];
-
-		const int lane = threadIdx.x;
-		const int unit = lane % H;
-		const int gate = (lane / H) & 3;
-		const int r = gate * H + unit; // this lane's gate row
-		const int slot = slots[blockIdx.x];
-		const int row = rows[blockIdx.x];
-		const float* inRow = in + (size_t)row * inStride;
-		float* outRow = out + (size_t)row * outStride;
-
-		// layer 0: W row-major [4H][1 + H], then bias[4H] (LSTM.h:42-56); h weights rotated by `unit`
-		const float* w0 = m.w + m.layerOff[0];
-		const float wx0 = w0[(size_t)r * (1 + H)];
-		float wh0[H];
-#pragma unroll
-		for (int k = 0; k < H; k++) wh0[k] = w0[(size_t)r * (1 + H) + 1 + ((unit - k + H) % H)]; // row_ror:k hands lane p the value of lane p-k
-		const float b0 = w0[(size_t)4 * H * (1 + H) + r];
-		// layer 1: W [4H][H + H]: input = layer-0 h, then own h
-		float wi1[H], wh1[H];
-		float b1 = 0.0f;
-		if (L > 1)
-		{
-			const float* w1 = m.w + m.layerOff[L > 1 ? 1 : 0];
-#pragma unroll
-			for (int k = 0; k < H; k++)
-			{
-				wi1[k] = w1[(size_t)r * (2 * H) + ((unit - k + H) % H)];
-				wh1[k] = w1[(size_t)r * (2 * H) + H + ((unit - k + H) % H)];
-			}
-			b1 = w1[(size_t)4 * H * (2 * H) + r];
-		}
-
-		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
-		float h[L], c[L];
-#pragma unroll
-		for (int l = 0; l < L; l++)
-		{
-			h[l] = state[(size_t)(l * 2 * H + unit) * capacity + slot];
-			c[l] = state[(size_t)(l * 2 * H + H + unit) * capacity + slot];
-		}
-		LstmWaveSync();
-
-		float x = xin[0];
-		for (int f = 0; f < n; f++)
-		{
-			const float xNext = xin[(f + 1 < n) ? f + 1 : f]; // off the recurrence: fetched a step ahead
-			float acc = wx0 * x; // LSTM.h:168 -- column 0 is the input sample
-			DppDot<H>(acc, wh0, h[0]);
-			acc += b0;
-			h[0] = DppCellUpdate<H>(acc, gate, unit, c[0]);
-			if (L > 1)
-			{
-				float acc1 = 0.0f;
-				DppDot<H>(acc1, wi1, h[0]); // LSTM.h:170-180
-				DppDot<H>(acc1, wh1, h[L > 1 ? 1 : 0]);
-				acc1 += b1;
-				h[L > 1 ? 1 : 0] = DppCellUpdate<H>(acc1, gate, unit, c[L > 1 ? 1 : 0]);
-			}
-			if (lane < H) hout[f * HP + lane] = h[L - 1];
-			x = xNext;
-		}
-		LstmWaveSync();
-
-		// dense head for the whole block, lane = sample (LSTM.h:182-189)
-		const float* headW = m.w + m.headOff;
-		for (int f = lane; f < n; f += 64)
-		{
-			float acc = 0.0f;
-#pragma unroll
-			for (int k = 0; k < H; k++) acc += headW[k] * hout[f * HP + k];
-			outRow[f] = acc + headW[H];
-		}
-		if (lane < H)
-		{
-#pragma unroll
-			for (int l = 0; l < L; l++)
-			{
-				state[(size_t)(l * 2 * H + lane) * capacity + slot] = h[l];
-				state[(size_t)(l * 2 * H + H + lane) * capacity + slot] = c[l];
-			}
-		}
-	}
-
-	template <int H, int L>
-	static hipError_t LaunchDppHL(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
-		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream)
-	{
-		hipLaunchKernelGGL((LstmDppKernel<H, L>), dim3((unsigned)numStreams), dim3(64), 0, stream, m, state, capacity, slots, rows, in, out,
-			inStride, outStride, n);
-		return hipGetLastError();
-	}
-
 	template <int H, int L>
 	static hipError_t LaunchWaveHL(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream)
@@ -456,12 +296,10 @@ namespace na
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err)
 	{
 		static const bool noDpp = getenv("NA_LSTM_NO_DPP") != nullptr; // tuning knob: fall back to the LDS-broadcast wave kernel
-		if (!noDpp && (m.hidden == 8 || m.hidden == 16) && (m.numLayers == 1 || m.numLayers == 2))
+		if (!noDpp && RecurrentDppSupported(m))
 		{
-			if (m.hidden == 8) err = m.numLayers == 1 ? LaunchDppHL<8, 1>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream)
-													  : LaunchDppHL<8, 2>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
-			else err = m.numLayers == 1 ? LaunchDppHL<16, 1>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream)
-										: LaunchDppHL<16, 2>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+			const RecurrentGroup g = { m, state, capacity, slots, rows, numStreams };
+			err = LaunchRecurrentDpp(&g, 1, in, out, inStride, outStride, n, stream);
 			return true;
 		}
 #define NA_LSTM_WAVE(HH) \

@@ -13,6 +13,21 @@ namespace na
 	hipError_t LaunchLstmBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream);
 
+	// LDS-free kernels for hidden size 8 / 16, 1-2 layers, LSTM or GRU (recurrent_dpp_kernels.hip): one launch over several model groups
+	constexpr int RECURRENT_MAX_GROUPS = 8;
+	struct RecurrentGroup
+	{
+		LstmModelDev model;
+		float* state;
+		int capacity;
+		const int* slots;
+		const int* rows;
+		int numStreams;
+	};
+	bool RecurrentDppSupported(const LstmModelDev& m);
+	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream);
+
 	// keras GRU (gru_kernels.hip): same state layout (only the h half of every layer is used), m.cell == LSTM_CELL_GRU
 	bool GruShapeSupported(int hidden, int numLayers);
 	hipError_t LaunchGruBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,

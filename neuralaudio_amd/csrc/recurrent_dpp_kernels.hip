@@ -1,0 +1,359 @@
+// recurrent_dpp_kernels.hip -- the LDS-free recurrent kernels (LSTM and keras GRU, hidden size 8 or 16, 1-2 layers) as ONE
+// gfx950 kernel that serves up to RECURRENT_MAX_GROUPS model groups per launch: a batch holding several recurrent models
+// (BASELINE config 4: LSTM 2x16 + GRU) runs without stream fork/join and its waves share the chip.
+//
+// Reference arithmetic: LSTMModelT/LSTMLayerT::Process (NeuralAudio/LSTM.h:164-191, 87-100), FastMath (Activation.h:83-96);
+// keras GRU = RTNeural's GRULayer (NeuralAudio/RTNeuralModel.h:300,417-421; third-party, parity unpinned -- see gru_kernels.hip).
+#include <cstdlib>
+
+#include <hip/hip_runtime.h>
+
+#include "dpp_recurrent.h"
+#include "lstm_dev.h"
+#include "lstm_launch.h"
+
+namespace na
+{
+	__device__ __forceinline__ void RecurrentWaveSync()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+	}
+
+	// ------------------------------------------------------------------------------------------------------------
+	// Fastest path (H = 8 or 16): one wave per stream, NO LDS on the recurrence.
+	//   lane = H*gate + unit (gate order i,f,g,o; for H = 8 the upper 32 lanes mirror the lower 32), every lane keeps h[unit] and c[unit]
+	//   (replicated across the gate rows).  The mat-vec reads h[(unit - n) mod H] from a neighbour lane with DPP row_ror:n (a 16-lane row
+	//   holds the H units once or twice), against weights that were rotated the same way when they were loaded -- 1 instruction per
+	//   term, no broadcast through LDS or SGPRs.  The four gates of a unit meet through gfx950 lane swaps (GatherGates).
+	//   Each lane sums its row starting at column `unit` and walking down instead of 0..H-1: same products, different rounding order than
+	//   LSTM.h:87-100 (observed difference vs the oracle ~1e-7 RMS, tolerance 5e-6).  tanh divides with v_rcp_f32 like the WaveNet path.
+	// ------------------------------------------------------------------------------------------------------------
+	__device__ __forceinline__ float LstmRcpTanh(float x)
+	{
+		const float ax = fabsf(x);
+		const float x2 = x * x;
+		const float num = x * (2.45550750702956f + 2.45550750702956f * ax + (0.893229853513558f + 0.821226666969744f * ax) * x2);
+		const float den = 2.44506634652299f + (2.44506634652299f + x2) * (ax + 0.814642734961073f * x2); // |x + e x|x|| == |x| + e x^2
+		return num * __builtin_amdgcn_rcpf(den);
+	}
+
+	// All four gates of this lane's unit, from the lanes that computed them (lane = H*gate + unit), without touching LDS:
+	// gfx950 lane swaps (v_permlane32_swap: a.hi <-> b.lo; v_permlane16_swap: odd rows of a <-> even rows of b; probed on the box)
+	// replicate each 16-lane row into all four rows; for H = 8 a row holds two gates and DPP row_ror:8 with a bank mask merges halves.
+	template <int H>
+	__device__ __forceinline__ void GatherGates(float gv, float& gi, float& gf, float& gg, float& go)
+	{
+		int x = __builtin_bit_cast(int, gv);
+		int y = x;
+		if constexpr (H == 16)
+		{
+			LaneSwap32(x, y); // x: rows g0 g1 g0 g1, y: rows g2 g3 g2 g3
+			int x2 = x, y2 = y;
+			LaneSwap16(x, x2); // x: g0 everywhere, x2: g1 everywhere
+			LaneSwap16(y, y2);
+			gi = __builtin_bit_cast(float, x);
+			gf = __builtin_bit_cast(float, x2);
+			gg = __builtin_bit_cast(float, y);
+			go = __builtin_bit_cast(float, y2);
+		}
+		else
+		{
+			LaneSwap16(x, y); // x: every row = [g0 | g1], y: every row = [g2 | g3]
+			gi = __builtin_bit_cast(float, RowLowHalf(x));
+			gf = __builtin_bit_cast(float, RowHighHalf(x));
+			gg = __builtin_bit_cast(float, RowLowHalf(y));
+			go = __builtin_bit_cast(float, RowHighHalf(y));
+		}
+	}
+
+	// gate pre-activation -> (c, h) update for this lane's unit; returns the new h
+	template <int H>
+	__device__ __forceinline__ float DppCellUpdate(float acc, int gate, int unit, float& c)
+	{
+		const bool isG = gate == 2;
+		const float t = LstmRcpTanh(isG ? acc : acc * 0.5f);
+		const float gv = isG ? t : 0.5f * (t + 1.0f); // LSTM.h:33-36,94-99
+		float gi, gf, gg, go;
+		GatherGates<H>(gv, gi, gf, gg, go);
+		c = (gf * c) + (gi * gg);
+		return go * LstmRcpTanh(c);
+	}
+
+	// one stream (slot, row), one block of n samples; xin[128] and hout[128 * (H + 1)] are LDS scratch of this wave
+	template <int H, int L>
+	__device__ __forceinline__ void LstmDppBody(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
+	{
+		static_assert(H == 8 || H == 16, "a 16-lane DPP row must hold the units a whole number of times");
+		constexpr int HP = H + 1;
+		const int lane = threadIdx.x;
+		const int unit = lane % H;
+		const int gate = (lane / H) & 3;
+		const int r = gate * H + unit; // this lane's gate row
+		const float* inRow = in + (size_t)row * inStride;
+		float* outRow = out + (size_t)row * outStride;
+
+		// layer 0: W row-major [4H][1 + H], then bias[4H] (LSTM.h:42-56); h weights rotated by `unit`
+		const float* w0 = m.w + m.layerOff[0];
+		const float wx0 = w0[(size_t)r * (1 + H)];
+		float wh0[H];
+#pragma unroll
+		for (int k = 0; k < H; k++) wh0[k] = w0[(size_t)r * (1 + H) + 1 + ((unit - k + H) % H)]; // row_ror:k hands lane p the value of lane p-k
+		const float b0 = w0[(size_t)4 * H * (1 + H) + r];
+		// layer 1: W [4H][H + H]: input = layer-0 h, then own h
+		float wi1[H], wh1[H];
+		float b1 = 0.0f;
+		if (L > 1)
+		{
+			const float* w1 = m.w + m.layerOff[L > 1 ? 1 : 0];
+#pragma unroll
+			for (int k = 0; k < H; k++)
+			{
+				wi1[k] = w1[(size_t)r * (2 * H) + ((unit - k + H) % H)];
+				wh1[k] = w1[(size_t)r * (2 * H) + H + ((unit - k + H) % H)];
+			}
+			b1 = w1[(size_t)4 * H * (2 * H) + r];
+		}
+
+		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
+		float h[L], c[L];
+#pragma unroll
+		for (int l = 0; l < L; l++)
+		{
+			h[l] = state[(size_t)(l * 2 * H + unit) * capacity + slot];
+			c[l] = state[(size_t)(l * 2 * H + H + unit) * capacity + slot];
+		}
+		RecurrentWaveSync();
+
+		float x = xin[0];
+		for (int f = 0; f < n; f++)
+		{
+			const float xNext = xin[(f + 1 < n) ? f + 1 : f]; // off the recurrence: fetched a step ahead
+			float acc = wx0 * x; // LSTM.h:168 -- column 0 is the input sample
+			DppDot<H>(acc, wh0, h[0]);
+			acc += b0;
+			h[0] = DppCellUpdate<H>(acc, gate, unit, c[0]);
+			if (L > 1)
+			{
+				float acc1 = 0.0f;
+				DppDot<H>(acc1, wi1, h[0]); // LSTM.h:170-180
+				DppDot<H>(acc1, wh1, h[L > 1 ? 1 : 0]);
+				acc1 += b1;
+				h[L > 1 ? 1 : 0] = DppCellUpdate<H>(acc1, gate, unit, c[L > 1 ? 1 : 0]);
+			}
+			if (lane < H) hout[f * HP + lane] = h[L - 1];
+			x = xNext;
+		}
+		RecurrentWaveSync();
+
+		// dense head for the whole block, lane = sample (LSTM.h:182-189)
+		const float* headW = m.w + m.headOff;
+		for (int f = lane; f < n; f += 64)
+		{
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < H; k++) acc += headW[k] * hout[f * HP + k];
+			outRow[f] = acc + headW[H];
+		}
+		if (lane < H)
+		{
+#pragma unroll
+			for (int l = 0; l < L; l++)
+			{
+				state[(size_t)(l * 2 * H + lane) * capacity + slot] = h[l];
+				state[(size_t)(l * 2 * H + H + lane) * capacity + slot] = c[l];
+			}
+		}
+	}
+
+
+	// ------------------------------------------------------------------------------------------------------------
+	// H = 8 / 16: nothing on the recurrence touches LDS (same idea as LstmDppKernel).  lane = H*gate + unit with gate rows z, r, c
+	// and the fourth row duplicating c (for H = 8 the upper 32 lanes mirror the lower 32); every lane keeps h[unit].  The mat-vec
+	// reads h[(unit - n) mod H] with DPP row_ror:n against weights rotated at load time; z and r reach every lane through two
+	// lane swaps, c through one.  Each lane sums its row starting at column `unit` (different rounding order than the plain
+	// kernel; ~1e-7 RMS).
+	// ------------------------------------------------------------------------------------------------------------
+	template <int H>
+	__device__ __forceinline__ float GruDppCell(float ai, float ah, float h)
+	{
+		int zr = __builtin_bit_cast(int, GruSigmoid(ai + ah)); // meaningful on the z and r rows
+		int zr2 = zr;
+		float z, r;
+		if constexpr (H == 16)
+		{
+			LaneSwap32(zr, zr2); // zr: rows z r z r
+			int rr = zr;
+			LaneSwap16(zr, rr);  // zr: z everywhere, rr: r everywhere
+			z = __builtin_bit_cast(float, zr);
+			r = __builtin_bit_cast(float, rr);
+		}
+		else
+		{
+			LaneSwap16(zr, zr2); // zr: every row = [z | r]  (rows 0 and 2 hold it, the upper half of the wave mirrors the lower)
+			z = __builtin_bit_cast(float, RowLowHalf(zr));
+			r = __builtin_bit_cast(float, RowHighHalf(zr));
+		}
+		int c = __builtin_bit_cast(int, GruTanh(ai + r * ah)); // meaningful on the c rows (2 and 3 for H = 16; 1 and 3 for H = 8)
+		int c2 = c;
+		if constexpr (H == 16) LaneSwap32(c, c2); // c2: rows c c c c
+		else LaneSwap16(c, c2);                   // c2: rows 1 1 3 3 = c everywhere
+		const float cv = __builtin_bit_cast(float, c2);
+		return (1.0f - z) * cv + z * h;
+	}
+
+	template <int H, int L>
+	__device__ __forceinline__ void GruDppBody(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
+	{
+		static_assert(H == 8 || H == 16, "a 16-lane DPP row must hold the units a whole number of times");
+		constexpr int HP = H + 1;
+		const int lane = threadIdx.x;
+		const int unit = lane % H;
+		const int gate = min((lane / H) & 3, 2); // rows z, r, c, c
+		const int r = gate * H + unit;
+		const float* inRow = in + (size_t)row * inStride;
+		float* outRow = out + (size_t)row * outStride;
+
+		// layer 0: W row-major [3H][1 + H], b_in[3H], b_rec[3H]; h weights rotated so that row_ror:k pairs wh0[k] with h[(unit - k) mod H]
+		const float* w0 = m.w + m.layerOff[0];
+		const float wx0 = w0[(size_t)r * (1 + H)];
+		float wh0[H];
+#pragma unroll
+		for (int k = 0; k < H; k++) wh0[k] = w0[(size_t)r * (1 + H) + 1 + ((unit - k + H) % H)];
+		const float bi0 = w0[(size_t)3 * H * (1 + H) + r], bh0 = w0[(size_t)3 * H * (1 + H) + 3 * H + r];
+		float wi1[H], wh1[H];
+		float bi1 = 0.0f, bh1 = 0.0f;
+		if (L > 1)
+		{
+			const float* w1 = m.w + m.layerOff[L > 1 ? 1 : 0];
+#pragma unroll
+			for (int k = 0; k < H; k++)
+			{
+				wi1[k] = w1[(size_t)r * (2 * H) + ((unit - k + H) % H)];
+				wh1[k] = w1[(size_t)r * (2 * H) + H + ((unit - k + H) % H)];
+			}
+			bi1 = w1[(size_t)3 * H * (2 * H) + r];
+			bh1 = w1[(size_t)3 * H * (2 * H) + 3 * H + r];
+		}
+
+		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
+		float h[L];
+#pragma unroll
+		for (int l = 0; l < L; l++) h[l] = state[(size_t)(l * 2 * H + unit) * capacity + slot];
+		RecurrentWaveSync();
+
+		float x = xin[0];
+		for (int f = 0; f < n; f++)
+		{
+			const float xNext = xin[(f + 1 < n) ? f + 1 : f]; // off the recurrence: fetched a step ahead
+			float ah = bh0;
+			DppDot<H>(ah, wh0, h[0]);
+			h[0] = GruDppCell<H>(wx0 * x + bi0, ah, h[0]);
+			if (L > 1)
+			{
+				float ai1 = bi1, ah1 = bh1;
+				DppDot<H>(ai1, wi1, h[0]);
+				DppDot<H>(ah1, wh1, h[L > 1 ? 1 : 0]);
+				h[L > 1 ? 1 : 0] = GruDppCell<H>(ai1, ah1, h[L > 1 ? 1 : 0]);
+			}
+			if (lane < H) hout[f * HP + lane] = h[L - 1];
+			x = xNext;
+		}
+		RecurrentWaveSync();
+
+		const float* headW = m.w + m.headOff;
+		for (int f = lane; f < n; f += 64)
+		{
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < H; k++) acc += headW[k] * hout[f * HP + k];
+			outRow[f] = acc + headW[H];
+		}
+		if (lane < H)
+		{
+#pragma unroll
+			for (int l = 0; l < L; l++) state[(size_t)(l * 2 * H + lane) * capacity + slot] = h[l];
+		}
+	}
+
+
+	struct RecurrentGroupArgs
+	{
+		LstmModelDev m;
+		float* state;
+		const int* slots;
+		const int* rows;
+		int capacity, numStreams;
+		int firstBlock; // workgroups (= streams) [firstBlock, next group's firstBlock) belong to this group
+	};
+
+	struct RecurrentLaunchArgs
+	{
+		RecurrentGroupArgs g[RECURRENT_MAX_GROUPS];
+		int numGroups;
+	};
+
+	// grid = all streams of all groups, block = 64 (one wave per stream)
+	__global__ void __launch_bounds__(64) RecurrentDppKernel(const RecurrentLaunchArgs args, const float* __restrict__ in, float* __restrict__ out, long inStride,
+		long outStride, int n)
+	{
+		__shared__ float xin[LSTM_MAX_FRAMES];
+		__shared__ float hout[LSTM_MAX_FRAMES * 17];
+		int gi = 0;
+		for (int i = 1; i < args.numGroups; i++)
+			if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
+		const RecurrentGroupArgs& ga = args.g[gi];
+		const int idx = (int)blockIdx.x - ga.firstBlock;
+		const int slot = ga.slots[idx];
+		const int row = ga.rows[idx];
+		const int key = ga.m.cell * 100 + ga.m.hidden * 4 + ga.m.numLayers;
+#define NA_REC_CASE(CELL, HH, LL, BODY) \
+	case CELL * 100 + HH * 4 + LL: BODY<HH, LL>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout); break;
+		switch (key)
+		{
+			NA_REC_CASE(LSTM_CELL_LSTM, 8, 1, LstmDppBody)
+			NA_REC_CASE(LSTM_CELL_LSTM, 8, 2, LstmDppBody)
+			NA_REC_CASE(LSTM_CELL_LSTM, 16, 1, LstmDppBody)
+			NA_REC_CASE(LSTM_CELL_LSTM, 16, 2, LstmDppBody)
+			NA_REC_CASE(LSTM_CELL_GRU, 8, 1, GruDppBody)
+			NA_REC_CASE(LSTM_CELL_GRU, 8, 2, GruDppBody)
+			NA_REC_CASE(LSTM_CELL_GRU, 16, 1, GruDppBody)
+			NA_REC_CASE(LSTM_CELL_GRU, 16, 2, GruDppBody)
+		default: break;
+		}
+#undef NA_REC_CASE
+	}
+
+	bool RecurrentDppSupported(const LstmModelDev& m)
+	{
+		return (m.hidden == 8 || m.hidden == 16) && (m.numLayers == 1 || m.numLayers == 2) && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU);
+	}
+
+	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream)
+	{
+		if (n <= 0 || numGroups <= 0) return hipSuccess;
+		if (n > LSTM_MAX_FRAMES || numGroups > RECURRENT_MAX_GROUPS) return hipErrorInvalidValue;
+		RecurrentLaunchArgs args = {};
+		args.numGroups = numGroups;
+		int blocks = 0;
+		for (int i = 0; i < numGroups; i++)
+		{
+			if (!RecurrentDppSupported(groups[i].model) || groups[i].numStreams <= 0) return hipErrorInvalidValue;
+			RecurrentGroupArgs& a = args.g[i];
+			a.m = groups[i].model;
+			a.state = groups[i].state;
+			a.slots = groups[i].slots;
+			a.rows = groups[i].rows;
+			a.capacity = groups[i].capacity;
+			a.numStreams = groups[i].numStreams;
+			a.firstBlock = blocks;
+			blocks += groups[i].numStreams;
+		}
+		hipLaunchKernelGGL(RecurrentDppKernel, dim3((unsigned)blocks), dim3(64), 0, stream, args, in, out, inStride, outStride, n);
+		return hipGetLastError();
+	}
+}
