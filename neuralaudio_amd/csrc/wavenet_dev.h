@@ -1,18 +1,15 @@
-// wavenet_dev.h -- device-side data model shared by the host packer (wavenet_plan.cpp) and the
-// gfx950 kernels (wavenet_kernels.hip).
+// wavenet_dev.h -- device-side data model shared by the host packer (wavenet_plan.cpp) and the gfx950 WaveNet kernels
+// (wavenet_frame_kernels.hip = the shipped path; wavenet_kernels.hip and wavenet_pk_kernels.hip = measured alternatives).
 //
-// A WaveNet model (reference: NeuralAudio/WaveNet.h) is lowered at load time into a short
-// "stage program".  One wave64 executes the whole program for one audio stream and one block of
-// up to 128 frames; every mat-mul in it is issued as v_mfma_f32_16x16x4_f32 with
-//     M = output channels (padded to 16), N = 16 frames (one "tile"), K = 4 input channels.
+// A WaveNet model (reference: NeuralAudio/WaveNet.h) is lowered at load time into a short "stage program" (WnStage: one per
+// rechannel / layer / array link / head) plus per-kernel weight images.  A workgroup interprets the program for one or two
+// audio streams and one block of up to 128 frames.
 //
-// Register / memory tile layout ("D layout", identical for registers, LDS and the HBM rings):
-//     a tile is 16 frames x 4*G channels; lane (g = lane>>4, j = lane&15) owns the float4 holding
-//     channels 4g..4g+3 of frame j.  That is exactly the C/D fragment of the 16x16x4 MFMA
-//     (row = 4*(lane>>4)+reg, col = lane&15), and with weights permuted on the host it is also a
-//     valid B fragment for the next mat-mul (k-slot = lane group, one MFMA per float4 element),
-//     so activations never need a cross-lane shuffle.
-//     Memory image of a tile: float4 index (tile*G + g)*16 + j  -> one coalesced 1 KB (G=4) store.
+// Tile layout (identical for the LDS block image and the HBM rings):
+//     a tile is 16 frames x 4*G channels; the float4 holding channels 4g..4g+3 of frame j has index (tile*G + g)*16 + j, i.e.
+//     16 frames x 4 channels per 256-byte row.  The frame kernel's lanes (lane = frame) read and write full rows; for the tile
+//     kernel the same image is the C/D fragment of v_mfma_f32_16x16x4_f32 (row = 4*(lane>>4)+reg, col = lane&15) and, with the
+//     weight operand permuted on the host, also a valid B fragment for the next mat-mul.
 //
 // HBM state per stream (float4 units):
 //     [0, 16)            header: 64 ints, header[r] = write cursor (frame index) of ring r
