@@ -58,6 +58,32 @@ def test_config3_mixed_lite_feather_nano_batch(na, loader):
         assert O.rms(y[s] - ora.process(x[s])) < TOL_RMS, s
 
 
+def test_fused_launch_odd_group_sizes_two_streams_per_workgroup(na, loader):
+    """>= 512 streams: one fused launch over three architectures with two streams per workgroup; odd group sizes leave a
+    half-filled last workgroup per group (the shadow wave must not write), interleaved rows make the slot/row tables non-contiguous."""
+    std = loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=False)
+    feather = loader.CreateFromFile(_path("BossWN-feather.nam"), doPrewarm=False)
+    nano = loader.CreateFromFile(_path("BossWN-nano.nam"), doPrewarm=False)
+    b = na.Batch(0)
+    first_f = b.AddStreams(feather, 201)     # rows 0..200 (contiguous group)
+    first_s = b.AddStreams(std, 119)         # rows 201..319
+    rows_n = []
+    for k in range(100):                     # nano and extra feather streams interleaved: non-contiguous row tables
+        rows_n.append(b.AddStreams(nano, 1))
+        b.AddStreams(feather, 1)
+    S = 201 + 119 + 200
+    assert S >= 512
+    n, blocks = 128, 3
+    x = np.stack([O.signal_noise(n * blocks, 7000 + s) for s in range(S)])
+    y = _run_blocks(b, x, n)
+    assert np.all(np.isfinite(y))
+    checks = [(first_f, "BossWN-feather.nam"), (first_f + 200, "BossWN-feather.nam"), (first_s, "BossWN-standard.nam"),
+              (first_s + 118, "BossWN-standard.nam"), (rows_n[0], "BossWN-nano.nam"), (rows_n[-1], "BossWN-nano.nam"),
+              (rows_n[-1] + 1, "BossWN-feather.nam")]
+    for row, name in checks:
+        assert O.rms(y[row] - O.oracle_from_file(name).process(x[row])) < TOL_RMS, (row, name)
+
+
 def test_config5_a2_quality_sweep_and_midstream_switch(na, loader):
     """BASELINE configs[4]: A2 slimmable container, quality 0..1 per stream; a mid-stream quality change switches the
     active submodel and leaves the inactive one's state frozen (CompositeModel.h:94-100,176-181)."""
