@@ -439,6 +439,27 @@ def nam_json_wavenet_a1(channels, head_size, weights, lite=None):
                        "weights": [float(w) for w in weights], "sample_rate": 48000})
 
 
+def nam_json_wavenet_generic(arrays, weights):
+    """A .nam document for ANY array list in the oracle's dict format: A1 form when every layer of an array shares one kernel size and
+    the head is 1x1, A2 form ('kernel_sizes' + 'head' block) otherwise.  This is what the reference's dynamic path reads
+    (WaveNetDynamic.h / InternalModel.h:177-248)."""
+    layers = []
+    for a in arrays:
+        a2_form = len(set(a["kernel_sizes"])) > 1 or a["head_kernel_size"] != 1 or a["activation"] == ACT_LEAKYRELU
+        if a2_form:
+            act = {"type": "LeakyReLU", "negative_slope": 0.01} if a["activation"] == ACT_LEAKYRELU else {"type": "Tanh"}
+            layers.append({"input_size": a["input_size"], "condition_size": 1, "channels": a["channels"], "kernel_sizes": list(a["kernel_sizes"]),
+                           "dilations": list(a["dilations"]), "activation": [act] * len(a["dilations"]),
+                           "head": {"out_channels": a["head_size"], "kernel_size": a["head_kernel_size"], "bias": bool(a["has_head_bias"])}})
+        else:
+            layers.append({"input_size": a["input_size"], "condition_size": 1, "head_size": a["head_size"], "channels": a["channels"],
+                           "kernel_size": a["kernel_sizes"][0], "dilations": list(a["dilations"]), "activation": "Tanh", "gated": False,
+                           "head_bias": bool(a["has_head_bias"])})
+    return json.dumps({"version": "0.5.4", "architecture": "WaveNet", "metadata": {"loudness": -10.0},
+                       "config": {"layers": layers, "head": None, "head_scale": 0.02},
+                       "weights": [float(w) for w in weights], "sample_rate": 48000})
+
+
 def nam_json_lstm(num_layers, hidden, weights):
     return json.dumps({"version": "0.5.4", "architecture": "LSTM", "metadata": {"loudness": -12.0},
                        "config": {"input_size": 1, "hidden_size": hidden, "num_layers": num_layers},

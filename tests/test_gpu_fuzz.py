@@ -1,0 +1,59 @@
+"""Randomised parity: runtime-shaped WaveNet architectures (what the reference's dynamic path accepts -- any channel count <= 16,
+kernel size, dilation list, head shape) through the loader and the HIP path vs the oracle."""
+import numpy as np
+import pytest
+
+import na_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL_RMS = 2e-6
+
+
+@pytest.fixture(scope="module")
+def na():
+    import neuralaudio_amd
+    return neuralaudio_amd
+
+
+def _random_arrays(rng):
+    kind = rng.integers(0, 3)
+    if kind == 0:  # A1-style chain of two arrays, one kernel size per array, 1x1 heads
+        c1 = int(rng.choice([2, 3, 4, 5, 7, 8, 11, 12, 16]))
+        c2 = int(rng.choice([1, 2, 3, 4, 6, 8]))
+        arrays = []
+        for i, (cin, c, h, bias) in enumerate([(1, c1, c2, False), (c1, c2, 1, True)]):
+            nl = int(rng.integers(1, 7))
+            arrays.append(dict(input_size=cin, condition_size=1, head_size=h, head_kernel_size=1, head_dilation=1, channels=c,
+                               has_head_bias=bias, activation=O.ACT_TANH, kernel_sizes=[int(rng.integers(2, 6))] * nl,
+                               dilations=[int(rng.choice([1, 2, 3, 5, 8, 16, 31, 64, 100, 128, 200, 256])) for _ in range(nl)]))
+        return arrays
+    # single array, per-layer kernel sizes, conv head (A2 style); tanh or LeakyReLU
+    c = int(rng.choice([1, 2, 3, 5, 8, 13, 16]))
+    nl = int(rng.integers(1, 9))
+    return [dict(input_size=1, condition_size=1, head_size=1, head_kernel_size=int(rng.choice([1, 2, 7, 16])), head_dilation=1, channels=c,
+                 has_head_bias=bool(rng.integers(0, 2)) or kind == 2, activation=O.ACT_LEAKYRELU if kind == 2 else O.ACT_TANH,
+                 kernel_sizes=[int(rng.integers(1, 17)) for _ in range(nl)],
+                 dilations=[int(rng.choice([1, 2, 3, 7, 13, 17, 41, 64, 101, 239])) for _ in range(nl)])]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_architecture_matches_oracle(na, seed):
+    rng = np.random.default_rng(1000 + seed)
+    arrays = _random_arrays(rng)
+    w = O.synth_wavenet_weights(arrays, seed=seed)
+    loader = na.NeuralModelLoader()
+    m = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam", doPrewarm=True)
+    assert m is not None, arrays
+    ora = O.OracleWaveNet(arrays, w)
+    assert m.GetReceptiveFieldSize() == ora.receptive_field
+    x = O.signal_noise(1500, seed=seed)
+    sizes, pos, out = [int(v) for v in rng.choice([1, 17, 64, 65, 128, 200, 333], size=12)], 0, []
+    for n in sizes:
+        n = min(n, x.size - pos)
+        if n <= 0:
+            break
+        out.append(m.Process(x[pos:pos + n]))
+        pos += n
+    y = np.concatenate(out)
+    err = O.rms(y - ora.process(x[:pos]))
+    assert err < TOL_RMS, (arrays, err)
