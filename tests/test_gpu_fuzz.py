@@ -57,3 +57,15 @@ def test_random_architecture_matches_oracle(na, seed):
     y = np.concatenate(out)
     err = O.rms(y - ora.process(x[:pos]))
     assert err < TOL_RMS, (arrays, err)
+
+
+@pytest.mark.parametrize("hidden,layers", [(4, 1), (8, 3), (12, 2), (16, 3), (20, 1), (24, 2), (32, 1), (40, 1)])
+def test_lstm_shapes_beyond_the_official_ones(na, hidden, layers):
+    """NAM LSTM files of any supported shape (the reference's dynamic LSTM path, LSTMDynamic.h): every kernel family is hit --
+    LDS-free DPP (8/16, <= 2 layers), wave-per-stream (12..32, <= 2 layers), lane-per-stream (the rest)."""
+    w = O.synth_lstm_weights(layers, hidden, seed=hidden * 10 + layers)
+    m = na.NeuralModelLoader().CreateFromString(O.nam_json_lstm(layers, hidden, w), ".nam", doPrewarm=True)
+    assert m is not None
+    x = O.signal_noise(700, seed=hidden)
+    y = np.concatenate([m.Process(x[i:i + 100]) for i in range(0, x.size, 100)])
+    assert O.rms(y - O.OracleLSTM.from_nam(layers, hidden, w).process(x)) < 5e-6
