@@ -86,11 +86,13 @@ def cpu_baseline(seconds_target=12.0):
 
 
 def main():
+    global BLOCK
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (default: the BASELINE config)")
+    ap.add_argument("--block", type=int, default=BLOCK, help="samples per buffer (default 128 = the BASELINE config; other sizes are exploration only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed sustained load before warm-up so the shader clock reaches steady state")
     ap.add_argument("--workload", default="standard",
@@ -101,6 +103,7 @@ def main():
     import numpy as np
     import torch
 
+    BLOCK = args.block
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
