@@ -154,13 +154,21 @@ namespace na
 		template <int G>
 		__device__ __forceinline__ void FetchFramePre(float (&x)[4 * G], const f32x4* xb, int off, const f32x4 (&hpre)[G])
 		{
-			const int base = TileIdx(off < 0 ? 0 : off, G, 0);
+			// one divergent region per tap (not one per channel group): the in-block lanes overwrite the prefetched history with
+			// the LDS image, all G reads back to back
+			f32x4 v[G];
+#pragma unroll
+			for (int cg = 0; cg < G; cg++) v[cg] = hpre[cg];
+			if (off >= 0)
+			{
+				const int base = TileIdx(off, G, 0);
+#pragma unroll
+				for (int cg = 0; cg < G; cg++) v[cg] = xb[base + cg * 16];
+			}
 #pragma unroll
 			for (int cg = 0; cg < G; cg++)
 			{
-				const f32x4 l = xb[base + cg * 16];
-				const f32x4 v = (off < 0) ? hpre[cg] : l;
-				x[4 * cg] = v.x; x[4 * cg + 1] = v.y; x[4 * cg + 2] = v.z; x[4 * cg + 3] = v.w;
+				x[4 * cg] = v[cg].x; x[4 * cg + 1] = v[cg].y; x[4 * cg + 2] = v[cg].z; x[4 * cg + 3] = v[cg].w;
 			}
 		}
 
