@@ -122,6 +122,10 @@ namespace na
 		// float4 index of (frame, channel group) in a tiled image with G groups: ((frame>>4)*G + cg)*16 + (frame&15)
 		__device__ __forceinline__ int TileIdx(int frame, int G, int cg) { return ((frame >> 4) * G + cg) * 16 + (frame & 15); }
 
+		// float4 index of (frame, channel group) in the LDS block image: [64-frame wave part][cg][64 frames] -- a lane reads or writes its
+		// frame's G float4s 1 KB apart (one immediate offset per channel group), 64 consecutive frames are 1 KB contiguous
+		__device__ __forceinline__ int LdsIdx(int frame, int G, int cg) { return ((frame >> 6) * G + cg) * 64 + (frame & 63); }
+
 		// Channels [4*cg, 4*cg+4) of the frame `off` frames from the block start (off < 0: history) for this lane.
 		// lo/hi: range of `off` over the wave (scalar) -> whole wave in block / whole wave in history / mixed.
 		constexpr int HPF = 2; // shifted taps (most shifted first) whose history can be prefetched one layer ahead
@@ -161,9 +165,9 @@ namespace na
 			for (int cg = 0; cg < G; cg++) v[cg] = hpre[cg];
 			if (off >= 0)
 			{
-				const int base = TileIdx(off, G, 0);
+				const int base = LdsIdx(off, G, 0);
 #pragma unroll
-				for (int cg = 0; cg < G; cg++) v[cg] = xb[base + cg * 16];
+				for (int cg = 0; cg < G; cg++) v[cg] = xb[base + cg * 64];
 			}
 #pragma unroll
 			for (int cg = 0; cg < G; cg++)
@@ -180,9 +184,9 @@ namespace na
 			if (lo >= 0)
 			{
 				// whole wave inside the current block: LDS only
-				const int base = TileIdx(off, G, 0);
+				const int base = LdsIdx(off, G, 0);
 #pragma unroll
-				for (int cg = 0; cg < G; cg++) v[cg] = xb[base + cg * 16];
+				for (int cg = 0; cg < G; cg++) v[cg] = xb[base + cg * 64];
 			}
 			else
 			{
@@ -199,13 +203,13 @@ namespace na
 				else
 				{
 					// the wave straddles the block start: both, all loads issued before any is consumed
-					const int base = TileIdx(off < 0 ? 0 : off, G, 0);
+					const int base = LdsIdx(off < 0 ? 0 : off, G, 0);
 					const int hoff = (off < 0) ? vbase : OOB;
 					f32x4 l[G], h[G];
 #pragma unroll
 					for (int cg = 0; cg < G; cg++)
 					{
-						l[cg] = xb[base + cg * 16];
+						l[cg] = xb[base + cg * 64];
 						h[cg] = BufLoad(srsrc, hoff + cg * 256);
 					}
 #pragma unroll
@@ -269,7 +273,7 @@ namespace na
 		__device__ __forceinline__ void PublishLds(const float (&x)[MAXC], f32x4* xb, int f)
 		{
 #pragma unroll
-			for (int cg = 0; cg < G; cg++) xb[TileIdx(f, G, cg)] = f32x4{ x[4 * cg], x[4 * cg + 1], x[4 * cg + 2], x[4 * cg + 3] };
+			for (int cg = 0; cg < G; cg++) xb[LdsIdx(f, G, cg)] = f32x4{ x[4 * cg], x[4 * cg + 1], x[4 * cg + 2], x[4 * cg + 3] };
 		}
 
 		// ... and -> the next layer's HBM ring (history for LATER blocks: only the last R-128 frames of a block can ever be read back).
