@@ -128,6 +128,9 @@ namespace na
 
 		// Channels [4*cg, 4*cg+4) of the frame `off` frames from the block start (off < 0: history) for this lane.
 		// lo/hi: range of `off` over the wave (scalar) -> whole wave in block / whole wave in history / mixed.
+		// float4 per thread staged per stage by WeightStager (>= 6 KB per workgroup >= any official stage; larger blocks use its tail loop)
+		constexpr int StagerWcopy(int nwaves) { return (384 + 64 * nwaves - 1) / (64 * nwaves); }
+
 		constexpr int HPF = 2; // shifted taps (most shifted first) whose history can be prefetched one layer ahead
 
 		// history part of one tap for this lane's frame: channels of frame (pos0 + off) from the ring (lanes inside the block: nothing)
@@ -300,11 +303,46 @@ namespace na
 			StoreRing<G>(x, srsrc, ringOff, pos0, R, n, f);
 		}
 
+		// What a layer needs to know about the NEXT layer to request its ring history (PF == 2)
+		struct NextHistory
+		{
+			bool valid;
+			int ringOff, dilation, ksize, pos0, R;
+		};
+
+		// PF == 2: ring history straight into LDS (buffer_load_dwordx4 ... lds, no VGPRs): lane l's frame (f - shift) of channel group cg
+		// lands in hb[cg * 64 + l] -- the same [cg][64] shape as a wave part of the block image, so a tap reads either place through one
+		// selected base address.  Always G instructions (predicated through the offset): the VMEM count per layer stays fixed.
+		template <int G>
+		__device__ __forceinline__ void DmaHistory(f32x4* hb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int f, int shift, bool valid, int pos0, int R)
+		{
+			if (NA_ABL & 4) return;
+			int base = pos0 - shift; // shift <= R - 128, so one wrap is enough
+			if (base < 0) base += R;
+			unsigned p = (unsigned)(base + f);
+			p = __builtin_elementwise_min(p, p - (unsigned)R); // p >= R ? p - R : p
+			const int addr = (int)((p >> 4) * (unsigned)(G * 256) + (unsigned)(ringOff * 16)) + (int)((p & 15u) << 4);
+			const int hoff = (valid && f < shift) ? addr : OOB;
+#pragma unroll
+			for (int cg = 0; cg < G; cg++)
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (__attribute__((address_space(3))) void*)(hb + cg * 64), 16, hoff + cg * 256, 0, 0, 0);
+		}
+
+		// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt in bits 3:0 and 15:14; expcnt 6:4 and lgkmcnt 11:8 left at "don't wait")
+		template <int N>
+		__device__ __forceinline__ void WaitVmcnt()
+		{
+			static_assert(N >= 0 && N < 64, "");
+			asm volatile("" ::: "memory");
+			__builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+			asm volatile("" ::: "memory");
+		}
+
 		// WaveNetLayerT::Process (WaveNet.h:462-494) for one frame per lane
-		template <int G, int WPS, bool PF>
+		template <int G, int WPS, int PF, int NW>
 		__device__ __forceinline__ void LayerFr(const WnStage& sd, const f32x4* wl, CFloat vec, const f32x4* xbCur, f32x4* xbNext,
 			__amdgpu_buffer_rsrc_t srsrc, int inPos0, int outPos0, int n, int nSt, int f, int wave, int lane, float cond, float (&xc)[MAXC], float (&hd)[MAXC],
-			const f32x4 (&hcur)[HPF][G], bool haveCur)
+			const f32x4 (&hcur)[HPF][PF == 2 ? 1 : G], bool haveCur, f32x4* hb, const NextHistory& nh, __amdgpu_buffer_rsrc_t lrsrc, bool counted)
 		{
 			constexpr int C = 4 * G;
 			const int K = sd.ksize;
@@ -324,7 +362,36 @@ namespace na
 			// With PF the history of the first HPF taps was loaded during the previous layer (hcur); those taps are peeled so that each
 			// names its registers statically.
 			int kFirst = 0;
-			if (PF)
+			if (PF == 2)
+			{
+				// History of tap k was requested into hb[k] while the previous layer ran.  VMEM instructions this wave issued after that
+				// request, on every path: the other tap's G, the previous layer's G ring stores, WCOPY weight loads -- all others may stay
+				// in flight.  (`counted` is false for the first layer of a run, whose request has a different tail.)
+				constexpr int LATER = 2 * G + StagerWcopy(NW);
+#pragma unroll
+				for (int k = 0; k < HPF; k++)
+				{
+					if (k < K - 1)
+					{
+						const int off = f - d * (K - 1 - k);
+						if (counted) WaitVmcnt<LATER>();
+						else WaitVmcnt<0>();
+						const f32x4* src = (off < 0) ? hb + (k * G) * 64 + lane : xbCur + LdsIdx(off < 0 ? 0 : off, G, 0);
+						float x[C];
+#pragma unroll
+						for (int cg = 0; cg < G; cg++)
+						{
+							const f32x4 v = src[cg * 64];
+							x[4 * cg] = v.x; x[4 * cg + 1] = v.y; x[4 * cg + 2] = v.z; x[4 * cg + 3] = v.w;
+						}
+						DenseMfma<C, C>(acc, a4 + k * (64 * G), x);
+					}
+					// hb[k] is free again: request the next layer's tap k (issued even when there is nothing to fetch, see DmaHistory)
+					DmaHistory<G>(hb + (k * G) * 64, lrsrc, nh.ringOff, f, nh.dilation * (nh.ksize - 1 - k), nh.valid && k < nh.ksize - 1, nh.pos0, nh.R);
+				}
+				kFirst = HPF;
+			}
+			else if constexpr (PF == 1)
 			{
 #pragma unroll
 				for (int k = 0; k < HPF; k++)
@@ -434,7 +501,7 @@ namespace na
 		struct WeightStager
 		{
 			static constexpr int NTHREADS = 64 * NWAVES;
-			static constexpr int WCOPY = (384 + NTHREADS - 1) / NTHREADS; // float4 per thread (>= 6 KB per workgroup >= any official stage; larger blocks use the tail loop)
+			static constexpr int WCOPY = StagerWcopy(NWAVES);
 
 			__device__ __forceinline__ void Begin(f32x4* wlNext, __amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn, int waveAll)
 			{
@@ -484,6 +551,7 @@ namespace na
 			CFloat wvec;   // wpack (bias vectors of the non-layer stages), scalar loads
 			CFloat wpk;    // wpk, scalar loads (head weights)
 			f32x4* xbuf;   // this stream's [2][NTB*64] block images
+			f32x4* hbuf;   // PF == 2: this WAVE's [HPF][4][64] history buffers
 			__amdgpu_buffer_rsrc_t srsrc; // this stream's state
 			__amdgpu_buffer_rsrc_t lrsrc; // = srsrc (tuning builds: NA_ABL & 128 redirects the history loads)
 			int myPos;     // lane r: write cursor of ring r
@@ -577,7 +645,7 @@ namespace na
 		// A run of consecutive WaveNet layer stages with the same channel-group count G.  With `pre`, sd is the rechannel / array-link
 		// stage in front of the run and sdFirst its first layer: the ring history of that layer is requested BEFORE the pre-stage
 		// computes, so its HBM latency hides behind it (the per-frame state stays in registers typed by G either way).
-		template <int G, int WPS, bool PF, int SPB>
+		template <int G, int WPS, int PF, int SPB>
 		__device__ __forceinline__ void RunLayers(const FrCtx& cx, int& s, WnStage& sd, const WnStage& sdFirst, bool pre, int& cur, float (&xc)[MAXC], float (&hd)[MAXC])
 		{
 			constexpr int NTB = WPS * 4;
@@ -585,17 +653,21 @@ namespace na
 			long long* __restrict__ trace = cx.trace;
 			const int traceBlock = cx.traceBlock;
 			(void)waveAll; (void)trace; (void)traceBlock; (void)lane;
-			// history of the first HPF taps of the current layer; loaded here for the first layer of the run, afterwards one layer ahead
-			f32x4 hcur[HPF][G];
+			// history of the first HPF taps of the current layer; requested here for the first layer of the run, afterwards one layer ahead
+			// (PF == 1: into registers; PF == 2: into this wave's LDS history buffers)
+			f32x4 hcur[HPF][PF == 2 ? 1 : G];
+			f32x4* hb = cx.hbuf;
 #pragma unroll
 			for (int t = 0; t < HPF; t++)
 			{
 				const int shift0 = sdFirst.dilation * (sdFirst.ksize - 1 - t);
-				LoadHistory<G>(hcur[t], cx.lrsrc, sdFirst.ring_off, f, shift0, PF && t < sdFirst.ksize - 1, __builtin_amdgcn_readlane(cx.myPos, sdFirst.ring_id),
-					sdFirst.ring_frames);
+				const int pos0 = __builtin_amdgcn_readlane(cx.myPos, sdFirst.ring_id);
+				if constexpr (PF == 2) DmaHistory<G>(hb + (t * G) * 64, cx.lrsrc, sdFirst.ring_off, f, shift0, t < sdFirst.ksize - 1, pos0, sdFirst.ring_frames);
+				else LoadHistory<G>(hcur[t], cx.lrsrc, sdFirst.ring_off, f, shift0, PF && t < sdFirst.ksize - 1, pos0, sdFirst.ring_frames);
 			}
 			if (pre) OtherStage<WPS, SPB, false>(cx, s, sd, sdFirst, cur, xc, hd);
 			const bool haveCur = true;
+			bool counted = false; // the first layer's history request is followed by an irregular number of VMEM instructions
 			do
 			{
 				FR_TRACE(0);
@@ -611,23 +683,30 @@ namespace na
 				const int inPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
 				// history of the NEXT layer's first HPF taps: issued at the start of this layer (before its ring stores), consumed a layer
 				// later.  Always HPF*G loads, predicated through the offset, so the VMEM count per layer is the same on every path.
-				f32x4 hnext[HPF][G];
+				f32x4 hnext[HPF][PF == 2 ? 1 : G];
 				const bool haveNext = PF && (s + 1 < cx.nstages) && sdn.type == WN_ST_LAYER && sdn.G == G;
 				const int nextPos0 = __builtin_amdgcn_readlane(cx.myPos, haveNext ? sdn.ring_id : 0);
-#pragma unroll
-				for (int t = 0; t < HPF; t++)
+				if constexpr (PF == 1)
 				{
-					const int shiftN = sdn.dilation * (sdn.ksize - 1 - t);
-					if (PF) LoadHistory<G>(hnext[t], cx.lrsrc, sdn.ring_off, f, shiftN, haveNext && t < sdn.ksize - 1, nextPos0, sdn.ring_frames);
+#pragma unroll
+					for (int t = 0; t < HPF; t++)
+					{
+						const int shiftN = sdn.dilation * (sdn.ksize - 1 - t);
+						LoadHistory<G>(hnext[t], cx.lrsrc, sdn.ring_off, f, shiftN, haveNext && t < sdn.ksize - 1, nextPos0, sdn.ring_frames);
+					}
 				}
+				const NextHistory nh = { haveNext, sdn.ring_off, sdn.dilation, sdn.ksize, nextPos0, sdn.ring_frames };
 
-				LayerFr<G, WPS, PF>(sd, wl, cx.wvec + sd.vec_off * 4, cx.xbuf + cur * (NTB * 64), cx.xbuf + (cur ^ 1) * (NTB * 64), cx.srsrc, inPos0, outPos0, cx.n,
-					cx.nSt, f, cx.wave, lane, cx.cond, xc, hd, hcur, haveCur);
+				LayerFr<G, WPS, PF, WPS * SPB>(sd, wl, cx.wvec + sd.vec_off * 4, cx.xbuf + cur * (NTB * 64), cx.xbuf + (cur ^ 1) * (NTB * 64), cx.srsrc, inPos0,
+					outPos0, cx.n, cx.nSt, f, cx.wave, lane, cx.cond, xc, hd, hcur, haveCur, hb, nh, cx.lrsrc, counted);
+				counted = true;
+				if constexpr (PF == 1)
+				{
 #pragma unroll
-				for (int t = 0; t < HPF; t++)
+					for (int t = 0; t < HPF; t++)
 #pragma unroll
-					for (int cg = 0; cg < G; cg++)
-						if (PF) hcur[t][cg] = hnext[t][cg];
+						for (int cg = 0; cg < G; cg++) hcur[t][cg] = hnext[t][cg];
+				}
 				if (sd.flags & WN_FLAG_PUBLISH) cur ^= 1;
 				FR_TRACE(1);
 				stager.template End<PF ? 3 * G : 0>(wlNext, cx.wrsrc, sdn); // PF: 2G history loads + G ring stores follow Begin() on every path
@@ -666,7 +745,7 @@ namespace na
 			int numGroups;
 		};
 
-		template <int WPS, bool PF, int SPB>
+		template <int WPS, int PF, int SPB>
 		__global__ void __launch_bounds__(64 * WPS * SPB) WaveNetFrameKernel(const FrLaunchArgs args, int maxA4F4, const float* __restrict__ in,
 			float* __restrict__ out, long inStride, long outStride, int n, long long* __restrict__ trace, int traceBlock)
 		{
@@ -731,6 +810,7 @@ namespace na
 			cx.wvec = (CFloat)wpack;
 			cx.wpk = (CFloat)wpkGlobal;
 			cx.xbuf = xbuf;
+			cx.hbuf = reinterpret_cast<f32x4*>(smem) + SPB * (2 * NTB * 64) + 2 * maxA4F4 + waveAll * (HPF * 4 * 64); // after wbuf, PF == 2 only
 			cx.srsrc = MakeRsrc(st, (unsigned)stateF4 * 16u);
 			cx.lrsrc = (NA_ABL & 128) ? MakeRsrc(state + (size_t)(groupBlock & 7) * (size_t)stateF4, (unsigned)stateF4 * 16u) : cx.srsrc; // 128: history loads hit 8 hot slots
 			cx.myPos = myPos;
@@ -795,7 +875,7 @@ namespace na
 			}
 		}
 
-		template <int WPS, bool PF, int SPB>
+		template <int WPS, int PF, int SPB>
 		static hipError_t Launch(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream)
 		{
 			// stride of the two LDS weight buffers: the LDS-DMA staging always writes WCOPY * NTHREADS float4 slots (zeros past the block)
@@ -818,7 +898,7 @@ namespace na
 				blocks += (g.numStreams + SPB - 1) / SPB;
 				maxA4F4 = std::max(maxA4F4, (m.max_a4_floats + 3) / 4);
 			}
-			const size_t lds = (size_t)SPB * 2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16;
+			const size_t lds = (size_t)SPB * 2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16 + (PF == 2 ? (size_t)WPS * SPB * HPF * 4 * 64 * 16 : 0);
 			if (lds > 160 * 1024) return hipErrorInvalidValue;
 			auto kernel = WaveNetFrameKernel<WPS, PF, SPB>;
 			if (lds > 64 * 1024)
@@ -850,19 +930,21 @@ namespace na
 			total += groups[i].numStreams;
 			ldsWeights = std::max(ldsWeights, (size_t)2 * ((groups[i].model->max_a4_floats + 3) / 4) * 16);
 		}
-		static const bool prefetch = getenv("NA_FR_PF") ? atoi(getenv("NA_FR_PF")) != 0 : true; // tuning knob: cross-layer history prefetch
+		static const int prefetch = getenv("NA_FR_PF") ? atoi(getenv("NA_FR_PF")) : 1; // tuning knob: 0 none, 1 history prefetch into registers, 2 into LDS (LDS-DMA)
 		static const int spbEnv = getenv("NA_FR_SPB") ? atoi(getenv("NA_FR_SPB")) : 0;            // tuning knob: streams per workgroup (1, 2, 4)
 		// streams per workgroup: two streams share one staged copy of the weights once there are enough streams to cover all 256 CUs
 		// (measured 1024 x Standard: SPB 1 / 2 / 4 = 61.5 / 61.3 / 65.0 us -- at 4 the 8-wave barrier skew eats the saving)
 		const int spb = spbEnv > 0 ? spbEnv : (total >= 512 ? 2 : 1);
 		if (n > 64)
 		{
-			if (!prefetch) return fr::Launch<2, false, 1>(groups, numGroups, in, out, inStride, outStride, n, stream);
-			if (spb >= 4 && ldsWeights + 4 * 16384 <= 160 * 1024) return fr::Launch<2, true, 4>(groups, numGroups, in, out, inStride, outStride, n, stream);
-			if (spb >= 2) return fr::Launch<2, true, 2>(groups, numGroups, in, out, inStride, outStride, n, stream);
-			return fr::Launch<2, true, 1>(groups, numGroups, in, out, inStride, outStride, n, stream);
+			if (!prefetch) return fr::Launch<2, 0, 1>(groups, numGroups, in, out, inStride, outStride, n, stream);
+			if (spb >= 4 && ldsWeights + 4 * 16384 <= 160 * 1024) return fr::Launch<2, 1, 4>(groups, numGroups, in, out, inStride, outStride, n, stream);
+			if (prefetch == 2) return spb >= 2 ? fr::Launch<2, 2, 2>(groups, numGroups, in, out, inStride, outStride, n, stream)
+									   : fr::Launch<2, 2, 1>(groups, numGroups, in, out, inStride, outStride, n, stream);
+			if (spb >= 2) return fr::Launch<2, 1, 2>(groups, numGroups, in, out, inStride, outStride, n, stream);
+			return fr::Launch<2, 1, 1>(groups, numGroups, in, out, inStride, outStride, n, stream);
 		}
-		return fr::Launch<1, false, 1>(groups, numGroups, in, out, inStride, outStride, n, stream);
+		return fr::Launch<1, 0, 1>(groups, numGroups, in, out, inStride, outStride, n, stream);
 	}
 
 	hipError_t LaunchWaveNetFrame(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in, float* out,
