@@ -233,6 +233,9 @@ namespace na
 				dev.wpack_f4 = (int)(plan.wpack.size() / 4);
 				dev.max_stage_f4 = plan.maxStageF4;
 				dev.max_a4_floats = plan.maxA4Floats;
+				dev.max_ksize = 1;
+				for (const WnStage& st : plan.stages)
+					if (st.type == WN_ST_LAYER) dev.max_ksize = std::max(dev.max_ksize, st.ksize);
 				dev.wpk_floats = (int)plan.wpk.size();
 				dev.nrings = (int)plan.rings.size();
 				dev.state_f4 = plan.stateF4;

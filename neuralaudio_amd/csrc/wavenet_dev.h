@@ -116,6 +116,7 @@ namespace na
 		int wpack_f4;         // size of wpack in float4 units
 		int max_stage_f4;     // largest per-stage weight block in float4 units
 		int max_a4_floats;    // largest per-stage A-operand block of the frame kernel
+		int max_ksize;        // largest conv kernel size over all layers
 		int wpk_floats;
 		int nrings;
 		int state_f4;         // per-stream state size in float4 units (header + rings)

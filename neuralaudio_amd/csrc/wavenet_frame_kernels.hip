@@ -131,7 +131,10 @@ namespace na
 		// float4 per thread staged per stage by WeightStager (>= 6 KB per workgroup >= any official stage; larger blocks use its tail loop)
 		constexpr int StagerWcopy(int nwaves) { return (384 + 64 * nwaves - 1) / (64 * nwaves); }
 
-		constexpr int HPF = 2; // shifted taps (most shifted first) whose history can be prefetched one layer ahead
+		// HPF = number of shifted taps (most shifted first) whose ring history is requested one layer ahead: 2 covers every tap of the K = 3
+		// architectures; runs of narrow layers (G <= 2) of models with larger kernels (A2: K = 6 / 15) use HPF_WIDE, the rest of their taps
+		// load in line.  HPF_LDS sizes the per-wave LDS history buffers of the PF == 2 variant.
+		constexpr int HPF_NARROW = 2, HPF_WIDE = 5, HPF_LDS = 2;
 
 		// history part of one tap for this lane's frame: channels of frame (pos0 + off) from the ring (lanes inside the block: nothing)
 		// = frame (f - shift) of the block for the lanes with f < shift, when `valid` (wave-uniform); all other lanes load nothing.
@@ -339,7 +342,7 @@ namespace na
 		}
 
 		// WaveNetLayerT::Process (WaveNet.h:462-494) for one frame per lane
-		template <int G, int WPS, int PF, int NW>
+		template <int G, int WPS, int PF, int NW, int HPF>
 		__device__ __forceinline__ void LayerFr(const WnStage& sd, const f32x4* wl, CFloat vec, const f32x4* xbCur, f32x4* xbNext,
 			__amdgpu_buffer_rsrc_t srsrc, int inPos0, int outPos0, int n, int nSt, int f, int wave, int lane, float cond, float (&xc)[MAXC], float (&hd)[MAXC],
 			const f32x4 (&hcur)[HPF][PF == 2 ? 1 : G], bool haveCur, f32x4* hb, const NextHistory& nh, __amdgpu_buffer_rsrc_t lrsrc, bool counted)
@@ -362,11 +365,12 @@ namespace na
 			// With PF the history of the first HPF taps was loaded during the previous layer (hcur); those taps are peeled so that each
 			// names its registers statically.
 			int kFirst = 0;
-			if (PF == 2)
+			if constexpr (PF == 2)
 			{
 				// History of tap k was requested into hb[k] while the previous layer ran.  VMEM instructions this wave issued after that
 				// request, on every path: the other tap's G, the previous layer's G ring stores, WCOPY weight loads -- all others may stay
 				// in flight.  (`counted` is false for the first layer of a run, whose request has a different tail.)
+				static_assert(HPF == HPF_LDS, "the LDS history buffers hold HPF_LDS taps");
 				constexpr int LATER = 2 * G + StagerWcopy(NW);
 #pragma unroll
 				for (int k = 0; k < HPF; k++)
@@ -551,7 +555,7 @@ namespace na
 			CFloat wvec;   // wpack (bias vectors of the non-layer stages), scalar loads
 			CFloat wpk;    // wpk, scalar loads (head weights)
 			f32x4* xbuf;   // this stream's [2][NTB*64] block images
-			f32x4* hbuf;   // PF == 2: this WAVE's [HPF][4][64] history buffers
+			f32x4* hbuf;   // PF == 2: this WAVE's [HPF_LDS][4][64] history buffers
 			__amdgpu_buffer_rsrc_t srsrc; // this stream's state
 			__amdgpu_buffer_rsrc_t lrsrc; // = srsrc (tuning builds: NA_ABL & 128 redirects the history loads)
 			int myPos;     // lane r: write cursor of ring r
@@ -645,7 +649,7 @@ namespace na
 		// A run of consecutive WaveNet layer stages with the same channel-group count G.  With `pre`, sd is the rechannel / array-link
 		// stage in front of the run and sdFirst its first layer: the ring history of that layer is requested BEFORE the pre-stage
 		// computes, so its HBM latency hides behind it (the per-frame state stays in registers typed by G either way).
-		template <int G, int WPS, int PF, int SPB>
+		template <int G, int WPS, int PF, int SPB, int HPF>
 		__device__ __forceinline__ void RunLayers(const FrCtx& cx, int& s, WnStage& sd, const WnStage& sdFirst, bool pre, int& cur, float (&xc)[MAXC], float (&hd)[MAXC])
 		{
 			constexpr int NTB = WPS * 4;
@@ -697,7 +701,7 @@ namespace na
 				}
 				const NextHistory nh = { haveNext, sdn.ring_off, sdn.dilation, sdn.ksize, nextPos0, sdn.ring_frames };
 
-				LayerFr<G, WPS, PF, WPS * SPB>(sd, wl, cx.wvec + sd.vec_off * 4, cx.xbuf + cur * (NTB * 64), cx.xbuf + (cur ^ 1) * (NTB * 64), cx.srsrc, inPos0,
+				LayerFr<G, WPS, PF, WPS * SPB, HPF>(sd, wl, cx.wvec + sd.vec_off * 4, cx.xbuf + cur * (NTB * 64), cx.xbuf + (cur ^ 1) * (NTB * 64), cx.srsrc, inPos0,
 					outPos0, cx.n, cx.nSt, f, cx.wave, lane, cx.cond, xc, hd, hcur, haveCur, hb, nh, cx.lrsrc, counted);
 				counted = true;
 				if constexpr (PF == 1)
@@ -709,7 +713,7 @@ namespace na
 				}
 				if (sd.flags & WN_FLAG_PUBLISH) cur ^= 1;
 				FR_TRACE(1);
-				stager.template End<PF ? 3 * G : 0>(wlNext, cx.wrsrc, sdn); // PF: 2G history loads + G ring stores follow Begin() on every path
+				stager.template End<PF ? (HPF + 1) * G : 0>(wlNext, cx.wrsrc, sdn); // PF: HPF*G history loads + G ring stores follow Begin() on every path
 				FR_TRACE(2);
 				BlockBarrier<WPS * SPB>();
 				FR_TRACE(3);
@@ -736,6 +740,7 @@ namespace na
 			int nstages, nrings, stateF4, wpkFloats;
 			float headScale;
 			int numStreams, slot0, row0;
+			int maxKsize;   // largest conv kernel of the model
 			int firstBlock; // workgroups [firstBlock, next group's firstBlock) belong to this group
 		};
 
@@ -810,7 +815,7 @@ namespace na
 			cx.wvec = (CFloat)wpack;
 			cx.wpk = (CFloat)wpkGlobal;
 			cx.xbuf = xbuf;
-			cx.hbuf = reinterpret_cast<f32x4*>(smem) + SPB * (2 * NTB * 64) + 2 * maxA4F4 + waveAll * (HPF * 4 * 64); // after wbuf, PF == 2 only
+			cx.hbuf = reinterpret_cast<f32x4*>(smem) + SPB * (2 * NTB * 64) + 2 * maxA4F4 + waveAll * (HPF_LDS * 4 * 64); // after wbuf, PF == 2 only
 			cx.srsrc = MakeRsrc(st, (unsigned)stateF4 * 16u);
 			cx.lrsrc = (NA_ABL & 128) ? MakeRsrc(state + (size_t)(groupBlock & 7) * (size_t)stateF4, (unsigned)stateF4 * 16u) : cx.srsrc; // 128: history loads hit 8 hot slots
 			cx.myPos = myPos;
@@ -846,10 +851,20 @@ namespace na
 				if (pre || sd.type == WN_ST_LAYER)
 				{
 					const WnStage& first = pre ? sdn : sd;
-					if (first.G == 4) RunLayers<4, WPS, PF, SPB>(cx, s, sd, first, pre, cur, xc, hd);
-					else if (first.G == 3) RunLayers<3, WPS, PF, SPB>(cx, s, sd, first, pre, cur, xc, hd);
-					else if (first.G == 2) RunLayers<2, WPS, PF, SPB>(cx, s, sd, first, pre, cur, xc, hd);
-					else RunLayers<1, WPS, PF, SPB>(cx, s, sd, first, pre, cur, xc, hd);
+					// narrow layers of a model with kernels larger than 3 (A2): request 5 taps ahead instead of 2
+					const bool wide = PF == 1 && ga.maxKsize > 3;
+					if (first.G == 4) RunLayers<4, WPS, PF, SPB, HPF_NARROW>(cx, s, sd, first, pre, cur, xc, hd);
+					else if (first.G == 3) RunLayers<3, WPS, PF, SPB, HPF_NARROW>(cx, s, sd, first, pre, cur, xc, hd);
+					else if (first.G == 2)
+					{
+						if (wide) RunLayers<2, WPS, PF, SPB, PF == 1 ? HPF_WIDE : HPF_NARROW>(cx, s, sd, first, pre, cur, xc, hd);
+						else RunLayers<2, WPS, PF, SPB, HPF_NARROW>(cx, s, sd, first, pre, cur, xc, hd);
+					}
+					else
+					{
+						if (wide) RunLayers<1, WPS, PF, SPB, PF == 1 ? HPF_WIDE : HPF_NARROW>(cx, s, sd, first, pre, cur, xc, hd);
+						else RunLayers<1, WPS, PF, SPB, HPF_NARROW>(cx, s, sd, first, pre, cur, xc, hd);
+					}
 					continue;
 				}
 				OtherStage<WPS, SPB, true>(cx, s, sd, sdn, cur, xc, hd);
@@ -894,11 +909,12 @@ namespace na
 				a.nstages = m.nstages; a.nrings = m.nrings; a.stateF4 = m.state_f4; a.wpkFloats = m.wpk_floats;
 				a.headScale = m.head_scale;
 				a.numStreams = g.numStreams; a.slot0 = g.slot0; a.row0 = g.row0;
+				a.maxKsize = m.max_ksize;
 				a.firstBlock = blocks;
 				blocks += (g.numStreams + SPB - 1) / SPB;
 				maxA4F4 = std::max(maxA4F4, (m.max_a4_floats + 3) / 4);
 			}
-			const size_t lds = (size_t)SPB * 2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16 + (PF == 2 ? (size_t)WPS * SPB * HPF * 4 * 64 * 16 : 0);
+			const size_t lds = (size_t)SPB * 2 * WPS * 4 * 64 * 16 + (size_t)2 * maxA4F4 * 16 + (PF == 2 ? (size_t)WPS * SPB * HPF_LDS * 4 * 64 * 16 : 0);
 			if (lds > 160 * 1024) return hipErrorInvalidValue;
 			auto kernel = WaveNetFrameKernel<WPS, PF, SPB>;
 			if (lds > 64 * 1024)
