@@ -544,6 +544,31 @@ namespace na
 #define FR_TRACE(point) (void)0
 #endif
 
+		// Head conv whose whole reach (K-1)*dil fits in 16 frames (every official A2 head: K = 16, dil = 1): the 16 frames before the
+		// block start were parked in `pad` ([cg][16] float4, see OtherStage), so every tap reads LDS only -- no ring loads, no waits per tap.
+		template <int G>
+		__device__ __forceinline__ float HeadConvLds(const WnStage& sd, CFloat wpk, const f32x4* xb, const f32x4* pad, int f, float bias)
+		{
+			constexpr int C = 4 * G;
+			float acc = bias;
+			CFloat w = wpk + sd.pk_conv_off;
+			for (int k = 0; k < sd.ksize; k++)
+			{
+				const int off = f - sd.dilation * (sd.ksize - 1 - k);
+#pragma unroll
+				for (int cg = 0; cg < G; cg++)
+				{
+					const f32x4* src = (off < 0) ? pad + cg * 16 + (off + 16) : xb + LdsIdx(off < 0 ? 0 : off, G, cg);
+					const f32x4 v = *src;
+					acc = __builtin_fmaf(w[k * C + 4 * cg + 0], v.x, acc);
+					acc = __builtin_fmaf(w[k * C + 4 * cg + 1], v.y, acc);
+					acc = __builtin_fmaf(w[k * C + 4 * cg + 2], v.z, acc);
+					acc = __builtin_fmaf(w[k * C + 4 * cg + 3], v.w, acc);
+				}
+			}
+			return acc;
+		}
+
 		// everything a stage needs that does not change from stage to stage
 		struct FrCtx
 		{
@@ -628,10 +653,27 @@ namespace na
 			{
 				PublishAny(sd.out_G, hd, xbNext, cx.srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, cx.nSt, f);
 				cur ^= 1;
+				// short reach: park the 16 frames before the block start next to the image (the other block buffer is dead by now)
+				const bool shortReach = sd.dilation * (sd.ksize - 1) <= 16;
+				f32x4* pad = cx.xbuf + (cur ^ 1) * (NTB * 64); // = the buffer the last layer read from
+				if (shortReach && cx.wave == 0 && lane < 16)
+				{
+					const int R = sd.ring_frames;
+					int p = inPos0 - 16 + lane;
+					if (p < 0) p += R;
+					for (int cg = 0; cg < sd.G; cg++) pad[cg * 16 + lane] = BufLoad(cx.srsrc, (sd.ring_off + TileIdx(p, sd.G, cg)) * 16);
+				}
 				BlockBarrier<WPS * SPB>();
 				const float bias = (sd.flags & WN_FLAG_BIAS) ? vec[0] : 0.0f;
 				float o;
-				if (sd.G == 4) o = HeadConvPk<4>(sd, cx.wpk, xbNext, cx.srsrc, inPos0, f, cx.wave, bias);
+				if (shortReach)
+				{
+					if (sd.G == 4) o = HeadConvLds<4>(sd, cx.wpk, xbNext, pad, f, bias);
+					else if (sd.G == 3) o = HeadConvLds<3>(sd, cx.wpk, xbNext, pad, f, bias);
+					else if (sd.G == 2) o = HeadConvLds<2>(sd, cx.wpk, xbNext, pad, f, bias);
+					else o = HeadConvLds<1>(sd, cx.wpk, xbNext, pad, f, bias);
+				}
+				else if (sd.G == 4) o = HeadConvPk<4>(sd, cx.wpk, xbNext, cx.srsrc, inPos0, f, cx.wave, bias);
 				else if (sd.G == 3) o = HeadConvPk<3>(sd, cx.wpk, xbNext, cx.srsrc, inPos0, f, cx.wave, bias);
 				else if (sd.G == 2) o = HeadConvPk<2>(sd, cx.wpk, xbNext, cx.srsrc, inPos0, f, cx.wave, bias);
 				else o = HeadConvPk<1>(sd, cx.wpk, xbNext, cx.srsrc, inPos0, f, cx.wave, bias);

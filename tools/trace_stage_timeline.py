@@ -10,7 +10,7 @@ from neuralaudio_amd import capi
 S, n = 1024, 128
 dev = torch.device("cuda", 0)
 loader = na.NeuralModelLoader()
-model = loader.CreateFromFile(os.path.join(ROOT, "tests/golden/models/BossWN-standard.nam"), doPrewarm=False)
+model = loader.CreateFromFile(os.path.join(ROOT, "tests/golden/models", os.environ.get("NA_TRACE_MODEL", "BossWN-standard.nam")), doPrewarm=False)
 ts = torch.cuda.Stream(device=dev); torch.cuda.set_stream(ts)
 batch = na.Batch(0, hip_stream=ts.cuda_stream)
 batch.AddStreams(model, S)
@@ -18,7 +18,7 @@ x = torch.clamp(0.25 * torch.randn(S, n), -1, 1).to(dev); y = torch.empty_like(x
 for _ in range(5):
     batch.ProcessDevice(x.data_ptr(), y.data_ptr(), n)
 torch.cuda.synchronize()
-nst, waves = 24, int(os.environ.get("NA_TRACE_WAVES", "4"))  # 23 stages of Standard + 1 slot for kernel entry / exit
+nst, waves = int(os.environ.get("NA_TRACE_STAGES", "23")) + 1, int(os.environ.get("NA_TRACE_WAVES", "4"))  # 23 stages of Standard + 1 slot for kernel entry / exit
 trace = torch.zeros(nst * 4 * waves, dtype=torch.int64, device=dev)
 capi.load_library().NA_DebugSetTraceBuffer(trace.data_ptr())
 batch.ProcessDevice(x.data_ptr(), y.data_ptr(), n)
