@@ -47,15 +47,12 @@ namespace na
 
 	struct WnStage
 	{
+		// ---- first 16 ints: everything the frame kernel reads per stage (one s_load_dwordx16; a stage is 128 bytes)
 		int type;
 		int flags;
 		int G;               // channel groups of this stage's conv input
-		int nrounds;         // conv rounds (4 k-quads = 4 MFMAs x 4 lane groups each)
-		int wconv_off;       // float4 index into wpack: [round][64 lanes]
-		int qdesc_off;       // int4 index into qdesc: [round][4 lane groups] = {shift, channel group, valid, 0}
-		int vec_off;         // float4 index: [0..3] conv/dense bias, [4..7] mix-in w, [8..11] 1x1 bias, [12..15] aux
-		int w1_off;          // float4 index: [64 lanes] 1x1 (layer) / head dense
-		int w2_off;          // float4 index: [64 lanes] second dense of WN_ST_ARRAY_LINK (rechannel)
+		int ksize;           // conv kernel size / dilation of this stage (0 for stages without a conv)
+		int dilation;
 		int ring_id;         // ring read by this stage's conv (-1: none)
 		int ring_off;        // float4 offset of that ring in the stream state
 		int ring_frames;
@@ -63,19 +60,26 @@ namespace na
 		int out_ring_off;
 		int out_ring_frames;
 		int out_G;
+		// frame kernel (lane = frame, v_mfma_f32_4x4x1_16b_f32): this stage's A-operand block in wpk, staged into LDS one stage ahead
+		int a4_off;          // float offset into wpk ([conv taps | 1x1 | vectors] or [head dense | rechannel])
+		int a4_floats;       // 0: stage has no MFMA weights
+		int vec_off;         // float4 index into wpack: [0..3] conv/dense bias, [4..7] mix-in w, [8..11] 1x1 bias, [12..15] aux
+		int pk_conv_off;     // packed-FMA layouts, float offsets into wpk: conv [tap][in c][out o]  (head conv: [tap][in c])
+		// ---- the rest: head dense of the frame kernel, tile kernel, packed-FMA kernel
+		int pk_w1_off;       // 1x1 / head dense [in c][out o]
+		int pk_w2_off;       // rechannel of WN_ST_ARRAY_LINK [in c][out o]
+		int nrounds;         // tile kernel: conv rounds (4 k-quads = 4 MFMAs x 4 lane groups each)
+		int wconv_off;       // float4 index into wpack: [round][64 lanes]
+		int qdesc_off;       // int4 index into qdesc: [round][4 lane groups] = {shift, channel group, valid, 0}
+		int w1_off;          // float4 index: [64 lanes] 1x1 (layer) / head dense
+		int w2_off;          // float4 index: [64 lanes] second dense of WN_ST_ARRAY_LINK (rechannel)
 		int hist_rounds;     // leading conv rounds that may read history (shift > 0); later rounds are in-block only
 		int wblk_off;        // float4 index: this stage's weights are ONE contiguous block [wblk_off, wblk_off + wblk_f4)
 		int wblk_f4;         // (vec | conv rounds | w1 | w2), staged into LDS one stage ahead
-		int ksize;           // conv kernel size / dilation of this stage (0 for stages without a conv)
-		int dilation;
-		// packed-FMA (lane = frame) kernel: float offsets into wpk, all blocks padded to C = 4*G (link stages: 16)
-		int pk_conv_off;     // conv [tap][in c][out o]  (head conv: [tap][in c])
-		int pk_w1_off;       // 1x1 / head dense [in c][out o]
-		int pk_w2_off;       // rechannel of WN_ST_ARRAY_LINK [in c][out o]
-		// frame kernel (lane = frame, v_mfma_f32_4x4x1_16b_f32): this stage's A-operand block in wpk, staged into LDS one stage ahead
-		int a4_off;          // float offset into wpk ([conv taps | 1x1] or [head dense | rechannel])
-		int a4_floats;       // 0: stage has no MFMA weights
+		int reserved[6];
 	};
+	static_assert(sizeof(WnStage) == 128, "stage descriptors are 128-byte records");
+
 
 	struct WnQuad
 	{

@@ -20,6 +20,7 @@
 // f32 MFMA runs at the f32 VALU rate and does NOT overlap with VALU work on the same SIMD, so every padded MFMA row and
 // every activation evaluated on a padding lane is pure loss; the tile mapping pads 8-channel layers to 16 rows.
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
@@ -42,7 +43,6 @@ namespace na
                  // 4: no history loads / ring stores, 8: no barrier, 16: no weight staging, 32: staging loads but no LDS writes, 64: LDS writes but no loads, 128: history loads from cache-resident slots, 256: no ring stores
 #endif
 		constexpr int OOB = (int)0x80000000;
-		constexpr int STAGE_INTS = (int)(sizeof(WnStage) / sizeof(int));
 		constexpr int MAXC = 16;
 
 		__device__ __forceinline__ __amdgpu_buffer_rsrc_t MakeRsrc(const void* base, unsigned bytes)
@@ -60,13 +60,25 @@ namespace na
 			__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
 		}
 
-		__device__ __forceinline__ WnStage LoadStage(const WnStage* __restrict__ stages, int s)
+		// the 16 hot ints of a stage descriptor (WnStage's first 64 bytes: one scalar load), as a plain struct of scalars so that it
+		// lives in SGPRs (the full 128-byte record with its reserved[] tail would be copied through scratch memory)
+		struct FrStage
 		{
-			WnStage sd;
+			int type, flags, G, ksize, dilation, ring_id, ring_off, ring_frames, out_ring_id, out_ring_off, out_ring_frames, out_G, a4_off, a4_floats, vec_off,
+				pk_conv_off;
+		};
+		constexpr int STAGE_HOT_INTS = (int)(sizeof(FrStage) / sizeof(int));
+		static_assert(STAGE_HOT_INTS == 16 && offsetof(WnStage, type) == 0 && offsetof(WnStage, a4_floats) == 13 * sizeof(int) &&
+						  offsetof(WnStage, pk_conv_off) == 15 * sizeof(int) && offsetof(WnStage, pk_w1_off) == 16 * sizeof(int),
+			"FrStage mirrors the first 16 ints of WnStage");
+
+		__device__ __forceinline__ FrStage LoadStage(const WnStage* __restrict__ stages, int s)
+		{
+			FrStage sd;
 			CInt src = (CInt)(const int*)(stages + s);
 			int* dst = reinterpret_cast<int*>(&sd);
 #pragma unroll
-			for (int i = 0; i < STAGE_INTS; i++) dst[i] = src[i];
+			for (int i = 0; i < STAGE_HOT_INTS; i++) dst[i] = src[i];
 			return sd;
 		}
 
@@ -343,7 +355,7 @@ namespace na
 
 		// WaveNetLayerT::Process (WaveNet.h:462-494) for one frame per lane
 		template <int G, int WPS, int PF, int NW, int HPF>
-		__device__ __forceinline__ void LayerFr(const WnStage& sd, const f32x4* wl, CFloat vec, const f32x4* xbCur, f32x4* xbNext,
+		__device__ __forceinline__ void LayerFr(const FrStage& sd, const f32x4* wl, CFloat vec, const f32x4* xbCur, f32x4* xbNext,
 			__amdgpu_buffer_rsrc_t srsrc, int inPos0, int outPos0, int n, int nSt, int f, int wave, int lane, float cond, float (&xc)[MAXC], float (&hd)[MAXC],
 			const f32x4 (&hcur)[HPF][PF == 2 ? 1 : G], bool haveCur, f32x4* hb, const NextHistory& nh, __amdgpu_buffer_rsrc_t lrsrc, bool counted)
 		{
@@ -480,7 +492,7 @@ namespace na
 
 		// A2 head: out = scale * (bias + sum_k sum_c w[k][c] * head[t - (K-1-k)*dil][c])   (WaveNet.h:658-660, Conv1D C -> 1, K = 16)
 		template <int G>
-		__device__ __forceinline__ float HeadConvPk(const WnStage& sd, CFloat wpk, const f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int pos0, int f,
+		__device__ __forceinline__ float HeadConvPk(const FrStage& sd, CFloat wpk, const f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int pos0, int f,
 			int wave, float bias)
 		{
 			constexpr int C = 4 * G;
@@ -507,7 +519,7 @@ namespace na
 			static constexpr int NTHREADS = 64 * NWAVES;
 			static constexpr int WCOPY = StagerWcopy(NWAVES);
 
-			__device__ __forceinline__ void Begin(f32x4* wlNext, __amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn, int waveAll)
+			__device__ __forceinline__ void Begin(f32x4* wlNext, __amdgpu_buffer_rsrc_t wrsrc, const FrStage& sdn, int waveAll)
 			{
 				if (NA_ABL & 16) return;
 				const int nextF4 = sdn.a4_floats / 4;
@@ -523,7 +535,7 @@ namespace na
 
 			// LATER = number of VMEM instructions this wave issued after Begin() on every path (they may stay in flight), or 0
 			template <int LATER>
-			__device__ __forceinline__ void End(f32x4* wlNext, __amdgpu_buffer_rsrc_t wrsrc, const WnStage& sdn)
+			__device__ __forceinline__ void End(f32x4* wlNext, __amdgpu_buffer_rsrc_t wrsrc, const FrStage& sdn)
 			{
 				if (NA_ABL & 16) return;
 				const int nextF4 = sdn.a4_floats / 4;
@@ -547,7 +559,7 @@ namespace na
 		// Head conv whose whole reach (K-1)*dil fits in 16 frames (every official A2 head: K = 16, dil = 1): the 16 frames before the
 		// block start were parked in `pad` ([cg][16] float4, see OtherStage), so every tap reads LDS only -- no ring loads, no waits per tap.
 		template <int G>
-		__device__ __forceinline__ float HeadConvLds(const WnStage& sd, CFloat wpk, const f32x4* xb, const f32x4* pad, int f, float bias)
+		__device__ __forceinline__ float HeadConvLds(const FrStage& sd, CFloat wpk, const f32x4* xb, const f32x4* pad, int f, float bias)
 		{
 			constexpr int C = 4 * G;
 			float acc = bias;
@@ -596,7 +608,7 @@ namespace na
 
 		// One non-layer stage (rechannel / array link / head), including the staging of the next stage's weights and the closing barrier.
 		template <int WPS, int SPB, bool HEADS>
-		__device__ __forceinline__ void OtherStage(const FrCtx& cx, int& s, WnStage& sd, const WnStage& sdn, int& cur, float (&xc)[MAXC], float (&hd)[MAXC])
+		__device__ __forceinline__ void OtherStage(const FrCtx& cx, int& s, FrStage& sd, const FrStage& sdn, int& cur, float (&xc)[MAXC], float (&hd)[MAXC])
 		{
 			constexpr int NTB = WPS * 4;
 			const int lane = cx.lane, waveAll = cx.waveAll, f = cx.f;
@@ -644,7 +656,7 @@ namespace na
 			else if (HEADS && sd.type == WN_ST_HEAD_DENSE_OUT)
 			{
 				float o = (sd.flags & WN_FLAG_BIAS) ? vec[0] : 0.0f;
-				CFloat wh = cx.wpk + sd.pk_w1_off;
+				CFloat wh = cx.wpk + ((CInt)(const int*)(cx.stages + s))[STAGE_HOT_INTS]; // pk_w1_off = first cold field (static_assert below)
 #pragma unroll
 				for (int c = 0; c < MAXC; c++) o = __builtin_fmaf(wh[c], hd[c], o);
 				if (f < cx.nSt) cx.out[cx.outBase + f] = cx.headScale * o; // :793-798
@@ -692,7 +704,7 @@ namespace na
 		// stage in front of the run and sdFirst its first layer: the ring history of that layer is requested BEFORE the pre-stage
 		// computes, so its HBM latency hides behind it (the per-frame state stays in registers typed by G either way).
 		template <int G, int WPS, int PF, int SPB, int HPF>
-		__device__ __forceinline__ void RunLayers(const FrCtx& cx, int& s, WnStage& sd, const WnStage& sdFirst, bool pre, int& cur, float (&xc)[MAXC], float (&hd)[MAXC])
+		__device__ __forceinline__ void RunLayers(const FrCtx& cx, int& s, FrStage& sd, const FrStage& sdFirst, bool pre, int& cur, float (&xc)[MAXC], float (&hd)[MAXC])
 		{
 			constexpr int NTB = WPS * 4;
 			const int lane = cx.lane, waveAll = cx.waveAll, f = cx.f;
@@ -717,7 +729,7 @@ namespace na
 			do
 			{
 				FR_TRACE(0);
-				WnStage sdn = sd;
+				FrStage sdn = sd;
 				sdn.a4_floats = 0;
 				sdn.type = -1;
 				if (s + 1 < cx.nstages) sdn = LoadStage(cx.stages, s + 1);
@@ -874,7 +886,7 @@ namespace na
 			cx.trace = trace;
 			cx.traceBlock = traceBlock;
 
-			WnStage sd = LoadStage(stages, 0);
+			FrStage sd = LoadStage(stages, 0);
 			for (int i = threadIdx.x; i < sd.a4_floats / 4; i += NTHREADS) wbuf[i] = BufLoad(cx.wrsrc, (sd.a4_off / 4 + i) * 16);
 			BlockBarrier<WPS * SPB>();
 
@@ -885,14 +897,14 @@ namespace na
 				// Hot path: runs of WaveNet layers with the same channel-group count execute in their own tight loop, so the per-frame
 				// state (xc, hd) stays in fixed registers across layers (no phi copies at the stage-type branches).  The rechannel /
 				// array-link stage in front of a run executes inside it (see RunLayers).
-				WnStage sdn = sd;
+				FrStage sdn = sd;
 				sdn.a4_floats = 0;
 				sdn.type = -1;
 				if (s + 1 < nstages) sdn = LoadStage(stages, s + 1);
 				const bool pre = (sd.type == WN_ST_RECHANNEL_COND || sd.type == WN_ST_ARRAY_LINK) && sdn.type == WN_ST_LAYER;
 				if (pre || sd.type == WN_ST_LAYER)
 				{
-					const WnStage& first = pre ? sdn : sd;
+					const FrStage& first = pre ? sdn : sd;
 					// narrow layers of a model with kernels larger than 3 (A2): request 5 taps ahead instead of 2
 					const bool wide = PF == 1 && ga.maxKsize > 3;
 					if (first.G == 4) RunLayers<4, WPS, PF, SPB, HPF_NARROW>(cx, s, sd, first, pre, cur, xc, hd);
