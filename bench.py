@@ -53,7 +53,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(seconds_target=12.0):
+def cpu_baseline(workload="standard", seconds_target=12.0):
     """The oracle ('port' of the reference's Internal CPU path) timed on this box's host cores,
     ModelTest protocol (blocks of zeros after prewarm, Utils/ModelTest/ModelTest.cpp:59-79)."""
     import ctypes as C
@@ -61,27 +61,44 @@ def cpu_baseline(seconds_target=12.0):
     import na_oracle as O  # cpu_baseline leg only
 
     lib = O.load_native_lib()
-    j = O.load_json("BossWN-standard.nam")
-    arrays = O.wavenet_arrays_from_nam(j)
-    cfgs = O._cfgs(arrays)
+    files = {"standard": "BossWN-standard.nam", "feather": "BossWN-feather.nam", "nano": "BossWN-nano.nam", "a2full": "BossWN-a2.nam",
+             "a2lite": "BossWN-a2.nam", "lstm1x16": "BossLSTM-1x16.nam", "lstm2x8": "BossLSTM-2x8.nam"}
+    if workload not in files:
+        raise ValueError("no CPU baseline for workload " + workload)
+    j = O.load_json(files[workload])
+    if j["architecture"] == "SlimmableContainer":
+        j = j["config"]["submodels"][O.quality_to_submodel(j, 0.0 if workload == "a2lite" else 1.0)]["model"]
     w = np.ascontiguousarray(j["weights"], dtype=np.float32)
     wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    if j["architecture"] == "LSTM":
+        nl, hid = int(j["config"]["num_layers"]), int(j["config"]["hidden_size"])
+        lib.na_oracle_lstm_bench.restype = C.c_double
+        lib.na_oracle_lstm_bench.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_int, C.c_int]
+
+        def run(blocks, threads):
+            return lib.na_oracle_lstm_bench(nl, hid, wp, w.size, BLOCK, blocks, threads)
+    else:
+        arrays = O.wavenet_arrays_from_nam(j)
+        cfgs = O._cfgs(arrays)
+
+        def run(blocks, threads):
+            return lib.na_oracle_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, blocks, threads)
     cores = usable_cores()
     # calibrate on a short all-core run, then size the timed run to ~seconds_target of wall time
-    t1 = lib.na_oracle_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, 32, 1)
+    t1 = run(32, 1)
     single = 32 * BLOCK / t1
-    tc = lib.na_oracle_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, 16, cores)
+    tc = run(16, cores)
     per_thread = 16 * BLOCK / tc
-    blocks = max(16, min(int(seconds_target * per_thread / BLOCK), 200000))
-    t = lib.na_oracle_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, blocks, cores)
+    blocks = max(16, min(int(seconds_target * per_thread / BLOCK), 2000000))
+    t = run(blocks, cores)
     total = cores * blocks * BLOCK
     return {
         "value": total / t / 1e6,
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d threads x %d buffers of %d zero samples each after prewarm (ModelTest protocol), %.1f s wall; "
-                  "single-thread %.3f Msamples/s (%.1fx real-time)" % (cores, blocks, BLOCK, t, single / 1e6, single / 48000.0),
+        "sample": "%s: %d threads x %d buffers of %d zero samples each after prewarm (ModelTest protocol), %.1f s wall; "
+                  "single-thread %.3f Msamples/s (%.1fx real-time)" % (files[workload], cores, blocks, BLOCK, t, single / 1e6, single / 48000.0),
     }
 
 
@@ -275,9 +292,9 @@ def main():
             lat = sorted(lat[50:])
             out["host_buffer_latency_ms"] = {"p50": lat[len(lat) // 2], "p99": lat[int(len(lat) * 0.99)], "max": lat[-1], "calls": len(lat),
                                              "what": "NA_BatchProcess, %d streams x %d samples, host pointers" % (S, BLOCK)}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "standard":
+        if world == 1 and not args.no_cpu_baseline and args.workload not in ("mixed3", "config4"):
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(args.workload)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
