@@ -69,3 +69,75 @@ def test_lstm_shapes_beyond_the_official_ones(na, hidden, layers):
     x = O.signal_noise(700, seed=hidden)
     y = np.concatenate([m.Process(x[i:i + 100]) for i in range(0, x.size, 100)])
     assert O.rms(y - O.OracleLSTM.from_nam(layers, hidden, w).process(x)) < 5e-6
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_batch_operations_track_per_stream_oracles(na, seed):
+    """A stateful walk over the batch API: streams of four model kinds join at random times (prewarmed or fresh), A2 streams switch
+    quality mid-run, single streams are re-prewarmed, buffer sizes are ragged -- every stream must keep matching its own oracle,
+    which is driven through the same sequence.  (CompositeModel.h:94-100,176-181 semantics for the quality switch: the active
+    submodel processes, the inactive one's state stays frozen.)"""
+    import json
+    import os
+    rng = np.random.default_rng(500 + seed)
+    loader = na.NeuralModelLoader()
+    mdir = O.MODELS_DIR
+    gj = O.synth_keras_gru(1, 8, seed=77)
+    models = {
+        "feather": loader.CreateFromFile(os.path.join(mdir, "BossWN-feather.nam"), doPrewarm=False),
+        "nano": loader.CreateFromFile(os.path.join(mdir, "BossWN-nano.nam"), doPrewarm=False),
+        "a2": loader.CreateFromFile(os.path.join(mdir, "BossWN-a2.nam"), doPrewarm=False),
+        "lstm": loader.CreateFromFile(os.path.join(mdir, "BossLSTM-2x8.nam"), doPrewarm=False),
+        "gru": loader.CreateFromString(json.dumps(gj), ".json", doPrewarm=False),
+    }
+    a2json = O.load_json("BossWN-a2.nam")
+
+    class Ref:  # one reference-side stream: a set of oracle submodels + the active index
+        def __init__(self, kind, quality, prewarm):
+            self.kind = kind
+            if kind == "a2":
+                self.subs = [O.oracle_from_file("BossWN-a2.nam", quality=q, prewarm=prewarm) for q in (0.0, 1.0)]  # ch3, ch8 (LoadAll)
+                self.active = O.quality_to_submodel(a2json, quality)
+            elif kind == "gru":
+                self.subs, self.active = [O.OracleGRU(gj, prewarm=prewarm)], 0
+            else:
+                name = {"feather": "BossWN-feather.nam", "nano": "BossWN-nano.nam", "lstm": "BossLSTM-2x8.nam"}[kind]
+                self.subs, self.active = [O.oracle_from_file(name, prewarm=prewarm)], 0
+
+        def process(self, x):
+            return self.subs[self.active].process(x)
+
+    b = na.Batch(0)
+    refs = []
+    worst = 0.0
+    for step in range(14):
+        op = rng.integers(0, 4) if refs else 0
+        if op == 0 or len(refs) < 3:  # add 1-3 streams of a random kind
+            kind = str(rng.choice(list(models)))
+            q = float(rng.choice([0.0, 0.3, 0.5, 0.51, 1.0]))
+            pre = bool(rng.integers(0, 2))
+            count = int(rng.integers(1, 4))
+            first = b.AddStreams(models[kind], count, quality=q, doPrewarm=pre)
+            assert first == len(refs)
+            refs.extend(Ref(kind, q, pre) for _ in range(count))
+        elif op == 1:  # quality switch on a random A2 stream
+            idx = [i for i, r in enumerate(refs) if r.kind == "a2"]
+            if idx:
+                i = int(rng.choice(idx))
+                q = float(rng.choice([0.0, 0.5, 0.75, 1.0]))
+                b.SetQuality(i, q)
+                refs[i].active = O.quality_to_submodel(a2json, q)
+                assert b.GetActiveSubModel(i) == refs[i].active
+        elif op == 2:  # re-prewarm one stream (all of its submodels, like NeuralModel::Prewarm on a LoadAll composite)
+            i = int(rng.integers(0, len(refs)))
+            b.Prewarm(i)
+            for sub in refs[i].subs:
+                sub.prewarm()
+        n = int(rng.choice([1, 31, 64, 100, 128, 129, 300]))
+        x = np.stack([O.signal_noise(n, 10000 * seed + 100 * step + s) for s in range(len(refs))])
+        y = b.Process(x)
+        for s, r in enumerate(refs):
+            err = O.rms(y[s] - r.process(x[s]))
+            worst = max(worst, err)
+            assert err < 5e-6, (step, s, r.kind, err)
+    assert len(refs) >= 3
