@@ -8,6 +8,9 @@
                       oracle for every sample model on sin(0.01 n) after prewarm.  They make the oracle's
                       behaviour reproducible on the GPU box and catch accidental edits; they do not pin parity
                       (see oracle/na_oracle.h for what does).
+  gru_torch.npz       INDEPENDENT-IMPLEMENTATION VECTORS for the keras GRU (RTNeural is absent from the reference tree, so there is no
+                      reference output to record): output of torch.nn.GRU (float64, weights permuted from keras z|r|c to torch r|z|n order)
+                      + dense head on the committed synthetic model models/synthetic_gru_1x16.json, after 2048 zeros of prewarm.
 """
 import ctypes as C
 import os
@@ -57,7 +60,31 @@ def make_oracle_outputs():
     np.savez_compressed(os.path.join(HERE, "oracle_outputs.npz"), **out)
 
 
+def make_gru():
+    import json
+    import torch
+    H = 16
+    j = O.synth_keras_gru(1, H, seed=20260928)
+    with open(os.path.join(HERE, "models", "synthetic_gru_1x16.json"), "w") as f:
+        json.dump(j, f)
+    x = O.signal_sine(1024)
+    gru = torch.nn.GRU(1, H, num_layers=1, batch_first=True).double()
+    perm = np.concatenate([np.arange(H, 2 * H), np.arange(0, H), np.arange(2 * H, 3 * H)])
+    with torch.no_grad():
+        k, u, b = (np.array(j["layers"][0]["weights"][i], dtype=np.float64) for i in range(3))
+        gru.weight_ih_l0.copy_(torch.from_numpy(k.T[perm].copy()))
+        gru.weight_hh_l0.copy_(torch.from_numpy(u.T[perm].copy()))
+        gru.bias_ih_l0.copy_(torch.from_numpy(b[0][perm].copy()))
+        gru.bias_hh_l0.copy_(torch.from_numpy(b[1][perm].copy()))
+        xs = torch.from_numpy(np.concatenate([np.zeros(2048), x.astype(np.float64)])).reshape(1, -1, 1)
+        hs, _ = gru(xs)
+        wh = torch.from_numpy(np.array(j["layers"][-1]["weights"][0], dtype=np.float64).ravel())
+        y = (hs[0] @ wh + float(j["layers"][-1]["weights"][1][0])).numpy()[2048:]
+    np.savez_compressed(os.path.join(HERE, "gru_torch.npz"), input=x, output=y.astype(np.float32))
+
+
 if __name__ == "__main__":
     make_matmul()
     make_oracle_outputs()
+    make_gru()
     print("golden fixtures written")

@@ -78,3 +78,15 @@ def test_batch_streams_are_independent_and_match_oracle(na, loader):
     for s in (0, 1, 31, 63):
         yo = O.oracle_from_file("BossWN-standard.nam").process(x[s])
         assert O.rms(y[s] - yo) < TOL_RMS, (s, O.rms(y[s] - yo))
+
+
+def test_keras_gru_file_matches_committed_torch_vectors(na, loader):
+    """HIP path vs an INDEPENDENT implementation: tests/golden/gru_torch.npz holds torch.nn.GRU's output for the committed synthetic
+    keras GRU model (the reference evaluates GRU with RTNeural, which is absent: parity unpinned)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gru_torch.npz"))
+    m = loader.CreateFromFile(_model_path("synthetic_gru_1x16.json"))
+    assert m is not None
+    x = g["input"]
+    y = np.concatenate([m.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
+    assert O.rms(y - g["output"]) < 5e-6

@@ -267,3 +267,10 @@ def test_gru_oracle_chunking_and_prewarm():
     c = O.OracleGRU(j, prewarm=False)
     c.process(np.zeros(2048, dtype=np.float32))
     assert np.array_equal(a, c.process(x))
+
+
+def test_gru_oracle_matches_committed_torch_vectors():
+    """tests/golden/gru_torch.npz: torch.nn.GRU output for the committed synthetic keras GRU model (make_golden.py)."""
+    g = np.load(os.path.join(GOLDEN, "gru_torch.npz"))
+    y = O.oracle_from_file("synthetic_gru_1x16.json").process(g["input"])
+    assert O.rms(y - g["output"]) < 1e-6
