@@ -357,8 +357,16 @@ namespace na
 		template <int G, int WPS, int PF, int NW, int HPF>
 		__device__ __forceinline__ void LayerFr(const FrStage& sd, const f32x4* wl, CFloat vec, const f32x4* xbCur, f32x4* xbNext,
 			__amdgpu_buffer_rsrc_t srsrc, int inPos0, int outPos0, int n, int nSt, int f, int wave, int lane, float cond, float (&xc)[MAXC], float (&hd)[MAXC],
-			const f32x4 (&hcur)[HPF][PF == 2 ? 1 : G], bool haveCur, f32x4* hb, const NextHistory& nh, __amdgpu_buffer_rsrc_t lrsrc, bool counted)
+			const f32x4 (&hcur)[HPF][PF == 2 ? 1 : G], bool haveCur, f32x4* hb, const NextHistory& nh, __amdgpu_buffer_rsrc_t lrsrc, bool counted,
+			long long* sub = nullptr)
 		{
+			// trace builds: 7 in-layer shader-clock stamps per (stage, wave), see tools/trace_stage_timeline.py
+#ifdef NA_FR_TRACE
+#define FR_SUB(i) if (sub != nullptr && lane == 0) sub[i] = (long long)__builtin_readcyclecounter()
+#else
+#define FR_SUB(i) (void)0
+#endif
+			FR_SUB(0);
 			constexpr int C = 4 * G;
 			const int K = sd.ksize;
 			const int d = sd.dilation;
@@ -376,6 +384,7 @@ namespace na
 			// dilated conv (:139-290): tap k reads the frame d*(K-1-k) back; the last tap is the layer input itself (registers).
 			// With PF the history of the first HPF taps was loaded during the previous layer (hcur); those taps are peeled so that each
 			// names its registers statically.
+			FR_SUB(1); // bias / mix-in read
 			int kFirst = 0;
 			if constexpr (PF == 2)
 			{
@@ -430,12 +439,14 @@ namespace na
 				FetchFrame<G>(x, xbCur, srsrc, sd.ring_off, f - shift, lo, lo + 63, inPos0, sd.ring_frames);
 				DenseMfma<C, C>(acc, a4 + k * (64 * G), x);
 			}
+			FR_SUB(2); // shifted taps done
 			{
 				float x[C];
 #pragma unroll
 				for (int c = 0; c < C; c++) x[c] = xc[c];
 				DenseMfma<C, C>(acc, a4 + (K - 1) * (64 * G), x);
 			}
+			FR_SUB(3); // last tap done
 
 			// activation (:473-480), head accumulate (:482)
 			float z[C];
@@ -462,6 +473,7 @@ namespace na
 #pragma unroll
 			for (int c = 0; c < C; c++) hd[c] += z[c];
 
+			FR_SUB(4); // activation + head accumulate done
 			if (sd.flags & WN_FLAG_NEED_OUTPUT)
 			{
 				// 1x1 + bias + residual (:486-491)
@@ -476,9 +488,12 @@ namespace na
 					xc[4 * og] = y[og].x; xc[4 * og + 1] = y[og].y; xc[4 * og + 2] = y[og].z; xc[4 * og + 3] = y[og].w;
 				}
 			}
+			FR_SUB(5); // 1x1 done
 			// (deferring the ring store to the start of the next layer was tried: no gain, the cost is the store instructions themselves)
 			if (PF) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, (sd.flags & WN_FLAG_PUBLISH) ? nSt : 0, f);
 			else if (sd.flags & WN_FLAG_PUBLISH) PublishFrame<G>(xc, xbNext, srsrc, sd.out_ring_off, outPos0, sd.out_ring_frames, nSt, f);
+			FR_SUB(6); // published
+#undef FR_SUB
 		}
 
 		__device__ __forceinline__ void PublishAny(int G, const float (&x)[MAXC], f32x4* xb, __amdgpu_buffer_rsrc_t srsrc, int ringOff, int pos0, int R,
@@ -756,7 +771,13 @@ namespace na
 				const NextHistory nh = { haveNext, sdn.ring_off, sdn.dilation, sdn.ksize, nextPos0, sdn.ring_frames };
 
 				LayerFr<G, WPS, PF, WPS * SPB, HPF>(sd, wl, cx.wvec + sd.vec_off * 4, cx.xbuf + cur * (NTB * 64), cx.xbuf + (cur ^ 1) * (NTB * 64), cx.srsrc, inPos0,
-					outPos0, cx.n, cx.nSt, f, cx.wave, lane, cx.cond, xc, hd, hcur, haveCur, hb, nh, cx.lrsrc, counted);
+					outPos0, cx.n, cx.nSt, f, cx.wave, lane, cx.cond, xc, hd, hcur, haveCur, hb, nh, cx.lrsrc, counted,
+#ifdef NA_FR_TRACE
+					(trace != nullptr && (int)blockIdx.x == traceBlock) ? trace + ((cx.nstages + 1) * 4 + s * 8) * (WPS * SPB) + waveAll * 8 : nullptr
+#else
+					nullptr
+#endif
+				);
 				counted = true;
 				if constexpr (PF == 1)
 				{

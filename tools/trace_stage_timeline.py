@@ -19,12 +19,14 @@ for _ in range(5):
     batch.ProcessDevice(x.data_ptr(), y.data_ptr(), n)
 torch.cuda.synchronize()
 nst, waves = int(os.environ.get("NA_TRACE_STAGES", "23")) + 1, int(os.environ.get("NA_TRACE_WAVES", "4"))  # 23 stages of Standard + 1 slot for kernel entry / exit
-trace = torch.zeros(nst * 4 * waves, dtype=torch.int64, device=dev)
+trace = torch.zeros(nst * 4 * waves + nst * 8 * waves, dtype=torch.int64, device=dev)  # + 8 in-layer stamps per (stage, wave)
 capi.load_library().NA_DebugSetTraceBuffer(trace.data_ptr())
 batch.ProcessDevice(x.data_ptr(), y.data_ptr(), n)
 torch.cuda.synchronize()
 capi.load_library().NA_DebugSetTraceBuffer(None)
-t = trace.cpu().numpy().reshape(nst, 4, waves).astype(np.float64)
+raw = trace.cpu().numpy().astype(np.float64)
+t = raw[: nst * 4 * waves].reshape(nst, 4, waves)
+sub = raw[nst * 4 * waves:].reshape(nst, waves, 8)
 t0 = t[-1, 0].min()
 print("kernel entry -> exit: %.0f cycles; entry -> stage 0: %.0f; last barrier -> exit: %.0f" % (t[-1, 1].max() - t0, t[0, 0].min() - t0, t[-1, 1].max() - t[-2, 3].max()))
 print("stage  start(min..max)   conv   epi+pub  barrier-wait | per-wave mean cycles")
@@ -33,3 +35,11 @@ for s in range(nst - 1):
     conv = np.where(cv > 0, cv - st, 0)
     epi = np.where(cv > 0, ep - cv, ep - st)
     print("%2d  %7.0f..%7.0f  %6.0f  %6.0f  %6.0f   stage total %6.0f" % (s, st.min() - t0, st.max() - t0, conv.mean(), epi.mean(), (br - ep).mean(), br.max() - st.min()))
+
+print("in-layer split (mean over waves, cycles): vec-read | shifted taps | last tap | activation | 1x1 | publish")
+for s in range(nst - 1):
+    u = sub[s]
+    if u[:, 6].max() <= 0:
+        continue
+    d = np.diff(u[:, :7], axis=1).mean(axis=0)
+    print("%2d  %6.0f %6.0f %6.0f %6.0f %6.0f %6.0f   layer total %6.0f" % ((s,) + tuple(d) + ((u[:, 6] - u[:, 0]).mean(),)))
