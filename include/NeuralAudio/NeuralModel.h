@@ -23,6 +23,12 @@
 #include <utility>
 #include <vector>
 
+// Both classes are exported from libNeuralAudioCAPI.so (the library itself is built with -fvisibility=hidden): a C++ host links
+// against it exactly as it would against the reference's static NeuralAudio library (tools/ModelTest is such a host).
+#ifndef NEURALAUDIO_API
+#define NEURALAUDIO_API __attribute__((visibility("default")))
+#endif
+
 #ifndef DEFAULT_QUALITY_SCALE
 #define DEFAULT_QUALITY_SCALE 1.0
 #endif
@@ -34,10 +40,14 @@ namespace NeuralAudio
 {
 	enum EModelLoadMode { Internal, RTNeural, NAMCore };          // ref :20-25 (values 0,1,2 cross the C ABI)
 	enum ECompositeModelLoadMode { LoadAll, OnDemand };           // ref :27-31
+	// The reference picks its activation arithmetic at build time (-DWAVENET_MATH / -DLSTM_MATH = FastMath | StdMath,
+	// NeuralAudio/CMakeLists.txt:82-96, Activation.h:12-118); here it is a load-time knob with the same two policies.
+	// FastMath (the reference default) = the rational tanh of Activation.h:83-96; StdMath = std::tanh / 1/(1+exp(-x)) (:20-45).
+	enum EMathMode { FastMath, StdMath };
 
 	// Runtime interface: one instance == one mono audio stream.  Not thread-safe; call Process() from one
 	// thread.  The base class is a silent no-op model, exactly as in the reference.
-	class NeuralModel
+	class NEURALAUDIO_API NeuralModel
 	{
 	public:
 		virtual ~NeuralModel() {}
@@ -87,7 +97,7 @@ namespace NeuralAudio
 	};
 
 	// Factory + load-time settings.  Loading is not real-time safe.
-	class NeuralModelLoader
+	class NEURALAUDIO_API NeuralModelLoader
 	{
 	public:
 		// nullptr when the file does not exist or no engine accepts the model; throws on malformed files
@@ -120,6 +130,11 @@ namespace NeuralAudio
 		// MI355X additions: HIP device the created models run on (default 0)
 		void SetDevice(int deviceIndex) { device = deviceIndex; }
 		int GetDevice() { return device; }
+		// math policy of the models created next (the reference's WAVENET_MATH / LSTM_MATH build options)
+		void SetWaveNetMathMode(EMathMode mode) { wavenetMath = mode; }
+		EMathMode GetWaveNetMathMode() { return wavenetMath; }
+		void SetLSTMMathMode(EMathMode mode) { lstmMath = mode; }
+		EMathMode GetLSTMMathMode() { return lstmMath; }
 
 	protected:
 		EModelLoadMode lstmLoadMode = EModelLoadMode::Internal;
@@ -130,5 +145,7 @@ namespace NeuralAudio
 		float defaultQualityScaleFactor = (float)DEFAULT_QUALITY_SCALE;
 		int externalSampleRate = 48000;
 		int device = 0;
+		EMathMode wavenetMath = EMathMode::FastMath;
+		EMathMode lstmMath = EMathMode::FastMath;
 	};
 }

@@ -29,6 +29,17 @@ NA_EXTERN const char* NA_GetVersion(void);
 NA_EXTERN NeuralModel* NA_CreateModelFromFileUtf8(NeuralModelLoader* loader, const char* utf8Path, int doPrewarm);
 NA_EXTERN NeuralModel* NA_CreateModelFromString(NeuralModelLoader* loader, const char* jsonText, const char* extension, int doPrewarm);
 NA_EXTERN void NA_SetDevice(NeuralModelLoader* loader, int device);
+/* activation arithmetic of the models created next: 0 = FastMath (default), 1 = StdMath -- the reference's build options
+ * WAVENET_MATH / LSTM_MATH (NeuralAudio/CMakeLists.txt:82-96, Activation.h:12-118) as load-time knobs */
+NA_EXTERN void NA_SetWaveNetMathMode(NeuralModelLoader* loader, int mathMode);
+NA_EXTERN void NA_SetLSTMMathMode(NeuralModelLoader* loader, int mathMode);
+/* ECompositeModelLoadMode (NeuralModel.h:27-31,166-174): 0 = LoadAll (default), 1 = OnDemand */
+NA_EXTERN void NA_SetCompositeModelLoadMode(NeuralModelLoader* loader, int loadMode);
+/* NeuralModel::IsQualityChangeRealtimeSafe (NeuralModel.h:54-59) */
+NA_EXTERN int NA_IsQualityChangeRealtimeSafe(NeuralModel* model, float newQuality);
+/* NeuralModel::Process with a status: 0 ok; on failure `output` is zero-filled (silence) and NA_GetLastError() says why.
+ * The legacy Process() symbol forwards here and drops the status. */
+NA_EXTERN int NA_ProcessChecked(NeuralModel* model, float* input, float* output, size_t numSamples);
 NA_EXTERN void NA_SetDefaultQualityScaleFactor(NeuralModelLoader* loader, float quality);
 NA_EXTERN void NA_SetExternalSampleRate(NeuralModelLoader* loader, int sampleRate);
 NA_EXTERN int NA_HasQualityScaling(NeuralModel* model);

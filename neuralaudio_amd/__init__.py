@@ -13,7 +13,8 @@ import numpy as np
 
 from . import capi
 
-__all__ = ["NeuralModelLoader", "NeuralModel", "Batch", "EModelLoadMode", "device_count", "NeuralAudioError"]
+__all__ = ["NeuralModelLoader", "NeuralModel", "Batch", "EModelLoadMode", "EMathMode", "ECompositeModelLoadMode", "device_count",
+           "NeuralAudioError"]
 
 
 class NeuralAudioError(RuntimeError):
@@ -24,6 +25,16 @@ class EModelLoadMode:
     Internal = 0
     RTNeural = 1
     NAMCore = 2
+
+
+class EMathMode:
+    FastMath = 0
+    StdMath = 1
+
+
+class ECompositeModelLoadMode:
+    LoadAll = 0
+    OnDemand = 1
 
 
 def device_count():
@@ -90,9 +101,12 @@ class NeuralModel:
         """input -> output (same length), any number of samples; runs on the GPU."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         y = np.empty_like(x)
-        self._lib.NA_GetLastError()
-        self._lib.Process(self._h, _fptr(x), _fptr(y), x.size)
+        if self._lib.NA_ProcessChecked(self._h, _fptr(x), _fptr(y), x.size) != 0:
+            raise NeuralAudioError(capi.last_error())
         return y
+
+    def IsQualityChangeRealtimeSafe(self, q):
+        return bool(self._lib.NA_IsQualityChangeRealtimeSafe(self._h, float(q)))
 
     def close(self):
         if self._h:
@@ -135,6 +149,15 @@ class NeuralModelLoader:
 
     def SetDevice(self, device):
         self._lib.NA_SetDevice(self._h, int(device))
+
+    def SetWaveNetMathMode(self, mode):
+        self._lib.NA_SetWaveNetMathMode(self._h, int(mode))
+
+    def SetLSTMMathMode(self, mode):
+        self._lib.NA_SetLSTMMathMode(self._h, int(mode))
+
+    def SetCompositeModelLoadMode(self, mode):
+        self._lib.NA_SetCompositeModelLoadMode(self._h, int(mode))
 
     def CreateFromFile(self, path, doPrewarm=True, use_wchar_entry=False):
         """Returns None when the file is missing / unsupported (reference: nullptr); raises on malformed files."""

@@ -25,7 +25,8 @@ NA_SYMBOLS = [
     "NA_GetModelVersion", "NA_BatchCreate", "NA_BatchDestroy", "NA_BatchAddStreams", "NA_BatchNumStreams",
     "NA_BatchSetQuality", "NA_BatchGetActiveSubModel", "NA_BatchPrewarm", "NA_BatchProcess", "NA_BatchProcessDevice",
     "NA_BatchSynchronize", "NA_BatchGetHipStream", "NA_BatchAlgorithmicBytesPerSample", "NA_BatchMacsPerSample",
-    "NA_BatchStateBytes", "NA_DebugSetTraceBuffer",
+    "NA_BatchStateBytes", "NA_DebugSetTraceBuffer", "NA_SetWaveNetMathMode", "NA_SetLSTMMathMode", "NA_SetCompositeModelLoadMode",
+    "NA_IsQualityChangeRealtimeSafe", "NA_ProcessChecked",
 ]
 
 _lib = None
@@ -88,6 +89,11 @@ def load_library():
         "NA_BatchMacsPerSample": (C.c_double, [vp]),
         "NA_BatchStateBytes": (C.c_double, [vp]),
         "NA_DebugSetTraceBuffer": (None, [vp]),
+        "NA_SetWaveNetMathMode": (None, [vp, C.c_int]),
+        "NA_SetLSTMMathMode": (None, [vp, C.c_int]),
+        "NA_SetCompositeModelLoadMode": (None, [vp, C.c_int]),
+        "NA_IsQualityChangeRealtimeSafe": (C.c_int, [vp, C.c_float]),
+        "NA_ProcessChecked": (C.c_int, [vp, fp, fp, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

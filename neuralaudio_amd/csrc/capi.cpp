@@ -182,8 +182,7 @@ float GetSampleRate(NeuralModel* model) { return model ? model->model->GetSample
 
 void Process(NeuralModel* model, float* input, float* output, size_t numSamples)
 {
-	if (!model) return;
-	Guard([&] { model->model->Process(input, output, numSamples); });
+	(void)NA_ProcessChecked(model, input, output, numSamples);
 }
 
 // ---------------------------------------------------------------- additive API (include/neuralaudio_amd.h)
@@ -216,6 +215,40 @@ NeuralModel* NA_CreateModelFromString(NeuralModelLoader* loader, const char* jso
 		result = Wrap(m);
 	});
 	return result;
+}
+
+// The legacy Process() cannot report failure; an audio host must never be handed uninitialised memory, so a failed call
+// (no device, HIP error) returns silence and leaves the reason in NA_GetLastError().
+int NA_ProcessChecked(NeuralModel* model, float* input, float* output, size_t numSamples)
+{
+	if (!model || !output)
+	{
+		SetError("Process: null argument");
+		return -1;
+	}
+	const int rc = Guard([&] { model->model->Process(input, output, numSamples); });
+	if (rc != 0) memset(output, 0, numSamples * sizeof(float));
+	return rc;
+}
+
+void NA_SetWaveNetMathMode(NeuralModelLoader* loader, int mathMode)
+{
+	if (loader) loader->loader->SetWaveNetMathMode(mathMode == 1 ? NeuralAudio::EMathMode::StdMath : NeuralAudio::EMathMode::FastMath);
+}
+
+void NA_SetLSTMMathMode(NeuralModelLoader* loader, int mathMode)
+{
+	if (loader) loader->loader->SetLSTMMathMode(mathMode == 1 ? NeuralAudio::EMathMode::StdMath : NeuralAudio::EMathMode::FastMath);
+}
+
+void NA_SetCompositeModelLoadMode(NeuralModelLoader* loader, int loadMode)
+{
+	if (loader) loader->loader->SetCompositeModelLoadMode(loadMode == 1 ? NeuralAudio::ECompositeModelLoadMode::OnDemand : NeuralAudio::ECompositeModelLoadMode::LoadAll);
+}
+
+int NA_IsQualityChangeRealtimeSafe(NeuralModel* model, float newQuality)
+{
+	return (model && model->model->IsQualityChangeRealtimeSafe(newQuality)) ? 1 : 0;
 }
 
 void NA_SetDevice(NeuralModelLoader* loader, int device)

@@ -45,4 +45,8 @@ namespace na
 	}
 
 	__device__ __forceinline__ float GruSigmoid(float x) { return (GruTanh(x * 0.5f) + 1.0f) * 0.5f; }
+
+	// StdMath (Activation.h:37-45): std::tanh and 1 / (1 + exp(-x)), on the same exp2 / rcp units (absolute error ~1e-7)
+	__device__ __forceinline__ float StdTanh(float x) { return GruTanh(x); }
+	__device__ __forceinline__ float StdSigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 }

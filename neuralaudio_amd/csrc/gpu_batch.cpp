@@ -349,14 +349,7 @@ namespace na
 			LstmGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s) : ModelGroup(d, s)
 			{
 				const LSTMDesc& lstm = d->lstm;
-				if (lstm.numLayers < 1 || lstm.numLayers > LSTM_MAX_LAYERS) throw std::runtime_error("LSTM: unsupported number of layers");
-				if (lstm.cell == CELL_GRU)
-				{
-					if (!GruShapeSupported(lstm.hiddenSize, lstm.numLayers))
-						throw std::runtime_error("GRU: " + std::to_string(lstm.numLayers) + "x" + std::to_string(lstm.hiddenSize) + " has no gfx950 kernel instance");
-				}
-				else if (!LstmHiddenSizeSupported(lstm.hiddenSize))
-					throw std::runtime_error("LSTM: hidden size " + std::to_string(lstm.hiddenSize) + " has no gfx950 kernel instance");
+				ValidateRecurrentDesc(lstm); // the loader already did; descs built by hand get the same message
 				std::vector<float> w;
 				for (int l = 0; l < lstm.numLayers; l++)
 				{
@@ -375,6 +368,7 @@ namespace na
 				dev.cell = (lstm.cell == CELL_GRU) ? LSTM_CELL_GRU : LSTM_CELL_LSTM;
 				dev.numLayers = lstm.numLayers;
 				dev.hidden = lstm.hiddenSize;
+				dev.math = (lstm.mathMode == MATH_STD) ? LSTM_MATH_STD : LSTM_MATH_FAST;
 				numElems = lstm.numLayers * 2 * lstm.hiddenSize;
 				dZeros.Alloc(LSTM_MAX_FRAMES);
 				CheckHip(hipMemsetAsync(dZeros.Get(), 0, LSTM_MAX_FRAMES * sizeof(float), stream), "hipMemsetAsync");

@@ -131,11 +131,6 @@ namespace na
 		}
 	}
 
-	bool GruShapeSupported(int hidden, int numLayers)
-	{
-		return (hidden == 8 || hidden == 12 || hidden == 16 || hidden == 20) && (numLayers == 1 || numLayers == 2);
-	}
-
 	hipError_t LaunchGruBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams, const float* in,
 		float* out, long inStride, long outStride, int n, hipStream_t stream)
 	{

@@ -16,6 +16,21 @@ namespace na
 	constexpr int LSTM_MAX_FRAMES = 128;
 
 	enum { LSTM_CELL_LSTM = 0, LSTM_CELL_GRU = 1 };
+	enum { LSTM_MATH_FAST = 0, LSTM_MATH_STD = 1 };
+
+	// Shapes with a kernel (host-side predicates, no HIP types: the loader rejects everything else at load time).
+	//   LSTM: any hidden size / layer count whose lane = stream working set fits the 160 KB LDS (LstmGenericKernel); the usual sizes
+	//   have shaped kernels.  GRU: GruWaveKernel instances.
+	inline bool LstmShapeSupported(int hidden, int numLayers)
+	{
+		if (hidden < 1 || numLayers < 1 || numLayers > LSTM_MAX_LAYERS) return false;
+		const long bytes = (64L * (LSTM_MAX_FRAMES + 1) + (long)numLayers * 2 * hidden * 64 + (long)hidden * 64) * 4;
+		return bytes <= 160L * 1024;
+	}
+	inline bool GruShapeSupported(int hidden, int numLayers)
+	{
+		return (numLayers == 1 || numLayers == 2) && (hidden == 8 || hidden == 12 || hidden == 16 || hidden == 20);
+	}
 
 	struct LstmModelDev
 	{
@@ -28,5 +43,6 @@ namespace na
 		int hidden;
 		int layerOff[LSTM_MAX_LAYERS]; // float offset of layer l's W
 		int headOff;
+		int math;      // LSTM only: 0 = FastMath (Activation.h:83-96), 1 = StdMath (Activation.h:20-45) -- the reference's LSTM_MATH build option
 	};
 }

@@ -28,10 +28,15 @@ namespace na
 	// Activation.h:93-96
 	__device__ __forceinline__ float LstmFastSigmoid(float x) { return 0.5f * (LstmFastTanh(x * 0.5f) + 1.0f); }
 
+	// the reference's LSTM_MATH build option as a wave-uniform run-time switch (these kernels are the fallback shapes; the H = 8 / 16
+	// kernels in recurrent_dpp_kernels.hip carry the policy as a template parameter)
+	__device__ __forceinline__ float LstmTanh(float x, int math) { return math == LSTM_MATH_STD ? StdTanh(x) : LstmFastTanh(x); }
+	__device__ __forceinline__ float LstmSigmoid(float x, int math) { return math == LSTM_MATH_STD ? StdSigmoid(x) : LstmFastSigmoid(x); }
+
 	// One layer step for one stream (lane).  state = [x (I values); h (H values)] in registers.
 	//   cell/hidden columns live in LDS: hc[k * 64 + lane]
 	template <int H, int I>
-	__device__ __forceinline__ void LstmLayerStep(const float* __restrict__ w, const float (&xin)[I], float* hc, int lane)
+	__device__ __forceinline__ void LstmLayerStep(const float* __restrict__ w, const float (&xin)[I], float* hc, int lane, int math)
 	{
 		constexpr int W = I + H;
 		float s[W];
@@ -63,9 +68,9 @@ namespace na
 			gg += bias[2 * H + i];
 			go += bias[3 * H + i];
 			// LSTM.h:94-99
-			const float c = (LstmFastSigmoid(gf) * hc[(H + i) * 64 + lane]) + (LstmFastSigmoid(gi) * LstmFastTanh(gg));
+			const float c = (LstmSigmoid(gf, math) * hc[(H + i) * 64 + lane]) + (LstmSigmoid(gi, math) * LstmTanh(gg, math));
 			hc[(H + i) * 64 + lane] = c;
-			hc[i * 64 + lane] = LstmFastSigmoid(go) * LstmFastTanh(c);
+			hc[i * 64 + lane] = LstmSigmoid(go, math) * LstmTanh(c, math);
 		}
 	}
 
@@ -106,13 +111,13 @@ namespace na
 		for (int f = 0; f < n; f++)
 		{
 			float x1[1] = { io[lane * ioStride + f] };
-			LstmLayerStep<H, 1>(m.w + m.layerOff[0], x1, hcAll, lane); // LSTM.h:168
+			LstmLayerStep<H, 1>(m.w + m.layerOff[0], x1, hcAll, lane, m.math); // LSTM.h:168
 			for (int l = 1; l < m.numLayers; l++)
 			{
 				float xh[H];
 #pragma unroll
 				for (int k = 0; k < H; k++) xh[k] = hcAll[((l - 1) * 2 * H + k) * 64 + lane];
-				LstmLayerStep<H, H>(m.w + m.layerOff[l], xh, hcAll + (size_t)l * 2 * H * 64, lane); // LSTM.h:170-180
+				LstmLayerStep<H, H>(m.w + m.layerOff[l], xh, hcAll + (size_t)l * 2 * H * 64, lane, m.math); // LSTM.h:170-180
 			}
 			const float* hl = hcAll + (size_t)(m.numLayers - 1) * 2 * H * 64;
 			float acc = 0.0f;
@@ -168,7 +173,7 @@ namespace na
 
 	// gates of one layer for this sample: s = [x (I values from `xin`), h (H values from `hvec`)] broadcast from LDS
 	template <int H, int I>
-	__device__ __forceinline__ void GateRows(const LstmRows<H, I>& rows, const float* xin, const float* hvec, float* gates, int lane)
+	__device__ __forceinline__ void GateRows(const LstmRows<H, I>& rows, const float* xin, const float* hvec, float* gates, int lane, int math)
 	{
 		constexpr int W = I + H;
 		float sv[W];
@@ -186,8 +191,14 @@ namespace na
 			acc += rows.b[q];
 			// rows [2H, 3H) are the cell candidate (tanh), the others sigmoid = 0.5*(tanh(0.5 x) + 1)  (LSTM.h:33-36,94-99)
 			const bool isG = (r >= 2 * H) && (r < 3 * H);
-			const float t = LstmFastTanh(isG ? acc : acc * 0.5f);
-			if (r < 4 * H) gates[r] = isG ? t : 0.5f * (t + 1.0f);
+			float gv;
+			if (math == LSTM_MATH_STD) gv = isG ? StdTanh(acc) : StdSigmoid(acc); // Activation.h:37-45
+			else
+			{
+				const float t = LstmFastTanh(isG ? acc : acc * 0.5f);
+				gv = isG ? t : 0.5f * (t + 1.0f);
+			}
+			if (r < 4 * H) gates[r] = gv;
 		}
 	}
 
@@ -236,25 +247,25 @@ namespace na
 
 		for (int f = 0; f < n; f++)
 		{
-			GateRows<H, 1>(rows0, xin + f, hvec[0], gates, lane); // LSTM.h:168
+			GateRows<H, 1>(rows0, xin + f, hvec[0], gates, lane, m.math); // LSTM.h:168
 			LstmWaveSync();
 			if (lane < H)
 			{
 				// LSTM.h:94-99
 				c[0] = (gates[H + lane] * c[0]) + (gates[lane] * gates[2 * H + lane]);
-				const float h = gates[3 * H + lane] * LstmFastTanh(c[0]);
+				const float h = gates[3 * H + lane] * LstmTanh(c[0], m.math);
 				hvec[0][lane] = h;
 				if (L == 1) hout[f * HP + lane] = h;
 			}
 			LstmWaveSync();
 			if (L > 1)
 			{
-				GateRows<H, H>(rows1, hvec[0], hvec[L > 1 ? 1 : 0], gates, lane); // LSTM.h:170-180
+				GateRows<H, H>(rows1, hvec[0], hvec[L > 1 ? 1 : 0], gates, lane, m.math); // LSTM.h:170-180
 				LstmWaveSync();
 				if (lane < H)
 				{
 					c[L - 1] = (gates[H + lane] * c[L - 1]) + (gates[lane] * gates[2 * H + lane]);
-					const float h = gates[3 * H + lane] * LstmFastTanh(c[L - 1]);
+					const float h = gates[3 * H + lane] * LstmTanh(c[L - 1], m.math);
 					hvec[L > 1 ? 1 : 0][lane] = h;
 					hout[f * HP + lane] = h;
 				}
@@ -342,13 +353,109 @@ namespace na
 		return hipGetLastError();
 	}
 
-	bool LstmHiddenSizeSupported(int hidden)
+
+	// ------------------------------------------------------------------------------------------------------------
+	// Any hidden size / layer count (the reference's runtime-shaped path, LSTMDynamic.h:95-108,175-215): lane = stream, runtime loops,
+	// weights through wave-uniform loads.  LDS: io[64][n + 1] | hc[numLayers][2H][64] | hnew[H][64].  Slow next to the shaped kernels
+	// (no unrolling, every weight is a scalar load per use) but it accepts what the reference accepts.
+	// ------------------------------------------------------------------------------------------------------------
+	__global__ void __launch_bounds__(64) LstmGenericKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
+		const int* __restrict__ rows, int numStreams, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
 	{
-		switch (hidden)
+		extern __shared__ __attribute__((aligned(16))) float lds[];
+		const int H = m.hidden;
+		float* io = lds;
+		const int ioStride = n + 1;
+		float* hcAll = lds + 64 * ioStride;
+		float* hnew = hcAll + (size_t)m.numLayers * 2 * H * 64;
+
+		const int lane = threadIdx.x;
+		const int idx = blockIdx.x * 64 + lane;
+		const bool active = idx < numStreams;
+		const int slot = active ? slots[idx] : 0;
+		for (int r = 0; r < 64; r++)
 		{
-		case 4: case 8: case 12: case 16: case 20: case 24: case 32: case 40: return true;
-		default: return false;
+			const int ridx = blockIdx.x * 64 + r;
+			if (ridx < numStreams)
+			{
+				const float* src = in + (size_t)rows[ridx] * inStride;
+				for (int f = lane; f < n; f += 64) io[r * ioStride + f] = src[f];
+			}
 		}
+		for (int k = 0; k < m.numLayers * 2 * H; k++) hcAll[k * 64 + lane] = active ? state[(size_t)k * capacity + slot] : 0.0f;
+		__syncthreads();
+
+		const float* headW = m.w + m.headOff;
+		for (int f = 0; f < n; f++)
+		{
+			const float x0 = io[lane * ioStride + f];
+			for (int l = 0; l < m.numLayers; l++)
+			{
+				const int I = (l == 0) ? 1 : H;
+				const int W = I + H;
+				const float* w = m.w + m.layerOff[l];
+				const float* bias = w + (size_t)4 * H * W;
+				float* hc = hcAll + (size_t)l * 2 * H * 64;
+				const float* below = hcAll + (size_t)(l > 0 ? l - 1 : 0) * 2 * H * 64; // h of the layer below (already updated for this sample)
+				for (int i = 0; i < H; i++)
+				{
+					float g[4];
+					for (int q = 0; q < 4; q++)
+					{
+						const float* r = w + (size_t)(q * H + i) * W;
+						float acc = 0.0f;
+						if (l == 0) acc += r[0] * x0; // LSTM.h:168
+						else
+							for (int k = 0; k < H; k++) acc += r[k] * below[k * 64 + lane]; // LSTM.h:170-180
+						for (int k = 0; k < H; k++) acc += r[I + k] * hc[k * 64 + lane];
+						g[q] = acc + bias[q * H + i];
+					}
+					// LSTM.h:94-99 (gate row blocks i, f, g, o)
+					const float c = (LstmSigmoid(g[1], m.math) * hc[(H + i) * 64 + lane]) + (LstmSigmoid(g[0], m.math) * LstmTanh(g[2], m.math));
+					hc[(H + i) * 64 + lane] = c;
+					hnew[i * 64 + lane] = LstmSigmoid(g[3], m.math) * LstmTanh(c, m.math);
+				}
+				for (int i = 0; i < H; i++) hc[i * 64 + lane] = hnew[i * 64 + lane];
+			}
+			const float* hl = hcAll + (size_t)(m.numLayers - 1) * 2 * H * 64;
+			float acc = 0.0f;
+			for (int k = 0; k < H; k++) acc += headW[k] * hl[k * 64 + lane];
+			io[lane * ioStride + f] = acc + headW[H]; // LSTM.h:182-189
+		}
+		__syncthreads();
+
+		for (int k = 0; k < m.numLayers * 2 * H; k++)
+			if (active) state[(size_t)k * capacity + slot] = hcAll[k * 64 + lane];
+		for (int r = 0; r < 64; r++)
+		{
+			const int ridx = blockIdx.x * 64 + r;
+			if (ridx < numStreams)
+			{
+				float* dst = out + (size_t)rows[ridx] * outStride;
+				for (int f = lane; f < n; f += 64) dst[f] = io[r * ioStride + f];
+			}
+		}
+	}
+
+	static size_t LstmGenericLdsBytes(int hidden, int numLayers, int n)
+	{
+		return ((size_t)64 * (n + 1) + (size_t)numLayers * 2 * hidden * 64 + (size_t)hidden * 64) * sizeof(float);
+	}
+
+	static hipError_t LaunchGeneric(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams, const float* in,
+		float* out, long inStride, long outStride, int n, hipStream_t stream)
+	{
+		const size_t ldsBytes = LstmGenericLdsBytes(m.hidden, m.numLayers, n);
+		if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
+		static bool attrSet = false;
+		if (!attrSet)
+		{
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&LstmGenericKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			attrSet = true;
+		}
+		hipLaunchKernelGGL(LstmGenericKernel, dim3((unsigned)((numStreams + 63) / 64)), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows,
+			numStreams, in, out, inStride, outStride, n);
+		return hipGetLastError();
 	}
 
 	hipError_t LaunchLstmBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
@@ -372,7 +479,7 @@ namespace na
 			NA_LSTM_CASE(24);
 			NA_LSTM_CASE(32);
 			NA_LSTM_CASE(40);
-		default: return hipErrorInvalidValue;
+		default: return LaunchGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 		}
 #undef NA_LSTM_CASE
 	}

@@ -7,7 +7,6 @@
 
 namespace na
 {
-	bool LstmHiddenSizeSupported(int hidden);
 
 	// One block of n <= 128 samples for `numStreams` streams of one model (lane = stream).
 	hipError_t LaunchLstmBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
@@ -29,7 +28,6 @@ namespace na
 		hipStream_t stream);
 
 	// keras GRU (gru_kernels.hip): same state layout (only the h half of every layer is used), m.cell == LSTM_CELL_GRU
-	bool GruShapeSupported(int hidden, int numLayers);
 	hipError_t LaunchGruBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream);
 

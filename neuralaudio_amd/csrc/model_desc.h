@@ -11,6 +11,8 @@
 namespace na
 {
 	enum ActivationType { ACT_TANH = 0, ACT_LEAKYRELU = 1 };
+	// the reference's WAVENET_MATH / LSTM_MATH build options (Activation.h:12-118) as a per-model field
+	enum MathMode { MATH_FAST = 0, MATH_STD = 1 };
 
 	// Template parameters of WaveNetLayerArrayT (NeuralAudio/WaveNet.h:503)
 	struct WnArrayCfg
@@ -32,6 +34,7 @@ namespace na
 		std::vector<WnArrayCfg> arrays;
 		std::vector<float> weights; // flat, reference order (WaveNet.h:700-719)
 		bool isStatic = false;      // matched one of the official architectures (InternalModel.h:12-20)
+		int mathMode = MATH_FAST;   // tanh policy of ACT_TANH layers
 
 		size_t ExpectedNumWeights() const;
 		int ReceptiveFieldSize() const; // WaveNet.h:534-542,674-684
@@ -58,7 +61,12 @@ namespace na
 		float headBias = 0.0f;
 		std::vector<float> headBiasVec; // scratch of the keras readers
 		bool isStatic = false;
+		int mathMode = MATH_FAST; // LSTM only (the GRU follows RTNeural's accurate maths)
 	};
+
+	// load-time checks (throw std::runtime_error): weight count (WaveNet.h:704-709) and the shapes the gfx950 kernels accept
+	void ValidateWaveNetDesc(const WaveNetDesc& desc);   // wavenet_plan.cpp
+	void ValidateRecurrentDesc(const LSTMDesc& desc);    // model_loader.cpp
 
 	enum ModelKind { MODEL_NONE = 0, MODEL_WAVENET = 1, MODEL_LSTM = 2 };
 

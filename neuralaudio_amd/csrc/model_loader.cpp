@@ -1,5 +1,6 @@
 // model_loader.cpp -- see model_loader.h.
 #include "model_loader.h"
+#include "lstm_dev.h"
 
 #include <algorithm>
 #include <fstream>
@@ -203,7 +204,7 @@ namespace na
 			return false;
 		}
 
-		std::shared_ptr<ModelDesc> ReadNAMWaveNet(const Json& modelJson, int oversampleFactor)
+		std::shared_ptr<ModelDesc> ReadNAMWaveNet(const Json& modelJson, int oversampleFactor, const LoaderOptions& opts)
 		{
 			auto desc = std::make_shared<ModelDesc>();
 			desc->kind = MODEL_WAVENET;
@@ -226,11 +227,32 @@ namespace na
 			}
 			modelJson.At("weights").FlattenNumbers(desc->wavenet.weights);
 			desc->wavenet.isStatic = (oversampleFactor == 1) && IsOfficialArchitecture(desc->wavenet.arrays);
+			desc->wavenet.mathMode = opts.wavenetMath;
+			// the reference throws "Wrong number of weights" inside CreateFromJson (WaveNet.h:704-709); so does this loader, together with
+			// the limits of the gfx950 kernels, instead of deferring them to the first device use on the audio thread
+			ValidateWaveNetDesc(desc->wavenet);
 			return desc;
 		}
 
+	}
+
+	void ValidateRecurrentDesc(const LSTMDesc& d)
+	{
+		if (d.cell == CELL_GRU)
+		{
+			if (!GruShapeSupported(d.hiddenSize, d.numLayers))
+				throw std::runtime_error("GRU " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
+					" is not supported (gfx950 kernels exist for 1-2 layers of hidden size 8, 12, 16 or 20)");
+		}
+		else if (!LstmShapeSupported(d.hiddenSize, d.numLayers))
+			throw std::runtime_error("LSTM " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
+				" is not supported (1-8 layers; the per-stream state must fit the 160 KB LDS)");
+	}
+
+	namespace
+	{
 		// LSTM.h:42-56,130-147
-		std::shared_ptr<ModelDesc> ReadNAMLSTM(const Json& modelJson)
+		std::shared_ptr<ModelDesc> ReadNAMLSTM(const Json& modelJson, const LoaderOptions& opts)
 		{
 			auto desc = std::make_shared<ModelDesc>();
 			desc->kind = MODEL_LSTM;
@@ -268,11 +290,13 @@ namespace na
 			lstm.headBias = w[it++];
 			// InternalLSTMDefinitionT list, NeuralModel.cpp:31-38 (only when BUILD_INTERNAL_STATIC_LSTM)
 			lstm.isStatic = false;
+			lstm.mathMode = opts.lstmMath;
+			ValidateRecurrentDesc(lstm);
 			return desc;
 		}
 
 		// InternalModel.h:311-356 / :473-519 and LSTM.h:58-85
-		std::shared_ptr<ModelDesc> ReadKerasLSTM(const Json& modelJson)
+		std::shared_ptr<ModelDesc> ReadKerasLSTM(const Json& modelJson, const LoaderOptions& opts)
 		{
 			const Json& layers = modelJson.At("layers");
 			const size_t numLayers = layers.Size();
@@ -314,6 +338,8 @@ namespace na
 				ld.c0.assign((size_t)H, 0.0f);
 				lstm.layers.push_back(std::move(ld));
 			}
+			lstm.mathMode = opts.lstmMath;
+			ValidateRecurrentDesc(lstm);
 			return desc;
 		}
 
@@ -364,6 +390,7 @@ namespace na
 				ld.c0.assign((size_t)H, 0.0f);
 				gru.layers.push_back(std::move(ld));
 			}
+			ValidateRecurrentDesc(gru);
 			return desc;
 		}
 
@@ -414,8 +441,8 @@ namespace na
 
 			SubModel sm;
 			sm.info = model->info;
-			if (arch == "WaveNet") sm.desc = ReadNAMWaveNet(modelJson, OversampleFactor(modelJson, opts.externalSampleRate));
-			else if (arch == "LSTM") sm.desc = ReadNAMLSTM(modelJson);
+			if (arch == "WaveNet") sm.desc = ReadNAMWaveNet(modelJson, OversampleFactor(modelJson, opts.externalSampleRate), opts);
+			else if (arch == "LSTM") sm.desc = ReadNAMLSTM(modelJson, opts);
 			else return nullptr;
 			model->subModels.push_back(sm);
 			model->qualityLevels.push_back({ 1.0f, 0 });
@@ -431,7 +458,7 @@ namespace na
 			if (modelType != "lstm" && modelType != "gru") return nullptr;
 			SubModel sm;
 			sm.info = model->info;
-			sm.desc = (modelType == "gru") ? ReadKerasGRU(modelJson) : ReadKerasLSTM(modelJson);
+			sm.desc = (modelType == "gru") ? ReadKerasGRU(modelJson) : ReadKerasLSTM(modelJson, opts);
 			if (!sm.desc) return nullptr;
 			model->subModels.push_back(sm);
 			model->qualityLevels.push_back({ 1.0f, 0 });

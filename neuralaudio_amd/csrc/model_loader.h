@@ -46,6 +46,8 @@ namespace na
 	struct LoaderOptions
 	{
 		int externalSampleRate = 48000; // NeuralModel.h:229
+		int wavenetMath = MATH_FAST;    // WAVENET_MATH (NeuralAudio/CMakeLists.txt:82-84)
+		int lstmMath = MATH_FAST;       // LSTM_MATH (:94-96)
 	};
 
 	// `extension` is ".nam", ".json" or ".aidax".  Returns nullptr when no Internal-path engine accepts the

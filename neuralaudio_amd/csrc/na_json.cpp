@@ -1,6 +1,8 @@
 // na_json.cpp -- recursive-descent RFC 8259 reader (see na_json.h).
 #include "na_json.h"
 
+#include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -101,10 +103,21 @@ namespace na
 				if (p >= end || !(*p >= '0' && *p <= '9')) Fail("bad exponent");
 				while (p < end && *p >= '0' && *p <= '9') p++;
 			}
-			std::string tok(s, p);
+			// std::from_chars is locale-independent (strtod follows LC_NUMERIC: under a comma-decimal locale "0.1234" would parse as 0)
 			Json v;
 			v.type = Json::Number;
-			v.number = strtod(tok.c_str(), nullptr);
+			v.number = 0.0;
+			const std::from_chars_result res = std::from_chars(s, p, v.number);
+			if (res.ec == std::errc::invalid_argument || res.ptr != p) Fail("bad number");
+			if (res.ec == std::errc::result_out_of_range)
+			{
+				// from_chars leaves the value untouched on overflow / underflow; nlohmann keeps +-inf / 0 there
+				const bool neg = (*s == '-');
+				const char* e = s;
+				while (e < p && *e != 'e' && *e != 'E') e++;
+				const bool tiny = (e < p && e + 1 < p && e[1] == '-');
+				v.number = tiny ? 0.0 : (neg ? -HUGE_VAL : HUGE_VAL);
+			}
 			v.numberIsInteger = isInt;
 			return v;
 		}
@@ -317,13 +330,25 @@ namespace na
 		case Json::Bool: out += v.AsBool() ? "true" : "false"; break;
 		case Json::Number:
 		{
-			double d = v.AsDouble();
-			char buf[40];
-			if (std::floor(d) == d && std::fabs(d) < 1e15)
-				snprintf(buf, sizeof(buf), "%.0f", d);
-			else
-				snprintf(buf, sizeof(buf), "%.17g", d);
-			out += buf;
+			// nlohmann::json::dump(): integer tokens as integers, everything else in the shortest form that round-trips, with a
+			// trailing ".0" when that form has neither a fraction nor an exponent (3.0 stays "3.0")
+			const double d = v.AsDouble();
+			char buf[48];
+			if (!std::isfinite(d))
+			{
+				out += "null";
+				break;
+			}
+			if (v.IsIntegerToken() && std::fabs(d) < 9.2e18)
+			{
+				snprintf(buf, sizeof(buf), "%lld", (long long)d);
+				out += buf;
+				break;
+			}
+			const std::to_chars_result r = std::to_chars(buf, buf + sizeof(buf) - 3, d);
+			std::string tok(buf, r.ptr);
+			if (tok.find_first_of(".eE") == std::string::npos) tok += ".0";
+			out += tok;
 			break;
 		}
 		case Json::String: DumpString(v.AsString(), out); break;
@@ -340,7 +365,9 @@ namespace na
 		{
 			out.push_back('{');
 			bool first = true;
-			for (const auto& k : v.Keys())
+			std::vector<std::string> keys = v.Keys();
+			std::sort(keys.begin(), keys.end()); // nlohmann::json objects are std::map: keys come out sorted
+			for (const auto& k : keys)
 			{
 				if (!first) out.push_back(',');
 				first = false;

@@ -71,6 +71,9 @@ namespace na
 			return it->second;
 		}
 
+		// true when the number was written without fraction / exponent (nlohmann keeps such tokens as integers)
+		bool IsIntegerToken() const { return type == Number && numberIsInteger; }
+
 		// keys in document order
 		const std::vector<std::string>& Keys() const { return keys; }
 

@@ -37,8 +37,11 @@ namespace NeuralAudio
 	void GpuModel::EnsureDeviceState()
 	{
 		if (batch) return;
-		batch.reset(new na::GpuBatch(device));
-		batch->AddStream(model, quality, prewarmPending);
+		// build aside and publish only once the stream exists: a throwing AddStream (no device, HIP error) must not leave a batch
+		// with zero streams behind, or every later Process() would silently write nothing
+		std::unique_ptr<na::GpuBatch> fresh(new na::GpuBatch(device));
+		fresh->AddStream(model, quality, prewarmPending);
+		batch = std::move(fresh);
 		prewarmPending = false;
 	}
 
@@ -116,6 +119,8 @@ namespace NeuralAudio
 	{
 		na::LoaderOptions opts;
 		opts.externalSampleRate = externalSampleRate;
+		opts.wavenetMath = (wavenetMath == EMathMode::StdMath) ? na::MATH_STD : na::MATH_FAST;
+		opts.lstmMath = (lstmMath == EMathMode::StdMath) ? na::MATH_STD : na::MATH_FAST;
 		std::shared_ptr<na::LoadedModel> loaded = na::LoadModelFromText(jsonText, extension.string(), opts);
 		if (!loaded) return nullptr;
 		GpuModel* m = new GpuModel(loaded, this, doPrewarm);

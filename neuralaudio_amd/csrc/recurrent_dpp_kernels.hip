@@ -69,21 +69,29 @@ namespace na
 	}
 
 	// gate pre-activation -> (c, h) update for this lane's unit; returns the new h
-	template <int H>
+	template <int H, bool STD>
 	__device__ __forceinline__ float DppCellUpdate(float acc, int gate, int unit, float& c)
 	{
 		const bool isG = gate == 2;
-		const float t = LstmRcpTanh(isG ? acc : acc * 0.5f);
-		const float gv = isG ? t : 0.5f * (t + 1.0f); // LSTM.h:33-36,94-99
+		float gv;
+		if constexpr (STD)
+		{
+			gv = isG ? StdTanh(acc) : StdSigmoid(acc); // Activation.h:37-45
+		}
+		else
+		{
+			const float t = LstmRcpTanh(isG ? acc : acc * 0.5f);
+			gv = isG ? t : 0.5f * (t + 1.0f); // LSTM.h:33-36,94-99
+		}
 		float gi, gf, gg, go;
 		GatherGates<H>(gv, gi, gf, gg, go);
 		c = (gf * c) + (gi * gg);
-		return go * LstmRcpTanh(c);
+		return go * (STD ? StdTanh(c) : LstmRcpTanh(c));
 	}
 
 	// one stream (slot, row), one block of n samples; xin[128] and hout[128 * (H + 1)] are LDS scratch of this wave
-	template <int H, int L>
-	__device__ __forceinline__ void LstmDppBody(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
+	template <int H, int L, bool STD>
+	__device__ __forceinline__ void LstmDppBodyM(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
 		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
 	{
 		static_assert(H == 8 || H == 16, "a 16-lane DPP row must hold the units a whole number of times");
@@ -134,14 +142,14 @@ namespace na
 			float acc = wx0 * x; // LSTM.h:168 -- column 0 is the input sample
 			DppDot<H>(acc, wh0, h[0]);
 			acc += b0;
-			h[0] = DppCellUpdate<H>(acc, gate, unit, c[0]);
+			h[0] = DppCellUpdate<H, STD>(acc, gate, unit, c[0]);
 			if (L > 1)
 			{
 				float acc1 = 0.0f;
 				DppDot<H>(acc1, wi1, h[0]); // LSTM.h:170-180
 				DppDot<H>(acc1, wh1, h[L > 1 ? 1 : 0]);
 				acc1 += b1;
-				h[L > 1 ? 1 : 0] = DppCellUpdate<H>(acc1, gate, unit, c[L > 1 ? 1 : 0]);
+				h[L > 1 ? 1 : 0] = DppCellUpdate<H, STD>(acc1, gate, unit, c[L > 1 ? 1 : 0]);
 			}
 			if (lane < H) hout[f * HP + lane] = h[L - 1];
 			x = xNext;
@@ -168,6 +176,20 @@ namespace na
 		}
 	}
 
+
+	template <int H, int L>
+	__device__ __forceinline__ void LstmDppBody(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
+	{
+		LstmDppBodyM<H, L, false>(m, state, capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+	}
+
+	template <int H, int L>
+	__device__ __forceinline__ void LstmDppBodyStd(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
+	{
+		LstmDppBodyM<H, L, true>(m, state, capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+	}
 
 	// ------------------------------------------------------------------------------------------------------------
 	// H = 8 / 16: nothing on the recurrence touches LDS (same idea as LstmDppKernel).  lane = H*gate + unit with gate rows z, r, c
@@ -309,7 +331,7 @@ namespace na
 		const int idx = (int)blockIdx.x - ga.firstBlock;
 		const int slot = ga.slots[idx];
 		const int row = ga.rows[idx];
-		const int key = ga.m.cell * 100 + ga.m.hidden * 4 + ga.m.numLayers;
+		const int key = ga.m.cell * 100 + ga.m.hidden * 4 + ga.m.numLayers + ((ga.m.cell == LSTM_CELL_LSTM && ga.m.math == LSTM_MATH_STD) ? 1000 : 0);
 #define NA_REC_CASE(CELL, HH, LL, BODY) \
 	case CELL * 100 + HH * 4 + LL: BODY<HH, LL>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout); break;
 		switch (key)
@@ -318,6 +340,10 @@ namespace na
 			NA_REC_CASE(LSTM_CELL_LSTM, 8, 2, LstmDppBody)
 			NA_REC_CASE(LSTM_CELL_LSTM, 16, 1, LstmDppBody)
 			NA_REC_CASE(LSTM_CELL_LSTM, 16, 2, LstmDppBody)
+			NA_REC_CASE(10 + LSTM_CELL_LSTM, 8, 1, LstmDppBodyStd)
+			NA_REC_CASE(10 + LSTM_CELL_LSTM, 8, 2, LstmDppBodyStd)
+			NA_REC_CASE(10 + LSTM_CELL_LSTM, 16, 1, LstmDppBodyStd)
+			NA_REC_CASE(10 + LSTM_CELL_LSTM, 16, 2, LstmDppBodyStd)
 			NA_REC_CASE(LSTM_CELL_GRU, 8, 1, GruDppBody)
 			NA_REC_CASE(LSTM_CELL_GRU, 8, 2, GruDppBody)
 			NA_REC_CASE(LSTM_CELL_GRU, 16, 1, GruDppBody)

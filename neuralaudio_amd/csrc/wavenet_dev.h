@@ -43,6 +43,7 @@ namespace na
 		WN_FLAG_NEED_OUTPUT = 2, // compute the 1x1 + residual (NeedOutput, WaveNet.h:486-491)
 		WN_FLAG_PUBLISH = 4,     // write the layer output to LDS + the next layer's ring
 		WN_FLAG_BIAS = 8,        // dense/head stage has a bias
+		WN_FLAG_STD_TANH = 16,   // StdMath policy: std::tanh instead of the rational FastMath tanh (Activation.h:37-40)
 	};
 
 	struct WnStage
@@ -94,7 +95,7 @@ namespace na
 	{
 		int kind;       // 0: layer, 1: head conv (K may be 1)
 		int cin, cout, ksize;
-		int act;        // 0 tanh, 1 leaky
+		int act;        // 0 FastMath tanh, 1 leaky, 2 StdMath tanh
 		int wconv;      // offsets into the flat reference-order weight array
 		int bconv;      // -1 if none
 		int wmix;       // -1 for head

@@ -105,6 +105,15 @@ namespace na
 			return num * r;
 		}
 
+		// StdMath policy (Activation.h:37-40): tanh(x) = 1 - 2 / (e^(2x) + 1) on the exp2 / rcp units (absolute error ~1e-7)
+		__device__ __forceinline__ f32x2 StdTanh2(f32x2 x)
+		{
+			f32x2 r;
+			r.x = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x.x * 2.885390081777927f) + 1.0f);
+			r.y = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x.y * 2.885390081777927f) + 1.0f);
+			return r;
+		}
+
 		// Activation.h:110-118
 		__device__ __forceinline__ f32x2 LeakyReLU2(f32x2 v)
 		{
@@ -457,6 +466,16 @@ namespace na
 				{
 					const f32x2 lo2 = LeakyReLU2(f32x2{ acc[og].x, acc[og].y });
 					const f32x2 hi2 = LeakyReLU2(f32x2{ acc[og].z, acc[og].w });
+					z[4 * og] = lo2.x; z[4 * og + 1] = lo2.y; z[4 * og + 2] = hi2.x; z[4 * og + 3] = hi2.y;
+				}
+			}
+			else if (sd.flags & WN_FLAG_STD_TANH)
+			{
+#pragma unroll
+				for (int og = 0; og < G; og++)
+				{
+					const f32x2 lo2 = StdTanh2(f32x2{ acc[og].x, acc[og].y });
+					const f32x2 hi2 = StdTanh2(f32x2{ acc[og].z, acc[og].w });
 					z[4 * og] = lo2.x; z[4 * og + 1] = lo2.y; z[4 * og + 2] = hi2.x; z[4 * og + 3] = hi2.y;
 				}
 			}

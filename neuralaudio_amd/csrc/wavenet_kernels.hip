@@ -566,7 +566,7 @@ namespace na
 						for (int c = 0; c < L.cin; c++) acc += w[L.wconv + (i * L.cin + c) * L.ksize + k] * x[c];
 					acc += w[L.bconv + i];
 					// mix-in * condition(0) adds nothing
-					acc = (L.act == 1) ? LeakyReLU(acc) : FastTanh(acc);
+					acc = (L.act == 1) ? LeakyReLU(acc) : (L.act == 2 ? (1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc * 2.885390081777927f) + 1.0f)) : FastTanh(acc));
 				}
 				__syncthreads();
 				if (i < 16)

@@ -43,6 +43,46 @@ namespace na
 		return rf;
 	}
 
+	// Everything that can be wrong with a WaveNet description, checked at LOAD time (the reference throws "Wrong number of weights"
+	// from SetWeights inside CreateFromJson, WaveNet.h:704-709) together with the limits of the gfx950 kernels.
+	void ValidateWaveNetDesc(const WaveNetDesc& desc)
+	{
+		if (desc.arrays.empty()) throw std::runtime_error("WaveNet without layer arrays");
+		const int numArrays = (int)desc.arrays.size();
+		int rings = 0;
+		for (int a = 0; a < numArrays; a++)
+		{
+			const WnArrayCfg& cfg = desc.arrays[a];
+			if (cfg.channels < 1 || cfg.headSize < 1 || cfg.inputSize < 1) throw std::runtime_error("WaveNet layer array with a zero-sized dimension");
+			if (cfg.channels > 16 || cfg.headSize > 16 || cfg.inputSize > 16)
+				throw std::runtime_error("WaveNet channels > 16 are not supported by the gfx950 MFMA kernel");
+			if (cfg.conditionSize != 1) throw std::runtime_error("WaveNet condition_size != 1 is not supported");
+			if (cfg.kernelSizes.size() != cfg.dilations.size() || cfg.kernelSizes.empty())
+				throw std::runtime_error("WaveNet kernel_sizes/dilations mismatch");
+			for (size_t l = 0; l < cfg.kernelSizes.size(); l++)
+				if (cfg.kernelSizes[l] < 1 || cfg.dilations[l] < 1) throw std::runtime_error("WaveNet kernel_size / dilation must be >= 1");
+			if (cfg.headKernelSize < 1 || cfg.headDilation < 1) throw std::runtime_error("WaveNet head kernel_size / dilation must be >= 1");
+			rings += (int)cfg.kernelSizes.size() + (cfg.headKernelSize > 1 ? 1 : 0);
+			if (a > 0)
+			{
+				// head accumulation continues in place in the previous array's head outputs (WaveNet.h:785-789)
+				if (desc.arrays[a - 1].headSize != cfg.channels || cfg.inputSize != desc.arrays[a - 1].channels)
+					throw std::runtime_error("WaveNet layer arrays do not chain (head_size/input_size mismatch)");
+				if (desc.arrays[a - 1].headKernelSize != 1)
+					throw std::runtime_error("WaveNet: head kernel > 1 is only supported on the last layer array");
+			}
+		}
+		if (desc.arrays[0].inputSize != 1) throw std::runtime_error("WaveNet first layer array must have input_size 1");
+		if (rings > WN_MAX_RINGS) throw std::runtime_error("WaveNet has more than 64 conv layers (unsupported)");
+		const size_t expected = desc.ExpectedNumWeights();
+		if (expected != desc.weights.size())
+		{
+			std::stringstream str;
+			str << "Wrong number of weights. Expected " << expected << " but got " << desc.weights.size();
+			throw std::runtime_error(str.str());
+		}
+	}
+
 	namespace
 	{
 		struct Builder
@@ -238,14 +278,7 @@ namespace na
 
 			void Build()
 			{
-				const size_t expected = desc.ExpectedNumWeights();
-				if (expected != desc.weights.size())
-				{
-					std::stringstream str;
-					str << "Wrong number of weights. Expected " << expected << " but got " << desc.weights.size();
-					throw std::runtime_error(str.str());
-				}
-				if (desc.arrays.empty()) throw std::runtime_error("WaveNet without layer arrays");
+				ValidateWaveNetDesc(desc);
 
 				plan.arrays = desc.arrays;
 				plan.receptiveField = desc.ReceptiveFieldSize();
@@ -259,25 +292,11 @@ namespace na
 				for (int a = 0; a < numArrays; a++)
 				{
 					const WnArrayCfg& cfg = desc.arrays[a];
-					if (cfg.channels > 16 || cfg.headSize > 16 || cfg.inputSize > 16)
-						throw std::runtime_error("WaveNet channels > 16 are not supported by the gfx950 MFMA kernel");
-					if (cfg.conditionSize != 1) throw std::runtime_error("WaveNet condition_size != 1 is not supported");
-					if (cfg.kernelSizes.size() != cfg.dilations.size() || cfg.kernelSizes.empty())
-						throw std::runtime_error("WaveNet kernel_sizes/dilations mismatch");
 					for (size_t l = 0; l < cfg.kernelSizes.size(); l++)
 						layerRing[a].push_back(AddRing(cfg.channels, (cfg.kernelSizes[l] - 1) * cfg.dilations[l]));
 					if (cfg.headKernelSize > 1)
 						headRing[a] = AddRing(cfg.channels, (cfg.headKernelSize - 1) * cfg.headDilation);
-					if (a > 0)
-					{
-						// head accumulation continues in place in the previous array's head outputs (WaveNet.h:785-789)
-						if (desc.arrays[a - 1].headSize != cfg.channels || cfg.inputSize != desc.arrays[a - 1].channels)
-							throw std::runtime_error("WaveNet layer arrays do not chain (head_size/input_size mismatch)");
-						if (desc.arrays[a - 1].headKernelSize != 1)
-							throw std::runtime_error("WaveNet: head kernel > 1 is only supported on the last layer array");
-					}
 				}
-				if (desc.arrays[0].inputSize != 1) throw std::runtime_error("WaveNet first layer array must have input_size 1");
 
 				// Pass 2: walk the flat weights and emit stages
 				int prevHeadW = -1, prevHeadB = -1;
@@ -358,6 +377,7 @@ namespace na
 						st.a4_floats = (K + 1) * 64 * st.G + 12 * st.G;
 						SetRing(st, layerRing[a][l]);
 						if (cfg.activation == ACT_LEAKYRELU) st.flags |= WN_FLAG_LEAKY;
+						else if (desc.mathMode == MATH_STD) st.flags |= WN_FLAG_STD_TANH;
 						// NeedOutput=false for the very last layer (WaveNet.h:643,785); for a single-array model the
 						// reference still computes it but nothing reads it.
 						if (!(lastLayer && lastArray)) st.flags |= WN_FLAG_NEED_OUTPUT;
@@ -371,7 +391,7 @@ namespace na
 						WnPrewarmLayer pw = {};
 						pw.kind = 0;
 						pw.cin = C; pw.cout = C; pw.ksize = K;
-						pw.act = cfg.activation;
+						pw.act = (cfg.activation == ACT_LEAKYRELU) ? 1 : (desc.mathMode == MATH_STD ? 2 : 0);
 						pw.wconv = wconv; pw.bconv = bconv; pw.wmix = wmix; pw.w1 = w1; pw.b1 = b1;
 						pw.ring_id = layerRing[a][l];
 						pw.need_output = 1;

@@ -90,3 +90,61 @@ def test_keras_gru_file_matches_committed_torch_vectors(na, loader):
     x = g["input"]
     y = np.concatenate([m.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
     assert O.rms(y - g["output"]) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------ StdMath policy
+
+def test_keras_lstm_known_answer_vector_through_the_hip_path(na):
+    """The reference's ONLY golden output: Utils/Models/tw40_blues_deluxe_deerinkstudios.json carries input_batch -> output_batch
+    (exact-math vector: StdMath, zero state, no prewarm).  The HIP path in StdMath mode (the reference's -DLSTM_MATH=StdMath build,
+    NeuralAudio/CMakeLists.txt:94-96, Activation.h:20-45) must reproduce it directly -- no oracle in between."""
+    j = O.load_json("tw40_blues_deluxe_deerinkstudios.json")
+    x = np.asarray(j["input_batch"], np.float32).ravel()
+    want = np.asarray(j["output_batch"], np.float32).ravel()
+    ld = na.NeuralModelLoader()
+    ld.SetLSTMMathMode(na.EMathMode.StdMath)
+    m = ld.CreateFromFile(_model_path("tw40_blues_deluxe_deerinkstudios.json"), doPrewarm=False)
+    y = np.concatenate([m.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
+    err = O.rms(y - want)
+    assert O.rms(want) > 0.01
+    assert err < 1e-6, err
+    # and the default FastMath build of the same file is NOT that vector (4.8e-3 RMS in the oracle): the knob is live
+    m2 = na.NeuralModelLoader().CreateFromFile(_model_path("tw40_blues_deluxe_deerinkstudios.json"), doPrewarm=False)
+    y2 = np.concatenate([m2.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
+    assert O.rms(y2 - want) > 1e-3
+
+
+@pytest.mark.parametrize("name", ["BossLSTM-1x16.nam", "BossLSTM-2x8.nam", "tw40_blues_deluxe_deerinkstudios.json"])
+def test_stdmath_lstm_matches_stdmath_oracle(na, name):
+    ld = na.NeuralModelLoader()
+    ld.SetLSTMMathMode(na.EMathMode.StdMath)
+    m = ld.CreateFromFile(_model_path(name))
+    x = O.signal_noise(2048, 5)
+    y = np.concatenate([m.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
+    yo = O.oracle_from_file(name, math_mode=O.MATH_STD).process(x)
+    assert O.rms(y - yo) < 5e-6, (name, O.rms(y - yo))
+
+
+@pytest.mark.parametrize("name", ["BossWN-standard.nam", "BossWN-nano.nam"])
+def test_stdmath_wavenet_matches_stdmath_oracle(na, name):
+    ld = na.NeuralModelLoader()
+    ld.SetWaveNetMathMode(na.EMathMode.StdMath)
+    m = ld.CreateFromFile(_model_path(name))
+    x = O.signal_sine(2048)
+    y = np.concatenate([m.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
+    yo = O.oracle_from_file(name, math_mode=O.MATH_STD).process(x)
+    assert O.rms(y - yo) < 5e-6, (name, O.rms(y - yo))
+    yf = O.oracle_from_file(name).process(x)
+    assert O.rms(yo - yf) > 1e-5  # the two policies differ measurably (6.6e-4 on Standard / sine)
+
+
+@pytest.mark.parametrize("layers,hidden", [(1, 3), (1, 18), (3, 16), (2, 40), (2, 64)])
+def test_runtime_shaped_lstm_matches_oracle(na, loader, layers, hidden):
+    """Hidden sizes / layer counts without a shaped kernel run on the runtime-shaped one (LSTMDynamic.h:95-108 accepts any)."""
+    w = O.synth_lstm_weights(layers, hidden, seed=100 + hidden)
+    m = loader.CreateFromString(O.nam_json_lstm(layers, hidden, w), ".nam")
+    assert m is not None
+    x = O.signal_noise(512, 3)
+    y = np.concatenate([m.Process(x[i:i + 100]) for i in range(0, x.size, 100)])
+    yo = O.OracleLSTM.from_nam(layers, hidden, w).process(x)
+    assert O.rms(y - yo) < 5e-6, (layers, hidden, O.rms(y - yo))

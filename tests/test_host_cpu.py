@@ -56,6 +56,46 @@ def test_library_exports_every_declared_symbol(na):
     assert sorted(capi.LEGACY_SYMBOLS + capi.NA_SYMBOLS) == sorted(declared)
 
 
+def test_cpp_api_is_exported_and_a_cpp_host_links(na, tmp_path):
+    """The C++ boundary (NeuralModel.h:33-153 of the reference): NeuralModel / NeuralModelLoader are exported from the shared
+    library, and a C++ translation unit written against include/NeuralAudio/NeuralModel.h alone links and runs."""
+    from neuralaudio_amd import capi
+    out = subprocess.run(["nm", "-D", "-C", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for sym in ("NeuralAudio::NeuralModelLoader::CreateFromFile(", "NeuralAudio::NeuralModelLoader::CreateFromStream(",
+                "NeuralAudio::NeuralModelLoader::CreateFromString(", "NeuralAudio::NeuralModelLoader::SupportsWaveNetLoadMode(",
+                "NeuralAudio::NeuralModelLoader::SupportsLSTMLoadMode(", "vtable for NeuralAudio::NeuralModel",
+                "typeinfo for NeuralAudio::NeuralModel"):
+        assert sym in out, sym
+    src = tmp_path / "host.cpp"
+    src.write_text(
+        '#include <NeuralAudio/NeuralModel.h>\n#include <cstdio>\n'
+        'int main(int argc, char** argv) {\n'
+        '  NeuralAudio::NeuralModelLoader loader;\n'
+        '  loader.SetDefaultMaxAudioBufferSize(128);\n'
+        '  NeuralAudio::NeuralModel* m = loader.CreateFromFile(argv[1], false);\n'
+        '  if (!m) return 3;\n'
+        '  std::printf("%d %g %d %d\\n", (int)m->GetLoadMode(), m->GetSampleRate(), m->GetReceptiveFieldSize(), (int)m->IsStatic());\n'
+        '  delete m;\n  return loader.CreateFromFile("/nonexistent.nam") == nullptr ? 0 : 4;\n}\n')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir, "-lNeuralAudioCAPI",
+                    "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([str(exe), os.path.join(O.MODELS_DIR, "BossWN-standard.nam")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["0", "48000", "4092", "1"]
+
+
+def test_modeltest_host_builds_and_reports_a_missing_gpu(na):
+    """tools/ModelTest (the reference's Utils/ModelTest counterpart) is a C++ host of the exported API; without a device it must say so."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tools", "ModelTest")], check=True, capture_output=True)
+    exe = os.path.join(ROOT, "neuralaudio_amd", "ModelTest")
+    assert subprocess.run([exe, "--bogus"], capture_output=True).returncode == 1
+    if na.device_count() > 0:
+        pytest.skip("a GPU is present: tests/test_gpu_modeltest.py runs it for real")
+    r = subprocess.run([exe, "-b", "128", os.path.join(O.MODELS_DIR, "BossLSTM-1x16.nam")], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stdout and "Block size: 128  Quality Scale: 1" in r.stdout
+
+
 def test_library_embeds_gfx950_code_object(na):
     from neuralaudio_amd import capi
     data = open(capi.LIB_PATH, "rb").read()
@@ -121,8 +161,12 @@ def test_missing_and_malformed_files(na, tmp_path):
     j["weights"] = j["weights"][:-3]
     short = tmp_path / "short.nam"
     short.write_text(json.dumps(j))
-    m = loader.CreateFromFile(str(short), doPrewarm=False)  # loads; the weight count is checked when device tables are built
-    assert m is not None
+    with pytest.raises(na.NeuralAudioError, match="Wrong number of weights. Expected 842 but got 839"):  # at LOAD, like WaveNet.h:704-709
+        loader.CreateFromFile(str(short), doPrewarm=False)
+    wide_wn = O.nam_json_wavenet_generic([dict(O.a1_arrays(4, 2)[0], channels=20, head_size=1)], [0.0])
+    short.write_text(wide_wn)
+    with pytest.raises(na.NeuralAudioError, match="channels > 16"):  # kernel limits are load-time errors too
+        loader.CreateFromFile(str(short), doPrewarm=False)
     conv = tmp_path / "conv.json"
     conv.write_text(json.dumps({"in_shape": [None, None, 1], "layers": [{"type": "conv1d", "shape": [None, None, 8], "weights": []},
                                                                         {"type": "dense", "shape": [None, None, 1], "weights": []}]}))
@@ -135,6 +179,72 @@ def test_missing_and_malformed_files(na, tmp_path):
     wide["layers"][-1]["weights"] = [[[0.1, 0.2]] * 16, [0.0, 0.0]]  # dense head with 2 outputs: not this path
     gru.write_text(json.dumps(wide))
     assert loader.CreateFromFile(str(gru), doPrewarm=False) is None
+
+
+def test_lstm_shapes_accepted_or_rejected_at_load(na, tmp_path):
+    """Any hidden size the reference's dynamic LSTM takes loads (runtime-shaped kernel); what has no kernel fails at load, with a reason."""
+    loader = na.NeuralModelLoader()
+    path = tmp_path / "m.nam"
+    for layers, hidden in ((1, 3), (1, 18), (3, 16), (2, 64)):
+        path.write_text(O.nam_json_lstm(layers, hidden, O.synth_lstm_weights(layers, hidden, seed=hidden)))
+        assert loader.CreateFromFile(str(path), doPrewarm=False) is not None
+    path.write_text(O.nam_json_lstm(2, 192, O.synth_lstm_weights(2, 192, seed=1)))
+    with pytest.raises(na.NeuralAudioError, match="LSTM 2x192 is not supported"):
+        loader.CreateFromFile(str(path), doPrewarm=False)
+    gru = tmp_path / "gru.json"
+    gru.write_text(json.dumps(O.synth_keras_gru(3, 16, seed=3)))
+    with pytest.raises(na.NeuralAudioError, match="GRU 3x16 is not supported"):
+        loader.CreateFromFile(str(gru), doPrewarm=False)
+
+
+def test_number_parsing_ignores_the_c_locale(na, tmp_path):
+    """A host that called setlocale(LC_ALL, "") under a comma-decimal locale must still read "0.1234" as 0.1234."""
+    import locale
+    import subprocess
+    import sys
+    code = (
+        "import locale, sys, os\n"
+        "sys.path.insert(0, %r)\n"
+        "ok = False\n"
+        "for name in ('de_DE.UTF-8', 'fr_FR.UTF-8', 'de_DE', 'fr_FR', 'nl_NL.UTF-8', 'ru_RU.UTF-8'):\n"
+        "    try:\n"
+        "        locale.setlocale(locale.LC_ALL, name); ok = True; break\n"
+        "    except locale.Error:\n"
+        "        pass\n"
+        "import neuralaudio_amd as na\n"
+        "m = na.NeuralModelLoader().CreateFromFile(%r, doPrewarm=False)\n"
+        "print('LOCALE' if ok else 'NOLOCALE', m.GetMetadata('loudness'), m.GetRecommendedOutputDBAdjustment())\n"
+    ) % (ROOT, os.path.join(O.MODELS_DIR, "BossWN-nano.nam"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()
+    ref = json.load(open(os.path.join(O.MODELS_DIR, "BossWN-nano.nam")))["metadata"]["loudness"]
+    assert float(out[1]) == ref and abs(float(out[2]) - (-18 - ref)) < 1e-5
+    # the image may carry no comma-decimal locale: the in-process check below covers the parser either way
+    loader = na.NeuralModelLoader()
+    j = O.load_json("BossWN-nano.nam")
+    j["metadata"]["gain"] = 0.1234
+    j["metadata"]["loudness"] = -20.5
+    p = tmp_path / "m.nam"
+    p.write_text(json.dumps(j))
+    m = loader.CreateFromFile(str(p), doPrewarm=False)
+    assert m.GetMetadata("gain") == "0.1234" and abs(m.GetRecommendedOutputDBAdjustment() - 2.5) < 1e-6
+
+
+def test_metadata_values_are_dumped_like_nlohmann(na, tmp_path):
+    """GetMetadata returns json.dump() text (NeuralModelImpl.h:85-94): shortest round-trip floats, "3.0" stays "3.0", sorted keys."""
+    loader = na.NeuralModelLoader()
+    j = O.load_json("BossWN-nano.nam")
+    j["metadata"].update({"a_tenth": 0.1, "three": 3.0, "int": 3, "tiny": 1e-05, "big": 1.5e+20, "neg": -0.25,
+                          "nested": {"zeta": 1, "alpha": [1.5, 2, "x"], "mid": None}})
+    p = tmp_path / "m.nam"
+    p.write_text(json.dumps(j))
+    m = loader.CreateFromFile(str(p), doPrewarm=False)
+    assert m.GetMetadata("a_tenth") == "0.1"
+    assert m.GetMetadata("three") == "3.0"
+    assert m.GetMetadata("int") == "3"
+    assert m.GetMetadata("tiny") == "1e-05"
+    assert m.GetMetadata("big") == "1.5e+20"
+    assert m.GetMetadata("neg") == "-0.25"
+    assert m.GetMetadata("nested") == '{"alpha":[1.5,2,"x"],"mid":null,"zeta":1}'
 
 
 def test_a2_features_outside_the_internal_path_are_rejected(na, tmp_path):
@@ -205,7 +315,13 @@ def test_process_without_gpu_fails_loudly(na):
     fp = C.POINTER(C.c_float)
     capi.load_library().Process(m._h, x.ctypes.data_as(fp), y.ctypes.data_as(fp), 16)
     assert "no HIP device" in capi.last_error()
-    assert np.all(y == 123.0)  # output untouched
+    assert np.all(y == 0.0)  # silence, never uninitialised memory (and never numbers from some fallback)
+    # a second call must fail the same way (no half-built device state left behind by the first)
+    y[:] = 123.0
+    assert capi.load_library().NA_ProcessChecked(m._h, x.ctypes.data_as(fp), y.ctypes.data_as(fp), 16) != 0
+    assert np.all(y == 0.0)
+    with pytest.raises(na.NeuralAudioError):
+        m.Process(x)
     with pytest.raises(na.NeuralAudioError):
         na.Batch(0)
 
