@@ -195,6 +195,22 @@ namespace na
 
 	namespace
 	{
+		// WaveNet kernel family (process-wide, read once): "split" = the f16-split MFMA kernel (default), "frame" = the f32 4x4x1-MFMA
+		// kernel of round 1, "tile" / "pk" = the older measured alternatives.  The families differ in their stream-state format.
+		enum WnFamily { WN_FAMILY_SPLIT, WN_FAMILY_FRAME, WN_FAMILY_TILE, WN_FAMILY_PK };
+		WnFamily WaveNetFamily()
+		{
+			static const WnFamily fam = []() {
+				const char* e = getenv("NA_WN_KERNEL");
+				const std::string w = e ? e : "split";
+				if (w == "frame") return WN_FAMILY_FRAME;
+				if (w == "tile") return WN_FAMILY_TILE;
+				if (w == "pk") return WN_FAMILY_PK;
+				return WN_FAMILY_SPLIT;
+			}();
+			return fam;
+		}
+
 		class WaveNetGroup : public ModelGroup
 		{
 		public:
@@ -206,6 +222,8 @@ namespace na
 				dWpk.Upload(plan.wpk, stream);
 				dPrewarm.Upload(plan.prewarm, stream);
 				dWeights.Upload(d->wavenet.weights, stream);
+				dSStages.Upload(plan.sstages, stream);
+				dWsplit.Upload(plan.wsplit, stream);
 
 				std::vector<int> ringOff, ringFrames, ringG;
 				for (const auto& r : plan.rings)
@@ -240,6 +258,11 @@ namespace na
 				dev.nrings = (int)plan.rings.size();
 				dev.state_f4 = plan.stateF4;
 				dev.head_scale = plan.headScale;
+				dev.sstages = dSStages.Get();
+				dev.wsplit = dWsplit.Get();
+				dev.wsplit_quads = (int)(plan.wsplit.size() / 8);
+				dev.max_split_ops = plan.maxSplitOps;
+				dev.max_G = plan.maxG;
 			}
 
 			// ChannelHistoryBuffer::AllocBuffer zero-fills (WaveNet.h:38-40)
@@ -262,7 +285,7 @@ namespace na
 				DevArray<int> list;
 				list.Upload(members, stream);
 				CheckHip(LaunchWaveNetFillRings(state.Get(), plan.stateF4, list.Get(), (int)members.size(), (int)plan.rings.size(),
-					dRingOff.Get(), dRingFrames.Get(), dRingG.Get(), dCols.Get(), stream), "WaveNetFillRingsKernel");
+					dRingOff.Get(), dRingFrames.Get(), dRingG.Get(), dCols.Get(), stream, WaveNetFamily() == WN_FAMILY_SPLIT), "WaveNetFillRingsKernel");
 				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize"); // `list` is freed on return
 			}
 
@@ -277,11 +300,16 @@ namespace na
 				while (n > 0)
 				{
 					const int chunk = (int)std::min<size_t>(n, (size_t)WN_MAX_FRAMES);
-					static const std::string which = getenv("NA_WN_KERNEL") ? getenv("NA_WN_KERNEL") : "frame"; // tuning knob: frame | tile | pk
-					if (which == "frame")
+					const WnFamily which = WaveNetFamily();
+					if (which == WN_FAMILY_SPLIT)
+					{
+						const WnFrameGroup g = { &dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0 };
+						CheckHip(LaunchWaveNetSplitFused(&g, 1, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "WaveNetSplitKernel");
+					}
+					else if (which == WN_FAMILY_FRAME)
 						CheckHip(LaunchWaveNetFrame(dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset,
 							inStride, outStride, chunk, launchStream, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0), "WaveNetFrameKernel");
-					else if (which != "pk")
+					else if (which != WN_FAMILY_PK)
 						CheckHip(LaunchWaveNetBlock(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
 							outStride, chunk, launchStream), "WaveNetBlockKernel");
 					else
@@ -294,8 +322,7 @@ namespace na
 
 			bool FusedLaunchArgs(WnFrameGroup& out) override
 			{
-				static const bool frame = !getenv("NA_WN_KERNEL") || std::string(getenv("NA_WN_KERNEL")) == "frame";
-				if (!frame) return false;
+				if (WaveNetFamily() != WN_FAMILY_SPLIT && WaveNetFamily() != WN_FAMILY_FRAME) return false;
 				SyncActiveLists();
 				out.model = &dev;
 				out.state = state.Get();
@@ -339,6 +366,8 @@ namespace na
 			DevArray<float> dWeights;
 			DevArray<int> dRingOff, dRingFrames, dRingG;
 			DevArray<float> dCols;
+			DevArray<WnSplitStage> dSStages;
+			DevArray<uint16_t> dWsplit;
 			DevArray<float> state;
 			size_t capacity = 0;
 		};
@@ -640,8 +669,9 @@ namespace na
 			{
 				const int chunk = (int)std::min<size_t>(left, (size_t)WN_MAX_FRAMES);
 				for (size_t first = 0; first < fusedWn.size(); first += WN_FRAME_MAX_GROUPS)
-					CheckHip(LaunchWaveNetFrameFused(fusedWn.data() + first, (int)std::min<size_t>(fusedWn.size() - first, (size_t)WN_FRAME_MAX_GROUPS),
-						dIn + offset, dOut + offset, inStride, outStride, chunk, s), "WaveNetFrameKernel (fused)");
+					CheckHip((WaveNetFamily() == WN_FAMILY_SPLIT ? LaunchWaveNetSplitFused : LaunchWaveNetFrameFused)(fusedWn.data() + first,
+						(int)std::min<size_t>(fusedWn.size() - first, (size_t)WN_FRAME_MAX_GROUPS), dIn + offset, dOut + offset, inStride, outStride, chunk, s),
+						"WaveNet kernel (fused)");
 				offset += (size_t)chunk;
 				left -= (size_t)chunk;
 			}

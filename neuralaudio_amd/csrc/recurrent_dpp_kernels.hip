@@ -333,7 +333,7 @@ namespace na
 		const int row = ga.rows[idx];
 		const int key = ga.m.cell * 100 + ga.m.hidden * 4 + ga.m.numLayers + ((ga.m.cell == LSTM_CELL_LSTM && ga.m.math == LSTM_MATH_STD) ? 1000 : 0);
 #define NA_REC_CASE(CELL, HH, LL, BODY) \
-	case CELL * 100 + HH * 4 + LL: BODY<HH, LL>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout); break;
+	case (CELL) * 100 + HH * 4 + LL: BODY<HH, LL>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout); break;
 		switch (key)
 		{
 			NA_REC_CASE(LSTM_CELL_LSTM, 8, 1, LstmDppBody)

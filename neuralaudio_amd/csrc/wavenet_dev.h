@@ -82,6 +82,32 @@ namespace na
 	static_assert(sizeof(WnStage) == 128, "stage descriptors are 128-byte records");
 
 
+	// ---- the f16-split MFMA kernel (wavenet_split_kernels.hip, the shipped path) ------------------------------------------
+	// Its own, compact stage record (16 ints = one scalar load).  Activations live in HBM rings / LDS as "split quads": 4 consecutive
+	// channels of one frame = 16 bytes = [h0 h1 | h2 h3 | l0 l1 | l2 l3] f16, h = f16(x), l = f16(x - h) -- the same 4 bytes per
+	// element as f32, 22 mantissa bits.  Ring image: frame-major [frame][channel group] quads (a wave's 64 lanes = 16 frames x 4
+	// groups, or 32 x 2, or 64 x 1, always touch 1 KB of consecutive bytes).
+	struct WnSplitStage
+	{
+		int type;            // WnStageType
+		int flags;           // WnStageFlags
+		int G;               // channel groups (of 4) of this stage's input
+		int Gp;              // lane mode: 1, 2 or 4 channel groups per 16-frame tile (G rounded up to a power of two)
+		int ksize;           // conv kernel size; WN_ST_ARRAY_LINK: lane mode of the NEXT array
+		int dilation;
+		int ring_off;        // quad (16 B) offset of the ring this stage's conv reads, -1: none
+		int ring_frames;
+		int ring_id;
+		int out_ring_off;    // ring receiving this stage's output, -1: none
+		int out_ring_frames;
+		int out_ring_id;
+		int out_G;
+		int a_off;           // this stage's A-operand block in the split weight image: quad offset (64 quads = 1 KB per MFMA operand)
+		int a_ops;           // number of 1 KB operands
+		int reserved;
+	};
+	static_assert(sizeof(WnSplitStage) == 64, "split stage descriptors are 64-byte records");
+
 	struct WnQuad
 	{
 		int shift;  // frames back: dilation * (K - 1 - tap)
@@ -126,5 +152,11 @@ namespace na
 		int nrings;
 		int state_f4;         // per-stream state size in float4 units (header + rings)
 		float head_scale;
+		// f16-split kernel
+		const WnSplitStage* sstages;
+		const void* wsplit;   // A-operand image (f16), 16-byte units
+		int wsplit_quads;
+		int max_split_ops;    // largest per-stage operand count (sizes the LDS weight buffers)
+		int max_G;            // largest channel-group count of any ring / stage (sizes the LDS block image)
 	};
 }

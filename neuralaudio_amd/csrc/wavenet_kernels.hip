@@ -608,9 +608,21 @@ namespace na
 		}
 	}
 
-	// grid = (streams to fill, rings), block = 256: fill ring r of stream slot with its steady-state column
+	// float quad -> split quad [h0 h1 | h2 h3 | l0 l1 | l2 l3] (h = f16(v), l = f16(v - h)): the storage format of the f16-split kernel
+	__device__ __forceinline__ f32x4 SplitQuadBits(f32x4 v)
+	{
+		typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+		typedef float f2 __attribute__((ext_vector_type(2)));
+		const h2 h01 = __builtin_convertvector(f2{ v.x, v.y }, h2), h23 = __builtin_convertvector(f2{ v.z, v.w }, h2);
+		const h2 l01 = __builtin_convertvector(f2{ v.x - (float)h01.x, v.y - (float)h01.y }, h2);
+		const h2 l23 = __builtin_convertvector(f2{ v.z - (float)h23.x, v.w - (float)h23.y }, h2);
+		return f32x4{ __builtin_bit_cast(float, h01), __builtin_bit_cast(float, h23), __builtin_bit_cast(float, l01), __builtin_bit_cast(float, l23) };
+	}
+
+	// grid = (streams to fill, rings), block = 256: fill ring r of stream slot with its steady-state column.
+	// split == 0: f32 quads in the tile layout (frame kernel); split == 1: split quads, frame-major rings (f16-split kernel).
 	__global__ void __launch_bounds__(256) WaveNetFillRingsKernel(f32x4* __restrict__ state, int stateF4, const int* __restrict__ slots,
-		const int* __restrict__ ringOffF4, const int* __restrict__ ringFrames, const int* __restrict__ ringG, const float* __restrict__ cols)
+		const int* __restrict__ ringOffF4, const int* __restrict__ ringFrames, const int* __restrict__ ringG, const float* __restrict__ cols, int split)
 	{
 		const int slot = slots[blockIdx.x];
 		const int r = blockIdx.y;
@@ -620,9 +632,10 @@ namespace na
 		f32x4* ring = st + ringOffF4[r];
 		for (int idx = threadIdx.x; idx < nF4; idx += blockDim.x)
 		{
-			const int cg = (idx >> 4) % G;
+			const int cg = split ? (idx % G) : ((idx >> 4) % G);
 			const float* c = cols + r * 16 + cg * 4;
-			ring[idx] = f32x4{ c[0], c[1], c[2], c[3] };
+			const f32x4 v = f32x4{ c[0], c[1], c[2], c[3] };
+			ring[idx] = split ? SplitQuadBits(v) : v;
 		}
 		if (r == 0 && threadIdx.x < WN_MAX_RINGS) reinterpret_cast<int*>(st)[threadIdx.x] = 0; // cursors
 	}
@@ -673,11 +686,11 @@ namespace na
 	}
 
 	hipError_t LaunchWaveNetFillRings(float* state, int stateF4, const int* slots, int numStreams, int numRings, const int* ringOffF4,
-		const int* ringFrames, const int* ringG, const float* cols, hipStream_t stream)
+		const int* ringFrames, const int* ringG, const float* cols, hipStream_t stream, bool splitFormat)
 	{
 		if (numStreams <= 0) return hipSuccess;
 		hipLaunchKernelGGL(WaveNetFillRingsKernel, dim3((unsigned)numStreams, (unsigned)numRings), dim3(256), 0, stream,
-			reinterpret_cast<f32x4*>(state), stateF4, slots, ringOffF4, ringFrames, ringG, cols);
+			reinterpret_cast<f32x4*>(state), stateF4, slots, ringOffF4, ringFrames, ringG, cols, splitFormat ? 1 : 0);
 		return hipGetLastError();
 	}
 }

@@ -30,6 +30,11 @@ namespace na
 	hipError_t LaunchWaveNetFrameFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream);
 
+	// Same contract, the f16-split MFMA kernel (wavenet_split_kernels.hip) -- the shipped path.  Its stream state uses split quads in
+	// frame-major rings (see WnSplitStage), so a model group stays on one kernel family for its whole life.
+	hipError_t LaunchWaveNetSplitFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream);
+
 	// slots == nullptr: the active streams are contiguous -- stream i uses state slot slot0 + i and matrix row row0 + i (saves the
 	// kernel a dependent global load before it can touch the stream's state)
 	hipError_t LaunchWaveNetFrame(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
@@ -43,7 +48,8 @@ namespace na
 	hipError_t LaunchWaveNetPrewarmColumns(const WnPrewarmLayer* layers, int numLayers, const float* weights, float* cols,
 		hipStream_t stream);
 
-	// Broadcast the columns into the rings of the listed stream slots and zero their cursors.
+	// Broadcast the columns into the rings of the listed stream slots and zero their cursors.  splitFormat: the f16-split kernel's state
+	// (split quads, frame-major rings) instead of the frame kernel's (f32 quads, tile layout).
 	hipError_t LaunchWaveNetFillRings(float* state, int stateF4, const int* slots, int numStreams, int numRings, const int* ringOffF4,
-		const int* ringFrames, const int* ringG, const float* cols, hipStream_t stream);
+		const int* ringFrames, const int* ringG, const float* cols, hipStream_t stream, bool splitFormat);
 }

@@ -7,6 +7,9 @@
 #include "wavenet_plan.h"
 
 #include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
 #include <sstream>
 #include <stdexcept>
 
@@ -82,6 +85,44 @@ namespace na
 			throw std::runtime_error(str.str());
 		}
 	}
+
+
+	// ---- f16-split kernel: A-operand image -------------------------------------------------------------------------------
+	// float -> IEEE binary16 bit pattern, round to nearest even, subnormals kept (what v_cvt_pk_f16_f32 does for the activations)
+	static uint16_t FloatToHalfBits(float f)
+	{
+		uint32_t x;
+		memcpy(&x, &f, 4);
+		const uint32_t sign = (x >> 16) & 0x8000u;
+		x &= 0x7fffffffu;
+		if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+		if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u); // rounds to >= 65520 -> inf
+		if (x < 0x33000001u) return (uint16_t)sign;              // < 2^-25 (or exactly, ties to even 0)
+		int e = (int)(x >> 23) - 127;
+		uint32_t m = (x & 0x7fffffu) | 0x800000u;
+		int shift = (e < -14) ? (13 + (-14 - e)) : 13; // subnormal: shift further
+		uint32_t half = m >> shift;
+		const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+		if (rem > halfway || (rem == halfway && (half & 1u))) half++;
+		if (e < -14) return (uint16_t)(sign | half); // subnormal (a carry into the exponent field is the right bit pattern)
+		half += (uint32_t)(e + 15 - 1) << 10;       // hidden bit adds 1 to the exponent field
+		return (uint16_t)(sign | half);
+	}
+
+	static float HalfBitsToFloat(uint16_t h)
+	{
+		const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+		const int e = (h >> 10) & 0x1f;
+		const uint32_t m = h & 0x3ffu;
+		float v;
+		if (e == 0) v = std::ldexp((float)m, -24);
+		else if (e == 31) v = m ? NAN : INFINITY;
+		else v = std::ldexp((float)(m | 0x400u), e - 25);
+		return sign ? -v : v;
+	}
+
+	// lane mode of a channel count: channel groups per 16-frame tile, rounded up to a power of two
+	static int LaneMode(int channels) { return channels <= 4 ? 1 : (channels <= 8 ? 2 : 4); }
 
 	namespace
 	{
@@ -276,6 +317,200 @@ namespace na
 				st.out_G = plan.rings[ringId].G;
 			}
 
+
+			// ---- f16-split kernel ------------------------------------------------------------------------------------------
+			// One MFMA A operand (v_mfma_f32_16x16x32_f16): lane (row i = lane & 15, k-block q = lane >> 4) holds 8 halfs, the weights
+			// that multiply the 8 halfs of lane (column, q)'s B operand = one split quad [h0..h3 | l0..l3].  W*x ~= Wh*(xh + xl) + Wl*xh:
+			// the "hi" operand carries Wh in all 8 slots, the "lo" operand Wl in the four h slots (zeros against l).
+			// Rows [rowBase, rowBase + cout) x k-blocks [kbBase, kbBase + ceil(cin/4)) receive W(o, c); everything else stays zero, so
+			// several tiles share one MFMA through block-diagonal operands (mode Gp: tile slot p owns rows 4*Gp*p.. and k-blocks Gp*p..).
+			int NewSplitOps(int count)
+			{
+				const int first = (int)(plan.wsplit.size() / 512);
+				plan.wsplit.resize(plan.wsplit.size() + (size_t)count * 512, 0);
+				return first;
+			}
+
+			void FillSplitBlock(int opHi, int opLo, int rowBase, int kbBase, int cout, int cin, const std::function<float(int, int)>& w)
+			{
+				for (int o = 0; o < cout; o++)
+					for (int c = 0; c < cin; c++)
+					{
+						const int row = rowBase + o, q = kbBase + c / 4, r = c % 4;
+						if (row > 15 || q > 3) throw std::runtime_error("internal: split operand block out of range");
+						const float v = w(o, c);
+						const uint16_t hi = FloatToHalfBits(v);
+						const uint16_t lo = FloatToHalfBits(v - HalfBitsToFloat(hi));
+						const size_t lane = (size_t)q * 16 + row;
+						plan.wsplit[(size_t)opHi * 512 + lane * 8 + r] = hi;
+						plan.wsplit[(size_t)opHi * 512 + lane * 8 + 4 + r] = hi;
+						plan.wsplit[(size_t)opLo * 512 + lane * 8 + r] = lo;
+					}
+			}
+
+			// the same weights for every tile slot of mode Gp (merged block-diagonal operand pair)
+			void FillSplitMerged(int opHi, int Gp, int cout, int cin, const std::function<float(int, int)>& w)
+			{
+				for (int p = 0; p < 4 / Gp; p++) FillSplitBlock(opHi, opHi + 1, 4 * Gp * p, Gp * p, cout, cin, w);
+			}
+
+			// "aux" pseudo channel group (cond, 1, 0, 0) riding in the cg = 0 k-block of each tile slot: weights (wCond[o], wOne[o])
+			void FillSplitAux(int opHi, int Gp, int cout, int condOff, int oneOff)
+			{
+				FillSplitMerged(opHi, Gp, cout, 2, [&](int o, int c) { return c == 0 ? (condOff >= 0 ? W(condOff + o) : 0.0f) : (oneOff >= 0 ? W(oneOff + o) : 0.0f); });
+			}
+
+			static WnSplitStage EmptySplit(int type)
+			{
+				WnSplitStage st = {};
+				st.type = type;
+				st.ring_off = -1; st.ring_id = -1;
+				st.out_ring_off = -1; st.out_ring_id = -1;
+				return st;
+			}
+
+			void SplitRing(WnSplitStage& st, int ringId)
+			{
+				st.ring_id = ringId;
+				st.ring_off = plan.rings[ringId].offF4;
+				st.ring_frames = plan.rings[ringId].frames;
+			}
+
+			void SplitOutRing(WnSplitStage& st, int ringId)
+			{
+				st.out_ring_id = ringId;
+				st.out_ring_off = plan.rings[ringId].offF4;
+				st.out_ring_frames = plan.rings[ringId].frames;
+				st.out_G = plan.rings[ringId].G;
+			}
+
+			// second walk over the flat weights (same order as Build): stage program + A-operand image of the f16-split kernel
+			void BuildSplit(const std::vector<std::vector<int>>& layerRing, const std::vector<int>& headRing)
+			{
+				cursor = 0;
+				const int numArrays = (int)desc.arrays.size();
+				int prevHeadW = -1, prevHeadB = -1;
+				for (int a = 0; a < numArrays; a++)
+				{
+					const WnArrayCfg& cfg = desc.arrays[a];
+					const int C = cfg.channels, G = CeilDiv(C, 4), Gp = LaneMode(C);
+					const int numLayers = (int)cfg.kernelSizes.size();
+					const bool lastArray = (a == numArrays - 1);
+					plan.maxG = std::max(plan.maxG, G);
+					const int rechOff = Take((size_t)C * cfg.inputSize);
+					if (a == 0)
+					{
+						// x = w_re * cond (WaveNet.h:637, input_size == 1): the aux operand with weights (w_re, 0)
+						WnSplitStage st = EmptySplit(WN_ST_RECHANNEL_COND);
+						st.G = G; st.Gp = Gp;
+						st.a_ops = 2;
+						st.a_off = NewSplitOps(st.a_ops) * 64;
+						FillSplitAux(st.a_off / 64, Gp, C, rechOff, -1);
+						SplitOutRing(st, layerRing[a][0]);
+						st.flags = WN_FLAG_PUBLISH;
+						plan.sstages.push_back(st);
+					}
+					else
+					{
+						// previous array's head rechannel (K = 1, WaveNet.h:658-660) and this array's rechannel (:637), one tile at a time: the
+						// operand for tile t places its output rows in tile slot t % Pn of the NEW lane mode and takes its k-blocks from tile
+						// slot t % Po of the OLD one, so the MFMA itself re-lays the data out between the two modes.
+						const WnArrayCfg& prev = desc.arrays[a - 1];
+						const int GpO = LaneMode(prev.channels), Po = 4 / GpO, Pn = 4 / Gp, NC = std::max(Po, Pn);
+						WnSplitStage st = EmptySplit(WN_ST_ARRAY_LINK);
+						st.G = CeilDiv(prev.channels, 4); st.Gp = GpO; st.ksize = Gp;
+						st.a_ops = 4 * NC + 2;
+						st.a_off = NewSplitOps(st.a_ops) * 64;
+						const int op0 = st.a_off / 64;
+						for (int u = 0; u < NC; u++)
+						{
+							const int pn = u % Pn, po = u % Po;
+							FillSplitBlock(op0 + 4 * u, op0 + 4 * u + 1, 4 * Gp * pn, GpO * po, prev.headSize, prev.channels,
+								[&](int o, int c) { return W(prevHeadW + o * prev.channels + c); });
+							FillSplitBlock(op0 + 4 * u + 2, op0 + 4 * u + 3, 4 * Gp * pn, GpO * po, C, cfg.inputSize,
+								[&](int o, int c) { return W(rechOff + o * cfg.inputSize + c); });
+						}
+						if (prev.hasHeadBias)
+						{
+							st.flags |= WN_FLAG_BIAS;
+							FillSplitAux(op0 + 4 * NC, Gp, prev.headSize, -1, prevHeadB);
+						}
+						SplitOutRing(st, layerRing[a][0]);
+						st.flags |= WN_FLAG_PUBLISH;
+						plan.sstages.push_back(st);
+					}
+
+					for (int l = 0; l < numLayers; l++)
+					{
+						const int K = cfg.kernelSizes[l];
+						const int wconv = Take((size_t)C * C * K);
+						const int bconv = Take((size_t)C);
+						const int wmix = Take((size_t)C * cfg.conditionSize);
+						const int w1 = Take((size_t)C * C);
+						const int b1 = Take((size_t)C);
+						const bool lastLayer = (l == numLayers - 1);
+						const bool needOutput = !(lastLayer && lastArray);
+
+						WnSplitStage st = EmptySplit(WN_ST_LAYER);
+						st.G = G; st.Gp = Gp; st.ksize = K; st.dilation = cfg.dilations[l];
+						// operands: taps 0..K-1 (hi, lo each; tap K-1 is the unshifted one), aux = (mix-in, conv bias), then 1x1 and its bias
+						st.a_ops = 2 * K + 2 + (needOutput ? 4 : 0);
+						st.a_off = NewSplitOps(st.a_ops) * 64;
+						const int op0 = st.a_off / 64;
+						for (int k = 0; k < K; k++)
+							FillSplitMerged(op0 + 2 * k, Gp, C, C, [&](int o, int c) { return W(wconv + (o * C + c) * K + k); });
+						FillSplitAux(op0 + 2 * K, Gp, C, wmix, bconv);
+						if (needOutput)
+						{
+							FillSplitMerged(op0 + 2 * K + 2, Gp, C, C, [&](int o, int c) { return W(w1 + o * C + c); });
+							FillSplitAux(op0 + 2 * K + 4, Gp, C, -1, b1);
+							st.flags |= WN_FLAG_NEED_OUTPUT;
+						}
+						SplitRing(st, layerRing[a][l]);
+						if (cfg.activation == ACT_LEAKYRELU) st.flags |= WN_FLAG_LEAKY;
+						else if (desc.mathMode == MATH_STD) st.flags |= WN_FLAG_STD_TANH;
+						if (!lastLayer)
+						{
+							st.flags |= WN_FLAG_PUBLISH;
+							SplitOutRing(st, layerRing[a][l + 1]);
+						}
+						plan.sstages.push_back(st);
+					}
+
+					const int wh = Take((size_t)cfg.headSize * C * cfg.headKernelSize);
+					const int bh = cfg.hasHeadBias ? Take((size_t)cfg.headSize) : -1;
+					if (lastArray)
+					{
+						// only head channel 0 reaches the output (WaveNet.h:793-798): one output row per tile slot
+						const int Kh = cfg.headKernelSize;
+						WnSplitStage st = EmptySplit(Kh == 1 ? WN_ST_HEAD_DENSE_OUT : WN_ST_HEAD_CONV_OUT);
+						st.G = G; st.Gp = Gp; st.ksize = Kh; st.dilation = cfg.headDilation;
+						st.a_ops = 2 * Kh + 2;
+						st.a_off = NewSplitOps(st.a_ops) * 64;
+						const int op0 = st.a_off / 64;
+						for (int k = 0; k < Kh; k++)
+							FillSplitMerged(op0 + 2 * k, Gp, 1, C, [&](int o, int c) { return W(wh + (o * C + c) * Kh + k); });
+						if (cfg.hasHeadBias)
+						{
+							st.flags |= WN_FLAG_BIAS;
+							FillSplitAux(op0 + 2 * Kh, Gp, 1, -1, bh);
+						}
+						if (Kh > 1)
+						{
+							SplitRing(st, headRing[a]);
+							SplitOutRing(st, headRing[a]);
+						}
+						plan.sstages.push_back(st);
+					}
+					else
+					{
+						prevHeadW = wh;
+						prevHeadB = bh;
+					}
+				}
+				for (const WnSplitStage& st : plan.sstages) plan.maxSplitOps = std::max(plan.maxSplitOps, st.a_ops);
+			}
+
 			void Build()
 			{
 				ValidateWaveNetDesc(desc);
@@ -453,6 +688,7 @@ namespace na
 				}
 
 				plan.headScale = W(Take(1));
+				BuildSplit(layerRing, headRing);
 				// every stage's weights were allocated back to back starting with its vec block
 				for (size_t i = 0; i < plan.stages.size(); i++)
 				{

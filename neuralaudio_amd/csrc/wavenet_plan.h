@@ -2,6 +2,7 @@
 // consumed by the gfx950 kernels (see wavenet_dev.h for the layouts).
 #pragma once
 
+#include <cstdint>
 #include <vector>
 
 #include "model_desc.h"
@@ -25,6 +26,10 @@ namespace na
 		std::vector<float> wpk;     // weights for the packed-FMA (lane = frame) kernel
 		std::vector<WnRingInfo> rings;
 		std::vector<WnPrewarmLayer> prewarm;
+		std::vector<WnSplitStage> sstages; // stage program of the f16-split kernel
+		std::vector<uint16_t> wsplit;      // its A-operand image: f16 bit patterns, 512 per MFMA operand
+		int maxSplitOps = 0;
+		int maxG = 1;
 		int stateF4 = 0;            // per-stream state in float4 units
 		int maxA4Floats = 0;        // largest per-stage A-operand block of the frame kernel (floats)
 		int maxStageF4 = 0;         // largest per-stage weight block (float4), sizes the LDS staging buffers

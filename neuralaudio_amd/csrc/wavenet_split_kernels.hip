@@ -1,0 +1,801 @@
+// wavenet_split_kernels.hip -- the shipped WaveNet block kernel for gfx950: every mat-mul of the path on v_mfma_f32_16x16x32_f16,
+// f32 accuracy from a three-product f16 split.
+//
+// Reference arithmetic being replaced (one stream, per-sample loops on the CPU): WaveNetModelT / LayerArrayT / LayerT::Process,
+// Conv1DT::Process, DenseLayerT::Process (NeuralAudio/WaveNet.h:768-799, 632-661, 462-494, 139-290, 336-383), FastMath / StdMath
+// activations (Activation.h:20-118).
+//
+// Why f16 MFMA for an f32 path: f32-input MFMA runs at the f32 VECTOR rate on gfx950 (32 MAC / cycle / SIMD) and, measured in
+// round 1, shares its issue slots with the VALU -- the frame kernel (wavenet_frame_kernels.hip) spends 23 of its 60 us issuing them.
+// v_mfma_f32_16x16x32_f16 runs 16x faster (8192 MAC in 17 cycles), overlaps with plain VALU work of the same and of other waves
+// (tools/microbench/mfma_f16_valu_mix.hip) and accumulates in f32.  Every value v is carried as h = f16(v), l = f16(v - h) (22
+// mantissa bits) and W*x is evaluated as Wh*xh + Wh*xl + Wl*xh; the dropped Wl*xl term is 2^-22 relative.  Measured against a
+// float64 evaluation of the real models the split is as accurate as f32 arithmetic (1.1e-7 vs 1.3e-7 RMS on Standard).
+//
+// Mapping (16x16x32: D[16 rows][16 cols] += A[16][32] * B[32][16]; lane = (j = lane & 15, q = lane >> 4)):
+//   * columns = 16 consecutive frames (a tile), rows = output channels, k = input channels x split parts;
+//   * B operand of lane (j, q) = 8 halfs = ONE "split quad": channels 4cg..4cg+3 of the lane's frame as [h0 h1 h2 h3 l0 l1 l2 l3].
+//     That is also the storage format of the activations (LDS block image and HBM rings, 16 bytes per 4 channels -- the same bytes as
+//     f32), so a conv tap is ONE 16-byte load straight into the MFMA operand, with no conversion;
+//   * D of lane (j, q) = rows 4q..4q+3 of column j: 4 channels of the lane's frame in f32 -> activation, split (8 VALU per quad) and
+//     the result is again the B operand of the next mat-mul: nothing is ever shuffled between lanes;
+//   * A operands (weights, host-packed, wavenet_plan.cpp) are staged global -> LDS one stage ahead by LDS-DMA and read with one
+//     ds_read_b128 per MFMA, shared by all tiles of the wave;
+//   * narrow layers: with C <= 8 (<= 4) channels two (four) tiles share one MFMA through block-diagonal A operands ("lane mode"
+//     Gp = channel groups per tile = 4, 2, 1), so the VALU never sees padding lanes: an 8-channel layer costs half of a 16-channel one;
+//   * bias and the input mix-in ride in the MFMA too: an "aux" operand (cond, 1, 0, 0) per frame against weights (w_mix, bias).
+// A wave owns T consecutive tiles of one stream's block; a workgroup = SPB streams x (8 / T) waves sharing one staged copy of the
+// weights; one LDS-only barrier per layer (the dependency is causal).
+#include <algorithm>
+#include <cstddef>
+#include <cstdlib>
+
+#include <hip/hip_runtime.h>
+
+#include "wavenet_dev.h"
+#include "wavenet_launch.h"
+
+namespace na
+{
+	namespace sp
+	{
+		typedef float f32x4 __attribute__((ext_vector_type(4)));
+		typedef float f32x2 __attribute__((ext_vector_type(2)));
+		typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+		typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+		typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+		typedef const int __attribute__((address_space(4)))* CInt;
+
+		constexpr int OOB = (int)0x80000000;
+		constexpr int FRAMES = WN_MAX_FRAMES; // 128 frames per launch = 8 tiles
+
+		__device__ __forceinline__ __amdgpu_buffer_rsrc_t MakeRsrc(const void* base, unsigned bytes)
+		{
+			return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+		}
+
+		__device__ __forceinline__ u32x4 BufLoad(__amdgpu_buffer_rsrc_t r, int voff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0); }
+		__device__ __forceinline__ void BufStore(__amdgpu_buffer_rsrc_t r, u32x4 v, int voff) { __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0); }
+
+		struct Stage
+		{
+			int type, flags, G, Gp, ksize, dilation, ring_off, ring_frames, ring_id, out_ring_off, out_ring_frames, out_ring_id, out_G, a_off, a_ops, reserved;
+		};
+		static_assert(sizeof(Stage) == sizeof(WnSplitStage), "Stage mirrors WnSplitStage");
+
+		__device__ __forceinline__ Stage LoadStage(const WnSplitStage* __restrict__ stages, int s)
+		{
+			Stage sd;
+			CInt src = (CInt)(const int*)(stages + s);
+			int* dst = reinterpret_cast<int*>(&sd);
+#pragma unroll
+			for (int i = 0; i < 16; i++) dst[i] = src[i];
+			return sd;
+		}
+
+		// ---- arithmetic -------------------------------------------------------------------------------------------------------
+
+		__device__ __forceinline__ f32x4 Mfma(u32x4 a, u32x4 b, f32x4 c)
+		{
+			return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+		}
+
+		__device__ __forceinline__ unsigned PackHalf2(float a, float b)
+		{
+			const f16x2 h = __builtin_convertvector(f32x2{ a, b }, f16x2); // v_cvt_pk_f16_f32 (round to nearest even)
+			return __builtin_bit_cast(unsigned, h);
+		}
+
+		// 4 channels (f32) -> split quad [h0 h1 | h2 h3 | l0 l1 | l2 l3]
+		__device__ __forceinline__ u32x4 SplitQuad(f32x4 v)
+		{
+			const f16x2 h01 = __builtin_convertvector(f32x2{ v.x, v.y }, f16x2);
+			const f16x2 h23 = __builtin_convertvector(f32x2{ v.z, v.w }, f16x2);
+			// v - f32(h), exact in f32; written as fma(f32(h), -1, v) so that the f16 -> f32 conversion folds into v_fma_mix_f32
+			const float r0 = __builtin_fmaf((float)h01.x, -1.0f, v.x), r1 = __builtin_fmaf((float)h01.y, -1.0f, v.y), r2 = __builtin_fmaf((float)h23.x, -1.0f, v.z), r3 = __builtin_fmaf((float)h23.y, -1.0f, v.w);
+			u32x4 q;
+			q.x = __builtin_bit_cast(unsigned, h01);
+			q.y = __builtin_bit_cast(unsigned, h23);
+			q.z = PackHalf2(r0, r1);
+			q.w = PackHalf2(r2, r3);
+			return q;
+		}
+
+		// Activation.h:83-91, plain (unpacked) VALU on purpose: packed f32 instructions do not issue beside MFMAs on gfx950
+		// (tools/microbench/mfma_f16_valu_mix.hip).  |x + e*x*|x|| == |x| + e*x^2 since 1 + e|x| > 0; division = num * v_rcp_f32(den).
+		__device__ __forceinline__ float FastTanh(float x)
+		{
+			const float ax = __builtin_fabsf(x);
+			const float x2 = x * x;
+			const float p = __builtin_fmaf(__builtin_fmaf(0.821226666969744f, ax, 0.893229853513558f), x2, __builtin_fmaf(2.45550750702956f, ax, 2.45550750702956f));
+			const float den = __builtin_fmaf(2.44506634652299f + x2, __builtin_fmaf(0.814642734961073f, x2, ax), 2.44506634652299f);
+			return (x * p) * __builtin_amdgcn_rcpf(den);
+		}
+
+		// StdMath policy (Activation.h:37-40): tanh(x) = 1 - 2 / (e^(2x) + 1) on the exp2 / rcp units (absolute error ~1e-7)
+		__device__ __forceinline__ float StdTanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.885390081777927f) + 1.0f); }
+
+		// Activation.h:110-118
+		__device__ __forceinline__ float LeakyReLU(float v) { return v > 0.0f ? v : 0.01f * v; }
+
+		__device__ __forceinline__ f32x4 Activate(f32x4 a, int flags)
+		{
+			f32x4 z;
+			if (flags & WN_FLAG_LEAKY) // wave-uniform
+			{
+				z.x = LeakyReLU(a.x); z.y = LeakyReLU(a.y); z.z = LeakyReLU(a.z); z.w = LeakyReLU(a.w);
+			}
+			else if (flags & WN_FLAG_STD_TANH)
+			{
+				z.x = StdTanh(a.x); z.y = StdTanh(a.y); z.z = StdTanh(a.z); z.w = StdTanh(a.w);
+			}
+			else
+			{
+				z.x = FastTanh(a.x); z.y = FastTanh(a.y); z.z = FastTanh(a.z); z.w = FastTanh(a.w);
+			}
+			return z;
+		}
+
+		template <int NWAVES>
+		__device__ __forceinline__ void BlockBarrier()
+		{
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+			__builtin_amdgcn_s_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+		}
+
+		// ---- lane geometry ----------------------------------------------------------------------------------------------------
+		// Mode GP (channel groups per tile: 4, 2, 1): P = 4 / GP tiles share one MFMA "set"; a wave of T tiles has S sets.
+		// lane (j, q): tile slot p = q / GP, channel group cg = q % GP; frame of set s: f = F0 + 16 * (P * s + p) + j.
+		template <int GP, int T>
+		struct Geo
+		{
+			static constexpr int P = 4 / GP;
+			static constexpr int S = (T + P - 1) / P;
+			static constexpr bool PARTIAL = (T % P) != 0; // some tile slots of the (only) set lie beyond the wave's tiles
+		};
+
+		// everything a stage needs that does not change from stage to stage
+		struct Ctx
+		{
+			const WnSplitStage* __restrict__ stages;
+			int nstages;
+			const u32x4* wbuf;            // [2][wstride] staged A operands (quads)
+			int wstride;
+			__amdgpu_buffer_rsrc_t wrsrc; // split weight image (staging source)
+			u32x4* img;                   // this stream's [2][maxG][FRAMES] block images (quads)
+			int imgStride;                // quads per image = maxG * FRAMES
+			const u32x4* auxq;            // this stream's aux operands in LDS: split quad of (cond, 1, 0, 0) per frame [FRAMES]
+			__amdgpu_buffer_rsrc_t srsrc; // this stream's state
+			int myPos;                    // lane r: write cursor of ring r
+			int n, nSt;                   // frames in the block; frames this wave may store (0 for a shadow wave)
+			int F0;                       // first frame of this wave
+			int lane, j, q, waveAll;
+			float* __restrict__ out;
+			size_t outBase;
+			float headScale;
+		};
+
+		// ring address (bytes) of channel group `cg` of ring position p, frame-major image: (p * G + cg) * 16
+		__device__ __forceinline__ int RingByte(int ringOff, int G, int p, int cg) { return (ringOff + p * G + cg) * 16; }
+
+		// History part of one tap for one set: the split quad of frame (f - shift) for the lanes with f < shift (frames before the block
+		// start), from the ring whose write cursor is pos0.  Always one load per call, predicated through the offset, so that the number
+		// of VMEM operations per layer is the same on every path (the compiler can then place counted vmcnt waits).
+		__device__ __forceinline__ u32x4 LoadHistory(const Ctx& cx, int ringOff, int R, int G, int pos0, int f, int cg, int shift, bool valid)
+		{
+			int base = pos0 - shift; // shift <= R - FRAMES: one wrap is enough
+			if (base < 0) base += R;
+			unsigned p = (unsigned)(base + f);
+			p = __builtin_elementwise_min(p, p - (unsigned)R); // p >= R ? p - R : p
+			const int addr = RingByte(ringOff, G, (int)p, cg);
+			return BufLoad(cx.srsrc, (valid && f < shift) ? addr : OOB);
+		}
+
+		// one conv tap operand: in-block frames come from the LDS block image, earlier ones were prefetched from the ring (`hist`)
+		__device__ __forceinline__ u32x4 TapOperand(const u32x4* img, u32x4 hist, int off, int cg)
+		{
+			u32x4 v = hist;
+			if (off >= 0) v = img[cg * FRAMES + off]; // divergent: the in-block lanes overwrite the prefetched history
+			return v;
+		}
+
+		// ... without a prefetch (taps beyond the prefetched ones, head conv): LDS, ring, or both, decided per wave
+		__device__ __forceinline__ u32x4 TapOperandInline(const Ctx& cx, const u32x4* img, int ringOff, int R, int G, int pos0, int f, int cg, int shift, int lo, int hi)
+		{
+			const int off = f - shift;
+			if (lo >= 0) return img[cg * FRAMES + off];
+			int p = pos0 + off;
+			if (p < 0) p += R;
+			if (p >= R) p -= R;
+			if (hi < 0) return BufLoad(cx.srsrc, RingByte(ringOff, G, p, cg));
+			const u32x4 h = BufLoad(cx.srsrc, off < 0 ? RingByte(ringOff, G, p, cg) : OOB);
+			const u32x4 l = img[cg * FRAMES + (off < 0 ? 0 : off)];
+			u32x4 v;
+			v.x = off < 0 ? h.x : l.x; v.y = off < 0 ? h.y : l.y; v.z = off < 0 ? h.z : l.z; v.w = off < 0 ? h.w : l.w;
+			return v;
+		}
+
+		// layer output -> LDS block image (in-block taps of the next layer) and -> the next layer's HBM ring (history for LATER blocks:
+		// only the last R - FRAMES frames of a block can ever be read back).  One store instruction on every path.
+		__device__ __forceinline__ void Publish(const Ctx& cx, u32x4* imgNext, u32x4 v, int f, int cg, bool liveLane, int outRingOff, int outR, int outG, int outPos0, int nSt)
+		{
+			if (liveLane) imgNext[cg * FRAMES + f] = v;
+			const int firstKept = nSt - (outR - FRAMES);
+			unsigned p = (unsigned)(outPos0 + f);
+			p = __builtin_elementwise_min(p, p - (unsigned)outR);
+			const bool keep = liveLane && (f < nSt) && (f >= firstKept);
+			BufStore(cx.srsrc, v, keep ? RingByte(outRingOff, outG, (int)p, cg) : OOB);
+		}
+
+		// Stages the NEXT stage's A-operand block into the other LDS weight buffer with LDS-DMA loads (buffer_load_dwordx4 ... lds: lane l's
+		// 16 bytes land at ldsBase + 16 l, no VGPRs, no ds_write), issued at the start of a stage and awaited just before its closing
+		// barrier.  WCOPY loads per thread cover 16 KB per workgroup of 512; larger blocks (K = 15 layers) use the tail loop.
+		template <int NTHREADS>
+		struct WeightStager
+		{
+			static constexpr int WCOPY = (1024 + NTHREADS - 1) / NTHREADS; // quads per thread in the fixed part (16 KB)
+
+			__device__ __forceinline__ void Begin(const Ctx& cx, int nextBuf, const Stage& sdn) const
+			{
+				const int nextQ = sdn.a_ops * 64;
+#pragma unroll
+				for (int c = 0; c < WCOPY; c++)
+				{
+					const int i0 = c * NTHREADS + cx.waveAll * 64; // first quad of this wave's 1 KB slice (wave-uniform)
+					const int i = i0 + cx.lane;
+					__builtin_amdgcn_raw_ptr_buffer_load_lds(cx.wrsrc, (__attribute__((address_space(3))) void*)(const_cast<u32x4*>(cx.wbuf) + nextBuf * cx.wstride + i0), 16,
+						(i < nextQ) ? (sdn.a_off + i) * 16 : OOB, 0, 0, 0);
+				}
+			}
+
+			// LATER = number of VMEM instructions this wave issued after Begin() on every path (they may stay in flight), or 0
+			template <int LATER>
+			__device__ __forceinline__ void End(const Ctx& cx, int nextBuf, const Stage& sdn) const
+			{
+				const int nextQ = sdn.a_ops * 64;
+				u32x4* dst = const_cast<u32x4*>(cx.wbuf) + nextBuf * cx.wstride;
+				for (int i = (int)threadIdx.x + WCOPY * NTHREADS; i < nextQ; i += NTHREADS) dst[i] = BufLoad(cx.wrsrc, (sdn.a_off + i) * 16);
+				// the DMA data must be in LDS before the closing barrier lets other waves read it (the workgroup fence only covers lgkmcnt)
+				// gfx9 s_waitcnt: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at "don't wait"
+				__builtin_amdgcn_s_waitcnt((LATER & 15) | ((LATER >> 4) << 14) | (7 << 4) | (15 << 8));
+			}
+		};
+
+		// per-wave register state carried from stage to stage (sized for the widest mode; narrow modes use the first S entries)
+		template <int T>
+		struct State
+		{
+			f32x4 xc[T]; // layer input (residual stream), f32; its split quad lives in the LDS block image (the unshifted tap reads it back)
+			f32x4 hd[T]; // head accumulator
+		};
+
+		template <int GP, int T>
+		__device__ __forceinline__ void FrameOf(const Ctx& cx, int s, int& f, int& cg, bool& tileLive)
+		{
+			constexpr int P = Geo<GP, T>::P;
+			const int p = cx.q / GP;
+			cg = cx.q % GP;
+			f = cx.F0 + 16 * (P * s + p) + cx.j;
+			tileLive = !Geo<GP, T>::PARTIAL || (P * s + p < T);
+		}
+
+		// this lane's aux operand for frame f
+		__device__ __forceinline__ u32x4 AuxOf(const Ctx& cx, int f) { return cx.auxq[f & (FRAMES - 1)]; }
+
+		// A run of consecutive WaveNet layer stages (WaveNetLayerT::Process, WaveNet.h:462-494) of one lane mode.
+		// VMEM operations per layer, in this order on every path: WCOPY weight DMA loads, HPF*S history loads (for the NEXT layer,
+		// issued once this layer's taps have consumed the previous ones, into the same registers), S ring stores.
+		template <int GP, int T, int NTHREADS, int HPF>
+		__device__ __forceinline__ void RunLayers(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
+		{
+			constexpr int S = Geo<GP, T>::S;
+			constexpr int P = Geo<GP, T>::P;
+			const WeightStager<NTHREADS> stager;
+			int f[S], cg[S];
+			bool live[S];
+#pragma unroll
+			for (int i = 0; i < S; i++) FrameOf<GP, T>(cx, i, f[i], cg[i], live[i]);
+
+			// ring history of the first HPF taps of the current layer: requested here for the first layer of the run, afterwards during
+			// the previous layer
+			u32x4 hist[HPF][S];
+			{
+				const int pos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
+#pragma unroll
+				for (int t = 0; t < HPF; t++)
+#pragma unroll
+					for (int i = 0; i < S; i++)
+						hist[t][i] = LoadHistory(cx, sd.ring_off, sd.ring_frames, sd.G, pos0, f[i], cg[i], sd.dilation * (sd.ksize - 1 - t), t < sd.ksize - 1 && cg[i] < sd.G);
+			}
+			do
+			{
+				Stage sdn = sd;
+				sdn.a_ops = 0;
+				sdn.type = -1;
+				if (s + 1 < cx.nstages) sdn = LoadStage(cx.stages, s + 1);
+				stager.Begin(cx, (s + 1) & 1, sdn);
+				const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane; // this lane's quad of operand m: wl[m * 64]
+				const u32x4* imgCur = cx.img + cur * cx.imgStride;
+				u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
+				const int K = sd.ksize, d = sd.dilation, G = sd.G;
+				const bool mask = Geo<GP, T>::PARTIAL || G < GP; // wave-uniform: some lanes have no channel group / no tile of their own
+				const int inPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
+				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id) : 0;
+
+				// dilated conv (WaveNet.h:139-290): tap k reads the frame d*(K-1-k) back; accumulation starts from zero, bias and mix-in
+				// arrive through the aux operand
+				f32x4 acc[S];
+#pragma unroll
+				for (int i = 0; i < S; i++) acc[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+				for (int k = 0; k < HPF; k++)
+				{
+					if (k < K - 1)
+					{
+						const u32x4 ah = wl[(2 * k) * 64], al = wl[(2 * k + 1) * 64];
+#pragma unroll
+						for (int i = 0; i < S; i++)
+						{
+							u32x4 b = TapOperand(imgCur, hist[k][i], f[i] - d * (K - 1 - k), cg[i]);
+							if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 }; // no garbage (NaN) into the MFMA
+							acc[i] = Mfma(ah, b, acc[i]);
+							acc[i] = Mfma(al, b, acc[i]);
+						}
+					}
+				}
+				// history of the NEXT layer's first HPF taps (the registers are free again)
+				{
+					const bool haveNext = (s + 1 < cx.nstages) && sdn.type == WN_ST_LAYER && sdn.Gp == GP;
+					const int nextPos0 = __builtin_amdgcn_readlane(cx.myPos, haveNext ? sdn.ring_id : 0);
+#pragma unroll
+					for (int t = 0; t < HPF; t++)
+#pragma unroll
+						for (int i = 0; i < S; i++)
+							hist[t][i] = LoadHistory(cx, sdn.ring_off, sdn.ring_frames, sdn.G, nextPos0, f[i], cg[i], sdn.dilation * (sdn.ksize - 1 - t),
+								haveNext && t < sdn.ksize - 1 && cg[i] < sdn.G);
+				}
+				for (int k = HPF; k < K - 1; k++)
+				{
+					const u32x4 ah = wl[(2 * k) * 64], al = wl[(2 * k + 1) * 64];
+					const int shift = d * (K - 1 - k);
+#pragma unroll
+					for (int i = 0; i < S; i++)
+					{
+						const int lo = cx.F0 + 16 * P * i - shift; // first frame of the set (wave-uniform)
+						u32x4 b = TapOperandInline(cx, imgCur, sd.ring_off, sd.ring_frames, G, inPos0, f[i], cg[i] < G ? cg[i] : 0, shift, lo, lo + 16 * P - 1);
+						if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 };
+						acc[i] = Mfma(ah, b, acc[i]);
+						acc[i] = Mfma(al, b, acc[i]);
+					}
+				}
+				{
+					// unshifted tap (the layer input itself, read back from the block image) and the aux operand:
+					// (mix-in, conv bias) * (cond, 1)   (:288-289, :471)
+					const u32x4 ah = wl[(2 * K - 2) * 64], al = wl[(2 * K - 1) * 64], xh = wl[(2 * K) * 64], xl = wl[(2 * K + 1) * 64];
+#pragma unroll
+					for (int i = 0; i < S; i++)
+					{
+						u32x4 b = imgCur[cg[i] * FRAMES + f[i]];
+						if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 };
+						const u32x4 ax = AuxOf(cx, f[i]);
+						acc[i] = Mfma(ah, b, acc[i]);
+						acc[i] = Mfma(al, b, acc[i]);
+						acc[i] = Mfma(xh, ax, acc[i]);
+						acc[i] = Mfma(xl, ax, acc[i]);
+					}
+				}
+
+				// activation (:473-480), head accumulate (:482), 1x1 + bias + residual (:486-491)
+				const bool needOutput = (sd.flags & WN_FLAG_NEED_OUTPUT) != 0;
+				u32x4 w1h, w1l, b1h, b1l;
+				if (needOutput)
+				{
+					w1h = wl[(2 * K + 2) * 64]; w1l = wl[(2 * K + 3) * 64]; b1h = wl[(2 * K + 4) * 64]; b1l = wl[(2 * K + 5) * 64];
+				}
+#pragma unroll
+				for (int i = 0; i < S; i++)
+				{
+					const f32x4 z = Activate(acc[i], sd.flags);
+					st.hd[i] += z;
+					u32x4 ys = u32x4{ 0, 0, 0, 0 };
+					if (needOutput)
+					{
+						const u32x4 zs = SplitQuad(z);
+						const u32x4 ax = AuxOf(cx, f[i]);
+						f32x4 y = st.xc[i];
+						y = Mfma(w1h, zs, y);
+						y = Mfma(w1l, zs, y);
+						y = Mfma(b1h, ax, y);
+						y = Mfma(b1l, ax, y);
+						st.xc[i] = y;
+						ys = SplitQuad(y);
+					}
+					// always one store per set (predicated through the offset): fixed VMEM count per layer
+					const bool pub = (sd.flags & WN_FLAG_PUBLISH) != 0;
+					Publish(cx, imgNext, ys, f[i], cg[i], pub && live[i] && cg[i] < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, pub ? cx.nSt : 0);
+				}
+				if (sd.flags & WN_FLAG_PUBLISH) cur ^= 1;
+				stager.template End<(HPF + 1) * S>(cx, (s + 1) & 1, sdn); // HPF*S history loads + S ring stores follow Begin() on every path
+				BlockBarrier<NTHREADS / 64>();
+				sd = sdn;
+				s++;
+			} while (s < cx.nstages && sd.type == WN_ST_LAYER && sd.Gp == GP);
+		}
+
+		// array 0 rechannel: x = w_re * cond (WaveNet.h:637 with InputSize == 1) -- the aux operand against (w_re, 0)
+		template <int GP, int T, int NTHREADS>
+		__device__ __forceinline__ void RechannelStage(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
+		{
+			constexpr int S = Geo<GP, T>::S;
+			const WeightStager<NTHREADS> stager;
+			Stage sdn = LoadStage(cx.stages, s + 1);
+			stager.Begin(cx, (s + 1) & 1, sdn);
+			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane;
+			u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
+			const int outPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id);
+			const u32x4 ah = wl[0], al = wl[64];
+#pragma unroll
+			for (int i = 0; i < S; i++)
+			{
+				int f, cg; bool live;
+				FrameOf<GP, T>(cx, i, f, cg, live);
+				const u32x4 ax = AuxOf(cx, f);
+				f32x4 x = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+				x = Mfma(ah, ax, x);
+				x = Mfma(al, ax, x);
+				st.xc[i] = x;
+				st.hd[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
+				Publish(cx, imgNext, SplitQuad(x), f, cg, live && cg < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
+			}
+			cur ^= 1;
+			stager.template End<0>(cx, (s + 1) & 1, sdn);
+			BlockBarrier<NTHREADS / 64>();
+			sd = sdn;
+			s++;
+		}
+
+		// array link: previous array's head rechannel (K = 1, WaveNet.h:658-660) and this array's rechannel (:637), tile by tile; the
+		// operand of tile t writes the rows of tile slot t % Pn of the new mode from the k-blocks of slot t % Po of the old one
+		template <int GPO, int GPN, int T, int NTHREADS>
+		__device__ __forceinline__ void LinkStage(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
+		{
+			constexpr int Po = 4 / GPO, Pn = 4 / GPN, NC = Po > Pn ? Po : Pn;
+			constexpr int So = Geo<GPO, T>::S, Sn = Geo<GPN, T>::S;
+			const WeightStager<NTHREADS> stager;
+			Stage sdn = LoadStage(cx.stages, s + 1);
+			stager.Begin(cx, (s + 1) & 1, sdn);
+			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane;
+			u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
+			const int outPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id);
+
+			u32x4 hs[So], xs[So];
+#pragma unroll
+			for (int i = 0; i < So; i++)
+			{
+				int f, cg; bool live;
+				FrameOf<GPO, T>(cx, i, f, cg, live);
+				hs[i] = SplitQuad(st.hd[i]);
+				xs[i] = SplitQuad(st.xc[i]);
+				if (Geo<GPO, T>::PARTIAL || GPO == 4)
+				{
+					const bool ok = live && cg < sd.G;
+					hs[i] = ok ? hs[i] : u32x4{ 0, 0, 0, 0 };
+					xs[i] = ok ? xs[i] : u32x4{ 0, 0, 0, 0 };
+				}
+			}
+			f32x4 hn[Sn], xn[Sn];
+			int fn[Sn], cgn[Sn];
+			bool liven[Sn];
+#pragma unroll
+			for (int i = 0; i < Sn; i++)
+			{
+				FrameOf<GPN, T>(cx, i, fn[i], cgn[i], liven[i]);
+				hn[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+				xn[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+				if (sd.flags & WN_FLAG_BIAS)
+				{
+					const u32x4 ax = AuxOf(cx, fn[i]);
+					hn[i] = Mfma(wl[(4 * NC) * 64], ax, hn[i]);
+					hn[i] = Mfma(wl[(4 * NC + 1) * 64], ax, hn[i]);
+				}
+			}
+#pragma unroll
+			for (int t = 0; t < T; t++)
+			{
+				const int u = t % NC, so = t / Po, sn = t / Pn;
+				hn[sn] = Mfma(wl[(4 * u) * 64], hs[so], hn[sn]);
+				hn[sn] = Mfma(wl[(4 * u + 1) * 64], hs[so], hn[sn]);
+				xn[sn] = Mfma(wl[(4 * u + 2) * 64], xs[so], xn[sn]);
+				xn[sn] = Mfma(wl[(4 * u + 3) * 64], xs[so], xn[sn]);
+			}
+#pragma unroll
+			for (int i = 0; i < Sn; i++)
+			{
+				st.hd[i] = hn[i];
+				st.xc[i] = xn[i];
+				Publish(cx, imgNext, SplitQuad(xn[i]), fn[i], cgn[i], liven[i] && cgn[i] < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
+			}
+			cur ^= 1;
+			stager.template End<0>(cx, (s + 1) & 1, sdn);
+			BlockBarrier<NTHREADS / 64>();
+			sd = sdn;
+			s++;
+		}
+
+		// last array's head: out = scale * (conv_K(head) + b)[0]  (WaveNet.h:658-660, :793-798); K = 1 (A1) straight from registers,
+		// K > 1 (A2: 16) through the LDS image / head ring like a layer conv.  One output row per tile slot.
+		template <int GP, int T, int NTHREADS>
+		__device__ __forceinline__ void HeadStage(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
+		{
+			constexpr int S = Geo<GP, T>::S;
+			constexpr int P = Geo<GP, T>::P;
+			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane;
+			const int K = sd.ksize, G = sd.G;
+			int f[S], cg[S];
+			bool live[S];
+			u32x4 hs[S];
+#pragma unroll
+			for (int i = 0; i < S; i++)
+			{
+				FrameOf<GP, T>(cx, i, f[i], cg[i], live[i]);
+				hs[i] = SplitQuad(st.hd[i]);
+				if (Geo<GP, T>::PARTIAL || GP == 4) hs[i] = (live[i] && cg[i] < G) ? hs[i] : u32x4{ 0, 0, 0, 0 };
+			}
+			f32x4 acc[S];
+#pragma unroll
+			for (int i = 0; i < S; i++) acc[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+			if (K > 1)
+			{
+				u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
+				const int pos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
+#pragma unroll
+				for (int i = 0; i < S; i++) Publish(cx, imgNext, hs[i], f[i], cg[i], live[i] && cg[i] < G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, pos0, cx.nSt);
+				cur ^= 1;
+				BlockBarrier<NTHREADS / 64>();
+				for (int k = 0; k < K - 1; k++)
+				{
+					const u32x4 ah = wl[(2 * k) * 64], al = wl[(2 * k + 1) * 64];
+					const int shift = sd.dilation * (K - 1 - k);
+#pragma unroll
+					for (int i = 0; i < S; i++)
+					{
+						const int lo = cx.F0 + 16 * P * i - shift;
+						u32x4 b = TapOperandInline(cx, imgNext, sd.ring_off, sd.ring_frames, G, pos0, f[i], cg[i] < G ? cg[i] : 0, shift, lo, lo + 16 * P - 1);
+						if (Geo<GP, T>::PARTIAL || GP == 4) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 };
+						acc[i] = Mfma(ah, b, acc[i]);
+						acc[i] = Mfma(al, b, acc[i]);
+					}
+				}
+			}
+			{
+				const u32x4 ah = wl[(2 * K - 2) * 64], al = wl[(2 * K - 1) * 64];
+#pragma unroll
+				for (int i = 0; i < S; i++)
+				{
+					acc[i] = Mfma(ah, hs[i], acc[i]);
+					acc[i] = Mfma(al, hs[i], acc[i]);
+					if (sd.flags & WN_FLAG_BIAS)
+					{
+						const u32x4 ax = AuxOf(cx, f[i]);
+						acc[i] = Mfma(wl[(2 * K) * 64], ax, acc[i]);
+						acc[i] = Mfma(wl[(2 * K + 1) * 64], ax, acc[i]);
+					}
+					if (live[i] && cg[i] == 0 && f[i] < cx.nSt) cx.out[cx.outBase + f[i]] = cx.headScale * acc[i].x;
+				}
+			}
+			s++;
+		}
+
+		// per model group of one (possibly fused) launch; passed by value in the kernarg segment
+		struct GroupArgs
+		{
+			const WnSplitStage* stages;
+			const void* wsplit;
+			const int* ringFrames;
+			u32x4* state;
+			const int* slots; // nullptr: contiguous, stream i uses slot0 + i / row0 + i
+			const int* rows;
+			int nstages, nrings, stateF4, wsplitQuads;
+			float headScale;
+			int numStreams, slot0, row0;
+			int maxG;
+			int firstBlock; // workgroups [firstBlock, next group's firstBlock) belong to this group
+		};
+
+		struct LaunchArgs
+		{
+			GroupArgs g[WN_FRAME_MAX_GROUPS];
+			int numGroups;
+		};
+
+		// grid = active streams / SPB; workgroup = SPB streams x WPS waves of T tiles (WPS * T * 16 >= n).
+		// dynamic LDS: auxq[SPB][FRAMES] quads | img[SPB][2][maxG][FRAMES] quads | wbuf[2][wstride] quads
+		template <int T, int SPB, int WPS>
+		__global__ void __launch_bounds__(64 * WPS * SPB) WaveNetSplitKernel(const LaunchArgs args, int maxGAll, int wstride, const float* __restrict__ in, float* __restrict__ out,
+			long inStride, long outStride, int n)
+		{
+			constexpr int NTHREADS = 64 * WPS * SPB;
+			int gi = 0;
+			for (int i = 1; i < args.numGroups; i++)
+				if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
+			const GroupArgs& ga = args.g[gi];
+			const int groupBlock = (int)blockIdx.x - ga.firstBlock;
+			extern __shared__ __attribute__((aligned(16))) char smem[];
+
+			const int lane = threadIdx.x & 63;
+			const int waveAll = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int sub = waveAll / WPS;  // stream within the workgroup
+			const int wave = waveAll % WPS; // part of the stream's block
+			u32x4* auxAll = reinterpret_cast<u32x4*>(smem);
+			u32x4* imgAll = auxAll + SPB * FRAMES;
+			const int imgStride = maxGAll * FRAMES;
+			u32x4* wbuf = imgAll + SPB * 2 * imgStride;
+
+			// a partial last workgroup: the surplus waves shadow the last stream (they must keep staging weights and meeting barriers)
+			int sidx = groupBlock * SPB + sub;
+			const bool liveStream = sidx < ga.numStreams;
+			if (!liveStream) sidx = ga.numStreams - 1;
+			const int slot = ga.slots ? ga.slots[sidx] : ga.slot0 + sidx;
+			const int row = ga.slots ? ga.rows[sidx] : ga.row0 + sidx;
+			u32x4* stt = ga.state + (size_t)slot * (size_t)ga.stateF4;
+			int* header = reinterpret_cast<int*>(stt);
+
+			Ctx cx;
+			cx.stages = ga.stages;
+			cx.nstages = ga.nstages;
+			cx.wbuf = wbuf;
+			cx.wstride = wstride;
+			cx.wrsrc = MakeRsrc(ga.wsplit, (unsigned)ga.wsplitQuads * 16u);
+			cx.img = imgAll + sub * 2 * imgStride;
+			cx.imgStride = imgStride;
+			cx.auxq = auxAll + sub * FRAMES;
+			cx.srsrc = MakeRsrc(stt, (unsigned)ga.stateF4 * 16u);
+			cx.myPos = header[lane]; // lane r holds the write cursor of ring r
+			cx.n = n;
+			cx.nSt = liveStream ? n : 0;
+			cx.F0 = wave * 16 * T;
+			cx.lane = lane;
+			cx.j = lane & 15;
+			cx.q = lane >> 4;
+			cx.waveAll = waveAll;
+			cx.out = out;
+			cx.outBase = (size_t)row * outStride;
+			cx.headScale = ga.headScale;
+
+			// input row (WaveNet.h:770 input -> condition) -> the aux operand of every frame: split quad of (cond, 1, 0, 0); cond = 0 beyond n
+			{
+				u32x4* auxq = auxAll + sub * FRAMES;
+				for (int i = wave * 64 + lane; i < FRAMES; i += WPS * 64)
+					auxq[i] = SplitQuad(f32x4{ (i < n) ? in[(size_t)row * inStride + i] : 0.0f, 1.0f, 0.0f, 0.0f });
+			}
+			Stage sd = LoadStage(cx.stages, 0);
+			for (int i = threadIdx.x; i < sd.a_ops * 64; i += NTHREADS) wbuf[i] = BufLoad(cx.wrsrc, (sd.a_off + i) * 16);
+			BlockBarrier<NTHREADS / 64>();
+
+			State<T> st;
+			int cur = 0;
+			int s = 0;
+			int mode = sd.Gp;
+			while (s < cx.nstages)
+			{
+				if (sd.type == WN_ST_LAYER)
+				{
+					// K = 3 models: both shifted taps' history is requested a layer ahead; larger kernels (A2: 6 / 15): the first 2 as well,
+					// the rest in line
+					if (mode == 4) RunLayers<4, T, NTHREADS, 2>(cx, s, sd, cur, st);
+					else if (mode == 2) RunLayers<2, T, NTHREADS, 2>(cx, s, sd, cur, st);
+					else RunLayers<1, T, NTHREADS, 2>(cx, s, sd, cur, st);
+				}
+				else if (sd.type == WN_ST_RECHANNEL_COND)
+				{
+					if (mode == 4) RechannelStage<4, T, NTHREADS>(cx, s, sd, cur, st);
+					else if (mode == 2) RechannelStage<2, T, NTHREADS>(cx, s, sd, cur, st);
+					else RechannelStage<1, T, NTHREADS>(cx, s, sd, cur, st);
+				}
+				else if (sd.type == WN_ST_ARRAY_LINK)
+				{
+					const int next = sd.ksize;
+					const int key = mode * 8 + next;
+					switch (key)
+					{
+					case 4 * 8 + 4: LinkStage<4, 4, T, NTHREADS>(cx, s, sd, cur, st); break;
+					case 4 * 8 + 2: LinkStage<4, 2, T, NTHREADS>(cx, s, sd, cur, st); break;
+					case 4 * 8 + 1: LinkStage<4, 1, T, NTHREADS>(cx, s, sd, cur, st); break;
+					case 2 * 8 + 4: LinkStage<2, 4, T, NTHREADS>(cx, s, sd, cur, st); break;
+					case 2 * 8 + 2: LinkStage<2, 2, T, NTHREADS>(cx, s, sd, cur, st); break;
+					case 2 * 8 + 1: LinkStage<2, 1, T, NTHREADS>(cx, s, sd, cur, st); break;
+					case 1 * 8 + 4: LinkStage<1, 4, T, NTHREADS>(cx, s, sd, cur, st); break;
+					case 1 * 8 + 2: LinkStage<1, 2, T, NTHREADS>(cx, s, sd, cur, st); break;
+					default: LinkStage<1, 1, T, NTHREADS>(cx, s, sd, cur, st); break;
+					}
+					mode = next;
+				}
+				else
+				{
+					if (mode == 4) HeadStage<4, T, NTHREADS>(cx, s, sd, cur, st);
+					else if (mode == 2) HeadStage<2, T, NTHREADS>(cx, s, sd, cur, st);
+					else HeadStage<1, T, NTHREADS>(cx, s, sd, cur, st);
+				}
+			}
+
+			// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
+			if (wave == 0 && liveStream && lane < ga.nrings)
+			{
+				const int R = ga.ringFrames[lane];
+				int p = cx.myPos + n;
+				if (p >= R) p -= R;
+				header[lane] = p;
+			}
+		}
+
+		template <int T, int SPB, int WPS>
+		static hipError_t Launch(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream)
+		{
+			LaunchArgs args = {};
+			args.numGroups = numGroups;
+			int blocks = 0, maxG = 1, maxOps = 16;
+			for (int i = 0; i < numGroups; i++)
+			{
+				const WnFrameGroup& g = groups[i];
+				const WnModelDev& m = *g.model;
+				GroupArgs& a = args.g[i];
+				a.stages = m.sstages; a.wsplit = m.wsplit; a.ringFrames = m.ring_frames;
+				a.state = reinterpret_cast<u32x4*>(g.state); a.slots = g.slots; a.rows = g.rows;
+				a.nstages = m.nstages; a.nrings = m.nrings; a.stateF4 = m.state_f4; a.wsplitQuads = m.wsplit_quads;
+				a.headScale = m.head_scale;
+				a.numStreams = g.numStreams; a.slot0 = g.slot0; a.row0 = g.row0;
+				a.maxG = m.max_G;
+				a.firstBlock = blocks;
+				blocks += (g.numStreams + SPB - 1) / SPB;
+				maxG = std::max(maxG, m.max_G);
+				maxOps = std::max(maxOps, m.max_split_ops);
+			}
+			const int wstride = maxOps * 64; // quads per LDS weight buffer (the LDS-DMA staging always writes its fixed 16 KB part)
+			const size_t lds = (size_t)SPB * FRAMES * 16 + (size_t)SPB * 2 * maxG * FRAMES * 16 + (size_t)2 * wstride * 16;
+			if (lds > 160 * 1024) return hipErrorInvalidValue;
+			auto kernel = WaveNetSplitKernel<T, SPB, WPS>;
+			if (lds > 64 * 1024)
+			{
+				static size_t granted = 0; // per instantiation
+				if (lds > granted)
+				{
+					const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+					if (e != hipSuccess) return e;
+					granted = lds;
+				}
+			}
+			hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WPS * SPB), lds, stream, args, maxG, wstride, in, out, inStride, outStride, n);
+			return hipGetLastError();
+		}
+	}
+
+	hipError_t LaunchWaveNetSplitFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream)
+	{
+		if (n <= 0 || numGroups <= 0) return hipSuccess;
+		if (n > WN_MAX_FRAMES || numGroups > WN_FRAME_MAX_GROUPS) return hipErrorInvalidValue;
+		int total = 0;
+		for (int i = 0; i < numGroups; i++)
+		{
+			if (groups[i].numStreams <= 0) return hipErrorInvalidValue;
+			total += groups[i].numStreams;
+		}
+		static const int tEnv = getenv("NA_SP_T") ? atoi(getenv("NA_SP_T")) : 2;     // tuning knob: tiles per wave (2, 4)
+		static const int spbEnv = getenv("NA_SP_SPB") ? atoi(getenv("NA_SP_SPB")) : 0; // tuning knob: streams per workgroup (1, 2)
+		const int spb = spbEnv > 0 ? spbEnv : (total >= 512 ? 2 : 1);
+		const int tiles = (n + 15) / 16;
+#define NA_SP_LAUNCH(TT, SS, WW) return sp::Launch<TT, SS, WW>(groups, numGroups, in, out, inStride, outStride, n, stream)
+		if (tEnv == 4)
+		{
+			if (tiles > 4) { if (spb >= 2) NA_SP_LAUNCH(4, 2, 2); NA_SP_LAUNCH(4, 1, 2); }
+			if (spb >= 2) NA_SP_LAUNCH(4, 2, 1);
+			NA_SP_LAUNCH(4, 1, 1);
+		}
+		if (tiles > 4) { if (spb >= 2) NA_SP_LAUNCH(2, 2, 4); NA_SP_LAUNCH(2, 1, 4); }
+		if (tiles > 2) { if (spb >= 2) NA_SP_LAUNCH(2, 2, 2); NA_SP_LAUNCH(2, 1, 2); }
+		if (spb >= 2) NA_SP_LAUNCH(2, 2, 1);
+		NA_SP_LAUNCH(2, 1, 1);
+#undef NA_SP_LAUNCH
+	}
+}
