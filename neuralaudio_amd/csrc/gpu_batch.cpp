@@ -263,6 +263,7 @@ namespace na
 				dev.wsplit_quads = (int)(plan.wsplit.size() / 8);
 				dev.max_split_ops = plan.maxSplitOps;
 				dev.max_G = plan.maxG;
+				dev.split_fast_T = plan.splitFastT;
 			}
 
 			// ChannelHistoryBuffer::AllocBuffer zero-fills (WaveNet.h:38-40)

@@ -158,5 +158,6 @@ namespace na
 		int wsplit_quads;
 		int max_split_ops;    // largest per-stage operand count (sizes the LDS weight buffers)
 		int max_G;            // largest channel-group count of any ring / stage (sizes the LDS block image)
+		int split_fast_T;     // fewest tiles per wave the fast instantiation can run this model with (2 or 4); 0: needs the generic one
 	};
 }

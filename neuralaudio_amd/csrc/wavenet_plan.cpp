@@ -509,6 +509,14 @@ namespace na
 					}
 				}
 				for (const WnSplitStage& st : plan.sstages) plan.maxSplitOps = std::max(plan.maxSplitOps, st.a_ops);
+				// fast instantiation of the kernel: K == 3 everywhere, every array fills its lane mode (G == Gp), 1x1 heads, weight blocks
+				// within the fixed 16 KB staging part
+				plan.splitFastT = 2;
+				for (const WnSplitStage& st : plan.sstages)
+				{
+					if (st.a_ops > 16 || st.G != st.Gp || st.type == WN_ST_HEAD_CONV_OUT || (st.type == WN_ST_LAYER && st.ksize != 3)) plan.splitFastT = 0;
+					if (plan.splitFastT && (st.Gp == 1 || (st.type == WN_ST_ARRAY_LINK && st.ksize == 1))) plan.splitFastT = 4; // 4 tiles share an MFMA
+				}
 			}
 
 			void Build()

@@ -30,6 +30,7 @@ namespace na
 		std::vector<uint16_t> wsplit;      // its A-operand image: f16 bit patterns, 512 per MFMA operand
 		int maxSplitOps = 0;
 		int maxG = 1;
+		int splitFastT = 0;                // see WnModelDev::split_fast_T
 		int stateF4 = 0;            // per-stream state in float4 units
 		int maxA4Floats = 0;        // largest per-stage A-operand block of the frame kernel (floats)
 		int maxStageF4 = 0;         // largest per-stage weight block (float4), sizes the LDS staging buffers

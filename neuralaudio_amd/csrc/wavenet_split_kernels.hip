@@ -91,11 +91,16 @@ namespace na
 		{
 			const f16x2 h01 = __builtin_convertvector(f32x2{ v.x, v.y }, f16x2);
 			const f16x2 h23 = __builtin_convertvector(f32x2{ v.z, v.w }, f16x2);
-			// v - f32(h), exact in f32; written as fma(f32(h), -1, v) so that the f16 -> f32 conversion folds into v_fma_mix_f32
-			const float r0 = __builtin_fmaf((float)h01.x, -1.0f, v.x), r1 = __builtin_fmaf((float)h01.y, -1.0f, v.y), r2 = __builtin_fmaf((float)h23.x, -1.0f, v.z), r3 = __builtin_fmaf((float)h23.y, -1.0f, v.w);
 			u32x4 q;
 			q.x = __builtin_bit_cast(unsigned, h01);
 			q.y = __builtin_bit_cast(unsigned, h23);
+			// v - f32(h), exact in f32, one instruction each: v_fma_mix_f32 reads the f16 half directly (the compiler emits
+			// v_cvt_f32_f16 + v_sub_f32 for the plain expression)
+			float r0, r1, r2, r3;
+			asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(q.x), "v"(v.x));
+			asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(q.x), "v"(v.y));
+			asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(q.y), "v"(v.z));
+			asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(q.y), "v"(v.w));
 			q.z = PackHalf2(r0, r1);
 			q.w = PackHalf2(r2, r3);
 			return q;
@@ -165,6 +170,7 @@ namespace na
 			__amdgpu_buffer_rsrc_t wrsrc; // split weight image (staging source)
 			u32x4* img;                   // this stream's [2][maxG][FRAMES] block images (quads)
 			int imgStride;                // quads per image = maxG * FRAMES
+			const u32x4* idop;            // identity A operand [64 lanes] (head accumulation rides on the matrix pipe)
 			const u32x4* auxq;            // this stream's aux operands in LDS: split quad of (cond, 1, 0, 0) per frame [FRAMES]
 			__amdgpu_buffer_rsrc_t srsrc; // this stream's state
 			int myPos;                    // lane r: write cursor of ring r
@@ -231,7 +237,7 @@ namespace na
 		// Stages the NEXT stage's A-operand block into the other LDS weight buffer with LDS-DMA loads (buffer_load_dwordx4 ... lds: lane l's
 		// 16 bytes land at ldsBase + 16 l, no VGPRs, no ds_write), issued at the start of a stage and awaited just before its closing
 		// barrier.  WCOPY loads per thread cover 16 KB per workgroup of 512; larger blocks (K = 15 layers) use the tail loop.
-		template <int NTHREADS>
+		template <int NTHREADS, bool GEN>
 		struct WeightStager
 		{
 			static constexpr int WCOPY = (1024 + NTHREADS - 1) / NTHREADS; // quads per thread in the fixed part (16 KB)
@@ -255,7 +261,8 @@ namespace na
 			{
 				const int nextQ = sdn.a_ops * 64;
 				u32x4* dst = const_cast<u32x4*>(cx.wbuf) + nextBuf * cx.wstride;
-				for (int i = (int)threadIdx.x + WCOPY * NTHREADS; i < nextQ; i += NTHREADS) dst[i] = BufLoad(cx.wrsrc, (sdn.a_off + i) * 16);
+				if constexpr (GEN) // blocks beyond the fixed 16 KB part (K = 15 layers); the fast instantiation is only used when there are none
+					for (int i = (int)threadIdx.x + WCOPY * NTHREADS; i < nextQ; i += NTHREADS) dst[i] = BufLoad(cx.wrsrc, (sdn.a_off + i) * 16);
 				// the DMA data must be in LDS before the closing barrier lets other waves read it (the workgroup fence only covers lgkmcnt)
 				// gfx9 s_waitcnt: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at "don't wait"
 				__builtin_amdgcn_s_waitcnt((LATER & 15) | ((LATER >> 4) << 14) | (7 << 4) | (15 << 8));
@@ -286,12 +293,12 @@ namespace na
 		// A run of consecutive WaveNet layer stages (WaveNetLayerT::Process, WaveNet.h:462-494) of one lane mode.
 		// VMEM operations per layer, in this order on every path: WCOPY weight DMA loads, HPF*S history loads (for the NEXT layer,
 		// issued once this layer's taps have consumed the previous ones, into the same registers), S ring stores.
-		template <int GP, int T, int NTHREADS, int HPF>
+		template <int GP, int T, int NTHREADS, int HPF, bool GEN>
 		__device__ __forceinline__ void RunLayers(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
 		{
 			constexpr int S = Geo<GP, T>::S;
 			constexpr int P = Geo<GP, T>::P;
-			const WeightStager<NTHREADS> stager;
+			const WeightStager<NTHREADS, GEN> stager;
 			int f[S], cg[S];
 			bool live[S];
 #pragma unroll
@@ -318,8 +325,9 @@ namespace na
 				const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane; // this lane's quad of operand m: wl[m * 64]
 				const u32x4* imgCur = cx.img + cur * cx.imgStride;
 				u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
-				const int K = sd.ksize, d = sd.dilation, G = sd.G;
-				const bool mask = Geo<GP, T>::PARTIAL || G < GP; // wave-uniform: some lanes have no channel group / no tile of their own
+				// the fast instantiation (GEN == false) is only launched for models whose layers all have K == 3 and fill their lane mode
+				const int K = GEN ? sd.ksize : 3, d = sd.dilation, G = GEN ? sd.G : GP;
+				const bool mask = GEN && (Geo<GP, T>::PARTIAL || G < GP); // wave-uniform: some lanes have no channel group / no tile of their own
 				const int inPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
 				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id) : 0;
 
@@ -331,7 +339,7 @@ namespace na
 #pragma unroll
 				for (int k = 0; k < HPF; k++)
 				{
-					if (k < K - 1)
+					if (!GEN || k < K - 1)
 					{
 						const u32x4 ah = wl[(2 * k) * 64], al = wl[(2 * k + 1) * 64];
 #pragma unroll
@@ -355,6 +363,7 @@ namespace na
 							hist[t][i] = LoadHistory(cx, sdn.ring_off, sdn.ring_frames, sdn.G, nextPos0, f[i], cg[i], sdn.dilation * (sdn.ksize - 1 - t),
 								haveNext && t < sdn.ksize - 1 && cg[i] < sdn.G);
 				}
+				if constexpr (GEN)
 				for (int k = HPF; k < K - 1; k++)
 				{
 					const u32x4 ah = wl[(2 * k) * 64], al = wl[(2 * k + 1) * 64];
@@ -386,8 +395,27 @@ namespace na
 					}
 				}
 
-				// activation (:473-480), head accumulate (:482), 1x1 + bias + residual (:486-491)
+				// activation (:473-480), one wave-uniform branch per layer
+				f32x4 z[S];
+				if (sd.flags & WN_FLAG_LEAKY)
+				{
+#pragma unroll
+					for (int i = 0; i < S; i++) z[i] = f32x4{ LeakyReLU(acc[i].x), LeakyReLU(acc[i].y), LeakyReLU(acc[i].z), LeakyReLU(acc[i].w) };
+				}
+				else if (sd.flags & WN_FLAG_STD_TANH)
+				{
+#pragma unroll
+					for (int i = 0; i < S; i++) z[i] = f32x4{ StdTanh(acc[i].x), StdTanh(acc[i].y), StdTanh(acc[i].z), StdTanh(acc[i].w) };
+				}
+				else
+				{
+#pragma unroll
+					for (int i = 0; i < S; i++) z[i] = f32x4{ FastTanh(acc[i].x), FastTanh(acc[i].y), FastTanh(acc[i].z), FastTanh(acc[i].w) };
+				}
+				// head accumulate (:482) on the matrix pipe: head += I * (zh + zl); 1x1 + bias + residual (:486-491)
 				const bool needOutput = (sd.flags & WN_FLAG_NEED_OUTPUT) != 0;
+				const bool pub = (sd.flags & WN_FLAG_PUBLISH) != 0;
+				const u32x4 idop = cx.idop[cx.lane];
 				u32x4 w1h, w1l, b1h, b1l;
 				if (needOutput)
 				{
@@ -396,12 +424,11 @@ namespace na
 #pragma unroll
 				for (int i = 0; i < S; i++)
 				{
-					const f32x4 z = Activate(acc[i], sd.flags);
-					st.hd[i] += z;
-					u32x4 ys = u32x4{ 0, 0, 0, 0 };
+					const u32x4 zs = SplitQuad(z[i]);
+					st.hd[i] = Mfma(idop, zs, st.hd[i]);
+					u32x4 ys = zs;
 					if (needOutput)
 					{
-						const u32x4 zs = SplitQuad(z);
 						const u32x4 ax = AuxOf(cx, f[i]);
 						f32x4 y = st.xc[i];
 						y = Mfma(w1h, zs, y);
@@ -412,8 +439,7 @@ namespace na
 						ys = SplitQuad(y);
 					}
 					// always one store per set (predicated through the offset): fixed VMEM count per layer
-					const bool pub = (sd.flags & WN_FLAG_PUBLISH) != 0;
-					Publish(cx, imgNext, ys, f[i], cg[i], pub && live[i] && cg[i] < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, pub ? cx.nSt : 0);
+					Publish(cx, imgNext, ys, f[i], cg[i], pub && (!GEN || (live[i] && cg[i] < sd.out_G)), sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, pub ? cx.nSt : 0);
 				}
 				if (sd.flags & WN_FLAG_PUBLISH) cur ^= 1;
 				stager.template End<(HPF + 1) * S>(cx, (s + 1) & 1, sdn); // HPF*S history loads + S ring stores follow Begin() on every path
@@ -424,11 +450,11 @@ namespace na
 		}
 
 		// array 0 rechannel: x = w_re * cond (WaveNet.h:637 with InputSize == 1) -- the aux operand against (w_re, 0)
-		template <int GP, int T, int NTHREADS>
+		template <int GP, int T, int NTHREADS, bool GEN>
 		__device__ __forceinline__ void RechannelStage(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
 		{
 			constexpr int S = Geo<GP, T>::S;
-			const WeightStager<NTHREADS> stager;
+			const WeightStager<NTHREADS, GEN> stager;
 			Stage sdn = LoadStage(cx.stages, s + 1);
 			stager.Begin(cx, (s + 1) & 1, sdn);
 			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane;
@@ -457,12 +483,12 @@ namespace na
 
 		// array link: previous array's head rechannel (K = 1, WaveNet.h:658-660) and this array's rechannel (:637), tile by tile; the
 		// operand of tile t writes the rows of tile slot t % Pn of the new mode from the k-blocks of slot t % Po of the old one
-		template <int GPO, int GPN, int T, int NTHREADS>
+		template <int GPO, int GPN, int T, int NTHREADS, bool GEN>
 		__device__ __forceinline__ void LinkStage(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
 		{
 			constexpr int Po = 4 / GPO, Pn = 4 / GPN, NC = Po > Pn ? Po : Pn;
 			constexpr int So = Geo<GPO, T>::S, Sn = Geo<GPN, T>::S;
-			const WeightStager<NTHREADS> stager;
+			const WeightStager<NTHREADS, GEN> stager;
 			Stage sdn = LoadStage(cx.stages, s + 1);
 			stager.Begin(cx, (s + 1) & 1, sdn);
 			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane;
@@ -610,8 +636,8 @@ namespace na
 		};
 
 		// grid = active streams / SPB; workgroup = SPB streams x WPS waves of T tiles (WPS * T * 16 >= n).
-		// dynamic LDS: auxq[SPB][FRAMES] quads | img[SPB][2][maxG][FRAMES] quads | wbuf[2][wstride] quads
-		template <int T, int SPB, int WPS>
+		// dynamic LDS: auxq[SPB][FRAMES] quads | img[SPB][2][maxG][FRAMES] quads | wbuf[2][wstride] quads | idop[64] quads
+		template <int T, int SPB, int WPS, bool GEN>
 		__global__ void __launch_bounds__(64 * WPS * SPB) WaveNetSplitKernel(const LaunchArgs args, int maxGAll, int wstride, const float* __restrict__ in, float* __restrict__ out,
 			long inStride, long outStride, int n)
 		{
@@ -650,6 +676,7 @@ namespace na
 			cx.img = imgAll + sub * 2 * imgStride;
 			cx.imgStride = imgStride;
 			cx.auxq = auxAll + sub * FRAMES;
+			cx.idop = wbuf + 2 * wstride;
 			cx.srsrc = MakeRsrc(stt, (unsigned)ga.stateF4 * 16u);
 			cx.myPos = header[lane]; // lane r holds the write cursor of ring r
 			cx.n = n;
@@ -669,6 +696,15 @@ namespace na
 				for (int i = wave * 64 + lane; i < FRAMES; i += WPS * 64)
 					auxq[i] = SplitQuad(f32x4{ (i < n) ? in[(size_t)row * inStride + i] : 0.0f, 1.0f, 0.0f, 0.0f });
 			}
+			// identity A operand: row i x k-block q = i / 4: 1.0 against the h AND the l half of channel i % 4
+			if (threadIdx.x < 64)
+			{
+				const int i = lane & 15, q = lane >> 4;
+				const unsigned one = 0x3c00u; // f16 1.0
+				const unsigned lo = (q == (i >> 2)) ? (((i & 3) == 0) ? one : ((i & 3) == 1) ? (one << 16) : 0u) : 0u;
+				const unsigned hi = (q == (i >> 2)) ? (((i & 3) == 2) ? one : ((i & 3) == 3) ? (one << 16) : 0u) : 0u;
+				(wbuf + 2 * wstride)[lane] = u32x4{ lo, hi, lo, hi };
+			}
 			Stage sd = LoadStage(cx.stages, 0);
 			for (int i = threadIdx.x; i < sd.a_ops * 64; i += NTHREADS) wbuf[i] = BufLoad(cx.wrsrc, (sd.a_off + i) * 16);
 			BlockBarrier<NTHREADS / 64>();
@@ -683,15 +719,15 @@ namespace na
 				{
 					// K = 3 models: both shifted taps' history is requested a layer ahead; larger kernels (A2: 6 / 15): the first 2 as well,
 					// the rest in line
-					if (mode == 4) RunLayers<4, T, NTHREADS, 2>(cx, s, sd, cur, st);
-					else if (mode == 2) RunLayers<2, T, NTHREADS, 2>(cx, s, sd, cur, st);
-					else RunLayers<1, T, NTHREADS, 2>(cx, s, sd, cur, st);
+					if (mode == 4) RunLayers<4, T, NTHREADS, 2, GEN>(cx, s, sd, cur, st);
+					else if (mode == 2) RunLayers<2, T, NTHREADS, 2, GEN>(cx, s, sd, cur, st);
+					else RunLayers<1, T, NTHREADS, 2, GEN>(cx, s, sd, cur, st);
 				}
 				else if (sd.type == WN_ST_RECHANNEL_COND)
 				{
-					if (mode == 4) RechannelStage<4, T, NTHREADS>(cx, s, sd, cur, st);
-					else if (mode == 2) RechannelStage<2, T, NTHREADS>(cx, s, sd, cur, st);
-					else RechannelStage<1, T, NTHREADS>(cx, s, sd, cur, st);
+					if (mode == 4) RechannelStage<4, T, NTHREADS, GEN>(cx, s, sd, cur, st);
+					else if (mode == 2) RechannelStage<2, T, NTHREADS, GEN>(cx, s, sd, cur, st);
+					else RechannelStage<1, T, NTHREADS, GEN>(cx, s, sd, cur, st);
 				}
 				else if (sd.type == WN_ST_ARRAY_LINK)
 				{
@@ -699,15 +735,15 @@ namespace na
 					const int key = mode * 8 + next;
 					switch (key)
 					{
-					case 4 * 8 + 4: LinkStage<4, 4, T, NTHREADS>(cx, s, sd, cur, st); break;
-					case 4 * 8 + 2: LinkStage<4, 2, T, NTHREADS>(cx, s, sd, cur, st); break;
-					case 4 * 8 + 1: LinkStage<4, 1, T, NTHREADS>(cx, s, sd, cur, st); break;
-					case 2 * 8 + 4: LinkStage<2, 4, T, NTHREADS>(cx, s, sd, cur, st); break;
-					case 2 * 8 + 2: LinkStage<2, 2, T, NTHREADS>(cx, s, sd, cur, st); break;
-					case 2 * 8 + 1: LinkStage<2, 1, T, NTHREADS>(cx, s, sd, cur, st); break;
-					case 1 * 8 + 4: LinkStage<1, 4, T, NTHREADS>(cx, s, sd, cur, st); break;
-					case 1 * 8 + 2: LinkStage<1, 2, T, NTHREADS>(cx, s, sd, cur, st); break;
-					default: LinkStage<1, 1, T, NTHREADS>(cx, s, sd, cur, st); break;
+					case 4 * 8 + 4: LinkStage<4, 4, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
+					case 4 * 8 + 2: LinkStage<4, 2, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
+					case 4 * 8 + 1: LinkStage<4, 1, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
+					case 2 * 8 + 4: LinkStage<2, 4, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
+					case 2 * 8 + 2: LinkStage<2, 2, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
+					case 2 * 8 + 1: LinkStage<2, 1, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
+					case 1 * 8 + 4: LinkStage<1, 4, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
+					case 1 * 8 + 2: LinkStage<1, 2, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
+					default: LinkStage<1, 1, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
 					}
 					mode = next;
 				}
@@ -729,7 +765,7 @@ namespace na
 			}
 		}
 
-		template <int T, int SPB, int WPS>
+		template <int T, int SPB, int WPS, bool GEN>
 		static hipError_t Launch(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream)
 		{
 			LaunchArgs args = {};
@@ -752,9 +788,9 @@ namespace na
 				maxOps = std::max(maxOps, m.max_split_ops);
 			}
 			const int wstride = maxOps * 64; // quads per LDS weight buffer (the LDS-DMA staging always writes its fixed 16 KB part)
-			const size_t lds = (size_t)SPB * FRAMES * 16 + (size_t)SPB * 2 * maxG * FRAMES * 16 + (size_t)2 * wstride * 16;
+			const size_t lds = (size_t)SPB * FRAMES * 16 + (size_t)SPB * 2 * maxG * FRAMES * 16 + (size_t)2 * wstride * 16 + 1024;
 			if (lds > 160 * 1024) return hipErrorInvalidValue;
-			auto kernel = WaveNetSplitKernel<T, SPB, WPS>;
+			auto kernel = WaveNetSplitKernel<T, SPB, WPS, GEN>;
 			if (lds > 64 * 1024)
 			{
 				static size_t granted = 0; // per instantiation
@@ -781,12 +817,23 @@ namespace na
 			if (groups[i].numStreams <= 0) return hipErrorInvalidValue;
 			total += groups[i].numStreams;
 		}
-		static const int tEnv = getenv("NA_SP_T") ? atoi(getenv("NA_SP_T")) : 2;     // tuning knob: tiles per wave (2, 4)
+		static const int tEnv = getenv("NA_SP_T") ? atoi(getenv("NA_SP_T")) : 0;       // tuning knob: tiles per wave (2, 4)
 		static const int spbEnv = getenv("NA_SP_SPB") ? atoi(getenv("NA_SP_SPB")) : 0; // tuning knob: streams per workgroup (1, 2)
+		static const bool genEnv = getenv("NA_SP_GEN") != nullptr;                      // tuning knob: always the generic instantiation
 		const int spb = spbEnv > 0 ? spbEnv : (total >= 512 ? 2 : 1);
 		const int tiles = (n + 15) / 16;
-#define NA_SP_LAUNCH(TT, SS, WW) return sp::Launch<TT, SS, WW>(groups, numGroups, in, out, inStride, outStride, n, stream)
-		if (tEnv == 4)
+		// fast instantiation: every layer of every group has K == 3 and fills its lane mode (the official A1 architectures except Lite);
+		// split_fast_T = fewest tiles per wave it can run with (4 when an array has <= 4 channels), 0 = needs the generic one
+		bool gen = genEnv;
+		int t = (tEnv == 2 || tEnv == 4) ? tEnv : 4;
+		for (int i = 0; i < numGroups; i++)
+		{
+			if (groups[i].model->split_fast_T == 0) gen = true;
+			else t = std::max(t, groups[i].model->split_fast_T);
+		}
+#define NA_SP_LAUNCH(TT, SS, WW) do { return gen ? sp::Launch<TT, SS, WW, true>(groups, numGroups, in, out, inStride, outStride, n, stream) \
+	: sp::Launch<TT, SS, WW, false>(groups, numGroups, in, out, inStride, outStride, n, stream); } while (0)
+		if (t == 4)
 		{
 			if (tiles > 4) { if (spb >= 2) NA_SP_LAUNCH(4, 2, 2); NA_SP_LAUNCH(4, 1, 2); }
 			if (spb >= 2) NA_SP_LAUNCH(4, 2, 1);
