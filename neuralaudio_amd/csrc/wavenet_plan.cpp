@@ -354,10 +354,21 @@ namespace na
 				for (int p = 0; p < 4 / Gp; p++) FillSplitBlock(opHi, opHi + 1, 4 * Gp * p, Gp * p, cout, cin, w);
 			}
 
-			// "aux" pseudo channel group (cond, 1, 0, 0) riding in the cg = 0 k-block of each tile slot: weights (wCond[o], wOne[o])
-			void FillSplitAux(int opHi, int Gp, int cout, int condOff, int oneOff)
+			// "aux" operand: bias and input mix-in ride in the MFMA too.  The kernel's aux B operand of a frame is the 8 halfs
+			// [cond_h, 1, cond_l, 1, cond_h, 0, 0, 0]; against the row [wc_h, w1_h, wc_h, w1_l, wc_l, 0, 0, 0] it contributes
+			// wc * cond + w1 to that row (same three-product split, ONE operand).  It sits in the cg = 0 k-block of each tile slot.
+			void FillSplitAux(int op, int Gp, int cout, int condOff, int oneOff)
 			{
-				FillSplitMerged(opHi, Gp, cout, 2, [&](int o, int c) { return c == 0 ? (condOff >= 0 ? W(condOff + o) : 0.0f) : (oneOff >= 0 ? W(oneOff + o) : 0.0f); });
+				for (int p = 0; p < 4 / Gp; p++)
+					for (int o = 0; o < cout; o++)
+					{
+						const float wc = condOff >= 0 ? W(condOff + o) : 0.0f, w1 = oneOff >= 0 ? W(oneOff + o) : 0.0f;
+						const uint16_t wch = FloatToHalfBits(wc), wcl = FloatToHalfBits(wc - HalfBitsToFloat(wch));
+						const uint16_t w1h = FloatToHalfBits(w1), w1l = FloatToHalfBits(w1 - HalfBitsToFloat(w1h));
+						const size_t lane = (size_t)(Gp * p) * 16 + (size_t)(4 * Gp * p + o);
+						uint16_t* e = &plan.wsplit[(size_t)op * 512 + lane * 8];
+						e[0] = wch; e[1] = w1h; e[2] = wch; e[3] = w1l; e[4] = wcl;
+					}
 			}
 
 			static WnSplitStage EmptySplit(int type)
@@ -403,7 +414,7 @@ namespace na
 						// x = w_re * cond (WaveNet.h:637, input_size == 1): the aux operand with weights (w_re, 0)
 						WnSplitStage st = EmptySplit(WN_ST_RECHANNEL_COND);
 						st.G = G; st.Gp = Gp;
-						st.a_ops = 2;
+						st.a_ops = 1;
 						st.a_off = NewSplitOps(st.a_ops) * 64;
 						FillSplitAux(st.a_off / 64, Gp, C, rechOff, -1);
 						SplitOutRing(st, layerRing[a][0]);
@@ -419,7 +430,7 @@ namespace na
 						const int GpO = LaneMode(prev.channels), Po = 4 / GpO, Pn = 4 / Gp, NC = std::max(Po, Pn);
 						WnSplitStage st = EmptySplit(WN_ST_ARRAY_LINK);
 						st.G = CeilDiv(prev.channels, 4); st.Gp = GpO; st.ksize = Gp;
-						st.a_ops = 4 * NC + 2;
+						st.a_ops = 4 * NC + 1;
 						st.a_off = NewSplitOps(st.a_ops) * 64;
 						const int op0 = st.a_off / 64;
 						for (int u = 0; u < NC; u++)
@@ -453,8 +464,8 @@ namespace na
 
 						WnSplitStage st = EmptySplit(WN_ST_LAYER);
 						st.G = G; st.Gp = Gp; st.ksize = K; st.dilation = cfg.dilations[l];
-						// operands: taps 0..K-1 (hi, lo each; tap K-1 is the unshifted one), aux = (mix-in, conv bias), then 1x1 and its bias
-						st.a_ops = 2 * K + 2 + (needOutput ? 4 : 0);
+						// operands: taps 0..K-1 (hi, lo each; tap K-1 is the unshifted one), aux = (mix-in, conv bias), then 1x1 (hi, lo) and its bias
+						st.a_ops = 2 * K + 1 + (needOutput ? 3 : 0);
 						st.a_off = NewSplitOps(st.a_ops) * 64;
 						const int op0 = st.a_off / 64;
 						for (int k = 0; k < K; k++)
@@ -462,8 +473,8 @@ namespace na
 						FillSplitAux(op0 + 2 * K, Gp, C, wmix, bconv);
 						if (needOutput)
 						{
-							FillSplitMerged(op0 + 2 * K + 2, Gp, C, C, [&](int o, int c) { return W(w1 + o * C + c); });
-							FillSplitAux(op0 + 2 * K + 4, Gp, C, -1, b1);
+							FillSplitMerged(op0 + 2 * K + 1, Gp, C, C, [&](int o, int c) { return W(w1 + o * C + c); });
+							FillSplitAux(op0 + 2 * K + 3, Gp, C, -1, b1);
 							st.flags |= WN_FLAG_NEED_OUTPUT;
 						}
 						SplitRing(st, layerRing[a][l]);
@@ -485,7 +496,7 @@ namespace na
 						const int Kh = cfg.headKernelSize;
 						WnSplitStage st = EmptySplit(Kh == 1 ? WN_ST_HEAD_DENSE_OUT : WN_ST_HEAD_CONV_OUT);
 						st.G = G; st.Gp = Gp; st.ksize = Kh; st.dilation = cfg.headDilation;
-						st.a_ops = 2 * Kh + 2;
+						st.a_ops = 2 * Kh + 1;
 						st.a_off = NewSplitOps(st.a_ops) * 64;
 						const int op0 = st.a_off / 64;
 						for (int k = 0; k < Kh; k++)

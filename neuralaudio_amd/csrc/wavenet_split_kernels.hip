@@ -46,8 +46,29 @@ namespace na
 		typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 		typedef const int __attribute__((address_space(4)))* CInt;
 
+#ifndef NA_ABL
+#define NA_ABL 0 // ablation bit mask for tuning builds only (tools/ablate.sh); 0 in the product.  1: no activation math, 2: no MFMA,
+                 // 4: no history loads / ring stores, 8: no barrier, 16: no weight staging, 32: no split arithmetic, 64: no LDS publish,
+                 // 128: no A-operand LDS reads (one operand reused)
+#endif
+#ifndef NA_PK_TANH
+#define NA_PK_TANH 1 // tuning builds: 0 = the unpacked tanh in the activation phase
+#endif
+		// tuning aid (make SUFFIX=_trace EXTRA=-DNA_SP_TRACE, tools/trace_split_timeline.py): shader-clock stamps of one workgroup,
+		// trace[(stage * 8 + point) * waves + wave]; the scheduling barriers pin the stamp between the phases (and cost a little overlap)
+#ifdef NA_SP_TRACE
+#define SP_STAMP(point) do { __builtin_amdgcn_sched_barrier(0); if (cx.trace != nullptr && cx.lane == 0) cx.trace[((s * 8 + (point)) * cx.nwaves) + cx.waveAll] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SP_STAMP(point) (void)0
+#endif
+#define WOP(m) (((NA_ABL & 128) ? 0 : (m)) * 64)
 		constexpr int OOB = (int)0x80000000;
 		constexpr int FRAMES = WN_MAX_FRAMES; // 128 frames per launch = 8 tiles
+		// LDS block image: one plane per channel group, GUARD quads in front of frame 0; the quad just before frame 0 is kept zero, so a tap
+		// whose frame lies before the block start reads zeros by clamping its frame index to -1 (no exec masking, no select)
+		constexpr int GUARD = 16;
+		constexpr int PLANE = GUARD + FRAMES; // quads per plane (a multiple of 16: lanes of different planes never share a bank group)
+		__device__ __forceinline__ int ImgIdx(int cg, int f) { return cg * PLANE + GUARD + f; }
 
 		__device__ __forceinline__ __amdgpu_buffer_rsrc_t MakeRsrc(const void* base, unsigned bytes)
 		{
@@ -77,6 +98,7 @@ namespace na
 
 		__device__ __forceinline__ f32x4 Mfma(u32x4 a, u32x4 b, f32x4 c)
 		{
+			if (NA_ABL & 2) return f32x4{ c.x + __builtin_bit_cast(float, a.x ^ b.x), c.y, c.z, c.w };
 			return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 		}
 
@@ -89,6 +111,7 @@ namespace na
 		// 4 channels (f32) -> split quad [h0 h1 | h2 h3 | l0 l1 | l2 l3]
 		__device__ __forceinline__ u32x4 SplitQuad(f32x4 v)
 		{
+			if (NA_ABL & 32) return __builtin_bit_cast(u32x4, v);
 			const f16x2 h01 = __builtin_convertvector(f32x2{ v.x, v.y }, f16x2);
 			const f16x2 h23 = __builtin_convertvector(f32x2{ v.z, v.w }, f16x2);
 			u32x4 q;
@@ -110,11 +133,30 @@ namespace na
 		// (tools/microbench/mfma_f16_valu_mix.hip).  |x + e*x*|x|| == |x| + e*x^2 since 1 + e|x| > 0; division = num * v_rcp_f32(den).
 		__device__ __forceinline__ float FastTanh(float x)
 		{
+			if (NA_ABL & 1) return x * 0.5f;
 			const float ax = __builtin_fabsf(x);
 			const float x2 = x * x;
 			const float p = __builtin_fmaf(__builtin_fmaf(0.821226666969744f, ax, 0.893229853513558f), x2, __builtin_fmaf(2.45550750702956f, ax, 2.45550750702956f));
 			const float den = __builtin_fmaf(2.44506634652299f + x2, __builtin_fmaf(0.814642734961073f, x2, ax), 2.44506634652299f);
 			return (x * p) * __builtin_amdgcn_rcpf(den);
+		}
+
+		// The same on two channels with packed f32 math (13 instructions per pair instead of 20).  Packed f32 instructions stall next to
+		// MFMAs of the same wave, but the activation is a phase of its own between the conv and the 1x1 chains, where halving the
+		// instruction count wins (tools/microbench/mfma_f16_valu_mix.hip: 3 vs 6 cycles per element in bulk).
+		__device__ __forceinline__ f32x2 FastTanh2(f32x2 x)
+		{
+			if (NA_ABL & 1) return x * 0.5f;
+			f32x2 ax;
+			ax.x = __builtin_fabsf(x.x);
+			ax.y = __builtin_fabsf(x.y);
+			const f32x2 x2 = x * x;
+			const f32x2 num = x * (2.45550750702956f + 2.45550750702956f * ax + (0.893229853513558f + 0.821226666969744f * ax) * x2);
+			const f32x2 den = 2.44506634652299f + (2.44506634652299f + x2) * (ax + 0.814642734961073f * x2);
+			f32x2 r;
+			r.x = __builtin_amdgcn_rcpf(den.x);
+			r.y = __builtin_amdgcn_rcpf(den.y);
+			return num * r;
 		}
 
 		// StdMath policy (Activation.h:37-40): tanh(x) = 1 - 2 / (e^(2x) + 1) on the exp2 / rcp units (absolute error ~1e-7)
@@ -144,6 +186,7 @@ namespace na
 		template <int NWAVES>
 		__device__ __forceinline__ void BlockBarrier()
 		{
+			if (NA_ABL & 8) return;
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 			__builtin_amdgcn_s_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -168,10 +211,10 @@ namespace na
 			const u32x4* wbuf;            // [2][wstride] staged A operands (quads)
 			int wstride;
 			__amdgpu_buffer_rsrc_t wrsrc; // split weight image (staging source)
-			u32x4* img;                   // this stream's [2][maxG][FRAMES] block images (quads)
-			int imgStride;                // quads per image = maxG * FRAMES
+			u32x4* img;                   // this stream's [2][maxG][PLANE] block images (quads)
+			int imgStride;                // quads per image = maxG * PLANE
 			const u32x4* idop;            // identity A operand [64 lanes] (head accumulation rides on the matrix pipe)
-			const u32x4* auxq;            // this stream's aux operands in LDS: split quad of (cond, 1, 0, 0) per frame [FRAMES]
+			const u32x4* auxq;            // this stream's aux operands in LDS: [cond_h, 1, cond_l, 1, cond_h, 0, 0, 0] per frame [FRAMES]
 			__amdgpu_buffer_rsrc_t srsrc; // this stream's state
 			int myPos;                    // lane r: write cursor of ring r
 			int n, nSt;                   // frames in the block; frames this wave may store (0 for a shadow wave)
@@ -180,16 +223,20 @@ namespace na
 			float* __restrict__ out;
 			size_t outBase;
 			float headScale;
+			long long* trace; // nullptr unless this is the traced workgroup of a trace build
+			int nwaves;
 		};
 
 		// ring address (bytes) of channel group `cg` of ring position p, frame-major image: (p * G + cg) * 16
-		__device__ __forceinline__ int RingByte(int ringOff, int G, int p, int cg) { return (ringOff + p * G + cg) * 16; }
+		// (v_mad_u32_u24: full rate; a plain 32-bit multiply is a quarter-rate instruction and rings are far smaller than 2^24 quads)
+		__device__ __forceinline__ int RingByte(int ringOff, int G, int p, int cg) { return (int)(__umul24((unsigned)p, (unsigned)(G * 16)) + (unsigned)((ringOff + cg) * 16)); }
 
 		// History part of one tap for one set: the split quad of frame (f - shift) for the lanes with f < shift (frames before the block
 		// start), from the ring whose write cursor is pos0.  Always one load per call, predicated through the offset, so that the number
 		// of VMEM operations per layer is the same on every path (the compiler can then place counted vmcnt waits).
 		__device__ __forceinline__ u32x4 LoadHistory(const Ctx& cx, int ringOff, int R, int G, int pos0, int f, int cg, int shift, bool valid)
 		{
+			if (NA_ABL & 4) return u32x4{ 0, 0, 0, 0 };
 			int base = pos0 - shift; // shift <= R - FRAMES: one wrap is enough
 			if (base < 0) base += R;
 			unsigned p = (unsigned)(base + f);
@@ -198,25 +245,26 @@ namespace na
 			return BufLoad(cx.srsrc, (valid && f < shift) ? addr : OOB);
 		}
 
-		// one conv tap operand: in-block frames come from the LDS block image, earlier ones were prefetched from the ring (`hist`)
-		__device__ __forceinline__ u32x4 TapOperand(const u32x4* img, u32x4 hist, int off, int cg)
+		// In-block part of one conv tap operand: the split quad of frame `off` of the block image, zeros for the lanes whose frame lies
+		// before the block start.  Their part was prefetched from the ring (LoadHistory: zeros for the in-block lanes, an out-of-range
+		// buffer load returns 0) and goes through its own MFMA -- the conv is linear in the operand, so nothing has to be merged.
+		__device__ __forceinline__ u32x4 TapInBlock(const u32x4* img, int off, int cg)
 		{
-			u32x4 v = hist;
-			if (off >= 0) v = img[cg * FRAMES + off]; // divergent: the in-block lanes overwrite the prefetched history
-			return v;
+			if (NA_ABL & 256) return u32x4{ (unsigned)off, 0, 0, 0 };
+			return img[ImgIdx(cg, off < -1 ? -1 : off)];
 		}
 
 		// ... without a prefetch (taps beyond the prefetched ones, head conv): LDS, ring, or both, decided per wave
 		__device__ __forceinline__ u32x4 TapOperandInline(const Ctx& cx, const u32x4* img, int ringOff, int R, int G, int pos0, int f, int cg, int shift, int lo, int hi)
 		{
 			const int off = f - shift;
-			if (lo >= 0) return img[cg * FRAMES + off];
+			if (lo >= 0) return img[ImgIdx(cg, off)];
 			int p = pos0 + off;
 			if (p < 0) p += R;
 			if (p >= R) p -= R;
 			if (hi < 0) return BufLoad(cx.srsrc, RingByte(ringOff, G, p, cg));
 			const u32x4 h = BufLoad(cx.srsrc, off < 0 ? RingByte(ringOff, G, p, cg) : OOB);
-			const u32x4 l = img[cg * FRAMES + (off < 0 ? 0 : off)];
+			const u32x4 l = img[ImgIdx(cg, off < 0 ? 0 : off)];
 			u32x4 v;
 			v.x = off < 0 ? h.x : l.x; v.y = off < 0 ? h.y : l.y; v.z = off < 0 ? h.z : l.z; v.w = off < 0 ? h.w : l.w;
 			return v;
@@ -226,7 +274,8 @@ namespace na
 		// only the last R - FRAMES frames of a block can ever be read back).  One store instruction on every path.
 		__device__ __forceinline__ void Publish(const Ctx& cx, u32x4* imgNext, u32x4 v, int f, int cg, bool liveLane, int outRingOff, int outR, int outG, int outPos0, int nSt)
 		{
-			if (liveLane) imgNext[cg * FRAMES + f] = v;
+			if (!(NA_ABL & 64) && liveLane) imgNext[ImgIdx(cg, f)] = v;
+			if (NA_ABL & 4) return;
 			const int firstKept = nSt - (outR - FRAMES);
 			unsigned p = (unsigned)(outPos0 + f);
 			p = __builtin_elementwise_min(p, p - (unsigned)outR);
@@ -244,6 +293,7 @@ namespace na
 
 			__device__ __forceinline__ void Begin(const Ctx& cx, int nextBuf, const Stage& sdn) const
 			{
+				if (NA_ABL & 16) return;
 				const int nextQ = sdn.a_ops * 64;
 #pragma unroll
 				for (int c = 0; c < WCOPY; c++)
@@ -277,13 +327,24 @@ namespace na
 			f32x4 hd[T]; // head accumulator
 		};
 
+		// The lane index goes through an opaque asm at the start of every stage function: without it the compiler hoists the lane
+		// geometry (frames, channel groups, LDS / ring address parts) of EVERY inlined stage variant to the top of the kernel and
+		// keeps all of it alive across the stage loop -- dozens of VGPRs for code paths that never run.
+		__device__ __forceinline__ int OpaqueLane(const Ctx& cx)
+		{
+			int lane = cx.lane;
+			asm volatile("" : "+v"(lane));
+			return lane;
+		}
+
 		template <int GP, int T>
-		__device__ __forceinline__ void FrameOf(const Ctx& cx, int s, int& f, int& cg, bool& tileLive)
+		__device__ __forceinline__ void FrameOf(const Ctx& cx, int lane, int s, int& f, int& cg, bool& tileLive)
 		{
 			constexpr int P = Geo<GP, T>::P;
-			const int p = cx.q / GP;
-			cg = cx.q % GP;
-			f = cx.F0 + 16 * (P * s + p) + cx.j;
+			const int q = lane >> 4;
+			const int p = q / GP;
+			cg = q % GP;
+			f = cx.F0 + 16 * (P * s + p) + (lane & 15);
 			tileLive = !Geo<GP, T>::PARTIAL || (P * s + p < T);
 		}
 
@@ -299,10 +360,11 @@ namespace na
 			constexpr int S = Geo<GP, T>::S;
 			constexpr int P = Geo<GP, T>::P;
 			const WeightStager<NTHREADS, GEN> stager;
+			const int lane = OpaqueLane(cx);
 			int f[S], cg[S];
 			bool live[S];
 #pragma unroll
-			for (int i = 0; i < S; i++) FrameOf<GP, T>(cx, i, f[i], cg[i], live[i]);
+			for (int i = 0; i < S; i++) FrameOf<GP, T>(cx, lane, i, f[i], cg[i], live[i]);
 
 			// ring history of the first HPF taps of the current layer: requested here for the first layer of the run, afterwards during
 			// the previous layer
@@ -321,8 +383,9 @@ namespace na
 				sdn.a_ops = 0;
 				sdn.type = -1;
 				if (s + 1 < cx.nstages) sdn = LoadStage(cx.stages, s + 1);
+				SP_STAMP(0);
 				stager.Begin(cx, (s + 1) & 1, sdn);
-				const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane; // this lane's quad of operand m: wl[m * 64]
+				const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + lane; // this lane's quad of operand m: wl[m * 64]
 				const u32x4* imgCur = cx.img + cur * cx.imgStride;
 				u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
 				// the fast instantiation (GEN == false) is only launched for models whose layers all have K == 3 and fill their lane mode
@@ -341,14 +404,44 @@ namespace na
 				{
 					if (!GEN || k < K - 1)
 					{
-						const u32x4 ah = wl[(2 * k) * 64], al = wl[(2 * k + 1) * 64];
-#pragma unroll
-						for (int i = 0; i < S; i++)
+						const u32x4 ah = wl[WOP(2 * k)], al = wl[WOP(2 * k + 1)];
+						// Where do the frames of this tap lie for this wave?  All before the block start: the ring prefetch is the whole
+						// operand.  All inside the block: the LDS image is.  Otherwise both parts go through the MFMA (the conv is linear
+						// in the operand: the ring part is zero for in-block lanes and vice versa, nothing has to be merged).
+						const int shift = d * (K - 1 - k);
+						const int lo = cx.F0 - shift, hi = cx.F0 + 16 * P * S - 1 - shift; // wave-uniform
+						if (hi < 0)
 						{
-							u32x4 b = TapOperand(imgCur, hist[k][i], f[i] - d * (K - 1 - k), cg[i]);
-							if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 }; // no garbage (NaN) into the MFMA
-							acc[i] = Mfma(ah, b, acc[i]);
-							acc[i] = Mfma(al, b, acc[i]);
+#pragma unroll
+							for (int i = 0; i < S; i++)
+							{
+								acc[i] = Mfma(ah, hist[k][i], acc[i]);
+								acc[i] = Mfma(al, hist[k][i], acc[i]);
+							}
+						}
+						else if (lo >= 0)
+						{
+#pragma unroll
+							for (int i = 0; i < S; i++)
+							{
+								u32x4 b = imgCur[ImgIdx(cg[i], f[i] - shift)];
+								if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 }; // no garbage (NaN) into the MFMA
+								acc[i] = Mfma(ah, b, acc[i]);
+								acc[i] = Mfma(al, b, acc[i]);
+							}
+						}
+						else
+						{
+#pragma unroll
+							for (int i = 0; i < S; i++)
+							{
+								u32x4 b = TapInBlock(imgCur, f[i] - shift, cg[i]);
+								if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 };
+								acc[i] = Mfma(ah, hist[k][i], acc[i]);
+								acc[i] = Mfma(al, hist[k][i], acc[i]);
+								acc[i] = Mfma(ah, b, acc[i]);
+								acc[i] = Mfma(al, b, acc[i]);
+							}
 						}
 					}
 				}
@@ -366,7 +459,7 @@ namespace na
 				if constexpr (GEN)
 				for (int k = HPF; k < K - 1; k++)
 				{
-					const u32x4 ah = wl[(2 * k) * 64], al = wl[(2 * k + 1) * 64];
+					const u32x4 ah = wl[WOP(2 * k)], al = wl[WOP(2 * k + 1)];
 					const int shift = d * (K - 1 - k);
 #pragma unroll
 					for (int i = 0; i < S; i++)
@@ -381,20 +474,20 @@ namespace na
 				{
 					// unshifted tap (the layer input itself, read back from the block image) and the aux operand:
 					// (mix-in, conv bias) * (cond, 1)   (:288-289, :471)
-					const u32x4 ah = wl[(2 * K - 2) * 64], al = wl[(2 * K - 1) * 64], xh = wl[(2 * K) * 64], xl = wl[(2 * K + 1) * 64];
+					const u32x4 ah = wl[WOP(2 * K - 2)], al = wl[WOP(2 * K - 1)], xa = wl[WOP(2 * K)];
 #pragma unroll
 					for (int i = 0; i < S; i++)
 					{
-						u32x4 b = imgCur[cg[i] * FRAMES + f[i]];
+						u32x4 b = imgCur[ImgIdx(cg[i], f[i])];
 						if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 };
 						const u32x4 ax = AuxOf(cx, f[i]);
 						acc[i] = Mfma(ah, b, acc[i]);
 						acc[i] = Mfma(al, b, acc[i]);
-						acc[i] = Mfma(xh, ax, acc[i]);
-						acc[i] = Mfma(xl, ax, acc[i]);
+						acc[i] = Mfma(xa, ax, acc[i]);
 					}
 				}
 
+				SP_STAMP(1);
 				// activation (:473-480), one wave-uniform branch per layer
 				f32x4 z[S];
 				if (sd.flags & WN_FLAG_LEAKY)
@@ -410,40 +503,72 @@ namespace na
 				else
 				{
 #pragma unroll
-					for (int i = 0; i < S; i++) z[i] = f32x4{ FastTanh(acc[i].x), FastTanh(acc[i].y), FastTanh(acc[i].z), FastTanh(acc[i].w) };
+					for (int i = 0; i < S; i++)
+					{
+						if (NA_PK_TANH)
+						{
+							const f32x2 lo = FastTanh2(f32x2{ acc[i].x, acc[i].y }), hi = FastTanh2(f32x2{ acc[i].z, acc[i].w });
+							z[i] = f32x4{ lo.x, lo.y, hi.x, hi.y };
+						}
+						else z[i] = f32x4{ FastTanh(acc[i].x), FastTanh(acc[i].y), FastTanh(acc[i].z), FastTanh(acc[i].w) };
+					}
 				}
+				SP_STAMP(2);
 				// head accumulate (:482) on the matrix pipe: head += I * (zh + zl); 1x1 + bias + residual (:486-491)
 				const bool needOutput = (sd.flags & WN_FLAG_NEED_OUTPUT) != 0;
 				const bool pub = (sd.flags & WN_FLAG_PUBLISH) != 0;
-				const u32x4 idop = cx.idop[cx.lane];
-				u32x4 w1h, w1l, b1h, b1l;
-				if (needOutput)
+				const u32x4 idop = cx.idop[lane];
+				if (needOutput && pub)
 				{
-					w1h = wl[(2 * K + 2) * 64]; w1l = wl[(2 * K + 3) * 64]; b1h = wl[(2 * K + 4) * 64]; b1l = wl[(2 * K + 5) * 64];
-				}
+					// every layer but the last one of an array: straight-line code for all sets
+					const u32x4 w1h = wl[WOP(2 * K + 1)], w1l = wl[WOP(2 * K + 2)], b1a = wl[WOP(2 * K + 3)];
 #pragma unroll
-				for (int i = 0; i < S; i++)
-				{
-					const u32x4 zs = SplitQuad(z[i]);
-					st.hd[i] = Mfma(idop, zs, st.hd[i]);
-					u32x4 ys = zs;
-					if (needOutput)
+					for (int i = 0; i < S; i++)
 					{
+						const u32x4 zs = SplitQuad(z[i]);
 						const u32x4 ax = AuxOf(cx, f[i]);
+						st.hd[i] = Mfma(idop, zs, st.hd[i]);
 						f32x4 y = st.xc[i];
 						y = Mfma(w1h, zs, y);
 						y = Mfma(w1l, zs, y);
-						y = Mfma(b1h, ax, y);
-						y = Mfma(b1l, ax, y);
+						y = Mfma(b1a, ax, y);
 						st.xc[i] = y;
-						ys = SplitQuad(y);
+						Publish(cx, imgNext, SplitQuad(y), f[i], cg[i], !GEN || (live[i] && cg[i] < sd.out_G), sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
 					}
-					// always one store per set (predicated through the offset): fixed VMEM count per layer
-					Publish(cx, imgNext, ys, f[i], cg[i], pub && (!GEN || (live[i] && cg[i] < sd.out_G)), sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, pub ? cx.nSt : 0);
+				}
+				else
+				{
+					u32x4 w1h, w1l, b1a;
+					if (needOutput)
+					{
+						w1h = wl[WOP(2 * K + 1)]; w1l = wl[WOP(2 * K + 2)]; b1a = wl[WOP(2 * K + 3)];
+					}
+#pragma unroll
+					for (int i = 0; i < S; i++)
+					{
+						const u32x4 zs = SplitQuad(z[i]);
+						st.hd[i] = Mfma(idop, zs, st.hd[i]);
+						u32x4 ys = zs;
+						if (needOutput)
+						{
+							const u32x4 ax = AuxOf(cx, f[i]);
+							f32x4 y = st.xc[i];
+							y = Mfma(w1h, zs, y);
+							y = Mfma(w1l, zs, y);
+							y = Mfma(b1a, ax, y);
+							st.xc[i] = y;
+							ys = SplitQuad(y);
+						}
+						// always one store per set (predicated through the offset): fixed VMEM count per layer
+						Publish(cx, imgNext, ys, f[i], cg[i], pub && (!GEN || (live[i] && cg[i] < sd.out_G)), sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, pub ? cx.nSt : 0);
+					}
 				}
 				if (sd.flags & WN_FLAG_PUBLISH) cur ^= 1;
+				SP_STAMP(3);
 				stager.template End<(HPF + 1) * S>(cx, (s + 1) & 1, sdn); // HPF*S history loads + S ring stores follow Begin() on every path
+				SP_STAMP(4);
 				BlockBarrier<NTHREADS / 64>();
+				SP_STAMP(5);
 				sd = sdn;
 				s++;
 			} while (s < cx.nstages && sd.type == WN_ST_LAYER && sd.Gp == GP);
@@ -455,21 +580,21 @@ namespace na
 		{
 			constexpr int S = Geo<GP, T>::S;
 			const WeightStager<NTHREADS, GEN> stager;
+			const int lane = OpaqueLane(cx);
 			Stage sdn = LoadStage(cx.stages, s + 1);
 			stager.Begin(cx, (s + 1) & 1, sdn);
-			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane;
+			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + lane;
 			u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
 			const int outPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id);
-			const u32x4 ah = wl[0], al = wl[64];
+			const u32x4 ra = wl[0];
 #pragma unroll
 			for (int i = 0; i < S; i++)
 			{
 				int f, cg; bool live;
-				FrameOf<GP, T>(cx, i, f, cg, live);
+				FrameOf<GP, T>(cx, lane, i, f, cg, live);
 				const u32x4 ax = AuxOf(cx, f);
 				f32x4 x = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-				x = Mfma(ah, ax, x);
-				x = Mfma(al, ax, x);
+				x = Mfma(ra, ax, x);
 				st.xc[i] = x;
 				st.hd[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
 				Publish(cx, imgNext, SplitQuad(x), f, cg, live && cg < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
@@ -489,9 +614,10 @@ namespace na
 			constexpr int Po = 4 / GPO, Pn = 4 / GPN, NC = Po > Pn ? Po : Pn;
 			constexpr int So = Geo<GPO, T>::S, Sn = Geo<GPN, T>::S;
 			const WeightStager<NTHREADS, GEN> stager;
+			const int lane = OpaqueLane(cx);
 			Stage sdn = LoadStage(cx.stages, s + 1);
 			stager.Begin(cx, (s + 1) & 1, sdn);
-			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane;
+			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + lane;
 			u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
 			const int outPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id);
 
@@ -500,7 +626,7 @@ namespace na
 			for (int i = 0; i < So; i++)
 			{
 				int f, cg; bool live;
-				FrameOf<GPO, T>(cx, i, f, cg, live);
+				FrameOf<GPO, T>(cx, lane, i, f, cg, live);
 				hs[i] = SplitQuad(st.hd[i]);
 				xs[i] = SplitQuad(st.xc[i]);
 				if (Geo<GPO, T>::PARTIAL || GPO == 4)
@@ -516,14 +642,13 @@ namespace na
 #pragma unroll
 			for (int i = 0; i < Sn; i++)
 			{
-				FrameOf<GPN, T>(cx, i, fn[i], cgn[i], liven[i]);
+				FrameOf<GPN, T>(cx, lane, i, fn[i], cgn[i], liven[i]);
 				hn[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 				xn[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 				if (sd.flags & WN_FLAG_BIAS)
 				{
 					const u32x4 ax = AuxOf(cx, fn[i]);
 					hn[i] = Mfma(wl[(4 * NC) * 64], ax, hn[i]);
-					hn[i] = Mfma(wl[(4 * NC + 1) * 64], ax, hn[i]);
 				}
 			}
 #pragma unroll
@@ -556,7 +681,8 @@ namespace na
 		{
 			constexpr int S = Geo<GP, T>::S;
 			constexpr int P = Geo<GP, T>::P;
-			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + cx.lane;
+			const int lane = OpaqueLane(cx);
+			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + lane;
 			const int K = sd.ksize, G = sd.G;
 			int f[S], cg[S];
 			bool live[S];
@@ -564,7 +690,7 @@ namespace na
 #pragma unroll
 			for (int i = 0; i < S; i++)
 			{
-				FrameOf<GP, T>(cx, i, f[i], cg[i], live[i]);
+				FrameOf<GP, T>(cx, lane, i, f[i], cg[i], live[i]);
 				hs[i] = SplitQuad(st.hd[i]);
 				if (Geo<GP, T>::PARTIAL || GP == 4) hs[i] = (live[i] && cg[i] < G) ? hs[i] : u32x4{ 0, 0, 0, 0 };
 			}
@@ -605,7 +731,6 @@ namespace na
 					{
 						const u32x4 ax = AuxOf(cx, f[i]);
 						acc[i] = Mfma(wl[(2 * K) * 64], ax, acc[i]);
-						acc[i] = Mfma(wl[(2 * K + 1) * 64], ax, acc[i]);
 					}
 					if (live[i] && cg[i] == 0 && f[i] < cx.nSt) cx.out[cx.outBase + f[i]] = cx.headScale * acc[i].x;
 				}
@@ -636,10 +761,10 @@ namespace na
 		};
 
 		// grid = active streams / SPB; workgroup = SPB streams x WPS waves of T tiles (WPS * T * 16 >= n).
-		// dynamic LDS: auxq[SPB][FRAMES] quads | img[SPB][2][maxG][FRAMES] quads | wbuf[2][wstride] quads | idop[64] quads
+		// dynamic LDS: auxq[SPB][FRAMES] quads | img[SPB][2][maxG][PLANE] quads | wbuf[2][wstride] quads | idop[64] quads
 		template <int T, int SPB, int WPS, bool GEN>
-		__global__ void __launch_bounds__(64 * WPS * SPB) WaveNetSplitKernel(const LaunchArgs args, int maxGAll, int wstride, const float* __restrict__ in, float* __restrict__ out,
-			long inStride, long outStride, int n)
+		__global__ void __launch_bounds__(64 * WPS * SPB) __attribute__((amdgpu_waves_per_eu(T == 2 ? 4 : 2))) WaveNetSplitKernel(const LaunchArgs args, int maxGAll, int wstride, const float* __restrict__ in, float* __restrict__ out,
+			long inStride, long outStride, int n, long long* __restrict__ trace, int traceBlock)
 		{
 			constexpr int NTHREADS = 64 * WPS * SPB;
 			int gi = 0;
@@ -655,7 +780,7 @@ namespace na
 			const int wave = waveAll % WPS; // part of the stream's block
 			u32x4* auxAll = reinterpret_cast<u32x4*>(smem);
 			u32x4* imgAll = auxAll + SPB * FRAMES;
-			const int imgStride = maxGAll * FRAMES;
+			const int imgStride = maxGAll * PLANE;
 			u32x4* wbuf = imgAll + SPB * 2 * imgStride;
 
 			// a partial last workgroup: the surplus waves shadow the last stream (they must keep staging weights and meeting barriers)
@@ -689,13 +814,26 @@ namespace na
 			cx.out = out;
 			cx.outBase = (size_t)row * outStride;
 			cx.headScale = ga.headScale;
+			cx.trace = ((int)blockIdx.x == traceBlock) ? trace : nullptr;
+			cx.nwaves = NTHREADS / 64;
+#ifdef NA_SP_TRACE
+			if (cx.trace != nullptr && lane == 0) cx.trace[((ga.nstages * 8 + 0) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
+#endif
 
 			// input row (WaveNet.h:770 input -> condition) -> the aux operand of every frame: split quad of (cond, 1, 0, 0); cond = 0 beyond n
 			{
 				u32x4* auxq = auxAll + sub * FRAMES;
 				for (int i = wave * 64 + lane; i < FRAMES; i += WPS * 64)
-					auxq[i] = SplitQuad(f32x4{ (i < n) ? in[(size_t)row * inStride + i] : 0.0f, 1.0f, 0.0f, 0.0f });
+				{
+					// [cond_h, 1 | cond_l, 1 | cond_h, 0 | 0, 0] (see FillSplitAux in wavenet_plan.cpp)
+					const float c = (i < n) ? in[(size_t)row * inStride + i] : 0.0f;
+					const _Float16 ch = (_Float16)c, cl = (_Float16)(c - (float)ch);
+					const f16x2 a = { ch, (_Float16)1.0f }, b = { cl, (_Float16)1.0f }, d = { ch, (_Float16)0.0f };
+					auxq[i] = u32x4{ __builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, d), 0u };
+				}
 			}
+			// zero quad in front of frame 0 of every plane of both block images
+			for (int i = threadIdx.x; i < SPB * 2 * maxGAll; i += NTHREADS) imgAll[i * PLANE + GUARD - 1] = u32x4{ 0, 0, 0, 0 };
 			// identity A operand: row i x k-block q = i / 4: 1.0 against the h AND the l half of channel i % 4
 			if (threadIdx.x < 64)
 			{
@@ -755,6 +893,9 @@ namespace na
 				}
 			}
 
+#ifdef NA_SP_TRACE
+			if (cx.trace != nullptr && lane == 0) cx.trace[((ga.nstages * 8 + 1) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
+#endif
 			// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
 			if (wave == 0 && liveStream && lane < ga.nrings)
 			{
@@ -788,7 +929,7 @@ namespace na
 				maxOps = std::max(maxOps, m.max_split_ops);
 			}
 			const int wstride = maxOps * 64; // quads per LDS weight buffer (the LDS-DMA staging always writes its fixed 16 KB part)
-			const size_t lds = (size_t)SPB * FRAMES * 16 + (size_t)SPB * 2 * maxG * FRAMES * 16 + (size_t)2 * wstride * 16 + 1024;
+			const size_t lds = (size_t)SPB * FRAMES * 16 + (size_t)SPB * 2 * maxG * PLANE * 16 + (size_t)2 * wstride * 16 + 1024;
 			if (lds > 160 * 1024) return hipErrorInvalidValue;
 			auto kernel = WaveNetSplitKernel<T, SPB, WPS, GEN>;
 			if (lds > 64 * 1024)
@@ -801,7 +942,8 @@ namespace na
 					granted = lds;
 				}
 			}
-			hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WPS * SPB), lds, stream, args, maxG, wstride, in, out, inStride, outStride, n);
+			hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WPS * SPB), lds, stream, args, maxG, wstride, in, out, inStride, outStride, n, GetWaveNetTraceBuffer(),
+				[]() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
 			return hipGetLastError();
 		}
 	}
@@ -825,7 +967,7 @@ namespace na
 		// fast instantiation: every layer of every group has K == 3 and fills its lane mode (the official A1 architectures except Lite);
 		// split_fast_T = fewest tiles per wave it can run with (4 when an array has <= 4 channels), 0 = needs the generic one
 		bool gen = genEnv;
-		int t = (tEnv == 2 || tEnv == 4) ? tEnv : 4;
+		int t = (tEnv == 2 || tEnv == 4) ? tEnv : 2;
 		for (int i = 0; i < numGroups; i++)
 		{
 			if (groups[i].model->split_fast_T == 0) gen = true;
