@@ -3,11 +3,12 @@
 
 Workload (BASELINE.json configs[1]): NAM A1 WaveNet 'Standard', 1024 batched streams per GPU,
 128-sample buffers, FP32.  One "step" = one pass of the hot path over one buffer of every stream
-(one WaveNetFrameKernel launch over 1024 streams x 128 samples), inputs already resident in HBM.
+(one WaveNetSplitKernel launch over 1024 streams x 128 samples), inputs already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
-   one rank per GPU; streams are independent so ranks share nothing on the data path: weak scaling)
+  (N > 1: one rank per GPU, launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; run
+   WITHOUT that launcher, `bench.py --gpus N` spawns it itself.  Streams are independent, so ranks share nothing on the data
+   path: weak scaling; RCCL carries the timing barrier / max-over-ranks and one all-reduce that counts the ranks.)
 
 Prints ONE JSON line (rank 0).  PyTorch is plumbing only: device buffers, the stream/event used for
 timing, and torch.distributed (RCCL) for the barrier + max-over-ranks.
@@ -63,9 +64,13 @@ def cpu_baseline(workload="standard", seconds_target=12.0):
     lib = O.load_native_lib()
     files = {"standard": "BossWN-standard.nam", "feather": "BossWN-feather.nam", "nano": "BossWN-nano.nam", "a2full": "BossWN-a2.nam",
              "a2lite": "BossWN-a2.nam", "lstm1x16": "BossLSTM-1x16.nam", "lstm2x8": "BossLSTM-2x8.nam"}
-    if workload not in files:
+    if workload == "lite":
+        j = json.loads(synthetic_lite_nam())
+        files = dict(files, lite="synthetic A1 Lite (12/6 channels, seeded weights)")
+    elif workload not in files:
         raise ValueError("no CPU baseline for workload " + workload)
-    j = O.load_json(files[workload])
+    else:
+        j = O.load_json(files[workload])
     if j["architecture"] == "SlimmableContainer":
         j = j["config"]["submodels"][O.quality_to_submodel(j, 0.0 if workload == "a2lite" else 1.0)]["model"]
     w = np.ascontiguousarray(j["weights"], dtype=np.float32)
@@ -102,6 +107,63 @@ def cpu_baseline(workload="standard", seconds_target=12.0):
     }
 
 
+def synthetic_lite_nam():
+    """A1 'Lite' (channels 12 / head 6; dilation lists of InternalModel.h:12-17): no Lite file ships with the reference, so the
+    weights are seeded U(-a, a) with a = 1/sqrt(fan_in), head scale 0.02."""
+    import numpy as np
+    rng = np.random.default_rng(126)
+    d1, d2 = [1, 2, 4, 8, 16, 32, 64], [128, 256, 512, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512]
+    arrays = [dict(input_size=1, channels=12, head_size=6, dil=d1, head_bias=False), dict(input_size=12, channels=6, head_size=1, dil=d2, head_bias=True)]
+    w = []
+
+    def u(n, fan_in):
+        a = 1.0 / np.sqrt(max(fan_in, 1))
+        w.append(rng.uniform(-a, a, size=n))
+
+    layers = []
+    for a in arrays:
+        c = a["channels"]
+        u(c * a["input_size"], a["input_size"])
+        for _ in a["dil"]:
+            u(c * c * 3, c * 3); u(c, c * 3); u(c, 1); u(c * c, c); u(c, c)
+        u(a["head_size"] * c, c)
+        if a["head_bias"]:
+            u(a["head_size"], c)
+        layers.append({"input_size": a["input_size"], "condition_size": 1, "head_size": a["head_size"], "channels": c, "kernel_size": 3,
+                       "dilations": a["dil"], "activation": "Tanh", "gated": False, "head_bias": a["head_bias"]})
+    w.append(np.array([0.02]))
+    return json.dumps({"version": "0.5.4", "architecture": "WaveNet", "metadata": {"loudness": -10.0},
+                       "config": {"layers": layers, "head": None, "head_scale": 0.02},
+                       "weights": [float(v) for v in np.concatenate(w).astype(np.float32)], "sample_rate": 48000})
+
+
+def mixed_cpu_baseline(parts, seconds_target=12.0):
+    """Stream-weighted CPU baseline of a mixed batch: equal stream counts per model -> harmonic mean of the per-model rates."""
+    res = [cpu_baseline(w, seconds_target / len(parts)) for w in parts]
+    rate = len(res) / sum(1.0 / r["value"] for r in res)
+    return {"value": rate, "unit": "Msamples/s", "cores": res[0]["cores"], "kind": "port",
+            "sample": "harmonic mean over equal stream shares of: " + " | ".join(r["sample"] for r in res)}
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     global BLOCK
     ap = argparse.ArgumentParser()
@@ -113,9 +175,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed sustained load before warm-up so the shader clock reaches steady state")
     ap.add_argument("--workload", default="standard",
-                    help="standard (default = the BASELINE metric's config) | feather | nano | a2full | a2lite | lstm1x16 | lstm2x8 | mixed3 | config4 "
+                    help="standard (default = the BASELINE metric's config) | lite | feather | nano | a2full | a2lite | lstm1x16 | lstm2x8 | "
+                         "config3 (Lite+Feather+Nano, 4096 streams) | config4 (LSTM 2x16 + GRU) | config5 (A2 quality sweep, 2048 streams) "
                          "(other BASELINE configs, for DESIGN.md numbers; the driver uses the default)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+    if args.workload == "mixed3":
+        args.workload = "config3"
 
     import numpy as np
     import torch
@@ -132,18 +199,32 @@ def main():
     import neuralaudio_amd as na
     from neuralaudio_amd import dist as nd
 
+    rccl_ranks = 1
     if distributed:
         nd.init(backend="nccl", device=dev)  # nccl == RCCL on ROCm; one rank per GPU
+        import torch.distributed as tdist
+        ones = torch.ones(1, device=dev)
+        tdist.all_reduce(ones)  # every rank adds 1 over RCCL: proves N ranks on N GPUs are really in the job
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != world or world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but RCCL sees %d ranks (WORLD_SIZE %d)" % (args.gpus, rccl_ranks, world))
 
     S = args.streams
+    if args.workload == "config3" and S == STREAMS_PER_GPU:
+        S = 4096  # BASELINE configs[2]
+    if args.workload == "config5" and S == STREAMS_PER_GPU:
+        S = 2048  # BASELINE configs[4]: 16384 streams over 8 GPUs
     loader = na.NeuralModelLoader()
     loader.SetDevice(local_rank)
     mdir = os.path.dirname(MODEL_FILE)
     files = {"standard": ["BossWN-standard.nam"], "feather": ["BossWN-feather.nam"], "nano": ["BossWN-nano.nam"],
              "a2full": ["BossWN-a2.nam"], "a2lite": ["BossWN-a2.nam"], "lstm1x16": ["BossLSTM-1x16.nam"], "lstm2x8": ["BossLSTM-2x8.nam"],
-             "mixed3": ["BossWN-standard.nam", "BossWN-feather.nam", "BossWN-nano.nam"], "config4": []}[args.workload]
+             "lite": [], "config3": ["BossWN-feather.nam", "BossWN-nano.nam"], "config4": [], "config5": ["BossWN-a2.nam"]}[args.workload]
     quality = 0.0 if args.workload == "a2lite" else 1.0
     models = [loader.CreateFromFile(os.path.join(mdir, f), doPrewarm=False) for f in files]
+    if args.workload in ("lite", "config3"):
+        models.insert(0, loader.CreateFromString(synthetic_lite_nam(), ".nam", doPrewarm=False))
+        files = ["synthetic-A1-lite"] + files
     if args.workload == "config4":
         # BASELINE configs[3]: LSTM 2x16 + keras GRU (H=16), half/half; no such files ship with the reference -> seeded U(-a, a) weights
         rng = np.random.default_rng(4)
@@ -162,8 +243,13 @@ def main():
     tstream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream handle
     torch.cuda.set_stream(tstream)
     batch = na.Batch(local_rank, hip_stream=tstream.cuda_stream)
-    for k, mdl in enumerate(models):
-        batch.AddStreams(mdl, S // len(models) + (1 if k < S % len(models) else 0), quality=quality)
+    if args.workload == "config5":
+        # quality sweep 0 -> 1 over the streams: half run the 3-channel submodel, half the 8-channel one
+        for q in (0.0, 0.25, 0.5, 0.75, 1.0, 0.1, 0.6, 0.9):
+            batch.AddStreams(models[0], S // 8, quality=q)
+    else:
+        for k, mdl in enumerate(models):
+            batch.AddStreams(mdl, S // len(models) + (1 if k < S % len(models) else 0), quality=quality)
 
     # synthetic 48 kHz buffers (bench-C of SURVEY 8d): clip(0.25*N(0,1), +-1), per-rank seed; a ring of 8 distinct buffers
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -226,12 +312,15 @@ def main():
         alg_bytes_per_launch = bytes_per_sample * samples_per_step
         achieved_gbs = alg_bytes_per_launch / (kernel_ms_avg * 1e-3) / 1e9
         achieved_tflops = flops_per_sample * samples_per_step / (kernel_ms_avg * 1e-3) / 1e12
-        traffic = None
+        # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes from the committed rocprofv3
+        # --pmc passes of this same command (tools/pmc_passes.sh -> profiles/traffic_latest.json), named in traffic_source
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath) and args.workload == "standard" and S == STREAMS_PER_GPU:
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    tj = json.load(f)
+                traffic, traffic_source = tj.get("hbm_bytes_per_launch"), "profiles/traffic_latest.json: " + str(tj.get("source"))
             except Exception:
                 traffic = None
         out = {
@@ -239,6 +328,7 @@ def main():
             "value": value,
             "unit": "Msamples/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -268,9 +358,11 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_sample": bytes_per_sample,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "kernel": "LstmDppKernel" if args.workload.startswith("lstm") else ("LstmDppKernel+GruWaveKernel" if args.workload == "config4" else "WaveNetFrameKernel"),
+                "kernel": "RecurrentDppKernel" if (args.workload.startswith("lstm") or args.workload == "config4") else
+                          ("WaveNetFrameKernel" if os.environ.get("NA_WN_KERNEL") == "frame" else "WaveNetSplitKernel"),
             },
             "roofline_mfma_f32": {
                 "achieved": achieved_tflops,
@@ -292,9 +384,21 @@ def main():
             lat = sorted(lat[50:])
             out["host_buffer_latency_ms"] = {"p50": lat[len(lat) // 2], "p99": lat[int(len(lat) * 0.99)], "max": lat[-1], "calls": len(lat),
                                              "what": "NA_BatchProcess, %d streams x %d samples, host pointers" % (S, BLOCK)}
-        if world == 1 and not args.no_cpu_baseline and args.workload not in ("mixed3", "config4"):
+            # PCIe-inclusive throughput (SURVEY 8d metric 1): host buffers in, host buffers out, through the pipelined entry points
+            # (NA_BatchSubmit / NA_BatchCollect: upload of buffer k+1 and download of k-1 overlap the kernels of k).  Never `value`.
+            nb = 400
+            tickets = [batch.Submit(xh)]
+            t_a = time.perf_counter()
+            for i in range(nb):
+                tickets.append(batch.Submit(xh))
+                batch.Collect(tickets.pop(0))
+            batch.Collect(tickets.pop(0))
+            t_p = (time.perf_counter() - t_a) / nb
+            out["pcie_inclusive"] = {"ms_per_buffer": t_p * 1e3, "Msamples/s": S * BLOCK / t_p / 1e6,
+                                     "what": "NA_BatchSubmit/NA_BatchCollect, 2 buffers in flight, %d streams x %d samples host -> host" % (S, BLOCK)}
+        if world == 1 and not args.no_cpu_baseline and args.workload not in ("config4", "config5"):
             try:
-                out["cpu_baseline"] = cpu_baseline(args.workload)
+                out["cpu_baseline"] = mixed_cpu_baseline(["lite", "feather", "nano"]) if args.workload == "config3" else cpu_baseline(args.workload)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

@@ -65,6 +65,11 @@ NA_EXTERN int NA_BatchGetActiveSubModel(NA_Batch* batch, int stream);
 NA_EXTERN int NA_BatchPrewarm(NA_Batch* batch, int stream); /* stream < 0: all */
 /* host pointers, layout [streams][n]; synchronous */
 NA_EXTERN int NA_BatchProcess(NA_Batch* batch, const float* in, float* out, size_t n);
+/* Pipelined host-buffer interface: NA_BatchSubmit copies `in` ([streams][n]) and enqueues upload, kernels and download, returning a
+ * ticket (>= 0; up to 3 may be in flight); NA_BatchCollect blocks until that buffer is done and copies its [streams][n] result to
+ * `out`.  Uploads / downloads of neighbouring buffers overlap the kernels.  Buffers are processed in submission order. */
+NA_EXTERN int NA_BatchSubmit(NA_Batch* batch, const float* in, size_t n);
+NA_EXTERN int NA_BatchCollect(NA_Batch* batch, int ticket, float* out);
 /* DEVICE pointers, row s = stream s, rows `stride` floats apart; asynchronous on the batch's stream */
 NA_EXTERN int NA_BatchProcessDevice(NA_Batch* batch, const float* dIn, float* dOut, size_t n, long inStride, long outStride);
 NA_EXTERN int NA_BatchSynchronize(NA_Batch* batch);

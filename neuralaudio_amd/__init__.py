@@ -231,6 +231,22 @@ class Batch:
             raise NeuralAudioError(capi.last_error())
         return y
 
+    def Submit(self, x):
+        """Pipelined variant of Process: returns a ticket for Collect(); up to 3 buffers may be in flight."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.ndim == 2 and x.shape[0] == self.NumStreams(), "expected [streams, n]"
+        t = self._lib.NA_BatchSubmit(self._h, _fptr(x), x.shape[1])
+        if t < 0:
+            raise NeuralAudioError(capi.last_error())
+        return t, x.shape
+
+    def Collect(self, ticket):
+        t, shape = ticket
+        y = np.empty(shape, np.float32)
+        if self._lib.NA_BatchCollect(self._h, int(t), _fptr(y)) != 0:
+            raise NeuralAudioError(capi.last_error())
+        return y
+
     def ProcessDevice(self, d_in, d_out, n, in_stride=None, out_stride=None):
         """d_in / d_out: raw device pointers (ints); asynchronous on the batch's HIP stream."""
         rc = self._lib.NA_BatchProcessDevice(self._h, C.c_void_p(d_in), C.c_void_p(d_out), int(n),

@@ -357,6 +357,20 @@ int NA_BatchProcess(NA_Batch* batch, const float* in, float* out, size_t n)
 	return Guard([&] { batch->batch->ProcessHost(in, out, n); });
 }
 
+int NA_BatchSubmit(NA_Batch* batch, const float* in, size_t n)
+{
+	int ticket = -1;
+	if (!batch) return -1;
+	const int rc = Guard([&] { ticket = batch->batch->Submit(in, n); });
+	return rc == 0 ? ticket : -1;
+}
+
+int NA_BatchCollect(NA_Batch* batch, int ticket, float* out)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->Collect(ticket, out); });
+}
+
 int NA_BatchProcessDevice(NA_Batch* batch, const float* dIn, float* dOut, size_t n, long inStride, long outStride)
 {
 	if (!batch) return -1;

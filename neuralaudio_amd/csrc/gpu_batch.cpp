@@ -138,9 +138,10 @@ namespace na
 		virtual size_t StateBytesPerStream() const = 0;
 		// WaveNet groups on the frame kernel can share ONE launch with other such groups (a heterogeneous batch without stream
 		// fork/join); fills `out` with this group's part of that launch.  Other groups return false.
-		virtual bool FusedLaunchArgs(WnFrameGroup& out)
+		virtual bool FusedLaunchArgs(WnFrameGroup& out, bool& splitFamily)
 		{
 			(void)out;
+			(void)splitFamily;
 			return false;
 		}
 
@@ -195,26 +196,37 @@ namespace na
 
 	namespace
 	{
-		// WaveNet kernel family (process-wide, read once): "split" = the f16-split MFMA kernel (default), "frame" = the f32 4x4x1-MFMA
-		// kernel of round 1, "tile" / "pk" = the older measured alternatives.  The families differ in their stream-state format.
-		enum WnFamily { WN_FAMILY_SPLIT, WN_FAMILY_FRAME, WN_FAMILY_TILE, WN_FAMILY_PK };
-		WnFamily WaveNetFamily()
+		// WaveNet kernel families: "split" = the f16-split MFMA kernel (wavenet_split_kernels.hip), "frame" = the f32 4x4x1-MFMA kernel
+		// (wavenet_frame_kernels.hip).  They keep different stream-state formats.  NA_WN_KERNEL=split|frame forces one for every model
+		// (tuning / tests); default: chosen per model (FamilyFor).
+		enum WnFamily { WN_FAMILY_AUTO, WN_FAMILY_SPLIT, WN_FAMILY_FRAME };
+		WnFamily WaveNetFamilyOverride()
 		{
 			static const WnFamily fam = []() {
 				const char* e = getenv("NA_WN_KERNEL");
-				const std::string w = e ? e : "split";
+				const std::string w = e ? e : "auto";
+				if (w == "split") return WN_FAMILY_SPLIT;
 				if (w == "frame") return WN_FAMILY_FRAME;
-				if (w == "tile") return WN_FAMILY_TILE;
-				if (w == "pk") return WN_FAMILY_PK;
-				return WN_FAMILY_SPLIT;
+				return WN_FAMILY_AUTO;
 			}();
 			return fam;
+		}
+
+		// Which kernel family runs a model (fixed for the life of its group: the families keep different stream-state formats).
+		// Measured on MI355X, 1024 streams x 128 frames: the f16-split kernel wins where its fast instantiation applies with 2 tiles
+		// per wave (every array has 5..8 or 13..16 channels, K = 3: Standard 50 vs 60 us); narrow (Feather, Nano: <= 4-channel
+		// arrays), 12-channel (Lite) and large-kernel (A2) models are faster on the frame kernel (33 / 30 / 71 us vs 44 / 44 / 133 us).
+		WnFamily FamilyFor(const WaveNetPlan& plan)
+		{
+			const WnFamily o = WaveNetFamilyOverride();
+			if (o != WN_FAMILY_AUTO) return o;
+			return plan.splitFastT == 2 ? WN_FAMILY_SPLIT : WN_FAMILY_FRAME;
 		}
 
 		class WaveNetGroup : public ModelGroup
 		{
 		public:
-			WaveNetGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s) : ModelGroup(d, s), plan(BuildWaveNetPlan(d->wavenet))
+			WaveNetGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s) : ModelGroup(d, s), plan(BuildWaveNetPlan(d->wavenet)), family(FamilyFor(plan))
 			{
 				dStages.Upload(plan.stages, stream);
 				dWpack.Upload(plan.wpack, stream);
@@ -286,7 +298,7 @@ namespace na
 				DevArray<int> list;
 				list.Upload(members, stream);
 				CheckHip(LaunchWaveNetFillRings(state.Get(), plan.stateF4, list.Get(), (int)members.size(), (int)plan.rings.size(),
-					dRingOff.Get(), dRingFrames.Get(), dRingG.Get(), dCols.Get(), stream, WaveNetFamily() == WN_FAMILY_SPLIT), "WaveNetFillRingsKernel");
+					dRingOff.Get(), dRingFrames.Get(), dRingG.Get(), dCols.Get(), stream, family == WN_FAMILY_SPLIT), "WaveNetFillRingsKernel");
 				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize"); // `list` is freed on return
 			}
 
@@ -301,29 +313,23 @@ namespace na
 				while (n > 0)
 				{
 					const int chunk = (int)std::min<size_t>(n, (size_t)WN_MAX_FRAMES);
-					const WnFamily which = WaveNetFamily();
+					const WnFamily which = family;
 					if (which == WN_FAMILY_SPLIT)
 					{
 						const WnFrameGroup g = { &dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0 };
 						CheckHip(LaunchWaveNetSplitFused(&g, 1, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "WaveNetSplitKernel");
 					}
-					else if (which == WN_FAMILY_FRAME)
+					else
 						CheckHip(LaunchWaveNetFrame(dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset,
 							inStride, outStride, chunk, launchStream, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0), "WaveNetFrameKernel");
-					else if (which != WN_FAMILY_PK)
-						CheckHip(LaunchWaveNetBlock(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
-							outStride, chunk, launchStream), "WaveNetBlockKernel");
-					else
-						CheckHip(LaunchWaveNetPk(dev, state.Get(), dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride,
-							outStride, chunk, launchStream), "WaveNetPkKernel");
 					offset += (size_t)chunk;
 					n -= (size_t)chunk;
 				}
 			}
 
-			bool FusedLaunchArgs(WnFrameGroup& out) override
+			bool FusedLaunchArgs(WnFrameGroup& out, bool& splitFamily) override
 			{
-				if (WaveNetFamily() != WN_FAMILY_SPLIT && WaveNetFamily() != WN_FAMILY_FRAME) return false;
+				splitFamily = family == WN_FAMILY_SPLIT;
 				SyncActiveLists();
 				out.model = &dev;
 				out.state = state.Get();
@@ -358,6 +364,7 @@ namespace na
 
 		private:
 			WaveNetPlan plan;
+			const WnFamily family;
 			WnModelDev dev = {};
 			DevArray<WnStage> dStages;
 			DevArray<float> dWpack;
@@ -540,6 +547,17 @@ namespace na
 		groups.clear();
 		if (hostStage) (void)hipHostFree(hostStage);
 		if (devStage) (void)hipFree(devStage);
+		for (PipeSlot& p : pipe)
+		{
+			if (p.hostIn) (void)hipHostFree(p.hostIn);
+			if (p.hostOut) (void)hipHostFree(p.hostOut);
+			if (p.dev) (void)hipFree(p.dev);
+			if (p.uploaded) (void)hipEventDestroy(p.uploaded);
+			if (p.computed) (void)hipEventDestroy(p.computed);
+			if (p.downloaded) (void)hipEventDestroy(p.downloaded);
+		}
+		if (copyIn) (void)hipStreamDestroy(copyIn);
+		if (copyOut) (void)hipStreamDestroy(copyOut);
 		for (auto& e : graphCache) (void)hipGraphExecDestroy(e.exec);
 		if (forkEvent) (void)hipEventDestroy(forkEvent);
 		if (stream && ownsStream) (void)hipStreamDestroy(stream);
@@ -638,20 +656,23 @@ namespace na
 		// Mixed batch.  Groups that can share a launch are fused: all WaveNet groups on the frame kernel into one launch, all LSTM / GRU
 		// groups with an LDS-free kernel instance into another (the workgroups of all architectures share the chip, no fork/join per
 		// group).  What remains are independent "units" (disjoint rows, disjoint state); one unit runs directly on the batch stream.
-		std::vector<WnFrameGroup> fusedWn;
+		std::vector<WnFrameGroup> fusedWn, fusedWnSplit; // frame-kernel groups / f16-split-kernel groups: one launch per family
 		std::vector<RecurrentGroup> fusedRec;
 		std::vector<ModelGroup*> singles;
 		ModelGroup* wnOwner = nullptr;  // lends its side stream / event to the fused unit
+		ModelGroup* wnSplitOwner = nullptr;
 		ModelGroup* recOwner = nullptr;
 		for (auto& g : groups)
 		{
 			if (g->NumActive() == 0) continue;
 			WnFrameGroup a;
 			RecurrentGroup r;
-			if (g->FusedLaunchArgs(a))
+			bool splitFamily = false;
+			if (g->FusedLaunchArgs(a, splitFamily))
 			{
-				fusedWn.push_back(a);
-				if (!wnOwner) wnOwner = g.get();
+				(splitFamily ? fusedWnSplit : fusedWn).push_back(a);
+				ModelGroup*& owner = splitFamily ? wnSplitOwner : wnOwner;
+				if (!owner) owner = g.get();
 			}
 			else if (g->FusedRecurrentArgs(r))
 			{
@@ -664,19 +685,21 @@ namespace na
 				singles.push_back(g.get());
 			}
 		}
-		auto launchWn = [&](hipStream_t s) {
+		auto launchWnFamily = [&](const std::vector<WnFrameGroup>& list, bool splitFamily, hipStream_t s) {
 			size_t offset = 0, left = n;
 			while (left > 0)
 			{
 				const int chunk = (int)std::min<size_t>(left, (size_t)WN_MAX_FRAMES);
-				for (size_t first = 0; first < fusedWn.size(); first += WN_FRAME_MAX_GROUPS)
-					CheckHip((WaveNetFamily() == WN_FAMILY_SPLIT ? LaunchWaveNetSplitFused : LaunchWaveNetFrameFused)(fusedWn.data() + first,
-						(int)std::min<size_t>(fusedWn.size() - first, (size_t)WN_FRAME_MAX_GROUPS), dIn + offset, dOut + offset, inStride, outStride, chunk, s),
+				for (size_t first = 0; first < list.size(); first += WN_FRAME_MAX_GROUPS)
+					CheckHip((splitFamily ? LaunchWaveNetSplitFused : LaunchWaveNetFrameFused)(list.data() + first,
+						(int)std::min<size_t>(list.size() - first, (size_t)WN_FRAME_MAX_GROUPS), dIn + offset, dOut + offset, inStride, outStride, chunk, s),
 						"WaveNet kernel (fused)");
 				offset += (size_t)chunk;
 				left -= (size_t)chunk;
 			}
 		};
+		auto launchWn = [&](hipStream_t s) { launchWnFamily(fusedWn, false, s); };
+		auto launchWnSplit = [&](hipStream_t s) { launchWnFamily(fusedWnSplit, true, s); };
 		auto launchRec = [&](hipStream_t s) {
 			size_t offset = 0, left = n;
 			while (left > 0)
@@ -689,10 +712,11 @@ namespace na
 				left -= (size_t)chunk;
 			}
 		};
-		const size_t units = (fusedWn.empty() ? 0 : 1) + (fusedRec.empty() ? 0 : 1) + singles.size();
+		const size_t units = (fusedWn.empty() ? 0 : 1) + (fusedWnSplit.empty() ? 0 : 1) + (fusedRec.empty() ? 0 : 1) + singles.size();
 		if (units == 1)
 		{
 			if (!fusedWn.empty()) launchWn(stream);
+			else if (!fusedWnSplit.empty()) launchWnSplit(stream);
 			else if (!fusedRec.empty()) launchRec(stream);
 			else singles[0]->Process(dIn, dOut, inStride, outStride, n, stream);
 			return;
@@ -730,6 +754,7 @@ namespace na
 					CheckHip(hipStreamWaitEvent(stream, owner->DoneEvent(), 0), "hipStreamWaitEvent");
 				};
 				if (!fusedWn.empty()) branch(wnOwner, launchWn);
+				if (!fusedWnSplit.empty()) branch(wnSplitOwner, launchWnSplit);
 				if (!fusedRec.empty()) branch(recOwner, launchRec);
 				for (ModelGroup* g : singles) branch(g, [&](hipStream_t s) { g->Process(dIn, dOut, inStride, outStride, n, s); });
 			}
@@ -773,6 +798,64 @@ namespace na
 		CheckHip(hipMemcpyAsync(hostStage, devStage, total * sizeof(float), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H");
 		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 		memcpy(out, hostStage, total * sizeof(float));
+	}
+
+	void GpuBatch::EnsurePipeSlot(PipeSlot& p, size_t floats)
+	{
+		if (!p.uploaded)
+		{
+			CheckHip(hipEventCreateWithFlags(&p.uploaded, hipEventDisableTiming), "hipEventCreate");
+			CheckHip(hipEventCreateWithFlags(&p.computed, hipEventDisableTiming), "hipEventCreate");
+			CheckHip(hipEventCreateWithFlags(&p.downloaded, hipEventDisableTiming), "hipEventCreate");
+		}
+		if (floats <= p.floats) return;
+		if (p.hostIn) (void)hipHostFree(p.hostIn);
+		if (p.hostOut) (void)hipHostFree(p.hostOut);
+		if (p.dev) (void)hipFree(p.dev);
+		p.hostIn = p.hostOut = p.dev = nullptr;
+		p.floats = 0;
+		CheckHip(hipHostMalloc(reinterpret_cast<void**>(&p.hostIn), floats * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+		CheckHip(hipHostMalloc(reinterpret_cast<void**>(&p.hostOut), floats * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+		CheckHip(hipMalloc(reinterpret_cast<void**>(&p.dev), floats * sizeof(float)), "hipMalloc");
+		p.floats = floats;
+	}
+
+	int GpuBatch::Submit(const float* in, size_t n)
+	{
+		if (n == 0 || streams.empty()) throw std::runtime_error("neuralaudio_amd: Submit on an empty batch / buffer");
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		if (!copyIn)
+		{
+			CheckHip(hipStreamCreateWithFlags(&copyIn, hipStreamNonBlocking), "hipStreamCreate");
+			CheckHip(hipStreamCreateWithFlags(&copyOut, hipStreamNonBlocking), "hipStreamCreate");
+		}
+		const int ticket = nextSlot;
+		PipeSlot& p = pipe[ticket];
+		if (p.busy) throw std::runtime_error("neuralaudio_amd: Submit with every pipeline slot in flight (Collect the oldest ticket first)");
+		const size_t total = streams.size() * n;
+		EnsurePipeSlot(p, total);
+		p.n = n;
+		memcpy(p.hostIn, in, total * sizeof(float));
+		CheckHip(hipMemcpyAsync(p.dev, p.hostIn, total * sizeof(float), hipMemcpyHostToDevice, copyIn), "hipMemcpyAsync H2D");
+		CheckHip(hipEventRecord(p.uploaded, copyIn), "hipEventRecord");
+		CheckHip(hipStreamWaitEvent(stream, p.uploaded, 0), "hipStreamWaitEvent");
+		ProcessDevice(p.dev, p.dev, n, (long)n, (long)n);
+		CheckHip(hipEventRecord(p.computed, stream), "hipEventRecord");
+		CheckHip(hipStreamWaitEvent(copyOut, p.computed, 0), "hipStreamWaitEvent");
+		CheckHip(hipMemcpyAsync(p.hostOut, p.dev, total * sizeof(float), hipMemcpyDeviceToHost, copyOut), "hipMemcpyAsync D2H");
+		CheckHip(hipEventRecord(p.downloaded, copyOut), "hipEventRecord");
+		p.busy = true;
+		nextSlot = (nextSlot + 1) % kPipelineSlots;
+		return ticket;
+	}
+
+	void GpuBatch::Collect(int ticket, float* out)
+	{
+		if (ticket < 0 || ticket >= kPipelineSlots || !pipe[ticket].busy) throw std::runtime_error("neuralaudio_amd: Collect with an invalid ticket");
+		PipeSlot& p = pipe[ticket];
+		CheckHip(hipEventSynchronize(p.downloaded), "hipEventSynchronize");
+		memcpy(out, p.hostOut, streams.size() * p.n * sizeof(float));
+		p.busy = false;
 	}
 
 	void GpuBatch::Synchronize()

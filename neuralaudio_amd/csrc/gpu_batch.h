@@ -67,6 +67,14 @@ namespace na
 		// in/out are HOST pointers laid out [streams][n]; stages through pinned buffers; synchronous.
 		void ProcessHost(const float* in, float* out, size_t n);
 
+		// Pipelined host-buffer interface: Submit() copies `in` ([streams][n], host) into a pinned slot and enqueues H2D (copy-in
+		// stream), the kernels (batch stream) and D2H (copy-out stream); Collect() waits for that slot and copies the result out.
+		// With two slots in flight the upload of buffer k+1 and the download of buffer k-1 overlap the kernels of buffer k.
+		// Buffers are processed strictly in submission order (the streams' state depends on it).
+		static constexpr int kPipelineSlots = 3;
+		int Submit(const float* in, size_t n);       // returns a ticket; throws if all slots are in flight
+		void Collect(int ticket, float* out);        // blocks until that buffer is done
+
 		void Synchronize();
 		hipStream_t GetStream() const { return stream; }
 		int GetDevice() const { return device; }
@@ -115,5 +123,19 @@ namespace na
 		float* hostStage = nullptr; // pinned
 		float* devStage = nullptr;
 		size_t stageFloats = 0;
+
+		struct PipeSlot
+		{
+			float* hostIn = nullptr;  // pinned
+			float* hostOut = nullptr; // pinned
+			float* dev = nullptr;
+			size_t floats = 0, n = 0;
+			hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
+			bool busy = false;
+		};
+		PipeSlot pipe[kPipelineSlots];
+		hipStream_t copyIn = nullptr, copyOut = nullptr;
+		int nextSlot = 0;
+		void EnsurePipeSlot(PipeSlot& s, size_t floats);
 	};
 }

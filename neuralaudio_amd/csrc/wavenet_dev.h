@@ -1,5 +1,6 @@
 // wavenet_dev.h -- device-side data model shared by the host packer (wavenet_plan.cpp) and the gfx950 WaveNet kernels
-// (wavenet_frame_kernels.hip = the shipped path; wavenet_kernels.hip and wavenet_pk_kernels.hip = measured alternatives).
+// (wavenet_split_kernels.hip and wavenet_frame_kernels.hip, one per model, see FamilyFor() in gpu_batch.cpp; the tile / packed-FMA
+// fields below belong to the round-1 alternatives kept under tools/alternates/, not built into the library).
 //
 // A WaveNet model (reference: NeuralAudio/WaveNet.h) is lowered at load time into a short "stage program" (WnStage: one per
 // rechannel / layer / array link / head) plus per-kernel weight images.  A workgroup interprets the program for one or two

@@ -1,6 +1,7 @@
 // wavenet_frame_kernels.hip -- the "lane = frame" WaveNet block kernel for gfx950 (v_mfma_f32_4x4x1_16b_f32).
 //
-// Same path, same HBM/LDS data layout and same stage program as wavenet_kernels.hip (reference functions:
+// The f32 kernel of round 1; since round 2 it serves the models the f16-split kernel (wavenet_split_kernels.hip) is not faster on --
+// narrow (<= 4-channel arrays), 12-channel and large-kernel (A2) architectures, see FamilyFor() in gpu_batch.cpp (reference functions:
 // WaveNetModelT/LayerArrayT/LayerT::Process, Conv1DT::Process, DenseLayerT::Process -- NeuralAudio/WaveNet.h:768-799,
 // 632-661,462-494,139-290,336-383; FastMath -- NeuralAudio/Activation.h:83-118), different mapping of the arithmetic:
 //
@@ -16,7 +17,7 @@
 //   * the A operands of a stage (4.3 KB for a 16-channel layer) are staged into LDS one stage ahead; a tap costs ONE LDS read
 //     per lane (16 B for 16 channels) for its C*C/4 MFMAs.
 //
-// Why not the 16x16x4 tile mapping (wavenet_kernels.hip) everywhere: measured on MI355X (tools/microbench/mfma_valu_overlap.hip)
+// Why not the f32 16x16x4 tile mapping (tools/alternates/wavenet_tile_kernels.hip, round 1): measured on MI355X (tools/microbench/mfma_valu_overlap.hip)
 // f32 MFMA runs at the f32 VALU rate and does NOT overlap with VALU work on the same SIMD, so every padded MFMA row and
 // every activation evaluated on a padding lane is pure loss; the tile mapping pads 8-channel layers to 16 rows.
 #include <algorithm>

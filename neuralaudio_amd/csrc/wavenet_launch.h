@@ -1,4 +1,4 @@
-// wavenet_launch.h -- host-callable launchers for the kernels in wavenet_kernels.hip
+// wavenet_launch.h -- host-callable launchers of the WaveNet kernels (wavenet_split_kernels.hip, wavenet_frame_kernels.hip, wavenet_prewarm_kernels.hip)
 #pragma once
 
 #include <hip/hip_runtime_api.h>
@@ -7,16 +7,9 @@
 
 namespace na
 {
-	// One block of n <= 128 frames for `numStreams` streams of one model.
-	//   slots[i]: state slot of active stream i; rows[i]: its row in `in`/`out` (row stride in floats)
-	hipError_t LaunchWaveNetBlock(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
-		float* out, long inStride, long outStride, int n, hipStream_t stream);
-
-	// Same contract as LaunchWaveNetBlock, packed-FMA (lane = frame) kernel (wavenet_pk_kernels.hip)
-	hipError_t LaunchWaveNetPk(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
-		float* out, long inStride, long outStride, int n, hipStream_t stream);
-
-	// Same contract, lane = frame kernel on v_mfma_f32_4x4x1_16b_f32 (wavenet_frame_kernels.hip)
+	// One block of n <= 128 frames for `numStreams` streams of one model:
+	//   slots[i]: state slot of active stream i; rows[i]: its row in `in`/`out` (row stride in floats).
+	// Lane = frame kernel on v_mfma_f32_4x4x1_16b_f32 (wavenet_frame_kernels.hip).
 	// One launch over several model groups (a heterogeneous batch): workgroups are assigned to the groups in order.
 	constexpr int WN_FRAME_MAX_GROUPS = 8;
 	struct WnFrameGroup

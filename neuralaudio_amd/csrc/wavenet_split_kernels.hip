@@ -981,7 +981,7 @@ namespace na
 			if (spb >= 2) NA_SP_LAUNCH(4, 2, 1);
 			NA_SP_LAUNCH(4, 1, 1);
 		}
-		if (tiles > 4) { if (spb >= 2) NA_SP_LAUNCH(2, 2, 4); NA_SP_LAUNCH(2, 1, 4); }
+		if (tiles > 4) { if (spb >= 4) NA_SP_LAUNCH(2, 4, 4); if (spb >= 2) NA_SP_LAUNCH(2, 2, 4); NA_SP_LAUNCH(2, 1, 4); }
 		if (tiles > 2) { if (spb >= 2) NA_SP_LAUNCH(2, 2, 2); NA_SP_LAUNCH(2, 1, 2); }
 		if (spb >= 2) NA_SP_LAUNCH(2, 2, 1);
 		NA_SP_LAUNCH(2, 1, 1);

@@ -1,0 +1,25 @@
+"""Both WaveNet kernel families against the oracle on EVERY architecture.
+
+By default a model runs on the family that is faster for it (FamilyFor() in gpu_batch.cpp: the f16-split kernel for Standard-like
+models, the f32 frame kernel for narrow / 12-channel / large-kernel ones).  NA_WN_KERNEL forces one family for all models; it is read
+once per process, so each forced run is a subprocess of the same parity + fuzz + batch test files."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("env", [{"NA_WN_KERNEL": "split"}, {"NA_WN_KERNEL": "split", "NA_SP_T": "4"}, {"NA_WN_KERNEL": "split", "NA_SP_GEN": "1"},
+                                 {"NA_WN_KERNEL": "frame"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_forced_family_passes_parity_fuzz_and_batch_suites(env):
+    if os.environ.get("NA_WN_KERNEL"):
+        pytest.skip("already inside a forced-family run")
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_fuzz.py"), os.path.join(ROOT, "tests", "test_gpu_batch.py")],
+                       env=e, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

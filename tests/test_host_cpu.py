@@ -99,7 +99,7 @@ def test_modeltest_host_builds_and_reports_a_missing_gpu(na):
 def test_library_embeds_gfx950_code_object(na):
     from neuralaudio_amd import capi
     data = open(capi.LIB_PATH, "rb").read()
-    assert b"gfx950" in data and b"WaveNetBlockKernel" in data and b"LstmBlockKernel" in data
+    assert b"gfx950" in data and b"WaveNetSplitKernel" in data and b"WaveNetFrameKernel" in data and b"LstmBlockKernel" in data
 
 
 @pytest.mark.parametrize("name", ["BossWN-standard.nam", "BossWN-feather.nam", "BossWN-nano.nam", "BossWN-a2.nam",
