@@ -62,6 +62,8 @@ NA_EXTERN int NA_BatchAddStreams(NA_Batch* batch, NeuralModel* model, float qual
 NA_EXTERN int NA_BatchNumStreams(NA_Batch* batch);
 NA_EXTERN int NA_BatchSetQuality(NA_Batch* batch, int stream, float quality);
 NA_EXTERN int NA_BatchGetActiveSubModel(NA_Batch* batch, int stream);
+/* 1 when NA_BatchSetQuality(stream, quality) costs the next NA_BatchProcess* call no allocation / synchronisation / prewarm */
+NA_EXTERN int NA_BatchIsQualityChangeRealtimeSafe(NA_Batch* batch, int stream, float quality);
 NA_EXTERN int NA_BatchPrewarm(NA_Batch* batch, int stream); /* stream < 0: all */
 /* host pointers, layout [streams][n]; synchronous */
 NA_EXTERN int NA_BatchProcess(NA_Batch* batch, const float* in, float* out, size_t n);
@@ -70,6 +72,11 @@ NA_EXTERN int NA_BatchProcess(NA_Batch* batch, const float* in, float* out, size
  * `out`.  Uploads / downloads of neighbouring buffers overlap the kernels.  Buffers are processed in submission order. */
 NA_EXTERN int NA_BatchSubmit(NA_Batch* batch, const float* in, size_t n);
 NA_EXTERN int NA_BatchCollect(NA_Batch* batch, int ticket, float* out);
+/* Zero-copy variants: NA_BatchNextInput returns the pinned [streams][n] staging buffer of the next submission -- fill it, then call
+ * NA_BatchSubmit(batch, NULL, n); NA_BatchCollect(batch, ticket, NULL) only waits, and NA_BatchOutputView(batch, ticket) is the pinned
+ * result, valid until that slot is submitted again (3 submissions later). */
+NA_EXTERN float* NA_BatchNextInput(NA_Batch* batch, size_t n);
+NA_EXTERN const float* NA_BatchOutputView(NA_Batch* batch, int ticket);
 /* DEVICE pointers, row s = stream s, rows `stride` floats apart; asynchronous on the batch's stream */
 NA_EXTERN int NA_BatchProcessDevice(NA_Batch* batch, const float* dIn, float* dOut, size_t n, long inStride, long outStride);
 NA_EXTERN int NA_BatchSynchronize(NA_Batch* batch);

@@ -215,6 +215,9 @@ class Batch:
         if self._lib.NA_BatchSetQuality(self._h, int(stream), float(q)) != 0:
             raise NeuralAudioError(capi.last_error())
 
+    def IsQualityChangeRealtimeSafe(self, stream, q):
+        return bool(self._lib.NA_BatchIsQualityChangeRealtimeSafe(self._h, int(stream), float(q)))
+
     def GetActiveSubModel(self, stream):
         return int(self._lib.NA_BatchGetActiveSubModel(self._h, int(stream)))
 
@@ -246,6 +249,26 @@ class Batch:
         if self._lib.NA_BatchCollect(self._h, int(t), _fptr(y)) != 0:
             raise NeuralAudioError(capi.last_error())
         return y
+
+    def NextInput(self, n):
+        """Zero-copy: a numpy view [streams, n] of the pinned staging buffer of the next submission; fill it, then SubmitInput(n)."""
+        p = self._lib.NA_BatchNextInput(self._h, int(n))
+        if not p:
+            raise NeuralAudioError(capi.last_error())
+        return np.ctypeslib.as_array(p, shape=(self.NumStreams(), int(n)))
+
+    def SubmitInput(self, n):
+        t = self._lib.NA_BatchSubmit(self._h, None, int(n))
+        if t < 0:
+            raise NeuralAudioError(capi.last_error())
+        return t, (self.NumStreams(), int(n))
+
+    def CollectView(self, ticket):
+        """Zero-copy: waits for the buffer and returns a numpy view of the pinned result (valid for the next 2 submissions)."""
+        t, shape = ticket
+        if self._lib.NA_BatchCollect(self._h, int(t), None) != 0:
+            raise NeuralAudioError(capi.last_error())
+        return np.ctypeslib.as_array(self._lib.NA_BatchOutputView(self._h, int(t)), shape=shape)
 
     def ProcessDevice(self, d_in, d_out, n, in_stride=None, out_stride=None):
         """d_in / d_out: raw device pointers (ints); asynchronous on the batch's HIP stream."""

@@ -26,7 +26,7 @@ NA_SYMBOLS = [
     "NA_BatchSetQuality", "NA_BatchGetActiveSubModel", "NA_BatchPrewarm", "NA_BatchProcess", "NA_BatchProcessDevice",
     "NA_BatchSynchronize", "NA_BatchGetHipStream", "NA_BatchAlgorithmicBytesPerSample", "NA_BatchMacsPerSample",
     "NA_BatchStateBytes", "NA_DebugSetTraceBuffer", "NA_SetWaveNetMathMode", "NA_SetLSTMMathMode", "NA_SetCompositeModelLoadMode",
-    "NA_IsQualityChangeRealtimeSafe", "NA_ProcessChecked", "NA_BatchSubmit", "NA_BatchCollect",
+    "NA_IsQualityChangeRealtimeSafe", "NA_ProcessChecked", "NA_BatchSubmit", "NA_BatchCollect", "NA_BatchNextInput", "NA_BatchOutputView", "NA_BatchIsQualityChangeRealtimeSafe",
 ]
 
 _lib = None
@@ -96,6 +96,9 @@ def load_library():
         "NA_ProcessChecked": (C.c_int, [vp, fp, fp, C.c_size_t]),
         "NA_BatchSubmit": (C.c_int, [vp, fp, C.c_size_t]),
         "NA_BatchCollect": (C.c_int, [vp, C.c_int, fp]),
+        "NA_BatchNextInput": (fp, [vp, C.c_size_t]),
+        "NA_BatchOutputView": (fp, [vp, C.c_int]),
+        "NA_BatchIsQualityChangeRealtimeSafe": (C.c_int, [vp, C.c_int, C.c_float]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

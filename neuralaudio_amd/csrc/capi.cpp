@@ -320,7 +320,7 @@ int NA_BatchAddStreams(NA_Batch* batch, NeuralModel* model, float quality, int c
 		if (!batch || !model || count < 1) throw std::runtime_error("NA_BatchAddStreams: bad argument");
 		NeuralAudio::GpuModel* gm = dynamic_cast<NeuralAudio::GpuModel*>(model->model);
 		if (!gm) throw std::runtime_error("NA_BatchAddStreams: model was not created by this library");
-		first = batch->batch->AddStreams(gm->GetLoadedModel(), quality, count, doPrewarm != 0);
+		first = batch->batch->AddStreams(gm->GetLoadedModel(), quality, count, doPrewarm != 0, gm->IsOnDemand());
 	});
 	return rc == 0 ? first : -1;
 }
@@ -331,6 +331,14 @@ int NA_BatchSetQuality(NA_Batch* batch, int stream, float quality)
 {
 	if (!batch) return -1;
 	return Guard([&] { batch->batch->SetQuality(stream, quality); });
+}
+
+int NA_BatchIsQualityChangeRealtimeSafe(NA_Batch* batch, int stream, float quality)
+{
+	int safe = 0;
+	if (!batch) return 0;
+	Guard([&] { safe = batch->batch->IsQualityChangeRealtimeSafe(stream, quality) ? 1 : 0; });
+	return safe;
 }
 
 int NA_BatchGetActiveSubModel(NA_Batch* batch, int stream)
@@ -369,6 +377,22 @@ int NA_BatchCollect(NA_Batch* batch, int ticket, float* out)
 {
 	if (!batch) return -1;
 	return Guard([&] { batch->batch->Collect(ticket, out); });
+}
+
+float* NA_BatchNextInput(NA_Batch* batch, size_t n)
+{
+	float* ptr = nullptr;
+	if (!batch) return nullptr;
+	Guard([&] { ptr = batch->batch->NextInput(n); });
+	return ptr;
+}
+
+const float* NA_BatchOutputView(NA_Batch* batch, int ticket)
+{
+	const float* ptr = nullptr;
+	if (!batch) return nullptr;
+	Guard([&] { ptr = batch->batch->OutputView(ticket); });
+	return ptr;
 }
 
 int NA_BatchProcessDevice(NA_Batch* batch, const float* dIn, float* dOut, size_t n, long inStride, long outStride)

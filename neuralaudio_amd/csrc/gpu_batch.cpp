@@ -94,6 +94,11 @@ namespace na
 		{
 			if (sideStream) (void)hipStreamDestroy(sideStream);
 			if (doneEvent) (void)hipEventDestroy(doneEvent);
+			for (int b = 0; b < 2; b++)
+			{
+				if (pinnedLists[b]) (void)hipHostFree(pinnedLists[b]);
+				if (listEvent[b]) (void)hipEventDestroy(listEvent[b]);
+			}
 		}
 
 		// created on first use: lets independent model groups of a mixed batch run concurrently
@@ -115,6 +120,7 @@ namespace na
 		{
 			const int member = (int)memberRow.size();
 			EnsureCapacity(member + 1);
+			EnsureListCapacity((size_t)member + 1);
 			memberRow.push_back(-1);
 			return member;
 		}
@@ -159,7 +165,10 @@ namespace na
 			return c;
 		}
 
-		// upload the active-stream lists if they changed (host -> device copy + sync: never inside a graph capture)
+		// Upload the active-stream lists if they changed.  Real-time safe: everything it touches was allocated when the members were
+		// added (AddMember is the non-real-time side); the copy is asynchronous on the batch stream from one of two pinned staging
+		// buffers, so a quality switch costs the audio thread two small enqueues and no synchronisation (the reference switches an
+		// atomic index, CompositeModel.h:49-63).  Never called inside a graph capture.
 		void SyncActiveLists()
 		{
 			if (!activeDirty) return;
@@ -173,8 +182,20 @@ namespace na
 					hRows.push_back(memberRow[m]);
 				}
 			}
-			dSlots.Upload(hSlots, stream);
-			dRows.Upload(hRows, stream);
+			if (!hSlots.empty())
+			{
+				listFlip ^= 1;
+				int* pin = pinnedLists[listFlip];
+				// the copy issued from this buffer two switches ago: long finished unless the host is far ahead of the device
+				if (listEvent[listFlip]) CheckHip(hipEventSynchronize(listEvent[listFlip]), "hipEventSynchronize");
+				else CheckHip(hipEventCreateWithFlags(&listEvent[listFlip], hipEventDisableTiming), "hipEventCreate");
+				const size_t nA = hSlots.size();
+				memcpy(pin, hSlots.data(), nA * sizeof(int));
+				memcpy(pin + listCapacity, hRows.data(), nA * sizeof(int));
+				CheckHip(hipMemcpyAsync(dSlots.Get(), pin, nA * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+				CheckHip(hipMemcpyAsync(dRows.Get(), pin + listCapacity, nA * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+				CheckHip(hipEventRecord(listEvent[listFlip], stream), "hipEventRecord");
+			}
 			contiguous = !hSlots.empty();
 			for (size_t i = 1; i < hSlots.size() && contiguous; i++)
 				contiguous = hSlots[i] == hSlots[0] + (int)i && hRows[i] == hRows[0] + (int)i;
@@ -184,12 +205,36 @@ namespace na
 	protected:
 		virtual void EnsureCapacity(int members) = 0;
 
+		// index lists (device + two pinned staging buffers) sized for every member: grown here, on the AddStreams side only
+		void EnsureListCapacity(size_t members)
+		{
+			if (members <= listCapacity) return;
+			const size_t cap = std::max<size_t>(members, std::max<size_t>(listCapacity * 2, 64));
+			CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+			dSlots.Alloc(cap);
+			dRows.Alloc(cap);
+			for (int b = 0; b < 2; b++)
+			{
+				if (pinnedLists[b]) (void)hipHostFree(pinnedLists[b]);
+				pinnedLists[b] = nullptr;
+				CheckHip(hipHostMalloc(reinterpret_cast<void**>(&pinnedLists[b]), 2 * cap * sizeof(int), hipHostMallocDefault), "hipHostMalloc");
+			}
+			hSlots.reserve(cap);
+			hRows.reserve(cap);
+			listCapacity = cap;
+			activeDirty = true;
+		}
+
 		hipStream_t stream;
 		hipStream_t sideStream = nullptr;
 		hipEvent_t doneEvent = nullptr;
 		std::vector<int> memberRow; // member == state slot
 		std::vector<int> hSlots, hRows;
 		DevArray<int> dSlots, dRows;
+		int* pinnedLists[2] = { nullptr, nullptr }; // [slots | rows], listCapacity ints each
+		hipEvent_t listEvent[2] = { nullptr, nullptr };
+		size_t listCapacity = 0;
+		int listFlip = 0;
 		bool contiguous = false; // active streams are slot0+i / row0+i: kernels may skip the index arrays
 		bool activeDirty = true;
 	};
@@ -576,12 +621,12 @@ namespace na
 		return groups.back().get();
 	}
 
-	int GpuBatch::AddStream(const std::shared_ptr<const LoadedModel>& model, float quality, bool prewarm)
+	int GpuBatch::AddStream(const std::shared_ptr<const LoadedModel>& model, float quality, bool prewarm, bool onDemand)
 	{
-		return AddStreams(model, quality, 1, prewarm);
+		return AddStreams(model, quality, 1, prewarm, onDemand);
 	}
 
-	int GpuBatch::AddStreams(const std::shared_ptr<const LoadedModel>& model, float quality, int count, bool prewarm)
+	int GpuBatch::AddStreams(const std::shared_ptr<const LoadedModel>& model, float quality, int count, bool prewarm, bool onDemand)
 	{
 		if (!model || model->subModels.empty()) throw std::runtime_error("neuralaudio_amd: AddStream with an empty model");
 		if (count < 1) throw std::runtime_error("neuralaudio_amd: AddStreams with count < 1");
@@ -599,6 +644,8 @@ namespace na
 			ref.model = model;
 			ref.quality = quality;
 			ref.active = active;
+			ref.onDemand = onDemand;
+			ref.prewarmed.assign(numSub, 0);
 			const int row = first + i;
 			for (size_t k = 0; k < numSub; k++)
 			{
@@ -609,11 +656,14 @@ namespace na
 			ref.members[(size_t)active].first->SetActive(ref.members[(size_t)active].second, row);
 			streams.push_back(ref);
 		}
-		// fresh state for every new member, then (LoadAll semantics, CompositeModel.h:111-118) prewarm every submodel
+		// fresh state for every new member, then prewarm: every submodel (LoadAll, CompositeModel.h:111-118) or only the active one
+		// (OnDemand, :104-109 -- the others are prewarmed when a quality change first selects them, :52-60)
 		for (size_t k = 0; k < numSub; k++)
 		{
 			subGroups[k]->Reset(newMembers[k]);
-			if (prewarm) subGroups[k]->Prewarm(newMembers[k]);
+			const bool now = prewarm && (!onDemand || (int)k == active);
+			if (now) subGroups[k]->Prewarm(newMembers[k]);
+			for (int i = 0; i < count; i++) streams[(size_t)(first + i)].prewarmed[k] = now ? 1 : 0;
 		}
 		return first;
 	}
@@ -629,6 +679,28 @@ namespace na
 		ref.active = idx;
 		ref.members[(size_t)idx].first->SetActive(ref.members[(size_t)idx].second, s);
 		topologyVersion++;
+		if (ref.onDemand && !ref.prewarmed[(size_t)idx])
+		{
+			// CompositeModel::SetCurrentModelIndex (CompositeModel.h:52-60): first use of this submodel -- NOT real-time safe, which
+			// IsQualityChangeRealtimeSafe() reports beforehand
+			CheckHip(hipSetDevice(device), "hipSetDevice");
+			ref.members[(size_t)idx].first->Prewarm({ ref.members[(size_t)idx].second });
+			ref.prewarmed[(size_t)idx] = 1;
+		}
+	}
+
+	bool GpuBatch::IsQualityChangeRealtimeSafe(int s, float quality) const
+	{
+		const StreamRef& ref = streams.at((size_t)s);
+		if (!ref.model->isComposite) return true;
+		const int idx = ref.model->ModelIndexFromQuality(quality);
+		if (idx == ref.active) return true;
+		if (ref.onDemand && !ref.prewarmed[(size_t)idx]) return false; // would prewarm (CompositeModel.h:44-50)
+		// a switch re-uploads two pinned index lists asynchronously; only a batch that forks several launch units per buffer has to
+		// re-capture its hipGraph
+		int units = 0;
+		for (const auto& g : groups) units += (g->NumActive() > 0 || g.get() == ref.members[(size_t)idx].first) ? 1 : 0;
+		return units <= 1 || allGroupsFuse;
 	}
 
 	float GpuBatch::GetQuality(int s) const { return streams.at((size_t)s).quality; }
@@ -638,8 +710,13 @@ namespace na
 	{
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		StreamRef& ref = streams.at((size_t)s);
-		// LoadAll semantics (CompositeModel.h:111-118): every submodel is prewarmed
-		for (auto& m : ref.members) m.first->Prewarm({ m.second });
+		// LoadAll: every submodel is prewarmed (CompositeModel.h:111-118); OnDemand: the current one (:104-109)
+		for (size_t k = 0; k < ref.members.size(); k++)
+		{
+			if (ref.onDemand && (int)k != ref.active) continue;
+			ref.members[k].first->Prewarm({ ref.members[k].second });
+			ref.prewarmed[k] = 1;
+		}
 	}
 
 	void GpuBatch::ProcessDevice(const float* dIn, float* dOut, size_t n, long inStride, long outStride)
@@ -650,6 +727,7 @@ namespace na
 		for (auto& g : groups) activeGroups += (g->NumActive() > 0);
 		if (activeGroups <= 1)
 		{
+			allGroupsFuse = true;
 			for (auto& g : groups) g->Process(dIn, dOut, inStride, outStride, n, stream);
 			return;
 		}
@@ -713,6 +791,7 @@ namespace na
 			}
 		};
 		const size_t units = (fusedWn.empty() ? 0 : 1) + (fusedWnSplit.empty() ? 0 : 1) + (fusedRec.empty() ? 0 : 1) + singles.size();
+		allGroupsFuse = units == 1;
 		if (units == 1)
 		{
 			if (!fusedWn.empty()) launchWn(stream);
@@ -835,7 +914,7 @@ namespace na
 		const size_t total = streams.size() * n;
 		EnsurePipeSlot(p, total);
 		p.n = n;
-		memcpy(p.hostIn, in, total * sizeof(float));
+		if (in) memcpy(p.hostIn, in, total * sizeof(float)); // nullptr: the caller filled NextInput() in place
 		CheckHip(hipMemcpyAsync(p.dev, p.hostIn, total * sizeof(float), hipMemcpyHostToDevice, copyIn), "hipMemcpyAsync H2D");
 		CheckHip(hipEventRecord(p.uploaded, copyIn), "hipEventRecord");
 		CheckHip(hipStreamWaitEvent(stream, p.uploaded, 0), "hipStreamWaitEvent");
@@ -854,8 +933,24 @@ namespace na
 		if (ticket < 0 || ticket >= kPipelineSlots || !pipe[ticket].busy) throw std::runtime_error("neuralaudio_amd: Collect with an invalid ticket");
 		PipeSlot& p = pipe[ticket];
 		CheckHip(hipEventSynchronize(p.downloaded), "hipEventSynchronize");
-		memcpy(out, p.hostOut, streams.size() * p.n * sizeof(float));
+		if (out) memcpy(out, p.hostOut, streams.size() * p.n * sizeof(float)); // nullptr: the caller reads OutputView() in place
 		p.busy = false;
+	}
+
+	float* GpuBatch::NextInput(size_t n)
+	{
+		if (n == 0 || streams.empty()) throw std::runtime_error("neuralaudio_amd: NextInput on an empty batch / buffer");
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		PipeSlot& p = pipe[nextSlot];
+		if (p.busy) throw std::runtime_error("neuralaudio_amd: NextInput with every pipeline slot in flight (Collect the oldest ticket first)");
+		EnsurePipeSlot(p, streams.size() * n);
+		return p.hostIn;
+	}
+
+	const float* GpuBatch::OutputView(int ticket) const
+	{
+		if (ticket < 0 || ticket >= kPipelineSlots) throw std::runtime_error("neuralaudio_amd: OutputView with an invalid ticket");
+		return pipe[ticket].hostOut;
 	}
 
 	void GpuBatch::Synchronize()

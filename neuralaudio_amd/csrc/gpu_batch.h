@@ -45,15 +45,20 @@ namespace na
 
 		// Adds a stream running `model`; its row in the [streams][n] input/output arrays is the returned id.
 		// For a SlimmableContainer every submodel gets state, `quality` picks the active one.
-		int AddStream(const std::shared_ptr<const LoadedModel>& model, float quality, bool prewarm);
+		// onDemand = ECompositeModelLoadMode::OnDemand (CompositeModel.h:104-109): only the active submodel is prewarmed now, the
+		// others when a quality change first selects them.
+		int AddStream(const std::shared_ptr<const LoadedModel>& model, float quality, bool prewarm, bool onDemand = false);
 		// `count` streams of the same model at once (one state reset / prewarm launch per model group); returns the first id
-		int AddStreams(const std::shared_ptr<const LoadedModel>& model, float quality, int count, bool prewarm);
+		int AddStreams(const std::shared_ptr<const LoadedModel>& model, float quality, int count, bool prewarm, bool onDemand = false);
 
 		int NumStreams() const { return (int)streams.size(); }
 
 		// ScalableCompositeModel::SetQualityScaleFactor (CompositeModel.h:176-181): switches the active submodel,
 		// the inactive one keeps its state untouched.
 		void SetQuality(int stream, float quality);
+		// CompositeModel::IsModelChangeRealtimeSafe (CompositeModel.h:44-50) for this engine: false when the switch would prewarm a
+		// submodel (OnDemand) or force a hipGraph re-capture; true when it only re-uploads the pinned index lists asynchronously
+		bool IsQualityChangeRealtimeSafe(int stream, float quality) const;
 		float GetQuality(int stream) const;
 		int GetActiveSubModel(int stream) const;
 
@@ -74,6 +79,11 @@ namespace na
 		static constexpr int kPipelineSlots = 3;
 		int Submit(const float* in, size_t n);       // returns a ticket; throws if all slots are in flight
 		void Collect(int ticket, float* out);        // blocks until that buffer is done
+		// Zero-copy variants: the caller writes the next buffer straight into the pinned staging memory the upload reads
+		// (NextInput, then Submit(nullptr, n)) and reads results in place (Collect(ticket, nullptr), then OutputView: valid until
+		// that slot is submitted again, kPipelineSlots submissions later).
+		float* NextInput(size_t n);
+		const float* OutputView(int ticket) const;
 
 		void Synchronize();
 		hipStream_t GetStream() const { return stream; }
@@ -91,7 +101,10 @@ namespace na
 			std::vector<std::pair<ModelGroup*, int>> members; // per submodel: (group, member index)
 			int active = 0;
 			float quality = 1.0f;
+			bool onDemand = false;
+			std::vector<char> prewarmed; // per submodel: had its initial prewarm
 		};
+		bool allGroupsFuse = false; // set by ProcessDevice: the batch runs as ONE launch per buffer (no hipGraph involved)
 
 		ModelGroup* GroupFor(const std::shared_ptr<const ModelDesc>& desc);
 		void EnsureStaging(size_t floats);

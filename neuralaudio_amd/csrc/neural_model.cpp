@@ -30,6 +30,8 @@ namespace NeuralAudio
 		// ScalableCompositeModel::CreateModelFromNAMJson ends with SetQualityScaleFactor(default) (CompositeModel.h:155)
 		quality = model->isComposite ? loader->GetDefaultQualityScaleFactor() : 1.0f;
 		activeIndex = model->isComposite ? model->ModelIndexFromQuality(quality) : 0;
+		appliedQuality = quality;
+		onDemand = loader->GetCompositeModelLoadMode() == ECompositeModelLoadMode::OnDemand; // CompositeModel.h:139
 	}
 
 	GpuModel::~GpuModel() {}
@@ -40,40 +42,52 @@ namespace NeuralAudio
 		// build aside and publish only once the stream exists: a throwing AddStream (no device, HIP error) must not leave a batch
 		// with zero streams behind, or every later Process() would silently write nothing
 		std::unique_ptr<na::GpuBatch> fresh(new na::GpuBatch(device));
-		fresh->AddStream(model, quality, prewarmPending);
+		appliedQuality = quality.load();
+		fresh->AddStream(model, appliedQuality, prewarmPending, onDemand);
 		batch = std::move(fresh);
 		prewarmPending = false;
 	}
 
 	bool GpuModel::HasQualityScaling() { return model->isComposite; }
 
-	float GpuModel::GetQualityScaleFactor() { return model->isComposite ? quality : 1.0f; }
+	float GpuModel::GetQualityScaleFactor() { return model->isComposite ? quality.load() : 1.0f; }
 
+	// CompositeModel::IsModelChangeRealtimeSafe (CompositeModel.h:44-50): a switch to a submodel that already had its prewarm only
+	// re-uploads two pinned index lists asynchronously on the next Process() (no allocation, no synchronisation); in OnDemand mode
+	// the first switch to a submodel prewarms it, which is not real-time safe.  Before any device state exists there is nothing to
+	// switch yet (the first Process()/Prewarm() builds it, and that call is the non-real-time one).
 	bool GpuModel::IsQualityChangeRealtimeSafe(float newScaleFactor)
 	{
-		// LoadAll semantics: every submodel has state and was prewarmed (CompositeModel.h:44-50); what a switch
-		// costs here is one small host->device index-list upload on the next Process().
-		(void)newScaleFactor;
-		return true;
+		if (!model->isComposite) return true;
+		if (!batch) return !onDemand || model->ModelIndexFromQuality(newScaleFactor) == activeIndex.load();
+		return batch->IsQualityChangeRealtimeSafe(0, newScaleFactor);
 	}
 
+	// May be called from another thread than Process(): stores only (see neural_model_impl.h)
 	void GpuModel::SetQualityScaleFactor(float scaleFactor)
 	{
 		if (!model->isComposite) return;
-		quality = scaleFactor;
-		activeIndex = model->ModelIndexFromQuality(scaleFactor);
-		if (batch) batch->SetQuality(0, scaleFactor);
+		quality.store(scaleFactor);
+		activeIndex.store(model->ModelIndexFromQuality(scaleFactor));
+	}
+
+	void GpuModel::ApplyPendingQuality()
+	{
+		const float q = quality.load();
+		if (q == appliedQuality) return;
+		appliedQuality = q;
+		batch->SetQuality(0, q);
 	}
 
 	bool GpuModel::IsStatic()
 	{
-		const na::ModelDesc& d = *model->subModels[(size_t)activeIndex].desc;
+		const na::ModelDesc& d = *model->subModels[(size_t)activeIndex.load()].desc;
 		return d.kind == na::MODEL_WAVENET ? d.wavenet.isStatic : d.lstm.isStatic;
 	}
 
 	int GpuModel::GetReceptiveFieldSize()
 	{
-		const na::ModelDesc& d = *model->subModels[(size_t)activeIndex].desc;
+		const na::ModelDesc& d = *model->subModels[(size_t)activeIndex.load()].desc;
 		return d.kind == na::MODEL_WAVENET ? d.wavenet.ReceptiveFieldSize() : -1;
 	}
 
@@ -81,6 +95,7 @@ namespace NeuralAudio
 	{
 		if (numSamples == 0) return;
 		EnsureDeviceState();
+		ApplyPendingQuality();
 		batch->ProcessHost(input, output, numSamples);
 	}
 
@@ -92,6 +107,7 @@ namespace NeuralAudio
 			EnsureDeviceState();
 			return;
 		}
+		ApplyPendingQuality();
 		batch->Prewarm(0);
 	}
 

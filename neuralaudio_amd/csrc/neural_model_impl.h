@@ -1,6 +1,7 @@
 // neural_model_impl.h -- concrete NeuralModel of this implementation (internal header).
 #pragma once
 
+#include <atomic>
 #include <memory>
 
 #include <NeuralAudio/NeuralModel.h>
@@ -28,15 +29,22 @@ namespace NeuralAudio
 		// host-side model, shareable with a many-stream na::GpuBatch
 		const std::shared_ptr<const na::LoadedModel>& GetLoadedModel() const { return model; }
 		int GetDevice() const { return device; }
+		bool IsOnDemand() const { return onDemand; }
 
 	private:
 		void EnsureDeviceState();
 
 		std::shared_ptr<const na::LoadedModel> model;
 		std::unique_ptr<na::GpuBatch> batch;
+		void ApplyPendingQuality(); // audio thread: hand the latest requested quality to the batch
+
 		int device;
-		float quality = 1.0f;
-		int activeIndex = 0;
+		// SetQualityScaleFactor may come from another thread than Process (CompositeModel.h:122,196-197 keeps atomics for that): the
+		// setter only stores; the audio thread applies the switch at the top of its next Process().
+		std::atomic<float> quality{ 1.0f };
+		std::atomic<int> activeIndex{ 0 };
+		float appliedQuality = 1.0f; // audio thread only
+		bool onDemand = false;
 		bool prewarmPending;
 	};
 }

@@ -236,3 +236,245 @@ def test_zero_input_stays_at_steady_state(na, loader):
     y = np.concatenate([m.Process(np.zeros(128, np.float32)) for _ in range(40)])   # > receptive field
     assert np.max(np.abs(y - y[0])) < 1e-6
     assert abs(y[0] - O.oracle_from_file("BossWN-standard.nam").process(np.zeros(4, np.float32))[0]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ round 2 additions
+
+def test_pipelined_submit_collect_matches_process(na, loader):
+    """NA_BatchSubmit / NA_BatchCollect (upload, kernels and download of neighbouring buffers overlap) and the zero-copy pinned
+    variants give bit-for-bit what the synchronous NA_BatchProcess gives."""
+    m = loader.CreateFromFile(_path("BossWN-feather.nam"), doPrewarm=False)
+    S, n, blocks = 48, 128, 9
+    x = np.stack([O.signal_noise(n * blocks, 900 + s) for s in range(S)])
+    ref = na.Batch(0)
+    ref.AddStreams(m, S)
+    want = _run_blocks(ref, x, n)
+    b = na.Batch(0)
+    b.AddStreams(m, S)
+    tickets, got = [], []
+    for i in range(blocks):
+        tickets.append(b.Submit(x[:, i * n:(i + 1) * n]))
+        if len(tickets) == 3:  # at most 3 in flight
+            got.append(b.Collect(tickets.pop(0)))
+    while tickets:
+        got.append(b.Collect(tickets.pop(0)))
+    assert np.array_equal(np.concatenate(got, axis=1), want)
+    with pytest.raises(na.NeuralAudioError):
+        b.Collect((0, (S, n)))  # nothing in flight any more
+    z = na.Batch(0)
+    z.AddStreams(m, S)
+    tickets, got = [], []
+    for i in range(blocks):
+        z.NextInput(n)[:] = x[:, i * n:(i + 1) * n]
+        tickets.append(z.SubmitInput(n))
+        if len(tickets) == 2:
+            got.append(z.CollectView(tickets.pop(0)).copy())
+    while tickets:
+        got.append(z.CollectView(tickets.pop(0)).copy())
+    assert np.array_equal(np.concatenate(got, axis=1), want)
+    for k in range(3):
+        z.Submit(x[:, :n])
+    with pytest.raises(na.NeuralAudioError, match="every pipeline slot in flight"):
+        z.Submit(x[:, :n])
+
+
+def test_quality_switch_every_buffer_2048_a2_streams_is_cheap(na, loader):
+    """BASELINE configs[4] size on one GPU (2048 A2 streams): flipping the quality of HALF the streams before EVERY buffer must stay a
+    real-time operation -- the active-stream lists travel from pinned memory asynchronously, nothing is allocated, synchronised or
+    re-captured.  p99 per-buffer latency through the host-buffer entry point < 1 ms (the north star's bound), and the switch is
+    reported real-time safe (LoadAll: every submodel was prewarmed, CompositeModel.h:44-50)."""
+    import time
+    m = loader.CreateFromFile(_path("BossWN-a2.nam"), doPrewarm=False)
+    S, n = 2048, 128
+    b = na.Batch(0)
+    b.AddStreams(m, S, quality=1.0)
+    x = np.stack([O.signal_noise(n, 40 + (s % 16)) for s in range(S)])
+    for _ in range(5):
+        b.Process(x)
+    assert b.IsQualityChangeRealtimeSafe(0, 0.0) and b.IsQualityChangeRealtimeSafe(0, 1.0)
+    lat = []
+    for it in range(120):
+        q = 0.0 if it % 2 == 0 else 1.0
+        for s in range(0, S, 2):
+            b.SetQuality(s, q)
+        t0 = time.perf_counter()
+        y = b.Process(x)
+        lat.append((time.perf_counter() - t0) * 1e3)
+        assert b.GetActiveSubModel(0) == (0 if q == 0.0 else 1) and b.GetActiveSubModel(1) == 1
+    lat = sorted(lat[10:])
+    assert np.all(np.isfinite(y))
+    assert lat[int(len(lat) * 0.99)] < 1.0, lat[-5:]
+
+
+def test_a2_stream_with_switches_matches_two_oracles(na, loader):
+    """A stream that alternates between the two A2 submodels: each submodel only advances while it is active (CompositeModel::Process,
+    CompositeModel.h:94-100), so its output equals an oracle of that submodel fed only the buffers it was active for."""
+    m = loader.CreateFromFile(_path("BossWN-a2.nam"))
+    b = na.Batch(0)
+    b.AddStreams(m, 3, quality=1.0)
+    n, blocks = 128, 16
+    x = O.signal_noise(n * blocks, 77)
+    ora = {0: O.oracle_from_file("BossWN-a2.nam", quality=0.0), 1: O.oracle_from_file("BossWN-a2.nam", quality=1.0)}
+    for i in range(blocks):
+        q = 1.0 if (i // 3) % 2 == 0 else 0.2
+        b.SetQuality(1, q)
+        xb = x[i * n:(i + 1) * n]
+        y = b.Process(np.stack([xb, xb, xb]))
+        idx = b.GetActiveSubModel(1)
+        assert idx == (1 if q == 1.0 else 0)
+        assert O.rms(y[1] - ora[idx].process(xb)) < TOL_RMS, i
+
+
+def test_ondemand_composite_load_mode(na):
+    """ECompositeModelLoadMode::OnDemand (CompositeModel.h:52-60,104-109): only the current submodel is prewarmed at load; the first
+    switch to another one prewarms it (not real-time safe, reported beforehand) and from then on switching is real-time safe.  The
+    audio is the same as with LoadAll: a submodel that was never run sits at its prewarmed state either way."""
+    ld = na.NeuralModelLoader()
+    ld.SetCompositeModelLoadMode(na.ECompositeModelLoadMode.OnDemand)
+    ld.SetDefaultQualityScaleFactor(1.0)
+    m = ld.CreateFromFile(_path("BossWN-a2.nam"))
+    x = O.signal_sine(512)
+    y1 = np.concatenate([m.Process(x[i:i + 128]) for i in range(0, 256, 128)])
+    assert m.IsQualityChangeRealtimeSafe(0.9) and not m.IsQualityChangeRealtimeSafe(0.1)
+    m.SetQualityScaleFactor(0.1)
+    y0 = np.concatenate([m.Process(x[i:i + 128]) for i in range(256, 512, 128)])
+    assert m.IsQualityChangeRealtimeSafe(0.1) and m.IsQualityChangeRealtimeSafe(1.0)  # both had their prewarm now
+    assert O.rms(y1 - O.oracle_from_file("BossWN-a2.nam", quality=1.0).process(x[:256])) < TOL_RMS
+    assert O.rms(y0 - O.oracle_from_file("BossWN-a2.nam", quality=0.0).process(x[256:])) < TOL_RMS
+    la = na.NeuralModelLoader().CreateFromFile(_path("BossWN-a2.nam"))
+    la.Process(x[:128])
+    assert la.IsQualityChangeRealtimeSafe(0.1)  # LoadAll: everything prewarmed at load
+
+
+def test_quality_setter_from_another_thread(na, loader):
+    """SetQualityScaleFactor may come from a UI thread while the audio thread is inside Process (the reference keeps the index in
+    atomics, CompositeModel.h:122,196-197).  Here the setter only stores atomically and the audio thread applies the change at the
+    top of its next Process: hammering it from a second thread must never break a buffer."""
+    import threading
+    m = loader.CreateFromFile(_path("BossWN-a2.nam"))
+    stop = threading.Event()
+
+    def ui():
+        k = 0
+        while not stop.is_set():
+            m.SetQualityScaleFactor(0.05 if k % 2 else 0.95)
+            k += 1
+
+    t = threading.Thread(target=ui)
+    t.start()
+    try:
+        x = O.signal_noise(128, 5)
+        outs = [m.Process(x) for _ in range(300)]
+    finally:
+        stop.set()
+        t.join()
+    assert all(np.all(np.isfinite(o)) for o in outs)
+    assert m.GetQualityScaleFactor() in (pytest.approx(0.05), pytest.approx(0.95))
+
+
+def test_oversampling_rewrite_matches_oracle_with_scaled_dilations(na):
+    """SetExternalSampleRate(96000) on a 48 kHz WaveNet multiplies every dilation by 2 and runs the model as a runtime-shaped one
+    (OversampleNAMConfig, NeuralModel.cpp:92-130).  The HIP path must equal an oracle built with those dilations."""
+    ld = na.NeuralModelLoader()
+    ld.SetExternalSampleRate(96000)
+    for name in ("BossWN-nano.nam", "BossWN-standard.nam"):
+        m = ld.CreateFromFile(_path(name))
+        assert m is not None and not m.IsStatic() and m.GetReceptiveFieldSize() == 2 * 4092
+        j = O.load_json(name)
+        arrays = O.wavenet_arrays_from_nam(j)
+        for a in arrays:
+            a["dilations"] = [2 * d for d in a["dilations"]]
+        x = O.signal_sine(2048)
+        y = np.concatenate([m.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
+        assert O.rms(y - O.OracleWaveNet(arrays, j["weights"]).process(x)) < TOL_RMS, name
+    a2 = ld.CreateFromFile(_path("BossWN-a2.nam"))  # A2: dilations x 2 and head dilation 2
+    j = O.load_json("BossWN-a2.nam")["config"]["submodels"][1]["model"]
+    arrays = O.wavenet_arrays_from_nam(j)
+    for a in arrays:
+        a["dilations"] = [2 * d for d in a["dilations"]]
+        a["head_dilation"] = 2
+    x = O.signal_sine(1024)
+    y = np.concatenate([a2.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
+    assert O.rms(y - O.OracleWaveNet(arrays, j["weights"]).process(x)) < TOL_RMS
+
+
+def _full_size_properties(na, add, S, n, spot, tol, chunk_exact=True):
+    """Size-independent properties at a BASELINE batch size: (a) streams of one model fed the same input agree bit-for-bit wherever
+    they sit, (b) 2 x 64 samples == 1 x 128 bit-for-bit, (c) a few streams against the oracle.  `add(batch)` adds the streams and
+    returns kind[s] (streams with equal kind share a model + quality); spot: [(stream, oracle factory)]."""
+    base = np.stack([O.signal_noise(n * 2, 3000 + s) for s in range(4)])
+    b1 = na.Batch(0)
+    kind = add(b1)
+    assert len(kind) == S and b1.NumStreams() == S
+    x = base[np.arange(S) % 4]
+    y = _run_blocks(b1, x, n)
+    assert np.all(np.isfinite(y))
+    first = {}
+    for s in range(S):
+        key = (kind[s], s % 4)
+        first.setdefault(key, s)
+    for s in range(0, S, 61):
+        assert np.array_equal(y[s], y[first[(kind[s], s % 4)]]), s
+    b2 = na.Batch(0)
+    add(b2)
+    y64 = _run_blocks(b2, x, 64)
+    if chunk_exact:
+        assert np.array_equal(y64, y)
+    else:  # recurrent kernels: the block size may change the compiler's contraction of the per-sample arithmetic by an ulp
+        assert np.max(np.abs(y64 - y)) < 1e-6
+    for s, make in spot:
+        assert O.rms(y[s] - make().process(x[s])) < tol, s
+
+
+def test_full_size_properties_config3_4096_mixed_streams(na, loader):
+    lite_arrays = O.a1_arrays(12, 6)
+    lite_w = O.synth_wavenet_weights(lite_arrays, seed=33)
+    models = [loader.CreateFromString(O.nam_json_wavenet_a1(12, 6, lite_w), ".nam", doPrewarm=False),
+              loader.CreateFromFile(_path("BossWN-feather.nam"), doPrewarm=False), loader.CreateFromFile(_path("BossWN-nano.nam"), doPrewarm=False)]
+    S = 4096
+
+    def add(b):
+        kind = []
+        for k, m in enumerate(models):  # sorted by architecture, a third each (SURVEY 8d)
+            cnt = S // 3 + (1 if k < S % 3 else 0)
+            b.AddStreams(m, cnt)
+            kind += [k] * cnt
+        return kind
+
+    _full_size_properties(na, add, S, 128, [(0, lambda: O.OracleWaveNet(lite_arrays, lite_w)), (2000, lambda: O.oracle_from_file("BossWN-feather.nam")),
+                                            (4095, lambda: O.oracle_from_file("BossWN-nano.nam"))], TOL_RMS)
+
+
+def test_full_size_properties_config4_1024_lstm_and_gru_streams(na, loader):
+    w = O.synth_lstm_weights(2, 16, seed=4)
+    gj = O.synth_keras_gru(1, 16, seed=9)
+    import json
+    models = [loader.CreateFromString(O.nam_json_lstm(2, 16, w), ".nam"), loader.CreateFromString(json.dumps(gj), ".json")]
+    S = 1024
+
+    def add(b):
+        b.AddStreams(models[0], S // 2)
+        b.AddStreams(models[1], S // 2)
+        return [0] * (S // 2) + [1] * (S // 2)
+
+    _full_size_properties(na, add, S, 128, [(0, lambda: O.OracleLSTM.from_nam(2, 16, w)), (511, lambda: O.OracleLSTM.from_nam(2, 16, w)),
+                                            (1023, lambda: O.OracleGRU(gj))], 5e-6, chunk_exact=False)
+
+
+def test_full_size_properties_config5_2048_a2_streams_quality_sweep(na, loader):
+    m = loader.CreateFromFile(_path("BossWN-a2.nam"), doPrewarm=False)
+    S = 2048
+    qs = [s / (S - 1) for s in range(S)]  # q_s = s / (S - 1): half the streams on each submodel (SURVEY 8d)
+
+    def add(b):
+        kind = []
+        # streams are added in runs of equal submodel (AddStreams is per quality value; 2 runs would do, 16 exercise the run merging)
+        for r in range(16):
+            q = qs[r * 128]
+            b.AddStreams(m, 128, quality=q)
+            kind += [0 if q <= 0.5 else 1] * 128
+        return kind
+
+    _full_size_properties(na, add, S, 128, [(0, lambda: O.oracle_from_file("BossWN-a2.nam", quality=0.0)),
+                                            (1023, lambda: O.oracle_from_file("BossWN-a2.nam", quality=0.5)),
+                                            (2047, lambda: O.oracle_from_file("BossWN-a2.nam", quality=1.0))], TOL_RMS)
