@@ -8,6 +8,13 @@
                       oracle for every sample model on sin(0.01 n) after prewarm.  They make the oracle's
                       behaviour reproducible on the GPU box and catch accidental edits; they do not pin parity
                       (see oracle/na_oracle.h for what does).
+  fixture_matrix.npz  THE PARITY MATRIX OF SURVEY.md 8(c): {Standard, Feather, Nano, A2 q=0 (3 ch), A2 q=1 (8 ch), LSTM 1x16, LSTM 2x8}
+                      x {sin(0.01 n), seeded clipped noise, zeros} x 4096 samples after prewarm, in two independent evaluations:
+                      "np64/<model>/<input>" = tests/ref_np.py (float64 numpy restatement of SURVEY Appendix B, whole-signal, no rings /
+                      chunks / prewarm code), "oracle/<model>/<input>" = the C oracle (f32, streaming).  Plus "switch/*": one A2 stream
+                      whose quality flips mid-stream (each submodel only advances while active, CompositeModel.h:94-100).  The reference
+                      cannot be built here (no Eigen), so these are NOT reference outputs; they are what the GPU tests hold the HIP path
+                      to in addition to the live oracle, so that kernel and oracle cannot drift together unnoticed.
   gru_torch.npz       INDEPENDENT-IMPLEMENTATION VECTORS for the keras GRU (RTNeural is absent from the reference tree, so there is no
                       reference output to record): output of torch.nn.GRU (float64, weights permuted from keras z|r|c to torch r|z|n order)
                       + dense head on the committed synthetic model models/synthetic_gru_1x16.json, after 2048 zeros of prewarm.
@@ -83,8 +90,64 @@ def make_gru():
     np.savez_compressed(os.path.join(HERE, "gru_torch.npz"), input=x, output=y.astype(np.float32))
 
 
+MATRIX_MODELS = [("standard", "BossWN-standard.nam", 1.0), ("feather", "BossWN-feather.nam", 1.0), ("nano", "BossWN-nano.nam", 1.0),
+                 ("a2q0", "BossWN-a2.nam", 0.0), ("a2q1", "BossWN-a2.nam", 1.0), ("lstm1x16", "BossLSTM-1x16.nam", 1.0),
+                 ("lstm2x8", "BossLSTM-2x8.nam", 1.0)]
+MATRIX_N = 4096
+SWITCH_PLAN = [(0, 1.0), (8, 0.2), (20, 0.9), (27, 0.0)]  # (first 128-sample block, quality) of the mid-stream switch run, 32 blocks
+
+
+def matrix_inputs():
+    return {"sine": O.signal_sine(MATRIX_N), "noise": O.signal_noise(MATRIX_N, 20260928), "zeros": np.zeros(MATRIX_N, np.float32)}
+
+
+def _np64(name, q, x):
+    import ref_np
+    j = O.load_json(name)
+    if j["architecture"] == "SlimmableContainer":
+        j = j["config"]["submodels"][O.quality_to_submodel(j, q)]["model"]
+    if j["architecture"] == "WaveNet":
+        return ref_np.wavenet_forward(O.wavenet_arrays_from_nam(j), j["weights"], x)[0]
+    c = j["config"]
+    return ref_np.lstm_forward_nam(int(c["num_layers"]), int(c["hidden_size"]), j["weights"], x)
+
+
+def make_fixture_matrix():
+    out = {}
+    inputs = matrix_inputs()
+    for k, x in inputs.items():
+        out["input/" + k] = x
+    for tag, name, q in MATRIX_MODELS:
+        for k, x in inputs.items():
+            out["oracle/%s/%s" % (tag, k)] = O.oracle_from_file(name, quality=q).process(x)
+            out["np64/%s/%s" % (tag, k)] = np.asarray(_np64(name, q, x), np.float32)
+            err = O.rms(out["oracle/%s/%s" % (tag, k)] - out["np64/%s/%s" % (tag, k)])
+            assert err < (5e-6 if tag.startswith("lstm") else 1e-6), (tag, k, err)  # f32 recurrence vs float64: ~1e-6 on the LSTMs
+    # mid-stream quality switch on the A2 container: per-block active submodel, expected output from one evaluation per submodel over
+    # the concatenation of the blocks it was active for
+    x = O.signal_noise(32 * 128, 77)
+    j = O.load_json("BossWN-a2.nam")
+    active = np.zeros(32, np.int32)
+    for b0, q in SWITCH_PLAN:
+        active[b0:] = O.quality_to_submodel(j, q)
+    blocks = x.reshape(32, 128)
+    want_o, want_n = np.zeros_like(blocks), np.zeros_like(blocks)
+    for idx in (0, 1):
+        sel = np.flatnonzero(active == idx)
+        xs = blocks[sel].ravel()
+        qq = 0.0 if idx == O.quality_to_submodel(j, 0.0) else 1.0
+        want_o[sel] = O.oracle_from_file("BossWN-a2.nam", quality=qq).process(xs).reshape(-1, 128)
+        want_n[sel] = np.asarray(_np64("BossWN-a2.nam", qq, xs), np.float32).reshape(-1, 128)
+    out["switch/input"] = x
+    out["switch/active"] = active
+    out["switch/oracle"] = want_o.ravel()
+    out["switch/np64"] = want_n.ravel()
+    np.savez_compressed(os.path.join(HERE, "fixture_matrix.npz"), **out)
+
+
 if __name__ == "__main__":
     make_matmul()
+    make_fixture_matrix()
     make_oracle_outputs()
     make_gru()
     print("golden fixtures written")

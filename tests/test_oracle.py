@@ -274,3 +274,16 @@ def test_gru_oracle_matches_committed_torch_vectors():
     g = np.load(os.path.join(GOLDEN, "gru_torch.npz"))
     y = O.oracle_from_file("synthetic_gru_1x16.json").process(g["input"])
     assert O.rms(y - g["output"]) < 1e-6
+
+
+def test_oracle_matches_committed_fixture_matrix():
+    """tests/golden/fixture_matrix.npz (SURVEY 8c matrix: 7 models x {sine, noise, zeros} x 4096 samples): the live-built oracle
+    reproduces its own committed outputs bit-for-bit-ish (compiler flags may move the last ulp) and stays within f32 noise of the
+    committed float64 restatement -- on the GPU box too, where /root/reference and the generating script's inputs do not exist."""
+    from golden.make_golden import MATRIX_MODELS
+    g = np.load(os.path.join(GOLDEN, "fixture_matrix.npz"))
+    for tag, name, q in MATRIX_MODELS:
+        for k in ("sine", "noise", "zeros"):
+            y = O.oracle_from_file(name, quality=q).process(g["input/" + k])
+            assert O.rms(y - g["oracle/%s/%s" % (tag, k)]) < 2e-7, (tag, k)
+            assert O.rms(y - g["np64/%s/%s" % (tag, k)]) < (5e-6 if tag.startswith("lstm") else 1e-6), (tag, k)
