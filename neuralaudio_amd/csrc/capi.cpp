@@ -251,6 +251,18 @@ int NA_IsQualityChangeRealtimeSafe(NeuralModel* model, float newQuality)
 	return (model && model->model->IsQualityChangeRealtimeSafe(newQuality)) ? 1 : 0;
 }
 
+// bit 0: NAMIsA2(version), bit 1: NAMIsA2Standard(model) -- the reference's engine-selection predicates, exposed for tests
+int NA_DebugClassifyNam(const char* jsonText)
+{
+	int r = -1;
+	Guard([&] {
+		const na::Json j = na::Json::Parse(jsonText ? jsonText : "");
+		const std::string v = (j.IsObject() && j.Contains("version") && j.At("version").IsString()) ? j.At("version").AsString() : "";
+		r = (na::NAMIsA2(v) ? 1 : 0) | (na::NAMIsA2Standard(j) ? 2 : 0);
+	});
+	return r;
+}
+
 void NA_SetDevice(NeuralModelLoader* loader, int device)
 {
 	if (loader) loader->loader->SetDevice(device);

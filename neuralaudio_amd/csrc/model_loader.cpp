@@ -227,6 +227,8 @@ namespace na
 			}
 			modelJson.At("weights").FlattenNumbers(desc->wavenet.weights);
 			desc->wavenet.isStatic = (oversampleFactor == 1) && IsOfficialArchitecture(desc->wavenet.arrays);
+			// an A2-format file runs on the static engine only if it is the standard architecture (NeuralModel.cpp:365-380)
+			if (desc->wavenet.isStatic && layers.Size() == 1 && layers.At(0).Contains("kernel_sizes") && !NAMIsA2Standard(modelJson)) desc->wavenet.isStatic = false;
 			desc->wavenet.mathMode = opts.wavenetMath;
 			// the reference throws "Wrong number of weights" inside CreateFromJson (WaveNet.h:704-709); so does this loader, together with
 			// the limits of the gfx950 kernels, instead of deferring them to the first device use on the audio thread
@@ -234,6 +236,91 @@ namespace na
 			return desc;
 		}
 
+	}
+
+	// ---- NAMIsA2 / NAMIsA2Standard, restated rule for rule (NeuralModel.cpp:159-168, 188-317) -----------------------------------
+	// The reference uses them to decide which engine evaluates an A2-format file: the static Internal engine for the standard
+	// architecture, NAM Core for everything else.  Here they decide IsStatic() for A2 files (the rejection of features without
+	// arithmetic on this path is RejectUnsupportedA2Features above).  Note the reference's IsActive(): a MISSING block counts as active.
+	bool NAMIsA2(const std::string& version)
+	{
+		int major = 0, minor = 0, patch = 0;
+		char dot;
+		std::stringstream ss(version);
+		ss >> major >> dot >> minor >> dot >> patch;
+		return (major > 0) || (minor > 5) || ((minor == 5) && (patch > 4));
+	}
+
+	namespace
+	{
+		int ValueOr(const Json& j, const char* key, int dflt) { return (j.Contains(key) && j.At(key).IsNumber()) ? j.At(key).AsInt() : dflt; }
+		bool RefIsActive(const Json& j, const char* name)
+		{
+			if (!j.Contains(name)) return true;
+			const Json& b = j.At(name);
+			return b.IsObject() && b.Contains("active") && b.At("active").IsBool() && b.At("active").AsBool();
+		}
+		bool HasNonNull(const Json& j, const char* name) { return j.Contains(name) && !j.At(name).IsNull(); }
+		bool SequenceIs(const Json& j, const std::vector<int>& want)
+		{
+			if (!j.IsArray() || j.Size() != want.size()) return false;
+			for (size_t i = 0; i < want.size(); i++)
+				if (!j.At(i).IsNumber() || j.At(i).AsInt() != want[i]) return false;
+			return true;
+		}
+	}
+
+	bool NAMIsA2Standard(const Json& modelJson)
+	{
+		if (!modelJson.IsObject() || !modelJson.Contains("architecture")) return false;
+		if (!modelJson.At("architecture").IsString() || modelJson.At("architecture").AsString() != "WaveNet") return false;
+		if (!modelJson.Contains("config")) return false;
+		const Json& config = modelJson.At("config");
+		if (HasNonNull(config, "head")) return false;
+		if (config.Contains("condition_dsp")) return false;
+		if (ValueOr(config, "in_channels", 1) != 1) return false;
+		if (!config.Contains("layers") || config.At("layers").Size() != 1) return false;
+		const Json& lc = config.At("layers").At(0);
+		if (ValueOr(lc, "input_size", 0) != 1) return false;
+		if (ValueOr(lc, "condition_size", 0) != 1) return false;
+		const int channels = ValueOr(lc, "channels", 0);
+		if (channels != 3 && channels != 8) return false;
+		if (ValueOr(lc, "bottleneck", channels) != channels) return false;
+		if (!lc.Contains("kernel_sizes") || !SequenceIs(lc.At("kernel_sizes"), kA2KernelSizes)) return false;
+		if (!lc.Contains("dilations") || !SequenceIs(lc.At("dilations"), kA2Dilations)) return false;
+		if (!lc.Contains("activation") || !lc.At("activation").IsArray()) return false;
+		for (size_t i = 0; i < lc.At("activation").Size(); i++)
+		{
+			const Json& a = lc.At("activation").At(i);
+			if (!a.IsObject() || !a.Contains("type") || !a.At("type").IsString() || a.At("type").AsString() != "LeakyReLU") return false;
+			const float slope = (a.Contains("negative_slope") && a.At("negative_slope").IsNumber()) ? a.At("negative_slope").AsFloat() : 0.01f;
+			if (std::fabs(slope - 0.01f) > 1e-5f) return false;
+		}
+		if (lc.Contains("secondary_activation") && lc.At("secondary_activation").IsArray())
+			for (size_t i = 0; i < lc.At("secondary_activation").Size(); i++)
+				if (!lc.At("secondary_activation").At(i).IsNull()) return false;
+		if (lc.Contains("gating_mode") && lc.At("gating_mode").IsArray())
+			for (size_t i = 0; i < lc.At("gating_mode").Size(); i++)
+			{
+				const Json& g = lc.At("gating_mode").At(i);
+				if (!g.IsNull() && !(g.IsString() && g.AsString() == "none")) return false;
+			}
+		if (!lc.Contains("head") || !lc.At("head").IsObject()) return false;
+		const Json& head = lc.At("head");
+		if (ValueOr(head, "out_channels", 1) != 1) return false;
+		if (ValueOr(head, "kernel_size", 16) != 16) return false;
+		if (ValueOr(head, "head_dilation", 1) != 1) return false;
+		if (head.Contains("bias") && !Truthy(head.At("bias"))) return false;
+		if (!RefIsActive(lc, "layer1x1")) return false;
+		if (!lc.Contains("layer1x1")) return false; // the reference's .at("layer1x1") throws here; a file without the block is not standard
+		if (ValueOr(lc.At("layer1x1"), "groups", 1) != 1) return false;
+		for (const char* key : { "head1x1", "conv_pre_film", "conv_post_film", "input_mixin_pre_film", "input_mixin_post_film", "activation_pre_film",
+				 "activation_post_film", "layer1x1_post_film", "head1x1_post_film" })
+			if (RefIsActive(lc, key)) return false;
+		if (ValueOr(lc, "groups_input", 1) != 1) return false;
+		if (ValueOr(lc, "groups_input_mixin", 1) != 1) return false;
+		if (HasNonNull(lc, "slimmable")) return false;
+		return true;
 	}
 
 	void ValidateRecurrentDesc(const LSTMDesc& d)

@@ -55,6 +55,10 @@ namespace na
 	// reference (nlohmann exceptions, "Wrong number of weights").
 	std::shared_ptr<LoadedModel> LoadModelFromJson(const Json& modelJson, const std::string& extension, const LoaderOptions& opts);
 	std::shared_ptr<LoadedModel> LoadModelFromText(const std::string& text, const std::string& extension, const LoaderOptions& opts);
+	// the reference's engine-selection predicates for A2-format files (NeuralModel.cpp:159-168, 188-317)
+	bool NAMIsA2(const std::string& version);
+	bool NAMIsA2Standard(const Json& modelJson);
+
 	// returns nullptr if the file does not exist (NeuralModel.cpp:321-322)
 	std::shared_ptr<LoadedModel> LoadModelFromFile(const std::string& path, const LoaderOptions& opts);
 }

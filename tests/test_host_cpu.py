@@ -357,3 +357,71 @@ def test_shard_ranges_partition_and_balance(na):
     r = shard_ranges(costs, 8)
     loads = [sum(costs[a:b]) for a, b in r]
     assert max(loads) / (sum(loads) / 8) < 1.01
+
+
+def test_a2_engine_selection_predicates(na):
+    """NAMIsA2 (NeuralModel.cpp:159-168) and NAMIsA2Standard (:188-317), rule for rule, on accept / reject fixtures made from the
+    reference's own A2 sample file."""
+    from neuralaudio_amd import capi
+    lib = capi.load_library()
+
+    def classify(j):
+        return lib.NA_DebugClassifyNam(json.dumps(j).encode())
+
+    for v, want in (("0.5.4", 0), ("0.5.5", 1), ("0.6.0", 1), ("0.7.0", 1), ("1.0.0", 1), ("0.5.1", 0), ("0.4.9", 0)):
+        assert classify({"version": v}) & 1 == want, v
+    for sub in O.load_json("BossWN-a2.nam")["config"]["submodels"]:
+        base = sub["model"]
+        assert classify(base) == 3  # A2 version, standard architecture
+
+        def variant(edit):
+            j = copy.deepcopy(base)
+            edit(j["config"]["layers"][0], j["config"], j)
+            return classify(j) & 2
+
+        assert variant(lambda lc, c, j: None) == 2
+        rejects = [
+            lambda lc, c, j: j.update(architecture="LSTM"),
+            lambda lc, c, j: c.update(head={"x": 1}),
+            lambda lc, c, j: c.update(condition_dsp=None),  # mere presence counts
+            lambda lc, c, j: c.update(in_channels=2),
+            lambda lc, c, j: c["layers"].append(copy.deepcopy(lc)),
+            lambda lc, c, j: lc.update(input_size=2),
+            lambda lc, c, j: lc.update(condition_size=2),
+            lambda lc, c, j: lc.update(channels=4),
+            lambda lc, c, j: lc.update(bottleneck=lc["channels"] + 1),
+            lambda lc, c, j: lc["kernel_sizes"].__setitem__(3, 5),
+            lambda lc, c, j: lc["dilations"].__setitem__(0, 2),
+            lambda lc, c, j: lc["dilations"].append(1),
+            lambda lc, c, j: lc["activation"].__setitem__(2, {"type": "Tanh"}),
+            lambda lc, c, j: lc["activation"].__setitem__(2, {"type": "LeakyReLU", "negative_slope": 0.2}),
+            lambda lc, c, j: lc["secondary_activation"].__setitem__(1, {"type": "Sigmoid"}),
+            lambda lc, c, j: lc["gating_mode"].__setitem__(1, "gated"),
+            lambda lc, c, j: lc["head"].update(out_channels=2),
+            lambda lc, c, j: lc["head"].update(kernel_size=8),
+            lambda lc, c, j: lc["head"].update(head_dilation=2),
+            lambda lc, c, j: lc["head"].update(bias=False),
+            lambda lc, c, j: lc["layer1x1"].update(active=False),
+            lambda lc, c, j: lc["layer1x1"].update(groups=2),
+            lambda lc, c, j: lc["head1x1"].update(active=True),
+            lambda lc, c, j: lc["conv_pre_film"].update(active=True),
+            lambda lc, c, j: lc["head1x1_post_film"].update(active=True),
+            lambda lc, c, j: lc.pop("activation_pre_film"),  # the reference's IsActive(): a missing block counts as active
+            lambda lc, c, j: lc.update(groups_input=2),
+            lambda lc, c, j: lc.update(groups_input_mixin=4),
+            lambda lc, c, j: lc.update(slimmable={"method": "x"}),
+            lambda lc, c, j: lc.pop("head"),
+        ]
+        for k, edit in enumerate(rejects):
+            assert variant(edit) == 0, k
+        accepts = [
+            lambda lc, c, j: lc["gating_mode"].__setitem__(1, None),
+            lambda lc, c, j: lc["activation"].__setitem__(2, {"type": "LeakyReLU"}),  # default slope 0.01
+            lambda lc, c, j: lc.pop("secondary_activation"),
+            lambda lc, c, j: lc.pop("bottleneck"),
+            lambda lc, c, j: lc.update(slimmable=None),
+        ]
+        for k, edit in enumerate(accepts):
+            assert variant(edit) == 2, k
+    for a1 in ("BossWN-standard.nam", "BossWN-nano.nam", "BossLSTM-1x16.nam"):
+        assert classify(O.load_json(a1)) == 0
