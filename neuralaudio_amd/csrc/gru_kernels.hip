@@ -121,6 +121,102 @@ namespace na
 				if (lane < H) state[(size_t)(l * 2 * H + lane) * capacity + slot] = hvec[l][lane];
 		}
 
+
+		// Any hidden size / layer count (what RTNeural's run-time model accepts): lane = stream, run-time loops, weights through
+		// wave-uniform loads.  LDS: io[64][n + 1] | h[numLayers][H][64] | a[2][3H][64] (input and recurrent pre-activations).
+		__global__ void __launch_bounds__(64) GruGenericKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
+			const int* __restrict__ rows, int numStreams, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
+		{
+			extern __shared__ __attribute__((aligned(16))) float lds[];
+			const int H = m.hidden;
+			float* io = lds;
+			const int ioStride = n + 1;
+			float* hAll = lds + 64 * ioStride;
+			float* ai = hAll + (size_t)m.numLayers * H * 64;
+			float* ah = ai + (size_t)3 * H * 64;
+			const int lane = threadIdx.x;
+			const int idx = blockIdx.x * 64 + lane;
+			const bool active = idx < numStreams;
+			const int slot = active ? slots[idx] : 0;
+			for (int r = 0; r < 64; r++)
+			{
+				const int ridx = blockIdx.x * 64 + r;
+				if (ridx < numStreams)
+				{
+					const float* src = in + (size_t)rows[ridx] * inStride;
+					for (int f = lane; f < n; f += 64) io[r * ioStride + f] = src[f];
+				}
+			}
+			for (int l = 0; l < m.numLayers; l++)
+				for (int k = 0; k < H; k++) hAll[(l * H + k) * 64 + lane] = active ? state[(size_t)(l * 2 * H + k) * capacity + slot] : 0.0f;
+			__syncthreads();
+			const float* headW = m.w + m.headOff;
+			for (int f = 0; f < n; f++)
+			{
+				const float x0 = io[lane * ioStride + f];
+				for (int l = 0; l < m.numLayers; l++)
+				{
+					const int I = (l == 0) ? 1 : H, W = I + H;
+					const float* w = m.w + m.layerOff[l];
+					const float* bIn = w + (size_t)3 * H * W;
+					const float* bRec = bIn + 3 * H;
+					float* h = hAll + (size_t)l * H * 64;
+					const float* below = hAll + (size_t)(l > 0 ? l - 1 : 0) * H * 64;
+					for (int r = 0; r < 3 * H; r++)
+					{
+						const float* row = w + (size_t)r * W;
+						float a = bIn[r], b = bRec[r];
+						if (l == 0) a += row[0] * x0;
+						else
+							for (int k = 0; k < H; k++) a += row[k] * below[k * 64 + lane];
+						for (int k = 0; k < H; k++) b += row[I + k] * h[k * 64 + lane];
+						ai[r * 64 + lane] = a;
+						ah[r * 64 + lane] = b;
+					}
+					for (int u = 0; u < H; u++)
+					{
+						const float z = GruSigmoid(ai[u * 64 + lane] + ah[u * 64 + lane]);
+						const float rr = GruSigmoid(ai[(H + u) * 64 + lane] + ah[(H + u) * 64 + lane]);
+						const float c = GruTanh(ai[(2 * H + u) * 64 + lane] + rr * ah[(2 * H + u) * 64 + lane]);
+						h[u * 64 + lane] = (1.0f - z) * c + z * h[u * 64 + lane];
+					}
+				}
+				const float* hl = hAll + (size_t)(m.numLayers - 1) * H * 64;
+				float acc = 0.0f;
+				for (int k = 0; k < H; k++) acc += headW[k] * hl[k * 64 + lane];
+				io[lane * ioStride + f] = acc + headW[H];
+			}
+			__syncthreads();
+			for (int l = 0; l < m.numLayers; l++)
+				for (int k = 0; k < H; k++)
+					if (active) state[(size_t)(l * 2 * H + k) * capacity + slot] = hAll[(l * H + k) * 64 + lane];
+			for (int r = 0; r < 64; r++)
+			{
+				const int ridx = blockIdx.x * 64 + r;
+				if (ridx < numStreams)
+				{
+					float* dst = out + (size_t)rows[ridx] * outStride;
+					for (int f = lane; f < n; f += 64) dst[f] = io[r * ioStride + f];
+				}
+			}
+		}
+
+		hipError_t LaunchGruGeneric(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams, const float* in,
+			float* out, long inStride, long outStride, int n, hipStream_t stream)
+		{
+			const size_t ldsBytes = ((size_t)64 * (n + 1) + (size_t)m.numLayers * m.hidden * 64 + (size_t)6 * m.hidden * 64) * sizeof(float);
+			if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
+			static bool attrSet = false;
+			if (!attrSet)
+			{
+				(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&GruGenericKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+				attrSet = true;
+			}
+			hipLaunchKernelGGL(GruGenericKernel, dim3((unsigned)((numStreams + 63) / 64)), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows,
+				numStreams, in, out, inStride, outStride, n);
+			return hipGetLastError();
+		}
+
 		template <int H, int L>
 		hipError_t LaunchHL(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams, const float* in,
 			float* out, long inStride, long outStride, int n, hipStream_t stream)
@@ -143,13 +239,13 @@ namespace na
 			return LaunchRecurrentDpp(&g, 1, in, out, inStride, outStride, n, stream);
 		}
 #define NA_GRU_CASE(HH) \
-	if (m.hidden == HH) return m.numLayers == 1 ? LaunchHL<HH, 1>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream) \
+	if (m.hidden == HH && m.numLayers <= 2) return m.numLayers == 1 ? LaunchHL<HH, 1>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream) \
 												: LaunchHL<HH, 2>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 		NA_GRU_CASE(8)
 		NA_GRU_CASE(12)
 		NA_GRU_CASE(16)
 		NA_GRU_CASE(20)
 #undef NA_GRU_CASE
-		return hipErrorInvalidValue;
+		return LaunchGruGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 	}
 }

@@ -20,7 +20,7 @@ namespace na
 
 	// Shapes with a kernel (host-side predicates, no HIP types: the loader rejects everything else at load time).
 	//   LSTM: any hidden size / layer count whose lane = stream working set fits the 160 KB LDS (LstmGenericKernel); the usual sizes
-	//   have shaped kernels.  GRU: GruWaveKernel instances.
+	//   have shaped kernels.  GRU: likewise (GruGenericKernel; GruWaveKernel / DPP instances for 1-2 layers of 8, 12, 16, 20).
 	inline bool LstmShapeSupported(int hidden, int numLayers)
 	{
 		if (hidden < 1 || numLayers < 1 || numLayers > LSTM_MAX_LAYERS) return false;
@@ -29,7 +29,9 @@ namespace na
 	}
 	inline bool GruShapeSupported(int hidden, int numLayers)
 	{
-		return (numLayers == 1 || numLayers == 2) && (hidden == 8 || hidden == 12 || hidden == 16 || hidden == 20);
+		if (hidden < 1 || numLayers < 1 || numLayers > LSTM_MAX_LAYERS) return false;
+		const long bytes = (64L * (LSTM_MAX_FRAMES + 1) + (long)numLayers * hidden * 64 + 6L * hidden * 64) * 4; // GruGenericKernel's LDS
+		return bytes <= 160L * 1024;
 	}
 
 	struct LstmModelDev

@@ -329,7 +329,7 @@ namespace na
 		{
 			if (!GruShapeSupported(d.hiddenSize, d.numLayers))
 				throw std::runtime_error("GRU " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
-					" is not supported (gfx950 kernels exist for 1-2 layers of hidden size 8, 12, 16 or 20)");
+					" is not supported (1-8 layers; the per-stream state must fit the 160 KB LDS)");
 		}
 		else if (!LstmShapeSupported(d.hiddenSize, d.numLayers))
 			throw std::runtime_error("LSTM " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +

@@ -161,6 +161,18 @@ def test_keras_gru_single_stream_shapes(na, loader, layers, hidden):
     assert O.rms(y - O.OracleGRU(gj).process(x)) < 5e-6
 
 
+@pytest.mark.parametrize("layers,hidden", [(3, 16), (1, 5), (2, 24), (1, 40)])
+def test_runtime_shaped_keras_gru_matches_oracle(na, loader, layers, hidden):
+    """GRU shapes without a shaped kernel run on the lane = stream runtime-shaped one (RTNeural's run-time model takes any)."""
+    import json
+    j = O.synth_keras_gru(layers, hidden, seed=11 + hidden)
+    m = loader.CreateFromString(json.dumps(j), ".json")
+    assert m is not None
+    x = O.signal_noise(300, 8)
+    y = np.concatenate([m.Process(x[i:i + 100]) for i in range(0, x.size, 100)])
+    assert O.rms(y - O.OracleGRU(j).process(x)) < 5e-6
+
+
 @pytest.mark.parametrize("sizes", [[1, 15, 16, 17, 63, 64, 65, 127, 128], [300, 5, 129, 128, 1]])
 def test_ragged_buffer_sizes(na, loader, sizes):
     """Any n per call (the reference chunks at 64, InternalModel.h:104-117): 1, tile-straddling, > 128 (multi-launch)."""
