@@ -275,7 +275,6 @@ namespace na
 			{
 				dStages.Upload(plan.stages, stream);
 				dWpack.Upload(plan.wpack, stream);
-				dQdesc.Upload(plan.qdesc, stream);
 				dWpk.Upload(plan.wpk, stream);
 				dPrewarm.Upload(plan.prewarm, stream);
 				dWeights.Upload(d->wavenet.weights, stream);
@@ -300,13 +299,10 @@ namespace na
 
 				dev.stages = dStages.Get();
 				dev.wpack = dWpack.Get();
-				dev.qdesc = dQdesc.Get();
 				dev.wpk = dWpk.Get();
 				dev.ring_frames = dRingFrames.Get();
 				dev.nstages = (int)plan.stages.size();
-				dev.nqdesc = (int)plan.qdesc.size();
 				dev.wpack_f4 = (int)(plan.wpack.size() / 4);
-				dev.max_stage_f4 = plan.maxStageF4;
 				dev.max_a4_floats = plan.maxA4Floats;
 				dev.max_ksize = 1;
 				for (const WnStage& st : plan.stages)
@@ -413,7 +409,6 @@ namespace na
 			WnModelDev dev = {};
 			DevArray<WnStage> dStages;
 			DevArray<float> dWpack;
-			DevArray<WnQuad> dQdesc;
 			DevArray<float> dWpk;
 			DevArray<WnPrewarmLayer> dPrewarm;
 			DevArray<float> dWeights;

@@ -66,19 +66,10 @@ namespace na
 		int a4_off;          // float offset into wpk ([conv taps | 1x1 | vectors] or [head dense | rechannel])
 		int a4_floats;       // 0: stage has no MFMA weights
 		int vec_off;         // float4 index into wpack: [0..3] conv/dense bias, [4..7] mix-in w, [8..11] 1x1 bias, [12..15] aux
-		int pk_conv_off;     // packed-FMA layouts, float offsets into wpk: conv [tap][in c][out o]  (head conv: [tap][in c])
-		// ---- the rest: head dense of the frame kernel, tile kernel, packed-FMA kernel
-		int pk_w1_off;       // 1x1 / head dense [in c][out o]
-		int pk_w2_off;       // rechannel of WN_ST_ARRAY_LINK [in c][out o]
-		int nrounds;         // tile kernel: conv rounds (4 k-quads = 4 MFMAs x 4 lane groups each)
-		int wconv_off;       // float4 index into wpack: [round][64 lanes]
-		int qdesc_off;       // int4 index into qdesc: [round][4 lane groups] = {shift, channel group, valid, 0}
-		int w1_off;          // float4 index: [64 lanes] 1x1 (layer) / head dense
-		int w2_off;          // float4 index: [64 lanes] second dense of WN_ST_ARRAY_LINK (rechannel)
-		int hist_rounds;     // leading conv rounds that may read history (shift > 0); later rounds are in-block only
-		int wblk_off;        // float4 index: this stage's weights are ONE contiguous block [wblk_off, wblk_off + wblk_f4)
-		int wblk_f4;         // (vec | conv rounds | w1 | w2), staged into LDS one stage ahead
-		int reserved[6];
+		int pk_conv_off;     // head conv stage: [tap][in c] weights, float offset into wpk
+		// ---- the rest
+		int pk_w1_off;       // head dense [in c] (only head channel 0 reaches the output), float offset into wpk
+		int reserved[15];
 	};
 	static_assert(sizeof(WnStage) == 128, "stage descriptors are 128-byte records");
 
@@ -109,14 +100,6 @@ namespace na
 	};
 	static_assert(sizeof(WnSplitStage) == 64, "split stage descriptors are 64-byte records");
 
-	struct WnQuad
-	{
-		int shift;  // frames back: dilation * (K - 1 - tap)
-		int cg;     // channel group fetched by this lane group
-		int smin;   // min / max shift over the four lane groups of this round (same value in all four entries):
-		int smax;   // lets the kernel classify a (round, tile) as in-block / history / straddling with scalar compares
-	};
-
 	// Natural-layout tensor table used by the prewarm kernel (one entry per conv ring).
 	struct WnPrewarmLayer
 	{
@@ -139,14 +122,11 @@ namespace na
 	struct WnModelDev
 	{
 		const WnStage* stages;
-		const float* wpack;   // float4-aligned packed weights
-		const WnQuad* qdesc;
-		const float* wpk;       // weights in the packed-FMA kernel's layout (scalar-load friendly)
+		const float* wpack;   // per-stage bias / mix-in vectors (float4 aligned)
+		const float* wpk;       // frame kernel: per-stage A images + head weights (LDS-DMA / scalar-load friendly)
 		const int* ring_frames; // [nrings]
 		int nstages;
-		int nqdesc;           // total WnQuad entries
 		int wpack_f4;         // size of wpack in float4 units
-		int max_stage_f4;     // largest per-stage weight block in float4 units
 		int max_a4_floats;    // largest per-stage A-operand block of the frame kernel
 		int max_ksize;        // largest conv kernel size over all layers
 		int wpk_floats;

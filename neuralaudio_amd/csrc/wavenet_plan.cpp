@@ -164,75 +164,6 @@ namespace na
 				return (int)plan.rings.size() - 1;
 			}
 
-			// conv operand table: [round][lane] float4, lane (g,i): quad q = round*4+g -> (tap = q/G, cg = q%G),
-			// element kk -> input channel 4cg+kk, output channel i.  Flat conv weights: [(i*cin + c)*K + tap].
-			void PackConv(WnStage& st, int wOff, int cin, int cout, int ksize, int dilation)
-			{
-				const int G = CeilDiv(cin, 4);
-				const int nquads = ksize * G;
-				st.nrounds = CeilDiv(nquads, 4);
-				st.hist_rounds = CeilDiv((ksize - 1) * G, 4); // quads are tap-major, the last tap (shift 0) comes last
-				st.ksize = ksize;
-				st.dilation = dilation;
-				st.wconv_off = AllocF4(st.nrounds * 64);
-				st.qdesc_off = (int)plan.qdesc.size();
-				for (int r = 0; r < st.nrounds; r++)
-				{
-					WnQuad round[4];
-					for (int g = 0; g < 4; g++)
-					{
-						const int q = r * 4 + g;
-						WnQuad qd = { 0, 0, 0, 0 }; // idle quad: zero weights, reads (shift 0, group 0) = always valid in-block data
-						if (q < nquads)
-						{
-							const int tap = q / G;
-							qd.cg = q % G;
-							qd.shift = dilation * (ksize - 1 - tap); // tap k reads t - d*(K-1-k), WaveNet.h:160,255
-							for (int i = 0; i < 16; i++)
-							{
-								for (int kk = 0; kk < 4; kk++)
-								{
-									const int c = 4 * qd.cg + kk;
-									float v = 0.0f;
-									if (i < cout && c < cin) v = W(wOff + (i * cin + c) * ksize + tap);
-									plan.wpack[((size_t)st.wconv_off + (size_t)r * 64 + (size_t)(g * 16 + i)) * 4 + kk] = v;
-								}
-							}
-						}
-						round[g] = qd;
-					}
-					int smin = round[0].shift, smax = round[0].shift;
-					for (int g = 1; g < 4; g++)
-					{
-						smin = std::min(smin, round[g].shift);
-						smax = std::max(smax, round[g].shift);
-					}
-					for (int g = 0; g < 4; g++)
-					{
-						round[g].smin = smin;
-						round[g].smax = smax;
-						plan.qdesc.push_back(round[g]);
-					}
-				}
-			}
-
-			// dense-from-registers operand table: lane (g,i), element kk -> input channel 4g+kk. Flat [i*cin + c].
-			int PackDense(int wOff, int cin, int cout)
-			{
-				if (cin > 16 || cout > 16) throw std::runtime_error("WaveNet channels > 16 are not supported by the gfx950 MFMA kernel");
-				const int off = AllocF4(64);
-				for (int g = 0; g < 4; g++)
-					for (int i = 0; i < 16; i++)
-						for (int kk = 0; kk < 4; kk++)
-						{
-							const int c = 4 * g + kk;
-							float v = 0.0f;
-							if (i < cout && c < cin) v = W(wOff + i * cin + c);
-							plan.wpack[((size_t)off + (size_t)(g * 16 + i)) * 4 + kk] = v;
-						}
-				return off;
-			}
-
 			int AllocPk(int nFloats)
 			{
 				const int off = (int)plan.wpk.size();
@@ -240,7 +171,7 @@ namespace na
 				return off;
 			}
 
-			// conv for the packed-FMA kernel: [tap][in c][out o], both channel counts padded to CP; flat source [(o*cin + c)*K + tap]
+			// head conv of the frame kernel (plain FMAs over scalar-loaded weights): [tap][in c][out o], channel counts padded; flat source [(o*cin + c)*K + tap]
 			int PackConvPk(int wOff, int cin, int cout, int ksize, int CPin, int CPout)
 			{
 				const int off = AllocPk(ksize * CPin * CPout);
@@ -250,7 +181,7 @@ namespace na
 				return off;
 			}
 
-			// dense [in c][out o] padded; flat source [o*cin + c]
+			// head dense of the frame kernel: [in c][out o] padded; flat source [o*cin + c]
 			int PackDensePk(int wOff, int cin, int cout, int CPin, int CPout)
 			{
 				const int off = AllocPk(CPin * CPout);
@@ -577,15 +508,11 @@ namespace na
 						const WnArrayCfg& prev = desc.arrays[a - 1];
 						WnStage st = EmptyStage(WN_ST_ARRAY_LINK);
 						st.vec_off = AllocF4(16);
-						st.w1_off = PackDense(prevHeadW, prev.channels, prev.headSize);
 						if (prev.hasHeadBias)
 						{
 							st.flags |= WN_FLAG_BIAS;
 							SetVec(st, 0, prevHeadB, prev.headSize);
 						}
-						st.w2_off = PackDense(rechOff, cfg.inputSize, C);
-						st.pk_w1_off = PackDensePk(prevHeadW, prev.channels, prev.headSize, 16, 16);
-						st.pk_w2_off = PackDensePk(rechOff, cfg.inputSize, C, 16, 16);
 						st.a4_off = PackDenseA4(prevHeadW, prev.channels, prev.headSize, 4); // [head dense | rechannel], padded to 16x16 each
 						PackDenseA4(rechOff, cfg.inputSize, C, 4);
 						st.a4_floats = 2 * 256;
@@ -611,10 +538,8 @@ namespace na
 						SetVec(st, 0, bconv, C);
 						SetVec(st, 1, wmix, C);
 						SetVec(st, 2, b1, C);
-						PackConv(st, wconv, C, C, K, d);
-						st.w1_off = PackDense(w1, C, C);
-						st.pk_conv_off = PackConvPk(wconv, C, C, K, 4 * st.G, 4 * st.G);
-						st.pk_w1_off = PackDensePk(w1, C, C, 4 * st.G, 4 * st.G);
+						st.ksize = K;
+						st.dilation = d;
 						st.a4_off = PackConvA4(wconv, C, C, K, st.G);       // [conv taps | 1x1 | vectors], one contiguous block
 						PackDenseA4(w1, C, C, st.G);
 						{
@@ -672,7 +597,6 @@ namespace na
 						{
 							WnStage st = EmptyStage(WN_ST_HEAD_DENSE_OUT);
 							st.vec_off = AllocF4(16);
-							st.w1_off = PackDense(wh, C, cfg.headSize);
 							st.G = CeilDiv(C, 4);
 							st.pk_w1_off = PackDensePk(wh, C, 1, 16, 1); // only head channel 0 reaches the output (WaveNet.h:793-798)
 							if (cfg.hasHeadBias)
@@ -687,7 +611,8 @@ namespace na
 							WnStage st = EmptyStage(WN_ST_HEAD_CONV_OUT);
 							st.G = CeilDiv(C, 4);
 							st.vec_off = AllocF4(16);
-							PackConv(st, wh, C, cfg.headSize, cfg.headKernelSize, cfg.headDilation);
+							st.ksize = cfg.headKernelSize;
+							st.dilation = cfg.headDilation;
 							st.pk_conv_off = PackConvPk(wh, C, 1, cfg.headKernelSize, 4 * st.G, 1);
 							if (cfg.hasHeadBias)
 							{
@@ -708,16 +633,7 @@ namespace na
 
 				plan.headScale = W(Take(1));
 				BuildSplit(layerRing, headRing);
-				// every stage's weights were allocated back to back starting with its vec block
-				for (size_t i = 0; i < plan.stages.size(); i++)
-				{
-					WnStage& st = plan.stages[i];
-					const int end = (i + 1 < plan.stages.size()) ? plan.stages[i + 1].vec_off : (int)(plan.wpack.size() / 4);
-					st.wblk_off = st.vec_off;
-					st.wblk_f4 = end - st.vec_off;
-					plan.maxStageF4 = std::max(plan.maxStageF4, st.wblk_f4);
-					plan.maxA4Floats = std::max(plan.maxA4Floats, st.a4_floats);
-				}
+				for (const WnStage& st : plan.stages) plan.maxA4Floats = std::max(plan.maxA4Floats, st.a4_floats);
 				// round the state up to a 256-byte multiple so every stream's state starts float4/line aligned
 				plan.stateF4 = CeilDiv(plan.stateF4, 16) * 16;
 			}

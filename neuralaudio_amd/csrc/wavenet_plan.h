@@ -22,7 +22,6 @@ namespace na
 	{
 		std::vector<WnStage> stages;
 		std::vector<float> wpack;   // size multiple of 4
-		std::vector<WnQuad> qdesc;
 		std::vector<float> wpk;     // weights for the packed-FMA (lane = frame) kernel
 		std::vector<WnRingInfo> rings;
 		std::vector<WnPrewarmLayer> prewarm;
@@ -33,7 +32,6 @@ namespace na
 		int splitFastT = 0;                // see WnModelDev::split_fast_T
 		int stateF4 = 0;            // per-stream state in float4 units
 		int maxA4Floats = 0;        // largest per-stage A-operand block of the frame kernel (floats)
-		int maxStageF4 = 0;         // largest per-stage weight block (float4), sizes the LDS staging buffers
 		float headScale = 0.0f;
 		int receptiveField = 0;
 
