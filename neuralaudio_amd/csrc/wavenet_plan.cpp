@@ -396,18 +396,17 @@ namespace na
 						WnSplitStage st = EmptySplit(WN_ST_LAYER);
 						st.G = G; st.Gp = Gp; st.ksize = K; st.dilation = cfg.dilations[l];
 						// operands: taps 0..K-1 (hi, lo each; tap K-1 is the unshifted one), aux = (mix-in, conv bias), then 1x1 (hi, lo) and its bias
-						st.a_ops = 2 * K + 1 + (needOutput ? 3 : 0);
+						// (the very last layer's 1x1 output is dead -- NeedOutput == false, WaveNet.h:643,785 -- but it still gets its operands:
+						// the kernel runs ONE code path for every layer)
+						st.a_ops = 2 * K + 4;
 						st.a_off = NewSplitOps(st.a_ops) * 64;
 						const int op0 = st.a_off / 64;
 						for (int k = 0; k < K; k++)
 							FillSplitMerged(op0 + 2 * k, Gp, C, C, [&](int o, int c) { return W(wconv + (o * C + c) * K + k); });
 						FillSplitAux(op0 + 2 * K, Gp, C, wmix, bconv);
-						if (needOutput)
-						{
-							FillSplitMerged(op0 + 2 * K + 1, Gp, C, C, [&](int o, int c) { return W(w1 + o * C + c); });
-							FillSplitAux(op0 + 2 * K + 3, Gp, C, -1, b1);
-							st.flags |= WN_FLAG_NEED_OUTPUT;
-						}
+						FillSplitMerged(op0 + 2 * K + 1, Gp, C, C, [&](int o, int c) { return W(w1 + o * C + c); });
+						FillSplitAux(op0 + 2 * K + 3, Gp, C, -1, b1);
+						if (needOutput) st.flags |= WN_FLAG_NEED_OUTPUT;
 						SplitRing(st, layerRing[a][l]);
 						if (cfg.activation == ACT_LEAKYRELU) st.flags |= WN_FLAG_LEAKY;
 						else if (desc.mathMode == MATH_STD) st.flags |= WN_FLAG_STD_TANH;

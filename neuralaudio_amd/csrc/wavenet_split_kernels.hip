@@ -514,13 +514,13 @@ namespace na
 					}
 				}
 				SP_STAMP(2);
-				// head accumulate (:482) on the matrix pipe: head += I * (zh + zl); 1x1 + bias + residual (:486-491)
-				const bool needOutput = (sd.flags & WN_FLAG_NEED_OUTPUT) != 0;
+				// head accumulate (:482) on the matrix pipe: head += I * (zh + zl); 1x1 + bias + residual (:486-491).  ONE path for every
+				// layer: the last layer of an array publishes nothing (its stores are predicated off), the very last layer's 1x1 output is
+				// dead but computed all the same -- a second code path costs more (registers carried around the loop, copies to merge the
+				// state) than the two 1x1s it would save.
 				const bool pub = (sd.flags & WN_FLAG_PUBLISH) != 0;
 				const u32x4 idop = cx.idop[lane];
-				if (needOutput && pub)
 				{
-					// every layer but the last one of an array: straight-line code for all sets
 					const u32x4 w1h = wl[WOP(2 * K + 1)], w1l = wl[WOP(2 * K + 2)], b1a = wl[WOP(2 * K + 3)];
 #pragma unroll
 					for (int i = 0; i < S; i++)
@@ -533,34 +533,9 @@ namespace na
 						y = Mfma(w1l, zs, y);
 						y = Mfma(b1a, ax, y);
 						st.xc[i] = y;
-						Publish(cx, imgNext, SplitQuad(y), f[i], cg[i], !GEN || (live[i] && cg[i] < sd.out_G), sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
-					}
-				}
-				else
-				{
-					u32x4 w1h, w1l, b1a;
-					if (needOutput)
-					{
-						w1h = wl[WOP(2 * K + 1)]; w1l = wl[WOP(2 * K + 2)]; b1a = wl[WOP(2 * K + 3)];
-					}
-#pragma unroll
-					for (int i = 0; i < S; i++)
-					{
-						const u32x4 zs = SplitQuad(z[i]);
-						st.hd[i] = Mfma(idop, zs, st.hd[i]);
-						u32x4 ys = zs;
-						if (needOutput)
-						{
-							const u32x4 ax = AuxOf(cx, f[i]);
-							f32x4 y = st.xc[i];
-							y = Mfma(w1h, zs, y);
-							y = Mfma(w1l, zs, y);
-							y = Mfma(b1a, ax, y);
-							st.xc[i] = y;
-							ys = SplitQuad(y);
-						}
 						// always one store per set (predicated through the offset): fixed VMEM count per layer
-						Publish(cx, imgNext, ys, f[i], cg[i], pub && (!GEN || (live[i] && cg[i] < sd.out_G)), sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, pub ? cx.nSt : 0);
+						Publish(cx, imgNext, SplitQuad(y), f[i], cg[i], pub && (!GEN || (live[i] && cg[i] < sd.out_G)), sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0,
+							pub ? cx.nSt : 0);
 					}
 				}
 				if (sd.flags & WN_FLAG_PUBLISH) cur ^= 1;
@@ -973,8 +948,15 @@ namespace na
 			if (groups[i].model->split_fast_T == 0) gen = true;
 			else t = std::max(t, groups[i].model->split_fast_T);
 		}
+#ifdef NA_SP_QUICK
+#define NA_SP_LAUNCH(TT, SS, WW) do { return sp::Launch<2, 2, 4, false>(groups, numGroups, in, out, inStride, outStride, n, stream); } while (0)
+#else
 #define NA_SP_LAUNCH(TT, SS, WW) do { return gen ? sp::Launch<TT, SS, WW, true>(groups, numGroups, in, out, inStride, outStride, n, stream) \
 	: sp::Launch<TT, SS, WW, false>(groups, numGroups, in, out, inStride, outStride, n, stream); } while (0)
+#endif
+#ifdef NA_SP_QUICK // experiment builds: only the headline instantiation
+		NA_SP_LAUNCH(2, 2, 4);
+#endif
 		if (t == 4)
 		{
 			if (tiles > 4) { if (spb >= 2) NA_SP_LAUNCH(4, 2, 2); NA_SP_LAUNCH(4, 1, 2); }
