@@ -47,9 +47,11 @@ namespace na
 		typedef const int __attribute__((address_space(4)))* CInt;
 
 #ifndef NA_ABL
-#define NA_ABL 0 // ablation bit mask for tuning builds only (tools/ablate.sh); 0 in the product.  1: no activation math, 2: no MFMA,
-                 // 4: no history loads / ring stores, 8: no barrier, 16: no weight staging, 32: no split arithmetic, 64: no LDS publish,
-                 // 128: no A-operand LDS reads (one operand reused)
+#define NA_ABL 0 // ablation bit mask for tuning builds only (make SUFFIX=_ablN KEXTRA="-DNA_ABL=N -DNA_SP_QUICK", tools/ab_bench.sh); 0 in
+                 // the product.  1: no activation math, 2: no MFMA, 4: no history loads / ring stores, 8: no barrier, 16: no weight staging,
+                 // 32: no split arithmetic, 64: no LDS publish, 128: no A-operand LDS reads (one operand reused), 256: no tap reads,
+                 // 512: ring loads and stores issued but all out of range (no traffic), 1024: only the stores so, 2048: only the loads
+                 // (round-2 measurements: profiles/r02_ablation.txt)
 #endif
 #ifndef NA_PK_TANH
 #define NA_PK_TANH 1 // tuning builds: 0 = the unpacked tanh in the activation phase
@@ -77,6 +79,10 @@ namespace na
 
 		__device__ __forceinline__ u32x4 BufLoad(__amdgpu_buffer_rsrc_t r, int voff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0); }
 		__device__ __forceinline__ void BufStore(__amdgpu_buffer_rsrc_t r, u32x4 v, int voff) { __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0); }
+		// ring traffic (streamed: every byte is read once, a launch or more after it was written; nt / sc0 / sc1 cache policies measured:
+		// nt 2-4 % slower, the others within noise -- default policy)
+		__device__ __forceinline__ u32x4 RingLoad(__amdgpu_buffer_rsrc_t r, int voff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0); }
+		__device__ __forceinline__ void RingStore(__amdgpu_buffer_rsrc_t r, u32x4 v, int voff) { __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0); }
 
 		struct Stage
 		{
@@ -242,7 +248,7 @@ namespace na
 			unsigned p = (unsigned)(base + f);
 			p = __builtin_elementwise_min(p, p - (unsigned)R); // p >= R ? p - R : p
 			const int addr = RingByte(ringOff, G, (int)p, cg);
-			return BufLoad(cx.srsrc, (valid && f < shift) ? addr : OOB);
+			return RingLoad(cx.srsrc, (!(NA_ABL & (512 | 2048)) && valid && f < shift) ? addr : OOB);
 		}
 
 		// In-block part of one conv tap operand: the split quad of frame `off` of the block image, zeros for the lanes whose frame lies
@@ -280,7 +286,7 @@ namespace na
 			unsigned p = (unsigned)(outPos0 + f);
 			p = __builtin_elementwise_min(p, p - (unsigned)outR);
 			const bool keep = liveLane && (f < nSt) && (f >= firstKept);
-			BufStore(cx.srsrc, v, keep ? RingByte(outRingOff, outG, (int)p, cg) : OOB);
+			RingStore(cx.srsrc, v, (!(NA_ABL & (512 | 1024)) && keep) ? RingByte(outRingOff, outG, (int)p, cg) : OOB);
 		}
 
 		// Stages the NEXT stage's A-operand block into the other LDS weight buffer with LDS-DMA loads (buffer_load_dwordx4 ... lds: lane l's
@@ -385,6 +391,7 @@ namespace na
 				if (s + 1 < cx.nstages) sdn = LoadStage(cx.stages, s + 1);
 				SP_STAMP(0);
 				stager.Begin(cx, (s + 1) & 1, sdn);
+				SP_STAMP(6);
 				const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + lane; // this lane's quad of operand m: wl[m * 64]
 				const u32x4* imgCur = cx.img + cur * cx.imgStride;
 				u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
@@ -445,6 +452,7 @@ namespace na
 						}
 					}
 				}
+				SP_STAMP(7);
 				// history of the NEXT layer's first HPF taps (the registers are free again)
 				{
 					const bool haveNext = (s + 1 < cx.nstages) && sdn.type == WN_ST_LAYER && sdn.Gp == GP;

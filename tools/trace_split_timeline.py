@@ -37,3 +37,8 @@ for s in range(nst):
         continue
     d = np.diff(u[:6], axis=0).mean(axis=1)
     print("%2d  %7.0f  %6.0f %6.0f %6.0f %6.0f %6.0f   total %6.0f" % ((s, u[0].min() - t0) + tuple(d) + (u[5].max() - u[0].min(),)))
+for s in [int(v) for v in os.environ.get("NA_TRACE_DETAIL", "").split(",") if v]:
+    u = t[s]
+    print("stage %d, per wave, cycles since the first wave's layer start: start [dma-issued taps-done] conv activ 1x1+pub dma-wait barrier" % s)
+    for w in range(waves):
+        print("  wave %d: " % w + " ".join("%6.0f" % (u[k, w] - u[0].min()) for k in (0, 6, 7, 1, 2, 3, 4, 5)))
