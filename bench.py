@@ -16,6 +16,7 @@ timing, and torch.distributed (RCCL) for the barrier + max-over-ranks.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -385,29 +386,24 @@ def main():
             out["host_buffer_latency_ms"] = {"p50": lat[len(lat) // 2], "p99": lat[int(len(lat) * 0.99)], "max": lat[-1], "calls": len(lat),
                                              "what": "NA_BatchProcess, %d streams x %d samples, host pointers" % (S, BLOCK)}
             # PCIe-inclusive throughput (SURVEY 8d metric 1): host buffers in, host buffers out, through the pipelined entry points
-            # (NA_BatchSubmit / NA_BatchCollect: upload of buffer k+1 and download of k-1 overlap the kernels of k).  Never `value`.
-            nb = 400
-            tickets = [batch.Submit(xh)]
-            t_a = time.perf_counter()
-            for i in range(nb):
-                tickets.append(batch.Submit(xh))
-                batch.Collect(tickets.pop(0))
-            batch.Collect(tickets.pop(0))
-            t_p = (time.perf_counter() - t_a) / nb
-            # ... and with the zero-copy variants (the host writes into / reads from the pinned staging buffers in place)
-            tickets = [batch.SubmitInput(BLOCK)]
-            t_a = time.perf_counter()
-            acc = 0.0
-            for i in range(nb):
-                batch.NextInput(BLOCK)[0, 0] = 0.001 * i  # touch the buffer the upload will read
-                tickets.append(batch.SubmitInput(BLOCK))
-                acc += float(batch.CollectView(tickets.pop(0))[0, 0])
-            batch.CollectView(tickets.pop(0))
-            t_z = (time.perf_counter() - t_a) / nb
-            out["pcie_inclusive"] = {"ms_per_buffer": t_z * 1e3, "Msamples/s": S * BLOCK / t_z / 1e6,
-                                     "what": "pinned host buffers in / out (NA_BatchNextInput + NA_BatchSubmit / NA_BatchCollect + NA_BatchOutputView), 2 buffers "
-                                             "in flight, %d streams x %d samples: upload, kernels and download overlap" % (S, BLOCK),
-                                     "with_host_copies_ms_per_buffer": t_p * 1e3}
+            # (NA_BatchSubmit / NA_BatchCollect: upload of buffer k+1 and download of k-1 overlap the kernels of k), driven by a plain C++
+            # host (tools/HostPipeBench: a Python loop around 48 us kernels measures the interpreter).  Never `value`.
+            hp = os.path.join(ROOT, "neuralaudio_amd", "HostPipeBench")
+            model_path = os.path.join(mdir, files[0]) if args.workload in ("standard", "feather", "nano", "a2full", "lstm1x16", "lstm2x8") else None
+            if os.path.exists(hp) and model_path is not None:
+                torch.cuda.synchronize(dev)
+                r = subprocess.run([hp, model_path, str(S), str(BLOCK), "2000"], capture_output=True, text=True, timeout=300)
+                if r.returncode == 0:
+                    hj = json.loads(r.stdout.strip().splitlines()[-1])
+                    out["pcie_inclusive"] = {"ms_per_buffer": hj["us_per_buffer_zero_copy"] * 1e-3,
+                                             "Msamples/s": S * BLOCK / hj["us_per_buffer_zero_copy"],
+                                             "what": "tools/HostPipeBench (C++ host over the C ABI, its own batch on the same GPU): pinned host buffers in / out "
+                                                     "(NA_BatchNextInput + NA_BatchSubmit / NA_BatchCollect + NA_BatchOutputView), 2 buffers in flight, "
+                                                     "%d streams x %d samples: upload, kernels and download overlap" % (S, BLOCK),
+                                             "with_host_copies_ms_per_buffer": hj["us_per_buffer_copying"] * 1e-3,
+                                             "blocking_call_latency_us": hj["blocking_latency_us"]}
+                else:
+                    out["pcie_inclusive"] = {"ms_per_buffer": None, "what": "HostPipeBench failed: " + r.stderr.strip()[-300:]}
         if world == 1 and not args.no_cpu_baseline and args.workload not in ("config4", "config5"):
             try:
                 out["cpu_baseline"] = mixed_cpu_baseline(["lite", "feather", "nano"]) if args.workload == "config3" else cpu_baseline(args.workload)

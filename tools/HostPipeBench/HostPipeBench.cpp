@@ -1,0 +1,89 @@
+// HostPipeBench: PCIe-inclusive throughput of the batched engine from a plain C++ host, through the C ABI only
+// (include/neuralaudio_amd.h): host buffers in, host buffers out, pipelined with NA_BatchSubmit / NA_BatchCollect.
+//   HostPipeBench <model file> [streams=1024] [frames=128] [buffers=2000]
+// Prints one JSON object: microseconds per buffer for the copying entry points (caller-owned buffers) and for the zero-copy ones
+// (NA_BatchNextInput / NA_BatchOutputView: the host produces into / consumes from the pinned staging buffers), two buffers in
+// flight, plus the blocking NA_BatchProcess latency.  bench.py reports these as "pcie_inclusive" (never as `value`).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "neuralaudio_amd.h"
+
+static double Now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+#define CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "HostPipeBench: %s failed: %s\n", #cond, NA_GetLastError()); return 1; } } while (0)
+
+int main(int argc, char** argv)
+{
+	if (argc < 2) { std::fprintf(stderr, "usage: HostPipeBench <model> [streams] [frames] [buffers]\n"); return 2; }
+	const int streams = argc > 2 ? std::atoi(argv[2]) : 1024, frames = argc > 3 ? std::atoi(argv[3]) : 128, buffers = argc > 4 ? std::atoi(argv[4]) : 2000;
+	NeuralModelLoader* loader = CreateLoader();
+	CHECK(loader != nullptr);
+	NeuralModel* model = NA_CreateModelFromFileUtf8(loader, argv[1], 0);
+	CHECK(model != nullptr);
+	NA_Batch* batch = NA_BatchCreate(0, nullptr);
+	CHECK(batch != nullptr);
+	CHECK(NA_BatchAddStreams(batch, model, 1.0f, streams, 1) >= 0);
+	const size_t count = (size_t)streams * frames;
+	std::vector<float> in(count), out(count);
+	for (size_t i = 0; i < count; i++) in[i] = 0.25f * (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.0f - 0.125f;
+
+	// blocking call, one buffer at a time
+	std::vector<double> lat;
+	for (int i = 0; i < 300; i++)
+	{
+		const double t0 = Now();
+		CHECK(NA_BatchProcess(batch, in.data(), out.data(), (size_t)frames) == 0);
+		if (i >= 50) lat.push_back((Now() - t0) * 1e6);
+	}
+	std::sort(lat.begin(), lat.end());
+
+	// copying entry points, two buffers in flight
+	int pending = NA_BatchSubmit(batch, in.data(), (size_t)frames);
+	CHECK(pending >= 0);
+	double t0 = Now();
+	for (int i = 0; i < buffers; i++)
+	{
+		const int next = NA_BatchSubmit(batch, in.data(), (size_t)frames);
+		CHECK(next >= 0);
+		CHECK(NA_BatchCollect(batch, pending, out.data()) == 0);
+		pending = next;
+	}
+	CHECK(NA_BatchCollect(batch, pending, out.data()) == 0);
+	const double usCopy = (Now() - t0) * 1e6 / buffers;
+
+	// zero-copy entry points: the host writes the next input in place and reads the result in place (here: one pass over each)
+	float* slot = NA_BatchNextInput(batch, (size_t)frames);
+	CHECK(slot != nullptr);
+	std::memcpy(slot, in.data(), count * sizeof(float));
+	pending = NA_BatchSubmit(batch, nullptr, (size_t)frames);
+	CHECK(pending >= 0);
+	double checksum = 0.0;
+	t0 = Now();
+	for (int i = 0; i < buffers; i++)
+	{
+		slot = NA_BatchNextInput(batch, (size_t)frames);
+		CHECK(slot != nullptr);
+		std::memcpy(slot, in.data(), count * sizeof(float)); // the producer's write
+		const int next = NA_BatchSubmit(batch, nullptr, (size_t)frames);
+		CHECK(next >= 0);
+		CHECK(NA_BatchCollect(batch, pending, nullptr) == 0);
+		const float* y = NA_BatchOutputView(batch, pending);
+		CHECK(y != nullptr);
+		for (size_t k = 0; k < count; k += 4096) checksum += y[k]; // the consumer's read (sparse: a real consumer reads all of it)
+		pending = next;
+	}
+	CHECK(NA_BatchCollect(batch, pending, nullptr) == 0);
+	const double usZero = (Now() - t0) * 1e6 / buffers;
+
+	std::printf("{\"streams\": %d, \"frames\": %d, \"buffers\": %d, \"us_per_buffer_zero_copy\": %.3f, \"us_per_buffer_copying\": %.3f, "
+		"\"blocking_latency_us\": {\"p50\": %.1f, \"p99\": %.1f, \"max\": %.1f}, \"checksum\": %.6g}\n",
+		streams, frames, buffers, usZero, usCopy, lat[lat.size() / 2], lat[(size_t)(lat.size() * 0.99)], lat.back(), checksum);
+	NA_BatchDestroy(batch);
+	DeleteModel(model);
+	DeleteLoader(loader);
+	return 0;
+}
