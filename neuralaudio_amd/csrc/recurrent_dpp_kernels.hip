@@ -177,6 +177,83 @@ namespace na
 	}
 
 
+	// H = 8, two layers: the two layers run side by side, one step apart.  With H = 8 the four gate rows fill 32 lanes, so instead of
+	// mirroring them into the upper half (above), the lower 32 lanes hold layer 0 and the upper 32 layer 1: in tick t layer 0 processes
+	// sample t while layer 1 processes sample t - 1, whose input h0(t - 1) it takes from the lower half with ONE lane swap.  A tick is
+	// one cell update (the same instructions serve both halves) instead of two in sequence: the dependent chain per sample -- which is
+	// all that bounds a 1024-stream batch, one wave per SIMD -- is cut from (3 dots + 2 cell updates) to (2 dots + 1), and the two
+	// dots of the upper half accumulate separately (LSTM.h:170-180 adds them in one running sum: ~1e-7 RMS apart).  n + 1 ticks per
+	// block: the last one lets layer 1 catch up, so the saved state is the reference's at every block boundary.
+	template <bool STD>
+	__device__ __forceinline__ void LstmDppSkewBody(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
+	{
+		constexpr int H = 8, HP = H + 1;
+		const int lane = threadIdx.x;
+		const int unit = lane % H;
+		const int gate = (lane / H) & 3;
+		const int layer = lane >> 5; // 0: lanes 0..31, 1: lanes 32..63
+		const int r = gate * H + unit;
+		const float* inRow = in + (size_t)row * inStride;
+		float* outRow = out + (size_t)row * outStride;
+
+		// layer 0: W row-major [4H][1 + H], bias[4H]; layer 1: W [4H][H + H] (input = layer-0 h, then own h), bias[4H] (LSTM.h:42-56).
+		// wa multiplies the layer input h (own h for layer 0), wb the own h of layer 1; rotated by `unit` for the DPP walk.
+		const float* w0 = m.w + m.layerOff[0];
+		const float* w1 = m.w + m.layerOff[1];
+		const float wx = layer == 0 ? w0[(size_t)r * (1 + H)] : 0.0f;
+		float wa[H], wb[H];
+#pragma unroll
+		for (int k = 0; k < H; k++)
+		{
+			const int col = (unit - k + H) % H; // row_ror:k hands lane p the value of lane p - k
+			wa[k] = layer == 0 ? w0[(size_t)r * (1 + H) + 1 + col] : w1[(size_t)r * (2 * H) + col];
+			wb[k] = layer == 0 ? 0.0f : w1[(size_t)r * (2 * H) + H + col];
+		}
+		const float b = layer == 0 ? w0[(size_t)4 * H * (1 + H) + r] : w1[(size_t)4 * H * (2 * H) + r];
+
+		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
+		float h = state[(size_t)(layer * 2 * H + unit) * capacity + slot];
+		float c = state[(size_t)(layer * 2 * H + H + unit) * capacity + slot];
+		RecurrentWaveSync();
+
+		float x = xin[0];
+		for (int t = 0; t <= n; t++)
+		{
+			const float xNext = xin[(t + 1 < n) ? t + 1 : n - 1]; // off the recurrence: fetched a tick ahead
+			// layer input: own h in the lower half, the lower half's h (= h0 of the sample layer 1 is about to process) in the upper
+			int hin = __builtin_bit_cast(int, h), tmp = hin;
+			LaneSwap32(hin, tmp); // hin = [h.lo, h.lo]
+			float acc = __builtin_fmaf(wx, x, b);
+			float acc2 = 0.0f;
+			DppDot<H>(acc, wa, __builtin_bit_cast(float, hin));
+			DppDot<H>(acc2, wb, h);
+			float cn = c;
+			const float hn = DppCellUpdate<H, STD>(acc + acc2, gate, unit, cn);
+			const bool active = layer == 0 ? (t < n) : (t > 0); // layer 0 has no sample n, layer 1 no sample -1
+			h = active ? hn : h;
+			c = active ? cn : c;
+			if (t > 0 && lane >= 32 && lane < 32 + H) hout[(t - 1) * HP + (lane - 32)] = h;
+			x = xNext;
+		}
+		RecurrentWaveSync();
+
+		// dense head for the whole block, lane = sample (LSTM.h:182-189)
+		const float* headW = m.w + m.headOff;
+		for (int f = lane; f < n; f += 64)
+		{
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < H; k++) acc += headW[k] * hout[f * HP + k];
+			outRow[f] = acc + headW[H];
+		}
+		if (gate == 0) // lanes 0..7: layer 0, lanes 32..39: layer 1
+		{
+			state[(size_t)(layer * 2 * H + unit) * capacity + slot] = h;
+			state[(size_t)(layer * 2 * H + H + unit) * capacity + slot] = c;
+		}
+	}
+
 	template <int H, int L>
 	__device__ __forceinline__ void LstmDppBody(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
 		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
@@ -316,6 +393,7 @@ namespace na
 	{
 		RecurrentGroupArgs g[RECURRENT_MAX_GROUPS];
 		int numGroups;
+		int noSkew; // tuning / tests (NA_REC_NOSKEW): two-layer H = 8 LSTMs on the sequential body
 	};
 
 	// grid = all streams of all groups, block = 64 (one wave per stream)
@@ -337,11 +415,17 @@ namespace na
 		switch (key)
 		{
 			NA_REC_CASE(LSTM_CELL_LSTM, 8, 1, LstmDppBody)
-			NA_REC_CASE(LSTM_CELL_LSTM, 8, 2, LstmDppBody)
+			case LSTM_CELL_LSTM * 100 + 8 * 4 + 2:
+				if (args.noSkew) LstmDppBody<8, 2>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+				else LstmDppSkewBody<false>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+				break;
 			NA_REC_CASE(LSTM_CELL_LSTM, 16, 1, LstmDppBody)
 			NA_REC_CASE(LSTM_CELL_LSTM, 16, 2, LstmDppBody)
 			NA_REC_CASE(10 + LSTM_CELL_LSTM, 8, 1, LstmDppBodyStd)
-			NA_REC_CASE(10 + LSTM_CELL_LSTM, 8, 2, LstmDppBodyStd)
+			case (10 + LSTM_CELL_LSTM) * 100 + 8 * 4 + 2:
+				if (args.noSkew) LstmDppBodyStd<8, 2>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+				else LstmDppSkewBody<true>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+				break;
 			NA_REC_CASE(10 + LSTM_CELL_LSTM, 16, 1, LstmDppBodyStd)
 			NA_REC_CASE(10 + LSTM_CELL_LSTM, 16, 2, LstmDppBodyStd)
 			NA_REC_CASE(LSTM_CELL_GRU, 8, 1, GruDppBody)
@@ -365,6 +449,8 @@ namespace na
 		if (n > LSTM_MAX_FRAMES || numGroups > RECURRENT_MAX_GROUPS) return hipErrorInvalidValue;
 		RecurrentLaunchArgs args = {};
 		args.numGroups = numGroups;
+		static const bool noSkew = getenv("NA_REC_NOSKEW") != nullptr;
+		args.noSkew = noSkew ? 1 : 0;
 		int blocks = 0;
 		for (int i = 0; i < numGroups; i++)
 		{
