@@ -439,6 +439,20 @@ namespace na
 				dev.headOff = (int)w.size();
 				w.insert(w.end(), lstm.headWeights.begin(), lstm.headWeights.begin() + lstm.hiddenSize);
 				w.push_back(lstm.headBias);
+				dev.tailLayers = (int)lstm.tail.size(); // generic keras stack: a chain of dense layers instead of the head
+				dev.tailWidth = 0;
+				for (size_t t = 0; t < lstm.tail.size(); t++)
+				{
+					const DenseLayerDesc& dl = lstm.tail[t];
+					dev.tailOff[t] = (int)w.size();
+					dev.tailIn[t] = dl.in;
+					dev.tailOut[t] = dl.out;
+					dev.tailAct[t] = dl.activation;
+					dev.tailWidth = std::max(dev.tailWidth, dl.out);
+					w.insert(w.end(), dl.w.begin(), dl.w.end());
+					w.insert(w.end(), dl.b.begin(), dl.b.end());
+					tailMacs += (double)dl.in * dl.out;
+				}
 				dW.Upload(w, stream);
 				dInit.Upload(init, stream);
 				dev.w = dW.Get();
@@ -525,7 +539,7 @@ namespace na
 				double macs = 0.0;
 				const double gates = (lstm.cell == CELL_GRU) ? 3.0 : 4.0;
 				for (int l = 0; l < lstm.numLayers; l++) macs += gates * lstm.hiddenSize * ((l == 0 ? 1 : lstm.hiddenSize) + lstm.hiddenSize);
-				return macs + lstm.hiddenSize;
+				return macs + (lstm.tail.empty() ? lstm.hiddenSize : tailMacs);
 			}
 
 			size_t StateBytesPerStream() const override { return (size_t)numElems * sizeof(float); }
@@ -554,6 +568,7 @@ namespace na
 			DevArray<float> state;
 			std::vector<float> init;
 			int numElems = 0;
+			double tailMacs = 0.0;
 			size_t capacity = 0;
 		};
 	}

@@ -18,6 +18,7 @@
 #include "dpp_recurrent.h"
 #include "lstm_dev.h"
 #include "lstm_launch.h"
+#include "recurrent_tail.h"
 
 namespace na
 {
@@ -134,6 +135,8 @@ namespace na
 			float* hAll = lds + 64 * ioStride;
 			float* ai = hAll + (size_t)m.numLayers * H * 64;
 			float* ah = ai + (size_t)3 * H * 64;
+			float* tailA = ah + (size_t)3 * H * 64; // generic keras stack only: two [tailWidth][64] arrays
+			float* tailB = tailA + (size_t)m.tailWidth * 64;
 			const int lane = threadIdx.x;
 			const int idx = blockIdx.x * 64 + lane;
 			const bool active = idx < numStreams;
@@ -182,6 +185,11 @@ namespace na
 					}
 				}
 				const float* hl = hAll + (size_t)(m.numLayers - 1) * H * 64;
+				if (m.tailLayers > 0)
+				{
+					io[lane * ioStride + f] = DenseTail(m, hl, H, x0, tailA, tailB, lane);
+					continue;
+				}
 				float acc = 0.0f;
 				for (int k = 0; k < H; k++) acc += headW[k] * hl[k * 64 + lane];
 				io[lane * ioStride + f] = acc + headW[H];
@@ -204,7 +212,7 @@ namespace na
 		hipError_t LaunchGruGeneric(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams, const float* in,
 			float* out, long inStride, long outStride, int n, hipStream_t stream)
 		{
-			const size_t ldsBytes = ((size_t)64 * (n + 1) + (size_t)m.numLayers * m.hidden * 64 + (size_t)6 * m.hidden * 64) * sizeof(float);
+			const size_t ldsBytes = ((size_t)64 * (n + 1) + (size_t)m.numLayers * m.hidden * 64 + (size_t)6 * m.hidden * 64 + (size_t)2 * (m.tailLayers > 0 ? m.tailWidth : 0) * 64) * sizeof(float);
 			if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
 			static bool attrSet = false;
 			if (!attrSet)
@@ -231,7 +239,8 @@ namespace na
 		float* out, long inStride, long outStride, int n, hipStream_t stream)
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
-		if (n > LSTM_MAX_FRAMES || !GruShapeSupported(m.hidden, m.numLayers)) return hipErrorInvalidValue;
+		if (n > LSTM_MAX_FRAMES || !GruShapeSupported(m.hidden, m.numLayers, m.tailLayers > 0 ? m.tailWidth : 0)) return hipErrorInvalidValue;
+		if (m.tailLayers > 0) return LaunchGruGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream); // generic keras stack
 		static const bool noDpp = getenv("NA_GRU_NO_DPP") != nullptr; // tuning knob: the LDS-broadcast kernel for every shape
 		if (!noDpp && RecurrentDppSupported(m))
 		{

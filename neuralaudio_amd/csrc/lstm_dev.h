@@ -14,6 +14,8 @@ namespace na
 {
 	constexpr int LSTM_MAX_LAYERS = 8;
 	constexpr int LSTM_MAX_FRAMES = 128;
+	constexpr int LSTM_MAX_TAIL = 4;        // dense layers of a generic keras stack
+	constexpr int LSTM_MAX_TAIL_WIDTH = 64; // units per dense layer
 
 	enum { LSTM_CELL_LSTM = 0, LSTM_CELL_GRU = 1 };
 	enum { LSTM_MATH_FAST = 0, LSTM_MATH_STD = 1 };
@@ -21,16 +23,17 @@ namespace na
 	// Shapes with a kernel (host-side predicates, no HIP types: the loader rejects everything else at load time).
 	//   LSTM: any hidden size / layer count whose lane = stream working set fits the 160 KB LDS (LstmGenericKernel); the usual sizes
 	//   have shaped kernels.  GRU: likewise (GruGenericKernel; GruWaveKernel / DPP instances for 1-2 layers of 8, 12, 16, 20).
-	inline bool LstmShapeSupported(int hidden, int numLayers)
+	// tailWidth: widest dense layer of a generic keras stack (0: the classic 1-unit head); such a model may have no recurrent layer
+	inline bool LstmShapeSupported(int hidden, int numLayers, int tailWidth = 0)
 	{
-		if (hidden < 1 || numLayers < 1 || numLayers > LSTM_MAX_LAYERS) return false;
-		const long bytes = (64L * (LSTM_MAX_FRAMES + 1) + (long)numLayers * 2 * hidden * 64 + (long)hidden * 64) * 4;
+		if (hidden < 1 || numLayers < (tailWidth > 0 ? 0 : 1) || numLayers > LSTM_MAX_LAYERS || tailWidth > LSTM_MAX_TAIL_WIDTH) return false;
+		const long bytes = (64L * (LSTM_MAX_FRAMES + 1) + (long)numLayers * 2 * hidden * 64 + (long)hidden * 64 + 2L * tailWidth * 64) * 4;
 		return bytes <= 160L * 1024;
 	}
-	inline bool GruShapeSupported(int hidden, int numLayers)
+	inline bool GruShapeSupported(int hidden, int numLayers, int tailWidth = 0)
 	{
-		if (hidden < 1 || numLayers < 1 || numLayers > LSTM_MAX_LAYERS) return false;
-		const long bytes = (64L * (LSTM_MAX_FRAMES + 1) + (long)numLayers * hidden * 64 + 6L * hidden * 64) * 4; // GruGenericKernel's LDS
+		if (hidden < 1 || numLayers < 1 || numLayers > LSTM_MAX_LAYERS || tailWidth > LSTM_MAX_TAIL_WIDTH) return false;
+		const long bytes = (64L * (LSTM_MAX_FRAMES + 1) + (long)numLayers * hidden * 64 + 6L * hidden * 64 + 2L * tailWidth * 64) * 4; // GruGenericKernel's LDS
 		return bytes <= 160L * 1024;
 	}
 
@@ -46,5 +49,10 @@ namespace na
 		int layerOff[LSTM_MAX_LAYERS]; // float offset of layer l's W
 		int headOff;
 		int math;      // LSTM only: 0 = FastMath (Activation.h:83-96), 1 = StdMath (Activation.h:20-45) -- the reference's LSTM_MATH build option
+		// generic keras stack: tailLayers > 0 replaces the head by a chain of dense layers, layer t = W row-major [out][in] at
+		// tailOff[t], then bias[out]; activation codes = DenseActivation (model_desc.h).  Only the runtime-shaped kernels evaluate it.
+		int tailLayers;
+		int tailOff[LSTM_MAX_TAIL], tailIn[LSTM_MAX_TAIL], tailOut[LSTM_MAX_TAIL], tailAct[LSTM_MAX_TAIL];
+		int tailWidth; // widest layer
 	};
 }

@@ -12,6 +12,7 @@
 #include "dpp_recurrent.h"
 #include "lstm_dev.h"
 #include "lstm_launch.h"
+#include "recurrent_tail.h"
 
 namespace na
 {
@@ -368,6 +369,8 @@ namespace na
 		const int ioStride = n + 1;
 		float* hcAll = lds + 64 * ioStride;
 		float* hnew = hcAll + (size_t)m.numLayers * 2 * H * 64;
+		float* tailA = hnew + (size_t)H * 64; // generic keras stack only: two [tailWidth][64] arrays
+		float* tailB = tailA + (size_t)m.tailWidth * 64;
 
 		const int lane = threadIdx.x;
 		const int idx = blockIdx.x * 64 + lane;
@@ -417,7 +420,12 @@ namespace na
 				}
 				for (int i = 0; i < H; i++) hc[i * 64 + lane] = hnew[i * 64 + lane];
 			}
-			const float* hl = hcAll + (size_t)(m.numLayers - 1) * 2 * H * 64;
+			const float* hl = hcAll + (size_t)(m.numLayers > 0 ? m.numLayers - 1 : 0) * 2 * H * 64;
+			if (m.tailLayers > 0)
+			{
+				io[lane * ioStride + f] = DenseTail(m, m.numLayers > 0 ? hl : nullptr, m.numLayers > 0 ? H : 0, x0, tailA, tailB, lane);
+				continue;
+			}
 			float acc = 0.0f;
 			for (int k = 0; k < H; k++) acc += headW[k] * hl[k * 64 + lane];
 			io[lane * ioStride + f] = acc + headW[H]; // LSTM.h:182-189
@@ -437,15 +445,15 @@ namespace na
 		}
 	}
 
-	static size_t LstmGenericLdsBytes(int hidden, int numLayers, int n)
+	static size_t LstmGenericLdsBytes(int hidden, int numLayers, int n, int tailWidth)
 	{
-		return ((size_t)64 * (n + 1) + (size_t)numLayers * 2 * hidden * 64 + (size_t)hidden * 64) * sizeof(float);
+		return ((size_t)64 * (n + 1) + (size_t)numLayers * 2 * hidden * 64 + (size_t)hidden * 64 + (size_t)2 * tailWidth * 64) * sizeof(float);
 	}
 
 	static hipError_t LaunchGeneric(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams, const float* in,
 		float* out, long inStride, long outStride, int n, hipStream_t stream)
 	{
-		const size_t ldsBytes = LstmGenericLdsBytes(m.hidden, m.numLayers, n);
+		const size_t ldsBytes = LstmGenericLdsBytes(m.hidden, m.numLayers, n, m.tailLayers > 0 ? m.tailWidth : 0);
 		if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
 		static bool attrSet = false;
 		if (!attrSet)
@@ -463,6 +471,7 @@ namespace na
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > LSTM_MAX_FRAMES) return hipErrorInvalidValue;
+		if (m.tailLayers > 0) return LaunchGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream); // generic keras stack
 		{
 			static const bool forceLaneKernel = getenv("NA_LSTM_LANE_KERNEL") != nullptr; // tuning knob
 			hipError_t err = hipSuccess;

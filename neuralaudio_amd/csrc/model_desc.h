@@ -51,6 +51,16 @@ namespace na
 
 	enum RecurrentCell { CELL_LSTM = 0, CELL_GRU = 1 };
 
+	// one keras "dense" layer of a generic stack (RTNeural's Dense + activation layer, RTNeuralModel.h:300)
+	enum DenseActivation { DENSE_LINEAR = 0, DENSE_TANH = 1, DENSE_RELU = 2, DENSE_SIGMOID = 3, DENSE_ELU = 4 };
+	struct DenseLayerDesc
+	{
+		int in = 0, out = 0;
+		int activation = DENSE_LINEAR;
+		std::vector<float> w; // row-major [out][in]
+		std::vector<float> b; // [out]
+	};
+
 	struct LSTMDesc
 	{
 		int cell = CELL_LSTM; // CELL_GRU: keras GRU (RTNeural's arithmetic in the reference, NeuralModel.cpp:565-572)
@@ -60,6 +70,10 @@ namespace na
 		std::vector<float> headWeights; // [H]
 		float headBias = 0.0f;
 		std::vector<float> headBiasVec; // scratch of the keras readers
+		// Generic keras stacks (the reference's RTNeuralModelDyn, NeuralModel.cpp:565-572): 0..8 recurrent layers of one kind followed by
+		// this chain of dense layers; the model output is unit 0 of the last one.  Empty: the classic [H] -> 1 linear head above.
+		// numLayers == 0 with a tail: a pure dense stack on the input sample.
+		std::vector<DenseLayerDesc> tail;
 		bool isStatic = false;
 		int mathMode = MATH_FAST; // LSTM only (the GRU follows RTNeural's accurate maths)
 	};

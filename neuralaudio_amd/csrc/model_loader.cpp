@@ -325,13 +325,27 @@ namespace na
 
 	void ValidateRecurrentDesc(const LSTMDesc& d)
 	{
+		int tailWidth = 0;
+		if (!d.tail.empty())
+		{
+			if ((int)d.tail.size() > LSTM_MAX_TAIL) throw std::runtime_error("keras model with more than " + std::to_string(LSTM_MAX_TAIL) + " dense layers is not supported");
+			int in = d.numLayers > 0 ? d.hiddenSize : 1;
+			for (const DenseLayerDesc& t : d.tail)
+			{
+				if (t.in != in || t.out < 1 || (int)t.w.size() != t.in * t.out || (int)t.b.size() != t.out)
+					throw std::runtime_error("keras dense layer has unexpected weight shapes");
+				if (t.out > LSTM_MAX_TAIL_WIDTH) throw std::runtime_error("keras dense layer wider than " + std::to_string(LSTM_MAX_TAIL_WIDTH) + " units is not supported");
+				tailWidth = std::max(tailWidth, t.out);
+				in = t.out;
+			}
+		}
 		if (d.cell == CELL_GRU)
 		{
-			if (!GruShapeSupported(d.hiddenSize, d.numLayers))
+			if (!GruShapeSupported(d.hiddenSize, d.numLayers, tailWidth))
 				throw std::runtime_error("GRU " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
 					" is not supported (1-8 layers; the per-stream state must fit the 160 KB LDS)");
 		}
-		else if (!LstmShapeSupported(d.hiddenSize, d.numLayers))
+		else if (!LstmShapeSupported(d.hiddenSize, d.numLayers, tailWidth))
 			throw std::runtime_error("LSTM " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
 				" is not supported (1-8 layers; the per-stream state must fit the 160 KB LDS)");
 	}
@@ -427,6 +441,112 @@ namespace na
 			}
 			lstm.mathMode = opts.lstmMath;
 			ValidateRecurrentDesc(lstm);
+			return desc;
+		}
+
+		// One keras dense layer: weights [in][out], bias [out], optional activation (RTNeural json_parser: a Dense layer followed by an
+		// activation layer).  Throws on an activation this library has no kernel for.
+		DenseLayerDesc ReadKerasDense(const Json& layer, int in)
+		{
+			DenseLayerDesc d;
+			d.in = in;
+			d.out = layer.At("shape").Back().AsInt();
+			std::vector<float> kernel;
+			layer.At("weights").At(0).FlattenNumbers(kernel); // [in][out]
+			layer.At("weights").At(1).FlattenNumbers(d.b);
+			if (d.out < 1 || (int)kernel.size() != d.in * d.out || (int)d.b.size() != d.out) throw std::runtime_error("keras dense layer has unexpected weight shapes");
+			d.w.assign(kernel.size(), 0.0f);
+			for (int k = 0; k < d.in; k++)
+				for (int o = 0; o < d.out; o++) d.w[(size_t)o * d.in + k] = kernel[(size_t)k * d.out + o];
+			const std::string act = layer.Contains("activation") ? layer.At("activation").AsString() : std::string();
+			if (act.empty() || act == "linear") d.activation = DENSE_LINEAR;
+			else if (act == "tanh") d.activation = DENSE_TANH;
+			else if (act == "relu") d.activation = DENSE_RELU;
+			else if (act == "sigmoid") d.activation = DENSE_SIGMOID;
+			else if (act == "elu") d.activation = DENSE_ELU;
+			else throw std::runtime_error("keras dense activation '" + act + "' is not supported");
+			return d;
+		}
+
+		// Generic keras stacks -- what the reference hands to RTNeural's json_parser (NeuralModel.cpp:565-572, RTNeuralModel.h:300):
+		// zero or more recurrent layers of ONE kind (lstm | gru, equal sizes) followed by one or more dense layers with activations;
+		// the output is unit 0 of the last layer (RTNeuralModelDyn::Process, RTNeuralModel.h:417-421).  Arithmetic as RTNeural's with the
+		// reference's FastMathsProvider (RTNeuralModel.h:10-31): accurate tanh, sigmoid = (tanh(x/2)+1)/2 -- so an LSTM in such a
+		// stack runs with the StdMath policy.  Parity unpinned (RTNeural is an absent submodule): tests compare against a numpy
+		// restatement of the Keras definitions.  Other layer types (conv1d, batchnorm, prelu ...) have no kernel: nullptr.
+		std::shared_ptr<ModelDesc> ReadKerasStack(const Json& modelJson)
+		{
+			const Json& layers = modelJson.At("layers");
+			const size_t total = layers.Size();
+			size_t numRec = 0;
+			std::string cell;
+			while (numRec < total)
+			{
+				const std::string t = layers.At(numRec).At("type").AsString();
+				if (t != "lstm" && t != "gru") break;
+				if (cell.empty()) cell = t;
+				else if (cell != t) return nullptr;
+				numRec++;
+			}
+			if (numRec == total) return nullptr; // no dense layer at the end
+			for (size_t i = numRec; i < total; i++)
+				if (layers.At(i).At("type").AsString() != "dense") return nullptr;
+
+			std::shared_ptr<ModelDesc> desc;
+			if (numRec > 0)
+			{
+				// the recurrent part through the classic readers (they expect [recurrent..., dense]): parse a copy of the layer list cut
+				// after the first dense layer, then replace its head by the real tail
+				desc = std::make_shared<ModelDesc>();
+				desc->kind = MODEL_LSTM;
+				LSTMDesc& d = desc->lstm;
+				d.cell = (cell == "gru") ? CELL_GRU : CELL_LSTM;
+				d.numLayers = (int)numRec;
+				d.hiddenSize = layers.At(0).At("shape").Back().AsInt();
+				const int H = d.hiddenSize, gates = (d.cell == CELL_GRU) ? 3 : 4;
+				for (size_t l = 0; l < numRec; l++)
+				{
+					const Json& layer = layers.At(l);
+					if (layer.At("shape").Back().AsInt() != H) return nullptr;
+					std::vector<float> kernel, recurrent, bias;
+					layer.At("weights").At(0).FlattenNumbers(kernel);    // [I][gates H]
+					layer.At("weights").At(1).FlattenNumbers(recurrent); // [H][gates H]
+					layer.At("weights").At(2).FlattenNumbers(bias);      // lstm [4H]; gru [2][3H]
+					LSTMLayerDesc ld;
+					ld.inputSize = (l == 0) ? 1 : H;
+					const int I = ld.inputSize, W = I + H, R = gates * H;
+					if ((int)kernel.size() != I * R || (int)recurrent.size() != H * R || (int)bias.size() != (d.cell == CELL_GRU ? 2 * R : R))
+						throw std::runtime_error("keras " + cell + " layer has unexpected weight shapes");
+					ld.w.assign((size_t)R * W, 0.0f);
+					for (int j = 0; j < I; j++)
+						for (int i = 0; i < R; i++) ld.w[(size_t)i * W + j] = kernel[(size_t)j * R + i];
+					for (int j = 0; j < H; j++)
+						for (int i = 0; i < R; i++) ld.w[(size_t)i * W + I + j] = recurrent[(size_t)j * R + i];
+					ld.bias = bias;
+					ld.h0.assign((size_t)H, 0.0f);
+					ld.c0.assign((size_t)H, 0.0f);
+					d.layers.push_back(std::move(ld));
+				}
+				d.mathMode = MATH_STD; // RTNeural with the reference's FastMathsProvider: accurate tanh
+			}
+			else
+			{
+				desc = std::make_shared<ModelDesc>();
+				desc->kind = MODEL_LSTM;
+				desc->lstm.cell = CELL_LSTM;
+				desc->lstm.numLayers = 0;
+				desc->lstm.hiddenSize = 1;
+				desc->lstm.mathMode = MATH_STD;
+			}
+			LSTMDesc& d = desc->lstm;
+			int in = numRec > 0 ? d.hiddenSize : 1;
+			for (size_t i = numRec; i < total; i++)
+			{
+				d.tail.push_back(ReadKerasDense(layers.At(i), in));
+				in = d.tail.back().out;
+			}
+			d.headWeights.assign((size_t)std::max(d.hiddenSize, 1), 0.0f); // unused with a tail
+			ValidateRecurrentDesc(d);
 			return desc;
 		}
 
@@ -540,12 +660,22 @@ namespace na
 			ReadKerasConfig(modelJson, model->info);
 			const Json& layers = modelJson.At("layers");
 			const std::string modelType = layers.At(0).At("type").AsString();
-			// "lstm": Internal path (NeuralModel.cpp:526-563); "gru": RTNeural in the reference (:565-572), restated here (parity
-			// unpinned); anything else (conv1d, activations, wider dense stacks ...) needs the generic RTNeural engine
-			if (modelType != "lstm" && modelType != "gru") return nullptr;
+			// "lstm": Internal path (NeuralModel.cpp:526-563); "gru" and every other stack of lstm | gru and dense layers: RTNeural in
+			// the reference (:565-572), restated here (parity unpinned); layer types without a kernel (conv1d, batchnorm ...): no model
 			SubModel sm;
 			sm.info = model->info;
-			sm.desc = (modelType == "gru") ? ReadKerasGRU(modelJson) : ReadKerasLSTM(modelJson, opts);
+			// the classic shapes first ([lstm..., dense(1)] / [gru..., dense(1)], no activation: the shaped kernels), then the generic stack
+			bool classic = (modelType == "lstm" || modelType == "gru");
+			if (classic)
+			{
+				const size_t nl = layers.Size();
+				for (size_t i = 0; i + 1 < nl && classic; i++) classic = layers.At(i).At("type").AsString() == modelType;
+				const Json& last = layers.At(nl - 1);
+				classic = classic && nl >= 2 && last.At("type").AsString() == "dense" && last.At("shape").Back().AsInt() == 1 &&
+					(!last.Contains("activation") || last.At("activation").AsString().empty() || last.At("activation").AsString() == "linear");
+			}
+			if (classic) sm.desc = (modelType == "gru") ? ReadKerasGRU(modelJson) : ReadKerasLSTM(modelJson, opts);
+			if (!sm.desc) sm.desc = ReadKerasStack(modelJson);
 			if (!sm.desc) return nullptr;
 			model->subModels.push_back(sm);
 			model->qualityLevels.push_back({ 1.0f, 0 });

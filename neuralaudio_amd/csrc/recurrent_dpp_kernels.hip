@@ -439,7 +439,8 @@ namespace na
 
 	bool RecurrentDppSupported(const LstmModelDev& m)
 	{
-		return (m.hidden == 8 || m.hidden == 16) && (m.numLayers == 1 || m.numLayers == 2) && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU);
+		return (m.hidden == 8 || m.hidden == 16) && (m.numLayers == 1 || m.numLayers == 2) && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU) &&
+			m.tailLayers == 0; // generic keras stacks run on the runtime-shaped kernels
 	}
 
 	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,

@@ -174,3 +174,66 @@ def gru_forward_keras(model_json, x, prewarm=2048):
             inp = h[l]
         out[t] = wh @ h[-1] + bh
     return out[prewarm:]
+
+
+def keras_stack_forward(model_json, x, prewarm=2048):
+    """Generic keras stack [lstm | gru]* + dense+ (what the reference hands to RTNeural's json_parser, RTNeuralModel.h:300), in float64
+    with the Keras layer definitions and accurate tanh / sigmoid = (tanh(x/2)+1)/2 (the reference's FastMathsProvider,
+    RTNeuralModel.h:10-31).  Output = unit 0 of the last layer; zero initial state, `prewarm` zeros first."""
+    layers = model_json["layers"]
+    sig = lambda v: 0.5 * (np.tanh(0.5 * v) + 1.0)
+    acts = {"": lambda v: v, "linear": lambda v: v, "tanh": np.tanh, "relu": lambda v: np.maximum(v, 0.0), "sigmoid": sig,
+            "elu": lambda v: np.where(v > 0, v, np.exp(np.minimum(v, 0.0)) - 1.0)}
+    state = []
+    for l in layers:
+        H = int(l["shape"][-1])
+        state.append([np.zeros(H), np.zeros(H)] if l["type"] in ("lstm", "gru") else None)
+    W = [[np.array(w, dtype=np.float64) for w in l["weights"]] for l in layers]
+    xs = np.concatenate([np.zeros(prewarm), np.asarray(x, dtype=np.float64)])
+    out = np.empty(xs.size)
+    for t, xv in enumerate(xs):
+        v = np.array([xv])
+        for i, l in enumerate(layers):
+            H = int(l["shape"][-1])
+            if l["type"] == "lstm":
+                h, c = state[i]
+                g = v @ W[i][0] + h @ W[i][1] + W[i][2].ravel()  # gate column blocks i, f, g(c), o
+                c = sig(g[H:2 * H]) * c + sig(g[:H]) * np.tanh(g[2 * H:3 * H])
+                h = sig(g[3 * H:]) * np.tanh(c)
+                state[i] = [h, c]
+                v = h
+            elif l["type"] == "gru":
+                h = state[i][0]
+                ai = v @ W[i][0] + W[i][2][0]
+                ah = h @ W[i][1] + W[i][2][1]
+                z = sig(ai[:H] + ah[:H])
+                r = sig(ai[H:2 * H] + ah[H:2 * H])
+                c = np.tanh(ai[2 * H:] + r * ah[2 * H:])
+                h = (1.0 - z) * c + z * h
+                state[i][0] = h
+                v = h
+            else:
+                v = acts[l.get("activation", "") or ""](v @ W[i][0] + W[i][1].ravel())
+        out[t] = v[0]
+    return out[prewarm:]
+
+
+def synth_keras_stack(spec, seed):
+    """spec: list of ("lstm" | "gru" | "dense", units[, activation]); seeded U(-a, a) weights, a = 1/sqrt(fan-in-ish)."""
+    rng = np.random.default_rng(seed)
+    layers = []
+    cur = 1
+    for item in spec:
+        kind, units = item[0], item[1]
+        a = 1.0 / np.sqrt(max(units, cur))
+        if kind in ("lstm", "gru"):
+            g = 4 if kind == "lstm" else 3
+            bias = rng.uniform(-a, a, (g * units,)) if kind == "lstm" else rng.uniform(-a, a, (2, g * units))
+            layers.append({"type": kind, "activation": "tanh", "shape": [None, None, units],
+                           "weights": [rng.uniform(-a, a, (cur, g * units)).round(7).tolist(), rng.uniform(-a, a, (units, g * units)).round(7).tolist(),
+                                       bias.round(7).tolist()]})
+        else:
+            layers.append({"type": "dense", "activation": item[2] if len(item) > 2 else "", "shape": [None, None, units],
+                           "weights": [rng.uniform(-a, a, (cur, units)).round(7).tolist(), rng.uniform(-a, a, (units,)).round(7).tolist()]})
+        cur = units
+    return {"in_shape": [None, None, 1], "in_skip": 0, "samplerate": 48000.0, "layers": layers}

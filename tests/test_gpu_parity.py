@@ -148,3 +148,25 @@ def test_runtime_shaped_lstm_matches_oracle(na, loader, layers, hidden):
     y = np.concatenate([m.Process(x[i:i + 100]) for i in range(0, x.size, 100)])
     yo = O.OracleLSTM.from_nam(layers, hidden, w).process(x)
     assert O.rms(y - yo) < 5e-6, (layers, hidden, O.rms(y - yo))
+
+
+@pytest.mark.parametrize("spec", [[("lstm", 8), ("dense", 6, "tanh"), ("dense", 1)], [("gru", 12), ("dense", 5, "relu"), ("dense", 3, "sigmoid"), ("dense", 1)],
+                                  [("dense", 8, "tanh"), ("dense", 4, "elu"), ("dense", 1)], [("gru", 8), ("gru", 8), ("dense", 2)],
+                                  [("lstm", 16), ("dense", 1, "tanh")], [("lstm", 5), ("lstm", 5), ("dense", 64, "relu"), ("dense", 1)]],
+                         ids=lambda s: "-".join("%s%d%s" % (l[0], l[1], l[2] if len(l) > 2 else "") for l in s))
+def test_generic_keras_stack_matches_numpy_restatement(na, loader, spec):
+    """Generic keras stacks (SURVEY 8 f3): the reference evaluates them with RTNeural, which is an absent submodule -- parity unpinned;
+    the checker is tests/ref_np.keras_stack_forward (Keras layer definitions, float64, accurate tanh as the reference's
+    FastMathsProvider).  Chunked processing must not matter either."""
+    import json
+    import ref_np as R
+    mj = R.synth_keras_stack(spec, seed=40 + len(spec))
+    m = loader.CreateFromString(json.dumps(mj), ".json")
+    assert m is not None
+    x = O.signal_noise(384, 9)
+    y = np.concatenate([m.Process(x[i:i + 100]) for i in range(0, x.size, 100)])
+    yr = R.keras_stack_forward(mj, x)
+    assert O.rms(y - yr) < 5e-6, (spec, O.rms(y - yr))
+    m2 = loader.CreateFromString(json.dumps(mj), ".json")
+    y2 = m2.Process(x)
+    assert np.max(np.abs(y2 - y)) < 1e-6

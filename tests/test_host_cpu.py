@@ -170,15 +170,20 @@ def test_missing_and_malformed_files(na, tmp_path):
     conv = tmp_path / "conv.json"
     conv.write_text(json.dumps({"in_shape": [None, None, 1], "layers": [{"type": "conv1d", "shape": [None, None, 8], "weights": []},
                                                                         {"type": "dense", "shape": [None, None, 1], "weights": []}]}))
-    assert loader.CreateFromFile(str(conv)) is None  # generic keras stacks need the RTNeural engine (NeuralModel.cpp:565-572)
+    assert loader.CreateFromFile(str(conv)) is None  # keras layer types without a kernel: no model (the reference needs RTNeural for them)
     gru = tmp_path / "gru.json"
     gru.write_text(json.dumps(O.synth_keras_gru(1, 16, seed=3)))
     g = loader.CreateFromFile(str(gru), doPrewarm=False)  # keras GRU: RTNeural's arithmetic in the reference, restated here
     assert g is not None and g.GetSampleRate() == 48000.0 and g.GetReceptiveFieldSize() == -1
     wide = O.synth_keras_gru(1, 16, seed=3)
-    wide["layers"][-1]["weights"] = [[[0.1, 0.2]] * 16, [0.0, 0.0]]  # dense head with 2 outputs: not this path
+    wide["layers"][-1]["weights"] = [[[0.1, 0.2]] * 16, [0.0, 0.0]]  # dense head with 2 outputs: a generic stack (output = unit 0)
+    wide["layers"][-1]["shape"] = [None, None, 2]
     gru.write_text(json.dumps(wide))
-    assert loader.CreateFromFile(str(gru), doPrewarm=False) is None
+    assert loader.CreateFromFile(str(gru), doPrewarm=False) is not None
+    wide["layers"][-1]["shape"] = [None, None, 1]  # ... but the declared shape must match the weights
+    gru.write_text(json.dumps(wide))
+    with pytest.raises(na.NeuralAudioError, match="unexpected weight shapes"):
+        loader.CreateFromFile(str(gru), doPrewarm=False)
 
 
 def test_lstm_shapes_accepted_or_rejected_at_load(na, tmp_path):
@@ -197,6 +202,34 @@ def test_lstm_shapes_accepted_or_rejected_at_load(na, tmp_path):
     gru.write_text(json.dumps(O.synth_keras_gru(1, 96, seed=3)))
     with pytest.raises(na.NeuralAudioError, match="GRU 1x96 is not supported"):
         loader.CreateFromFile(str(gru), doPrewarm=False)
+
+
+def test_generic_keras_stacks_accepted_or_rejected_at_load(na, tmp_path):
+    """Stacks of lstm | gru and dense layers with activations -- what the reference hands to RTNeural (NeuralModel.cpp:565-572) -- load;
+    layer types / activations / sizes without a kernel fail at load with a reason (no silent fallback)."""
+    import ref_np as R
+    loader = na.NeuralModelLoader()
+    path = tmp_path / "m.json"
+    for spec in ([("lstm", 8), ("dense", 6, "tanh"), ("dense", 1)], [("gru", 12), ("dense", 5, "relu"), ("dense", 3, "sigmoid"), ("dense", 1)],
+                 [("dense", 8, "tanh"), ("dense", 4, "elu"), ("dense", 1)], [("gru", 8), ("dense", 2)], [("lstm", 16), ("dense", 1, "tanh")]):
+        path.write_text(json.dumps(R.synth_keras_stack(spec, seed=5)))
+        m = loader.CreateFromFile(str(path), doPrewarm=False)
+        assert m is not None, spec
+    bad = R.synth_keras_stack([("gru", 8), ("dense", 4, "tanh"), ("dense", 1)], seed=6)
+    bad["layers"][1]["activation"] = "softmax"
+    path.write_text(json.dumps(bad))
+    with pytest.raises(na.NeuralAudioError, match="activation 'softmax' is not supported"):
+        loader.CreateFromFile(str(path), doPrewarm=False)
+    path.write_text(json.dumps(R.synth_keras_stack([("gru", 8), ("dense", 100, "tanh"), ("dense", 1)], seed=6)))
+    with pytest.raises(na.NeuralAudioError, match="wider than 64 units"):
+        loader.CreateFromFile(str(path), doPrewarm=False)
+    mixed = R.synth_keras_stack([("gru", 8), ("lstm", 8), ("dense", 1)], seed=7)  # two kinds of recurrent layers: no kernel
+    path.write_text(json.dumps(mixed))
+    assert loader.CreateFromFile(str(path), doPrewarm=False) is None
+    conv = R.synth_keras_stack([("dense", 4, "tanh"), ("dense", 1)], seed=8)
+    conv["layers"][0]["type"] = "conv1d"
+    path.write_text(json.dumps(conv))
+    assert loader.CreateFromFile(str(path), doPrewarm=False) is None
 
 
 def test_number_parsing_ignores_the_c_locale(na, tmp_path):
