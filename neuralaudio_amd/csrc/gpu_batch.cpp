@@ -242,9 +242,10 @@ namespace na
 	namespace
 	{
 		// WaveNet kernel families: "split" = the f16-split MFMA kernel (wavenet_split_kernels.hip), "frame" = the f32 4x4x1-MFMA kernel
-		// (wavenet_frame_kernels.hip).  They keep different stream-state formats.  NA_WN_KERNEL=split|frame forces one for every model
-		// (tuning / tests); default: chosen per model (FamilyFor).
-		enum WnFamily { WN_FAMILY_AUTO, WN_FAMILY_SPLIT, WN_FAMILY_FRAME };
+		// (wavenet_frame_kernels.hip), "generic" = the runtime-shaped kernel for layer arrays wider than 16 channels
+		// (wavenet_generic_kernels.hip; frame-kernel state format).  NA_WN_KERNEL=split|frame|generic forces one for every model it can
+		// run (tuning / tests); default: chosen per model (FamilyFor).
+		enum WnFamily { WN_FAMILY_AUTO, WN_FAMILY_SPLIT, WN_FAMILY_FRAME, WN_FAMILY_GENERIC };
 		WnFamily WaveNetFamilyOverride()
 		{
 			static const WnFamily fam = []() {
@@ -252,6 +253,7 @@ namespace na
 				const std::string w = e ? e : "auto";
 				if (w == "split") return WN_FAMILY_SPLIT;
 				if (w == "frame") return WN_FAMILY_FRAME;
+				if (w == "generic") return WN_FAMILY_GENERIC;
 				return WN_FAMILY_AUTO;
 			}();
 			return fam;
@@ -263,7 +265,9 @@ namespace na
 		// arrays), 12-channel (Lite) and large-kernel (A2) models are faster on the frame kernel (33 / 30 / 71 us vs 44 / 44 / 133 us).
 		WnFamily FamilyFor(const WaveNetPlan& plan)
 		{
+			if (plan.genericOnly) return WN_FAMILY_GENERIC; // > 16 channels: the runtime-shaped kernel is the only one that runs it
 			const WnFamily o = WaveNetFamilyOverride();
+			if (o == WN_FAMILY_GENERIC && !plan.genericOk) return WN_FAMILY_FRAME; // (conv heads: not in the runtime-shaped kernel)
 			if (o != WN_FAMILY_AUTO) return o;
 			return plan.splitFastT == 2 ? WN_FAMILY_SPLIT : WN_FAMILY_FRAME;
 		}
@@ -293,7 +297,7 @@ namespace na
 				dRingG.Upload(ringG, stream);
 
 				// steady-state columns: once per model (WaveNet.h:746-766)
-				dCols.Alloc(plan.rings.size() * 16);
+				dCols.Alloc(plan.rings.size() * WN_COL_STRIDE);
 				CheckHip(LaunchWaveNetPrewarmColumns(dPrewarm.Get(), (int)plan.prewarm.size(), dWeights.Get(), dCols.Get(), stream),
 					"WaveNetPrewarmColumnsKernel");
 
@@ -360,6 +364,10 @@ namespace na
 						const WnFrameGroup g = { &dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0 };
 						CheckHip(LaunchWaveNetSplitFused(&g, 1, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "WaveNetSplitKernel");
 					}
+					else if (which == WN_FAMILY_GENERIC)
+						CheckHip(LaunchWaveNetGeneric(dPrewarm.Get(), (int)plan.prewarm.size(), dWeights.Get(), dRingOff.Get(), dRingFrames.Get(), dRingG.Get(),
+							(int)plan.rings.size(), plan.stateF4, plan.maxChannels, plan.headScale, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive,
+							contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "WaveNetGenericKernel");
 					else
 						CheckHip(LaunchWaveNetFrame(dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset,
 							inStride, outStride, chunk, launchStream, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0), "WaveNetFrameKernel");
@@ -370,6 +378,7 @@ namespace na
 
 			bool FusedLaunchArgs(WnFrameGroup& out, bool& splitFamily) override
 			{
+				if (family == WN_FAMILY_GENERIC) return false; // its own launch
 				splitFamily = family == WN_FAMILY_SPLIT;
 				SyncActiveLists();
 				out.model = &dev;

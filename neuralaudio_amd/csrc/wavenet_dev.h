@@ -100,7 +100,10 @@ namespace na
 	};
 	static_assert(sizeof(WnSplitStage) == 64, "split stage descriptors are 64-byte records");
 
-	// Natural-layout tensor table used by the prewarm kernel (one entry per conv ring).
+	constexpr int WN_GENERIC_MAX_CHANNELS = 64; // runtime-shaped block kernel (wavenet_generic_kernels.hip): channels per layer array
+	constexpr int WN_COL_STRIDE = 64;           // floats per ring in the steady-state column table
+
+	// Natural-layout tensor table used by the prewarm kernel and the runtime-shaped block kernel (one entry per conv ring).
 	struct WnPrewarmLayer
 	{
 		int kind;       // 0: layer, 1: head conv (K may be 1)
@@ -115,7 +118,7 @@ namespace na
 		int last_of_array;
 		int rechannel;  // >=0: before this layer apply rechannel weights at this offset (first layer of an array)
 		int rech_in;
-		int pad0;
+		int dilation;   // layer conv / head conv dilation (the generic block kernel walks this table; the prewarm kernel ignores it)
 	};
 
 	// Everything the kernels need about one model; passed by value.

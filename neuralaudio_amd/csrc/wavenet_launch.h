@@ -28,6 +28,12 @@ namespace na
 	hipError_t LaunchWaveNetSplitFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream);
 
+	// The runtime-shaped block kernel (wavenet_generic_kernels.hip): up to 64 channels per layer array, dense heads; walks the
+	// natural-layout tensor table (WaveNetPlan::prewarm) over the flat reference-order weights; frame-kernel stream-state format.
+	hipError_t LaunchWaveNetGeneric(const WnPrewarmLayer* layers, int numLayers, const float* weights, const int* ringOffF4, const int* ringFrames,
+		const int* ringG, int nrings, int stateF4, int maxChannels, float headScale, float* state, const int* slots, const int* rows, int numStreams,
+		int slot0, int row0, const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream);
+
 	// slots == nullptr: the active streams are contiguous -- stream i uses state slot slot0 + i and matrix row row0 + i (saves the
 	// kernel a dependent global load before it can touch the stream's state)
 	hipError_t LaunchWaveNetFrame(const WnModelDev& m, float* state, const int* slots, const int* rows, int numStreams, const float* in,
@@ -37,7 +43,7 @@ namespace na
 	void SetWaveNetTraceBuffer(long long* deviceBuffer);
 	long long* GetWaveNetTraceBuffer();
 
-	// Zero-input steady-state columns per ring (once per model), cols = [nrings][16] floats.
+	// Zero-input steady-state columns per ring (once per model), cols = [nrings][WN_COL_STRIDE] floats.
 	hipError_t LaunchWaveNetPrewarmColumns(const WnPrewarmLayer* layers, int numLayers, const float* weights, float* cols,
 		hipStream_t stream);
 

@@ -57,8 +57,10 @@ namespace na
 		{
 			const WnArrayCfg& cfg = desc.arrays[a];
 			if (cfg.channels < 1 || cfg.headSize < 1 || cfg.inputSize < 1) throw std::runtime_error("WaveNet layer array with a zero-sized dimension");
-			if (cfg.channels > 16 || cfg.headSize > 16 || cfg.inputSize > 16)
-				throw std::runtime_error("WaveNet channels > 16 are not supported by the gfx950 MFMA kernel");
+			if (cfg.channels > WN_GENERIC_MAX_CHANNELS || cfg.headSize > WN_GENERIC_MAX_CHANNELS || cfg.inputSize > WN_GENERIC_MAX_CHANNELS)
+				throw std::runtime_error("WaveNet channels > 64 are not supported");
+			if ((cfg.channels > 16 || cfg.headSize > 16 || cfg.inputSize > 16) && cfg.headKernelSize != 1)
+				throw std::runtime_error("WaveNet channels > 16 with a head kernel > 1 are not supported (the runtime-shaped kernel has dense heads only)");
 			if (cfg.conditionSize != 1) throw std::runtime_error("WaveNet condition_size != 1 is not supported");
 			if (cfg.kernelSizes.size() != cfg.dilations.size() || cfg.kernelSizes.empty())
 				throw std::runtime_error("WaveNet kernel_sizes/dilations mismatch");
@@ -460,6 +462,53 @@ namespace na
 				}
 			}
 
+			// Models wider than the shaped kernels take (> 16 channels): rings and the natural-layout tensor table only -- what the prewarm
+			// kernel and the runtime-shaped block kernel (wavenet_generic_kernels.hip) walk.  Same weight order as Build() (WaveNet.h:700-719).
+			void BuildGenericOnly()
+			{
+				const int numArrays = (int)desc.arrays.size();
+				cursor = 0;
+				for (int a = 0; a < numArrays; a++)
+				{
+					const WnArrayCfg& cfg = desc.arrays[a];
+					const int C = cfg.channels;
+					const int numLayers = (int)cfg.kernelSizes.size();
+					const int rechOff = Take((size_t)C * cfg.inputSize);
+					for (int l = 0; l < numLayers; l++)
+					{
+						const int K = cfg.kernelSizes[l];
+						WnPrewarmLayer pw = {};
+						pw.kind = 0;
+						pw.cin = C; pw.cout = C; pw.ksize = K;
+						pw.act = (cfg.activation == ACT_LEAKYRELU) ? 1 : (desc.mathMode == MATH_STD ? 2 : 0);
+						pw.wconv = Take((size_t)C * C * K);
+						pw.bconv = Take((size_t)C);
+						pw.wmix = Take((size_t)C * cfg.conditionSize);
+						pw.w1 = Take((size_t)C * C);
+						pw.b1 = Take((size_t)C);
+						pw.ring_id = AddRing(C, (K - 1) * cfg.dilations[l]);
+						pw.need_output = 1;
+						pw.last_of_array = (l == numLayers - 1) ? 1 : 0;
+						pw.rechannel = (l == 0) ? rechOff : -1;
+						pw.rech_in = cfg.inputSize;
+						pw.dilation = cfg.dilations[l];
+						plan.prewarm.push_back(pw);
+					}
+					WnPrewarmLayer pw = {};
+					pw.kind = 1;
+					pw.cin = C; pw.cout = cfg.headSize; pw.ksize = cfg.headKernelSize;
+					pw.wconv = Take((size_t)cfg.headSize * C * cfg.headKernelSize);
+					pw.bconv = cfg.hasHeadBias ? Take((size_t)cfg.headSize) : -1;
+					pw.wmix = -1; pw.w1 = -1; pw.b1 = -1;
+					pw.ring_id = -1;
+					pw.rechannel = -1;
+					pw.dilation = cfg.headDilation;
+					plan.prewarm.push_back(pw);
+				}
+				plan.headScale = W(Take(1));
+				plan.stateF4 = CeilDiv(plan.stateF4, 16) * 16;
+			}
+
 			void Build()
 			{
 				ValidateWaveNetDesc(desc);
@@ -467,6 +516,18 @@ namespace na
 				plan.arrays = desc.arrays;
 				plan.receptiveField = desc.ReceptiveFieldSize();
 				plan.stateF4 = WN_HEADER_F4;
+				plan.genericOk = true;
+				for (const WnArrayCfg& cfg : desc.arrays)
+				{
+					plan.maxChannels = std::max(plan.maxChannels, std::max(cfg.channels, std::max(cfg.headSize, cfg.inputSize)));
+					if (cfg.headKernelSize != 1) plan.genericOk = false;
+				}
+				if (plan.maxChannels > 16)
+				{
+					plan.genericOnly = true;
+					BuildGenericOnly();
+					return;
+				}
 
 				const int numArrays = (int)desc.arrays.size();
 
@@ -576,6 +637,7 @@ namespace na
 						pw.last_of_array = lastLayer ? 1 : 0;
 						pw.rechannel = (l == 0) ? rechOff : -1;
 						pw.rech_in = cfg.inputSize;
+						pw.dilation = d;
 						plan.prewarm.push_back(pw);
 					}
 
@@ -588,6 +650,7 @@ namespace na
 					pw.wconv = wh; pw.bconv = bh; pw.wmix = -1; pw.w1 = -1; pw.b1 = -1;
 					pw.ring_id = headRing[a];
 					pw.rechannel = -1;
+					pw.dilation = cfg.headDilation;
 					plan.prewarm.push_back(pw);
 
 					if (lastArray)

@@ -30,6 +30,9 @@ namespace na
 		int maxSplitOps = 0;
 		int maxG = 1;
 		int splitFastT = 0;                // see WnModelDev::split_fast_T
+		int maxChannels = 0;               // widest layer array
+		bool genericOnly = false;          // > 16 channels: only rings + the natural-layout table are built (runtime-shaped block kernel)
+		bool genericOk = false;            // the runtime-shaped block kernel can run it (dense heads only)
 		int stateF4 = 0;            // per-stream state in float4 units
 		int maxA4Floats = 0;        // largest per-stage A-operand block of the frame kernel (floats)
 		float headScale = 0.0f;

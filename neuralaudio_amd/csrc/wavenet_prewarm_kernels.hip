@@ -30,14 +30,12 @@ namespace na
 	// in the reference's natural weight layout, then broadcast into every stream's rings.
 	// ------------------------------------------------------------------------------------------
 	__global__ void __launch_bounds__(64) WaveNetPrewarmColumnsKernel(const WnPrewarmLayer* __restrict__ layers, int numLayers,
-		const float* __restrict__ w, float* __restrict__ cols /* [ring][16] */)
+		const float* __restrict__ w, float* __restrict__ cols /* [ring][WN_COL_STRIDE] */)
 	{
-		__shared__ float x[16], z[16], head[16], lin[16];
+		constexpr int CW = WN_COL_STRIDE; // 64 = one lane per channel
+		__shared__ float x[CW], z[CW], head[CW], lin[CW];
 		const int i = threadIdx.x;
-		if (i < 16)
-		{
-			x[i] = 0.0f; z[i] = 0.0f; head[i] = 0.0f; lin[i] = 0.0f; // condition = 0 (:748), headArray zero (:750)
-		}
+		x[i] = 0.0f; z[i] = 0.0f; head[i] = 0.0f; lin[i] = 0.0f; // condition = 0 (:748), headArray zero (:750)
 		__syncthreads();
 
 		for (int li = 0; li < numLayers; li++)
@@ -52,10 +50,10 @@ namespace na
 					if (i < L.cin)
 						for (int c = 0; c < L.rech_in; c++) v += w[L.rechannel + i * L.rech_in + c] * lin[c];
 					__syncthreads();
-					if (i < 16) x[i] = (i < L.cin) ? v : 0.0f;
+					x[i] = (i < L.cin) ? v : 0.0f;
 					__syncthreads();
 				}
-				if (i < 16) cols[L.ring_id * 16 + i] = x[i]; // CopyBuffer (:74-82): the whole receptive field holds this column
+				cols[L.ring_id * CW + i] = x[i]; // CopyBuffer (:74-82): the whole receptive field holds this column
 
 				float acc = 0.0f;
 				if (i < L.cout)
@@ -67,11 +65,8 @@ namespace na
 					acc = (L.act == 1) ? LeakyReLU(acc) : (L.act == 2 ? (1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc * 2.885390081777927f) + 1.0f)) : FastTanh(acc));
 				}
 				__syncthreads();
-				if (i < 16)
-				{
-					z[i] = (i < L.cout) ? acc : 0.0f;
-					head[i] += z[i];
-				}
+				z[i] = (i < L.cout) ? acc : 0.0f;
+				head[i] += z[i];
 				__syncthreads();
 				float y = 0.0f;
 				if (i < L.cout)
@@ -81,17 +76,14 @@ namespace na
 					y += x[i];
 				}
 				__syncthreads();
-				if (i < 16)
-				{
-					if (L.last_of_array) lin[i] = (i < L.cout) ? y : 0.0f; // arrayOutputs feeds the next array's rechannel
-					else x[i] = (i < L.cout) ? y : 0.0f;
-				}
+				if (L.last_of_array) lin[i] = (i < L.cout) ? y : 0.0f; // arrayOutputs feeds the next array's rechannel
+				else x[i] = (i < L.cout) ? y : 0.0f;
 				__syncthreads();
 			}
 			else
 			{
 				// head rechannel (:625-629): steady-state head column, then conv over a constant history
-				if (L.ring_id >= 0 && i < 16) cols[L.ring_id * 16 + i] = (i < L.cin) ? head[i] : 0.0f;
+				if (L.ring_id >= 0) cols[L.ring_id * CW + i] = (i < L.cin) ? head[i] : 0.0f;
 				float acc = 0.0f;
 				if (i < L.cout)
 				{
@@ -100,7 +92,7 @@ namespace na
 					if (L.bconv >= 0) acc += w[L.bconv + i];
 				}
 				__syncthreads();
-				if (i < 16) head[i] = (i < L.cout) ? acc : 0.0f; // becomes the next array's head accumulator (:785-789)
+				head[i] = (i < L.cout) ? acc : 0.0f; // becomes the next array's head accumulator (:785-789)
 				__syncthreads();
 			}
 		}
@@ -131,7 +123,7 @@ namespace na
 		for (int idx = threadIdx.x; idx < nF4; idx += blockDim.x)
 		{
 			const int cg = split ? (idx % G) : ((idx >> 4) % G);
-			const float* c = cols + r * 16 + cg * 4;
+			const float* c = cols + r * WN_COL_STRIDE + cg * 4;
 			const f32x4 v = f32x4{ c[0], c[1], c[2], c[3] };
 			ring[idx] = split ? SplitQuadBits(v) : v;
 		}

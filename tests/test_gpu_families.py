@@ -1,7 +1,8 @@
 """Both WaveNet kernel families -- and every kernel variant that ships behind a tuning knob -- against the oracle on EVERY architecture.
 
 By default a model runs on the family that is faster for it (FamilyFor() in gpu_batch.cpp: the f16-split kernel for Standard-like
-models, the f32 frame kernel for narrow / 12-channel / large-kernel ones).  NA_WN_KERNEL forces one family for all models; it is read
+models, the f32 frame kernel for narrow / 12-channel / large-kernel ones, the runtime-shaped kernel for arrays wider than 16 channels).
+NA_WN_KERNEL forces one family for all models it can run; it is read
 once per process, so each forced run is a subprocess of the same parity + fuzz + batch test files."""
 import os
 import subprocess
@@ -15,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("env", [{"NA_WN_KERNEL": "split"}, {"NA_WN_KERNEL": "split", "NA_SP_T": "4"}, {"NA_WN_KERNEL": "split", "NA_SP_GEN": "1"},
                                  {"NA_WN_KERNEL": "frame"}, {"NA_WN_KERNEL": "frame", "NA_FR_PF": "2"}, {"NA_WN_KERNEL": "frame", "NA_FR_PF": "0"},
-                                 {"NA_WN_KERNEL": "frame", "NA_FR_SPB": "4"}, {"NA_LSTM_NO_DPP": "1", "NA_GRU_NO_DPP": "1"}, {"NA_LSTM_LANE_KERNEL": "1"}, {"NA_REC_NOSKEW": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+                                 {"NA_WN_KERNEL": "frame", "NA_FR_SPB": "4"}, {"NA_WN_KERNEL": "generic"}, {"NA_LSTM_NO_DPP": "1", "NA_GRU_NO_DPP": "1"}, {"NA_LSTM_LANE_KERNEL": "1"}, {"NA_REC_NOSKEW": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_forced_family_passes_parity_fuzz_and_batch_suites(env):
     if os.environ.get("NA_WN_KERNEL") or os.environ.get("NA_LSTM_NO_DPP") or os.environ.get("NA_LSTM_LANE_KERNEL") or os.environ.get("NA_REC_NOSKEW"):
         pytest.skip("already inside a forced run")

@@ -170,3 +170,23 @@ def test_generic_keras_stack_matches_numpy_restatement(na, loader, spec):
     m2 = loader.CreateFromString(json.dumps(mj), ".json")
     y2 = m2.Process(x)
     assert np.max(np.abs(y2 - y)) < 1e-6
+
+
+@pytest.mark.parametrize("channels,head", [(24, 12), (32, 8), (20, 3), (64, 2)])
+def test_wavenet_wider_than_16_channels_matches_oracle(na, loader, channels, head):
+    """Layer arrays wider than the shaped kernels take run on the runtime-shaped block kernel (the reference's dynamic engine accepts
+    any channel count, WaveNetDynamic.h:229-254): parity vs the oracle, chunk invariance, prewarmed start."""
+    arrays = [dict(input_size=1, condition_size=1, head_size=head, head_kernel_size=1, head_dilation=1, channels=channels, has_head_bias=False,
+                   activation=O.ACT_TANH, kernel_sizes=[3, 3, 2, 3], dilations=[1, 7, 64, 200]),
+              dict(input_size=channels, condition_size=1, head_size=1, head_kernel_size=1, head_dilation=1, channels=head, has_head_bias=True,
+                   activation=O.ACT_TANH, kernel_sizes=[3, 5], dilations=[3, 40])]
+    w = O.synth_wavenet_weights(arrays, seed=channels)
+    m = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam")
+    assert m is not None
+    x = O.signal_noise(700, 5)
+    y = np.concatenate([m.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
+    yo = O.OracleWaveNet(arrays, w).process(x)
+    assert O.rms(y - yo) < 2e-6, (channels, O.rms(y - yo))
+    m2 = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam")
+    y2 = np.concatenate([m2.Process(x[i:i + 37]) for i in range(0, x.size, 37)])
+    assert np.max(np.abs(y2 - y)) < 1e-6

@@ -163,9 +163,12 @@ def test_missing_and_malformed_files(na, tmp_path):
     short.write_text(json.dumps(j))
     with pytest.raises(na.NeuralAudioError, match="Wrong number of weights. Expected 842 but got 839"):  # at LOAD, like WaveNet.h:704-709
         loader.CreateFromFile(str(short), doPrewarm=False)
-    wide_wn = O.nam_json_wavenet_generic([dict(O.a1_arrays(4, 2)[0], channels=20, head_size=1)], [0.0])
-    short.write_text(wide_wn)
-    with pytest.raises(na.NeuralAudioError, match="channels > 16"):  # kernel limits are load-time errors too
+    arr = [dict(O.a1_arrays(4, 2)[0], channels=20, head_size=1)]
+    short.write_text(O.nam_json_wavenet_generic(arr, O.synth_wavenet_weights(arr, seed=2)))
+    assert loader.CreateFromFile(str(short), doPrewarm=False) is not None  # > 16 channels: the runtime-shaped kernel (WaveNetDynamic.h)
+    arr = [dict(O.a1_arrays(4, 2)[0], channels=80, head_size=1)]
+    short.write_text(O.nam_json_wavenet_generic(arr, [0.0]))
+    with pytest.raises(na.NeuralAudioError, match="channels > 64"):  # kernel limits are load-time errors too
         loader.CreateFromFile(str(short), doPrewarm=False)
     conv = tmp_path / "conv.json"
     conv.write_text(json.dumps({"in_shape": [None, None, 1], "layers": [{"type": "conv1d", "shape": [None, None, 8], "weights": []},
