@@ -362,8 +362,11 @@ def main():
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_sample": bytes_per_sample,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                # the dominant kernel of the workload (FamilyFor() in gpu_batch.cpp: the f16-split kernel for Standard-like models, the
+                # frame kernel for narrow / 12-channel / large-kernel ones; NA_WN_KERNEL overrides)
                 "kernel": "RecurrentDppKernel" if (args.workload.startswith("lstm") or args.workload == "config4") else
-                          ("WaveNetFrameKernel" if os.environ.get("NA_WN_KERNEL") == "frame" else "WaveNetSplitKernel"),
+                          {"split": "WaveNetSplitKernel", "frame": "WaveNetFrameKernel", "generic": "WaveNetGenericKernel"}.get(
+                              os.environ.get("NA_WN_KERNEL", ""), "WaveNetSplitKernel" if args.workload == "standard" else "WaveNetFrameKernel"),
             },
             "roofline_mfma_f32": {
                 "achieved": achieved_tflops,
