@@ -85,6 +85,8 @@ NA_EXTERN void* NA_BatchGetHipStream(NA_Batch* batch);
 NA_EXTERN double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames);
 NA_EXTERN double NA_BatchMacsPerSample(NA_Batch* batch);
 NA_EXTERN double NA_BatchStateBytes(NA_Batch* batch);
+/* > 1 when the stream of a narrow static WaveNet model runs packed with others of its model into one kernel-level stream (0: bad argument) */
+NA_EXTERN int NA_BatchStreamPackFactor(NA_Batch* batch, int stream);
 /* NAMIsA2 (bit 0) / NAMIsA2Standard (bit 1) of a .nam document (NeuralModel.cpp:159-168, 188-317); negative on a parse error */
 NA_EXTERN int NA_DebugClassifyNam(const char* jsonText);
 /* tuning aid: device buffer (long long[stages*4*waves]) that workgroup 0 of the WaveNet kernel stamps with the shader clock; NULL = off */

@@ -291,6 +291,9 @@ class Batch:
     def StateBytes(self):
         return float(self._lib.NA_BatchStateBytes(self._h))
 
+    def StreamPackFactor(self, stream):
+        return int(self._lib.NA_BatchStreamPackFactor(self._h, int(stream)))
+
     def close(self):
         if self._h:
             self._lib.NA_BatchDestroy(self._h)

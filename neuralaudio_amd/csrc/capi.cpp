@@ -432,4 +432,10 @@ void NA_DebugSetTraceBuffer(void* deviceBuffer) { na::SetWaveNetTraceBuffer(rein
 
 double NA_BatchStateBytes(NA_Batch* batch) { return batch ? (double)batch->batch->StateBytes() : 0.0; }
 
+int NA_BatchStreamPackFactor(NA_Batch* batch, int stream)
+{
+	try { return batch ? batch->batch->StreamPackFactor(stream) : 0; }
+	catch (...) { return 0; }
+}
+
 } // extern "C"

@@ -142,12 +142,14 @@ namespace na
 		virtual double AlgorithmicBytesPerSample(int blockFrames) const = 0;
 		virtual double MacsPerSample() const = 0;
 		virtual size_t StateBytesPerStream() const = 0;
+		virtual int PackFactor() const { return 1; } // real streams per kernel-level stream (WaveNet stream packing)
 		// WaveNet groups on the frame kernel can share ONE launch with other such groups (a heterogeneous batch without stream
 		// fork/join); fills `out` with this group's part of that launch.  Other groups return false.
-		virtual bool FusedLaunchArgs(WnFrameGroup& out, bool& splitFamily)
+		// `launchList`: which fused launch it joins (0 frame kernel, 1 f16-split kernel, 2 f16-split kernel with packed streams)
+		virtual bool FusedLaunchArgs(WnFrameGroup& out, int& launchList)
 		{
 			(void)out;
-			(void)splitFamily;
+			(void)launchList;
 			return false;
 		}
 
@@ -169,7 +171,7 @@ namespace na
 		// added (AddMember is the non-real-time side); the copy is asynchronous on the batch stream from one of two pinned staging
 		// buffers, so a quality switch costs the audio thread two small enqueues and no synchronisation (the reference switches an
 		// atomic index, CompositeModel.h:49-63).  Never called inside a graph capture.
-		void SyncActiveLists()
+		virtual void SyncActiveLists()
 		{
 			if (!activeDirty) return;
 			hSlots.clear();
@@ -275,13 +277,40 @@ namespace na
 		class WaveNetGroup : public ModelGroup
 		{
 		public:
-			WaveNetGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s) : ModelGroup(d, s), plan(BuildWaveNetPlan(d->wavenet)), family(FamilyFor(plan))
+			// Stream packing (wavenet_plan.cpp PackWaveNetDesc): several streams of a NARROW model share one virtual stream of the f16-split
+			// kernel -- 4 streams for <= 4-channel arrays (Nano), 2 for <= 8 (Feather).  It pays once the virtual streams fill the chip
+			// (measured, 128-frame blocks: Nano 4096 streams 60.9 vs 112.6 us, Feather 2048 43.6 vs 64.2 us; but Nano 1024 36.6 vs
+			// 30.1 us, Feather 1024 36.1 vs 33.6 us), and the state layout is fixed when the group is created, so the decision is taken
+			// from the size of the AddStreams call that creates it: at least 768 virtual streams.  Only for models that are not
+			// submodels of a slimmable container (`packHint` > 0: every member is always active).  NA_WN_PACK=0 never, =1 always.
+			static int PackFor(const WaveNetDesc& wn, int packHint)
 			{
+				static const int mode = getenv("NA_WN_PACK") ? atoi(getenv("NA_WN_PACK")) : -1;
+				const WnFamily o = WaveNetFamilyOverride();
+				if (packHint <= 0 || mode == 0 || (o != WN_FAMILY_AUTO && o != WN_FAMILY_SPLIT)) return 1;
+				ValidateWaveNetDesc(wn);
+				for (const WnArrayCfg& cfg : wn.arrays)
+					if (cfg.channels > 16) return 1;
+				const int P = WaveNetPackFactor(wn);
+				if (P < 2) return 1;
+				return (mode == 1 || packHint / P >= 768) ? P : 1;
+			}
+
+			// packHint: 0 = never pack (submodel of a container), otherwise the number of streams the creating AddStreams call brings
+			WaveNetGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s, int packHint = 0)
+				: ModelGroup(d, s), pack(PackFor(d->wavenet, packHint)), plan(pack > 1 ? BuildPackedWaveNetPlan(d->wavenet, pack) : BuildWaveNetPlan(d->wavenet)),
+				  family(pack > 1 ? WN_FAMILY_SPLIT : FamilyFor(plan))
+			{
+				if (pack > 1)
+				{
+					if (plan.splitFastT != 2) throw std::runtime_error("internal: packed WaveNet plan is not a fast split-kernel plan");
+					realPlan = BuildWaveNetPlan(d->wavenet); // bookkeeping (bytes / MACs / state per REAL stream)
+				}
 				dStages.Upload(plan.stages, stream);
 				dWpack.Upload(plan.wpack, stream);
 				dWpk.Upload(plan.wpk, stream);
 				dPrewarm.Upload(plan.prewarm, stream);
-				dWeights.Upload(d->wavenet.weights, stream);
+				dWeights.Upload(pack > 1 ? plan.packedWeights : d->wavenet.weights, stream);
 				dSStages.Upload(plan.sstages, stream);
 				dWsplit.Upload(plan.wsplit, stream);
 
@@ -326,6 +355,24 @@ namespace na
 			// ChannelHistoryBuffer::AllocBuffer zero-fills (WaveNet.h:38-40)
 			void Reset(const std::vector<int>& members) override
 			{
+				if (pack > 1)
+				{
+					// a member in position 0 opens a fresh virtual stream (cursors and every ring zero); the others only clear their own
+					// channel groups of a virtual stream that is already running
+					std::vector<int> slots, subs;
+					for (int m : members)
+					{
+						if (m % pack == 0)
+							CheckHip(hipMemsetAsync(state.Get() + (size_t)(m / pack) * (size_t)plan.stateF4 * 4, 0, (size_t)plan.stateF4 * 16, stream), "hipMemsetAsync");
+						else
+						{
+							slots.push_back(m / pack);
+							subs.push_back(m % pack);
+						}
+					}
+					FillPacked(slots, subs, true);
+					return;
+				}
 				// one memset per run of consecutive slots (a batch add is a single run)
 				for (size_t i = 0; i < members.size();)
 				{
@@ -340,6 +387,17 @@ namespace na
 			void Prewarm(const std::vector<int>& members) override
 			{
 				if (members.empty()) return;
+				if (pack > 1)
+				{
+					std::vector<int> slots, subs;
+					for (int m : members)
+					{
+						slots.push_back(m / pack);
+						subs.push_back(m % pack);
+					}
+					FillPacked(slots, subs, false);
+					return;
+				}
 				DevArray<int> list;
 				list.Upload(members, stream);
 				CheckHip(LaunchWaveNetFillRings(state.Get(), plan.stateF4, list.Get(), (int)members.size(), (int)plan.rings.size(),
@@ -361,7 +419,7 @@ namespace na
 					const WnFamily which = family;
 					if (which == WN_FAMILY_SPLIT)
 					{
-						const WnFrameGroup g = { &dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0 };
+						const WnFrameGroup g = { &dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0, pack };
 						CheckHip(LaunchWaveNetSplitFused(&g, 1, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "WaveNetSplitKernel");
 					}
 					else if (which == WN_FAMILY_GENERIC)
@@ -376,10 +434,11 @@ namespace na
 				}
 			}
 
-			bool FusedLaunchArgs(WnFrameGroup& out, bool& splitFamily) override
+			bool FusedLaunchArgs(WnFrameGroup& out, int& launchList) override
 			{
 				if (family == WN_FAMILY_GENERIC) return false; // its own launch
-				splitFamily = family == WN_FAMILY_SPLIT;
+				launchList = family == WN_FAMILY_SPLIT ? (pack > 1 ? 2 : 1) : 0;
+				out.pack = pack;
 				SyncActiveLists();
 				out.model = &dev;
 				out.state = state.Get();
@@ -391,13 +450,62 @@ namespace na
 				return out.numStreams > 0;
 			}
 
-			double AlgorithmicBytesPerSample(int blockFrames) const override { return plan.AlgorithmicBytesPerSample(blockFrames); }
-			double MacsPerSample() const override { return plan.MacsPerSample(); }
-			size_t StateBytesPerStream() const override { return (size_t)plan.stateF4 * 16; }
+			double AlgorithmicBytesPerSample(int blockFrames) const override { return (pack > 1 ? realPlan : plan).AlgorithmicBytesPerSample(blockFrames); }
+			double MacsPerSample() const override { return (pack > 1 ? realPlan : plan).MacsPerSample(); }
+			size_t StateBytesPerStream() const override { return (size_t)plan.stateF4 * 16 / (size_t)pack; }
+			int PackFactor() const override { return pack; }
+
+			// Packed groups: the launch lists name VIRTUAL streams -- slot = member / pack -- and hold `pack` rows each (-1: no member in
+			// that position yet).  Members of a static model are always active, so a virtual stream runs as soon as it has one member.
+			void SyncActiveLists() override
+			{
+				if (pack <= 1)
+				{
+					ModelGroup::SyncActiveLists();
+					return;
+				}
+				if (!activeDirty) return;
+				hSlots.clear();
+				hRows.clear();
+				const size_t numSlots = (memberRow.size() + (size_t)pack - 1) / (size_t)pack;
+				for (size_t v = 0; v < numSlots; v++)
+				{
+					bool any = false;
+					int rows[4] = { -1, -1, -1, -1 };
+					for (int q = 0; q < pack; q++)
+					{
+						const size_t m = v * (size_t)pack + (size_t)q;
+						if (m < memberRow.size() && memberRow[m] >= 0)
+						{
+							rows[q] = memberRow[m];
+							any = true;
+						}
+					}
+					if (!any) continue;
+					hSlots.push_back((int)v);
+					for (int q = 0; q < pack; q++) hRows.push_back(rows[q]);
+				}
+				if (!hSlots.empty())
+				{
+					listFlip ^= 1;
+					int* pin = pinnedLists[listFlip];
+					if (listEvent[listFlip]) CheckHip(hipEventSynchronize(listEvent[listFlip]), "hipEventSynchronize");
+					else CheckHip(hipEventCreateWithFlags(&listEvent[listFlip], hipEventDisableTiming), "hipEventCreate");
+					memcpy(pin, hSlots.data(), hSlots.size() * sizeof(int));
+					memcpy(pin + listCapacity, hRows.data(), hRows.size() * sizeof(int));
+					CheckHip(hipMemcpyAsync(dSlots.Get(), pin, hSlots.size() * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+					CheckHip(hipMemcpyAsync(dRows.Get(), pin + listCapacity, hRows.size() * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+					CheckHip(hipEventRecord(listEvent[listFlip], stream), "hipEventRecord");
+				}
+				contiguous = false; // the packed kernel always reads the lists
+				activeDirty = false;
+			}
 
 		protected:
-			void EnsureCapacity(int members) override
+			void EnsureCapacity(int numMembers) override
 			{
+				EnsureListCapacity((size_t)numMembers + (size_t)pack); // the row list holds `pack` entries per virtual stream
+				const int members = (numMembers + pack - 1) / pack;      // state slots = virtual streams
 				if ((size_t)members <= capacity) return;
 				const size_t newCap = std::max<size_t>((size_t)members, std::max<size_t>(capacity * 2, 16));
 				DevArray<float> bigger;
@@ -413,7 +521,20 @@ namespace na
 			}
 
 		private:
-			WaveNetPlan plan;
+			void FillPacked(const std::vector<int>& slots, const std::vector<int>& subs, bool zero)
+			{
+				if (slots.empty()) return;
+				DevArray<int> dS, dQ;
+				dS.Upload(slots, stream);
+				dQ.Upload(subs, stream);
+				CheckHip(LaunchWaveNetFillRings(state.Get(), plan.stateF4, dS.Get(), (int)slots.size(), (int)plan.rings.size(), dRingOff.Get(), dRingFrames.Get(),
+					dRingG.Get(), dCols.Get(), stream, true, dQ.Get(), pack, zero), "WaveNetFillRingsKernel");
+				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize"); // the lists are freed on return
+			}
+
+			const int pack;       // real streams per virtual stream (1: no packing)
+			WaveNetPlan plan;     // pack > 1: of the VIRTUAL model
+			WaveNetPlan realPlan; // pack > 1: of the real model (bookkeeping only)
 			const WnFamily family;
 			WnModelDev dev = {};
 			DevArray<WnStage> dStages;
@@ -627,13 +748,13 @@ namespace na
 		if (stream && ownsStream) (void)hipStreamDestroy(stream);
 	}
 
-	ModelGroup* GpuBatch::GroupFor(const std::shared_ptr<const ModelDesc>& desc)
+	ModelGroup* GpuBatch::GroupFor(const std::shared_ptr<const ModelDesc>& desc, int packHint)
 	{
 		for (auto& g : groups)
 			if (g->desc.get() == desc.get()) return g.get();
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		std::unique_ptr<ModelGroup> g;
-		if (desc->kind == MODEL_WAVENET) g.reset(new WaveNetGroup(desc, stream));
+		if (desc->kind == MODEL_WAVENET) g.reset(new WaveNetGroup(desc, stream, packHint));
 		else if (desc->kind == MODEL_LSTM) g.reset(new LstmGroup(desc, stream));
 		else throw std::runtime_error("neuralaudio_amd: unsupported model kind");
 		groups.push_back(std::move(g));
@@ -656,7 +777,7 @@ namespace na
 		const size_t numSub = model->subModels.size();
 		std::vector<ModelGroup*> subGroups(numSub);
 		std::vector<std::vector<int>> newMembers(numSub);
-		for (size_t k = 0; k < numSub; k++) subGroups[k] = GroupFor(model->subModels[k].desc);
+		for (size_t k = 0; k < numSub; k++) subGroups[k] = GroupFor(model->subModels[k].desc, (!model->isComposite && numSub == 1) ? count : 0);
 		for (int i = 0; i < count; i++)
 		{
 			StreamRef ref;
@@ -753,23 +874,22 @@ namespace na
 		// Mixed batch.  Groups that can share a launch are fused: all WaveNet groups on the frame kernel into one launch, all LSTM / GRU
 		// groups with an LDS-free kernel instance into another (the workgroups of all architectures share the chip, no fork/join per
 		// group).  What remains are independent "units" (disjoint rows, disjoint state); one unit runs directly on the batch stream.
-		std::vector<WnFrameGroup> fusedWn, fusedWnSplit; // frame-kernel groups / f16-split-kernel groups: one launch per family
+		constexpr int NUM_WN_LISTS = 3; // frame kernel | f16-split kernel | f16-split kernel, packed streams: one launch each
+		std::vector<WnFrameGroup> fusedWn[NUM_WN_LISTS];
 		std::vector<RecurrentGroup> fusedRec;
 		std::vector<ModelGroup*> singles;
-		ModelGroup* wnOwner = nullptr;  // lends its side stream / event to the fused unit
-		ModelGroup* wnSplitOwner = nullptr;
+		ModelGroup* wnOwner[NUM_WN_LISTS] = {}; // lends its side stream / event to the fused unit
 		ModelGroup* recOwner = nullptr;
 		for (auto& g : groups)
 		{
 			if (g->NumActive() == 0) continue;
-			WnFrameGroup a;
+			WnFrameGroup a = {};
 			RecurrentGroup r;
-			bool splitFamily = false;
-			if (g->FusedLaunchArgs(a, splitFamily))
+			int list = 0;
+			if (g->FusedLaunchArgs(a, list))
 			{
-				(splitFamily ? fusedWnSplit : fusedWn).push_back(a);
-				ModelGroup*& owner = splitFamily ? wnSplitOwner : wnOwner;
-				if (!owner) owner = g.get();
+				fusedWn[list].push_back(a);
+				if (!wnOwner[list]) wnOwner[list] = g.get();
 			}
 			else if (g->FusedRecurrentArgs(r))
 			{
@@ -782,21 +902,20 @@ namespace na
 				singles.push_back(g.get());
 			}
 		}
-		auto launchWnFamily = [&](const std::vector<WnFrameGroup>& list, bool splitFamily, hipStream_t s) {
+		auto launchWnList = [&](int which, hipStream_t s) {
+			const std::vector<WnFrameGroup>& list = fusedWn[which];
 			size_t offset = 0, left = n;
 			while (left > 0)
 			{
 				const int chunk = (int)std::min<size_t>(left, (size_t)WN_MAX_FRAMES);
 				for (size_t first = 0; first < list.size(); first += WN_FRAME_MAX_GROUPS)
-					CheckHip((splitFamily ? LaunchWaveNetSplitFused : LaunchWaveNetFrameFused)(list.data() + first,
+					CheckHip((which == 0 ? LaunchWaveNetFrameFused : LaunchWaveNetSplitFused)(list.data() + first,
 						(int)std::min<size_t>(list.size() - first, (size_t)WN_FRAME_MAX_GROUPS), dIn + offset, dOut + offset, inStride, outStride, chunk, s),
 						"WaveNet kernel (fused)");
 				offset += (size_t)chunk;
 				left -= (size_t)chunk;
 			}
 		};
-		auto launchWn = [&](hipStream_t s) { launchWnFamily(fusedWn, false, s); };
-		auto launchWnSplit = [&](hipStream_t s) { launchWnFamily(fusedWnSplit, true, s); };
 		auto launchRec = [&](hipStream_t s) {
 			size_t offset = 0, left = n;
 			while (left > 0)
@@ -809,15 +928,32 @@ namespace na
 				left -= (size_t)chunk;
 			}
 		};
-		const size_t units = (fusedWn.empty() ? 0 : 1) + (fusedWnSplit.empty() ? 0 : 1) + (fusedRec.empty() ? 0 : 1) + singles.size();
+		size_t units = (fusedRec.empty() ? 0 : 1) + singles.size();
+		for (int l = 0; l < NUM_WN_LISTS; l++) units += fusedWn[l].empty() ? 0 : 1;
 		allGroupsFuse = units == 1;
 		if (units == 1)
 		{
-			if (!fusedWn.empty()) launchWn(stream);
-			else if (!fusedWnSplit.empty()) launchWnSplit(stream);
-			else if (!fusedRec.empty()) launchRec(stream);
+			for (int l = 0; l < NUM_WN_LISTS; l++)
+				if (!fusedWn[l].empty())
+				{
+					launchWnList(l, stream);
+					return;
+				}
+			if (!fusedRec.empty()) launchRec(stream);
 			else singles[0]->Process(dIn, dOut, inStride, outStride, n, stream);
 			return;
+		}
+		{
+			// tuning knob: the units one after the other on the batch stream instead of concurrently on side streams
+			static const bool serial = getenv("NA_BATCH_SERIAL") != nullptr;
+			if (serial)
+			{
+				for (int l = 0; l < NUM_WN_LISTS; l++)
+					if (!fusedWn[l].empty()) launchWnList(l, stream);
+				if (!fusedRec.empty()) launchRec(stream);
+				for (ModelGroup* g : singles) g->Process(dIn, dOut, inStride, outStride, n, stream);
+				return;
+			}
 		}
 		// Several units: fork onto side streams so their kernels share the GPU, then join back into the batch stream.  The fork/join
 		// costs ~5 HIP calls per unit, which would make a buffer host-bound, so the sequence is captured once into a hipGraph and
@@ -851,8 +987,8 @@ namespace na
 					CheckHip(hipEventRecord(owner->DoneEvent(), side), "hipEventRecord");
 					CheckHip(hipStreamWaitEvent(stream, owner->DoneEvent(), 0), "hipStreamWaitEvent");
 				};
-				if (!fusedWn.empty()) branch(wnOwner, launchWn);
-				if (!fusedWnSplit.empty()) branch(wnSplitOwner, launchWnSplit);
+				for (int l = 0; l < NUM_WN_LISTS; l++)
+					if (!fusedWn[l].empty()) branch(wnOwner[l], [&, l](hipStream_t s) { launchWnList(l, s); });
 				if (!fusedRec.empty()) branch(recOwner, launchRec);
 				for (ModelGroup* g : singles) branch(g, [&](hipStream_t s) { g->Process(dIn, dOut, inStride, outStride, n, s); });
 			}
@@ -1000,6 +1136,12 @@ namespace na
 			n += g->NumActive();
 		}
 		return n ? sum / n : 0.0;
+	}
+
+	int GpuBatch::StreamPackFactor(int s) const
+	{
+		const StreamRef& ref = streams.at((size_t)s);
+		return ref.members[(size_t)ref.active].first->PackFactor();
 	}
 
 	size_t GpuBatch::StateBytes() const

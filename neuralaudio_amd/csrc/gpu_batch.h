@@ -93,6 +93,7 @@ namespace na
 		double AlgorithmicBytesPerSample(int blockFrames) const;
 		double MacsPerSample() const;
 		size_t StateBytes() const;
+		int StreamPackFactor(int stream) const; // > 1: the stream shares a kernel-level stream with others of its model (stream packing)
 
 	private:
 		struct StreamRef
@@ -106,7 +107,7 @@ namespace na
 		};
 		bool allGroupsFuse = false; // set by ProcessDevice: the batch runs as ONE launch per buffer (no hipGraph involved)
 
-		ModelGroup* GroupFor(const std::shared_ptr<const ModelDesc>& desc);
+		ModelGroup* GroupFor(const std::shared_ptr<const ModelDesc>& desc, int packHint = 0);
 		void EnsureStaging(size_t floats);
 
 		int device;

@@ -19,6 +19,9 @@ namespace na
 		const int* slots; // nullptr: contiguous (slot0 + i, row0 + i)
 		const int* rows;
 		int numStreams, slot0, row0;
+		// f16-split kernel only: > 1 = packed group (WaveNetPlan::pack real streams per virtual stream): numStreams / slots count VIRTUAL
+		// streams and rows holds `pack` entries per virtual stream (-1: no real stream in that position); slots must not be nullptr
+		int pack;
 	};
 	hipError_t LaunchWaveNetFrameFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream);
@@ -50,5 +53,6 @@ namespace na
 	// Broadcast the columns into the rings of the listed stream slots and zero their cursors.  splitFormat: the f16-split kernel's state
 	// (split quads, frame-major rings) instead of the frame kernel's (f32 quads, tile layout).
 	hipError_t LaunchWaveNetFillRings(float* state, int stateF4, const int* slots, int numStreams, int numRings, const int* ringOffF4,
-		const int* ringFrames, const int* ringG, const float* cols, hipStream_t stream, bool splitFormat);
+		const int* ringFrames, const int* ringG, const float* cols, hipStream_t stream, bool splitFormat, const int* sub = nullptr, int pack = 1,
+		bool zero = false); // packed groups: (slots[i], sub[i]) = one real stream, only its channel groups are written (see the kernel)
 }

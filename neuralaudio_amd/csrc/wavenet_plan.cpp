@@ -134,7 +134,9 @@ namespace na
 			WaveNetPlan plan;
 			size_t cursor = 0; // into desc.weights
 
-			explicit Builder(const WaveNetDesc& d) : desc(d) {}
+			int pack = 1; // > 1: `desc` is a packed virtual model (PackWaveNetDesc) of `pack` streams
+
+			explicit Builder(const WaveNetDesc& d, int packStreams = 1) : desc(d), pack(packStreams) {}
 
 			int Take(size_t n)
 			{
@@ -290,7 +292,10 @@ namespace na
 			// "aux" operand: bias and input mix-in ride in the MFMA too.  The kernel's aux B operand of a frame is the 8 halfs
 			// [cond_h, 1, cond_l, 1, cond_h, 0, 0, 0]; against the row [wc_h, w1_h, wc_h, w1_l, wc_l, 0, 0, 0] it contributes
 			// wc * cond + w1 to that row (same three-product split, ONE operand).  It sits in the cg = 0 k-block of each tile slot.
-			void FillSplitAux(int op, int Gp, int cout, int condOff, int oneOff)
+			// Packed plans (several streams of a narrow model as the channel groups of one virtual stream, see PackWaveNetDesc): the aux B
+			// operand of k-block q carries the condition of the stream that owns channel group q, so row o's weights sit in the first
+			// k-block of ITS stream (cpad = padded channels per stream; unpacked: cpad >= cout, i.e. always the cg = 0 k-block).
+			void FillSplitAux(int op, int Gp, int cout, int condOff, int oneOff, int cpad = 1 << 20)
 			{
 				for (int p = 0; p < 4 / Gp; p++)
 					for (int o = 0; o < cout; o++)
@@ -298,7 +303,7 @@ namespace na
 						const float wc = condOff >= 0 ? W(condOff + o) : 0.0f, w1 = oneOff >= 0 ? W(oneOff + o) : 0.0f;
 						const uint16_t wch = FloatToHalfBits(wc), wcl = FloatToHalfBits(wc - HalfBitsToFloat(wch));
 						const uint16_t w1h = FloatToHalfBits(w1), w1l = FloatToHalfBits(w1 - HalfBitsToFloat(w1h));
-						const size_t lane = (size_t)(Gp * p) * 16 + (size_t)(4 * Gp * p + o);
+						const size_t lane = (size_t)(Gp * p + (o / cpad) * (cpad / 4)) * 16 + (size_t)(4 * Gp * p + o);
 						uint16_t* e = &plan.wsplit[(size_t)op * 512 + lane * 8];
 						e[0] = wch; e[1] = w1h; e[2] = wch; e[3] = w1l; e[4] = wcl;
 					}
@@ -341,6 +346,8 @@ namespace na
 					const int numLayers = (int)cfg.kernelSizes.size();
 					const bool lastArray = (a == numArrays - 1);
 					plan.maxG = std::max(plan.maxG, G);
+					const int cpad = pack > 1 ? C / pack : (1 << 20); // channels per packed stream (a multiple of 4)
+					const int groupsPerStream = pack > 1 ? cpad / 4 : 4;
 					const int rechOff = Take((size_t)C * cfg.inputSize);
 					if (a == 0)
 					{
@@ -349,7 +356,8 @@ namespace na
 						st.G = G; st.Gp = Gp;
 						st.a_ops = 1;
 						st.a_off = NewSplitOps(st.a_ops) * 64;
-						FillSplitAux(st.a_off / 64, Gp, C, rechOff, -1);
+						FillSplitAux(st.a_off / 64, Gp, C, rechOff, -1, cpad);
+						st.reserved = groupsPerStream;
 						SplitOutRing(st, layerRing[a][0]);
 						st.flags = WN_FLAG_PUBLISH;
 						plan.sstages.push_back(st);
@@ -405,7 +413,8 @@ namespace na
 						const int op0 = st.a_off / 64;
 						for (int k = 0; k < K; k++)
 							FillSplitMerged(op0 + 2 * k, Gp, C, C, [&](int o, int c) { return W(wconv + (o * C + c) * K + k); });
-						FillSplitAux(op0 + 2 * K, Gp, C, wmix, bconv);
+						FillSplitAux(op0 + 2 * K, Gp, C, wmix, bconv, cpad);
+						st.reserved = groupsPerStream;
 						FillSplitMerged(op0 + 2 * K + 1, Gp, C, C, [&](int o, int c) { return W(w1 + o * C + c); });
 						FillSplitAux(op0 + 2 * K + 3, Gp, C, -1, b1);
 						if (needOutput) st.flags |= WN_FLAG_NEED_OUTPUT;
@@ -431,12 +440,13 @@ namespace na
 						st.a_ops = 2 * Kh + 1;
 						st.a_off = NewSplitOps(st.a_ops) * 64;
 						const int op0 = st.a_off / 64;
+						// (a packed plan: one output row per packed stream, head channel q = stream q, see PackWaveNetDesc)
 						for (int k = 0; k < Kh; k++)
-							FillSplitMerged(op0 + 2 * k, Gp, 1, C, [&](int o, int c) { return W(wh + (o * C + c) * Kh + k); });
+							FillSplitMerged(op0 + 2 * k, Gp, pack > 1 ? cfg.headSize : 1, C, [&](int o, int c) { return W(wh + (o * C + c) * Kh + k); });
 						if (cfg.hasHeadBias)
 						{
 							st.flags |= WN_FLAG_BIAS;
-							FillSplitAux(op0 + 2 * Kh, Gp, 1, -1, bh);
+							FillSplitAux(op0 + 2 * Kh, Gp, pack > 1 ? cfg.headSize : 1, -1, bh);
 						}
 						if (Kh > 1)
 						{
@@ -708,6 +718,115 @@ namespace na
 		b.Build();
 		return std::move(b.plan);
 	}
+
+	// ---- stream packing ------------------------------------------------------------------------------------------------------
+	// A narrow model leaves most of a 16x16 MFMA tile empty (4 channels: one channel group of four), and what a layer costs on the
+	// f16-split kernel hardly depends on its width.  So P streams of such a model run as ONE virtual stream whose channel groups belong
+	// to different streams: channels C_v = P * pad4(C) per layer array, every weight matrix block-diagonal (stream q's block at rows /
+	// columns q * pad4(C) ...), bias / mix-in / rechannel vectors replicated, the last head with one output row per stream.  The
+	// only thing that is per stream in the arithmetic is the condition (= input sample): the kernel's aux operand carries stream q's
+	// condition in the k-blocks of stream q's channel groups (FillSplitAux).  Same flat weight order as the reference (WaveNet.h:700-719).
+	int WaveNetPackFactor(const WaveNetDesc& desc)
+	{
+		int maxPad = 0;
+		for (const WnArrayCfg& cfg : desc.arrays)
+		{
+			maxPad = std::max(maxPad, CeilDiv(cfg.channels, 4) * 4);
+			if (cfg.headKernelSize != 1 || cfg.conditionSize != 1) return 1;
+			for (int k : cfg.kernelSizes)
+				if (k != 3) return 1; // the fast instantiation of the kernel
+		}
+		if (desc.arrays.back().headSize != 1) return 1;
+		return maxPad <= 4 ? 4 : (maxPad <= 8 ? 2 : 1);
+	}
+
+	WaveNetDesc PackWaveNetDesc(const WaveNetDesc& desc, int P)
+	{
+		WaveNetDesc v;
+		v.mathMode = desc.mathMode;
+		const int numArrays = (int)desc.arrays.size();
+		std::vector<int> cpad((size_t)numArrays);
+		for (int a = 0; a < numArrays; a++) cpad[(size_t)a] = CeilDiv(desc.arrays[(size_t)a].channels, 4) * 4;
+		size_t pos = 0;
+		auto take = [&](size_t n) { const size_t at = pos; pos += n; return at; };
+		for (int a = 0; a < numArrays; a++)
+		{
+			const WnArrayCfg& cfg = desc.arrays[(size_t)a];
+			const bool last = (a == numArrays - 1);
+			const int C = cfg.channels, Cp = cpad[(size_t)a], Cv = P * Cp;
+			const int In = cfg.inputSize, Inp = (a == 0) ? 1 : cpad[(size_t)a - 1], Inv = (a == 0) ? 1 : P * Inp;
+			const int Hs = cfg.headSize, Hp = last ? 1 : cpad[(size_t)a + 1], Hv = P * Hp;
+			WnArrayCfg vc = cfg;
+			vc.channels = Cv;
+			vc.inputSize = Inv;
+			vc.headSize = Hv;
+			v.arrays.push_back(vc);
+			// rechannel W[out][in]
+			{
+				const size_t w = take((size_t)C * In);
+				std::vector<float> m((size_t)Cv * Inv, 0.0f);
+				for (int q = 0; q < P; q++)
+					for (int o = 0; o < C; o++)
+						for (int c = 0; c < In; c++)
+							m[(size_t)(q * Cp + o) * Inv + (a == 0 ? 0 : q * Inp + c)] = desc.weights[w + (size_t)o * In + c];
+				v.weights.insert(v.weights.end(), m.begin(), m.end());
+			}
+			for (size_t l = 0; l < cfg.kernelSizes.size(); l++)
+			{
+				const int K = cfg.kernelSizes[l];
+				const size_t wconv = take((size_t)C * C * K), bconv = take((size_t)C), wmix = take((size_t)C), w1 = take((size_t)C * C), b1 = take((size_t)C);
+				std::vector<float> m((size_t)Cv * Cv * K, 0.0f), vb((size_t)Cv, 0.0f), vm((size_t)Cv, 0.0f), m1((size_t)Cv * Cv, 0.0f), vb1((size_t)Cv, 0.0f);
+				for (int q = 0; q < P; q++)
+					for (int o = 0; o < C; o++)
+					{
+						const int vo = q * Cp + o;
+						vb[(size_t)vo] = desc.weights[bconv + o];
+						vm[(size_t)vo] = desc.weights[wmix + o];
+						vb1[(size_t)vo] = desc.weights[b1 + o];
+						for (int c = 0; c < C; c++)
+						{
+							const int vcn = q * Cp + c;
+							m1[(size_t)vo * Cv + vcn] = desc.weights[w1 + (size_t)o * C + c];
+							for (int k = 0; k < K; k++) m[((size_t)vo * Cv + vcn) * K + k] = desc.weights[wconv + ((size_t)o * C + c) * K + k];
+						}
+					}
+				v.weights.insert(v.weights.end(), m.begin(), m.end());
+				v.weights.insert(v.weights.end(), vb.begin(), vb.end());
+				v.weights.insert(v.weights.end(), vm.begin(), vm.end());
+				v.weights.insert(v.weights.end(), m1.begin(), m1.end());
+				v.weights.insert(v.weights.end(), vb1.begin(), vb1.end());
+			}
+			// head rechannel (K = 1): W[out][in], bias[out]
+			{
+				const size_t wh = take((size_t)Hs * C), bh = cfg.hasHeadBias ? take((size_t)Hs) : 0;
+				std::vector<float> m((size_t)Hv * Cv, 0.0f), vb((size_t)Hv, 0.0f);
+				for (int q = 0; q < P; q++)
+					for (int o = 0; o < Hs; o++)
+					{
+						const int vo = q * Hp + o;
+						if (cfg.hasHeadBias) vb[(size_t)vo] = desc.weights[bh + o];
+						for (int c = 0; c < C; c++) m[(size_t)vo * Cv + (q * Cp + c)] = desc.weights[wh + (size_t)o * C + c];
+					}
+				v.weights.insert(v.weights.end(), m.begin(), m.end());
+				if (cfg.hasHeadBias) v.weights.insert(v.weights.end(), vb.begin(), vb.end());
+			}
+		}
+		v.weights.push_back(desc.weights[take(1)]); // head scale
+		if (pos != desc.weights.size()) throw std::runtime_error("internal: PackWaveNetDesc walked a different number of weights");
+		return v;
+	}
+
+	WaveNetPlan BuildPackedWaveNetPlan(const WaveNetDesc& desc, int P)
+	{
+		if (P < 2) return BuildWaveNetPlan(desc);
+		const WaveNetDesc v = PackWaveNetDesc(desc, P);
+		Builder b(v, P);
+		b.Build();
+		b.plan.pack = P;
+		b.plan.packedWeights = v.weights; // the prewarm kernel walks the natural layout of the VIRTUAL model
+		return std::move(b.plan);
+	}
+
 
 	// B(arch) = 8 + (4/N) * sum_layers C_l * [ sum_{j=1}^{K_l-1} min(j*d_l, N) + min(N, (K_l-1)*d_l) ]
 	// (compulsory ring traffic with perfect in-block reuse, weights amortised; includes a head conv with K > 1)

@@ -31,6 +31,8 @@ namespace na
 		int maxG = 1;
 		int splitFastT = 0;                // see WnModelDev::split_fast_T
 		int maxChannels = 0;               // widest layer array
+		int pack = 1;                      // streams per virtual stream (BuildPackedWaveNetPlan)
+		std::vector<float> packedWeights;  // pack > 1: flat weights of the virtual model (reference order)
 		bool genericOnly = false;          // > 16 channels: only rings + the natural-layout table are built (runtime-shaped block kernel)
 		bool genericOk = false;            // the runtime-shaped block kernel can run it (dense heads only)
 		int stateF4 = 0;            // per-stream state in float4 units
@@ -47,4 +49,9 @@ namespace na
 
 	// throws std::runtime_error("Wrong number of weights...") like WaveNet.h:704-709
 	WaveNetPlan BuildWaveNetPlan(const WaveNetDesc& desc);
+	// Stream packing (wavenet_plan.cpp): how many streams of this model fit one virtual stream of the f16-split kernel (1: none),
+	// the virtual model, and its plan (WaveNetPlan::pack = P; arrays / rings / stages describe the VIRTUAL model).
+	int WaveNetPackFactor(const WaveNetDesc& desc);
+	WaveNetDesc PackWaveNetDesc(const WaveNetDesc& desc, int P);
+	WaveNetPlan BuildPackedWaveNetPlan(const WaveNetDesc& desc, int P);
 }

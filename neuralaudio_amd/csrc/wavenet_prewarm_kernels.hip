@@ -111,8 +111,12 @@ namespace na
 
 	// grid = (streams to fill, rings), block = 256: fill ring r of stream slot with its steady-state column.
 	// split == 0: f32 quads in the tile layout (frame kernel); split == 1: split quads, frame-major rings (f16-split kernel).
+	// Packed groups (pack > 1, split format): entry i names one REAL stream = (virtual stream slots[i], position sub[i]); only the
+	// channel groups of that position are written and the cursors -- shared by the streams of a virtual stream -- are left alone (a
+	// steady-state column fills every ring position, so where the cursor stands does not matter).  zero != 0: zeros instead of the column.
 	__global__ void __launch_bounds__(256) WaveNetFillRingsKernel(f32x4* __restrict__ state, int stateF4, const int* __restrict__ slots,
-		const int* __restrict__ ringOffF4, const int* __restrict__ ringFrames, const int* __restrict__ ringG, const float* __restrict__ cols, int split)
+		const int* __restrict__ ringOffF4, const int* __restrict__ ringFrames, const int* __restrict__ ringG, const float* __restrict__ cols, int split,
+		const int* __restrict__ sub, int pack, int zero)
 	{
 		const int slot = slots[blockIdx.x];
 		const int r = blockIdx.y;
@@ -120,14 +124,17 @@ namespace na
 		const int G = ringG[r];
 		const int nF4 = (ringFrames[r] / 16) * G * 16;
 		f32x4* ring = st + ringOffF4[r];
+		const int gs = pack > 1 ? G / pack : G;            // channel groups per real stream
+		const int cgFirst = pack > 1 ? sub[blockIdx.x] * gs : 0;
 		for (int idx = threadIdx.x; idx < nF4; idx += blockDim.x)
 		{
 			const int cg = split ? (idx % G) : ((idx >> 4) % G);
+			if (cg < cgFirst || cg >= cgFirst + gs) continue;
 			const float* c = cols + r * WN_COL_STRIDE + cg * 4;
-			const f32x4 v = f32x4{ c[0], c[1], c[2], c[3] };
+			const f32x4 v = zero ? f32x4{ 0.0f, 0.0f, 0.0f, 0.0f } : f32x4{ c[0], c[1], c[2], c[3] };
 			ring[idx] = split ? SplitQuadBits(v) : v;
 		}
-		if (r == 0 && threadIdx.x < WN_MAX_RINGS) reinterpret_cast<int*>(st)[threadIdx.x] = 0; // cursors
+		if (pack <= 1 && r == 0 && threadIdx.x < WN_MAX_RINGS) reinterpret_cast<int*>(st)[threadIdx.x] = 0; // cursors
 	}
 
 	// ------------------------------------------------------------------------------------------ launchers
@@ -144,11 +151,11 @@ namespace na
 	}
 
 	hipError_t LaunchWaveNetFillRings(float* state, int stateF4, const int* slots, int numStreams, int numRings, const int* ringOffF4,
-		const int* ringFrames, const int* ringG, const float* cols, hipStream_t stream, bool splitFormat)
+		const int* ringFrames, const int* ringG, const float* cols, hipStream_t stream, bool splitFormat, const int* sub, int pack, bool zero)
 	{
 		if (numStreams <= 0) return hipSuccess;
 		hipLaunchKernelGGL(WaveNetFillRingsKernel, dim3((unsigned)numStreams, (unsigned)numRings), dim3(256), 0, stream,
-			reinterpret_cast<f32x4*>(state), stateF4, slots, ringOffF4, ringFrames, ringG, cols, splitFormat ? 1 : 0);
+			reinterpret_cast<f32x4*>(state), stateF4, slots, ringOffF4, ringFrames, ringG, cols, splitFormat ? 1 : 0, sub, pack, zero ? 1 : 0);
 		return hipGetLastError();
 	}
 }

@@ -44,6 +44,7 @@ namespace na
 		typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 		typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 		typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+		typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 		typedef const int __attribute__((address_space(4)))* CInt;
 
 #ifndef NA_ABL
@@ -221,6 +222,10 @@ namespace na
 			int imgStride;                // quads per image = maxG * PLANE
 			const u32x4* idop;            // identity A operand [64 lanes] (head accumulation rides on the matrix pipe)
 			const u32x4* auxq;            // this stream's aux operands in LDS: [cond_h, 1, cond_l, 1, cond_h, 0, 0, 0] per frame [FRAMES]
+			// packed launches (PK: several real streams as the channel groups of this virtual stream, wavenet_plan.cpp PackWaveNetDesc):
+			const u32x2* auxp;            // [pack][FRAMES] x 8 bytes: the first two dwords of stream q's aux operands (the rest follows from them)
+			int pack;                     // real streams in this virtual stream
+			long outRow[4];               // their output rows (float offsets into `out`), -1: slot not in use
 			__amdgpu_buffer_rsrc_t srsrc; // this stream's state
 			int myPos;                    // lane r: write cursor of ring r
 			int n, nSt;                   // frames in the block; frames this wave may store (0 for a shadow wave)
@@ -355,12 +360,22 @@ namespace na
 		}
 
 		// this lane's aux operand for frame f
-		__device__ __forceinline__ u32x4 AuxOf(const Ctx& cx, int f) { return cx.auxq[f & (FRAMES - 1)]; }
+		// packed: channel group cg belongs to stream cg >> gsShift (gsShift = log2 of the channel groups per stream of the current array)
+		template <bool PK>
+		__device__ __forceinline__ u32x4 AuxOf(const Ctx& cx, int f, int cg, int gsShift)
+		{
+			if constexpr (PK)
+			{
+				const u32x2 v = cx.auxp[(cg >> gsShift) * FRAMES + (f & (FRAMES - 1))];
+				return u32x4{ v.x, v.y, v.x & 0xffffu, 0u };
+			}
+			else return cx.auxq[f & (FRAMES - 1)];
+		}
 
 		// A run of consecutive WaveNet layer stages (WaveNetLayerT::Process, WaveNet.h:462-494) of one lane mode.
 		// VMEM operations per layer, in this order on every path: WCOPY weight DMA loads, HPF*S history loads (for the NEXT layer,
 		// issued once this layer's taps have consumed the previous ones, into the same registers), S ring stores.
-		template <int GP, int T, int NTHREADS, int HPF, bool GEN>
+		template <int GP, int T, int NTHREADS, int HPF, bool GEN, bool PK>
 		__device__ __forceinline__ void RunLayers(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
 		{
 			constexpr int S = Geo<GP, T>::S;
@@ -400,6 +415,7 @@ namespace na
 				const bool mask = GEN && (Geo<GP, T>::PARTIAL || G < GP); // wave-uniform: some lanes have no channel group / no tile of their own
 				const int inPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
 				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id) : 0;
+				const int gsShift = PK ? (sd.reserved >> 1) : 0; // channel groups per packed stream: 1, 2, 4 -> 0, 1, 2
 
 				// dilated conv (WaveNet.h:139-290): tap k reads the frame d*(K-1-k) back; accumulation starts from zero, bias and mix-in
 				// arrive through the aux operand
@@ -488,7 +504,7 @@ namespace na
 					{
 						u32x4 b = imgCur[ImgIdx(cg[i], f[i])];
 						if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 };
-						const u32x4 ax = AuxOf(cx, f[i]);
+						const u32x4 ax = AuxOf<PK>(cx, f[i], cg[i], gsShift);
 						acc[i] = Mfma(ah, b, acc[i]);
 						acc[i] = Mfma(al, b, acc[i]);
 						acc[i] = Mfma(xa, ax, acc[i]);
@@ -534,7 +550,7 @@ namespace na
 					for (int i = 0; i < S; i++)
 					{
 						const u32x4 zs = SplitQuad(z[i]);
-						const u32x4 ax = AuxOf(cx, f[i]);
+						const u32x4 ax = AuxOf<PK>(cx, f[i], cg[i], gsShift);
 						st.hd[i] = Mfma(idop, zs, st.hd[i]);
 						f32x4 y = st.xc[i];
 						y = Mfma(w1h, zs, y);
@@ -558,7 +574,7 @@ namespace na
 		}
 
 		// array 0 rechannel: x = w_re * cond (WaveNet.h:637 with InputSize == 1) -- the aux operand against (w_re, 0)
-		template <int GP, int T, int NTHREADS, bool GEN>
+		template <int GP, int T, int NTHREADS, bool GEN, bool PK>
 		__device__ __forceinline__ void RechannelStage(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
 		{
 			constexpr int S = Geo<GP, T>::S;
@@ -575,7 +591,7 @@ namespace na
 			{
 				int f, cg; bool live;
 				FrameOf<GP, T>(cx, lane, i, f, cg, live);
-				const u32x4 ax = AuxOf(cx, f);
+				const u32x4 ax = AuxOf<PK>(cx, f, cg, PK ? (sd.reserved >> 1) : 0);
 				f32x4 x = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 				x = Mfma(ra, ax, x);
 				st.xc[i] = x;
@@ -591,7 +607,7 @@ namespace na
 
 		// array link: previous array's head rechannel (K = 1, WaveNet.h:658-660) and this array's rechannel (:637), tile by tile; the
 		// operand of tile t writes the rows of tile slot t % Pn of the new mode from the k-blocks of slot t % Po of the old one
-		template <int GPO, int GPN, int T, int NTHREADS, bool GEN>
+		template <int GPO, int GPN, int T, int NTHREADS, bool GEN, bool PK>
 		__device__ __forceinline__ void LinkStage(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
 		{
 			constexpr int Po = 4 / GPO, Pn = 4 / GPN, NC = Po > Pn ? Po : Pn;
@@ -630,7 +646,7 @@ namespace na
 				xn[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 				if (sd.flags & WN_FLAG_BIAS)
 				{
-					const u32x4 ax = AuxOf(cx, fn[i]);
+					const u32x4 ax = AuxOf<PK>(cx, fn[i], 0, 0); // bias only: any stream's aux operand carries the ones it multiplies
 					hn[i] = Mfma(wl[(4 * NC) * 64], ax, hn[i]);
 				}
 			}
@@ -659,7 +675,7 @@ namespace na
 
 		// last array's head: out = scale * (conv_K(head) + b)[0]  (WaveNet.h:658-660, :793-798); K = 1 (A1) straight from registers,
 		// K > 1 (A2: 16) through the LDS image / head ring like a layer conv.  One output row per tile slot.
-		template <int GP, int T, int NTHREADS>
+		template <int GP, int T, int NTHREADS, bool PK>
 		__device__ __forceinline__ void HeadStage(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
 		{
 			constexpr int S = Geo<GP, T>::S;
@@ -712,10 +728,21 @@ namespace na
 					acc[i] = Mfma(al, hs[i], acc[i]);
 					if (sd.flags & WN_FLAG_BIAS)
 					{
-						const u32x4 ax = AuxOf(cx, f[i]);
+						const u32x4 ax = AuxOf<PK>(cx, f[i], 0, 0); // bias only
 						acc[i] = Mfma(wl[(2 * K) * 64], ax, acc[i]);
 					}
-					if (live[i] && cg[i] == 0 && f[i] < cx.nSt) cx.out[cx.outBase + f[i]] = cx.headScale * acc[i].x;
+					if constexpr (PK)
+					{
+						// one head row per packed stream: rows 0 .. pack-1 of the tile = the four values of the cg == 0 lane
+						if (live[i] && cg[i] == 0 && f[i] < cx.nSt)
+						{
+							const float v[4] = { acc[i].x, acc[i].y, acc[i].z, acc[i].w };
+#pragma unroll
+							for (int q = 0; q < 4; q++)
+								if (q < cx.pack && cx.outRow[q] >= 0) cx.out[cx.outRow[q] + f[i]] = cx.headScale * v[q];
+						}
+					}
+					else if (live[i] && cg[i] == 0 && f[i] < cx.nSt) cx.out[cx.outBase + f[i]] = cx.headScale * acc[i].x;
 				}
 			}
 			s++;
@@ -735,6 +762,7 @@ namespace na
 			int numStreams, slot0, row0;
 			int maxG;
 			int firstBlock; // workgroups [firstBlock, next group's firstBlock) belong to this group
+			int pack;       // packed launches: real streams per virtual stream; rows[] then holds `pack` rows per virtual stream (-1: unused)
 		};
 
 		struct LaunchArgs
@@ -745,7 +773,8 @@ namespace na
 
 		// grid = active streams / SPB; workgroup = SPB streams x WPS waves of T tiles (WPS * T * 16 >= n).
 		// dynamic LDS: auxq[SPB][FRAMES] quads | img[SPB][2][maxG][PLANE] quads | wbuf[2][wstride] quads | idop[64] quads
-		template <int T, int SPB, int WPS, bool GEN>
+		// PK: packed launch -- aux LDS is [SPB][4][FRAMES] x 8 bytes instead of [SPB][FRAMES] quads
+		template <int T, int SPB, int WPS, bool GEN, bool PK>
 		__global__ void __launch_bounds__(64 * WPS * SPB) __attribute__((amdgpu_waves_per_eu(T == 2 ? 4 : 2))) WaveNetSplitKernel(const LaunchArgs args, int maxGAll, int wstride, const float* __restrict__ in, float* __restrict__ out,
 			long inStride, long outStride, int n, long long* __restrict__ trace, int traceBlock)
 		{
@@ -762,7 +791,7 @@ namespace na
 			const int sub = waveAll / WPS;  // stream within the workgroup
 			const int wave = waveAll % WPS; // part of the stream's block
 			u32x4* auxAll = reinterpret_cast<u32x4*>(smem);
-			u32x4* imgAll = auxAll + SPB * FRAMES;
+			u32x4* imgAll = auxAll + (PK ? SPB * 4 * FRAMES / 2 : SPB * FRAMES);
 			const int imgStride = maxGAll * PLANE;
 			u32x4* wbuf = imgAll + SPB * 2 * imgStride;
 
@@ -771,7 +800,7 @@ namespace na
 			const bool liveStream = sidx < ga.numStreams;
 			if (!liveStream) sidx = ga.numStreams - 1;
 			const int slot = ga.slots ? ga.slots[sidx] : ga.slot0 + sidx;
-			const int row = ga.slots ? ga.rows[sidx] : ga.row0 + sidx;
+			const int row = PK ? 0 : (ga.slots ? ga.rows[sidx] : ga.row0 + sidx);
 			u32x4* stt = ga.state + (size_t)slot * (size_t)ga.stateF4;
 			int* header = reinterpret_cast<int*>(stt);
 
@@ -784,6 +813,15 @@ namespace na
 			cx.img = imgAll + sub * 2 * imgStride;
 			cx.imgStride = imgStride;
 			cx.auxq = auxAll + sub * FRAMES;
+			cx.auxp = reinterpret_cast<const u32x2*>(auxAll) + sub * 4 * FRAMES;
+			cx.pack = PK ? ga.pack : 1;
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+			{
+				// packed: rows[] always holds `pack` entries per virtual stream (the host fills -1 for the unused tail of the last one)
+				const int r = (PK && liveStream && q < ga.pack) ? ga.rows[sidx * ga.pack + q] : -1;
+				cx.outRow[q] = r >= 0 ? (long)r * outStride : -1;
+			}
 			cx.idop = wbuf + 2 * wstride;
 			cx.srsrc = MakeRsrc(stt, (unsigned)ga.stateF4 * 16u);
 			cx.myPos = header[lane]; // lane r holds the write cursor of ring r
@@ -804,6 +842,22 @@ namespace na
 #endif
 
 			// input row (WaveNet.h:770 input -> condition) -> the aux operand of every frame: split quad of (cond, 1, 0, 0); cond = 0 beyond n
+			if constexpr (PK)
+			{
+				u32x2* auxp = reinterpret_cast<u32x2*>(auxAll) + sub * 4 * FRAMES;
+				for (int q = 0; q < ga.pack; q++)
+				{
+					const int r = liveStream ? ga.rows[sidx * ga.pack + q] : -1;
+					for (int i = wave * 64 + lane; i < FRAMES; i += WPS * 64)
+					{
+						const float c = (r >= 0 && i < n) ? in[(size_t)r * inStride + i] : 0.0f;
+						const _Float16 ch = (_Float16)c, cl = (_Float16)(c - (float)ch);
+						const f16x2 a = { ch, (_Float16)1.0f }, b = { cl, (_Float16)1.0f };
+						auxp[q * FRAMES + i] = u32x2{ __builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b) };
+					}
+				}
+			}
+			else
 			{
 				u32x4* auxq = auxAll + sub * FRAMES;
 				for (int i = wave * 64 + lane; i < FRAMES; i += WPS * 64)
@@ -840,15 +894,15 @@ namespace na
 				{
 					// K = 3 models: both shifted taps' history is requested a layer ahead; larger kernels (A2: 6 / 15): the first 2 as well,
 					// the rest in line
-					if (mode == 4) RunLayers<4, T, NTHREADS, 2, GEN>(cx, s, sd, cur, st);
-					else if (mode == 2) RunLayers<2, T, NTHREADS, 2, GEN>(cx, s, sd, cur, st);
-					else RunLayers<1, T, NTHREADS, 2, GEN>(cx, s, sd, cur, st);
+					if (mode == 4) RunLayers<4, T, NTHREADS, 2, GEN, PK>(cx, s, sd, cur, st);
+					else if (mode == 2) RunLayers<2, T, NTHREADS, 2, GEN, PK>(cx, s, sd, cur, st);
+					else RunLayers<1, T, NTHREADS, 2, GEN, PK>(cx, s, sd, cur, st);
 				}
 				else if (sd.type == WN_ST_RECHANNEL_COND)
 				{
-					if (mode == 4) RechannelStage<4, T, NTHREADS, GEN>(cx, s, sd, cur, st);
-					else if (mode == 2) RechannelStage<2, T, NTHREADS, GEN>(cx, s, sd, cur, st);
-					else RechannelStage<1, T, NTHREADS, GEN>(cx, s, sd, cur, st);
+					if (mode == 4) RechannelStage<4, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st);
+					else if (mode == 2) RechannelStage<2, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st);
+					else RechannelStage<1, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st);
 				}
 				else if (sd.type == WN_ST_ARRAY_LINK)
 				{
@@ -856,23 +910,23 @@ namespace na
 					const int key = mode * 8 + next;
 					switch (key)
 					{
-					case 4 * 8 + 4: LinkStage<4, 4, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
-					case 4 * 8 + 2: LinkStage<4, 2, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
-					case 4 * 8 + 1: LinkStage<4, 1, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
-					case 2 * 8 + 4: LinkStage<2, 4, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
-					case 2 * 8 + 2: LinkStage<2, 2, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
-					case 2 * 8 + 1: LinkStage<2, 1, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
-					case 1 * 8 + 4: LinkStage<1, 4, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
-					case 1 * 8 + 2: LinkStage<1, 2, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
-					default: LinkStage<1, 1, T, NTHREADS, GEN>(cx, s, sd, cur, st); break;
+					case 4 * 8 + 4: LinkStage<4, 4, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st); break;
+					case 4 * 8 + 2: LinkStage<4, 2, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st); break;
+					case 4 * 8 + 1: LinkStage<4, 1, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st); break;
+					case 2 * 8 + 4: LinkStage<2, 4, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st); break;
+					case 2 * 8 + 2: LinkStage<2, 2, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st); break;
+					case 2 * 8 + 1: LinkStage<2, 1, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st); break;
+					case 1 * 8 + 4: LinkStage<1, 4, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st); break;
+					case 1 * 8 + 2: LinkStage<1, 2, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st); break;
+					default: LinkStage<1, 1, T, NTHREADS, GEN, PK>(cx, s, sd, cur, st); break;
 					}
 					mode = next;
 				}
 				else
 				{
-					if (mode == 4) HeadStage<4, T, NTHREADS>(cx, s, sd, cur, st);
-					else if (mode == 2) HeadStage<2, T, NTHREADS>(cx, s, sd, cur, st);
-					else HeadStage<1, T, NTHREADS>(cx, s, sd, cur, st);
+					if (mode == 4) HeadStage<4, T, NTHREADS, PK>(cx, s, sd, cur, st);
+					else if (mode == 2) HeadStage<2, T, NTHREADS, PK>(cx, s, sd, cur, st);
+					else HeadStage<1, T, NTHREADS, PK>(cx, s, sd, cur, st);
 				}
 			}
 
@@ -889,7 +943,7 @@ namespace na
 			}
 		}
 
-		template <int T, int SPB, int WPS, bool GEN>
+		template <int T, int SPB, int WPS, bool GEN, bool PK>
 		static hipError_t Launch(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream)
 		{
 			LaunchArgs args = {};
@@ -907,14 +961,17 @@ namespace na
 				a.numStreams = g.numStreams; a.slot0 = g.slot0; a.row0 = g.row0;
 				a.maxG = m.max_G;
 				a.firstBlock = blocks;
+				a.pack = g.pack > 1 ? g.pack : 1;
+				if ((a.pack > 1) != PK) return hipErrorInvalidValue; // packed and plain groups never share a launch
+				if (PK && g.slots == nullptr) return hipErrorInvalidValue; // packed launches always pass the row lists
 				blocks += (g.numStreams + SPB - 1) / SPB;
 				maxG = std::max(maxG, m.max_G);
 				maxOps = std::max(maxOps, m.max_split_ops);
 			}
 			const int wstride = maxOps * 64; // quads per LDS weight buffer (the LDS-DMA staging always writes its fixed 16 KB part)
-			const size_t lds = (size_t)SPB * FRAMES * 16 + (size_t)SPB * 2 * maxG * PLANE * 16 + (size_t)2 * wstride * 16 + 1024;
+			const size_t lds = (PK ? (size_t)SPB * 4 * FRAMES * 8 : (size_t)SPB * FRAMES * 16) + (size_t)SPB * 2 * maxG * PLANE * 16 + (size_t)2 * wstride * 16 + 1024;
 			if (lds > 160 * 1024) return hipErrorInvalidValue;
-			auto kernel = WaveNetSplitKernel<T, SPB, WPS, GEN>;
+			auto kernel = WaveNetSplitKernel<T, SPB, WPS, GEN, PK>;
 			if (lds > 64 * 1024)
 			{
 				static size_t granted = 0; // per instantiation
@@ -956,11 +1013,29 @@ namespace na
 			if (groups[i].model->split_fast_T == 0) gen = true;
 			else t = std::max(t, groups[i].model->split_fast_T);
 		}
-#ifdef NA_SP_QUICK
-#define NA_SP_LAUNCH(TT, SS, WW) do { return sp::Launch<2, 2, 4, false>(groups, numGroups, in, out, inStride, outStride, n, stream); } while (0)
+		// packed groups (several real streams per virtual stream, WaveNetPlan::pack): their own launch, fast instantiation, 2 tiles per wave
+		bool packed = false;
+		for (int i = 0; i < numGroups; i++) packed = packed || groups[i].pack > 1;
+		if (packed)
+		{
+			for (int i = 0; i < numGroups; i++)
+				if (groups[i].pack < 2 || groups[i].model->split_fast_T != 2) return hipErrorInvalidValue;
+#ifndef NA_SP_QUICK
+#define NA_SP_LAUNCH_PK(SS, WW) return sp::Launch<2, SS, WW, false, true>(groups, numGroups, in, out, inStride, outStride, n, stream)
+			if (tiles > 4) { if (spb >= 2) NA_SP_LAUNCH_PK(2, 4); NA_SP_LAUNCH_PK(1, 4); }
+			if (tiles > 2) { if (spb >= 2) NA_SP_LAUNCH_PK(2, 2); NA_SP_LAUNCH_PK(1, 2); }
+			if (spb >= 2) NA_SP_LAUNCH_PK(2, 1);
+			NA_SP_LAUNCH_PK(1, 1);
+#undef NA_SP_LAUNCH_PK
 #else
-#define NA_SP_LAUNCH(TT, SS, WW) do { return gen ? sp::Launch<TT, SS, WW, true>(groups, numGroups, in, out, inStride, outStride, n, stream) \
-	: sp::Launch<TT, SS, WW, false>(groups, numGroups, in, out, inStride, outStride, n, stream); } while (0)
+			return hipErrorInvalidValue;
+#endif
+		}
+#ifdef NA_SP_QUICK
+#define NA_SP_LAUNCH(TT, SS, WW) do { return sp::Launch<2, 2, 4, false, false>(groups, numGroups, in, out, inStride, outStride, n, stream); } while (0)
+#else
+#define NA_SP_LAUNCH(TT, SS, WW) do { return gen ? sp::Launch<TT, SS, WW, true, false>(groups, numGroups, in, out, inStride, outStride, n, stream) \
+	: sp::Launch<TT, SS, WW, false, false>(groups, numGroups, in, out, inStride, outStride, n, stream); } while (0)
 #endif
 #ifdef NA_SP_QUICK // experiment builds: only the headline instantiation
 		NA_SP_LAUNCH(2, 2, 4);

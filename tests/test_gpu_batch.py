@@ -490,3 +490,36 @@ def test_full_size_properties_config5_2048_a2_streams_quality_sweep(na, loader):
     _full_size_properties(na, add, S, 128, [(0, lambda: O.oracle_from_file("BossWN-a2.nam", quality=0.0)),
                                             (1023, lambda: O.oracle_from_file("BossWN-a2.nam", quality=0.5)),
                                             (2047, lambda: O.oracle_from_file("BossWN-a2.nam", quality=1.0))], TOL_RMS)
+
+
+@pytest.mark.parametrize("name,first,more", [("BossWN-nano.nam", 3077, 5), ("BossWN-feather.nam", 1539, 3)])
+def test_packed_narrow_streams_match_oracle_stream_by_stream(na, loader, name, first, more):
+    """Large batches of a narrow static model run PACKED: 4 (Nano) / 2 (Feather) real streams as the channel groups of one virtual
+    stream of the f16-split kernel (gpu_batch.cpp PackFor, wavenet_plan.cpp PackWaveNetDesc).  Every stream has its own input; streams
+    from all positions of a virtual stream, from the partially filled last one and from a later AddStreams call that completes it
+    must match the oracle, across a ragged sequence of block sizes, and a re-prewarm of one stream must not disturb its neighbours."""
+    m = loader.CreateFromFile(_path(name), doPrewarm=False)
+    b = na.Batch(0)
+    b.AddStreams(m, first)
+    b.AddStreams(m, more)  # joins the existing group: fills the last virtual stream and opens another
+    S = first + more
+    assert b.NumStreams() == S
+    forced_unpacked = os.environ.get("NA_WN_KERNEL") in ("frame", "generic") or os.environ.get("NA_WN_PACK") == "0"  # tests/test_gpu_families.py
+    assert b.StreamPackFactor(0) == b.StreamPackFactor(S - 1) == (1 if forced_unpacked else (4 if "nano" in name else 2))  # the packed path really runs
+    rng = np.random.default_rng(77)
+    n_total = 128 + 128 + 37 + 128
+    x = (0.3 * rng.standard_normal((S, n_total))).clip(-1, 1).astype(np.float32)
+    y = np.concatenate([b.Process(np.ascontiguousarray(x[:, a:a + c])) for a, c in ((0, 128), (128, 128), (256, 37), (293, 128))], axis=1)
+    assert np.all(np.isfinite(y))
+    picks = sorted(set([0, 1, 2, 3, 4, 5, first - 2, first - 1, first, first + 1, S - 1, S // 2, S // 3]))
+    for s in picks:
+        yo = O.oracle_from_file(name).process(x[s])
+        assert O.rms(y[s] - yo) < TOL_RMS, (s, O.rms(y[s] - yo))
+    # re-prewarm stream 1 only: it restarts from the steady state, its neighbours in the same virtual stream carry on
+    b.Prewarm(1)
+    x2 = (0.3 * rng.standard_normal((S, 128))).clip(-1, 1).astype(np.float32)
+    y2 = b.Process(x2)
+    assert O.rms(y2[1] - O.oracle_from_file(name).process(x2[1])) < TOL_RMS
+    for s in (0, 2, 3):
+        yo = O.oracle_from_file(name).process(np.concatenate([x[s], x2[s]]))[n_total:]
+        assert O.rms(y2[s] - yo) < TOL_RMS, s
