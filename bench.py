@@ -366,7 +366,9 @@ def main():
                 # frame kernel for narrow / 12-channel / large-kernel ones; NA_WN_KERNEL overrides)
                 "kernel": "RecurrentDppKernel" if (args.workload.startswith("lstm") or args.workload == "config4") else
                           {"split": "WaveNetSplitKernel", "frame": "WaveNetFrameKernel", "generic": "WaveNetGenericKernel"}.get(
-                              os.environ.get("NA_WN_KERNEL", ""), "WaveNetSplitKernel" if args.workload == "standard" else "WaveNetFrameKernel"),
+                              os.environ.get("NA_WN_KERNEL", ""),
+                              "WaveNetSplitKernel" if (args.workload == "standard" or batch.StreamPackFactor(0) > 1) else "WaveNetFrameKernel"),
+                "stream_pack_factor": batch.StreamPackFactor(0),  # > 1: narrow model, several real streams per kernel-level stream
             },
             "roofline_mfma_f32": {
                 "achieved": achieved_tflops,
