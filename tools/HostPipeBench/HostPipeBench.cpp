@@ -55,33 +55,45 @@ int main(int argc, char** argv)
 	CHECK(NA_BatchCollect(batch, pending, out.data()) == 0);
 	const double usCopy = (Now() - t0) * 1e6 / buffers;
 
-	// zero-copy entry points: the host writes the next input in place and reads the result in place (here: one pass over each)
-	float* slot = NA_BatchNextInput(batch, (size_t)frames);
-	CHECK(slot != nullptr);
-	std::memcpy(slot, in.data(), count * sizeof(float));
-	pending = NA_BatchSubmit(batch, nullptr, (size_t)frames);
-	CHECK(pending >= 0);
+	// zero-copy entry points: the host writes the next input in place and reads the result in place (here: one pass over each);
+	// `depth` buffers in flight (the engine has 3 slots)
+	double usZero[2] = { 0.0, 0.0 };
 	double checksum = 0.0;
-	t0 = Now();
-	for (int i = 0; i < buffers; i++)
+	for (int depth = 2; depth <= 3; depth++)
 	{
-		slot = NA_BatchNextInput(batch, (size_t)frames);
-		CHECK(slot != nullptr);
-		std::memcpy(slot, in.data(), count * sizeof(float)); // the producer's write
-		const int next = NA_BatchSubmit(batch, nullptr, (size_t)frames);
-		CHECK(next >= 0);
-		CHECK(NA_BatchCollect(batch, pending, nullptr) == 0);
-		const float* y = NA_BatchOutputView(batch, pending);
-		CHECK(y != nullptr);
-		for (size_t k = 0; k < count; k += 4096) checksum += y[k]; // the consumer's read (sparse: a real consumer reads all of it)
-		pending = next;
+		std::vector<int> tickets;
+		for (int k = 0; k < depth - 1; k++)
+		{
+			float* slot = NA_BatchNextInput(batch, (size_t)frames);
+			CHECK(slot != nullptr);
+			std::memcpy(slot, in.data(), count * sizeof(float));
+			const int t = NA_BatchSubmit(batch, nullptr, (size_t)frames);
+			CHECK(t >= 0);
+			tickets.push_back(t);
+		}
+		t0 = Now();
+		for (int i = 0; i < buffers; i++)
+		{
+			float* slot = NA_BatchNextInput(batch, (size_t)frames);
+			CHECK(slot != nullptr);
+			std::memcpy(slot, in.data(), count * sizeof(float)); // the producer's write
+			const int next = NA_BatchSubmit(batch, nullptr, (size_t)frames);
+			CHECK(next >= 0);
+			tickets.push_back(next);
+			const int done = tickets.front();
+			tickets.erase(tickets.begin());
+			CHECK(NA_BatchCollect(batch, done, nullptr) == 0);
+			const float* y = NA_BatchOutputView(batch, done);
+			CHECK(y != nullptr);
+			for (size_t k = 0; k < count; k += 4096) checksum += y[k]; // the consumer's read (sparse: a real consumer reads all of it)
+		}
+		for (int t : tickets) CHECK(NA_BatchCollect(batch, t, nullptr) == 0);
+		usZero[depth - 2] = (Now() - t0) * 1e6 / buffers;
 	}
-	CHECK(NA_BatchCollect(batch, pending, nullptr) == 0);
-	const double usZero = (Now() - t0) * 1e6 / buffers;
 
-	std::printf("{\"streams\": %d, \"frames\": %d, \"buffers\": %d, \"us_per_buffer_zero_copy\": %.3f, \"us_per_buffer_copying\": %.3f, "
+	std::printf("{\"streams\": %d, \"frames\": %d, \"buffers\": %d, \"us_per_buffer_zero_copy\": %.3f, \"us_per_buffer_zero_copy_3_in_flight\": %.3f, \"us_per_buffer_copying\": %.3f, "
 		"\"blocking_latency_us\": {\"p50\": %.1f, \"p99\": %.1f, \"max\": %.1f}, \"checksum\": %.6g}\n",
-		streams, frames, buffers, usZero, usCopy, lat[lat.size() / 2], lat[(size_t)(lat.size() * 0.99)], lat.back(), checksum);
+		streams, frames, buffers, usZero[0], usZero[1], usCopy, lat[lat.size() / 2], lat[(size_t)(lat.size() * 0.99)], lat.back(), checksum);
 	NA_BatchDestroy(batch);
 	DeleteModel(model);
 	DeleteLoader(loader);
