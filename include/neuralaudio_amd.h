@@ -89,6 +89,9 @@ NA_EXTERN double NA_BatchStateBytes(NA_Batch* batch);
 NA_EXTERN int NA_BatchStreamPackFactor(NA_Batch* batch, int stream);
 /* NAMIsA2 (bit 0) / NAMIsA2Standard (bit 1) of a .nam document (NeuralModel.cpp:159-168, 188-317); negative on a parse error */
 NA_EXTERN int NA_DebugClassifyNam(const char* jsonText);
+/* stream packing, host side only: pack factor of the model in a large batch (1: none); flat weights of the packed virtual model into
+ * out[capacity] when given; returns their count (0: model does not pack), -1 on failure */
+NA_EXTERN int NA_DebugPackedWeights(NeuralModel* model, int* packFactor, float* out, int capacity);
 /* tuning aid: device buffer (long long[stages*4*waves]) that workgroup 0 of the WaveNet kernel stamps with the shader clock; NULL = off */
 NA_EXTERN void NA_DebugSetTraceBuffer(void* deviceBuffer);
 

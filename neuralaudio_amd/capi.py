@@ -26,7 +26,7 @@ NA_SYMBOLS = [
     "NA_BatchSetQuality", "NA_BatchGetActiveSubModel", "NA_BatchPrewarm", "NA_BatchProcess", "NA_BatchProcessDevice",
     "NA_BatchSynchronize", "NA_BatchGetHipStream", "NA_BatchAlgorithmicBytesPerSample", "NA_BatchMacsPerSample",
     "NA_BatchStateBytes", "NA_BatchStreamPackFactor", "NA_DebugSetTraceBuffer", "NA_SetWaveNetMathMode", "NA_SetLSTMMathMode", "NA_SetCompositeModelLoadMode",
-    "NA_IsQualityChangeRealtimeSafe", "NA_ProcessChecked", "NA_BatchSubmit", "NA_BatchCollect", "NA_BatchNextInput", "NA_BatchOutputView", "NA_BatchIsQualityChangeRealtimeSafe", "NA_DebugClassifyNam",
+    "NA_IsQualityChangeRealtimeSafe", "NA_ProcessChecked", "NA_BatchSubmit", "NA_BatchCollect", "NA_BatchNextInput", "NA_BatchOutputView", "NA_BatchIsQualityChangeRealtimeSafe", "NA_DebugClassifyNam", "NA_DebugPackedWeights",
 ]
 
 _lib = None
@@ -101,6 +101,7 @@ def load_library():
         "NA_BatchOutputView": (fp, [vp, C.c_int]),
         "NA_BatchIsQualityChangeRealtimeSafe": (C.c_int, [vp, C.c_int, C.c_float]),
         "NA_DebugClassifyNam": (C.c_int, [C.c_char_p]),
+        "NA_DebugPackedWeights": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -8,6 +8,7 @@
 #include "neuralaudio_amd.h"
 #include "neural_model_impl.h"
 #include "wavenet_launch.h"
+#include "wavenet_plan.h"
 
 struct NeuralModel
 {
@@ -259,6 +260,40 @@ int NA_DebugClassifyNam(const char* jsonText)
 		const na::Json j = na::Json::Parse(jsonText ? jsonText : "");
 		const std::string v = (j.IsObject() && j.Contains("version") && j.At("version").IsString()) ? j.At("version").AsString() : "";
 		r = (na::NAMIsA2(v) ? 1 : 0) | (na::NAMIsA2Standard(j) ? 2 : 0);
+	});
+	return r;
+}
+
+// Stream packing, host side only (no GPU needed; tests): the pack factor the model would run with in a large batch (1: none) and, when
+// `out` is given, the flat weights of the packed virtual model (wavenet_plan.cpp PackWaveNetDesc); returns their count, -1 on failure.
+int NA_DebugPackedWeights(NeuralModel* model, int* packFactor, float* out, int capacity)
+{
+	int r = -1;
+	Guard([&] {
+		NeuralAudio::GpuModel* gm = model ? dynamic_cast<NeuralAudio::GpuModel*>(model->model) : nullptr;
+		if (!gm) throw std::runtime_error("NA_DebugPackedWeights: not a model of this library");
+		const auto& lm = gm->GetLoadedModel();
+		if (lm->subModels.size() != 1 || lm->subModels[0].desc->kind != na::MODEL_WAVENET)
+		{
+			if (packFactor) *packFactor = 1;
+			r = 0;
+			return;
+		}
+		const na::WaveNetDesc& wn = lm->subModels[0].desc->wavenet;
+		const int P = na::WaveNetPackFactor(wn);
+		if (packFactor) *packFactor = P;
+		if (P < 2)
+		{
+			r = 0;
+			return;
+		}
+		const na::WaveNetDesc v = na::PackWaveNetDesc(wn, P);
+		na::ValidateWaveNetDesc(v); // weight count and chaining of the virtual model
+		const na::WaveNetPlan plan = na::BuildPackedWaveNetPlan(wn, P);
+		if (plan.pack != P || plan.splitFastT != 2) throw std::runtime_error("NA_DebugPackedWeights: the packed plan is not a fast split-kernel plan");
+		r = (int)v.weights.size();
+		if (out)
+			for (int i = 0; i < r && i < capacity; i++) out[i] = v.weights[(size_t)i];
 	});
 	return r;
 }

@@ -235,6 +235,76 @@ def test_generic_keras_stacks_accepted_or_rejected_at_load(na, tmp_path):
     assert loader.CreateFromFile(str(path), doPrewarm=False) is None
 
 
+def test_stream_packing_builds_a_block_diagonal_virtual_model(na):
+    """Stream packing, host side (no GPU): Nano packs 4 streams, Feather 2, Standard / A2 none; the virtual model's flat weights hold
+    the real model's tensors on the block diagonal, replicated vectors, zeros elsewhere, in the reference's weight order."""
+    import ctypes as C
+    from neuralaudio_amd import capi
+    lib = capi.load_library()
+    loader = na.NeuralModelLoader()
+    mdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "models")
+
+    def packed(name):
+        m = loader.CreateFromFile(os.path.join(mdir, name), doPrewarm=False)
+        pf = C.c_int(0)
+        n = lib.NA_DebugPackedWeights(m._h, C.byref(pf), None, 0)
+        assert n >= 0, capi.last_error()
+        out = np.zeros(n, np.float32)
+        if n:
+            assert lib.NA_DebugPackedWeights(m._h, C.byref(pf), out.ctypes.data_as(C.POINTER(C.c_float)), n) == n
+        return pf.value, out
+
+    assert packed("BossWN-standard.nam")[0] == 1 and packed("BossWN-a2.nam")[0] == 1
+    for name, P in (("BossWN-nano.nam", 4), ("BossWN-feather.nam", 2)):
+        pf, v = packed(name)
+        assert pf == P
+        j = O.load_json(name)
+        w = np.array(j["weights"], np.float32)
+        arrays = O.wavenet_arrays_from_nam(j)
+        pad = [4 * ((a["channels"] + 3) // 4) for a in arrays]
+        pos = vpos = 0
+        for ai, a in enumerate(arrays):
+            C_, Cp = a["channels"], pad[ai]
+            Cv = P * Cp
+            In = a["input_size"]
+            Inv = 1 if ai == 0 else P * pad[ai - 1]
+            Inp = 1 if ai == 0 else pad[ai - 1]
+            re_ = w[pos:pos + C_ * In].reshape(C_, In); pos += C_ * In
+            vre = v[vpos:vpos + Cv * Inv].reshape(Cv, Inv); vpos += Cv * Inv
+            for q in range(P):
+                blk = vre[q * Cp:q * Cp + C_, (0 if ai == 0 else q * Inp):(1 if ai == 0 else q * Inp + In)]
+                assert np.array_equal(blk, re_)
+            assert np.count_nonzero(vre) == P * np.count_nonzero(re_)
+            for K in a["kernel_sizes"]:
+                conv = w[pos:pos + C_ * C_ * K].reshape(C_, C_, K); pos += C_ * C_ * K
+                vec = [w[pos + i * C_:pos + (i + 1) * C_] for i in range(2)]; pos += 2 * C_
+                w1 = w[pos:pos + C_ * C_].reshape(C_, C_); pos += C_ * C_
+                b1 = w[pos:pos + C_]; pos += C_
+                vconv = v[vpos:vpos + Cv * Cv * K].reshape(Cv, Cv, K); vpos += Cv * Cv * K
+                vvec = [v[vpos + i * Cv:vpos + (i + 1) * Cv] for i in range(2)]; vpos += 2 * Cv
+                vw1 = v[vpos:vpos + Cv * Cv].reshape(Cv, Cv); vpos += Cv * Cv
+                vb1 = v[vpos:vpos + Cv]; vpos += Cv
+                for q in range(P):
+                    s_ = slice(q * Cp, q * Cp + C_)
+                    assert np.array_equal(vconv[s_, s_], conv) and np.array_equal(vw1[s_, s_], w1) and np.array_equal(vb1[s_], b1)
+                    assert np.array_equal(vvec[0][s_], vec[0]) and np.array_equal(vvec[1][s_], vec[1])
+                assert np.count_nonzero(vconv) == P * np.count_nonzero(conv) and np.count_nonzero(vw1) == P * np.count_nonzero(w1)
+            Hs = a["head_size"]
+            last = ai == len(arrays) - 1
+            Hp = 1 if last else pad[ai + 1]
+            head = w[pos:pos + Hs * C_].reshape(Hs, C_); pos += Hs * C_
+            vhead = v[vpos:vpos + P * Hp * Cv].reshape(P * Hp, Cv); vpos += P * Hp * Cv
+            for q in range(P):
+                assert np.array_equal(vhead[q * Hp:q * Hp + Hs, q * Cp:q * Cp + C_], head)
+            assert np.count_nonzero(vhead) == P * np.count_nonzero(head)
+            if a["has_head_bias"]:
+                hb = w[pos:pos + Hs]; pos += Hs
+                vhb = v[vpos:vpos + P * Hp]; vpos += P * Hp
+                for q in range(P):
+                    assert np.array_equal(vhb[q * Hp:q * Hp + Hs], hb)
+        assert v[vpos] == w[pos] and vpos + 1 == v.size and pos + 1 == w.size  # head scale
+
+
 def test_number_parsing_ignores_the_c_locale(na, tmp_path):
     """A host that called setlocale(LC_ALL, "") under a comma-decimal locale must still read "0.1234" as 0.1234."""
     import locale
