@@ -362,12 +362,9 @@ def main():
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_sample": bytes_per_sample,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                # the dominant kernel of the workload (FamilyFor() in gpu_batch.cpp: the f16-split kernel for Standard-like models, the
-                # frame kernel for narrow / 12-channel / large-kernel ones; NA_WN_KERNEL overrides)
-                "kernel": "RecurrentDppKernel" if (args.workload.startswith("lstm") or args.workload == "config4") else
-                          {"split": "WaveNetSplitKernel", "frame": "WaveNetFrameKernel", "generic": "WaveNetGenericKernel"}.get(
-                              os.environ.get("NA_WN_KERNEL", ""),
-                              "WaveNetSplitKernel" if (args.workload == "standard" or batch.StreamPackFactor(0) > 1) else "WaveNetFrameKernel"),
+                # the kernel that runs stream 0 of the batch (the dominant one of every workload here: the first group is the largest /
+                # the only WaveNet one; FamilyFor(), PackFor(), PadFor() in gpu_batch.cpp decide per model)
+                "kernel": batch.StreamKernelName(0),
                 "stream_pack_factor": batch.StreamPackFactor(0),  # > 1: narrow model, several real streams per kernel-level stream
             },
             "roofline_mfma_f32": {

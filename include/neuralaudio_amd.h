@@ -87,6 +87,8 @@ NA_EXTERN double NA_BatchMacsPerSample(NA_Batch* batch);
 NA_EXTERN double NA_BatchStateBytes(NA_Batch* batch);
 /* > 1 when the stream of a narrow static WaveNet model runs packed with others of its model into one kernel-level stream (0: bad argument) */
 NA_EXTERN int NA_BatchStreamPackFactor(NA_Batch* batch, int stream);
+/* the kernel that runs the stream (its rocprof name without template arguments; static string, "" on a bad argument) */
+NA_EXTERN const char* NA_BatchStreamKernelName(NA_Batch* batch, int stream);
 /* NAMIsA2 (bit 0) / NAMIsA2Standard (bit 1) of a .nam document (NeuralModel.cpp:159-168, 188-317); negative on a parse error */
 NA_EXTERN int NA_DebugClassifyNam(const char* jsonText);
 /* stream packing, host side only: pack factor of the model in a large batch (1: none); flat weights of the packed virtual model into

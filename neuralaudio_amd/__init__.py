@@ -291,6 +291,9 @@ class Batch:
     def StateBytes(self):
         return float(self._lib.NA_BatchStateBytes(self._h))
 
+    def StreamKernelName(self, stream):
+        return self._lib.NA_BatchStreamKernelName(self._h, int(stream)).decode()
+
     def StreamPackFactor(self, stream):
         return int(self._lib.NA_BatchStreamPackFactor(self._h, int(stream)))
 

@@ -467,6 +467,12 @@ void NA_DebugSetTraceBuffer(void* deviceBuffer) { na::SetWaveNetTraceBuffer(rein
 
 double NA_BatchStateBytes(NA_Batch* batch) { return batch ? (double)batch->batch->StateBytes() : 0.0; }
 
+const char* NA_BatchStreamKernelName(NA_Batch* batch, int stream)
+{
+	try { return batch ? batch->batch->StreamKernelName(stream) : ""; }
+	catch (...) { return ""; }
+}
+
 int NA_BatchStreamPackFactor(NA_Batch* batch, int stream)
 {
 	try { return batch ? batch->batch->StreamPackFactor(stream) : 0; }

@@ -133,6 +133,7 @@ namespace na
 		}
 
 		int NumMembers() const { return (int)memberRow.size(); }
+		bool IsContiguous() const { return contiguous; }
 
 		// fresh (never prewarmed) state: zero history / the model's initial h,c
 		virtual void Reset(const std::vector<int>& members) = 0;
@@ -143,6 +144,7 @@ namespace na
 		virtual double MacsPerSample() const = 0;
 		virtual size_t StateBytesPerStream() const = 0;
 		virtual int PackFactor() const { return 1; } // real streams per kernel-level stream (WaveNet stream packing)
+		virtual const char* KernelName() const = 0;  // the kernel that runs this group's streams (rocprof name, without template arguments)
 		// WaveNet groups on the frame kernel can share ONE launch with other such groups (a heterogeneous batch without stream
 		// fork/join); fills `out` with this group's part of that launch.  Other groups return false.
 		// `launchList`: which fused launch it joins (0 frame kernel, 1 f16-split kernel, 2 f16-split kernel with packed streams)
@@ -279,10 +281,11 @@ namespace na
 		public:
 			// Stream packing (wavenet_plan.cpp PackWaveNetDesc): several streams of a NARROW model share one virtual stream of the f16-split
 			// kernel -- 4 streams for <= 4-channel arrays (Nano), 2 for <= 8 (Feather).  It pays once the virtual streams fill the chip
-			// (measured, 128-frame blocks: Nano 4096 streams 60.9 vs 112.6 us, Feather 2048 43.6 vs 64.2 us; but Nano 1024 36.6 vs
-			// 30.1 us, Feather 1024 36.1 vs 33.6 us), and the state layout is fixed when the group is created, so the decision is taken
-			// from the size of the AddStreams call that creates it: at least 768 virtual streams.  Only for models that are not
-			// submodels of a slimmable container (`packHint` > 0: every member is always active).  NA_WN_PACK=0 never, =1 always.
+			// (measured, 128-frame blocks: Nano 4096 streams 60.9 vs 112.6 us, 1366 38.8 vs 52.1; Feather 2048 43.6 vs 64.2, 1365 42.2 vs
+			// 60.2; but Nano 1024 36.6 vs 30.1 us, Feather 1024 36.1 vs 33.6 us: up to 1024 streams the unpacked launch is a single round
+			// of workgroups), and the state layout is fixed when the group is created, so the decision is taken from the size of the
+			// AddStreams call that creates it: more than 1024 streams.  Only for models that are not submodels of a slimmable
+			// container (`packHint` > 0: every member is always active).  NA_WN_PACK=0 never, =1 always.
 			static int PackFor(const WaveNetDesc& wn, int packHint)
 			{
 				static const int mode = getenv("NA_WN_PACK") ? atoi(getenv("NA_WN_PACK")) : -1;
@@ -293,24 +296,37 @@ namespace na
 					if (cfg.channels > 16) return 1;
 				const int P = WaveNetPackFactor(wn);
 				if (P < 2) return 1;
-				return (mode == 1 || packHint / P >= 768) ? P : 1;
+				return (mode == 1 || packHint > 1024) ? P : 1;
+			}
+
+			// Padding without packing (wavenet_plan.cpp WaveNetWantsPadding): a model whose arrays do not fill their lane mode (A1 Lite:
+			// 12 / 6 channels) is widened to 16 / 8 and runs the fast flavour of the split kernel (1024 streams: 43.8 vs 46.0 us on the
+			// frame kernel, 1365: 66.4 vs 76.0).  NA_WN_PAD=0 turns it off.
+			static bool PadFor(const WaveNetDesc& wn)
+			{
+				static const bool off = getenv("NA_WN_PAD") != nullptr && atoi(getenv("NA_WN_PAD")) == 0;
+				const WnFamily o = WaveNetFamilyOverride();
+				if (off || (o != WN_FAMILY_AUTO && o != WN_FAMILY_SPLIT)) return false;
+				ValidateWaveNetDesc(wn);
+				return WaveNetWantsPadding(wn);
 			}
 
 			// packHint: 0 = never pack (submodel of a container), otherwise the number of streams the creating AddStreams call brings
 			WaveNetGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s, int packHint = 0)
-				: ModelGroup(d, s), pack(PackFor(d->wavenet, packHint)), plan(pack > 1 ? BuildPackedWaveNetPlan(d->wavenet, pack) : BuildWaveNetPlan(d->wavenet)),
-				  family(pack > 1 ? WN_FAMILY_SPLIT : FamilyFor(plan))
+				: ModelGroup(d, s), pack(PackFor(d->wavenet, packHint)),
+				  plan((pack > 1 || PadFor(d->wavenet)) ? BuildPackedWaveNetPlan(d->wavenet, pack) : BuildWaveNetPlan(d->wavenet)),
+				  family(plan.isVirtual() ? WN_FAMILY_SPLIT : FamilyFor(plan))
 			{
-				if (pack > 1)
+				if (plan.isVirtual())
 				{
-					if (plan.splitFastT != 2) throw std::runtime_error("internal: packed WaveNet plan is not a fast split-kernel plan");
-					realPlan = BuildWaveNetPlan(d->wavenet); // bookkeeping (bytes / MACs / state per REAL stream)
+					if (plan.splitFastT != 2) throw std::runtime_error("internal: packed / padded WaveNet plan is not a fast split-kernel plan");
+					realPlan = BuildWaveNetPlan(d->wavenet); // bookkeeping (bytes / MACs per REAL stream)
 				}
 				dStages.Upload(plan.stages, stream);
 				dWpack.Upload(plan.wpack, stream);
 				dWpk.Upload(plan.wpk, stream);
 				dPrewarm.Upload(plan.prewarm, stream);
-				dWeights.Upload(pack > 1 ? plan.packedWeights : d->wavenet.weights, stream);
+				dWeights.Upload(plan.isVirtual() ? plan.packedWeights : d->wavenet.weights, stream);
 				dSStages.Upload(plan.sstages, stream);
 				dWsplit.Upload(plan.wsplit, stream);
 
@@ -437,7 +453,9 @@ namespace na
 			bool FusedLaunchArgs(WnFrameGroup& out, int& launchList) override
 			{
 				if (family == WN_FAMILY_GENERIC) return false; // its own launch
-				launchList = family == WN_FAMILY_SPLIT ? (pack > 1 ? 2 : 1) : 0;
+				// list 2 = the packed flavour of the split kernel; a plain group whose plan runs the fast flavour may join it (negative list:
+				// "1, or 2 if a packed group is in the batch" -- then it passes its index lists even when its streams are contiguous)
+				launchList = family == WN_FAMILY_SPLIT ? (pack > 1 ? 2 : (plan.splitFastT == 2 ? -1 : 1)) : 0;
 				out.pack = pack;
 				SyncActiveLists();
 				out.model = &dev;
@@ -447,13 +465,18 @@ namespace na
 				out.numStreams = (int)hSlots.size();
 				out.slot0 = contiguous ? hSlots[0] : 0;
 				out.row0 = contiguous ? hRows[0] : 0;
+				listSlots = dSlots.Get();
 				return out.numStreams > 0;
 			}
 
-			double AlgorithmicBytesPerSample(int blockFrames) const override { return (pack > 1 ? realPlan : plan).AlgorithmicBytesPerSample(blockFrames); }
-			double MacsPerSample() const override { return (pack > 1 ? realPlan : plan).MacsPerSample(); }
+			double AlgorithmicBytesPerSample(int blockFrames) const override { return (plan.isVirtual() ? realPlan : plan).AlgorithmicBytesPerSample(blockFrames); }
+			double MacsPerSample() const override { return (plan.isVirtual() ? realPlan : plan).MacsPerSample(); }
 			size_t StateBytesPerStream() const override { return (size_t)plan.stateF4 * 16 / (size_t)pack; }
 			int PackFactor() const override { return pack; }
+			const char* KernelName() const override
+			{
+				return family == WN_FAMILY_SPLIT ? "WaveNetSplitKernel" : (family == WN_FAMILY_GENERIC ? "WaveNetGenericKernel" : "WaveNetFrameKernel");
+			}
 
 			// Packed groups: the launch lists name VIRTUAL streams -- slot = member / pack -- and hold `pack` rows each (-1: no member in
 			// that position yet).  Members of a static model are always active, so a virtual stream runs as soon as it has one member.
@@ -532,6 +555,9 @@ namespace na
 				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize"); // the lists are freed on return
 			}
 
+		public:
+			const int* listSlots = nullptr; // device slot list of the last FusedLaunchArgs (always uploaded, also for contiguous groups)
+		private:
 			const int pack;       // real streams per virtual stream (1: no packing)
 			WaveNetPlan plan;     // pack > 1: of the VIRTUAL model
 			WaveNetPlan realPlan; // pack > 1: of the real model (bookkeeping only)
@@ -673,6 +699,11 @@ namespace na
 			}
 
 			size_t StateBytesPerStream() const override { return (size_t)numElems * sizeof(float); }
+			const char* KernelName() const override
+			{
+				if (RecurrentDppSupported(dev)) return "RecurrentDppKernel";
+				return dev.cell == LSTM_CELL_GRU ? "GruWaveKernel / GruGenericKernel" : "LstmWaveKernel / LstmBlockKernel / LstmGenericKernel";
+			}
 
 		protected:
 			void EnsureCapacity(int members) override
@@ -879,6 +910,7 @@ namespace na
 		std::vector<RecurrentGroup> fusedRec;
 		std::vector<ModelGroup*> singles;
 		ModelGroup* wnOwner[NUM_WN_LISTS] = {}; // lends its side stream / event to the fused unit
+		std::vector<std::pair<WnFrameGroup, ModelGroup*>> joiners;
 		ModelGroup* recOwner = nullptr;
 		for (auto& g : groups)
 		{
@@ -888,6 +920,13 @@ namespace na
 			int list = 0;
 			if (g->FusedLaunchArgs(a, list))
 			{
+				if (list < 0)
+				{
+					// a plain fast-flavour split group: joins the packed launch if there is one (decided below), else the plain split launch
+					a.slots = static_cast<WaveNetGroup*>(g.get())->listSlots;
+					joiners.push_back({ a, g.get() });
+					continue;
+				}
 				fusedWn[list].push_back(a);
 				if (!wnOwner[list]) wnOwner[list] = g.get();
 			}
@@ -901,6 +940,14 @@ namespace na
 				g->SyncActiveLists();
 				singles.push_back(g.get());
 			}
+		}
+		for (auto& j : joiners)
+		{
+			const int list = fusedWn[2].empty() ? 1 : 2;
+			WnFrameGroup a = j.first;
+			if (list == 1 && static_cast<WaveNetGroup*>(j.second)->IsContiguous()) a.slots = nullptr; // the plain kernel's shortcut
+			fusedWn[list].push_back(a);
+			if (!wnOwner[list]) wnOwner[list] = j.second;
 		}
 		auto launchWnList = [&](int which, hipStream_t s) {
 			const std::vector<WnFrameGroup>& list = fusedWn[which];
@@ -1136,6 +1183,12 @@ namespace na
 			n += g->NumActive();
 		}
 		return n ? sum / n : 0.0;
+	}
+
+	const char* GpuBatch::StreamKernelName(int s) const
+	{
+		const StreamRef& ref = streams.at((size_t)s);
+		return ref.members[(size_t)ref.active].first->KernelName();
 	}
 
 	int GpuBatch::StreamPackFactor(int s) const

@@ -93,6 +93,7 @@ namespace na
 		double AlgorithmicBytesPerSample(int blockFrames) const;
 		double MacsPerSample() const;
 		size_t StateBytes() const;
+		const char* StreamKernelName(int stream) const; // which kernel runs the stream (rocprof name without template arguments)
 		int StreamPackFactor(int stream) const; // > 1: the stream shares a kernel-level stream with others of its model (stream packing)
 
 	private:

@@ -740,13 +740,17 @@ namespace na
 		return maxPad <= 4 ? 4 : (maxPad <= 8 ? 2 : 1);
 	}
 
+	// P == 1: no packing, only padding -- every layer array is widened to the channel count that fills its lane mode (12 -> 16, 6 -> 8,
+	// 3 -> 4), so that a model like A1 Lite runs the fast flavour of the split kernel (zero rows / columns cost nothing there: the
+	// cost of a layer is its skeleton, not its width).
 	WaveNetDesc PackWaveNetDesc(const WaveNetDesc& desc, int P)
 	{
 		WaveNetDesc v;
 		v.mathMode = desc.mathMode;
 		const int numArrays = (int)desc.arrays.size();
 		std::vector<int> cpad((size_t)numArrays);
-		for (int a = 0; a < numArrays; a++) cpad[(size_t)a] = CeilDiv(desc.arrays[(size_t)a].channels, 4) * 4;
+		for (int a = 0; a < numArrays; a++)
+			cpad[(size_t)a] = P > 1 ? CeilDiv(desc.arrays[(size_t)a].channels, 4) * 4 : 4 * LaneMode(desc.arrays[(size_t)a].channels);
 		size_t pos = 0;
 		auto take = [&](size_t n) { const size_t at = pos; pos += n; return at; };
 		for (int a = 0; a < numArrays; a++)
@@ -816,9 +820,27 @@ namespace na
 		return v;
 	}
 
+	// true: the model qualifies for the fast split-kernel flavour except that some layer array does not fill its lane mode
+	bool WaveNetWantsPadding(const WaveNetDesc& desc)
+	{
+		bool partial = false;
+		for (const WnArrayCfg& cfg : desc.arrays)
+		{
+			if (cfg.channels > 16 || cfg.headKernelSize != 1 || cfg.conditionSize != 1) return false;
+			for (int k : cfg.kernelSizes)
+				if (k != 3) return false;
+			if (cfg.channels != 4 * LaneMode(cfg.channels)) partial = true;
+		}
+		if (desc.arrays.back().headSize != 1) return false;
+		// arrays of <= 4 channels want 4 tiles per wave when they run alone (packing is what helps them), leave those to PackFor
+		for (const WnArrayCfg& cfg : desc.arrays)
+			if (cfg.channels <= 4) return false;
+		return partial;
+	}
+
 	WaveNetPlan BuildPackedWaveNetPlan(const WaveNetDesc& desc, int P)
 	{
-		if (P < 2) return BuildWaveNetPlan(desc);
+		if (P < 1) return BuildWaveNetPlan(desc);
 		const WaveNetDesc v = PackWaveNetDesc(desc, P);
 		Builder b(v, P);
 		b.Build();

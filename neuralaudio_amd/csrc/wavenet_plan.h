@@ -32,6 +32,7 @@ namespace na
 		int splitFastT = 0;                // see WnModelDev::split_fast_T
 		int maxChannels = 0;               // widest layer array
 		int pack = 1;                      // streams per virtual stream (BuildPackedWaveNetPlan)
+		bool isVirtual() const { return !packedWeights.empty(); } // packed and / or padded: arrays, rings, stages describe the virtual model
 		std::vector<float> packedWeights;  // pack > 1: flat weights of the virtual model (reference order)
 		bool genericOnly = false;          // > 16 channels: only rings + the natural-layout table are built (runtime-shaped block kernel)
 		bool genericOk = false;            // the runtime-shaped block kernel can run it (dense heads only)
@@ -52,6 +53,7 @@ namespace na
 	// Stream packing (wavenet_plan.cpp): how many streams of this model fit one virtual stream of the f16-split kernel (1: none),
 	// the virtual model, and its plan (WaveNetPlan::pack = P; arrays / rings / stages describe the VIRTUAL model).
 	int WaveNetPackFactor(const WaveNetDesc& desc);
+	bool WaveNetWantsPadding(const WaveNetDesc& desc); // P == 1 "packing": widen the arrays to full lane modes (A1 Lite: 12 / 6 -> 16 / 8)
 	WaveNetDesc PackWaveNetDesc(const WaveNetDesc& desc, int P);
 	WaveNetPlan BuildPackedWaveNetPlan(const WaveNetDesc& desc, int P);
 }

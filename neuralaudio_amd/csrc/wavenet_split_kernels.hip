@@ -962,8 +962,8 @@ namespace na
 				a.maxG = m.max_G;
 				a.firstBlock = blocks;
 				a.pack = g.pack > 1 ? g.pack : 1;
-				if ((a.pack > 1) != PK) return hipErrorInvalidValue; // packed and plain groups never share a launch
-				if (PK && g.slots == nullptr) return hipErrorInvalidValue; // packed launches always pass the row lists
+				if (a.pack > 1 && !PK) return hipErrorInvalidValue; // the plain flavour cannot run packed groups (a plain group in a packed launch is pack = 1)
+				if (PK && g.slots == nullptr) return hipErrorInvalidValue; // packed launches always pass the index lists
 				blocks += (g.numStreams + SPB - 1) / SPB;
 				maxG = std::max(maxG, m.max_G);
 				maxOps = std::max(maxOps, m.max_split_ops);
@@ -1019,7 +1019,7 @@ namespace na
 		if (packed)
 		{
 			for (int i = 0; i < numGroups; i++)
-				if (groups[i].pack < 2 || groups[i].model->split_fast_T != 2) return hipErrorInvalidValue;
+				if (groups[i].model->split_fast_T != 2) return hipErrorInvalidValue; // plain groups may ride along (pack = 1) if their plan is a fast one
 #ifndef NA_SP_QUICK
 #define NA_SP_LAUNCH_PK(SS, WW) return sp::Launch<2, SS, WW, false, true>(groups, numGroups, in, out, inStride, outStride, n, stream)
 			if (tiles > 4) { if (spb >= 2) NA_SP_LAUNCH_PK(2, 4); NA_SP_LAUNCH_PK(1, 4); }
