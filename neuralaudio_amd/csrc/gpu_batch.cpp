@@ -266,7 +266,8 @@ namespace na
 		// Which kernel family runs a model (fixed for the life of its group: the families keep different stream-state formats).
 		// Measured on MI355X, 1024 streams x 128 frames: the f16-split kernel wins where its fast instantiation applies with 2 tiles
 		// per wave (every array has 5..8 or 13..16 channels, K = 3: Standard 50 vs 60 us); narrow (Feather, Nano: <= 4-channel
-		// arrays), 12-channel (Lite) and large-kernel (A2) models are faster on the frame kernel (33 / 30 / 71 us vs 44 / 44 / 133 us).
+		// arrays) and large-kernel (A2) models are faster on the frame kernel (33 / 30 / 71 us vs 44 / 44 / 133 us); a 12-channel model (Lite)
+		// is too as it is (46 vs 50 us), but padded to 16 / 8 channels it runs the fast split flavour (PadFor below: 42.6 us).
 		WnFamily FamilyFor(const WaveNetPlan& plan)
 		{
 			if (plan.genericOnly) return WN_FAMILY_GENERIC; // > 16 channels: the runtime-shaped kernel is the only one that runs it

@@ -1,7 +1,8 @@
 // wavenet_frame_kernels.hip -- the "lane = frame" WaveNet block kernel for gfx950 (v_mfma_f32_4x4x1_16b_f32).
 //
 // The f32 kernel of round 1; since round 2 it serves the models the f16-split kernel (wavenet_split_kernels.hip) is not faster on --
-// narrow (<= 4-channel arrays), 12-channel and large-kernel (A2) architectures, see FamilyFor() in gpu_batch.cpp (reference functions:
+// narrow (<= 4-channel arrays) models in batches of up to 1024 streams and large-kernel (A2) architectures, see FamilyFor() / PackFor() /
+// PadFor() in gpu_batch.cpp (reference functions:
 // WaveNetModelT/LayerArrayT/LayerT::Process, Conv1DT::Process, DenseLayerT::Process -- NeuralAudio/WaveNet.h:768-799,
 // 632-661,462-494,139-290,336-383; FastMath -- NeuralAudio/Activation.h:83-118), different mapping of the arithmetic:
 //

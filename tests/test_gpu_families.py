@@ -1,7 +1,8 @@
 """Both WaveNet kernel families -- and every kernel variant that ships behind a tuning knob -- against the oracle on EVERY architecture.
 
 By default a model runs on the family that is faster for it (FamilyFor() in gpu_batch.cpp: the f16-split kernel for Standard-like
-models, the f32 frame kernel for narrow / 12-channel / large-kernel ones, the runtime-shaped kernel for arrays wider than 16 channels).
+models and padded A1 Lite, the f32 frame kernel for narrow / large-kernel ones, the runtime-shaped kernel for arrays wider than 16
+channels; large batches of narrow models run packed).
 NA_WN_KERNEL forces one family for all models it can run; it is read
 once per process, so each forced run is a subprocess of the same parity + fuzz + batch test files."""
 import os
