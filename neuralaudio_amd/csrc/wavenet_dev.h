@@ -96,7 +96,7 @@ namespace na
 		int out_G;
 		int a_off;           // this stage's A-operand block in the split weight image: quad offset (64 quads = 1 KB per MFMA operand)
 		int a_ops;           // number of 1 KB operands
-		int reserved;        // bits 0..3: channel groups per packed stream (4: not packed); bits 4..: WN_ST_LAYER: layers left in the array, this one included
+		int reserved;
 	};
 	static_assert(sizeof(WnSplitStage) == 64, "split stage descriptors are 64-byte records");
 

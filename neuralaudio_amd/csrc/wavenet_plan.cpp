@@ -414,7 +414,7 @@ namespace na
 						for (int k = 0; k < K; k++)
 							FillSplitMerged(op0 + 2 * k, Gp, C, C, [&](int o, int c) { return W(wconv + (o * C + c) * K + k); });
 						FillSplitAux(op0 + 2 * K, Gp, C, wmix, bconv, cpad);
-						st.reserved = groupsPerStream + 16 * (numLayers - l); // bits 0..3: channel groups per packed stream; above: layers left in this array, this one included
+						st.reserved = groupsPerStream;
 						FillSplitMerged(op0 + 2 * K + 1, Gp, C, C, [&](int o, int c) { return W(w1 + o * C + c); });
 						FillSplitAux(op0 + 2 * K + 3, Gp, C, -1, b1);
 						if (needOutput) st.flags |= WN_FLAG_NEED_OUTPUT;

@@ -54,9 +54,6 @@ namespace na
                  // 512: ring loads and stores issued but all out of range (no traffic), 1024: only the stores so, 2048: only the loads
                  // (round-2 measurements: profiles/r02_ablation.txt)
 #endif
-#ifndef NA_SP_SKEW
-#define NA_SP_SKEW 0 // 1: two-stream workgroups run their streams half a layer apart (RunLayersSkew)
-#endif
 #ifndef NA_PK_TANH
 #define NA_PK_TANH 1 // tuning builds: 0 = the unpacked tanh in the activation phase
 #endif
@@ -418,7 +415,7 @@ namespace na
 				const bool mask = GEN && (Geo<GP, T>::PARTIAL || G < GP); // wave-uniform: some lanes have no channel group / no tile of their own
 				const int inPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
 				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id) : 0;
-				const int gsShift = PK ? ((sd.reserved & 15) >> 1) : 0; // channel groups per packed stream: 1, 2, 4 -> 0, 1, 2
+				const int gsShift = PK ? (sd.reserved >> 1) : 0; // channel groups per packed stream: 1, 2, 4 -> 0, 1, 2
 
 				// dilated conv (WaveNet.h:139-290): tap k reads the frame d*(K-1-k) back; accumulation starts from zero, bias and mix-in
 				// arrive through the aux operand
@@ -576,174 +573,6 @@ namespace na
 			} while (s < cx.nstages && sd.type == WN_ST_LAYER && sd.Gp == GP);
 		}
 
-		// The same run of layers for workgroups of TWO streams, the streams half a layer apart (fast flavour only).  A layer is a conv half
-		// X (taps -> accumulators: LDS reads + MFMAs + ring requests) and a tail half Y (activation, 1x1, publish: VALU + MFMAs + ring
-		// stores).  With both streams in the same half at the same time -- RunLayers -- the waves that share a SIMD want the same unit;
-		// here stream 0 runs X_l while stream 1 runs Y_(l-1), then Y_l beside X_l: two barriers per layer, each closing one half,
-		// one more half-step per run (stream 1 finishes a half layer late).  The weights of stage l + 1 are staged during the odd
-		// half-steps (stream 0 in Y_l, stream 1 in X_l): their LDS buffer was last read by stream 1's Y_(l-1) in the half-step before.
-		template <int GP, int T, int NTHREADS, bool PK, int ROLE>
-		__device__ __forceinline__ void RunLayersSkewRole(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
-		{
-			constexpr int S = Geo<GP, T>::S;
-			constexpr int P = Geo<GP, T>::P;
-			constexpr int HPF = 2, K = 3;
-			const WeightStager<NTHREADS, false> stager;
-			const int lane = OpaqueLane(cx);
-			int f[S], cg[S];
-			bool live[S];
-#pragma unroll
-			for (int i = 0; i < S; i++) FrameOf<GP, T>(cx, lane, i, f[i], cg[i], live[i]);
-			const int L = sd.reserved >> 4; // layers in this run (the plan counts them per array; an array is one lane mode)
-			const int s0 = s;
-			const int gsShift = PK ? ((sd.reserved & 15) >> 1) : 0;
-
-			u32x4 hist[HPF][S];
-			{
-				const int pos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
-#pragma unroll
-				for (int t = 0; t < HPF; t++)
-#pragma unroll
-					for (int i = 0; i < S; i++) hist[t][i] = LoadHistory(cx, sd.ring_off, sd.ring_frames, GP, pos0, f[i], cg[i], sd.dilation * (K - 1 - t), true);
-			}
-			if (ROLE == 1) BlockBarrier<NTHREADS / 64>(); // half-step 0: stream 0 alone (X_0)
-			for (int l = 0; l < L; l++)
-			{
-				const int sm = s0 + l;
-				Stage sdn = sd;
-				sdn.type = -1;
-				sdn.a_ops = 0;
-				if (sm + 1 < cx.nstages) sdn = LoadStage(cx.stages, sm + 1);
-				if (ROLE == 1) stager.Begin(cx, (sm + 1) & 1, sdn); // odd half-step 2l + 1: stream 1 is in X_l, stream 0 in Y_l
-				const u32x4* wl = cx.wbuf + (sm & 1) * cx.wstride + lane;
-				// ---- X: conv (WaveNet.h:139-290)
-				f32x4 acc[S];
-				{
-					const u32x4* imgCur = cx.img + cur * cx.imgStride;
-					const int d = sd.dilation;
-#pragma unroll
-					for (int i = 0; i < S; i++) acc[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-					for (int k = 0; k < HPF; k++)
-					{
-						const u32x4 ah = wl[WOP(2 * k)], al = wl[WOP(2 * k + 1)];
-						const int shift = d * (K - 1 - k);
-						const int lo = cx.F0 - shift, hi = cx.F0 + 16 * P * S - 1 - shift; // wave-uniform
-						if (hi < 0)
-						{
-#pragma unroll
-							for (int i = 0; i < S; i++)
-							{
-								acc[i] = Mfma(ah, hist[k][i], acc[i]);
-								acc[i] = Mfma(al, hist[k][i], acc[i]);
-							}
-						}
-						else if (lo >= 0)
-						{
-#pragma unroll
-							for (int i = 0; i < S; i++)
-							{
-								const u32x4 b = imgCur[ImgIdx(cg[i], f[i] - shift)];
-								acc[i] = Mfma(ah, b, acc[i]);
-								acc[i] = Mfma(al, b, acc[i]);
-							}
-						}
-						else
-						{
-#pragma unroll
-							for (int i = 0; i < S; i++)
-							{
-								const u32x4 b = TapInBlock(imgCur, f[i] - shift, cg[i]);
-								acc[i] = Mfma(ah, hist[k][i], acc[i]);
-								acc[i] = Mfma(al, hist[k][i], acc[i]);
-								acc[i] = Mfma(ah, b, acc[i]);
-								acc[i] = Mfma(al, b, acc[i]);
-							}
-						}
-					}
-					{
-						const bool haveNext = (l + 1 < L);
-						const int nextPos0 = __builtin_amdgcn_readlane(cx.myPos, haveNext ? sdn.ring_id : 0);
-#pragma unroll
-						for (int t = 0; t < HPF; t++)
-#pragma unroll
-							for (int i = 0; i < S; i++)
-								hist[t][i] = LoadHistory(cx, sdn.ring_off, sdn.ring_frames, GP, nextPos0, f[i], cg[i], sdn.dilation * (K - 1 - t), haveNext);
-					}
-					{
-						const u32x4 ah = wl[WOP(2 * K - 2)], al = wl[WOP(2 * K - 1)], xa = wl[WOP(2 * K)];
-#pragma unroll
-						for (int i = 0; i < S; i++)
-						{
-							const u32x4 b = imgCur[ImgIdx(cg[i], f[i])];
-							const u32x4 ax = AuxOf<PK>(cx, f[i], cg[i], gsShift);
-							acc[i] = Mfma(ah, b, acc[i]);
-							acc[i] = Mfma(al, b, acc[i]);
-							acc[i] = Mfma(xa, ax, acc[i]);
-						}
-					}
-				}
-				// the staging must have landed before the barrier; the HPF * S history requests issued after it may stay in flight
-				if (ROLE == 1) stager.template End<HPF * S>(cx, (sm + 1) & 1, sdn);
-				BlockBarrier<NTHREADS / 64>(); // stream 0: closes half-step 2l; stream 1: closes 2l + 1
-				if (ROLE == 0) stager.Begin(cx, (sm + 1) & 1, sdn); // odd half-step 2l + 1
-				// ---- Y: activation (:473-480), head accumulate (:482), 1x1 + bias + residual (:486-491), publish
-				{
-					u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
-					const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id) : 0;
-					f32x4 z[S];
-					if (sd.flags & WN_FLAG_LEAKY)
-					{
-#pragma unroll
-						for (int i = 0; i < S; i++) z[i] = f32x4{ LeakyReLU(acc[i].x), LeakyReLU(acc[i].y), LeakyReLU(acc[i].z), LeakyReLU(acc[i].w) };
-					}
-					else if (sd.flags & WN_FLAG_STD_TANH)
-					{
-#pragma unroll
-						for (int i = 0; i < S; i++) z[i] = f32x4{ StdTanh(acc[i].x), StdTanh(acc[i].y), StdTanh(acc[i].z), StdTanh(acc[i].w) };
-					}
-					else
-					{
-#pragma unroll
-						for (int i = 0; i < S; i++)
-						{
-							const f32x2 lo2 = FastTanh2(f32x2{ acc[i].x, acc[i].y }), hi2 = FastTanh2(f32x2{ acc[i].z, acc[i].w });
-							z[i] = f32x4{ lo2.x, lo2.y, hi2.x, hi2.y };
-						}
-					}
-					const bool pub = (sd.flags & WN_FLAG_PUBLISH) != 0;
-					const u32x4 idop = cx.idop[lane];
-					const u32x4 w1h = wl[WOP(2 * K + 1)], w1l = wl[WOP(2 * K + 2)], b1a = wl[WOP(2 * K + 3)];
-#pragma unroll
-					for (int i = 0; i < S; i++)
-					{
-						const u32x4 zs = SplitQuad(z[i]);
-						const u32x4 ax = AuxOf<PK>(cx, f[i], cg[i], gsShift);
-						st.hd[i] = Mfma(idop, zs, st.hd[i]);
-						f32x4 y = st.xc[i];
-						y = Mfma(w1h, zs, y);
-						y = Mfma(w1l, zs, y);
-						y = Mfma(b1a, ax, y);
-						st.xc[i] = y;
-						Publish(cx, imgNext, SplitQuad(y), f[i], cg[i], pub, sd.out_ring_off, sd.out_ring_frames, GP, outPos0, pub ? cx.nSt : 0);
-					}
-					if (pub) cur ^= 1;
-				}
-				if (ROLE == 0) stager.template End<S>(cx, (sm + 1) & 1, sdn); // the S ring stores of Y may stay in flight
-				BlockBarrier<NTHREADS / 64>(); // stream 0: closes 2l + 1; stream 1: closes 2l + 2
-				sd = sdn;
-			}
-			if (ROLE == 0) BlockBarrier<NTHREADS / 64>(); // half-step 2L: stream 1 alone (Y_(L-1))
-			s = s0 + L;
-		}
-
-		template <int GP, int T, int NTHREADS, bool PK>
-		__device__ __forceinline__ void RunLayersSkew(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st, int role)
-		{
-			if (role == 0) RunLayersSkewRole<GP, T, NTHREADS, PK, 0>(cx, s, sd, cur, st);
-			else RunLayersSkewRole<GP, T, NTHREADS, PK, 1>(cx, s, sd, cur, st);
-		}
-
 		// array 0 rechannel: x = w_re * cond (WaveNet.h:637 with InputSize == 1) -- the aux operand against (w_re, 0)
 		template <int GP, int T, int NTHREADS, bool GEN, bool PK>
 		__device__ __forceinline__ void RechannelStage(const Ctx& cx, int& s, Stage& sd, int& cur, State<T>& st)
@@ -762,7 +591,7 @@ namespace na
 			{
 				int f, cg; bool live;
 				FrameOf<GP, T>(cx, lane, i, f, cg, live);
-				const u32x4 ax = AuxOf<PK>(cx, f, cg, PK ? ((sd.reserved & 15) >> 1) : 0);
+				const u32x4 ax = AuxOf<PK>(cx, f, cg, PK ? (sd.reserved >> 1) : 0);
 				f32x4 x = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 				x = Mfma(ra, ax, x);
 				st.xc[i] = x;
@@ -1065,13 +894,7 @@ namespace na
 				{
 					// K = 3 models: both shifted taps' history is requested a layer ahead; larger kernels (A2: 6 / 15): the first 2 as well,
 					// the rest in line
-					if constexpr (NA_SP_SKEW && !GEN && SPB == 2 && T == 2)
-					{
-						if (mode == 4) RunLayersSkew<4, T, NTHREADS, PK>(cx, s, sd, cur, st, sub);
-						else if (mode == 2) RunLayersSkew<2, T, NTHREADS, PK>(cx, s, sd, cur, st, sub);
-						else RunLayers<1, T, NTHREADS, 2, GEN, PK>(cx, s, sd, cur, st);
-					}
-					else if (mode == 4) RunLayers<4, T, NTHREADS, 2, GEN, PK>(cx, s, sd, cur, st);
+					if (mode == 4) RunLayers<4, T, NTHREADS, 2, GEN, PK>(cx, s, sd, cur, st);
 					else if (mode == 2) RunLayers<2, T, NTHREADS, 2, GEN, PK>(cx, s, sd, cur, st);
 					else RunLayers<1, T, NTHREADS, 2, GEN, PK>(cx, s, sd, cur, st);
 				}
