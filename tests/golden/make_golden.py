@@ -15,6 +15,7 @@
                       whose quality flips mid-stream (each submodel only advances while active, CompositeModel.h:94-100).  The reference
                       cannot be built here (no Eigen), so these are NOT reference outputs; they are what the GPU tests hold the HIP path
                       to in addition to the live oracle, so that kernel and oracle cannot drift together unnoticed.
+  keras_stacks_torch.npz  the same for three generic keras stacks (lstm / gru / dense chains): torch.nn.LSTM / GRU / Linear, float64
   gru_torch.npz       INDEPENDENT-IMPLEMENTATION VECTORS for the keras GRU (RTNeural is absent from the reference tree, so there is no
                       reference output to record): output of torch.nn.GRU (float64, weights permuted from keras z|r|c to torch r|z|n order)
                       + dense head on the committed synthetic model models/synthetic_gru_1x16.json, after 2048 zeros of prewarm.
@@ -90,6 +91,50 @@ def make_gru():
     np.savez_compressed(os.path.join(HERE, "gru_torch.npz"), input=x, output=y.astype(np.float32))
 
 
+KERAS_STACKS = {"lstm8_dense6tanh_dense1": [("lstm", 8), ("dense", 6, "tanh"), ("dense", 1)],
+                "gru12_dense5relu_dense3sigmoid_dense1": [("gru", 12), ("dense", 5, "relu"), ("dense", 3, "sigmoid"), ("dense", 1)],
+                "dense8tanh_dense4elu_dense1": [("dense", 8, "tanh"), ("dense", 4, "elu"), ("dense", 1)]}
+
+
+def make_keras_stacks():
+    """INDEPENDENT-IMPLEMENTATION VECTORS for generic keras stacks (RTNeural is absent, so there is no reference output to
+    record): torch.nn.LSTM / GRU / Linear in float64 on committed synthetic models, zero state, 2048 zeros of prewarm."""
+    import json
+    import torch
+    import ref_np as R
+    acts = {"": lambda v: v, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid, "elu": torch.nn.functional.elu}
+    x = O.signal_noise(1024, 20260929)
+    out = {"input": x}
+    for name, spec in KERAS_STACKS.items():
+        j = R.synth_keras_stack(spec, seed=len(name))
+        with open(os.path.join(HERE, "models", "synthetic_stack_%s.json" % name), "w") as f:
+            json.dump(j, f)
+        with torch.no_grad():
+            v = torch.from_numpy(np.concatenate([np.zeros(2048), x.astype(np.float64)])).reshape(1, -1, 1)
+            for l in j["layers"]:
+                H = int(l["shape"][-1])
+                W = [np.array(w, dtype=np.float64) for w in l["weights"]]
+                if l["type"] == "lstm":
+                    m = torch.nn.LSTM(v.shape[-1], H, batch_first=True).double()  # keras gate order i, f, c, o == torch's i, f, g, o
+                    m.weight_ih_l0.copy_(torch.from_numpy(W[0].T.copy()))
+                    m.weight_hh_l0.copy_(torch.from_numpy(W[1].T.copy()))
+                    m.bias_ih_l0.copy_(torch.from_numpy(W[2].ravel().copy()))
+                    m.bias_hh_l0.zero_()
+                    v, _ = m(v)
+                elif l["type"] == "gru":
+                    m = torch.nn.GRU(v.shape[-1], H, batch_first=True).double()
+                    perm = np.concatenate([np.arange(H, 2 * H), np.arange(0, H), np.arange(2 * H, 3 * H)])  # keras z | r | c -> torch r | z | n
+                    m.weight_ih_l0.copy_(torch.from_numpy(W[0].T[perm].copy()))
+                    m.weight_hh_l0.copy_(torch.from_numpy(W[1].T[perm].copy()))
+                    m.bias_ih_l0.copy_(torch.from_numpy(W[2][0][perm].copy()))
+                    m.bias_hh_l0.copy_(torch.from_numpy(W[2][1][perm].copy()))
+                    v, _ = m(v)
+                else:
+                    v = acts[l.get("activation", "") or ""](v @ torch.from_numpy(W[0]) + torch.from_numpy(W[1].ravel()))
+            out[name] = v[0, 2048:, 0].numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "keras_stacks_torch.npz"), **out)
+
+
 MATRIX_MODELS = [("standard", "BossWN-standard.nam", 1.0), ("feather", "BossWN-feather.nam", 1.0), ("nano", "BossWN-nano.nam", 1.0),
                  ("a2q0", "BossWN-a2.nam", 0.0), ("a2q1", "BossWN-a2.nam", 1.0), ("lstm1x16", "BossLSTM-1x16.nam", 1.0),
                  ("lstm2x8", "BossLSTM-2x8.nam", 1.0)]
@@ -149,5 +194,6 @@ if __name__ == "__main__":
     make_matmul()
     make_fixture_matrix()
     make_oracle_outputs()
+    make_keras_stacks()
     make_gru()
     print("golden fixtures written")

@@ -190,3 +190,14 @@ def test_wavenet_wider_than_16_channels_matches_oracle(na, loader, channels, hea
     m2 = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam")
     y2 = np.concatenate([m2.Process(x[i:i + 37]) for i in range(0, x.size, 37)])
     assert np.max(np.abs(y2 - y)) < 1e-6
+
+
+def test_generic_keras_stack_files_match_committed_torch_vectors(na, loader):
+    """HIP path vs an INDEPENDENT implementation: tests/golden/keras_stacks_torch.npz holds torch.nn.LSTM / GRU / Linear outputs for three
+    committed synthetic keras stacks (RTNeural is absent: parity unpinned)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keras_stacks_torch.npz"))
+    for name in [k for k in g.files if k != "input"]:
+        m = loader.CreateFromFile(_model_path("synthetic_stack_%s.json" % name))
+        assert m is not None, name
+        y = m.Process(g["input"])
+        assert O.rms(y - g[name]) < 5e-6, (name, O.rms(y - g[name]))

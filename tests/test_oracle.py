@@ -287,3 +287,20 @@ def test_oracle_matches_committed_fixture_matrix():
             y = O.oracle_from_file(name, quality=q).process(g["input/" + k])
             assert O.rms(y - g["oracle/%s/%s" % (tag, k)]) < 2e-7, (tag, k)
             assert O.rms(y - g["np64/%s/%s" % (tag, k)]) < (5e-6 if tag.startswith("lstm") else 1e-6), (tag, k)
+
+
+def test_generic_keras_stack_restatement_matches_committed_torch_vectors():
+    """tests/ref_np.keras_stack_forward (the checker of the generic keras stacks) against an independent implementation:
+    torch.nn.LSTM / GRU / Linear outputs committed by tests/golden/make_golden.py (RTNeural, which evaluates these in the reference, is
+    an absent submodule: parity unpinned)."""
+    import json
+    import ref_np as R
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d = np.load(os.path.join(here, "keras_stacks_torch.npz"))
+    names = [k for k in d.files if k != "input"]
+    assert len(names) == 3
+    for name in names:
+        with open(os.path.join(here, "models", "synthetic_stack_%s.json" % name)) as f:
+            j = json.load(f)
+        y = R.keras_stack_forward(j, d["input"])
+        assert O.rms(y - d[name]) < 1e-6, (name, O.rms(y - d[name]))
