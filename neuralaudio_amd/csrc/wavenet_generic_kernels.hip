@@ -8,9 +8,12 @@
 // WaveNet.h:700-719) and keeps the frame kernel's stream-state format (f32 quads, tile layout), so prewarm / reset are shared.
 //
 //   workgroup = one stream, thread = one frame of the 128-frame block;
-//   LDS: x[C][128] layer input (updated in place), z[C][128] activations / scratch, head[C][128] head accumulator;
-//   dilated taps of in-block frames read x from LDS, frames before the block start from the layer's HBM ring (element loads);
-//   a layer = publish x to its ring -> conv + activation into z, head += z -> barrier -> 1x1 + residual into x -> barrier.
+//   LDS: x[C][128] layer input (updated in place), z[C][128] accumulators / activations, head[C][128] head accumulator, t[C][128] the
+//   tap being accumulated, and a [C][C] weight buffer (one tap's matrix, then the 1x1: the inner loops read four weights per
+//   broadcast ds_read_b128 instead of a scalar load per term);
+//   a layer = publish x to its ring -> per tap: stage its weight matrix, gather the tap's input column of every frame once (LDS for
+//   in-block frames, the layer's HBM ring for earlier ones), accumulate all outputs -> activation, head += z -> 1x1 + residual into x.
+#include <algorithm>
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
@@ -23,6 +26,7 @@ namespace na
 	namespace gn
 	{
 		constexpr int FRAMES = WN_MAX_FRAMES;
+		typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 		// Activation.h:83-91
 		__device__ __forceinline__ float FastTanh(float x)
@@ -69,6 +73,8 @@ namespace na
 			float* x = lds;                  // [C][FRAMES]
 			float* z = x + (size_t)C * FRAMES;
 			float* head = z + (size_t)C * FRAMES;
+			float* t = head + (size_t)C * FRAMES;  // [C][FRAMES]: the tap being accumulated, gathered per frame
+			float* wl = t + (size_t)C * FRAMES;    // [C * C]: one tap's weight matrix / the 1x1 matrix
 			const int f = threadIdx.x;
 			const int sidx = blockIdx.x;
 			const int slot = a.slots ? a.slots[sidx] : a.slot0 + sidx;
@@ -113,37 +119,73 @@ namespace na
 						if (f < n && f >= n - (R - FRAMES))
 							for (int c = 0; c < cin; c++) st[RingElem(roff, G, p, c)] = x[c * FRAMES + f];
 					}
-					__syncthreads(); // every thread's x (this block's layer input) is complete
-
-					// dilated conv + bias + mix-in (:139-290, :288-289, :471), activation (:473-480), head accumulate (:482)
+					// dilated conv + bias + mix-in (:139-290, :288-289, :471), tap by tap: the tap's weight matrix goes to LDS ([out][in], from
+					// [(o cin + c) K + k]), every thread gathers the tap's input column of ITS frame once (LDS for in-block frames, the ring
+					// for earlier ones) into t, then accumulates all outputs in its own column of z
+					const int K = L.ksize;
+					for (int o = 0; o < cin; o++) z[o * FRAMES + f] = w[L.bconv + o] + w[L.wmix + o] * cond;
+					for (int k = 0; k < K; k++)
+					{
+						__syncthreads(); // k == 0: every thread's x is complete; k > 0: the previous tap's weights are no longer read
+						for (int i = f; i < cin * cin; i += FRAMES) wl[i] = w[L.wconv + (size_t)i * K + k];
+						const int off = f - L.dilation * (K - 1 - k); // tap k reads the frame d (K-1-k) back
+						if (off >= 0)
+							for (int c = 0; c < cin; c++) t[c * FRAMES + f] = x[c * FRAMES + off];
+						else
+						{
+							int p = pos0 + off; // off >= -(R - FRAMES): one wrap
+							if (p < 0) p += R;
+							for (int c = 0; c < cin; c++) t[c * FRAMES + f] = st[RingElem(roff, G, p, c)];
+						}
+						__syncthreads(); // the tap's weights are staged (t is read by its own thread only)
+						for (int o = 0; o < cin; o++)
+						{
+							const float* wr = wl + o * cin;
+							float acc = z[o * FRAMES + f];
+							int c = 0;
+							if ((cin & 3) == 0) // rows of the weight buffer are 16-byte aligned: four weights per (broadcast) LDS read
+								for (; c < cin; c += 4)
+								{
+									const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + c);
+									acc = __builtin_fmaf(w4.x, t[c * FRAMES + f], acc);
+									acc = __builtin_fmaf(w4.y, t[(c + 1) * FRAMES + f], acc);
+									acc = __builtin_fmaf(w4.z, t[(c + 2) * FRAMES + f], acc);
+									acc = __builtin_fmaf(w4.w, t[(c + 3) * FRAMES + f], acc);
+								}
+							for (; c < cin; c++) acc = __builtin_fmaf(wr[c], t[c * FRAMES + f], acc);
+							z[o * FRAMES + f] = acc;
+						}
+					}
+					// activation (:473-480), head accumulate (:482)
 					for (int o = 0; o < cin; o++)
 					{
-						float acc = w[L.bconv + o] + w[L.wmix + o] * cond;
-						for (int k = 0; k < L.ksize; k++)
-						{
-							const int off = f - L.dilation * (L.ksize - 1 - k); // tap k reads the frame d (K-1-k) back
-							const float* wk = w + L.wconv + (size_t)o * cin * L.ksize + k;
-							if (off >= 0)
-								for (int c = 0; c < cin; c++) acc += wk[(size_t)c * L.ksize] * x[c * FRAMES + off];
-							else
-							{
-								int p = pos0 + off; // off >= -(R - FRAMES): one wrap
-								if (p < 0) p += R;
-								for (int c = 0; c < cin; c++) acc += wk[(size_t)c * L.ksize] * st[RingElem(roff, G, p, c)];
-							}
-						}
-						const float zv = Activate(acc, L.act);
+						const float zv = Activate(z[o * FRAMES + f], L.act);
 						z[o * FRAMES + f] = zv;
 						head[o * FRAMES + f] += zv;
 					}
-					__syncthreads(); // all taps read: x may be overwritten
-					// 1x1 + bias + residual (:486-491); the last layer's output feeds the next array's rechannel (or nothing)
+					__syncthreads(); // every tap gathered: x may be overwritten; the weight buffer is free
+					// 1x1 matrix -> LDS (natural [out][in]); 1x1 + bias + residual (:486-491); the last layer's output feeds the next array's
+					// rechannel (or nothing)
+					for (int i = f; i < cin * cin; i += FRAMES) wl[i] = w[L.w1 + i];
+					__syncthreads();
 					for (int o = 0; o < cin; o++)
 					{
+						const float* wr = wl + o * cin;
 						float y = w[L.b1 + o] + x[o * FRAMES + f];
-						for (int c = 0; c < cin; c++) y += w[L.w1 + o * cin + c] * z[c * FRAMES + f];
+						int c = 0;
+						if ((cin & 3) == 0)
+							for (; c < cin; c += 4)
+							{
+								const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + c);
+								y = __builtin_fmaf(w4.x, z[c * FRAMES + f], y);
+								y = __builtin_fmaf(w4.y, z[(c + 1) * FRAMES + f], y);
+								y = __builtin_fmaf(w4.z, z[(c + 2) * FRAMES + f], y);
+								y = __builtin_fmaf(w4.w, z[(c + 3) * FRAMES + f], y);
+							}
+						for (; c < cin; c++) y = __builtin_fmaf(wr[c], z[c * FRAMES + f], y);
 						x[o * FRAMES + f] = y;
 					}
+					__syncthreads(); // the weight buffer is rewritten by the next layer's staging
 					// (own-frame accesses only from here to the next publish: no barrier)
 				}
 				else
@@ -200,7 +242,8 @@ namespace na
 		a.rows = rows;
 		a.slot0 = slot0;
 		a.row0 = row0;
-		const size_t ldsBytes = (size_t)3 * maxChannels * gn::FRAMES * sizeof(float);
+		// LDS: four [C][128] float arrays + one [C][C] weight matrix (C = 64: 144 KB)
+		const size_t ldsBytes = ((size_t)4 * maxChannels * gn::FRAMES + (size_t)maxChannels * maxChannels) * sizeof(float);
 		static bool attrSet = false;
 		if (!attrSet)
 		{
