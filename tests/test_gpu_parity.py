@@ -201,3 +201,14 @@ def test_generic_keras_stack_files_match_committed_torch_vectors(na, loader):
         assert m is not None, name
         y = m.Process(g["input"])
         assert O.rms(y - g[name]) < 5e-6, (name, O.rms(y - g[name]))
+
+
+@pytest.mark.parametrize("amp", [30.0, 1000.0, 30000.0])
+def test_hot_inputs_stay_within_tolerance_on_the_f16_split_path(na, loader, amp):
+    """The f16-split kernel carries every value as f16 hi + lo parts (22 mantissa bits, f16 exponent range): inputs far outside the audio
+    range must still match the f32 oracle -- the condition enters through the aux operand, whose hi part is finite up to 65504."""
+    m = loader.CreateFromFile(_model_path("BossWN-standard.nam"))
+    x = (amp * np.sin(0.01 * np.arange(1024))).astype(np.float32)
+    y = m.Process(x)
+    yo = O.oracle_from_file("BossWN-standard.nam").process(x)
+    assert np.all(np.isfinite(y)) and O.rms(y - yo) < 5e-6 * max(1.0, O.rms(yo)), (amp, O.rms(y - yo))
