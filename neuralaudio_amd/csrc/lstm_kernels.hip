@@ -327,6 +327,136 @@ namespace na
 		return false;
 	}
 
+	// ------------------------------------------------------------------------------------------------------------
+	// The same mapping with run-time shapes: ONE WAVE PER STREAM for any hidden size up to 64 and any layer count whose weights fit
+	// the LDS -- 1x18, 3x16, 3x24, 2x40 ... (what LSTMDynamic.h:95-108 accepts; the lane = stream kernels below take these shapes
+	// too but need 6-250 ms per 128-sample block, this one 0.1-0.5 ms).  The 4H gate rows of a layer are spread over the 64 lanes
+	// (lane r owns rows r, r + 64, ...); the weights of ALL layers are copied to LDS once per block (row stride padded to an odd
+	// number of floats: lanes read different rows at the same column without bank conflicts), the state vector [x; h] is broadcast
+	// from LDS, gates are exchanged through LDS, lanes i < H own unit i.  Same arithmetic and summation order as LstmLayerStep.
+	// LDS: xin[128] | hvec[L][H] | cvec[L][H] | gates[4H] | hout[128][H + 1] | w[all layers, padded rows | bias]
+	// ------------------------------------------------------------------------------------------------------------
+	__device__ __forceinline__ int OddStride(int w) { return w | 1; }
+
+	static size_t LstmWaveRtLdsFloats(int H, int L, int n)
+	{
+		size_t f = (size_t)LSTM_MAX_FRAMES + (size_t)2 * L * H + (size_t)4 * H + (size_t)n * (H + 1);
+		for (int l = 0; l < L; l++) f += (size_t)4 * H * (size_t)(((l == 0 ? 1 : H) + H) | 1) + (size_t)4 * H;
+		return f;
+	}
+
+	__global__ void __launch_bounds__(64) LstmWaveRtKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
+		const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
+	{
+		extern __shared__ __attribute__((aligned(16))) float lds[];
+		const int H = m.hidden, L = m.numLayers, HP = H + 1;
+		float* xin = lds;
+		float* hvec = xin + LSTM_MAX_FRAMES; // [L][H]
+		float* cvec = hvec + L * H;          // [L][H]
+		float* gates = cvec + L * H;         // [4H]
+		float* hout = gates + 4 * H;         // [n][HP]
+		float* wl = hout + (size_t)n * HP;   // per layer: [4H][stride] then bias[4H]
+
+		const int lane = threadIdx.x;
+		const int slot = slots[blockIdx.x];
+		const int row = rows[blockIdx.x];
+		const float* inRow = in + (size_t)row * inStride;
+		float* outRow = out + (size_t)row * outStride;
+
+		// weights -> LDS (global layout per layer: W row-major [4H][I + H], then bias[4H])
+		{
+			float* dst = wl;
+			for (int l = 0; l < L; l++)
+			{
+				const int W = (l == 0 ? 1 : H) + H, stride = OddStride(W);
+				const float* src = m.w + m.layerOff[l];
+				for (int i = lane; i < 4 * H * W; i += 64) dst[(i / W) * stride + (i % W)] = src[i];
+				for (int i = lane; i < 4 * H; i += 64) dst[(size_t)4 * H * stride + i] = src[(size_t)4 * H * W + i];
+				dst += (size_t)4 * H * stride + 4 * H;
+			}
+		}
+		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
+		for (int i = lane; i < L * H; i += 64)
+		{
+			const int l = i / H, k = i % H;
+			hvec[i] = state[(size_t)(l * 2 * H + k) * capacity + slot];
+			cvec[i] = state[(size_t)(l * 2 * H + H + k) * capacity + slot];
+		}
+		LstmWaveSync();
+
+		for (int f = 0; f < n; f++)
+		{
+			const float* wlay = wl;
+			for (int l = 0; l < L; l++)
+			{
+				const int I = (l == 0) ? 1 : H, W = I + H, stride = OddStride(W);
+				const float* sIn = (l == 0) ? (xin + f) : (hvec + (l - 1) * H); // LSTM.h:168 / :170-180
+				const float* sH = hvec + l * H;
+				const float* bias = wlay + (size_t)4 * H * stride;
+				for (int r = lane; r < 4 * H; r += 64)
+				{
+					const float* wr = wlay + (size_t)r * stride;
+					float acc = 0.0f;
+#pragma unroll 8
+					for (int k = 0; k < I; k++) acc += wr[k] * sIn[k];
+#pragma unroll 8
+					for (int k = 0; k < H; k++) acc += wr[I + k] * sH[k]; // (unrolled: eight LDS reads in flight instead of one round trip per term)
+					acc += bias[r];
+					// rows [2H, 3H) are the cell candidate (tanh), the others sigmoid (LSTM.h:33-36,94-99)
+					const bool isG = (r >= 2 * H) && (r < 3 * H);
+					gates[r] = isG ? LstmTanh(acc, m.math) : LstmSigmoid(acc, m.math);
+				}
+				LstmWaveSync();
+				for (int u = lane; u < H; u += 64)
+				{
+					// LSTM.h:94-99
+					const float c = (gates[H + u] * cvec[l * H + u]) + (gates[u] * gates[2 * H + u]);
+					cvec[l * H + u] = c;
+					const float h = gates[3 * H + u] * LstmTanh(c, m.math);
+					hvec[l * H + u] = h;
+					if (l == L - 1) hout[(size_t)f * HP + u] = h;
+				}
+				LstmWaveSync();
+				wlay += (size_t)4 * H * stride + 4 * H;
+			}
+		}
+
+		// dense head for the whole block, lane = sample (LSTM.h:182-189)
+		const float* headW = m.w + m.headOff;
+		for (int f = lane; f < n; f += 64)
+		{
+			float acc = 0.0f;
+			for (int k = 0; k < H; k++) acc += headW[k] * hout[(size_t)f * HP + k];
+			outRow[f] = acc + headW[H];
+		}
+		for (int i = lane; i < L * H; i += 64)
+		{
+			const int l = i / H, k = i % H;
+			state[(size_t)(l * 2 * H + k) * capacity + slot] = hvec[i];
+			state[(size_t)(l * 2 * H + H + k) * capacity + slot] = cvec[i];
+		}
+	}
+
+	// false: the shape does not fit (hidden > 64 or the weights exceed the LDS): the lane = stream kernels take it
+	static bool LaunchLstmWaveRt(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
+		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err)
+	{
+		static const bool off = getenv("NA_LSTM_NO_WAVE_RT") != nullptr; // tuning knob / tests: the lane = stream kernels for every shape
+		if (off || m.hidden > 64 || m.numLayers < 1 || m.tailLayers > 0) return false;
+		const size_t ldsBytes = LstmWaveRtLdsFloats(m.hidden, m.numLayers, n) * sizeof(float);
+		if (ldsBytes > 160 * 1024) return false;
+		static bool attrSet = false;
+		if (!attrSet)
+		{
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&LstmWaveRtKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			attrSet = true;
+		}
+		hipLaunchKernelGGL(LstmWaveRtKernel, dim3((unsigned)numStreams), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows, in, out, inStride,
+			outStride, n);
+		err = hipGetLastError();
+		return true;
+	}
+
 	// initial hidden / cell state of the listed slots (NAM: stored in the weights, LSTM.h:51-55; keras: zeros)
 	__global__ void LstmInitStateKernel(float* __restrict__ state, int capacity, const int* __restrict__ slots, int numStreams,
 		const float* __restrict__ init /* [numLayers*2H] */, int numElems)
@@ -476,6 +606,7 @@ namespace na
 			static const bool forceLaneKernel = getenv("NA_LSTM_LANE_KERNEL") != nullptr; // tuning knob
 			hipError_t err = hipSuccess;
 			if (!forceLaneKernel && LaunchLstmWave(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
+			if (!forceLaneKernel && LaunchLstmWaveRt(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
 		}
 #define NA_LSTM_CASE(HH) case HH: return LaunchH<HH>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream)
 		switch (m.hidden)
