@@ -22,6 +22,56 @@ namespace na
 		else
 			asm volatile("s_nop 1\n" NA_DPP_TERM(1, 2) NA_DPP_TERM(2, 3) NA_DPP_TERM(3, 4) NA_DPP_TERM(4, 5) NA_DPP_TERM(5, 6) NA_DPP_TERM(6, 7) NA_DPP_TERM(7, 8) NA_DPP_TERM(8, 9) NA_DPP_TERM(9, 10) NA_DPP_TERM(10, 11) NA_DPP_TERM(11, 12) NA_DPP_TERM(12, 13) NA_DPP_TERM(13, 14) NA_DPP_TERM(14, 15) NA_DPP_TERM(15, 16) : "+v"(acc) : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
 	}
+
+	// The same sum started inside the block: acc = a0 * a1 + a2, then acc += w[0] * h, then the DPP terms.  The two leading
+	// instructions are the two wait states a DPP read of `h` needs after the VALU write that produced it, so `h` may come straight
+	// from the previous instruction and no s_nop is spent -- a lone wave pays ~5 cycles for EVERY instruction it issues, s_nop and
+	// scalar ones included (tools/microbench/lone_wave_issue.hip), so the recurrence is written for instruction count.
+	template <int H>
+	__device__ __forceinline__ void DppDotFrom(float& acc, float a0, float a1, float a2, const float (&w)[H], float h)
+	{
+		static_assert(H == 8 || H == 16, "");
+		float r;
+		if constexpr (H == 8)
+			asm volatile("v_fma_f32 %0, %2, %3, %4\nv_fmac_f32 %0, %5, %1\n" NA_DPP_TERM(1, 6) NA_DPP_TERM(2, 7) NA_DPP_TERM(3, 8) NA_DPP_TERM(4, 9) NA_DPP_TERM(5, 10) NA_DPP_TERM(6, 11) NA_DPP_TERM(7, 12)
+				: "=&v"(r) : "v"(h), "v"(a0), "v"(a1), "v"(a2), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+		else
+			asm volatile("v_fma_f32 %0, %2, %3, %4\nv_fmac_f32 %0, %5, %1\n" NA_DPP_TERM(1, 6) NA_DPP_TERM(2, 7) NA_DPP_TERM(3, 8) NA_DPP_TERM(4, 9) NA_DPP_TERM(5, 10) NA_DPP_TERM(6, 11) NA_DPP_TERM(7, 12)
+				NA_DPP_TERM(8, 13) NA_DPP_TERM(9, 14) NA_DPP_TERM(10, 15) NA_DPP_TERM(11, 16) NA_DPP_TERM(12, 17) NA_DPP_TERM(13, 18) NA_DPP_TERM(14, 19) NA_DPP_TERM(15, 20)
+				: "=&v"(r) : "v"(h), "v"(a0), "v"(a1), "v"(a2), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),
+				"v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+		acc = r;
+	}
+
+	// Two-input row (layer >= 1: input vector hin, own state h): acc = w[0] * hin + b; acc += u0 * h; DPP terms of hin.  The DPP
+	// terms of h follow with DppDotTail (an asm block takes at most 30 operands).
+	template <int H>
+	__device__ __forceinline__ void DppDotFrom2(float& acc, float b, const float (&w)[H], float hin, float u0, float h)
+	{
+		static_assert(H == 8 || H == 16, "");
+		float r;
+		if constexpr (H == 8)
+			asm volatile("v_fma_f32 %0, %5, %1, %2\nv_fmac_f32 %0, %3, %4\n" NA_DPP_TERM(1, 6) NA_DPP_TERM(2, 7) NA_DPP_TERM(3, 8) NA_DPP_TERM(4, 9) NA_DPP_TERM(5, 10) NA_DPP_TERM(6, 11) NA_DPP_TERM(7, 12)
+				: "=&v"(r) : "v"(hin), "v"(b), "v"(u0), "v"(h), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+		else
+			asm volatile("v_fma_f32 %0, %5, %1, %2\nv_fmac_f32 %0, %3, %4\n" NA_DPP_TERM(1, 6) NA_DPP_TERM(2, 7) NA_DPP_TERM(3, 8) NA_DPP_TERM(4, 9) NA_DPP_TERM(5, 10) NA_DPP_TERM(6, 11) NA_DPP_TERM(7, 12)
+				NA_DPP_TERM(8, 13) NA_DPP_TERM(9, 14) NA_DPP_TERM(10, 15) NA_DPP_TERM(11, 16) NA_DPP_TERM(12, 17) NA_DPP_TERM(13, 18) NA_DPP_TERM(14, 19) NA_DPP_TERM(15, 20)
+				: "=&v"(r) : "v"(hin), "v"(b), "v"(u0), "v"(h), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),
+				"v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+		acc = r;
+	}
+
+	// acc += sum_{n >= 1} w[n] * h[lane - n]: the DPP terms only, no leading wait states -- for an `h` that was written at least two
+	// instructions earlier (the caller's responsibility: e.g. the state of a layer while another row is being summed)
+	template <int H>
+	__device__ __forceinline__ void DppDotTail(float& acc, const float (&w)[H], float h)
+	{
+		static_assert(H == 8 || H == 16, "");
+		if constexpr (H == 8)
+			asm volatile(NA_DPP_TERM(1, 2) NA_DPP_TERM(2, 3) NA_DPP_TERM(3, 4) NA_DPP_TERM(4, 5) NA_DPP_TERM(5, 6) NA_DPP_TERM(6, 7) NA_DPP_TERM(7, 8) : "+v"(acc) : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+		else
+			asm volatile(NA_DPP_TERM(1, 2) NA_DPP_TERM(2, 3) NA_DPP_TERM(3, 4) NA_DPP_TERM(4, 5) NA_DPP_TERM(5, 6) NA_DPP_TERM(6, 7) NA_DPP_TERM(7, 8) NA_DPP_TERM(8, 9) NA_DPP_TERM(9, 10) NA_DPP_TERM(10, 11) NA_DPP_TERM(11, 12) NA_DPP_TERM(12, 13) NA_DPP_TERM(13, 14) NA_DPP_TERM(14, 15) NA_DPP_TERM(15, 16) : "+v"(acc) : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+	}
 #undef NA_DPP_TERM
 
 	// gfx950 lane swaps, written as asm with both registers in-out: the builtins' second result is mis-folded by this compiler
@@ -31,6 +81,42 @@ namespace na
 	//   LaneSwap16(a, b): odd 16-lane rows of a <-> even rows of b          a = rows [a0, b0, a2, b2], b = rows [a1, b1, a3, b3]
 	__device__ __forceinline__ void LaneSwap32(int& a, int& b) { asm volatile("s_nop 1\nv_permlane32_swap_b32 %0, %1\ns_nop 1\n" : "+v"(a), "+v"(b)); }
 	__device__ __forceinline__ void LaneSwap16(int& a, int& b) { asm volatile("s_nop 1\nv_permlane16_swap_b32 %0, %1\ns_nop 1\n" : "+v"(a), "+v"(b)); }
+
+	// Every 16-lane row of v replicated into all four rows, in ONE block with the fewest instructions the hazards allow (two wait
+	// states between a VALU write and a lane swap that reads it, and between a swap and a read of its result; copies double as
+	// wait states): r0..r3 = row 0..3 of v everywhere.  v must not be read by the instruction right before (it may be written by it).
+	__device__ __forceinline__ void ReplicateRows(float v, float& r0, float& r1, float& r2, float& r3)
+	{
+		int x = __builtin_bit_cast(int, v), y, x2, y2;
+		asm volatile(
+			"v_mov_b32 %1, %0\n"
+			"s_nop 1\n"
+			"v_permlane32_swap_b32 %0, %1\n" // x: rows 0 1 0 1, y: rows 2 3 2 3
+			"s_nop 1\n"
+			"v_mov_b32 %2, %0\n"
+			"v_mov_b32 %3, %1\n"
+			"s_nop 0\n"
+			"v_permlane16_swap_b32 %0, %2\n" // x: row 0 everywhere, x2: row 1
+			"v_permlane16_swap_b32 %1, %3\n" // y: row 2, y2: row 3
+			"s_nop 1\n"
+			: "+v"(x), "=&v"(y), "=&v"(x2), "=&v"(y2));
+		r0 = __builtin_bit_cast(float, x);
+		r1 = __builtin_bit_cast(float, x2);
+		r2 = __builtin_bit_cast(float, y);
+		r3 = __builtin_bit_cast(float, y2);
+	}
+
+	// H = 8 (a row holds two gate blocks): even rows of v replicated into every row -> lo, odd rows -> hi
+	__device__ __forceinline__ void ReplicateRowPairs(float v, float& lo, float& hi)
+	{
+		int x = __builtin_bit_cast(int, v), y;
+		asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane16_swap_b32 %0, %1\ns_nop 1\n" : "+v"(x), "=&v"(y));
+		lo = __builtin_bit_cast(float, x);
+		hi = __builtin_bit_cast(float, y);
+	}
+
+	// lane p of a row <- lane (p - 8) mod 16: the other half of the row
+	__device__ __forceinline__ float OtherHalf(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); }
 
 	// H = 8: a row is [lo half | hi half]; copy one half over the other (DPP row_ror:8 with a bank mask)
 	__device__ __forceinline__ int RowLowHalf(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xC, false); }  // lanes 8..15 <- lanes 0..7

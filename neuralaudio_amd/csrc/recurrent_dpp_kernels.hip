@@ -5,6 +5,7 @@
 // Reference arithmetic: LSTMModelT/LSTMLayerT::Process (NeuralAudio/LSTM.h:164-191, 87-100), FastMath (Activation.h:83-96);
 // keras GRU = RTNeural's GRULayer (NeuralAudio/RTNeuralModel.h:300,417-421; third-party, parity unpinned -- see gru_kernels.hip).
 #include <cstdlib>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -39,57 +40,98 @@ namespace na
 		return num * __builtin_amdgcn_rcpf(den);
 	}
 
-	// All four gates of this lane's unit, from the lanes that computed them (lane = H*gate + unit), without touching LDS:
-	// gfx950 lane swaps (v_permlane32_swap: a.hi <-> b.lo; v_permlane16_swap: odd rows of a <-> even rows of b; probed on the box)
-	// replicate each 16-lane row into all four rows; for H = 8 a row holds two gates and DPP row_ror:8 with a bank mask merges halves.
-	template <int H>
-	__device__ __forceinline__ void GatherGates(float gv, float& gi, float& gf, float& gg, float& go)
+	// Gate activation with the gate's identity folded into per-lane constants (no select, no branch: a lone wave pays ~5 cycles per
+	// instruction issued, whatever it is).  FastMath (LSTM.h:33-36,94-99; Activation.h:83-96): the g row takes Tanh(x), the i / f / o
+	// rows Sigmoid(x) = 0.5 (Tanh(0.5 x) + 1).  The inner 0.5 rides in the weights of those rows (scaling by a power of two is
+	// exact: every partial sum is exactly half the reference's), the outer 0.5 in the numerator constants (same argument), so
+	// value = A tanh(y) + B is one polynomial and one fma.  StdMath (Activation.h:37-45): rcp(1 + exp2(k y)) with k = -log2 e
+	// (sigmoid) or 2 log2 e and the result mapped by 1 - 2 t (tanh).
+	template <bool STD>
+	struct GateK;
+	template <>
+	struct GateK<false>
 	{
-		int x = __builtin_bit_cast(int, gv);
-		int y = x;
-		if constexpr (H == 16)
-		{
-			LaneSwap32(x, y); // x: rows g0 g1 g0 g1, y: rows g2 g3 g2 g3
-			int x2 = x, y2 = y;
-			LaneSwap16(x, x2); // x: g0 everywhere, x2: g1 everywhere
-			LaneSwap16(y, y2);
-			gi = __builtin_bit_cast(float, x);
-			gf = __builtin_bit_cast(float, x2);
-			gg = __builtin_bit_cast(float, y);
-			go = __builtin_bit_cast(float, y2);
-		}
-		else
-		{
-			LaneSwap16(x, y); // x: every row = [g0 | g1], y: every row = [g2 | g3]
-			gi = __builtin_bit_cast(float, RowLowHalf(x));
-			gf = __builtin_bit_cast(float, RowHighHalf(x));
-			gg = __builtin_bit_cast(float, RowLowHalf(y));
-			go = __builtin_bit_cast(float, RowHighHalf(y));
-		}
-	}
+		float aA, bA, cA, B;
+	};
+	template <>
+	struct GateK<true>
+	{
+		float k, A, B;
+	};
 
-	// gate pre-activation -> (c, h) update for this lane's unit; returns the new h
-	template <int H, bool STD>
-	__device__ __forceinline__ float DppCellUpdate(float acc, int gate, int unit, float& c)
+	template <bool STD>
+	__device__ __forceinline__ GateK<STD> MakeGateK(bool isG)
 	{
-		const bool isG = gate == 2;
-		float gv;
+		GateK<STD> K;
 		if constexpr (STD)
 		{
-			gv = isG ? StdTanh(acc) : StdSigmoid(acc); // Activation.h:37-45
+			K.k = isG ? 2.885390081777927f : -1.4426950408889634f;
+			K.A = isG ? -2.0f : 1.0f;
+			K.B = isG ? 1.0f : 0.0f;
 		}
 		else
 		{
-			const float t = LstmRcpTanh(isG ? acc : acc * 0.5f);
-			gv = isG ? t : 0.5f * (t + 1.0f); // LSTM.h:33-36,94-99
+			const float A = isG ? 1.0f : 0.5f;
+			K.aA = 2.45550750702956f * A;
+			K.bA = 0.893229853513558f * A;
+			K.cA = 0.821226666969744f * A;
+			K.B = isG ? 0.0f : 0.5f;
 		}
-		float gi, gf, gg, go;
-		GatherGates<H>(gv, gi, gf, gg, go);
-		c = (gf * c) + (gi * gg);
-		return go * (STD ? StdTanh(c) : LstmRcpTanh(c));
+		return K;
 	}
 
-	// one stream (slot, row), one block of n samples; xin[128] and hout[128 * (H + 1)] are LDS scratch of this wave
+	// the factor the weights and the bias of this lane's gate row are loaded with
+	template <bool STD>
+	__device__ __forceinline__ float GateRowScale(bool isG) { return (STD || isG) ? 1.0f : 0.5f; }
+
+	template <bool STD>
+	__device__ __forceinline__ float GateAct(float y, const GateK<STD>& K)
+	{
+		if constexpr (STD) return __builtin_fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y * K.k) + 1.0f), K.A, K.B);
+		else
+		{
+			const float ay = fabsf(y);
+			const float y2 = y * y;
+			const float p = __builtin_fmaf(y2, __builtin_fmaf(ay, K.cA, K.bA), __builtin_fmaf(ay, K.aA, K.aA));
+			const float den = 2.44506634652299f + (2.44506634652299f + y2) * (ay + 0.814642734961073f * y2);
+			return __builtin_fmaf(y * p, __builtin_amdgcn_rcpf(den), K.B);
+		}
+	}
+
+	// gate pre-activation (row-scaled, see GateRowScale) -> (c, h) update for this lane's unit; returns the new h.
+	// The four gates of a unit meet through gfx950 lane swaps (v_permlane32_swap: a.hi <-> b.lo; v_permlane16_swap: odd rows of a <->
+	// even rows of b; probed on the box), no LDS.  H = 16: lane = 16 gate + unit, every row gets every gate row (ReplicateRows).
+	// H = 8: a row holds two gate blocks ([i | f] and [g | o]); the lanes of the first block compute the unit (i and g are their own,
+	// f and o sit in the other half of the row: DPP row_ror:8 inside the consuming instruction) and their h is copied over the
+	// second block's -- whose c stays undefined and is never read.
+	template <int H, bool STD>
+	__device__ __forceinline__ float DppCellUpdate(float acc, const GateK<STD>& K, float& c)
+	{
+		const float gv = GateAct<STD>(acc, K);
+		if constexpr (H == 16)
+		{
+			float gi, gf, gg, go;
+			ReplicateRows(gv, gi, gf, gg, go);
+			c = __builtin_fmaf(gf, c, gi * gg);
+			return go * (STD ? StdTanh(c) : LstmRcpTanh(c));
+		}
+		else
+		{
+			float lo, hi; // rows [i | f], rows [g | o]
+			ReplicateRowPairs(gv, lo, hi);
+			c = __builtin_fmaf(OtherHalf(lo), c, lo * hi);
+			const float h = OtherHalf(hi) * (STD ? StdTanh(c) : LstmRcpTanh(c));
+			return __builtin_bit_cast(float, RowLowHalf(__builtin_bit_cast(int, h)));
+		}
+	}
+
+	// xin: this wave's input samples in LDS, read back four at a time (xs must be 16-byte aligned where the groups start, with at
+	// least 4 readable floats past the block); hout: the h of every sample, written by EVERY lane (lanes of the same unit hold
+	// the same value and write the same word: no exec mask, no branch on the recurrence)
+	constexpr int REC_XIN_FLOATS = LSTM_MAX_FRAMES + 16;
+	constexpr int REC_HOUT_FLOATS = (LSTM_MAX_FRAMES + 2) * 18;
+
+	// one stream (slot, row), one block of n samples
 	template <int H, int L, bool STD>
 	__device__ __forceinline__ void LstmDppBodyM(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
 		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
@@ -102,14 +144,16 @@ namespace na
 		const int r = gate * H + unit; // this lane's gate row
 		const float* inRow = in + (size_t)row * inStride;
 		float* outRow = out + (size_t)row * outStride;
+		const GateK<STD> K = MakeGateK<STD>(gate == 2);
+		const float gs = GateRowScale<STD>(gate == 2);
 
 		// layer 0: W row-major [4H][1 + H], then bias[4H] (LSTM.h:42-56); h weights rotated by `unit`
 		const float* w0 = m.w + m.layerOff[0];
-		const float wx0 = w0[(size_t)r * (1 + H)];
+		const float wx0 = gs * w0[(size_t)r * (1 + H)];
 		float wh0[H];
 #pragma unroll
-		for (int k = 0; k < H; k++) wh0[k] = w0[(size_t)r * (1 + H) + 1 + ((unit - k + H) % H)]; // row_ror:k hands lane p the value of lane p-k
-		const float b0 = w0[(size_t)4 * H * (1 + H) + r];
+		for (int k = 0; k < H; k++) wh0[k] = gs * w0[(size_t)r * (1 + H) + 1 + ((unit - k + H) % H)]; // row_ror:k hands lane p the value of lane p-k
+		const float b0 = gs * w0[(size_t)4 * H * (1 + H) + r];
 		// layer 1: W [4H][H + H]: input = layer-0 h, then own h
 		float wi1[H], wh1[H];
 		float b1 = 0.0f;
@@ -119,13 +163,13 @@ namespace na
 #pragma unroll
 			for (int k = 0; k < H; k++)
 			{
-				wi1[k] = w1[(size_t)r * (2 * H) + ((unit - k + H) % H)];
-				wh1[k] = w1[(size_t)r * (2 * H) + H + ((unit - k + H) % H)];
+				wi1[k] = gs * w1[(size_t)r * (2 * H) + ((unit - k + H) % H)];
+				wh1[k] = gs * w1[(size_t)r * (2 * H) + H + ((unit - k + H) % H)];
 			}
-			b1 = w1[(size_t)4 * H * (2 * H) + r];
+			b1 = gs * w1[(size_t)4 * H * (2 * H) + r];
 		}
 
-		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
+		for (int f = lane; f < n + 4; f += 64) xin[f] = f < n ? inRow[f] : 0.0f;
 		float h[L], c[L];
 #pragma unroll
 		for (int l = 0; l < L; l++)
@@ -135,25 +179,30 @@ namespace na
 		}
 		RecurrentWaveSync();
 
-		float x = xin[0];
-		for (int f = 0; f < n; f++)
-		{
-			const float xNext = xin[(f + 1 < n) ? f + 1 : f]; // off the recurrence: fetched a step ahead
-			float acc = wx0 * x; // LSTM.h:168 -- column 0 is the input sample
-			DppDot<H>(acc, wh0, h[0]);
-			acc += b0;
-			h[0] = DppCellUpdate<H, STD>(acc, gate, unit, c[0]);
-			if (L > 1)
+		float* hw = hout + unit;
+		auto step = [&](float x, float* dst) {
+			float acc;
+			DppDotFrom<H>(acc, wx0, x, b0, wh0, h[0]); // LSTM.h:168 -- column 0 is the input sample
+			h[0] = DppCellUpdate<H, STD>(acc, K, c[0]);
+			if constexpr (L > 1)
 			{
-				float acc1 = 0.0f;
-				DppDot<H>(acc1, wi1, h[0]); // LSTM.h:170-180
-				DppDot<H>(acc1, wh1, h[L > 1 ? 1 : 0]);
-				acc1 += b1;
-				h[L > 1 ? 1 : 0] = DppCellUpdate<H, STD>(acc1, gate, unit, c[L > 1 ? 1 : 0]);
+				float acc1;
+				DppDotFrom2<H>(acc1, b1, wi1, h[0], wh1[0], h[1]); // LSTM.h:170-180
+				DppDotTail<H>(acc1, wh1, h[1]);
+				h[1] = DppCellUpdate<H, STD>(acc1, K, c[1]);
 			}
-			if (lane < H) hout[f * HP + lane] = h[L - 1];
-			x = xNext;
+			*dst = h[L - 1];
+		};
+		int f = 0;
+		for (; f + 4 <= n; f += 4)
+		{
+			const float4 xv = *reinterpret_cast<const float4*>(xin + f);
+			step(xv.x, hw + (f + 0) * HP);
+			step(xv.y, hw + (f + 1) * HP);
+			step(xv.z, hw + (f + 2) * HP);
+			step(xv.w, hw + (f + 3) * HP);
 		}
+		for (; f < n; f++) step(xin[f], hw + f * HP);
 		RecurrentWaveSync();
 
 		// dense head for the whole block, lane = sample (LSTM.h:182-189)
@@ -183,12 +232,39 @@ namespace na
 	// one cell update (the same instructions serve both halves) instead of two in sequence: the dependent chain per sample -- which is
 	// all that bounds a 1024-stream batch, one wave per SIMD -- is cut from (3 dots + 2 cell updates) to (2 dots + 1), and the two
 	// dots of the upper half accumulate separately (LSTM.h:170-180 adds them in one running sum: ~1e-7 RMS apart).  n + 1 ticks per
-	// block: the last one lets layer 1 catch up, so the saved state is the reference's at every block boundary.
+	// block: the first and the last one (layer 1 has no sample -1, layer 0 no sample n) are peeled off with their masks, so the
+	// saved state is the reference's at every block boundary.
+
+	// both dots of a tick in one block: hin = [h.lo, h.lo] (the layer input of both halves) through one v_permlane32_swap whose wait
+	// states are filled with the start of the sums; acc = wx x + b + wa . hin(rotated) + wb . h(rotated)
+	__device__ __forceinline__ float SkewTickDots(float h, float wx, float x, float b, const float (&wa)[8], const float (&wb)[8])
+	{
+		float acc, hin, tmp, acc2;
+#define NA_SK_TERM(D, S, N, OP) "v_fmac_f32_dpp %" #D ", %" #S ", %" #OP " row_ror:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+		asm volatile(
+			"v_mov_b32 %1, %4\n"
+			"v_mov_b32 %2, %4\n"
+			"v_fma_f32 %0, %5, %6, %7\n"
+			"v_mul_f32 %3, %16, %4\n"
+			"v_permlane32_swap_b32 %1, %2\n"
+			NA_SK_TERM(3, 4, 1, 17) NA_SK_TERM(3, 4, 2, 18) NA_SK_TERM(3, 4, 3, 19) NA_SK_TERM(3, 4, 4, 20) NA_SK_TERM(3, 4, 5, 21) NA_SK_TERM(3, 4, 6, 22) NA_SK_TERM(3, 4, 7, 23)
+			"v_fmac_f32 %0, %8, %1\n"
+			NA_SK_TERM(0, 1, 1, 9) NA_SK_TERM(0, 1, 2, 10) NA_SK_TERM(0, 1, 3, 11) NA_SK_TERM(0, 1, 4, 12) NA_SK_TERM(0, 1, 5, 13) NA_SK_TERM(0, 1, 6, 14) NA_SK_TERM(0, 1, 7, 15)
+			"v_add_f32 %0, %0, %3\n"
+			: "=&v"(acc), "=&v"(hin), "=&v"(tmp), "=&v"(acc2)
+			: "v"(h), "v"(wx), "v"(x), "v"(b), "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wa[4]), "v"(wa[5]), "v"(wa[6]), "v"(wa[7]), "v"(wb[0]), "v"(wb[1]),
+			"v"(wb[2]), "v"(wb[3]), "v"(wb[4]), "v"(wb[5]), "v"(wb[6]), "v"(wb[7]));
+#undef NA_SK_TERM
+		return acc;
+	}
+
 	template <bool STD>
 	__device__ __forceinline__ void LstmDppSkewBody(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
 		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
 	{
 		constexpr int H = 8, HP = H + 1;
+		constexpr int HREGION = (LSTM_MAX_FRAMES + 1) * HP; // per layer: the h after every tick
+		static_assert(2 * HREGION <= REC_HOUT_FLOATS, "");
 		const int lane = threadIdx.x;
 		const int unit = lane % H;
 		const int gate = (lane / H) & 3;
@@ -196,55 +272,71 @@ namespace na
 		const int r = gate * H + unit;
 		const float* inRow = in + (size_t)row * inStride;
 		float* outRow = out + (size_t)row * outStride;
+		const GateK<STD> K = MakeGateK<STD>(gate == 2);
+		const float gs = GateRowScale<STD>(gate == 2);
 
 		// layer 0: W row-major [4H][1 + H], bias[4H]; layer 1: W [4H][H + H] (input = layer-0 h, then own h), bias[4H] (LSTM.h:42-56).
 		// wa multiplies the layer input h (own h for layer 0), wb the own h of layer 1; rotated by `unit` for the DPP walk.
 		const float* w0 = m.w + m.layerOff[0];
 		const float* w1 = m.w + m.layerOff[1];
-		const float wx = layer == 0 ? w0[(size_t)r * (1 + H)] : 0.0f;
+		const float wx = layer == 0 ? gs * w0[(size_t)r * (1 + H)] : 0.0f;
 		float wa[H], wb[H];
 #pragma unroll
 		for (int k = 0; k < H; k++)
 		{
 			const int col = (unit - k + H) % H; // row_ror:k hands lane p the value of lane p - k
-			wa[k] = layer == 0 ? w0[(size_t)r * (1 + H) + 1 + col] : w1[(size_t)r * (2 * H) + col];
-			wb[k] = layer == 0 ? 0.0f : w1[(size_t)r * (2 * H) + H + col];
+			wa[k] = gs * (layer == 0 ? w0[(size_t)r * (1 + H) + 1 + col] : w1[(size_t)r * (2 * H) + col]);
+			wb[k] = layer == 0 ? 0.0f : gs * w1[(size_t)r * (2 * H) + H + col];
 		}
-		const float b = layer == 0 ? w0[(size_t)4 * H * (1 + H) + r] : w1[(size_t)4 * H * (2 * H) + r];
+		const float b = gs * (layer == 0 ? w0[(size_t)4 * H * (1 + H) + r] : w1[(size_t)4 * H * (2 * H) + r]);
 
-		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
+		float* xs = xin + 3; // ticks 1, 5, 9, ... start the groups of four: &xs[1] is 16-byte aligned
+		for (int f = lane; f < n + 8; f += 64) xs[f] = f < n ? inRow[f] : 0.0f;
 		float h = state[(size_t)(layer * 2 * H + unit) * capacity + slot];
 		float c = state[(size_t)(layer * 2 * H + H + unit) * capacity + slot];
 		RecurrentWaveSync();
 
-		float x = xin[0];
-		for (int t = 0; t <= n; t++)
-		{
-			const float xNext = xin[(t + 1 < n) ? t + 1 : n - 1]; // off the recurrence: fetched a tick ahead
-			// layer input: own h in the lower half, the lower half's h (= h0 of the sample layer 1 is about to process) in the upper
-			int hin = __builtin_bit_cast(int, h), tmp = hin;
-			LaneSwap32(hin, tmp); // hin = [h.lo, h.lo]
-			float acc = __builtin_fmaf(wx, x, b);
-			float acc2 = 0.0f;
-			DppDot<H>(acc, wa, __builtin_bit_cast(float, hin));
-			DppDot<H>(acc2, wb, h);
+		// after tick t the lower half holds h0(t), the upper half h1(t - 1); both are stored (region `layer`, entry t): no exec mask
+		float* hw = hout + layer * HREGION + unit;
+		auto tick = [&](auto masked, float x, int t) {
+			const float acc = SkewTickDots(h, wx, x, b, wa, wb);
 			float cn = c;
-			const float hn = DppCellUpdate<H, STD>(acc + acc2, gate, unit, cn);
-			const bool active = layer == 0 ? (t < n) : (t > 0); // layer 0 has no sample n, layer 1 no sample -1
-			h = active ? hn : h;
-			c = active ? cn : c;
-			if (t > 0 && lane >= 32 && lane < 32 + H) hout[(t - 1) * HP + (lane - 32)] = h;
-			x = xNext;
+			const float hn = DppCellUpdate<H, STD>(acc, K, cn);
+			if constexpr (decltype(masked)::value)
+			{
+				const bool active = layer == 0 ? (t < n) : (t > 0); // layer 0 has no sample n, layer 1 no sample -1
+				h = active ? hn : h;
+				c = active ? cn : c;
+			}
+			else
+			{
+				h = hn;
+				c = cn;
+			}
+			hw[t * HP] = h;
+		};
+		tick(std::true_type{}, xs[0], 0);
+		int t = 1;
+		for (; t + 4 <= n; t += 4)
+		{
+			const float4 xv = *reinterpret_cast<const float4*>(xs + t);
+			tick(std::false_type{}, xv.x, t + 0);
+			tick(std::false_type{}, xv.y, t + 1);
+			tick(std::false_type{}, xv.z, t + 2);
+			tick(std::false_type{}, xv.w, t + 3);
 		}
+		for (; t < n; t++) tick(std::false_type{}, xs[t], t);
+		tick(std::true_type{}, 0.0f, n);
 		RecurrentWaveSync();
 
-		// dense head for the whole block, lane = sample (LSTM.h:182-189)
+		// dense head for the whole block, lane = sample (LSTM.h:182-189): h1 of sample f was stored by tick f + 1
 		const float* headW = m.w + m.headOff;
+		const float* h1 = hout + HREGION;
 		for (int f = lane; f < n; f += 64)
 		{
 			float acc = 0.0f;
 #pragma unroll
-			for (int k = 0; k < H; k++) acc += headW[k] * hout[f * HP + k];
+			for (int k = 0; k < H; k++) acc += headW[k] * h1[(f + 1) * HP + k];
 			outRow[f] = acc + headW[H];
 		}
 		if (gate == 0) // lanes 0..7: layer 0, lanes 32..39: layer 1
@@ -400,8 +492,8 @@ namespace na
 	__global__ void __launch_bounds__(64) RecurrentDppKernel(const RecurrentLaunchArgs args, const float* __restrict__ in, float* __restrict__ out, long inStride,
 		long outStride, int n)
 	{
-		__shared__ float xin[LSTM_MAX_FRAMES];
-		__shared__ float hout[LSTM_MAX_FRAMES * 17];
+		__shared__ __attribute__((aligned(16))) float xin[REC_XIN_FLOATS];
+		__shared__ float hout[REC_HOUT_FLOATS];
 		int gi = 0;
 		for (int i = 1; i < args.numGroups; i++)
 			if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
