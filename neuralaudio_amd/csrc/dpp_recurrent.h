@@ -106,13 +106,36 @@ namespace na
 		r3 = __builtin_bit_cast(float, y2);
 	}
 
-	// H = 8 (a row holds two gate blocks): even rows of v replicated into every row -> lo, odd rows -> hi
-	__device__ __forceinline__ void ReplicateRowPairs(float v, float& lo, float& hi)
+	// H = 8 LSTM cell state update in one block.  A row holds two gate blocks: after the swap every row of x is [i | f] and every row
+	// of y is [g | o].  The lanes of the first block compute the unit: c' = f c + i g with i and g their own and f from the other
+	// half of the row (DPP row_ror:8).  Returns c' (defined in lanes 0..7 of every row only) and y (o for the caller).
+	__device__ __forceinline__ void LstmCellState8(float gv, float& c, float& go)
 	{
-		int x = __builtin_bit_cast(int, v), y;
-		asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane16_swap_b32 %0, %1\ns_nop 1\n" : "+v"(x), "=&v"(y));
-		lo = __builtin_bit_cast(float, x);
-		hi = __builtin_bit_cast(float, y);
+		int x = __builtin_bit_cast(int, gv), y;
+		float t, cn;
+		asm volatile(
+			"v_mov_b32 %1, %0\n"
+			"s_nop 1\n"
+			"v_permlane16_swap_b32 %0, %1\n"
+			"s_nop 1\n"
+			"v_mov_b32_dpp %2, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+			"v_mul_f32 %3, %0, %1\n"
+			"v_fmac_f32 %3, %2, %4\n"
+			: "+v"(x), "=&v"(y), "=&v"(t), "=&v"(cn) : "v"(c));
+		c = cn;
+		go = __builtin_bit_cast(float, y);
+	}
+
+	// h = o tanh(c') in the first block of every row (o from the other half of the row), then copied over the second block
+	__device__ __forceinline__ float LstmCellOut8(float go, float tanhc)
+	{
+		float h;
+		asm volatile(
+			"v_mul_f32_dpp %0, %1, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+			"s_nop 1\n"
+			"v_mov_b32_dpp %0, %0 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+			: "=&v"(h) : "v"(go), "v"(tanhc));
+		return h;
 	}
 
 	// lane p of a row <- lane (p - 8) mod 16: the other half of the row

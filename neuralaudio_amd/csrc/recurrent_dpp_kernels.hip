@@ -117,11 +117,9 @@ namespace na
 		}
 		else
 		{
-			float lo, hi; // rows [i | f], rows [g | o]
-			ReplicateRowPairs(gv, lo, hi);
-			c = __builtin_fmaf(OtherHalf(lo), c, lo * hi);
-			const float h = OtherHalf(hi) * (STD ? StdTanh(c) : LstmRcpTanh(c));
-			return __builtin_bit_cast(float, RowLowHalf(__builtin_bit_cast(int, h)));
+			float go;
+			LstmCellState8(gv, c, go);
+			return LstmCellOut8(go, STD ? StdTanh(c) : LstmRcpTanh(c));
 		}
 	}
 
@@ -179,10 +177,13 @@ namespace na
 		}
 		RecurrentWaveSync();
 
+		// The h of sample f - 1 is stored right after the first dot of sample f: an instruction between the asm block and the first
+		// use of its result saves the wait state the compiler otherwise puts there.  (Entry 0 of hout = the h the block started with.)
 		float* hw = hout + unit;
 		auto step = [&](float x, float* dst) {
 			float acc;
 			DppDotFrom<H>(acc, wx0, x, b0, wh0, h[0]); // LSTM.h:168 -- column 0 is the input sample
+			*dst = h[L - 1];
 			h[0] = DppCellUpdate<H, STD>(acc, K, c[0]);
 			if constexpr (L > 1)
 			{
@@ -191,7 +192,6 @@ namespace na
 				DppDotTail<H>(acc1, wh1, h[1]);
 				h[1] = DppCellUpdate<H, STD>(acc1, K, c[1]);
 			}
-			*dst = h[L - 1];
 		};
 		int f = 0;
 		for (; f + 4 <= n; f += 4)
@@ -203,6 +203,7 @@ namespace na
 			step(xv.w, hw + (f + 3) * HP);
 		}
 		for (; f < n; f++) step(xin[f], hw + f * HP);
+		hw[n * HP] = h[L - 1];
 		RecurrentWaveSync();
 
 		// dense head for the whole block, lane = sample (LSTM.h:182-189)
@@ -211,7 +212,7 @@ namespace na
 		{
 			float acc = 0.0f;
 #pragma unroll
-			for (int k = 0; k < H; k++) acc += headW[k] * hout[f * HP + k];
+			for (int k = 0; k < H; k++) acc += headW[k] * hout[(f + 1) * HP + k];
 			outRow[f] = acc + headW[H];
 		}
 		if (lane < H)
@@ -231,27 +232,26 @@ namespace na
 	// sample t while layer 1 processes sample t - 1, whose input h0(t - 1) it takes from the lower half with ONE lane swap.  A tick is
 	// one cell update (the same instructions serve both halves) instead of two in sequence: the dependent chain per sample -- which is
 	// all that bounds a 1024-stream batch, one wave per SIMD -- is cut from (3 dots + 2 cell updates) to (2 dots + 1), and the two
-	// dots of the upper half accumulate separately (LSTM.h:170-180 adds them in one running sum: ~1e-7 RMS apart).  n + 1 ticks per
+	// dots of the upper half run into one sum (own state first, then the input; LSTM.h:170-180 the other way round: ~1e-7 RMS apart).  n + 1 ticks per
 	// block: the first and the last one (layer 1 has no sample -1, layer 0 no sample n) are peeled off with their masks, so the
 	// saved state is the reference's at every block boundary.
 
 	// both dots of a tick in one block: hin = [h.lo, h.lo] (the layer input of both halves) through one v_permlane32_swap whose wait
-	// states are filled with the start of the sums; acc = wx x + b + wa . hin(rotated) + wb . h(rotated)
+	// states are filled with the start of the sum; acc = wx x + b + wb . h(rotated) + wa . hin(rotated), one running sum like LSTM.h:170-180
 	__device__ __forceinline__ float SkewTickDots(float h, float wx, float x, float b, const float (&wa)[8], const float (&wb)[8])
 	{
-		float acc, hin, tmp, acc2;
-#define NA_SK_TERM(D, S, N, OP) "v_fmac_f32_dpp %" #D ", %" #S ", %" #OP " row_ror:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+		float acc, hin, tmp;
+#define NA_SK_TERM(S, N, OP) "v_fmac_f32_dpp %0, %" #S ", %" #OP " row_ror:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 		asm volatile(
-			"v_mov_b32 %1, %4\n"
-			"v_mov_b32 %2, %4\n"
-			"v_fma_f32 %0, %5, %6, %7\n"
-			"v_mul_f32 %3, %16, %4\n"
+			"v_mov_b32 %1, %3\n"
+			"v_mov_b32 %2, %3\n"
+			"v_fma_f32 %0, %4, %5, %6\n"
+			"v_fmac_f32 %0, %15, %3\n"
 			"v_permlane32_swap_b32 %1, %2\n"
-			NA_SK_TERM(3, 4, 1, 17) NA_SK_TERM(3, 4, 2, 18) NA_SK_TERM(3, 4, 3, 19) NA_SK_TERM(3, 4, 4, 20) NA_SK_TERM(3, 4, 5, 21) NA_SK_TERM(3, 4, 6, 22) NA_SK_TERM(3, 4, 7, 23)
-			"v_fmac_f32 %0, %8, %1\n"
-			NA_SK_TERM(0, 1, 1, 9) NA_SK_TERM(0, 1, 2, 10) NA_SK_TERM(0, 1, 3, 11) NA_SK_TERM(0, 1, 4, 12) NA_SK_TERM(0, 1, 5, 13) NA_SK_TERM(0, 1, 6, 14) NA_SK_TERM(0, 1, 7, 15)
-			"v_add_f32 %0, %0, %3\n"
-			: "=&v"(acc), "=&v"(hin), "=&v"(tmp), "=&v"(acc2)
+			NA_SK_TERM(3, 1, 16) NA_SK_TERM(3, 2, 17) NA_SK_TERM(3, 3, 18) NA_SK_TERM(3, 4, 19) NA_SK_TERM(3, 5, 20) NA_SK_TERM(3, 6, 21) NA_SK_TERM(3, 7, 22)
+			"v_fmac_f32 %0, %7, %1\n"
+			NA_SK_TERM(1, 1, 8) NA_SK_TERM(1, 2, 9) NA_SK_TERM(1, 3, 10) NA_SK_TERM(1, 4, 11) NA_SK_TERM(1, 5, 12) NA_SK_TERM(1, 6, 13) NA_SK_TERM(1, 7, 14)
+			: "=&v"(acc), "=&v"(hin), "=&v"(tmp)
 			: "v"(h), "v"(wx), "v"(x), "v"(b), "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wa[4]), "v"(wa[5]), "v"(wa[6]), "v"(wa[7]), "v"(wb[0]), "v"(wb[1]),
 			"v"(wb[2]), "v"(wb[3]), "v"(wb[4]), "v"(wb[5]), "v"(wb[6]), "v"(wb[7]));
 #undef NA_SK_TERM
@@ -263,7 +263,7 @@ namespace na
 		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
 	{
 		constexpr int H = 8, HP = H + 1;
-		constexpr int HREGION = (LSTM_MAX_FRAMES + 1) * HP; // per layer: the h after every tick
+		constexpr int HREGION = (LSTM_MAX_FRAMES + 2) * HP; // per layer: the h before every tick and after the last
 		static_assert(2 * HREGION <= REC_HOUT_FLOATS, "");
 		const int lane = threadIdx.x;
 		const int unit = lane % H;
@@ -296,10 +296,11 @@ namespace na
 		float c = state[(size_t)(layer * 2 * H + H + unit) * capacity + slot];
 		RecurrentWaveSync();
 
-		// after tick t the lower half holds h0(t), the upper half h1(t - 1); both are stored (region `layer`, entry t): no exec mask
+		// after tick t the lower half holds h0(t), the upper half h1(t - 1); both are stored (region `layer`, entry t + 1): no exec mask
 		float* hw = hout + layer * HREGION + unit;
 		auto tick = [&](auto masked, float x, int t) {
 			const float acc = SkewTickDots(h, wx, x, b, wa, wb);
+			hw[t * HP] = h; // the state BEFORE tick t = after tick t - 1 (placed here: see LstmDppBodyM)
 			float cn = c;
 			const float hn = DppCellUpdate<H, STD>(acc, K, cn);
 			if constexpr (decltype(masked)::value)
@@ -313,7 +314,6 @@ namespace na
 				h = hn;
 				c = cn;
 			}
-			hw[t * HP] = h;
 		};
 		tick(std::true_type{}, xs[0], 0);
 		int t = 1;
@@ -327,16 +327,17 @@ namespace na
 		}
 		for (; t < n; t++) tick(std::false_type{}, xs[t], t);
 		tick(std::true_type{}, 0.0f, n);
+		hw[(n + 1) * HP] = h;
 		RecurrentWaveSync();
 
-		// dense head for the whole block, lane = sample (LSTM.h:182-189): h1 of sample f was stored by tick f + 1
+		// dense head for the whole block, lane = sample (LSTM.h:182-189): h1 of sample f = the state after tick f + 1 = entry f + 2
 		const float* headW = m.w + m.headOff;
 		const float* h1 = hout + HREGION;
 		for (int f = lane; f < n; f += 64)
 		{
 			float acc = 0.0f;
 #pragma unroll
-			for (int k = 0; k < H; k++) acc += headW[k] * h1[(f + 1) * HP + k];
+			for (int k = 0; k < H; k++) acc += headW[k] * h1[(f + 2) * HP + k];
 			outRow[f] = acc + headW[H];
 		}
 		if (gate == 0) // lanes 0..7: layer 0, lanes 32..39: layer 1
