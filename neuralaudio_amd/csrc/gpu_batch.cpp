@@ -655,10 +655,13 @@ namespace na
 				const int numActive = (int)hSlots.size();
 				if (numActive == 0) return;
 				size_t offset = 0;
+				RecurrentGroup fused;
+				const bool dpp = FusedRecurrentArgs(fused); // the LDS-free kernel, as a launch of one group (with the contiguous-streams shortcut)
 				while (n > 0)
 				{
 					const int chunk = (int)std::min<size_t>(n, (size_t)LSTM_MAX_FRAMES);
-					CheckHip(Launch(dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "recurrent kernel");
+					if (dpp) CheckHip(LaunchRecurrentDpp(&fused, 1, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "RecurrentDppKernel");
+					else CheckHip(Launch(dSlots.Get(), dRows.Get(), numActive, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "recurrent kernel");
 					offset += (size_t)chunk;
 					n -= (size_t)chunk;
 				}
@@ -672,9 +675,11 @@ namespace na
 				out.model = dev;
 				out.state = state.Get();
 				out.capacity = (int)capacity;
-				out.slots = dSlots.Get();
+				out.slots = contiguous ? nullptr : dSlots.Get();
 				out.rows = dRows.Get();
 				out.numStreams = (int)hSlots.size();
+				out.slot0 = contiguous ? hSlots[0] : 0;
+				out.row0 = contiguous ? hRows[0] : 0;
 				return out.numStreams > 0;
 			}
 

@@ -19,9 +19,10 @@ namespace na
 		LstmModelDev model;
 		float* state;
 		int capacity;
-		const int* slots;
-		const int* rows;
+		const int* slots; // nullptr: the active streams are contiguous -- stream i uses state slot slot0 + i and matrix row row0 + i
+		const int* rows;  // (saves the kernel a dependent global load before it can touch the stream's state)
 		int numStreams;
+		int slot0, row0;
 	};
 	bool RecurrentDppSupported(const LstmModelDev& m);
 	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,

@@ -368,32 +368,44 @@ namespace na
 	// lane swaps, c through one.  Each lane sums its row starting at column `unit` (different rounding order than the plain
 	// kernel; ~1e-7 RMS).
 	// ------------------------------------------------------------------------------------------------------------
+	// One GRU cell update (keras reset_after form, RTNeural GRULayer): acc = the recurrent row sum, which on the z and r rows already
+	// holds the input part as well (folded into the start of the sum: the per-lane wxA / bA below), on the c rows only b_rec + U h;
+	// aic = W x + b_in of this lane's row (used on the c rows).  sigmoid = rcp(1 + exp2(-x log2 e)), tanh = 1 - 2 rcp(exp2(2 x log2 e) + 1).
 	template <int H>
-	__device__ __forceinline__ float GruDppCell(float ai, float ah, float h)
+	__device__ __forceinline__ float GruDppCell(float acc, float aic, float h)
 	{
-		int zr = __builtin_bit_cast(int, GruSigmoid(ai + ah)); // meaningful on the z and r rows
-		int zr2 = zr;
+		const float zrv = StdSigmoid(acc); // meaningful on the z and r rows
 		float z, r;
 		if constexpr (H == 16)
 		{
-			LaneSwap32(zr, zr2); // zr: rows z r z r
-			int rr = zr;
-			LaneSwap16(zr, rr);  // zr: z everywhere, rr: r everywhere
+			int zr = __builtin_bit_cast(int, zrv), zr2, rr;
+			asm volatile(
+				"s_nop 0\n" // zrv comes straight from v_rcp_f32: one wait state before a VALU may read a transcendental's result
+				"v_mov_b32 %1, %0\n"
+				"s_nop 1\n"
+				"v_permlane32_swap_b32 %0, %1\n" // zr: rows z r z r
+				"s_nop 1\n"
+				"v_mov_b32 %2, %0\n"
+				"s_nop 1\n"
+				"v_permlane16_swap_b32 %0, %2\n" // zr: z everywhere, rr: r everywhere
+				"s_nop 1\n"
+				: "+v"(zr), "=&v"(zr2), "=&v"(rr));
 			z = __builtin_bit_cast(float, zr);
 			r = __builtin_bit_cast(float, rr);
 		}
 		else
 		{
-			LaneSwap16(zr, zr2); // zr: every row = [z | r]  (rows 0 and 2 hold it, the upper half of the wave mirrors the lower)
+			int zr = __builtin_bit_cast(int, zrv), zr2;
+			asm volatile("s_nop 0\nv_mov_b32 %1, %0\ns_nop 1\nv_permlane16_swap_b32 %0, %1\ns_nop 1\n" : "+v"(zr), "=&v"(zr2)); // zr: every row = [z | r]
 			z = __builtin_bit_cast(float, RowLowHalf(zr));
 			r = __builtin_bit_cast(float, RowHighHalf(zr));
 		}
-		int c = __builtin_bit_cast(int, GruTanh(ai + r * ah)); // meaningful on the c rows (2 and 3 for H = 16; 1 and 3 for H = 8)
-		int c2 = c;
-		if constexpr (H == 16) LaneSwap32(c, c2); // c2: rows c c c c
-		else LaneSwap16(c, c2);                   // c2: rows 1 1 3 3 = c everywhere
+		int c = __builtin_bit_cast(int, StdTanh(__builtin_fmaf(r, acc, aic))); // meaningful on the c rows (2 and 3 for H = 16; 1 and 3 for H = 8)
+		int c2;
+		if constexpr (H == 16) asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane32_swap_b32 %0, %1\ns_nop 1\n" : "+v"(c), "=&v"(c2)); // c2: rows c c c c
+		else asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane16_swap_b32 %0, %1\ns_nop 1\n" : "+v"(c), "=&v"(c2));                 // c2: rows 1 1 3 3 = c everywhere
 		const float cv = __builtin_bit_cast(float, c2);
-		return (1.0f - z) * cv + z * h;
+		return __builtin_fmaf(z, h - cv, cv); // (1 - z) c + z h
 	}
 
 	template <int H, int L>
@@ -405,17 +417,21 @@ namespace na
 		const int lane = threadIdx.x;
 		const int unit = lane % H;
 		const int gate = min((lane / H) & 3, 2); // rows z, r, c, c
+		const bool isC = gate == 2;
 		const int r = gate * H + unit;
 		const float* inRow = in + (size_t)row * inStride;
 		float* outRow = out + (size_t)row * outStride;
 
-		// layer 0: W row-major [3H][1 + H], b_in[3H], b_rec[3H]; h weights rotated so that row_ror:k pairs wh0[k] with h[(unit - k) mod H]
+		// layer 0: W row-major [3H][1 + H], b_in[3H], b_rec[3H]; h weights rotated so that row_ror:k pairs wh0[k] with h[(unit - k) mod H].
+		// z / r rows: the input part joins the recurrent sum (start wx x + (b_in + b_rec)); c rows keep it apart (the reset gate scales
+		// the recurrent part only).
 		const float* w0 = m.w + m.layerOff[0];
 		const float wx0 = w0[(size_t)r * (1 + H)];
 		float wh0[H];
 #pragma unroll
 		for (int k = 0; k < H; k++) wh0[k] = w0[(size_t)r * (1 + H) + 1 + ((unit - k + H) % H)];
 		const float bi0 = w0[(size_t)3 * H * (1 + H) + r], bh0 = w0[(size_t)3 * H * (1 + H) + 3 * H + r];
+		const float wxA0 = isC ? 0.0f : wx0, bA0 = isC ? bh0 : bi0 + bh0;
 		float wi1[H], wh1[H];
 		float bi1 = 0.0f, bh1 = 0.0f;
 		if (L > 1)
@@ -431,29 +447,39 @@ namespace na
 			bh1 = w1[(size_t)3 * H * (2 * H) + 3 * H + r];
 		}
 
-		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
+		for (int f = lane; f < n + 4; f += 64) xin[f] = f < n ? inRow[f] : 0.0f;
 		float h[L];
 #pragma unroll
 		for (int l = 0; l < L; l++) h[l] = state[(size_t)(l * 2 * H + unit) * capacity + slot];
 		RecurrentWaveSync();
 
-		float x = xin[0];
-		for (int f = 0; f < n; f++)
-		{
-			const float xNext = xin[(f + 1 < n) ? f + 1 : f]; // off the recurrence: fetched a step ahead
-			float ah = bh0;
-			DppDot<H>(ah, wh0, h[0]);
-			h[0] = GruDppCell<H>(wx0 * x + bi0, ah, h[0]);
-			if (L > 1)
+		// (stores of h: every lane, after the first dot of the NEXT sample -- see LstmDppBodyM)
+		float* hw = hout + unit;
+		auto step = [&](float x, float* dst) {
+			float acc;
+			DppDotFrom<H>(acc, wxA0, x, bA0, wh0, h[0]);
+			*dst = h[L - 1];
+			h[0] = GruDppCell<H>(acc, __builtin_fmaf(wx0, x, bi0), h[0]);
+			if constexpr (L > 1)
 			{
-				float ai1 = bi1, ah1 = bh1;
-				DppDot<H>(ai1, wi1, h[0]);
-				DppDot<H>(ah1, wh1, h[L > 1 ? 1 : 0]);
-				h[L > 1 ? 1 : 0] = GruDppCell<H>(ai1, ah1, h[L > 1 ? 1 : 0]);
+				// layer 1: the input part is a dot of its own; on the z / r rows it is added to the recurrent sum, on the c rows it is `aic`
+				float ai1, ah1;
+				DppDotFrom<H>(ai1, 0.0f, 0.0f, bi1, wi1, h[0]);
+				DppDotFrom<H>(ah1, 0.0f, 0.0f, bh1, wh1, h[1]);
+				h[1] = GruDppCell<H>(isC ? ah1 : ai1 + ah1, ai1, h[1]);
 			}
-			if (lane < H) hout[f * HP + lane] = h[L - 1];
-			x = xNext;
+		};
+		int f = 0;
+		for (; f + 4 <= n; f += 4)
+		{
+			const float4 xv = *reinterpret_cast<const float4*>(xin + f);
+			step(xv.x, hw + (f + 0) * HP);
+			step(xv.y, hw + (f + 1) * HP);
+			step(xv.z, hw + (f + 2) * HP);
+			step(xv.w, hw + (f + 3) * HP);
 		}
+		for (; f < n; f++) step(xin[f], hw + f * HP);
+		hw[n * HP] = h[L - 1];
 		RecurrentWaveSync();
 
 		const float* headW = m.w + m.headOff;
@@ -461,7 +487,7 @@ namespace na
 		{
 			float acc = 0.0f;
 #pragma unroll
-			for (int k = 0; k < H; k++) acc += headW[k] * hout[f * HP + k];
+			for (int k = 0; k < H; k++) acc += headW[k] * hout[(f + 1) * HP + k];
 			outRow[f] = acc + headW[H];
 		}
 		if (lane < H)
@@ -479,6 +505,7 @@ namespace na
 		const int* slots;
 		const int* rows;
 		int capacity, numStreams;
+		int slot0, row0; // slots == nullptr: contiguous
 		int firstBlock; // workgroups (= streams) [firstBlock, next group's firstBlock) belong to this group
 	};
 
@@ -500,8 +527,8 @@ namespace na
 			if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
 		const RecurrentGroupArgs& ga = args.g[gi];
 		const int idx = (int)blockIdx.x - ga.firstBlock;
-		const int slot = ga.slots[idx];
-		const int row = ga.rows[idx];
+		const int slot = ga.slots ? ga.slots[idx] : ga.slot0 + idx;
+		const int row = ga.slots ? ga.rows[idx] : ga.row0 + idx;
 		const int key = ga.m.cell * 100 + ga.m.hidden * 4 + ga.m.numLayers + ((ga.m.cell == LSTM_CELL_LSTM && ga.m.math == LSTM_MATH_STD) ? 1000 : 0);
 #define NA_REC_CASE(CELL, HH, LL, BODY) \
 	case (CELL) * 100 + HH * 4 + LL: BODY<HH, LL>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout); break;
@@ -554,6 +581,8 @@ namespace na
 			a.state = groups[i].state;
 			a.slots = groups[i].slots;
 			a.rows = groups[i].rows;
+			a.slot0 = groups[i].slot0;
+			a.row0 = groups[i].row0;
 			a.capacity = groups[i].capacity;
 			a.numStreams = groups[i].numStreams;
 			a.firstBlock = blocks;
