@@ -708,7 +708,7 @@ namespace na
 			const char* KernelName() const override
 			{
 				if (RecurrentDppSupported(dev)) return "RecurrentDppKernel";
-				return dev.cell == LSTM_CELL_GRU ? "GruWaveKernel / GruGenericKernel" : "LstmWaveKernel / LstmBlockKernel / LstmGenericKernel";
+				return dev.cell == LSTM_CELL_GRU ? "GruWaveKernel / RecurrentWaveRtKernel / GruGenericKernel" : "LstmWaveKernel / RecurrentWaveRtKernel / LstmBlockKernel / LstmGenericKernel";
 			}
 
 		protected:

@@ -240,7 +240,13 @@ namespace na
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > LSTM_MAX_FRAMES || !GruShapeSupported(m.hidden, m.numLayers, m.tailLayers > 0 ? m.tailWidth : 0)) return hipErrorInvalidValue;
-		if (m.tailLayers > 0) return LaunchGruGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream); // generic keras stack
+		if (m.tailLayers > 0)
+		{
+			// generic keras stack: the runtime-shaped wave kernel if the weights fit the LDS, else the lane = stream kernel
+			hipError_t err = hipSuccess;
+			if (LaunchRecurrentWaveRt(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
+			return LaunchGruGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
+		}
 		static const bool noDpp = getenv("NA_GRU_NO_DPP") != nullptr; // tuning knob: the LDS-broadcast kernel for every shape
 		if (!noDpp && RecurrentDppSupported(m))
 		{
@@ -255,6 +261,10 @@ namespace na
 		NA_GRU_CASE(16)
 		NA_GRU_CASE(20)
 #undef NA_GRU_CASE
+		{
+			hipError_t err = hipSuccess;
+			if (LaunchRecurrentWaveRt(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
+		}
 		return LaunchGruGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 	}
 }

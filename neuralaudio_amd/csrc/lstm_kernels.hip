@@ -330,32 +330,45 @@ namespace na
 	// ------------------------------------------------------------------------------------------------------------
 	// The same mapping with run-time shapes: ONE WAVE PER STREAM for any hidden size up to 64 and any layer count whose weights fit
 	// the LDS -- 1x18, 3x16, 3x24, 2x40 ... (what LSTMDynamic.h:95-108 accepts; the lane = stream kernels below take these shapes
-	// too but need 6-250 ms per 128-sample block, this one 0.1-0.5 ms).  The 4H gate rows of a layer are spread over the 64 lanes
-	// (lane r owns rows r, r + 64, ...); the weights of ALL layers are copied to LDS once per block (row stride padded to an odd
-	// number of floats: lanes read different rows at the same column without bank conflicts), the state vector [x; h] is broadcast
-	// from LDS, gates are exchanged through LDS, lanes i < H own unit i.  Same arithmetic and summation order as LstmLayerStep.
-	// LDS: xin[128] | hvec[L][H] | cvec[L][H] | gates[4H] | hout[128][H + 1] | w[all layers, padded rows | bias]
+	// too but need 6-250 ms per 128-sample block, this one 0.1-1 ms), LSTM or keras GRU cells (RecurrentWaveRtKernel serves
+	// gru_kernels.hip as well), with the classic 1-unit head or the dense chain of a generic keras stack (also without any recurrent
+	// layer).  The gate rows of a layer (4H / 3H) are spread over the 64 lanes (lane r owns rows r, r + 64, ...); the weights of ALL
+	// layers are copied to LDS once per block (row stride padded to an odd number of floats: lanes read different rows at the same
+	// column without bank conflicts), the state vector [x; h] is broadcast from LDS, gates are exchanged through LDS, lanes i < H own
+	// unit i.  Same arithmetic and summation order as LstmLayerStep / GruLayerStep.  The head or the dense chain runs after the
+	// recurrence for the whole block with lane = sample (no dependence between samples there): the h of the last layer is kept as
+	// [pass][k][64] (sample = 64 pass + lane), the layout DenseTail reads.
+	// LDS: xin[128] | hvec[L][H] | cvec[L][H] | gates[6H] | hseq[2][Hs][64] | tail scratch 2 x [tailWidth][64] | w[all layers: padded rows | biases]
 	// ------------------------------------------------------------------------------------------------------------
 	__device__ __forceinline__ int OddStride(int w) { return w | 1; }
 
-	static size_t LstmWaveRtLdsFloats(int H, int L, int n)
+	static size_t RecurrentWaveRtLdsFloats(const LstmModelDev& m)
 	{
-		size_t f = (size_t)LSTM_MAX_FRAMES + (size_t)2 * L * H + (size_t)4 * H + (size_t)n * (H + 1);
-		for (int l = 0; l < L; l++) f += (size_t)4 * H * (size_t)(((l == 0 ? 1 : H) + H) | 1) + (size_t)4 * H;
+		const int H = m.hidden, L = m.numLayers;
+		const int rowsPerLayer = (m.cell == LSTM_CELL_GRU ? 3 : 4) * H, biases = (m.cell == LSTM_CELL_GRU ? 6 : 4) * H;
+		size_t f = (size_t)LSTM_MAX_FRAMES + (size_t)2 * L * H + (size_t)6 * H + (size_t)2 * (L > 0 ? H : 1) * 64 +
+			(size_t)2 * (m.tailLayers > 0 ? m.tailWidth : 0) * 64;
+		for (int l = 0; l < L; l++) f += (size_t)rowsPerLayer * (size_t)(((l == 0 ? 1 : H) + H) | 1) + (size_t)biases;
 		return f;
 	}
 
-	__global__ void __launch_bounds__(64) LstmWaveRtKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
+	__global__ void __launch_bounds__(64) RecurrentWaveRtKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
 		const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
 	{
 		extern __shared__ __attribute__((aligned(16))) float lds[];
-		const int H = m.hidden, L = m.numLayers, HP = H + 1;
+		const int H = m.hidden, L = m.numLayers;
+		const bool gru = m.cell == LSTM_CELL_GRU;
+		const int G = gru ? 3 : 4;          // gate row blocks per layer
+		const int NB = gru ? 6 * H : 4 * H; // bias floats per layer
+		const int Hs = L > 0 ? H : 1;
 		float* xin = lds;
-		float* hvec = xin + LSTM_MAX_FRAMES; // [L][H]
-		float* cvec = hvec + L * H;          // [L][H]
-		float* gates = cvec + L * H;         // [4H]
-		float* hout = gates + 4 * H;         // [n][HP]
-		float* wl = hout + (size_t)n * HP;   // per layer: [4H][stride] then bias[4H]
+		float* hvec = xin + LSTM_MAX_FRAMES;   // [L][H]
+		float* cvec = hvec + L * H;            // [L][H] (LSTM)
+		float* gates = cvec + L * H;           // LSTM: [4H] activated gates; GRU: ai[3H] | ah[3H]
+		float* hseq = gates + 6 * H;           // [2][Hs][64]
+		float* tailA = hseq + (size_t)2 * Hs * 64;
+		float* tailB = tailA + (size_t)(m.tailLayers > 0 ? m.tailWidth : 0) * 64;
+		float* wl = tailB + (size_t)(m.tailLayers > 0 ? m.tailWidth : 0) * 64; // per layer: [G H][stride] then the biases
 
 		const int lane = threadIdx.x;
 		const int slot = slots[blockIdx.x];
@@ -363,16 +376,16 @@ namespace na
 		const float* inRow = in + (size_t)row * inStride;
 		float* outRow = out + (size_t)row * outStride;
 
-		// weights -> LDS (global layout per layer: W row-major [4H][I + H], then bias[4H])
+		// weights -> LDS (global layout per layer: W row-major [G H][I + H], then the biases: LSTM bias[4H]; GRU b_in[3H], b_rec[3H])
 		{
 			float* dst = wl;
 			for (int l = 0; l < L; l++)
 			{
 				const int W = (l == 0 ? 1 : H) + H, stride = OddStride(W);
 				const float* src = m.w + m.layerOff[l];
-				for (int i = lane; i < 4 * H * W; i += 64) dst[(i / W) * stride + (i % W)] = src[i];
-				for (int i = lane; i < 4 * H; i += 64) dst[(size_t)4 * H * stride + i] = src[(size_t)4 * H * W + i];
-				dst += (size_t)4 * H * stride + 4 * H;
+				for (int i = lane; i < G * H * W; i += 64) dst[(i / W) * stride + (i % W)] = src[i];
+				for (int i = lane; i < NB; i += 64) dst[(size_t)G * H * stride + i] = src[(size_t)G * H * W + i];
+				dst += (size_t)G * H * stride + NB;
 			}
 		}
 		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
@@ -380,7 +393,7 @@ namespace na
 		{
 			const int l = i / H, k = i % H;
 			hvec[i] = state[(size_t)(l * 2 * H + k) * capacity + slot];
-			cvec[i] = state[(size_t)(l * 2 * H + H + k) * capacity + slot];
+			if (!gru) cvec[i] = state[(size_t)(l * 2 * H + H + k) * capacity + slot];
 		}
 		LstmWaveSync();
 
@@ -391,67 +404,102 @@ namespace na
 			{
 				const int I = (l == 0) ? 1 : H, W = I + H, stride = OddStride(W);
 				const float* sIn = (l == 0) ? (xin + f) : (hvec + (l - 1) * H); // LSTM.h:168 / :170-180
-				const float* sH = hvec + l * H;
-				const float* bias = wlay + (size_t)4 * H * stride;
-				for (int r = lane; r < 4 * H; r += 64)
+				float* sH = hvec + l * H;
+				const float* bias = wlay + (size_t)G * H * stride;
+				if (!gru)
 				{
-					const float* wr = wlay + (size_t)r * stride;
-					float acc = 0.0f;
+					for (int r = lane; r < 4 * H; r += 64)
+					{
+						const float* wr = wlay + (size_t)r * stride;
+						float acc = 0.0f;
 #pragma unroll 8
-					for (int k = 0; k < I; k++) acc += wr[k] * sIn[k];
+						for (int k = 0; k < I; k++) acc += wr[k] * sIn[k];
 #pragma unroll 8
-					for (int k = 0; k < H; k++) acc += wr[I + k] * sH[k]; // (unrolled: eight LDS reads in flight instead of one round trip per term)
-					acc += bias[r];
-					// rows [2H, 3H) are the cell candidate (tanh), the others sigmoid (LSTM.h:33-36,94-99)
-					const bool isG = (r >= 2 * H) && (r < 3 * H);
-					gates[r] = isG ? LstmTanh(acc, m.math) : LstmSigmoid(acc, m.math);
+						for (int k = 0; k < H; k++) acc += wr[I + k] * sH[k]; // (unrolled: eight LDS reads in flight instead of one round trip per term)
+						acc += bias[r];
+						// rows [2H, 3H) are the cell candidate (tanh), the others sigmoid (LSTM.h:33-36,94-99)
+						const bool isG = (r >= 2 * H) && (r < 3 * H);
+						gates[r] = isG ? LstmTanh(acc, m.math) : LstmSigmoid(acc, m.math);
+					}
+					LstmWaveSync();
+					for (int u = lane; u < H; u += 64)
+					{
+						// LSTM.h:94-99
+						const float c = (gates[H + u] * cvec[l * H + u]) + (gates[u] * gates[2 * H + u]);
+						cvec[l * H + u] = c;
+						sH[u] = gates[3 * H + u] * LstmTanh(c, m.math);
+					}
+				}
+				else
+				{
+					// keras GRU, reset_after (gru_kernels.hip GruLayerStep): input and recurrent pre-activations kept apart
+					for (int r = lane; r < 3 * H; r += 64)
+					{
+						const float* wr = wlay + (size_t)r * stride;
+						float ai = bias[r], ah = bias[3 * H + r];
+#pragma unroll 8
+						for (int k = 0; k < I; k++) ai += wr[k] * sIn[k];
+#pragma unroll 8
+						for (int k = 0; k < H; k++) ah += wr[I + k] * sH[k];
+						gates[r] = ai;
+						gates[3 * H + r] = ah;
+					}
+					LstmWaveSync();
+					for (int u = lane; u < H; u += 64)
+					{
+						const float z = GruSigmoid(gates[u] + gates[3 * H + u]);
+						const float rr = GruSigmoid(gates[H + u] + gates[4 * H + u]);
+						const float c = GruTanh(gates[2 * H + u] + rr * gates[5 * H + u]);
+						sH[u] = (1.0f - z) * c + z * sH[u];
+					}
 				}
 				LstmWaveSync();
-				for (int u = lane; u < H; u += 64)
-				{
-					// LSTM.h:94-99
-					const float c = (gates[H + u] * cvec[l * H + u]) + (gates[u] * gates[2 * H + u]);
-					cvec[l * H + u] = c;
-					const float h = gates[3 * H + u] * LstmTanh(c, m.math);
-					hvec[l * H + u] = h;
-					if (l == L - 1) hout[(size_t)f * HP + u] = h;
-				}
-				LstmWaveSync();
-				wlay += (size_t)4 * H * stride + 4 * H;
+				wlay += (size_t)G * H * stride + NB;
 			}
+			if (L > 0)
+				for (int u = lane; u < H; u += 64) hseq[(size_t)((f >> 6) * H + u) * 64 + (f & 63)] = hvec[(L - 1) * H + u];
 		}
+		LstmWaveSync();
 
-		// dense head for the whole block, lane = sample (LSTM.h:182-189)
+		// head / dense chain for the whole block, lane = sample (LSTM.h:182-189; RTNeuralModel.h:417-421)
 		const float* headW = m.w + m.headOff;
-		for (int f = lane; f < n; f += 64)
+		for (int pass = 0; pass * 64 < n; pass++)
 		{
-			float acc = 0.0f;
-			for (int k = 0; k < H; k++) acc += headW[k] * hout[(size_t)f * HP + k];
-			outRow[f] = acc + headW[H];
+			const int f = pass * 64 + lane;
+			const float* hs = hseq + (size_t)pass * Hs * 64;
+			float y;
+			if (m.tailLayers > 0) y = DenseTail(m, L > 0 ? hs : nullptr, L > 0 ? H : 0, xin[f < n ? f : 0], tailA, tailB, lane);
+			else
+			{
+				float acc = 0.0f;
+				for (int k = 0; k < H; k++) acc += headW[k] * hs[k * 64 + lane];
+				y = acc + headW[H];
+			}
+			if (f < n) outRow[f] = y;
 		}
 		for (int i = lane; i < L * H; i += 64)
 		{
 			const int l = i / H, k = i % H;
 			state[(size_t)(l * 2 * H + k) * capacity + slot] = hvec[i];
-			state[(size_t)(l * 2 * H + H + k) * capacity + slot] = cvec[i];
+			if (!gru) state[(size_t)(l * 2 * H + H + k) * capacity + slot] = cvec[i];
 		}
 	}
 
 	// false: the shape does not fit (hidden > 64 or the weights exceed the LDS): the lane = stream kernels take it
-	static bool LaunchLstmWaveRt(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
+	bool LaunchRecurrentWaveRt(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err)
 	{
 		static const bool off = getenv("NA_LSTM_NO_WAVE_RT") != nullptr; // tuning knob / tests: the lane = stream kernels for every shape
-		if (off || m.hidden > 64 || m.numLayers < 1 || m.tailLayers > 0) return false;
-		const size_t ldsBytes = LstmWaveRtLdsFloats(m.hidden, m.numLayers, n) * sizeof(float);
+		if (off || m.hidden > 64 || m.numLayers < 0 || (m.numLayers == 0 && m.tailLayers == 0)) return false;
+		const size_t ldsBytes = RecurrentWaveRtLdsFloats(m) * sizeof(float);
 		if (ldsBytes > 160 * 1024) return false;
 		static bool attrSet = false;
 		if (!attrSet)
 		{
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&LstmWaveRtKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&RecurrentWaveRtKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			attrSet = true;
 		}
-		hipLaunchKernelGGL(LstmWaveRtKernel, dim3((unsigned)numStreams), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows, in, out, inStride,
+		hipLaunchKernelGGL(RecurrentWaveRtKernel, dim3((unsigned)numStreams), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows, in, out, inStride,
 			outStride, n);
 		err = hipGetLastError();
 		return true;
@@ -601,13 +649,13 @@ namespace na
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > LSTM_MAX_FRAMES) return hipErrorInvalidValue;
-		if (m.tailLayers > 0) return LaunchGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream); // generic keras stack
 		{
 			static const bool forceLaneKernel = getenv("NA_LSTM_LANE_KERNEL") != nullptr; // tuning knob
 			hipError_t err = hipSuccess;
-			if (!forceLaneKernel && LaunchLstmWave(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
-			if (!forceLaneKernel && LaunchLstmWaveRt(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
+			if (!forceLaneKernel && m.tailLayers == 0 && LaunchLstmWave(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
+			if (!forceLaneKernel && LaunchRecurrentWaveRt(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
 		}
+		if (m.tailLayers > 0) return LaunchGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream); // generic keras stack
 #define NA_LSTM_CASE(HH) case HH: return LaunchH<HH>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream)
 		switch (m.hidden)
 		{

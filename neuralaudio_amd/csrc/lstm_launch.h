@@ -25,6 +25,10 @@ namespace na
 		int slot0, row0;
 	};
 	bool RecurrentDppSupported(const LstmModelDev& m);
+	// The runtime-shaped one-wave-per-stream kernel (lstm_kernels.hip): LSTM or GRU cells, hidden <= 64, any layer count, classic head or
+	// dense chain, as long as the weights of all layers fit the LDS.  false: not launched (the lane = stream kernels take the model).
+	bool LaunchRecurrentWaveRt(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
+		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err);
 	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream);
 
