@@ -20,7 +20,7 @@ x = torch.clamp(0.25 * torch.randn(S, n), -1, 1).to(dev); y = torch.empty_like(x
 for _ in range(200):
     batch.ProcessDevice(x.data_ptr(), y.data_ptr(), n)
 torch.cuda.synchronize()
-nst, waves = int(os.environ.get("NA_TRACE_STAGES", "23")), int(os.environ.get("NA_TRACE_WAVES", "4"))
+nst, waves = int(os.environ.get("NA_TRACE_STAGES", "23")), int(os.environ.get("NA_TRACE_WAVES", "8"))  # waves per workgroup of the traced instantiation (SPB x WPS)
 trace = torch.zeros((nst + 1) * 8 * waves, dtype=torch.int64, device=dev)
 capi.load_library().NA_DebugSetTraceBuffer(trace.data_ptr())
 for _ in range(3):
