@@ -581,6 +581,7 @@ namespace na
 			const WeightStager<NTHREADS, GEN> stager;
 			const int lane = OpaqueLane(cx);
 			Stage sdn = LoadStage(cx.stages, s + 1);
+			SP_STAMP(0);
 			stager.Begin(cx, (s + 1) & 1, sdn);
 			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + lane;
 			u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
@@ -599,8 +600,11 @@ namespace na
 				Publish(cx, imgNext, SplitQuad(x), f, cg, live && cg < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
 			}
 			cur ^= 1;
+			SP_STAMP(1); SP_STAMP(2); SP_STAMP(3);
 			stager.template End<0>(cx, (s + 1) & 1, sdn);
+			SP_STAMP(4);
 			BlockBarrier<NTHREADS / 64>();
+			SP_STAMP(5);
 			sd = sdn;
 			s++;
 		}
@@ -615,6 +619,7 @@ namespace na
 			const WeightStager<NTHREADS, GEN> stager;
 			const int lane = OpaqueLane(cx);
 			Stage sdn = LoadStage(cx.stages, s + 1);
+			SP_STAMP(0);
 			stager.Begin(cx, (s + 1) & 1, sdn);
 			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + lane;
 			u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
@@ -667,8 +672,11 @@ namespace na
 				Publish(cx, imgNext, SplitQuad(xn[i]), fn[i], cgn[i], liven[i] && cgn[i] < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
 			}
 			cur ^= 1;
+			SP_STAMP(1); SP_STAMP(2); SP_STAMP(3);
 			stager.template End<0>(cx, (s + 1) & 1, sdn);
+			SP_STAMP(4);
 			BlockBarrier<NTHREADS / 64>();
+			SP_STAMP(5);
 			sd = sdn;
 			s++;
 		}
