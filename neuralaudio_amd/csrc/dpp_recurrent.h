@@ -1,4 +1,4 @@
-// dpp_recurrent.h -- cross-lane building blocks of the LDS-free recurrent kernels (LstmDppKernel, GruDppKernel) on gfx950.
+// dpp_recurrent.h -- cross-lane building blocks of the LDS-free recurrent kernel (RecurrentDppKernel: LSTM and keras GRU bodies) on gfx950.
 //
 // Layout they assume: lane = H * gate + unit with H = 8 or 16, so a 16-lane DPP row holds the H units once (H = 16) or twice
 // (H = 8), and every lane keeps h[unit] (replicated across the gate rows).
@@ -8,22 +8,11 @@
 
 namespace na
 {
-	// acc += sum_n w[n] * h[lane - n within its 16-lane row]: v_fmac_f32 with a DPP row_ror:n source, one instruction per term.
-	// (Written as asm: the compiler keeps a separate v_mov_b32_dpp per term otherwise.  The leading s_nop covers the VALU-write ->
-	// DPP-read hazard on h, which the hazard recognizer cannot see inside an asm block.)
+	// Row sums: acc += sum_n w[n] * h[lane - n within its 16-lane row]: v_fmac_f32 with a DPP row_ror:n source, one instruction per term.
+	// (Written as asm: the compiler keeps a separate v_mov_b32_dpp per term otherwise.  A DPP read of a VGPR needs two wait states
+	// after the VALU write that produced it, which the hazard recognizer cannot see inside an asm block: see the variants below.)
 #define NA_DPP_TERM(N, OP) "v_fmac_f32_dpp %0, %1, %" #OP " row_ror:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-	template <int H>
-	__device__ __forceinline__ void DppDot(float& acc, const float (&w)[H], float h)
-	{
-		static_assert(H == 8 || H == 16, "");
-		acc = __builtin_fmaf(w[0], h, acc);
-		if constexpr (H == 8)
-			asm volatile("s_nop 1\n" NA_DPP_TERM(1, 2) NA_DPP_TERM(2, 3) NA_DPP_TERM(3, 4) NA_DPP_TERM(4, 5) NA_DPP_TERM(5, 6) NA_DPP_TERM(6, 7) NA_DPP_TERM(7, 8) : "+v"(acc) : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
-		else
-			asm volatile("s_nop 1\n" NA_DPP_TERM(1, 2) NA_DPP_TERM(2, 3) NA_DPP_TERM(3, 4) NA_DPP_TERM(4, 5) NA_DPP_TERM(5, 6) NA_DPP_TERM(6, 7) NA_DPP_TERM(7, 8) NA_DPP_TERM(8, 9) NA_DPP_TERM(9, 10) NA_DPP_TERM(10, 11) NA_DPP_TERM(11, 12) NA_DPP_TERM(12, 13) NA_DPP_TERM(13, 14) NA_DPP_TERM(14, 15) NA_DPP_TERM(15, 16) : "+v"(acc) : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
-	}
-
-	// The same sum started inside the block: acc = a0 * a1 + a2, then acc += w[0] * h, then the DPP terms.  The two leading
+	// The sum started inside the block: acc = a0 * a1 + a2, then acc += w[0] * h, then the DPP terms.  The two leading
 	// instructions are the two wait states a DPP read of `h` needs after the VALU write that produced it, so `h` may come straight
 	// from the previous instruction and no s_nop is spent -- a lone wave pays ~5 cycles for EVERY instruction it issues, s_nop and
 	// scalar ones included (tools/microbench/lone_wave_issue.hip), so the recurrence is written for instruction count.
@@ -75,12 +64,10 @@ namespace na
 #undef NA_DPP_TERM
 
 	// gfx950 lane swaps, written as asm with both registers in-out: the builtins' second result is mis-folded by this compiler
-	// (ROCm 7.2) when both operands derive from one value (tools/microbench/permlane_probe2.hip stores a[0] twice).  The s_nops
-	// cover VALU write -> permlane read (2 wait states); the hazard recognizer does not look inside asm.
-	//   LaneSwap32(a, b): a.lanes[32..63] <-> b.lanes[0..31]              a = [a.lo, b.lo], b = [a.hi, b.hi]
-	//   LaneSwap16(a, b): odd 16-lane rows of a <-> even rows of b          a = rows [a0, b0, a2, b2], b = rows [a1, b1, a3, b3]
-	__device__ __forceinline__ void LaneSwap32(int& a, int& b) { asm volatile("s_nop 1\nv_permlane32_swap_b32 %0, %1\ns_nop 1\n" : "+v"(a), "+v"(b)); }
-	__device__ __forceinline__ void LaneSwap16(int& a, int& b) { asm volatile("s_nop 1\nv_permlane16_swap_b32 %0, %1\ns_nop 1\n" : "+v"(a), "+v"(b)); }
+	// (ROCm 7.2) when both operands derive from one value (tools/microbench/permlane_probe2.hip stores a[0] twice).  s_nops (or
+	// useful instructions) cover VALU write -> permlane read (2 wait states); the hazard recognizer does not look inside asm.
+	//   v_permlane32_swap a, b: a.lanes[32..63] <-> b.lanes[0..31]        a = [a.lo, b.lo], b = [a.hi, b.hi]
+	//   v_permlane16_swap a, b: odd 16-lane rows of a <-> even rows of b    a = rows [a0, b0, a2, b2], b = rows [a1, b1, a3, b3]
 
 	// Every 16-lane row of v replicated into all four rows, in ONE block with the fewest instructions the hazards allow (two wait
 	// states between a VALU write and a lane swap that reads it, and between a swap and a read of its result; copies double as
@@ -138,8 +125,6 @@ namespace na
 		return h;
 	}
 
-	// lane p of a row <- lane (p - 8) mod 16: the other half of the row
-	__device__ __forceinline__ float OtherHalf(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); }
 
 	// H = 8: a row is [lo half | hi half]; copy one half over the other (DPP row_ror:8 with a bank mask)
 	__device__ __forceinline__ int RowLowHalf(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xC, false); }  // lanes 8..15 <- lanes 0..7
