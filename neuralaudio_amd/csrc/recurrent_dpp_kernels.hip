@@ -362,7 +362,7 @@ namespace na
 	}
 
 	// ------------------------------------------------------------------------------------------------------------
-	// H = 8 / 16: nothing on the recurrence touches LDS (same idea as LstmDppKernel).  lane = H*gate + unit with gate rows z, r, c
+	// H = 8 / 16: nothing on the recurrence touches LDS (same idea as the LSTM bodies above).  lane = H*gate + unit with gate rows z, r, c
 	// and the fourth row duplicating c (for H = 8 the upper 32 lanes mirror the lower 32); every lane keeps h[unit].  The mat-vec
 	// reads h[(unit - n) mod H] with DPP row_ror:n against weights rotated at load time; z and r reach every lane through two
 	// lane swaps, c through one.  Each lane sums its row starting at column `unit` (different rounding order than the plain
