@@ -139,7 +139,13 @@ namespace na
 		const int lane = threadIdx.x;
 		const int unit = lane % H;
 		const int gate = (lane / H) & 3;
-		const int r = gate * H + unit; // this lane's gate row
+		// H is the lane layout (8 or 16 units per gate block); the model's hidden size hr may be smaller (12 on the 16 layout, 4 .. 7 on
+		// the 8 layout): the surplus units carry zero weights, zero bias and zero state, so their gates stay sigmoid(0) / tanh(0), their
+		// c and h stay exactly 0 and they add nothing to anyone's row sum.
+		const int hr = m.hidden;
+		const bool real = unit < hr;
+		const int r = gate * hr + unit; // this lane's gate row in the model's tensors
+		auto col = [&](int k) { return (unit - k + H) % H; }; // row_ror:k hands lane p the value of lane p - k
 		const float* inRow = in + (size_t)row * inStride;
 		float* outRow = out + (size_t)row * outStride;
 		const GateK<STD> K = MakeGateK<STD>(gate == 2);
@@ -147,11 +153,11 @@ namespace na
 
 		// layer 0: W row-major [4H][1 + H], then bias[4H] (LSTM.h:42-56); h weights rotated by `unit`
 		const float* w0 = m.w + m.layerOff[0];
-		const float wx0 = gs * w0[(size_t)r * (1 + H)];
+		const float wx0 = real ? gs * w0[(size_t)r * (1 + hr)] : 0.0f;
 		float wh0[H];
 #pragma unroll
-		for (int k = 0; k < H; k++) wh0[k] = gs * w0[(size_t)r * (1 + H) + 1 + ((unit - k + H) % H)]; // row_ror:k hands lane p the value of lane p-k
-		const float b0 = gs * w0[(size_t)4 * H * (1 + H) + r];
+		for (int k = 0; k < H; k++) wh0[k] = (real && col(k) < hr) ? gs * w0[(size_t)r * (1 + hr) + 1 + col(k)] : 0.0f;
+		const float b0 = real ? gs * w0[(size_t)4 * hr * (1 + hr) + r] : 0.0f;
 		// layer 1: W [4H][H + H]: input = layer-0 h, then own h
 		float wi1[H], wh1[H];
 		float b1 = 0.0f;
@@ -161,10 +167,11 @@ namespace na
 #pragma unroll
 			for (int k = 0; k < H; k++)
 			{
-				wi1[k] = gs * w1[(size_t)r * (2 * H) + ((unit - k + H) % H)];
-				wh1[k] = gs * w1[(size_t)r * (2 * H) + H + ((unit - k + H) % H)];
+				const bool on = real && col(k) < hr;
+				wi1[k] = on ? gs * w1[(size_t)r * (2 * hr) + col(k)] : 0.0f;
+				wh1[k] = on ? gs * w1[(size_t)r * (2 * hr) + hr + col(k)] : 0.0f;
 			}
-			b1 = gs * w1[(size_t)4 * H * (2 * H) + r];
+			b1 = real ? gs * w1[(size_t)4 * hr * (2 * hr) + r] : 0.0f;
 		}
 
 		for (int f = lane; f < n + 4; f += 64) xin[f] = f < n ? inRow[f] : 0.0f;
@@ -172,8 +179,8 @@ namespace na
 #pragma unroll
 		for (int l = 0; l < L; l++)
 		{
-			h[l] = state[(size_t)(l * 2 * H + unit) * capacity + slot];
-			c[l] = state[(size_t)(l * 2 * H + H + unit) * capacity + slot];
+			h[l] = real ? state[(size_t)(l * 2 * hr + unit) * capacity + slot] : 0.0f;
+			c[l] = real ? state[(size_t)(l * 2 * hr + hr + unit) * capacity + slot] : 0.0f;
 		}
 		RecurrentWaveSync();
 
@@ -212,16 +219,16 @@ namespace na
 		{
 			float acc = 0.0f;
 #pragma unroll
-			for (int k = 0; k < H; k++) acc += headW[k] * hout[(f + 1) * HP + k];
-			outRow[f] = acc + headW[H];
+			for (int k = 0; k < H; k++) acc += (k < hr ? headW[k] : 0.0f) * hout[(f + 1) * HP + k];
+			outRow[f] = acc + headW[hr];
 		}
-		if (lane < H)
+		if (lane < hr)
 		{
 #pragma unroll
 			for (int l = 0; l < L; l++)
 			{
-				state[(size_t)(l * 2 * H + lane) * capacity + slot] = h[l];
-				state[(size_t)(l * 2 * H + H + lane) * capacity + slot] = c[l];
+				state[(size_t)(l * 2 * hr + lane) * capacity + slot] = h[l];
+				state[(size_t)(l * 2 * hr + hr + lane) * capacity + slot] = c[l];
 			}
 		}
 	}
@@ -269,7 +276,9 @@ namespace na
 		const int unit = lane % H;
 		const int gate = (lane / H) & 3;
 		const int layer = lane >> 5; // 0: lanes 0..31, 1: lanes 32..63
-		const int r = gate * H + unit;
+		const int hr = m.hidden; // <= 8: surplus units carry zero weights and zero state (see LstmDppBodyM)
+		const bool real = unit < hr;
+		const int r = gate * hr + unit;
 		const float* inRow = in + (size_t)row * inStride;
 		float* outRow = out + (size_t)row * outStride;
 		const GateK<STD> K = MakeGateK<STD>(gate == 2);
@@ -279,21 +288,22 @@ namespace na
 		// wa multiplies the layer input h (own h for layer 0), wb the own h of layer 1; rotated by `unit` for the DPP walk.
 		const float* w0 = m.w + m.layerOff[0];
 		const float* w1 = m.w + m.layerOff[1];
-		const float wx = layer == 0 ? gs * w0[(size_t)r * (1 + H)] : 0.0f;
+		const float wx = (layer == 0 && real) ? gs * w0[(size_t)r * (1 + hr)] : 0.0f;
 		float wa[H], wb[H];
 #pragma unroll
 		for (int k = 0; k < H; k++)
 		{
 			const int col = (unit - k + H) % H; // row_ror:k hands lane p the value of lane p - k
-			wa[k] = gs * (layer == 0 ? w0[(size_t)r * (1 + H) + 1 + col] : w1[(size_t)r * (2 * H) + col]);
-			wb[k] = layer == 0 ? 0.0f : gs * w1[(size_t)r * (2 * H) + H + col];
+			const bool on = real && col < hr;
+			wa[k] = on ? gs * (layer == 0 ? w0[(size_t)r * (1 + hr) + 1 + col] : w1[(size_t)r * (2 * hr) + col]) : 0.0f;
+			wb[k] = (layer == 0 || !on) ? 0.0f : gs * w1[(size_t)r * (2 * hr) + hr + col];
 		}
-		const float b = gs * (layer == 0 ? w0[(size_t)4 * H * (1 + H) + r] : w1[(size_t)4 * H * (2 * H) + r]);
+		const float b = real ? gs * (layer == 0 ? w0[(size_t)4 * hr * (1 + hr) + r] : w1[(size_t)4 * hr * (2 * hr) + r]) : 0.0f;
 
 		float* xs = xin + 3; // ticks 1, 5, 9, ... start the groups of four: &xs[1] is 16-byte aligned
 		for (int f = lane; f < n + 8; f += 64) xs[f] = f < n ? inRow[f] : 0.0f;
-		float h = state[(size_t)(layer * 2 * H + unit) * capacity + slot];
-		float c = state[(size_t)(layer * 2 * H + H + unit) * capacity + slot];
+		float h = real ? state[(size_t)(layer * 2 * hr + unit) * capacity + slot] : 0.0f;
+		float c = real ? state[(size_t)(layer * 2 * hr + hr + unit) * capacity + slot] : 0.0f;
 		RecurrentWaveSync();
 
 		// after tick t the lower half holds h0(t), the upper half h1(t - 1); both are stored (region `layer`, entry t + 1): no exec mask
@@ -337,13 +347,13 @@ namespace na
 		{
 			float acc = 0.0f;
 #pragma unroll
-			for (int k = 0; k < H; k++) acc += headW[k] * h1[(f + 2) * HP + k];
-			outRow[f] = acc + headW[H];
+			for (int k = 0; k < H; k++) acc += (k < hr ? headW[k] : 0.0f) * h1[(f + 2) * HP + k];
+			outRow[f] = acc + headW[hr];
 		}
-		if (gate == 0) // lanes 0..7: layer 0, lanes 32..39: layer 1
+		if (gate == 0 && real) // lanes 0..7: layer 0, lanes 32..39: layer 1
 		{
-			state[(size_t)(layer * 2 * H + unit) * capacity + slot] = h;
-			state[(size_t)(layer * 2 * H + H + unit) * capacity + slot] = c;
+			state[(size_t)(layer * 2 * hr + unit) * capacity + slot] = h;
+			state[(size_t)(layer * 2 * hr + hr + unit) * capacity + slot] = c;
 		}
 	}
 
@@ -418,7 +428,10 @@ namespace na
 		const int unit = lane % H;
 		const int gate = min((lane / H) & 3, 2); // rows z, r, c, c
 		const bool isC = gate == 2;
-		const int r = gate * H + unit;
+		const int hr = m.hidden; // <= H: surplus units carry zero weights and zero state (z = 0.5, c = 0: h stays 0)
+		const bool real = unit < hr;
+		const int r = gate * hr + unit;
+		auto col = [&](int k) { return (unit - k + H) % H; };
 		const float* inRow = in + (size_t)row * inStride;
 		float* outRow = out + (size_t)row * outStride;
 
@@ -426,11 +439,11 @@ namespace na
 		// z / r rows: the input part joins the recurrent sum (start wx x + (b_in + b_rec)); c rows keep it apart (the reset gate scales
 		// the recurrent part only).
 		const float* w0 = m.w + m.layerOff[0];
-		const float wx0 = w0[(size_t)r * (1 + H)];
+		const float wx0 = real ? w0[(size_t)r * (1 + hr)] : 0.0f;
 		float wh0[H];
 #pragma unroll
-		for (int k = 0; k < H; k++) wh0[k] = w0[(size_t)r * (1 + H) + 1 + ((unit - k + H) % H)];
-		const float bi0 = w0[(size_t)3 * H * (1 + H) + r], bh0 = w0[(size_t)3 * H * (1 + H) + 3 * H + r];
+		for (int k = 0; k < H; k++) wh0[k] = (real && col(k) < hr) ? w0[(size_t)r * (1 + hr) + 1 + col(k)] : 0.0f;
+		const float bi0 = real ? w0[(size_t)3 * hr * (1 + hr) + r] : 0.0f, bh0 = real ? w0[(size_t)3 * hr * (1 + hr) + 3 * hr + r] : 0.0f;
 		const float wxA0 = isC ? 0.0f : wx0, bA0 = isC ? bh0 : bi0 + bh0;
 		float wi1[H], wh1[H];
 		float bi1 = 0.0f, bh1 = 0.0f;
@@ -440,17 +453,18 @@ namespace na
 #pragma unroll
 			for (int k = 0; k < H; k++)
 			{
-				wi1[k] = w1[(size_t)r * (2 * H) + ((unit - k + H) % H)];
-				wh1[k] = w1[(size_t)r * (2 * H) + H + ((unit - k + H) % H)];
+				const bool on = real && col(k) < hr;
+				wi1[k] = on ? w1[(size_t)r * (2 * hr) + col(k)] : 0.0f;
+				wh1[k] = on ? w1[(size_t)r * (2 * hr) + hr + col(k)] : 0.0f;
 			}
-			bi1 = w1[(size_t)3 * H * (2 * H) + r];
-			bh1 = w1[(size_t)3 * H * (2 * H) + 3 * H + r];
+			bi1 = real ? w1[(size_t)3 * hr * (2 * hr) + r] : 0.0f;
+			bh1 = real ? w1[(size_t)3 * hr * (2 * hr) + 3 * hr + r] : 0.0f;
 		}
 
 		for (int f = lane; f < n + 4; f += 64) xin[f] = f < n ? inRow[f] : 0.0f;
 		float h[L];
 #pragma unroll
-		for (int l = 0; l < L; l++) h[l] = state[(size_t)(l * 2 * H + unit) * capacity + slot];
+		for (int l = 0; l < L; l++) h[l] = real ? state[(size_t)(l * 2 * hr + unit) * capacity + slot] : 0.0f;
 		RecurrentWaveSync();
 
 		// (stores of h: every lane, after the first dot of the NEXT sample -- see LstmDppBodyM)
@@ -487,13 +501,13 @@ namespace na
 		{
 			float acc = 0.0f;
 #pragma unroll
-			for (int k = 0; k < H; k++) acc += headW[k] * hout[(f + 1) * HP + k];
-			outRow[f] = acc + headW[H];
+			for (int k = 0; k < H; k++) acc += (k < hr ? headW[k] : 0.0f) * hout[(f + 1) * HP + k];
+			outRow[f] = acc + headW[hr];
 		}
-		if (lane < H)
+		if (lane < hr)
 		{
 #pragma unroll
-			for (int l = 0; l < L; l++) state[(size_t)(l * 2 * H + lane) * capacity + slot] = h[l];
+			for (int l = 0; l < L; l++) state[(size_t)(l * 2 * hr + lane) * capacity + slot] = h[l];
 		}
 	}
 
@@ -529,7 +543,8 @@ namespace na
 		const int idx = (int)blockIdx.x - ga.firstBlock;
 		const int slot = ga.slots ? ga.slots[idx] : ga.slot0 + idx;
 		const int row = ga.slots ? ga.rows[idx] : ga.row0 + idx;
-		const int key = ga.m.cell * 100 + ga.m.hidden * 4 + ga.m.numLayers + ((ga.m.cell == LSTM_CELL_LSTM && ga.m.math == LSTM_MATH_STD) ? 1000 : 0);
+		const int layoutH = ga.m.hidden <= 8 ? 8 : 16; // the lane layout the hidden size is padded into
+		const int key = ga.m.cell * 100 + layoutH * 4 + ga.m.numLayers + ((ga.m.cell == LSTM_CELL_LSTM && ga.m.math == LSTM_MATH_STD) ? 1000 : 0);
 #define NA_REC_CASE(CELL, HH, LL, BODY) \
 	case (CELL) * 100 + HH * 4 + LL: BODY<HH, LL>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout); break;
 		switch (key)
@@ -559,7 +574,8 @@ namespace na
 
 	bool RecurrentDppSupported(const LstmModelDev& m)
 	{
-		return (m.hidden == 8 || m.hidden == 16) && (m.numLayers == 1 || m.numLayers == 2) && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU) &&
+		// hidden sizes below a layout (8 or 16 units per gate block) are padded into it: 12 (the reference's static 1x12 / 2x12) runs as 16
+		return m.hidden >= 1 && m.hidden <= 16 && (m.numLayers == 1 || m.numLayers == 2) && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU) &&
 			m.tailLayers == 0; // generic keras stacks run on the runtime-shaped kernels
 	}
 

@@ -62,7 +62,7 @@ def test_random_architecture_matches_oracle(na, seed):
 @pytest.mark.parametrize("hidden,layers", [(4, 1), (8, 3), (12, 2), (16, 3), (20, 1), (24, 2), (32, 1), (40, 1)])
 def test_lstm_shapes_beyond_the_official_ones(na, hidden, layers):
     """NAM LSTM files of any supported shape (the reference's dynamic LSTM path, LSTMDynamic.h): every kernel family is hit --
-    LDS-free DPP (8/16, <= 2 layers), wave-per-stream (12..32, <= 2 layers), lane-per-stream (the rest)."""
+    LDS-free DPP (hidden <= 16 padded into the 8 / 16 layouts, <= 2 layers), wave-per-stream (20..32, <= 2 layers; runtime-shaped beyond), lane-per-stream (the rest)."""
     w = O.synth_lstm_weights(layers, hidden, seed=hidden * 10 + layers)
     m = na.NeuralModelLoader().CreateFromString(O.nam_json_lstm(layers, hidden, w), ".nam", doPrewarm=True)
     assert m is not None

@@ -138,6 +138,23 @@ def test_stdmath_wavenet_matches_stdmath_oracle(na, name):
     assert O.rms(yo - yf) > 1e-5  # the two policies differ measurably (6.6e-4 on Standard / sine)
 
 
+@pytest.mark.parametrize("layers,hidden", [(1, 12), (2, 12), (1, 4), (2, 6), (1, 13), (2, 9), (1, 1)])
+@pytest.mark.parametrize("std", [False, True], ids=["fastmath", "stdmath"])
+def test_lstm_hidden_sizes_padded_into_the_dpp_layouts_match_oracle(na, layers, hidden, std):
+    """Hidden sizes below a lane layout of the LDS-free kernel (8 or 16 units per gate block) run padded: the reference's static 1x12 /
+    2x12 (NeuralModel.cpp:33,37) as 16, small ones as 8 (two layers: side by side in the wave halves)."""
+    ld = na.NeuralModelLoader()
+    if std:
+        ld.SetLSTMMathMode(na.EMathMode.StdMath)
+    w = O.synth_lstm_weights(layers, hidden, seed=300 + 10 * hidden + layers)
+    m = ld.CreateFromString(O.nam_json_lstm(layers, hidden, w), ".nam", doPrewarm=True)
+    assert m is not None
+    x = O.signal_noise(1000, 7)
+    want = O.OracleLSTM.from_nam(layers, hidden, w, math_mode=O.MATH_STD if std else O.MATH_FAST).process(x)
+    got = np.concatenate([m.Process(x[i:i + 100]) for i in range(0, x.size, 100)])
+    assert O.rms(got - want) < 5e-6, (layers, hidden, O.rms(got - want))
+
+
 @pytest.mark.parametrize("layers,hidden", [(1, 3), (1, 18), (3, 16), (2, 40), (2, 64)])
 def test_runtime_shaped_lstm_matches_oracle(na, loader, layers, hidden):
     """Hidden sizes / layer counts without a shaped kernel run on the runtime-shaped one (LSTMDynamic.h:95-108 accepts any)."""
