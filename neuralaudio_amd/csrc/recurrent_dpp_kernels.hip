@@ -22,6 +22,14 @@ namespace na
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 	}
 
+	// p[idx] where `on`, else 0 -- as an unconditional load from a clamped index plus a select: a `cond ? p[i] : 0` per weight turns the
+	// prologue into a chain of exec-masked loads (measured: +1.5 us per launch)
+	__device__ __forceinline__ float LoadIf(const float* __restrict__ p, size_t idx, bool on)
+	{
+		const float v = p[on ? idx : (size_t)0];
+		return on ? v : 0.0f;
+	}
+
 	// ------------------------------------------------------------------------------------------------------------
 	// Fastest path (H = 8 or 16): one wave per stream, NO LDS on the recurrence.
 	//   lane = H*gate + unit (gate order i,f,g,o; for H = 8 the upper 32 lanes mirror the lower 32), every lane keeps h[unit] and c[unit]
@@ -128,6 +136,7 @@ namespace na
 	// the same value and write the same word: no exec mask, no branch on the recurrence)
 	constexpr int REC_XIN_FLOATS = LSTM_MAX_FRAMES + 16;
 	constexpr int REC_HOUT_FLOATS = (LSTM_MAX_FRAMES + 2) * 18;
+	constexpr int REC_HOUT32_FLOATS = (LSTM_MAX_FRAMES + 2) * 33; // the 32-unit layout (LstmDpp32Body)
 
 	// one stream (slot, row), one block of n samples
 	template <int H, int L, bool STD>
@@ -153,11 +162,11 @@ namespace na
 
 		// layer 0: W row-major [4H][1 + H], then bias[4H] (LSTM.h:42-56); h weights rotated by `unit`
 		const float* w0 = m.w + m.layerOff[0];
-		const float wx0 = real ? gs * w0[(size_t)r * (1 + hr)] : 0.0f;
+		const float wx0 = gs * LoadIf(w0, (size_t)r * (1 + hr), real);
 		float wh0[H];
 #pragma unroll
-		for (int k = 0; k < H; k++) wh0[k] = (real && col(k) < hr) ? gs * w0[(size_t)r * (1 + hr) + 1 + col(k)] : 0.0f;
-		const float b0 = real ? gs * w0[(size_t)4 * hr * (1 + hr) + r] : 0.0f;
+		for (int k = 0; k < H; k++) wh0[k] = gs * LoadIf(w0, (size_t)r * (1 + hr) + 1 + col(k), real && col(k) < hr);
+		const float b0 = gs * LoadIf(w0, (size_t)4 * hr * (1 + hr) + r, real);
 		// layer 1: W [4H][H + H]: input = layer-0 h, then own h
 		float wi1[H], wh1[H];
 		float b1 = 0.0f;
@@ -168,10 +177,10 @@ namespace na
 			for (int k = 0; k < H; k++)
 			{
 				const bool on = real && col(k) < hr;
-				wi1[k] = on ? gs * w1[(size_t)r * (2 * hr) + col(k)] : 0.0f;
-				wh1[k] = on ? gs * w1[(size_t)r * (2 * hr) + hr + col(k)] : 0.0f;
+				wi1[k] = gs * LoadIf(w1, (size_t)r * (2 * hr) + col(k), on);
+				wh1[k] = gs * LoadIf(w1, (size_t)r * (2 * hr) + hr + col(k), on);
 			}
-			b1 = real ? gs * w1[(size_t)4 * hr * (2 * hr) + r] : 0.0f;
+			b1 = gs * LoadIf(w1, (size_t)4 * hr * (2 * hr) + r, real);
 		}
 
 		for (int f = lane; f < n + 4; f += 64) xin[f] = f < n ? inRow[f] : 0.0f;
@@ -179,8 +188,8 @@ namespace na
 #pragma unroll
 		for (int l = 0; l < L; l++)
 		{
-			h[l] = real ? state[(size_t)(l * 2 * hr + unit) * capacity + slot] : 0.0f;
-			c[l] = real ? state[(size_t)(l * 2 * hr + hr + unit) * capacity + slot] : 0.0f;
+			h[l] = LoadIf(state, (size_t)(l * 2 * hr + unit) * capacity + slot, real);
+			c[l] = LoadIf(state, (size_t)(l * 2 * hr + hr + unit) * capacity + slot, real);
 		}
 		RecurrentWaveSync();
 
@@ -219,7 +228,7 @@ namespace na
 		{
 			float acc = 0.0f;
 #pragma unroll
-			for (int k = 0; k < H; k++) acc += (k < hr ? headW[k] : 0.0f) * hout[(f + 1) * HP + k];
+			for (int k = 0; k < H; k++) acc += LoadIf(headW, (size_t)k, k < hr) * hout[(f + 1) * HP + k];
 			outRow[f] = acc + headW[hr];
 		}
 		if (lane < hr)
@@ -288,22 +297,22 @@ namespace na
 		// wa multiplies the layer input h (own h for layer 0), wb the own h of layer 1; rotated by `unit` for the DPP walk.
 		const float* w0 = m.w + m.layerOff[0];
 		const float* w1 = m.w + m.layerOff[1];
-		const float wx = (layer == 0 && real) ? gs * w0[(size_t)r * (1 + hr)] : 0.0f;
+		const float wx = gs * LoadIf(w0, (size_t)r * (1 + hr), layer == 0 && real);
 		float wa[H], wb[H];
 #pragma unroll
 		for (int k = 0; k < H; k++)
 		{
 			const int col = (unit - k + H) % H; // row_ror:k hands lane p the value of lane p - k
 			const bool on = real && col < hr;
-			wa[k] = on ? gs * (layer == 0 ? w0[(size_t)r * (1 + hr) + 1 + col] : w1[(size_t)r * (2 * hr) + col]) : 0.0f;
-			wb[k] = (layer == 0 || !on) ? 0.0f : gs * w1[(size_t)r * (2 * hr) + hr + col];
+			wa[k] = gs * LoadIf(layer == 0 ? w0 : w1, layer == 0 ? (size_t)r * (1 + hr) + 1 + col : (size_t)r * (2 * hr) + col, on);
+			wb[k] = gs * LoadIf(w1, (size_t)r * (2 * hr) + hr + col, layer == 1 && on);
 		}
-		const float b = real ? gs * (layer == 0 ? w0[(size_t)4 * hr * (1 + hr) + r] : w1[(size_t)4 * hr * (2 * hr) + r]) : 0.0f;
+		const float b = gs * LoadIf(layer == 0 ? w0 : w1, layer == 0 ? (size_t)4 * hr * (1 + hr) + r : (size_t)4 * hr * (2 * hr) + r, real);
 
 		float* xs = xin + 3; // ticks 1, 5, 9, ... start the groups of four: &xs[1] is 16-byte aligned
 		for (int f = lane; f < n + 8; f += 64) xs[f] = f < n ? inRow[f] : 0.0f;
-		float h = real ? state[(size_t)(layer * 2 * hr + unit) * capacity + slot] : 0.0f;
-		float c = real ? state[(size_t)(layer * 2 * hr + hr + unit) * capacity + slot] : 0.0f;
+		float h = LoadIf(state, (size_t)(layer * 2 * hr + unit) * capacity + slot, real);
+		float c = LoadIf(state, (size_t)(layer * 2 * hr + hr + unit) * capacity + slot, real);
 		RecurrentWaveSync();
 
 		// after tick t the lower half holds h0(t), the upper half h1(t - 1); both are stored (region `layer`, entry t + 1): no exec mask
@@ -347,13 +356,115 @@ namespace na
 		{
 			float acc = 0.0f;
 #pragma unroll
-			for (int k = 0; k < H; k++) acc += (k < hr ? headW[k] : 0.0f) * h1[(f + 2) * HP + k];
+			for (int k = 0; k < H; k++) acc += LoadIf(headW, (size_t)k, k < hr) * h1[(f + 2) * HP + k];
 			outRow[f] = acc + headW[hr];
 		}
 		if (gate == 0 && real) // lanes 0..7: layer 0, lanes 32..39: layer 1
 		{
 			state[(size_t)(layer * 2 * hr + unit) * capacity + slot] = h;
 			state[(size_t)(layer * 2 * hr + hr + unit) * capacity + slot] = c;
+		}
+	}
+
+	// One layer, hidden 17 .. 32 (the reference's static 1x24, NeuralModel.cpp:35): the 32-unit layout.  A 16-lane row still walks 16
+	// units with row_ror, so the state lives as TWO vectors replicated in every row (a = h[0..15], b = h[16..31]) and a gate row sum is two
+	// DPP walks; every lane owns unit 16 r + j (r = row & 1) and TWO gates of it: rows 0-1 (pair A) the i and g gates, rows 2-3 (pair B)
+	// f and o.  So slot 0 is a sigmoid everywhere, i g is local to pair A, f c local to pair B, their sum meets through one
+	// v_permlane32_swap, h = o tanh(c') comes out in pair B and one more swap32 + one swap16 hand both halves to every row.  ~115
+	// instructions per sample (two gates x 33 for the sums): 72.7 -> 38 us per 1024 x 128 step against the LDS-broadcast wave kernel.
+	template <bool STD>
+	__device__ __forceinline__ void LstmDpp32Body(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
+	{
+		constexpr int HP = 33;
+		const int lane = threadIdx.x;
+		const int j = lane & 15, rho = lane >> 4, r = rho & 1, pair = rho >> 1; // pair 0 = A (i, g), 1 = B (f, o)
+		const int hr = m.hidden, unit = 16 * r + j;
+		const bool real = unit < hr;
+		const float* inRow = in + (size_t)row * inStride;
+		float* outRow = out + (size_t)row * outStride;
+		const GateK<STD> K0 = MakeGateK<STD>(false), K1 = MakeGateK<STD>(pair == 0);
+		const float gs0 = GateRowScale<STD>(false), gs1 = GateRowScale<STD>(pair == 0);
+
+		// W row-major [4 hr][1 + hr], then bias[4 hr] (LSTM.h:42-56); gate blocks i, f, g, o; columns rotated for the DPP walk
+		const float* w0 = m.w + m.layerOff[0];
+		const int R0 = (0 + pair) * hr + unit, R1 = (2 + pair) * hr + unit;
+		auto colA = [&](int k) { return (j - k + 16) & 15; };
+		const float wx0 = gs0 * LoadIf(w0, (size_t)R0 * (1 + hr), real), wx1 = gs1 * LoadIf(w0, (size_t)R1 * (1 + hr), real);
+		const float b0 = gs0 * LoadIf(w0, (size_t)4 * hr * (1 + hr) + R0, real), b1 = gs1 * LoadIf(w0, (size_t)4 * hr * (1 + hr) + R1, real);
+		float wa0[16], wb0[16], wa1[16], wb1[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+		{
+			const int ca = colA(k), cb = 16 + colA(k);
+			wa0[k] = gs0 * LoadIf(w0, (size_t)R0 * (1 + hr) + 1 + ca, real);
+			wa1[k] = gs1 * LoadIf(w0, (size_t)R1 * (1 + hr) + 1 + ca, real);
+			wb0[k] = gs0 * LoadIf(w0, (size_t)R0 * (1 + hr) + 1 + cb, real && cb < hr);
+			wb1[k] = gs1 * LoadIf(w0, (size_t)R1 * (1 + hr) + 1 + cb, real && cb < hr);
+		}
+
+		for (int f = lane; f < n + 4; f += 64) xin[f] = f < n ? inRow[f] : 0.0f;
+		float a = state[(size_t)j * capacity + slot];                                      // h[j], every row
+		float b = LoadIf(state, (size_t)(16 + j) * capacity + slot, 16 + j < hr);          // h[16 + j], every row
+		float c = LoadIf(state, (size_t)(hr + unit) * capacity + slot, real);
+		RecurrentWaveSync();
+
+		float* hw = hout + unit;
+		auto step = [&](float x, float* dst) {
+			float acc0, acc1;
+			DppDotFrom<16>(acc0, wx0, x, b0, wa0, a); // LSTM.h:168 -- column 0 is the input sample
+			DppDotFrom<16>(acc1, wx1, x, b1, wa1, a);
+			*dst = r ? b : a; // the h before this sample (entry f of hout), placed here: see LstmDppBodyM
+			acc0 = __builtin_fmaf(wb0[0], b, acc0);
+			acc1 = __builtin_fmaf(wb1[0], b, acc1);
+			DppDotTail<16>(acc0, wb0, b);
+			DppDotTail<16>(acc1, wb1, b);
+			const float g0 = GateAct<STD>(acc0, K0); // i (pair A) / f (pair B)
+			const float g1 = GateAct<STD>(acc1, K1); // g / o
+			// i g in pair A, f c in pair B; both halves of the wave get both through one swap
+			int t = __builtin_bit_cast(int, g0 * (pair == 0 ? g1 : c)), u;
+			asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane32_swap_b32 %0, %1\ns_nop 1\n" : "+v"(t), "=&v"(u)); // t: i g everywhere, u: f c everywhere
+			c = __builtin_bit_cast(float, t) + __builtin_bit_cast(float, u);
+			// h = o tanh(c') is right in pair B (rows 2, 3 = h[0..15], h[16..31]); y <- [h0 h1 h0 h1], then a <- h0, b <- h1 in every row
+			int hv = __builtin_bit_cast(int, g1 * (STD ? StdTanh(c) : LstmRcpTanh(c))), y, z;
+			asm volatile(
+				"v_mov_b32 %1, %0\n"
+				"s_nop 1\n"
+				"v_permlane32_swap_b32 %0, %1\n"
+				"s_nop 1\n"
+				"v_mov_b32 %2, %1\n"
+				"s_nop 1\n"
+				"v_permlane16_swap_b32 %1, %2\n"
+				"s_nop 1\n"
+				: "+v"(hv), "=&v"(y), "=&v"(z));
+			a = __builtin_bit_cast(float, y);
+			b = __builtin_bit_cast(float, z);
+		};
+		int f = 0;
+		for (; f + 4 <= n; f += 4)
+		{
+			const float4 xv = *reinterpret_cast<const float4*>(xin + f);
+			step(xv.x, hw + (f + 0) * HP);
+			step(xv.y, hw + (f + 1) * HP);
+			step(xv.z, hw + (f + 2) * HP);
+			step(xv.w, hw + (f + 3) * HP);
+		}
+		for (; f < n; f++) step(xin[f], hw + f * HP);
+		hw[n * HP] = r ? b : a;
+		RecurrentWaveSync();
+
+		// dense head for the whole block, lane = sample (LSTM.h:182-189)
+		const float* headW = m.w + m.headOff;
+		for (int f = lane; f < n; f += 64)
+		{
+			float acc = 0.0f;
+			for (int k = 0; k < hr; k++) acc += headW[k] * hout[(f + 1) * HP + k];
+			outRow[f] = acc + headW[hr];
+		}
+		if (pair == 0 && real)
+		{
+			state[(size_t)unit * capacity + slot] = r ? b : a;
+			state[(size_t)(hr + unit) * capacity + slot] = c;
 		}
 	}
 
@@ -439,11 +550,11 @@ namespace na
 		// z / r rows: the input part joins the recurrent sum (start wx x + (b_in + b_rec)); c rows keep it apart (the reset gate scales
 		// the recurrent part only).
 		const float* w0 = m.w + m.layerOff[0];
-		const float wx0 = real ? w0[(size_t)r * (1 + hr)] : 0.0f;
+		const float wx0 = LoadIf(w0, (size_t)r * (1 + hr), real);
 		float wh0[H];
 #pragma unroll
-		for (int k = 0; k < H; k++) wh0[k] = (real && col(k) < hr) ? w0[(size_t)r * (1 + hr) + 1 + col(k)] : 0.0f;
-		const float bi0 = real ? w0[(size_t)3 * hr * (1 + hr) + r] : 0.0f, bh0 = real ? w0[(size_t)3 * hr * (1 + hr) + 3 * hr + r] : 0.0f;
+		for (int k = 0; k < H; k++) wh0[k] = LoadIf(w0, (size_t)r * (1 + hr) + 1 + col(k), real && col(k) < hr);
+		const float bi0 = LoadIf(w0, (size_t)3 * hr * (1 + hr) + r, real), bh0 = LoadIf(w0, (size_t)3 * hr * (1 + hr) + 3 * hr + r, real);
 		const float wxA0 = isC ? 0.0f : wx0, bA0 = isC ? bh0 : bi0 + bh0;
 		float wi1[H], wh1[H];
 		float bi1 = 0.0f, bh1 = 0.0f;
@@ -454,17 +565,17 @@ namespace na
 			for (int k = 0; k < H; k++)
 			{
 				const bool on = real && col(k) < hr;
-				wi1[k] = on ? w1[(size_t)r * (2 * hr) + col(k)] : 0.0f;
-				wh1[k] = on ? w1[(size_t)r * (2 * hr) + hr + col(k)] : 0.0f;
+				wi1[k] = LoadIf(w1, (size_t)r * (2 * hr) + col(k), on);
+				wh1[k] = LoadIf(w1, (size_t)r * (2 * hr) + hr + col(k), on);
 			}
-			bi1 = real ? w1[(size_t)3 * hr * (2 * hr) + r] : 0.0f;
-			bh1 = real ? w1[(size_t)3 * hr * (2 * hr) + 3 * hr + r] : 0.0f;
+			bi1 = LoadIf(w1, (size_t)3 * hr * (2 * hr) + r, real);
+			bh1 = LoadIf(w1, (size_t)3 * hr * (2 * hr) + 3 * hr + r, real);
 		}
 
 		for (int f = lane; f < n + 4; f += 64) xin[f] = f < n ? inRow[f] : 0.0f;
 		float h[L];
 #pragma unroll
-		for (int l = 0; l < L; l++) h[l] = real ? state[(size_t)(l * 2 * hr + unit) * capacity + slot] : 0.0f;
+		for (int l = 0; l < L; l++) h[l] = LoadIf(state, (size_t)(l * 2 * hr + unit) * capacity + slot, real);
 		RecurrentWaveSync();
 
 		// (stores of h: every lane, after the first dot of the NEXT sample -- see LstmDppBodyM)
@@ -501,7 +612,7 @@ namespace na
 		{
 			float acc = 0.0f;
 #pragma unroll
-			for (int k = 0; k < H; k++) acc += (k < hr ? headW[k] : 0.0f) * hout[(f + 1) * HP + k];
+			for (int k = 0; k < H; k++) acc += LoadIf(headW, (size_t)k, k < hr) * hout[(f + 1) * HP + k];
 			outRow[f] = acc + headW[hr];
 		}
 		if (lane < hr)
@@ -535,7 +646,7 @@ namespace na
 		long outStride, int n)
 	{
 		__shared__ __attribute__((aligned(16))) float xin[REC_XIN_FLOATS];
-		__shared__ float hout[REC_HOUT_FLOATS];
+		extern __shared__ __attribute__((aligned(16))) float hout[]; // REC_HOUT_FLOATS, or REC_HOUT32_FLOATS when a 32-unit-layout group is in the launch
 		int gi = 0;
 		for (int i = 1; i < args.numGroups; i++)
 			if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
@@ -543,6 +654,12 @@ namespace na
 		const int idx = (int)blockIdx.x - ga.firstBlock;
 		const int slot = ga.slots ? ga.slots[idx] : ga.slot0 + idx;
 		const int row = ga.slots ? ga.rows[idx] : ga.row0 + idx;
+		if (ga.m.hidden > 16) // one-layer LSTMs of 17 .. 32 units (RecurrentDppSupported)
+		{
+			if (ga.m.math == LSTM_MATH_STD) LstmDpp32Body<true>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+			else LstmDpp32Body<false>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+			return;
+		}
 		const int layoutH = ga.m.hidden <= 8 ? 8 : 16; // the lane layout the hidden size is padded into
 		const int key = ga.m.cell * 100 + layoutH * 4 + ga.m.numLayers + ((ga.m.cell == LSTM_CELL_LSTM && ga.m.math == LSTM_MATH_STD) ? 1000 : 0);
 #define NA_REC_CASE(CELL, HH, LL, BODY) \
@@ -575,8 +692,11 @@ namespace na
 	bool RecurrentDppSupported(const LstmModelDev& m)
 	{
 		// hidden sizes below a layout (8 or 16 units per gate block) are padded into it: 12 (the reference's static 1x12 / 2x12) runs as 16
-		return m.hidden >= 1 && m.hidden <= 16 && (m.numLayers == 1 || m.numLayers == 2) && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU) &&
-			m.tailLayers == 0; // generic keras stacks run on the runtime-shaped kernels
+		// ... and one-layer LSTMs of 17 .. 32 units (the reference's static 1x24) on the 32-unit layout
+		static const bool no32 = getenv("NA_REC_NO_DPP32") != nullptr;
+		if (m.tailLayers != 0) return false; // generic keras stacks run on the runtime-shaped kernels
+		if (m.cell == LSTM_CELL_LSTM && m.numLayers == 1 && m.hidden > 16 && m.hidden <= 32) return !no32;
+		return m.hidden >= 1 && m.hidden <= 16 && (m.numLayers == 1 || m.numLayers == 2) && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU);
 	}
 
 	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
@@ -604,7 +724,10 @@ namespace na
 			a.firstBlock = blocks;
 			blocks += groups[i].numStreams;
 		}
-		hipLaunchKernelGGL(RecurrentDppKernel, dim3((unsigned)blocks), dim3(64), 0, stream, args, in, out, inStride, outStride, n);
+		bool any32 = false;
+		for (int i = 0; i < numGroups; i++) any32 |= groups[i].model.hidden > 16;
+		const size_t lds = sizeof(float) * (size_t)(any32 ? REC_HOUT32_FLOATS : REC_HOUT_FLOATS);
+		hipLaunchKernelGGL(RecurrentDppKernel, dim3((unsigned)blocks), dim3(64), lds, stream, args, in, out, inStride, outStride, n);
 		return hipGetLastError();
 	}
 }

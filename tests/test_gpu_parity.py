@@ -138,11 +138,12 @@ def test_stdmath_wavenet_matches_stdmath_oracle(na, name):
     assert O.rms(yo - yf) > 1e-5  # the two policies differ measurably (6.6e-4 on Standard / sine)
 
 
-@pytest.mark.parametrize("layers,hidden", [(1, 12), (2, 12), (1, 4), (2, 6), (1, 13), (2, 9), (1, 1)])
+@pytest.mark.parametrize("layers,hidden", [(1, 12), (2, 12), (1, 4), (2, 6), (1, 13), (2, 9), (1, 1), (1, 24), (1, 17), (1, 20), (1, 32)])
 @pytest.mark.parametrize("std", [False, True], ids=["fastmath", "stdmath"])
 def test_lstm_hidden_sizes_padded_into_the_dpp_layouts_match_oracle(na, layers, hidden, std):
     """Hidden sizes below a lane layout of the LDS-free kernel (8 or 16 units per gate block) run padded: the reference's static 1x12 /
-    2x12 (NeuralModel.cpp:33,37) as 16, small ones as 8 (two layers: side by side in the wave halves)."""
+    2x12 (NeuralModel.cpp:33,37) as 16, small ones as 8 (two layers: side by side in the wave halves); one layer of 17 .. 32 units (the
+    reference's static 1x24, :35) on the 32-unit layout."""
     ld = na.NeuralModelLoader()
     if std:
         ld.SetLSTMMathMode(na.EMathMode.StdMath)
