@@ -1,4 +1,6 @@
-// recurrent_dpp_kernels.hip -- the LDS-free recurrent kernels (LSTM and keras GRU, hidden size 8 or 16, 1-2 layers) as ONE
+// recurrent_dpp_kernels.hip -- the LDS-free recurrent kernels (LSTM and keras GRU, hidden size up to 16 padded into an 8- or 16-unit
+// lane layout, 1-2 layers; one-layer LSTMs up to 32 units on a 32-unit layout: every shape the reference builds statically,
+// NeuralModel.cpp:32-38) as ONE
 // gfx950 kernel that serves up to RECURRENT_MAX_GROUPS model groups per launch: a batch holding several recurrent models
 // (BASELINE config 4: LSTM 2x16 + GRU) runs without stream fork/join and its waves share the chip.
 //
@@ -35,7 +37,7 @@ namespace na
 	//   lane = H*gate + unit (gate order i,f,g,o; for H = 8 the upper 32 lanes mirror the lower 32), every lane keeps h[unit] and c[unit]
 	//   (replicated across the gate rows).  The mat-vec reads h[(unit - n) mod H] from a neighbour lane with DPP row_ror:n (a 16-lane row
 	//   holds the H units once or twice), against weights that were rotated the same way when they were loaded -- 1 instruction per
-	//   term, no broadcast through LDS or SGPRs.  The four gates of a unit meet through gfx950 lane swaps (GatherGates).
+	//   term, no broadcast through LDS or SGPRs.  The four gates of a unit meet through gfx950 lane swaps (ReplicateRows, LstmCellState8).
 	//   Each lane sums its row starting at column `unit` and walking down instead of 0..H-1: same products, different rounding order than
 	//   LSTM.h:87-100 (observed difference vs the oracle ~1e-7 RMS, tolerance 5e-6).  tanh divides with v_rcp_f32 like the WaveNet path.
 	// ------------------------------------------------------------------------------------------------------------
