@@ -374,7 +374,7 @@ namespace na
 	// f and o.  So slot 0 is a sigmoid everywhere, i g is local to pair A, f c local to pair B, their sum meets through one
 	// v_permlane32_swap, h = o tanh(c') comes out in pair B and one more swap32 + one swap16 hand both halves to every row.  ~115
 	// instructions per sample (two gates x 33 for the sums): 72.7 -> 38 us per 1024 x 128 step against the LDS-broadcast wave kernel.
-	template <bool STD>
+	template <bool STD, bool B8>
 	__device__ __forceinline__ void LstmDpp32Body(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
 		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
 	{
@@ -394,20 +394,28 @@ namespace na
 		auto colA = [&](int k) { return (j - k + 16) & 15; };
 		const float wx0 = gs0 * LoadIf(w0, (size_t)R0 * (1 + hr), real), wx1 = gs1 * LoadIf(w0, (size_t)R1 * (1 + hr), real);
 		const float b0 = gs0 * LoadIf(w0, (size_t)4 * hr * (1 + hr) + R0, real), b1 = gs1 * LoadIf(w0, (size_t)4 * hr * (1 + hr) + R1, real);
-		float wa0[16], wb0[16], wa1[16], wb1[16];
+		// B8 (hidden <= 24): the upper vector has at most 8 units and is kept TWICE in every row ([h16..h23 | h16..h23]), so its walk
+		// takes 8 terms instead of 16 (the same trick as the 8-unit layout)
+		constexpr int NB = B8 ? 8 : 16;
+		float wa0[16], wa1[16], wb0[NB], wb1[NB];
 #pragma unroll
 		for (int k = 0; k < 16; k++)
 		{
-			const int ca = colA(k), cb = 16 + colA(k);
+			const int ca = colA(k);
 			wa0[k] = gs0 * LoadIf(w0, (size_t)R0 * (1 + hr) + 1 + ca, real);
 			wa1[k] = gs1 * LoadIf(w0, (size_t)R1 * (1 + hr) + 1 + ca, real);
+		}
+#pragma unroll
+		for (int k = 0; k < NB; k++)
+		{
+			const int cb = 16 + ((j - k + 16) & (NB - 1));
 			wb0[k] = gs0 * LoadIf(w0, (size_t)R0 * (1 + hr) + 1 + cb, real && cb < hr);
 			wb1[k] = gs1 * LoadIf(w0, (size_t)R1 * (1 + hr) + 1 + cb, real && cb < hr);
 		}
 
 		for (int f = lane; f < n + 4; f += 64) xin[f] = f < n ? inRow[f] : 0.0f;
 		float a = state[(size_t)j * capacity + slot];                                      // h[j], every row
-		float b = LoadIf(state, (size_t)(16 + j) * capacity + slot, 16 + j < hr);          // h[16 + j], every row
+		float b = LoadIf(state, (size_t)(16 + (j & (NB - 1))) * capacity + slot, 16 + (j & (NB - 1)) < hr); // h[16 + j] (B8: h[16 + j % 8]), every row
 		float c = LoadIf(state, (size_t)(hr + unit) * capacity + slot, real);
 		RecurrentWaveSync();
 
@@ -419,8 +427,8 @@ namespace na
 			*dst = r ? b : a; // the h before this sample (entry f of hout), placed here: see LstmDppBodyM
 			acc0 = __builtin_fmaf(wb0[0], b, acc0);
 			acc1 = __builtin_fmaf(wb1[0], b, acc1);
-			DppDotTail<16>(acc0, wb0, b);
-			DppDotTail<16>(acc1, wb1, b);
+			DppDotTail<NB>(acc0, wb0, b);
+			DppDotTail<NB>(acc1, wb1, b);
 			const float g0 = GateAct<STD>(acc0, K0); // i (pair A) / f (pair B)
 			const float g1 = GateAct<STD>(acc1, K1); // g / o
 			// i g in pair A, f c in pair B; both halves of the wave get both through one swap
@@ -440,7 +448,7 @@ namespace na
 				"s_nop 1\n"
 				: "+v"(hv), "=&v"(y), "=&v"(z));
 			a = __builtin_bit_cast(float, y);
-			b = __builtin_bit_cast(float, z);
+			b = __builtin_bit_cast(float, B8 ? RowLowHalf(z) : z); // B8: lanes 8..15 of a row <- lanes 0..7
 		};
 		int f = 0;
 		for (; f + 4 <= n; f += 4)
@@ -658,8 +666,17 @@ namespace na
 		const int row = ga.slots ? ga.rows[idx] : ga.row0 + idx;
 		if (ga.m.hidden > 16) // one-layer LSTMs of 17 .. 32 units (RecurrentDppSupported)
 		{
-			if (ga.m.math == LSTM_MATH_STD) LstmDpp32Body<true>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
-			else LstmDpp32Body<false>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+			const bool std32 = ga.m.math == LSTM_MATH_STD;
+			if (ga.m.hidden <= 24)
+			{
+				if (std32) LstmDpp32Body<true, true>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+				else LstmDpp32Body<false, true>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+			}
+			else
+			{
+				if (std32) LstmDpp32Body<true, false>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+				else LstmDpp32Body<false, false>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+			}
 			return;
 		}
 		const int layoutH = ga.m.hidden <= 8 ? 8 : 16; // the lane layout the hidden size is padded into
