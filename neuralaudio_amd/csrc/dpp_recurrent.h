@@ -69,9 +69,10 @@ namespace na
 	//   v_permlane32_swap a, b: a.lanes[32..63] <-> b.lanes[0..31]        a = [a.lo, b.lo], b = [a.hi, b.hi]
 	//   v_permlane16_swap a, b: odd 16-lane rows of a <-> even rows of b    a = rows [a0, b0, a2, b2], b = rows [a1, b1, a3, b3]
 
-	// Every 16-lane row of v replicated into all four rows, in ONE block with the fewest instructions the hazards allow (two wait
-	// states between a VALU write and a lane swap that reads it, and between a swap and a read of its result; copies double as
-	// wait states): r0..r3 = row 0..3 of v everywhere.  v must not be read by the instruction right before (it may be written by it).
+	// Every 16-lane row of v replicated into all four rows, in ONE block with the fewest instructions the hazard allows: two wait
+	// states between a VALU write (a swap counts) of a register and a lane swap that reads it -- nothing is needed between a swap and a
+	// plain VALU read of its result (the LLVM gfx950 rule "VALU write vdst -> v_permlane read" is the only one; copies double as wait
+	// states).  r0..r3 = row 0..3 of v everywhere.
 	__device__ __forceinline__ void ReplicateRows(float v, float& r0, float& r1, float& r2, float& r3)
 	{
 		int x = __builtin_bit_cast(int, v), y, x2, y2;
@@ -79,13 +80,11 @@ namespace na
 			"v_mov_b32 %1, %0\n"
 			"s_nop 1\n"
 			"v_permlane32_swap_b32 %0, %1\n" // x: rows 0 1 0 1, y: rows 2 3 2 3
-			"s_nop 1\n"
 			"v_mov_b32 %2, %0\n"
 			"v_mov_b32 %3, %1\n"
 			"s_nop 0\n"
 			"v_permlane16_swap_b32 %0, %2\n" // x: row 0 everywhere, x2: row 1
 			"v_permlane16_swap_b32 %1, %3\n" // y: row 2, y2: row 3
-			"s_nop 1\n"
 			: "+v"(x), "=&v"(y), "=&v"(x2), "=&v"(y2));
 		r0 = __builtin_bit_cast(float, x);
 		r1 = __builtin_bit_cast(float, x2);

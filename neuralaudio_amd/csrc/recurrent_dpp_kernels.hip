@@ -433,7 +433,7 @@ namespace na
 			const float g1 = GateAct<STD>(acc1, K1); // g / o
 			// i g in pair A, f c in pair B; both halves of the wave get both through one swap
 			int t = __builtin_bit_cast(int, g0 * (pair == 0 ? g1 : c)), u;
-			asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane32_swap_b32 %0, %1\ns_nop 1\n" : "+v"(t), "=&v"(u)); // t: i g everywhere, u: f c everywhere
+			asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane32_swap_b32 %0, %1\n" : "+v"(t), "=&v"(u)); // t: i g everywhere, u: f c everywhere
 			c = __builtin_bit_cast(float, t) + __builtin_bit_cast(float, u);
 			// h = o tanh(c') is right in pair B (rows 2, 3 = h[0..15], h[16..31]); y <- [h0 h1 h0 h1], then a <- h0, b <- h1 in every row
 			int hv = __builtin_bit_cast(int, g1 * (STD ? StdTanh(c) : LstmRcpTanh(c))), y, z;
@@ -441,11 +441,9 @@ namespace na
 				"v_mov_b32 %1, %0\n"
 				"s_nop 1\n"
 				"v_permlane32_swap_b32 %0, %1\n"
-				"s_nop 1\n"
 				"v_mov_b32 %2, %1\n"
 				"s_nop 1\n"
 				"v_permlane16_swap_b32 %1, %2\n"
-				"s_nop 1\n"
 				: "+v"(hv), "=&v"(y), "=&v"(z));
 			a = __builtin_bit_cast(float, y);
 			b = __builtin_bit_cast(float, B8 ? RowLowHalf(z) : z); // B8: lanes 8..15 of a row <- lanes 0..7
@@ -515,11 +513,9 @@ namespace na
 				"v_mov_b32 %1, %0\n"
 				"s_nop 1\n"
 				"v_permlane32_swap_b32 %0, %1\n" // zr: rows z r z r
-				"s_nop 1\n"
 				"v_mov_b32 %2, %0\n"
 				"s_nop 1\n"
 				"v_permlane16_swap_b32 %0, %2\n" // zr: z everywhere, rr: r everywhere
-				"s_nop 1\n"
 				: "+v"(zr), "=&v"(zr2), "=&v"(rr));
 			z = __builtin_bit_cast(float, zr);
 			r = __builtin_bit_cast(float, rr);
@@ -527,14 +523,14 @@ namespace na
 		else
 		{
 			int zr = __builtin_bit_cast(int, zrv), zr2;
-			asm volatile("s_nop 0\nv_mov_b32 %1, %0\ns_nop 1\nv_permlane16_swap_b32 %0, %1\ns_nop 1\n" : "+v"(zr), "=&v"(zr2)); // zr: every row = [z | r]
+			asm volatile("s_nop 0\nv_mov_b32 %1, %0\ns_nop 1\nv_permlane16_swap_b32 %0, %1\n" : "+v"(zr), "=&v"(zr2)); // zr: every row = [z | r] (the DPP reads below: the compiler pads them)
 			z = __builtin_bit_cast(float, RowLowHalf(zr));
 			r = __builtin_bit_cast(float, RowHighHalf(zr));
 		}
 		int c = __builtin_bit_cast(int, StdTanh(__builtin_fmaf(r, acc, aic))); // meaningful on the c rows (2 and 3 for H = 16; 1 and 3 for H = 8)
 		int c2;
-		if constexpr (H == 16) asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane32_swap_b32 %0, %1\ns_nop 1\n" : "+v"(c), "=&v"(c2)); // c2: rows c c c c
-		else asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane16_swap_b32 %0, %1\ns_nop 1\n" : "+v"(c), "=&v"(c2));                 // c2: rows 1 1 3 3 = c everywhere
+		if constexpr (H == 16) asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane32_swap_b32 %0, %1\n" : "+v"(c), "=&v"(c2)); // c2: rows c c c c
+		else asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane16_swap_b32 %0, %1\n" : "+v"(c), "=&v"(c2));                 // c2: rows 1 1 3 3 = c everywhere
 		const float cv = __builtin_bit_cast(float, c2);
 		return __builtin_fmaf(z, h - cv, cv); // (1 - z) c + z h
 	}
