@@ -629,6 +629,98 @@ namespace na
 	}
 
 
+	// One keras GRU layer of 17 .. 32 units on the 32-unit layout (see LstmDpp32Body): rows 0-1 (pair A) own the z gate of unit 16 r + j,
+	// rows 2-3 (pair B) the r gate AND the candidate c -- c = tanh(W_c x + b_in + r (U_c h + b_rec)) needs r and the recurrent sum of c in
+	// one lane, which is exactly what pair B holds.  Slot 0 (z | r) is a sigmoid everywhere; ONE v_permlane32_swap then hands z and c to
+	// every row, every lane updates its own unit (h' = c + z (h - c)), and one v_permlane16_swap rebuilds the two replicated state
+	// vectors.  ~87 instructions per sample; 1x24 158 -> 32 us per 1024 x 128 step against the runtime-shaped wave kernel.
+	template <bool B8>
+	__device__ __forceinline__ void GruDpp32Body(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
+	{
+		constexpr int HP = 33;
+		constexpr int NB = B8 ? 8 : 16;
+		const int lane = threadIdx.x;
+		const int j = lane & 15, rho = lane >> 4, r = rho & 1, pair = rho >> 1; // pair 0 = A (z), 1 = B (r, c)
+		const int hr = m.hidden, unit = 16 * r + j;
+		const bool real = unit < hr, isB = pair == 1;
+		const float* inRow = in + (size_t)row * inStride;
+		float* outRow = out + (size_t)row * outStride;
+
+		// W row-major [3 hr][1 + hr] (rows z | r | c), b_in[3 hr], b_rec[3 hr]; recurrent columns rotated for the DPP walk
+		const float* w0 = m.w + m.layerOff[0];
+		const size_t W = (size_t)(1 + hr), bIn = (size_t)3 * hr * W, bRec = bIn + (size_t)3 * hr;
+		const int R0 = pair * hr + unit, R1 = 2 * hr + unit;
+		const float wx0 = LoadIf(w0, (size_t)R0 * W, real);                                        // z / r: the input part joins the sum
+		const float bA0 = LoadIf(w0, bIn + R0, real) + LoadIf(w0, bRec + R0, real);
+		const float wx1 = LoadIf(w0, (size_t)R1 * W, real && isB), bi1 = LoadIf(w0, bIn + R1, real && isB); // c: W x + b_in kept apart
+		const float bh1 = LoadIf(w0, bRec + R1, real && isB);
+		float wa0[16], wa1[16], wb0[NB], wb1[NB];
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+		{
+			const int ca = (j - k + 16) & 15;
+			wa0[k] = LoadIf(w0, (size_t)R0 * W + 1 + ca, real);
+			wa1[k] = LoadIf(w0, (size_t)R1 * W + 1 + ca, real && isB);
+		}
+#pragma unroll
+		for (int k = 0; k < NB; k++)
+		{
+			const int cb = 16 + ((j - k + 16) & (NB - 1));
+			wb0[k] = LoadIf(w0, (size_t)R0 * W + 1 + cb, real && cb < hr);
+			wb1[k] = LoadIf(w0, (size_t)R1 * W + 1 + cb, real && isB && cb < hr);
+		}
+
+		for (int f = lane; f < n + 4; f += 64) xin[f] = f < n ? inRow[f] : 0.0f;
+		float a = state[(size_t)j * capacity + slot];                                                               // h[j], every row
+		float b = LoadIf(state, (size_t)(16 + (j & (NB - 1))) * capacity + slot, 16 + (j & (NB - 1)) < hr);          // h[16 + j] (B8: h[16 + j % 8])
+		float hown = r ? b : a;
+		RecurrentWaveSync();
+
+		float* hw = hout + unit;
+		auto step = [&](float x, float* dst) {
+			float s0, s1;
+			DppDotFrom<16>(s0, wx0, x, bA0, wa0, a);
+			DppDotFrom<16>(s1, 0.0f, 0.0f, bh1, wa1, a);
+			*dst = hown; // the h before this sample (entry f of hout), placed here: see LstmDppBodyM
+			s0 = __builtin_fmaf(wb0[0], b, s0);
+			s1 = __builtin_fmaf(wb1[0], b, s1);
+			DppDotTail<NB>(s0, wb0, b);
+			DppDotTail<NB>(s1, wb1, b);
+			const float zr = StdSigmoid(s0);                                             // z (pair A) / r (pair B)
+			const float cv = StdTanh(__builtin_fmaf(zr, s1, __builtin_fmaf(wx1, x, bi1))); // c, right in pair B
+			int v = __builtin_bit_cast(int, isB ? cv : zr), vc;
+			asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane32_swap_b32 %0, %1\n" : "+v"(v), "=&v"(vc)); // v: z everywhere, vc: c everywhere
+			const float z = __builtin_bit_cast(float, v), c = __builtin_bit_cast(float, vc);
+			int hn = __builtin_bit_cast(int, __builtin_fmaf(z, hown - c, c)), hc; // (1 - z) c + z h, every lane for its own unit
+			asm volatile("v_mov_b32 %1, %0\ns_nop 1\nv_permlane16_swap_b32 %0, %1\n" : "+v"(hn), "=&v"(hc)); // hn: h[0..15] everywhere, hc: h[16..31]
+			a = __builtin_bit_cast(float, hn);
+			b = __builtin_bit_cast(float, B8 ? RowLowHalf(hc) : hc);
+			hown = r ? b : a;
+		};
+		int f = 0;
+		for (; f + 4 <= n; f += 4)
+		{
+			const float4 xv = *reinterpret_cast<const float4*>(xin + f);
+			step(xv.x, hw + (f + 0) * HP);
+			step(xv.y, hw + (f + 1) * HP);
+			step(xv.z, hw + (f + 2) * HP);
+			step(xv.w, hw + (f + 3) * HP);
+		}
+		for (; f < n; f++) step(xin[f], hw + f * HP);
+		hw[n * HP] = hown;
+		RecurrentWaveSync();
+
+		const float* headW = m.w + m.headOff;
+		for (int f = lane; f < n; f += 64)
+		{
+			float acc = 0.0f;
+			for (int k = 0; k < hr; k++) acc += headW[k] * hout[(f + 1) * HP + k];
+			outRow[f] = acc + headW[hr];
+		}
+		if (pair == 0 && real) state[(size_t)unit * capacity + slot] = hown;
+	}
+
 	struct RecurrentGroupArgs
 	{
 		LstmModelDev m;
@@ -660,6 +752,12 @@ namespace na
 		const int idx = (int)blockIdx.x - ga.firstBlock;
 		const int slot = ga.slots ? ga.slots[idx] : ga.slot0 + idx;
 		const int row = ga.slots ? ga.rows[idx] : ga.row0 + idx;
+		if (ga.m.hidden > 16 && ga.m.cell == LSTM_CELL_GRU) // one-layer GRUs of 17 .. 32 units
+		{
+			if (ga.m.hidden <= 24) GruDpp32Body<true>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+			else GruDpp32Body<false>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+			return;
+		}
 		if (ga.m.hidden > 16) // one-layer LSTMs of 17 .. 32 units (RecurrentDppSupported)
 		{
 			const bool std32 = ga.m.math == LSTM_MATH_STD;
@@ -707,10 +805,10 @@ namespace na
 	bool RecurrentDppSupported(const LstmModelDev& m)
 	{
 		// hidden sizes below a layout (8 or 16 units per gate block) are padded into it: 12 (the reference's static 1x12 / 2x12) runs as 16
-		// ... and one-layer LSTMs of 17 .. 32 units (the reference's static 1x24) on the 32-unit layout
+		// ... and one-layer LSTMs (the reference's static 1x24) / keras GRUs of 17 .. 32 units on the 32-unit layout
 		static const bool no32 = getenv("NA_REC_NO_DPP32") != nullptr;
 		if (m.tailLayers != 0) return false; // generic keras stacks run on the runtime-shaped kernels
-		if (m.cell == LSTM_CELL_LSTM && m.numLayers == 1 && m.hidden > 16 && m.hidden <= 32) return !no32;
+		if ((m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU) && m.numLayers == 1 && m.hidden > 16 && m.hidden <= 32) return !no32;
 		return m.hidden >= 1 && m.hidden <= 16 && (m.numLayers == 1 || m.numLayers == 2) && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU);
 	}
 

@@ -151,7 +151,7 @@ def test_config4_keras_gru_next_to_lstm_2x16(na, loader):
         assert O.rms(y[s] - O.OracleGRU(gj).process(x[s])) < 5e-6, s
 
 
-@pytest.mark.parametrize("layers,hidden", [(1, 16), (2, 8), (1, 12), (2, 20)])
+@pytest.mark.parametrize("layers,hidden", [(1, 16), (2, 8), (1, 12), (2, 20), (1, 5), (2, 13), (1, 17), (1, 20), (1, 24), (1, 25), (1, 32)])
 def test_keras_gru_single_stream_shapes(na, loader, layers, hidden):
     import json
     gj = O.synth_keras_gru(layers, hidden, seed=40 + hidden + layers)
