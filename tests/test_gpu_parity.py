@@ -156,6 +156,29 @@ def test_lstm_hidden_sizes_padded_into_the_dpp_layouts_match_oracle(na, layers, 
     assert O.rms(got - want) < 5e-6, (layers, hidden, O.rms(got - want))
 
 
+@pytest.mark.parametrize("kind,layers,hidden", [("lstm", 1, 16), ("lstm", 2, 8), ("lstm", 1, 24), ("lstm", 2, 12), ("lstm", 1, 32), ("lstm", 2, 5),
+                                                ("gru", 1, 24), ("gru", 1, 16), ("gru", 2, 8), ("gru", 1, 32), ("gru", 1, 7)])
+def test_recurrent_models_through_tiny_and_ragged_buffers(na, kind, layers, hidden):
+    """Every body of the LDS-free recurrent kernel (8 / 16 / 32-unit layouts, the side-by-side two-layer one with its peeled boundary ticks)
+    through buffers of 1, 2, 3, 5 ... 129, 300 samples: groups of four, tails, chunking above 128 (InternalModel.h:104-117 is chunk-invariant)."""
+    import json
+    sizes = [1, 2, 3, 5, 1, 4, 7, 128, 1, 127, 64, 33, 2, 129, 300]
+    x = O.signal_noise(sum(sizes), 11)
+    if kind == "lstm":
+        w = O.synth_lstm_weights(layers, hidden, seed=5 + hidden)
+        m = na.NeuralModelLoader().CreateFromString(O.nam_json_lstm(layers, hidden, w), ".nam", doPrewarm=True)
+        want = O.OracleLSTM.from_nam(layers, hidden, w).process(x)
+    else:
+        gj = O.synth_keras_gru(layers, hidden, seed=5 + hidden)
+        m = na.NeuralModelLoader().CreateFromString(json.dumps(gj), ".json", doPrewarm=True)
+        want = O.OracleGRU(gj).process(x)
+    out, pos = [], 0
+    for n in sizes:
+        out.append(m.Process(x[pos:pos + n]))
+        pos += n
+    assert O.rms(np.concatenate(out) - want) < 5e-6
+
+
 @pytest.mark.parametrize("layers,hidden", [(1, 3), (1, 18), (3, 16), (2, 40), (2, 64)])
 def test_runtime_shaped_lstm_matches_oracle(na, loader, layers, hidden):
     """Hidden sizes / layer counts without a shaped kernel run on the runtime-shaped one (LSTMDynamic.h:95-108 accepts any)."""
