@@ -151,6 +151,33 @@ def test_config4_keras_gru_next_to_lstm_2x16(na, loader):
         assert O.rms(y[s] - O.OracleGRU(gj).process(x[s])) < 5e-6, s
 
 
+def test_one_launch_serves_every_recurrent_layout(na, loader):
+    """Six recurrent models in one batch = one fused RecurrentDppKernel launch: LSTM 1x24 and GRU 1x24 (32-unit layouts, which also size the
+    launch's LDS), LSTM 1x12 (padded into the 16-unit layout), LSTM 2x8 (two layers side by side), LSTM 2x16, GRU 1x16; ragged stream counts."""
+    import json
+    specs = [("lstm", 1, 24, 9), ("gru", 1, 24, 7), ("lstm", 1, 12, 5), ("lstm", 2, 8, 11), ("lstm", 2, 16, 3), ("gru", 1, 16, 6)]
+    b = na.Batch(0)
+    oracles = []
+    for kind, layers, hidden, count in specs:
+        if kind == "lstm":
+            w = O.synth_lstm_weights(layers, hidden, seed=60 + hidden + layers)
+            m = loader.CreateFromString(O.nam_json_lstm(layers, hidden, w), ".nam", doPrewarm=True)
+            make = (lambda L=layers, H=hidden, W=w: O.OracleLSTM.from_nam(L, H, W))
+        else:
+            gj = O.synth_keras_gru(layers, hidden, seed=60 + hidden)
+            m = loader.CreateFromString(json.dumps(gj), ".json", doPrewarm=True)
+            make = (lambda G=gj: O.OracleGRU(G))
+        assert m is not None
+        b.AddStreams(m, count)
+        oracles += [make] * count
+    n, blocks = 128, 3
+    x = np.stack([O.signal_noise(n * blocks, 700 + s) for s in range(len(oracles))])
+    y = _run_blocks(b, x, n)
+    for s in range(len(oracles)):
+        assert b.StreamKernelName(s) == "RecurrentDppKernel"
+        assert O.rms(y[s] - oracles[s]().process(x[s])) < 5e-6, (s, specs)
+
+
 @pytest.mark.parametrize("layers,hidden", [(1, 16), (2, 8), (1, 12), (2, 20), (1, 5), (2, 13), (1, 17), (1, 20), (1, 24), (1, 25), (1, 32)])
 def test_keras_gru_single_stream_shapes(na, loader, layers, hidden):
     import json
