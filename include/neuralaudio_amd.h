@@ -89,11 +89,18 @@ NA_EXTERN double NA_BatchStateBytes(NA_Batch* batch);
 NA_EXTERN int NA_BatchStreamPackFactor(NA_Batch* batch, int stream);
 /* the kernel that runs the stream (its rocprof name without template arguments; static string, "" on a bad argument) */
 NA_EXTERN const char* NA_BatchStreamKernelName(NA_Batch* batch, int stream);
+/* Range contract of the kernel that runs the stream: input samples beyond +-limit are clamped, NaN reads as silence.  +inf for the f32
+ * kernels (they follow the reference's f32 chain at any amplitude); a per-model bound <= 32752 for the f16-split WaveNet kernels, whose
+ * values carry an f16 exponent -- far above any audio level (0 on a bad argument). */
+NA_EXTERN float NA_BatchStreamInputLimit(NA_Batch* batch, int stream);
 /* NAMIsA2 (bit 0) / NAMIsA2Standard (bit 1) of a .nam document (NeuralModel.cpp:159-168, 188-317); negative on a parse error */
 NA_EXTERN int NA_DebugClassifyNam(const char* jsonText);
 /* stream packing, host side only: pack factor of the model in a large batch (1: none); flat weights of the packed virtual model into
  * out[capacity] when given; returns their count (0: model does not pack), -1 on failure */
 NA_EXTERN int NA_DebugPackedWeights(NeuralModel* model, int* packFactor, float* out, int capacity);
+/* tests / tuning: 0 = WaveNet models with a compile-time specialised layer chain run on the stage interpreter instead (same stream state,
+ * bit-identical results); process-wide, set it only while no other thread is processing */
+NA_EXTERN void NA_DebugSetWaveNetSpec(int on);
 /* tuning aid: device buffer (long long[stages*4*waves]) that workgroup 0 of the WaveNet kernel stamps with the shader clock; NULL = off */
 NA_EXTERN void NA_DebugSetTraceBuffer(void* deviceBuffer);
 

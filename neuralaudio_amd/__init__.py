@@ -294,6 +294,9 @@ class Batch:
     def StreamKernelName(self, stream):
         return self._lib.NA_BatchStreamKernelName(self._h, int(stream)).decode()
 
+    def StreamInputLimit(self, stream):
+        return float(self._lib.NA_BatchStreamInputLimit(self._h, int(stream)))
+
     def StreamPackFactor(self, stream):
         return int(self._lib.NA_BatchStreamPackFactor(self._h, int(stream)))
 

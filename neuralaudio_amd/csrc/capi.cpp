@@ -463,6 +463,14 @@ double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames)
 
 double NA_BatchMacsPerSample(NA_Batch* batch) { return batch ? batch->batch->MacsPerSample() : 0.0; }
 
+float NA_BatchStreamInputLimit(NA_Batch* batch, int stream)
+{
+	try { return batch ? batch->batch->StreamInputLimit(stream) : 0.0f; }
+	catch (...) { return 0.0f; }
+}
+
+void NA_DebugSetWaveNetSpec(int on) { na::SetWaveNetSpecEnabled(on != 0); }
+
 void NA_DebugSetTraceBuffer(void* deviceBuffer) { na::SetWaveNetTraceBuffer(reinterpret_cast<long long*>(deviceBuffer)); }
 
 double NA_BatchStateBytes(NA_Batch* batch) { return batch ? (double)batch->batch->StateBytes() : 0.0; }

@@ -2,6 +2,7 @@
 #include "gpu_batch.h"
 
 #include <algorithm>
+#include <cmath>
 #include <functional>
 #include <cstdlib>
 #include <cstring>
@@ -144,6 +145,7 @@ namespace na
 		virtual double MacsPerSample() const = 0;
 		virtual size_t StateBytesPerStream() const = 0;
 		virtual int PackFactor() const { return 1; } // real streams per kernel-level stream (WaveNet stream packing)
+		virtual float InputLimit() const { return INFINITY; } // samples beyond +-limit are clamped by the kernel (f16-split WaveNet kernels)
 		virtual const char* KernelName() const = 0;  // the kernel that runs this group's streams (rocprof name, without template arguments)
 		// WaveNet groups on the frame kernel can share ONE launch with other such groups (a heterogeneous batch without stream
 		// fork/join); fills `out` with this group's part of that launch.  Other groups return false.
@@ -367,6 +369,8 @@ namespace na
 				dev.max_split_ops = plan.maxSplitOps;
 				dev.max_G = plan.maxG;
 				dev.split_fast_T = plan.splitFastT;
+				dev.cond_limit = plan.condLimit;
+				dev.spec_arch = family == WN_FAMILY_SPLIT ? WaveNetSpecArchId(plan.sstages.data(), (int)plan.sstages.size(), plan.stateF4, (int)(plan.wsplit.size() / 8)) : WN_SPEC_NONE;
 			}
 
 			// ChannelHistoryBuffer::AllocBuffer zero-fills (WaveNet.h:38-40)
@@ -474,9 +478,12 @@ namespace na
 			double MacsPerSample() const override { return (plan.isVirtual() ? realPlan : plan).MacsPerSample(); }
 			size_t StateBytesPerStream() const override { return (size_t)plan.stateF4 * 16 / (size_t)pack; }
 			int PackFactor() const override { return pack; }
+			float InputLimit() const override { return family == WN_FAMILY_SPLIT ? plan.condLimit : INFINITY; }
 			const char* KernelName() const override
 			{
-				return family == WN_FAMILY_SPLIT ? "WaveNetSplitKernel" : (family == WN_FAMILY_GENERIC ? "WaveNetGenericKernel" : "WaveNetFrameKernel");
+				// (a model with a specialised chain runs it for blocks of 128 / 64 / 32 frames, the interpreter for other lengths)
+				if (family == WN_FAMILY_SPLIT) return (dev.spec_arch != WN_SPEC_NONE && WaveNetSpecEnabled()) ? "WaveNetSpecKernel" : "WaveNetSplitKernel";
+				return family == WN_FAMILY_GENERIC ? "WaveNetGenericKernel" : "WaveNetFrameKernel";
 			}
 
 			// Packed groups: the launch lists name VIRTUAL streams -- slot = member / pack -- and hold `pack` rows each (-1: no member in
@@ -1213,6 +1220,12 @@ namespace na
 	{
 		const StreamRef& ref = streams.at((size_t)s);
 		return ref.members[(size_t)ref.active].first->KernelName();
+	}
+
+	float GpuBatch::StreamInputLimit(int s) const
+	{
+		const StreamRef& ref = streams.at((size_t)s);
+		return ref.members[(size_t)ref.active].first->InputLimit();
 	}
 
 	int GpuBatch::StreamPackFactor(int s) const

@@ -94,6 +94,8 @@ namespace na
 		double MacsPerSample() const;
 		size_t StateBytes() const;
 		const char* StreamKernelName(int stream) const; // which kernel runs the stream (rocprof name without template arguments)
+		// range contract: samples beyond +-limit are clamped (NaN reads as silence) by the kernel that runs the stream; +inf for the f32 kernels
+		float StreamInputLimit(int stream) const;
 		int StreamPackFactor(int stream) const; // > 1: the stream shares a kernel-level stream with others of its model (stream packing)
 
 	private:

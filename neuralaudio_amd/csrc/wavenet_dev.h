@@ -143,5 +143,15 @@ namespace na
 		int max_split_ops;    // largest per-stage operand count (sizes the LDS weight buffers)
 		int max_G;            // largest channel-group count of any ring / stage (sizes the LDS block image)
 		int split_fast_T;     // fewest tiles per wave the fast instantiation can run this model with (2 or 4); 0: needs the generic one
+		int spec_arch;        // WnSpecArch: the compile-time specialised chain that runs this model (wavenet_spec_kernels.hip), 0: none
+		float cond_limit;     // f16-split kernels: input samples are clamped to +-cond_limit (WaveNetPlan::condLimit)
+	};
+
+	enum WnSpecArch : int
+	{
+		WN_SPEC_NONE = 0,
+		WN_SPEC_STD = 1,    // A1 Standard: 16 / 8 channels, dilations 1..512 twice
+		WN_SPEC_LITE = 2,   // the lite dilation lists at 16 / 8 channels (A1 Lite padded, two packed Feather streams)
+		WN_SPEC_LITE16 = 3, // ... at 16 / 16 channels (four packed Nano streams)
 	};
 }

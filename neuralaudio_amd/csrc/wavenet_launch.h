@@ -31,6 +31,16 @@ namespace na
 	hipError_t LaunchWaveNetSplitFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream);
 
+	// Same contract on the compile-time specialised layer chains of the official architectures (wavenet_spec_kernels.hip): blocks of
+	// exactly 128 / 64 / 32 frames, every group of the launch from one architecture family (WnModelDev::spec_arch); returns
+	// hipErrorNotSupported otherwise -- LaunchWaveNetSplitFused tries it first and falls back to its stage interpreter.
+	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream);
+	bool WaveNetSpecEnabled();
+	void SetWaveNetSpecEnabled(bool on); // process-wide; not for use while launches are being issued from other threads
+	// which specialised chain (WnSpecArch) runs a split-kernel plan, WN_SPEC_NONE if none; host data
+	int WaveNetSpecArchId(const WnSplitStage* stages, int nstages, int stateF4, int wsplitQuads);
+
 	// The runtime-shaped block kernel (wavenet_generic_kernels.hip): up to 64 channels per layer array, dense heads; walks the
 	// natural-layout tensor table (WaveNetPlan::prewarm) over the flat reference-order weights; frame-kernel stream-state format.
 	hipError_t LaunchWaveNetGeneric(const WnPrewarmLayer* layers, int numLayers, const float* weights, const int* ringOffF4, const int* ringFrames,

@@ -259,6 +259,8 @@ namespace na
 			// the "hi" operand carries Wh in all 8 slots, the "lo" operand Wl in the four h slots (zeros against l).
 			// Rows [rowBase, rowBase + cout) x k-blocks [kbBase, kbBase + ceil(cin/4)) receive W(o, c); everything else stays zero, so
 			// several tiles share one MFMA through block-diagonal operands (mode Gp: tile slot p owns rows 4*Gp*p.. and k-blocks Gp*p..).
+			double rangeGain = 1.0, rangeAdd = 0.0, rangeGainMax = 0.0, rangeAddMax = 0.0;
+
 			int NewSplitOps(int count)
 			{
 				const int first = (int)(plan.wsplit.size() / 512);
@@ -349,6 +351,19 @@ namespace na
 					const int cpad = pack > 1 ? C / pack : (1 << 20); // channels per packed stream (a multiple of 4)
 					const int groupsPerStream = pack > 1 ? cpad / 4 : 4;
 					const int rechOff = Take((size_t)C * cfg.inputSize);
+					{
+						// range bookkeeping for condLimit: |residual stream| <= gain * |cond| + add through this array's rechannel
+						double rowMax = 0.0;
+						for (int o = 0; o < C; o++)
+						{
+							double row = 0.0;
+							for (int c = 0; c < cfg.inputSize; c++) row += std::fabs((double)W(rechOff + o * cfg.inputSize + c));
+							rowMax = std::max(rowMax, row);
+						}
+						rangeGain = (a == 0 ? 1.0 : rangeGain) * rowMax;
+						rangeAdd = (a == 0 ? 0.0 : rangeAdd) * rowMax;
+						rangeGainMax = std::max(rangeGainMax, rangeGain);
+					}
 					if (a == 0)
 					{
 						// x = w_re * cond (WaveNet.h:637, input_size == 1): the aux operand with weights (w_re, 0)
@@ -402,6 +417,18 @@ namespace na
 						const int b1 = Take((size_t)C);
 						const bool lastLayer = (l == numLayers - 1);
 						const bool needOutput = !(lastLayer && lastArray);
+						{
+							// the 1x1 adds at most max_o (sum_c |w1[o][c]| * 1.0081 + |b1[o]|) to the residual stream (|FastMath tanh| <= 1.0081)
+							double grow = 0.0;
+							for (int o = 0; o < C; o++)
+							{
+								double row = std::fabs((double)W(b1 + o));
+								for (int c = 0; c < C; c++) row += 1.0081 * std::fabs((double)W(w1 + o * C + c));
+								grow = std::max(grow, row);
+							}
+							rangeAdd += grow;
+							rangeAddMax = std::max(rangeAddMax, rangeAdd);
+						}
 
 						WnSplitStage st = EmptySplit(WN_ST_LAYER);
 						st.G = G; st.Gp = Gp; st.ksize = K; st.dilation = cfg.dilations[l];
@@ -462,6 +489,13 @@ namespace na
 					}
 				}
 				for (const WnSplitStage& st : plan.sstages) plan.maxSplitOps = std::max(plan.maxSplitOps, st.a_ops);
+				// Range contract of the f16-split kernels: the hi half of every value is an f16 (|v| <= 65504).  With the input clamped to
+				// +-condLimit the residual stream stays below half of that: gain * limit + (what the bounded activations can add) <= 32752.
+				// (LeakyReLU models have no such bound on the added part: for them the limit only covers the linear path.)
+				{
+					const double room = std::max(1.0, 32752.0 - rangeAddMax);
+					plan.condLimit = (float)std::min(32752.0, std::max(1.0, room / std::max(1e-6, rangeGainMax)));
+				}
 				// fast instantiation of the kernel: K == 3 everywhere, every array fills its lane mode (G == Gp), 1x1 heads, weight blocks
 				// within the fixed 16 KB staging part
 				plan.splitFastT = 2;

@@ -39,6 +39,7 @@ namespace na
 		int stateF4 = 0;            // per-stream state in float4 units
 		int maxA4Floats = 0;        // largest per-stage A-operand block of the frame kernel (floats)
 		float headScale = 0.0f;
+		float condLimit = 32752.0f; // f16-split kernels: input samples are clamped to +-condLimit (range contract)
 		int receptiveField = 0;
 
 		// roofline bookkeeping: compulsory HBM bytes and MACs per sample at block N

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 def main():
     root = sys.argv[1]
-    pat = sys.argv[2] if len(sys.argv) > 2 else "WaveNetSplitKernel"
+    pat = sys.argv[2] if len(sys.argv) > 2 else "WaveNetSpecKernel"
     acc = defaultdict(list)
     for f in sorted(glob.glob(os.path.join(root, "pass*", "*counter_collection.csv"))):
         with open(f) as fh:

@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-KPAT=${2:-WaveNetSplitKernel}
+KPAT=${2:-WaveNetSpecKernel}
 shift; shift
 BARGS="$@"
 export NA_PMC_BENCH_ARGS="$BARGS"
