@@ -336,7 +336,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            # what the path computes in: f32 values and f32 accumulation; the WaveNet mat-muls of the f16-split kernels evaluate each f32
+            # product as three f16 x f16 MFMA products (22 mantissa bits); the recurrent and frame kernels are plain f32
+            "dtype": "f32 (f16x3-split MFMA, f32 accumulate)" if batch.StreamKernelName(0) in ("WaveNetSpecKernel", "WaveNetSplitKernel") else "f32",
             "data": "synthetic",
             "config": {
                 "workload": ("NAM A1 WaveNet 'Standard' (BossWN-standard.nam weights), %d batched streams per GPU, "

@@ -185,6 +185,7 @@ namespace na
 			int cg;          // channel group
 			unsigned img;    // LDS byte address of (plane cg, frame F0 + fl) in image 0 of this stream
 			unsigned aux;    // LDS byte address of the aux entry of frame F0 + fl (PK: of the stream owning channel group cg)
+			unsigned ring;   // byte offset of (frame fl, group cg) within a frame-major ring of this mode: (fl * GP + cg) * 16
 
 			__device__ __forceinline__ void Init(const Ctx& cx, int gs)
 			{
@@ -194,6 +195,7 @@ namespace na
 				fl = 16 * p + j;
 				const int f = 32 * cx.wave + fl;
 				img = (unsigned)(C::IMG_OFF + cx.sub * 2 * C::IMG_ONE + (cg * PLANE + GUARD + f) * 16);
+				ring = (unsigned)((fl * GP + cg) * 16);
 				if constexpr (C::PK) aux = (unsigned)(C::AUX_OFF + ((cx.sub * 4 + (cg >> gs)) * FRAMES + f) * 8);
 				else aux = (unsigned)(C::AUX_OFF + (cx.sub * FRAMES + f) * 16);
 			}
@@ -219,15 +221,23 @@ namespace na
 			u32x4 hist[2][2];  // ring history of the current layer's shifted taps [tap][set]
 		};
 
-		// ring position -> byte offset in the stream state: quad (ringOff + p * G + cg)
-		template <int G>
-		__device__ __forceinline__ int RingByte(int ringOff, int p, int cg) { return (int)(__umul24((unsigned)p, (unsigned)(G * 16)) + (unsigned)((ringOff + cg) * 16)); }
+		// Byte offset of ring position (base + fl) mod R, channel group cg, relative to the ring's start: `base` in [0, R) is wave-uniform, the
+		// lane part fl < 32 is folded into Lanes::ring, so the wrap is one unsigned min on the byte offset (3 VALU per access); the
+		// ring's start rides in the instruction's scalar offset.
+		template <int GP, int R>
+		__device__ __forceinline__ int RingWrap(unsigned laneRing, int base)
+		{
+			unsigned a = laneRing + (unsigned)base * (unsigned)(GP * 16);
+			return (int)__builtin_elementwise_min(a, a - (unsigned)(R * GP * 16));
+		}
 
 		// Ring history of layer L's shifted tap k for set i (frames before the block start).  One load instruction whatever the class --
 		// every wave issues the same number of VMEM operations per stage, so the vmcnt waits can be counted -- with an out-of-range
 		// offset where this wave (TAP_LDS) or this lane (TAP_BOTH, frames inside the block) needs nothing: such a load returns zeros.
+		// (The scalar offset of a buffer instruction is not part of its range check: an out-of-range vector offset drops the access, and
+		// so does the zero-sized resource of a shadow wave, whatever the scalar offset.)
 		template <class C, int L, int WR>
-		__device__ __forceinline__ u32x4 HistLoad(const Ctx& cx, int fl, int cg, int k, int i)
+		__device__ __forceinline__ u32x4 HistLoad(const Ctx& cx, unsigned laneRing, int fl, int k, int i)
 		{
 			typedef typename C::TB TB;
 			constexpr int GP = TB::GPof(TB::ArrOf(L)), P = Geo<GP>::P, R = TB::RingFrames(L), OFF = TB::RingOff(L);
@@ -238,11 +248,9 @@ namespace na
 			int base = pos0 - shift + 32 * cx.wave + 16 * P * i; // wave-uniform; in (-R, 2R)
 			if (base < 0) base += R;
 			if (base >= R) base -= R;
-			unsigned p = (unsigned)(base + fl);
-			p = __builtin_elementwise_min(p, p - (unsigned)R);
-			const int addr = RingByte<GP>(OFF, (int)p, cg);
-			if (cls == TAP_HIST) return RingLoad(cx.srsrc, addr);
-			return RingLoad(cx.srsrc, (32 * cx.wave + 16 * P * i + fl < shift) ? addr : OOB);
+			const int addr = RingWrap<GP, R>(laneRing, base);
+			if (cls == TAP_HIST) return RingLoad(cx.srsrc, addr, OFF * 16);
+			return RingLoad(cx.srsrc, (32 * cx.wave + 16 * P * i + fl < shift) ? addr : OOB, OFF * 16);
 		}
 
 		// does any wave of the block need the ring history of (layer L, tap k, set i)?  (wave 0 has the earliest frames)
@@ -265,14 +273,14 @@ namespace na
 		}
 
 		template <class C, int L, int WR>
-		__device__ __forceinline__ void HistPrefetch(const Ctx& cx, int fl, int cg, State& st)
+		__device__ __forceinline__ void HistPrefetch(const Ctx& cx, unsigned laneRing, int fl, State& st)
 		{
 			constexpr int S = Geo<C::TB::GPof(C::TB::ArrOf(L))>::S;
 #pragma unroll
 			for (int k = 0; k < 2; k++)
 #pragma unroll
 				for (int i = 0; i < S; i++)
-					if (HistNeeded<C, L>(k, i)) st.hist[k][i] = HistLoad<C, L, WR>(cx, fl, cg, k, i);
+					if (HistNeeded<C, L>(k, i)) st.hist[k][i] = HistLoad<C, L, WR>(cx, laneRing, fl, k, i);
 		}
 
 		// The input of layer LN (produced by the stage in front of it) -> the LDS image (in-block taps of LN, if it has any) and LN's HBM
@@ -306,11 +314,9 @@ namespace na
 			const int pos0 = __builtin_amdgcn_readlane(cx.myPos, LN);
 			int base = pos0 + 32 * cx.wave + 16 * P * i; // < 2R
 			if (base >= R) base -= R;
-			unsigned p = (unsigned)(base + ln.fl);
-			p = __builtin_elementwise_min(p, p - (unsigned)R);
-			const int addr = RingByte<GP>(OFF, (int)p, ln.cg);
-			if (KEEP >= C::NF) RingStore(cx.srsrc, v, addr);
-			else RingStore(cx.srsrc, v, (32 * cx.wave + 16 * P * i + ln.fl >= C::NF - KEEP) ? addr : OOB);
+			const int addr = RingWrap<GP, R>(ln.ring, base);
+			if (KEEP >= C::NF) RingStore(cx.srsrc, v, addr, OFF * 16);
+			else RingStore(cx.srsrc, v, (32 * cx.wave + 16 * P * i + ln.fl >= C::NF - KEEP) ? addr : OOB, OFF * 16);
 		}
 
 		// Stage s + 1's A operands -> the other LDS weight buffer by LDS-DMA (lane l's 16 bytes land at base + 16 l; no VGPRs, no ds_write),
@@ -402,7 +408,7 @@ namespace na
 				}
 			}
 			// history of the NEXT layer's shifted taps (the registers are free again)
-			if constexpr (SG::NEXT) HistPrefetch<C, SG::NEXT ? L + 1 : L, WR>(cx, ln.fl, ln.cg, st);
+			if constexpr (SG::NEXT) HistPrefetch<C, SG::NEXT ? L + 1 : L, WR>(cx, ln.ring, ln.fl, st);
 			{
 				// unshifted tap = the layer input itself (registers) and the aux operand: (mix-in, conv bias) * (cond, 1)   (:288-289, :471)
 				const u32x4 ah = WOp<C>(cx, s, 4), al = WOp<C>(cx, s, 5), xa = WOp<C>(cx, s, 6);
@@ -469,7 +475,7 @@ namespace na
 
 		// history prefetch of the first layer of an array (issued by the rechannel / link stage in front of it): per wave class
 		template <class C, int L, int W>
-		__device__ __forceinline__ void FirstHistDispatch(const Ctx& cx, int fl, int cg, State& st)
+		__device__ __forceinline__ void FirstHistDispatch(const Ctx& cx, unsigned laneRing, int fl, State& st)
 		{
 			typedef typename C::TB TB;
 			constexpr int P = Geo<TB::GPof(TB::ArrOf(L))>::P, S = Geo<TB::GPof(TB::ArrOf(L))>::S;
@@ -482,11 +488,11 @@ namespace na
 							for (int i = 0; i < S; i++) r = r && TapClassOf(32 * w, P, i, TB::Dil(L) * (2 - k)) == TapClassOf(32 * W, P, i, TB::Dil(L) * (2 - k));
 					return r;
 				}();
-				if constexpr (same) HistPrefetch<C, L, W>(cx, fl, cg, st);
+				if constexpr (same) HistPrefetch<C, L, W>(cx, laneRing, fl, st);
 				else
 				{
-					if (cx.wave == W) HistPrefetch<C, L, W>(cx, fl, cg, st);
-					else FirstHistDispatch<C, L, W + 1>(cx, fl, cg, st);
+					if (cx.wave == W) HistPrefetch<C, L, W>(cx, laneRing, fl, st);
+					else FirstHistDispatch<C, L, W + 1>(cx, laneRing, fl, st);
 				}
 			}
 		}
@@ -509,7 +515,7 @@ namespace na
 				st.xs[i] = SplitQuad(x);
 				Publish<C, 0, GP>(cx, ln, st.xs[i], i, 1);
 			}
-			FirstHistDispatch<C, 0, 0>(cx, ln.fl, ln.cg, st);
+			FirstHistDispatch<C, 0, 0>(cx, ln.ring, ln.fl, st);
 			Stager<C, 1>::template End<StoresOf<C, 0>() + HistLoadsOf<C, 0>()>();
 			BlockBarrier<C::NTHREADS / 64>();
 		}
@@ -556,7 +562,7 @@ namespace na
 				st.xs[i] = SplitQuad(xn[i]);
 				Publish<C, LN, GPN>(cx, ln, st.xs[i], i, (s + 1) & 1);
 			}
-			FirstHistDispatch<C, LN, 0>(cx, ln.fl, ln.cg, st);
+			FirstHistDispatch<C, LN, 0>(cx, ln.ring, ln.fl, st);
 			Stager<C, s + 1>::template End<StoresOf<C, LN>() + HistLoadsOf<C, LN>()>();
 			BlockBarrier<C::NTHREADS / 64>();
 		}

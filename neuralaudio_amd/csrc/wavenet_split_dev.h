@@ -48,8 +48,8 @@ namespace na
 		__device__ __forceinline__ void BufStore(__amdgpu_buffer_rsrc_t r, u32x4 v, int voff) { __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0); }
 		// ring traffic (streamed: every byte is read once, a launch or more after it was written; nt / sc0 / sc1 cache policies measured:
 		// nt 2-4 % slower, the others within noise -- default policy)
-		__device__ __forceinline__ u32x4 RingLoad(__amdgpu_buffer_rsrc_t r, int voff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0); }
-		__device__ __forceinline__ void RingStore(__amdgpu_buffer_rsrc_t r, u32x4 v, int voff) { __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0); }
+		__device__ __forceinline__ u32x4 RingLoad(__amdgpu_buffer_rsrc_t r, int voff, int soff = 0) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); }
+		__device__ __forceinline__ void RingStore(__amdgpu_buffer_rsrc_t r, u32x4 v, int voff, int soff = 0) { __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0); }
 
 		// ---- arithmetic -------------------------------------------------------------------------------------------------------
 

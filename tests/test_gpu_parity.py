@@ -244,10 +244,11 @@ def test_generic_keras_stack_files_match_committed_torch_vectors(na, loader):
         assert O.rms(y - g[name]) < 5e-6, (name, O.rms(y - g[name]))
 
 
-@pytest.mark.parametrize("amp", [30.0, 1000.0, 30000.0])
+@pytest.mark.parametrize("amp", [30.0, 1000.0, 10000.0])
 def test_hot_inputs_stay_within_tolerance_on_the_f16_split_path(na, loader, amp):
     """The f16-split kernel carries every value as f16 hi + lo parts (22 mantissa bits, f16 exponent range): inputs far outside the audio
-    range must still match the f32 oracle -- the condition enters through the aux operand, whose hi part is finite up to 65504."""
+    range must still match the f32 oracle -- up to the model's clamp limit (NA_BatchStreamInputLimit: 12 203 for this model, the bound
+    under which no split value can overflow; beyond it samples are clamped, tests/test_gpu_spec.py)."""
     m = loader.CreateFromFile(_model_path("BossWN-standard.nam"))
     x = (amp * np.sin(0.01 * np.arange(1024))).astype(np.float32)
     y = m.Process(x)
