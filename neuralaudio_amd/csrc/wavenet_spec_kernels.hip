@@ -175,7 +175,18 @@ namespace na
 			int wave, sub, waveAll;       // wave within the stream's block, stream within the workgroup (wave-uniform)
 			int lane;
 			int gs0, gs1;                 // packed launches: log2(channel groups per real stream) of array 0 / the other arrays
+#ifdef NA_SP_TRACE
+			long long* trace;             // tuning aid (make SUFFIX=_trace EXTRA=-DNA_SP_TRACE, tools/trace_split_timeline.py): nullptr unless this is the traced workgroup
+			int nwaves;
+#endif
 		};
+
+		// shader-clock stamps of one workgroup, trace[(stage * 8 + point) * waves + wave]; the scheduling barriers pin the stamp between the phases
+#ifdef NA_SP_TRACE
+#define SPK_STAMP(stage, point) do { __builtin_amdgcn_sched_barrier(0); if (cx.trace != nullptr && cx.lane == 0) cx.trace[(((stage) * 8 + (point)) * cx.nwaves) + cx.waveAll] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SPK_STAMP(stage, point) (void)0
+#endif
 
 		// per-lane values of one lane mode (recomputed at an array link)
 		template <class C, int GP>
@@ -365,6 +376,7 @@ namespace na
 			typedef LayerSig<C, L> SG;
 			constexpr int GP = SG::GP, P = SG::P, S = SG::S, d = SG::d, s = TB::StageOfLayer(L);
 			constexpr int imgRead = s & 1, imgWrite = (s + 1) & 1;
+			SPK_STAMP(s, 0);
 			Stager<C, s + 1>::Begin(cx);
 
 			u32x4 ax[S];
@@ -420,14 +432,20 @@ namespace na
 					acc[i] = Mfma(xa, ax[i], acc[i]);
 				}
 			}
+			SPK_STAMP(s, 1);
 			// activation (:473-480)
 			f32x4 z[S];
 #pragma unroll
 			for (int i = 0; i < S; i++)
 			{
-				const f32x2 lo = FastTanh2(f32x2{ acc[i].x, acc[i].y }), hi = FastTanh2(f32x2{ acc[i].z, acc[i].w });
-				z[i] = f32x4{ lo.x, lo.y, hi.x, hi.y };
+				if (NA_PK_TANH)
+				{
+					const f32x2 lo = FastTanh2(f32x2{ acc[i].x, acc[i].y }), hi = FastTanh2(f32x2{ acc[i].z, acc[i].w });
+					z[i] = f32x4{ lo.x, lo.y, hi.x, hi.y };
+				}
+				else z[i] = f32x4{ FastTanh(acc[i].x), FastTanh(acc[i].y), FastTanh(acc[i].z), FastTanh(acc[i].w) };
 			}
+			SPK_STAMP(s, 2);
 			// head accumulate (:482) on the matrix pipe: head += I (zh + zl); 1x1 + bias + residual (:486-491)
 			{
 				const u32x4 idop = LdsRead16((unsigned)C::IDOP_OFF + (unsigned)cx.lane * 16u);
@@ -452,9 +470,12 @@ namespace na
 					}
 				}
 			}
+			SPK_STAMP(s, 3);
 			// the DMA data must be in LDS before the closing barrier lets other waves read it
 			Stager<C, s + 1>::template End<(SG::NEXT ? HistLoadsOf<C, SG::NEXT ? L + 1 : L>() + StoresOf<C, SG::NEXT ? L + 1 : L>() : 0)>();
+			SPK_STAMP(s, 4);
 			BlockBarrier<C::NTHREADS / 64>();
+			SPK_STAMP(s, 5);
 		}
 
 		template <class C, int L, int W>
@@ -502,6 +523,7 @@ namespace na
 		__device__ __forceinline__ void RechStage(const Ctx& cx, const Lanes<C, C::TB::GPof(0)>& ln, State& st)
 		{
 			constexpr int GP = C::TB::GPof(0), S = Geo<GP>::S;
+			SPK_STAMP(0, 0);
 			Stager<C, 1>::Begin(cx);
 			const u32x4 ra = WOp<C>(cx, 0, 0);
 #pragma unroll
@@ -516,8 +538,11 @@ namespace na
 				Publish<C, 0, GP>(cx, ln, st.xs[i], i, 1);
 			}
 			FirstHistDispatch<C, 0, 0>(cx, ln.ring, ln.fl, st);
+			SPK_STAMP(0, 1); SPK_STAMP(0, 2); SPK_STAMP(0, 3);
 			Stager<C, 1>::template End<StoresOf<C, 0>() + HistLoadsOf<C, 0>()>();
+			SPK_STAMP(0, 4);
 			BlockBarrier<C::NTHREADS / 64>();
+			SPK_STAMP(0, 5);
 		}
 
 		// array link: previous array's head rechannel (K = 1, WaveNet.h:658-660) and this array's rechannel (:637), tile by tile; the
@@ -528,6 +553,7 @@ namespace na
 			typedef typename C::TB TB;
 			constexpr int GPO = TB::GPof(AN - 1), GPN = TB::GPof(AN), Po = 4 / GPO, Pn = 4 / GPN, NC = Po > Pn ? Po : Pn;
 			constexpr int So = Geo<GPO>::S, Sn = Geo<GPN>::S, s = TB::LinkStage(AN), LN = TB::FirstLayerOfArr(AN);
+			SPK_STAMP(s, 0);
 			Stager<C, s + 1>::Begin(cx);
 			u32x4 hs[So], xq[So];
 #pragma unroll
@@ -563,8 +589,11 @@ namespace na
 				Publish<C, LN, GPN>(cx, ln, st.xs[i], i, (s + 1) & 1);
 			}
 			FirstHistDispatch<C, LN, 0>(cx, ln.ring, ln.fl, st);
+			SPK_STAMP(s, 1); SPK_STAMP(s, 2); SPK_STAMP(s, 3);
 			Stager<C, s + 1>::template End<StoresOf<C, LN>() + HistLoadsOf<C, LN>()>();
+			SPK_STAMP(s, 4);
 			BlockBarrier<C::NTHREADS / 64>();
+			SPK_STAMP(s, 5);
 		}
 
 		// last array's head: out = scale * (W_h head + b)[0]  (WaveNet.h:658-660, :793-798); one output row per tile slot (PK: per stream)
@@ -623,7 +652,11 @@ namespace na
 		// has no static LDS), so every LDS offset of the chain is an instruction immediate.
 		template <class F, int NF, int SPB, bool PK>
 		__global__ void __launch_bounds__(64 * (NF / 32) * SPB) __attribute__((amdgpu_waves_per_eu(4))) WaveNetSpecKernel(const LaunchArgs args, const float* __restrict__ in,
-			float* __restrict__ out, long inStride, long outStride)
+			float* __restrict__ out, long inStride, long outStride
+#ifdef NA_SP_TRACE
+			, long long* __restrict__ trace, int traceBlock
+#endif
+			)
 		{
 			typedef Cfg<typename F::A0, NF, SPB, PK> C;
 			typedef Cfg<typename F::A1, NF, SPB, PK> C1;
@@ -655,6 +688,11 @@ namespace na
 			cx.wrsrc = MakeRsrc(ga.wsplit, (unsigned)ga.wsplitQuads * 16u);
 			cx.myPos = header[lane];
 			cx.wave = wave; cx.sub = sub; cx.waveAll = waveAll; cx.lane = lane;
+#ifdef NA_SP_TRACE
+			cx.trace = ((int)blockIdx.x == traceBlock) ? trace : nullptr;
+			cx.nwaves = C::NTHREADS / 64;
+			if (cx.trace != nullptr && lane == 0) cx.trace[((C::TB::NSTAGES * 8 + 0) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
+#endif
 			// packed: channel groups per real stream = (channels / pack) / 4 -> shift (1, 2, 4 -> 0, 1, 2)
 			const int pack = PK ? ga.pack : 1;
 			cx.gs0 = PK ? ((ga.gps0 >> 1) & 3) : 0;
@@ -713,6 +751,9 @@ namespace na
 			if (F::N > 1 && ga.arch == 1) RunArrays<C1, 0>(cx, st, out, (size_t)row * outStride, outRow, pack, ga.headScale, live);
 			else RunArrays<C, 0>(cx, st, out, (size_t)row * outStride, outRow, pack, ga.headScale, live);
 
+#ifdef NA_SP_TRACE
+			if (cx.trace != nullptr && lane == 0) cx.trace[((C::TB::NSTAGES * 8 + 1) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
+#endif
 			// advance every ring cursor by NF (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
 			if (wave == 0 && live && lane < ga.nrings)
 			{
@@ -790,7 +831,11 @@ namespace na
 					granted = true;
 				}
 			}
-			hipLaunchKernelGGL((WaveNetSpecKernel<F, NF, SPB, PK>), dim3((unsigned)blocks), dim3(64 * (NF / 32) * SPB), C::LDS_BYTES, stream, args, in, out, inStride, outStride);
+			hipLaunchKernelGGL((WaveNetSpecKernel<F, NF, SPB, PK>), dim3((unsigned)blocks), dim3(64 * (NF / 32) * SPB), C::LDS_BYTES, stream, args, in, out, inStride, outStride
+#ifdef NA_SP_TRACE
+				, GetWaveNetTraceBuffer(), []() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }()
+#endif
+				);
 			return hipGetLastError();
 		}
 
