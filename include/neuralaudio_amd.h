@@ -57,9 +57,19 @@ NA_EXTERN int NA_GetModelVersion(NeuralModel* model, char* buf, int bufSize);
 NA_EXTERN NA_Batch* NA_BatchCreate(int device, void* hipStream);
 NA_EXTERN void NA_BatchDestroy(NA_Batch* batch);
 /* Adds `count` streams running `model` (weights are shared on the device); returns the id (= row) of the
- * first one, ids are consecutive; negative on failure.  quality is used by SlimmableContainer models. */
+ * first one, ids are consecutive; negative on failure.  quality is used by SlimmableContainer models.
+ * Ids retired by NA_BatchRemoveStreams are recycled first: the lowest retired id for count == 1, a run of `count` consecutive retired
+ * ids when there is one; otherwise new rows are appended.  The device layout of a model's streams (e.g. narrow WaveNet models run
+ * several streams per kernel-level stream) does not depend on how the streams arrived: 4096 single adds == one add of 4096. */
 NA_EXTERN int NA_BatchAddStreams(NA_Batch* batch, NeuralModel* model, float quality, int count, int doPrewarm);
-NA_EXTERN int NA_BatchNumStreams(NA_Batch* batch);
+/* Stream lifetime = the reference's model lifetime (NeuralAudioCApi.cpp:38-42 DeleteModel): frees the device state of streams
+ * [first, first + count) for recycling and retires their ids.  Rows keep their place in the [streams][n] arrays -- input ignored, host
+ * output zero -- except trailing retired rows, which leave the arrays (check NA_BatchNumStreams afterwards).  Waits for the batch's
+ * stream; call it between buffers, not from the audio callback.  Fails (negative) on ids that are out of range or already removed. */
+NA_EXTERN int NA_BatchRemoveStreams(NA_Batch* batch, int first, int count);
+NA_EXTERN int NA_BatchNumStreams(NA_Batch* batch);     /* rows of the [streams][n] arrays, retired ids included */
+NA_EXTERN int NA_BatchNumLiveStreams(NA_Batch* batch);
+NA_EXTERN int NA_BatchIsLive(NA_Batch* batch, int stream);
 NA_EXTERN int NA_BatchSetQuality(NA_Batch* batch, int stream, float quality);
 NA_EXTERN int NA_BatchGetActiveSubModel(NA_Batch* batch, int stream);
 /* 1 when NA_BatchSetQuality(stream, quality) costs the next NA_BatchProcess* call no allocation / synchronisation / prewarm */

@@ -211,6 +211,16 @@ class Batch:
     def NumStreams(self):
         return int(self._lib.NA_BatchNumStreams(self._h))
 
+    def NumLiveStreams(self):
+        return int(self._lib.NA_BatchNumLiveStreams(self._h))
+
+    def IsLive(self, stream):
+        return bool(self._lib.NA_BatchIsLive(self._h, int(stream)))
+
+    def RemoveStreams(self, first, count=1):
+        if self._lib.NA_BatchRemoveStreams(self._h, int(first), int(count)) != 0:
+            raise NeuralAudioError(capi.last_error())
+
     def SetQuality(self, stream, q):
         if self._lib.NA_BatchSetQuality(self._h, int(stream), float(q)) != 0:
             raise NeuralAudioError(capi.last_error())

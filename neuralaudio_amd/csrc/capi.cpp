@@ -374,6 +374,16 @@ int NA_BatchAddStreams(NA_Batch* batch, NeuralModel* model, float quality, int c
 
 int NA_BatchNumStreams(NA_Batch* batch) { return batch ? batch->batch->NumStreams() : -1; }
 
+int NA_BatchNumLiveStreams(NA_Batch* batch) { return batch ? batch->batch->NumLiveStreams() : -1; }
+
+int NA_BatchIsLive(NA_Batch* batch, int stream) { return (batch && batch->batch->IsLive(stream)) ? 1 : 0; }
+
+int NA_BatchRemoveStreams(NA_Batch* batch, int first, int count)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->RemoveStreams(first, count); });
+}
+
 int NA_BatchSetQuality(NA_Batch* batch, int stream, float quality)
 {
 	if (!batch) return -1;

@@ -117,14 +117,34 @@ namespace na
 
 		const std::shared_ptr<const ModelDesc> desc;
 
+		// a state slot for a new stream: the lowest freed one, else a new one
 		int AddMember()
 		{
+			if (!freeMembers.empty())
+			{
+				const int member = freeMembers.front();
+				freeMembers.erase(freeMembers.begin());
+				memberInUse[(size_t)member] = 1;
+				return member;
+			}
 			const int member = (int)memberRow.size();
 			EnsureCapacity(member + 1);
 			EnsureListCapacity((size_t)member + 1);
 			memberRow.push_back(-1);
+			memberInUse.push_back(1);
 			return member;
 		}
+
+		// the stream is gone: its slot goes inactive and may be handed to a later AddMember (which resets it)
+		void RemoveMember(int member)
+		{
+			SetActive(member, -1);
+			memberInUse[(size_t)member] = 0;
+			freeMembers.insert(std::lower_bound(freeMembers.begin(), freeMembers.end(), member), member);
+		}
+
+		bool InUse(int member) const { return member >= 0 && (size_t)member < memberInUse.size() && memberInUse[(size_t)member] != 0; }
+		int NumInUse() const { return (int)memberRow.size() - (int)freeMembers.size(); }
 
 		// row >= 0: active, reads/writes that row of the batch arrays; row < 0: inactive (state frozen)
 		void SetActive(int member, int row)
@@ -144,6 +164,10 @@ namespace na
 		virtual double AlgorithmicBytesPerSample(int blockFrames) const = 0;
 		virtual double MacsPerSample() const = 0;
 		virtual size_t StateBytesPerStream() const = 0;
+		// Which launch of a buffer this group's streams ride in (GpuBatch::ProcessDevice): 0 frame kernel, 1 f16-split kernel, 2 f16-split
+		// kernel with packed streams, -1 split kernel, joins list 2 when the batch has one (else 1), 3 the fused LDS-free recurrent launch,
+		// -2 a launch of its own
+		virtual int LaunchClass() const { return -2; }
 		virtual int PackFactor() const { return 1; } // real streams per kernel-level stream (WaveNet stream packing)
 		virtual float InputLimit() const { return INFINITY; } // samples beyond +-limit are clamped by the kernel (f16-split WaveNet kernels)
 		virtual const char* KernelName() const = 0;  // the kernel that runs this group's streams (rocprof name, without template arguments)
@@ -190,17 +214,7 @@ namespace na
 			}
 			if (!hSlots.empty())
 			{
-				listFlip ^= 1;
-				int* pin = pinnedLists[listFlip];
-				// the copy issued from this buffer two switches ago: long finished unless the host is far ahead of the device
-				if (listEvent[listFlip]) CheckHip(hipEventSynchronize(listEvent[listFlip]), "hipEventSynchronize");
-				else CheckHip(hipEventCreateWithFlags(&listEvent[listFlip], hipEventDisableTiming), "hipEventCreate");
-				const size_t nA = hSlots.size();
-				memcpy(pin, hSlots.data(), nA * sizeof(int));
-				memcpy(pin + listCapacity, hRows.data(), nA * sizeof(int));
-				CheckHip(hipMemcpyAsync(dSlots.Get(), pin, nA * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
-				CheckHip(hipMemcpyAsync(dRows.Get(), pin + listCapacity, nA * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
-				CheckHip(hipEventRecord(listEvent[listFlip], stream), "hipEventRecord");
+				UploadLists();
 			}
 			contiguous = !hSlots.empty();
 			for (size_t i = 1; i < hSlots.size() && contiguous; i++)
@@ -211,9 +225,27 @@ namespace na
 	protected:
 		virtual void EnsureCapacity(int members) = 0;
 
-		// index lists (device + two pinned staging buffers) sized for every member: grown here, on the AddStreams side only
+		// hSlots / hRows -> the device lists through one of two pinned staging buffers, asynchronously on the batch stream.  Real-time
+		// safe: buffers and both events were created on the AddStreams side (EnsureListCapacity).
+		void UploadLists()
+		{
+			listFlip ^= 1;
+			int* pin = pinnedLists[listFlip];
+			// the copy issued from this buffer two switches ago: long finished unless the host is far ahead of the device
+			if (listUsed[listFlip]) CheckHip(hipEventSynchronize(listEvent[listFlip]), "hipEventSynchronize");
+			memcpy(pin, hSlots.data(), hSlots.size() * sizeof(int));
+			memcpy(pin + listCapacity, hRows.data(), hRows.size() * sizeof(int));
+			CheckHip(hipMemcpyAsync(dSlots.Get(), pin, hSlots.size() * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+			CheckHip(hipMemcpyAsync(dRows.Get(), pin + listCapacity, hRows.size() * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+			CheckHip(hipEventRecord(listEvent[listFlip], stream), "hipEventRecord");
+			listUsed[listFlip] = true;
+		}
+
+		// index lists (device + two pinned staging buffers + their events) sized for every member: grown here, on the AddStreams side only
 		void EnsureListCapacity(size_t members)
 		{
+			for (int b = 0; b < 2; b++)
+				if (!listEvent[b]) CheckHip(hipEventCreateWithFlags(&listEvent[b], hipEventDisableTiming), "hipEventCreate");
 			if (members <= listCapacity) return;
 			const size_t cap = std::max<size_t>(members, std::max<size_t>(listCapacity * 2, 64));
 			CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
@@ -228,6 +260,7 @@ namespace na
 			hSlots.reserve(cap);
 			hRows.reserve(cap);
 			listCapacity = cap;
+			listUsed[0] = listUsed[1] = false;
 			activeDirty = true;
 		}
 
@@ -235,10 +268,13 @@ namespace na
 		hipStream_t sideStream = nullptr;
 		hipEvent_t doneEvent = nullptr;
 		std::vector<int> memberRow; // member == state slot
+		std::vector<char> memberInUse; // 0: slot is on the free list
+		std::vector<int> freeMembers;  // sorted
 		std::vector<int> hSlots, hRows;
 		DevArray<int> dSlots, dRows;
 		int* pinnedLists[2] = { nullptr, nullptr }; // [slots | rows], listCapacity ints each
 		hipEvent_t listEvent[2] = { nullptr, nullptr };
+		bool listUsed[2] = { false, false };
 		size_t listCapacity = 0;
 		int listFlip = 0;
 		bool contiguous = false; // active streams are slot0+i / row0+i: kernels may skip the index arrays
@@ -283,12 +319,11 @@ namespace na
 		{
 		public:
 			// Stream packing (wavenet_plan.cpp PackWaveNetDesc): several streams of a NARROW model share one virtual stream of the f16-split
-			// kernel -- 4 streams for <= 4-channel arrays (Nano), 2 for <= 8 (Feather).  It pays once the virtual streams fill the chip
-			// (measured, 128-frame blocks: Nano 4096 streams 60.9 vs 112.6 us, 1366 38.8 vs 52.1; Feather 2048 43.6 vs 64.2, 1365 42.2 vs
-			// 60.2; but Nano 1024 36.6 vs 30.1 us, Feather 1024 36.1 vs 33.6 us: up to 1024 streams the unpacked launch is a single round
-			// of workgroups), and the state layout is fixed when the group is created, so the decision is taken from the size of the
-			// AddStreams call that creates it: more than 1024 streams.  Only for models that are not submodels of a slimmable
-			// container (`packHint` > 0: every member is always active).  NA_WN_PACK=0 never, =1 always.
+			// kernel -- 4 streams for <= 4-channel arrays (Nano), 2 for <= 8 (Feather).  With the compile-time specialised chains it wins at
+			// every batch size (measured, 128-frame blocks, us per step packed / f32 frame kernel: Nano 64 streams 19.5 / 24.5, 1024: 26.8 /
+			// 30.6, 4096: 61 / 113; Feather 64: 15.4 / 26.5, 1024: 24.3 / 33.6), so every static narrow model that is not a submodel of a
+			// slimmable container (`packHint` > 0: its members are always active) runs packed, whatever the AddStreams call pattern -- the
+			// state layout of a group never depends on how its streams arrived.  NA_WN_PACK=0 turns packing off.
 			static int PackFor(const WaveNetDesc& wn, int packHint)
 			{
 				static const int mode = getenv("NA_WN_PACK") ? atoi(getenv("NA_WN_PACK")) : -1;
@@ -298,8 +333,7 @@ namespace na
 				for (const WnArrayCfg& cfg : wn.arrays)
 					if (cfg.channels > 16) return 1;
 				const int P = WaveNetPackFactor(wn);
-				if (P < 2) return 1;
-				return (mode == 1 || packHint > 1024) ? P : 1;
+				return P < 2 ? 1 : P;
 			}
 
 			// Padding without packing (wavenet_plan.cpp WaveNetWantsPadding): a model whose arrays do not fill their lane mode (A1 Lite:
@@ -381,10 +415,28 @@ namespace na
 					// a member in position 0 opens a fresh virtual stream (cursors and every ring zero); the others only clear their own
 					// channel groups of a virtual stream that is already running
 					std::vector<int> slots, subs;
+					// (`members` is ascending: freed slots are handed out lowest first, new ones follow)
+					auto isNew = [&](int o) { return std::binary_search(members.begin(), members.end(), o); };
 					for (int m : members)
 					{
-						if (m % pack == 0)
-							CheckHip(hipMemsetAsync(state.Get() + (size_t)(m / pack) * (size_t)plan.stateF4 * 4, 0, (size_t)plan.stateF4 * 16, stream), "hipMemsetAsync");
+						// a virtual stream none of whose other members is running starts fresh: cursors and every ring zero (once, by its
+						// first new member); a member joining -- or recycling a position of -- a running virtual stream only clears its own
+						// channel groups and leaves cursors and neighbours alone
+						const int v0 = (m / pack) * pack;
+						bool fresh = true;
+						int firstNew = m;
+						for (int q = 0; q < pack; q++)
+						{
+							const int o = v0 + q;
+							if (o == m) continue;
+							if (isNew(o)) firstNew = std::min(firstNew, o);
+							else if (InUse(o)) fresh = false;
+						}
+						if (fresh)
+						{
+							if (m == firstNew)
+								CheckHip(hipMemsetAsync(state.Get() + (size_t)(m / pack) * (size_t)plan.stateF4 * 4, 0, (size_t)plan.stateF4 * 16, stream), "hipMemsetAsync");
+						}
 						else
 						{
 							slots.push_back(m / pack);
@@ -460,7 +512,7 @@ namespace na
 				if (family == WN_FAMILY_GENERIC) return false; // its own launch
 				// list 2 = the packed flavour of the split kernel; a plain group whose plan runs the fast flavour may join it (negative list:
 				// "1, or 2 if a packed group is in the batch" -- then it passes its index lists even when its streams are contiguous)
-				launchList = family == WN_FAMILY_SPLIT ? (pack > 1 ? 2 : (plan.splitFastT == 2 ? -1 : 1)) : 0;
+				launchList = LaunchClass();
 				out.pack = pack;
 				SyncActiveLists();
 				out.model = &dev;
@@ -477,6 +529,11 @@ namespace na
 			double AlgorithmicBytesPerSample(int blockFrames) const override { return (plan.isVirtual() ? realPlan : plan).AlgorithmicBytesPerSample(blockFrames); }
 			double MacsPerSample() const override { return (plan.isVirtual() ? realPlan : plan).MacsPerSample(); }
 			size_t StateBytesPerStream() const override { return (size_t)plan.stateF4 * 16 / (size_t)pack; }
+			int LaunchClass() const override
+			{
+				if (family == WN_FAMILY_GENERIC) return -2;
+				return family == WN_FAMILY_SPLIT ? (pack > 1 ? 2 : (plan.splitFastT == 2 ? -1 : 1)) : 0;
+			}
 			int PackFactor() const override { return pack; }
 			float InputLimit() const override { return family == WN_FAMILY_SPLIT ? plan.condLimit : INFINITY; }
 			const char* KernelName() const override
@@ -516,18 +573,7 @@ namespace na
 					hSlots.push_back((int)v);
 					for (int q = 0; q < pack; q++) hRows.push_back(rows[q]);
 				}
-				if (!hSlots.empty())
-				{
-					listFlip ^= 1;
-					int* pin = pinnedLists[listFlip];
-					if (listEvent[listFlip]) CheckHip(hipEventSynchronize(listEvent[listFlip]), "hipEventSynchronize");
-					else CheckHip(hipEventCreateWithFlags(&listEvent[listFlip], hipEventDisableTiming), "hipEventCreate");
-					memcpy(pin, hSlots.data(), hSlots.size() * sizeof(int));
-					memcpy(pin + listCapacity, hRows.data(), hRows.size() * sizeof(int));
-					CheckHip(hipMemcpyAsync(dSlots.Get(), pin, hSlots.size() * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
-					CheckHip(hipMemcpyAsync(dRows.Get(), pin + listCapacity, hRows.size() * sizeof(int), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
-					CheckHip(hipEventRecord(listEvent[listFlip], stream), "hipEventRecord");
-				}
+				if (!hSlots.empty()) UploadLists();
 				contiguous = false; // the packed kernel always reads the lists
 				activeDirty = false;
 			}
@@ -712,6 +758,11 @@ namespace na
 			}
 
 			size_t StateBytesPerStream() const override { return (size_t)numElems * sizeof(float); }
+			int LaunchClass() const override
+			{
+				static const bool noDpp = getenv("NA_LSTM_NO_DPP") != nullptr || getenv("NA_GRU_NO_DPP") != nullptr || getenv("NA_LSTM_LANE_KERNEL") != nullptr;
+				return (!noDpp && RecurrentDppSupported(dev)) ? 3 : -2;
+			}
 			const char* KernelName() const override
 			{
 				if (RecurrentDppSupported(dev)) return "RecurrentDppKernel";
@@ -810,18 +861,36 @@ namespace na
 		return AddStreams(model, quality, 1, prewarm, onDemand);
 	}
 
+	// ids for `count` new streams: retired ones first (the lowest for a single stream, a run of consecutive ones for several), else new rows
+	int GpuBatch::AllocateIds(int count)
+	{
+		for (size_t i = 0; i + (size_t)count <= retired.size(); i++)
+		{
+			if (retired[i + (size_t)count - 1] == retired[i] + count - 1)
+			{
+				const int first = retired[i];
+				retired.erase(retired.begin() + (long)i, retired.begin() + (long)i + count);
+				return first;
+			}
+		}
+		const int first = (int)streams.size();
+		streams.resize(streams.size() + (size_t)count);
+		for (int i = 0; i < count; i++) streams[(size_t)(first + i)].live = false;
+		return first;
+	}
+
 	int GpuBatch::AddStreams(const std::shared_ptr<const LoadedModel>& model, float quality, int count, bool prewarm, bool onDemand)
 	{
 		if (!model || model->subModels.empty()) throw std::runtime_error("neuralaudio_amd: AddStream with an empty model");
 		if (count < 1) throw std::runtime_error("neuralaudio_amd: AddStreams with count < 1");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		topologyVersion++;
-		const int first = (int)streams.size();
 		const int active = model->isComposite ? model->ModelIndexFromQuality(quality) : 0;
 		const size_t numSub = model->subModels.size();
 		std::vector<ModelGroup*> subGroups(numSub);
 		std::vector<std::vector<int>> newMembers(numSub);
 		for (size_t k = 0; k < numSub; k++) subGroups[k] = GroupFor(model->subModels[k].desc, (!model->isComposite && numSub == 1) ? count : 0);
+		const int first = AllocateIds(count);
 		for (int i = 0; i < count; i++)
 		{
 			StreamRef ref;
@@ -829,6 +898,7 @@ namespace na
 			ref.quality = quality;
 			ref.active = active;
 			ref.onDemand = onDemand;
+			ref.live = true;
 			ref.prewarmed.assign(numSub, 0);
 			const int row = first + i;
 			for (size_t k = 0; k < numSub; k++)
@@ -838,12 +908,13 @@ namespace na
 				ref.members.push_back({ subGroups[k], member });
 			}
 			ref.members[(size_t)active].first->SetActive(ref.members[(size_t)active].second, row);
-			streams.push_back(ref);
+			streams[(size_t)row] = ref;
 		}
 		// fresh state for every new member, then prewarm: every submodel (LoadAll, CompositeModel.h:111-118) or only the active one
 		// (OnDemand, :104-109 -- the others are prewarmed when a quality change first selects them, :52-60)
 		for (size_t k = 0; k < numSub; k++)
 		{
+			std::sort(newMembers[k].begin(), newMembers[k].end());
 			subGroups[k]->Reset(newMembers[k]);
 			const bool now = prewarm && (!onDemand || (int)k == active);
 			if (now) subGroups[k]->Prewarm(newMembers[k]);
@@ -852,9 +923,48 @@ namespace na
 		return first;
 	}
 
+	void GpuBatch::RemoveStreams(int first, int count)
+	{
+		if (count < 1 || first < 0 || (size_t)first + (size_t)count > streams.size()) throw std::runtime_error("neuralaudio_amd: RemoveStreams: id range outside the batch");
+		for (int i = 0; i < count; i++)
+			if (!streams[(size_t)(first + i)].live) throw std::runtime_error("neuralaudio_amd: RemoveStreams: stream was already removed");
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		// the slots may be handed out again right away: nothing of theirs may still be in flight
+		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		topologyVersion++;
+		for (int i = 0; i < count; i++)
+		{
+			StreamRef& ref = streams[(size_t)(first + i)];
+			for (auto& gm : ref.members) gm.first->RemoveMember(gm.second);
+			ref = StreamRef();
+			ref.live = false;
+			retired.insert(std::lower_bound(retired.begin(), retired.end(), first + i), first + i);
+		}
+		// trailing retired rows leave the arrays altogether
+		while (!streams.empty() && !streams.back().live)
+		{
+			retired.pop_back();
+			streams.pop_back();
+		}
+	}
+
+	unsigned GpuBatch::StreamPrewarmedMask(int s) const
+	{
+		const StreamRef& ref = streams.at((size_t)s);
+		unsigned mask = 0;
+		for (size_t k = 0; k < ref.prewarmed.size() && k < 32; k++) mask |= ref.prewarmed[k] ? (1u << k) : 0u;
+		return mask;
+	}
+
+	void GpuBatch::ZeroRetiredRows(float* hostRows, size_t n) const
+	{
+		for (int id : retired) memset(hostRows + (size_t)id * n, 0, n * sizeof(float));
+	}
+
 	void GpuBatch::SetQuality(int s, float quality)
 	{
 		StreamRef& ref = streams.at((size_t)s);
+		if (!ref.live) throw std::runtime_error("neuralaudio_amd: stream was removed");
 		ref.quality = quality;
 		if (!ref.model->isComposite) return;
 		const int idx = ref.model->ModelIndexFromQuality(quality);
@@ -873,18 +983,41 @@ namespace na
 		}
 	}
 
+	// How many launches a buffer takes once `leaving` has lost / `entering` has gained an active stream (ProcessDevice's grouping: the
+	// WaveNet launch lists, the fused recurrent launch, everything else on its own)
+	int GpuBatch::LaunchUnitsAfterSwitch(const ModelGroup* leaving, const ModelGroup* entering) const
+	{
+		bool lists[3] = { false, false, false }, joiner = false, rec = false;
+		int singles = 0;
+		for (const auto& g : groups)
+		{
+			int active = g->NumActive();
+			if (g.get() == leaving) active -= 1;
+			if (g.get() == entering) active += 1;
+			if (active <= 0) continue;
+			const int c = g->LaunchClass();
+			if (c >= 0 && c <= 2) lists[c] = true;
+			else if (c == -1) joiner = true;
+			else if (c == 3) rec = true;
+			else singles++;
+		}
+		if (joiner && !lists[2]) lists[1] = true; // plain fast-flavour split groups ride in the packed launch when there is one
+		return (int)lists[0] + (int)lists[1] + (int)lists[2] + (int)rec + singles;
+	}
+
+	// CompositeModel::IsModelChangeRealtimeSafe (CompositeModel.h:44-50, HadInitialPrewarm): false when the target submodel never had its
+	// prewarm -- the switch would prewarm it (OnDemand) or run it cold (a stream added without prewarm) -- and false when the batch
+	// would take several launches per buffer afterwards: those run as a captured hipGraph, which a switch re-captures.  Otherwise a
+	// switch only re-uploads two pinned index lists asynchronously.
 	bool GpuBatch::IsQualityChangeRealtimeSafe(int s, float quality) const
 	{
 		const StreamRef& ref = streams.at((size_t)s);
+		if (!ref.live) return false;
 		if (!ref.model->isComposite) return true;
 		const int idx = ref.model->ModelIndexFromQuality(quality);
 		if (idx == ref.active) return true;
-		if (ref.onDemand && !ref.prewarmed[(size_t)idx]) return false; // would prewarm (CompositeModel.h:44-50)
-		// a switch re-uploads two pinned index lists asynchronously; only a batch that forks several launch units per buffer has to
-		// re-capture its hipGraph
-		int units = 0;
-		for (const auto& g : groups) units += (g->NumActive() > 0 || g.get() == ref.members[(size_t)idx].first) ? 1 : 0;
-		return units <= 1 || allGroupsFuse;
+		if (!ref.prewarmed[(size_t)idx]) return false;
+		return LaunchUnitsAfterSwitch(ref.members[(size_t)ref.active].first, ref.members[(size_t)idx].first) <= 1;
 	}
 
 	float GpuBatch::GetQuality(int s) const { return streams.at((size_t)s).quality; }
@@ -894,6 +1027,7 @@ namespace na
 	{
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		StreamRef& ref = streams.at((size_t)s);
+		if (!ref.live) return;
 		// LoadAll: every submodel is prewarmed (CompositeModel.h:111-118); OnDemand: the current one (:104-109)
 		for (size_t k = 0; k < ref.members.size(); k++)
 		{
@@ -911,7 +1045,6 @@ namespace na
 		for (auto& g : groups) activeGroups += (g->NumActive() > 0);
 		if (activeGroups <= 1)
 		{
-			allGroupsFuse = true;
 			for (auto& g : groups) g->Process(dIn, dOut, inStride, outStride, n, stream);
 			return;
 		}
@@ -990,7 +1123,6 @@ namespace na
 		};
 		size_t units = (fusedRec.empty() ? 0 : 1) + singles.size();
 		for (int l = 0; l < NUM_WN_LISTS; l++) units += fusedWn[l].empty() ? 0 : 1;
-		allGroupsFuse = units == 1;
 		if (units == 1)
 		{
 			for (int l = 0; l < NUM_WN_LISTS; l++)
@@ -1092,6 +1224,7 @@ namespace na
 		CheckHip(hipMemcpyAsync(hostStage, devStage, total * sizeof(float), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H");
 		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 		memcpy(out, hostStage, total * sizeof(float));
+		ZeroRetiredRows(out, n);
 	}
 
 	void GpuBatch::EnsurePipeSlot(PipeSlot& p, size_t floats)
@@ -1166,6 +1299,7 @@ namespace na
 		if (ticket < 0 || ticket >= kPipelineSlots || !pipe[ticket].busy) throw std::runtime_error("neuralaudio_amd: Collect with an invalid ticket");
 		PipeSlot& p = pipe[ticket];
 		CheckHip(hipEventSynchronize(p.downloaded), "hipEventSynchronize");
+		if (!retired.empty()) ZeroRetiredRows(p.hostOut, p.n);
 		if (out) memcpy(out, p.hostOut, streams.size() * p.n * sizeof(float)); // nullptr: the caller reads OutputView() in place
 		p.busy = false;
 	}
@@ -1219,25 +1353,28 @@ namespace na
 	const char* GpuBatch::StreamKernelName(int s) const
 	{
 		const StreamRef& ref = streams.at((size_t)s);
+		if (!ref.live) return "";
 		return ref.members[(size_t)ref.active].first->KernelName();
 	}
 
 	float GpuBatch::StreamInputLimit(int s) const
 	{
 		const StreamRef& ref = streams.at((size_t)s);
+		if (!ref.live) return 0.0f;
 		return ref.members[(size_t)ref.active].first->InputLimit();
 	}
 
 	int GpuBatch::StreamPackFactor(int s) const
 	{
 		const StreamRef& ref = streams.at((size_t)s);
+		if (!ref.live) return 0;
 		return ref.members[(size_t)ref.active].first->PackFactor();
 	}
 
 	size_t GpuBatch::StateBytes() const
 	{
 		size_t total = 0;
-		for (const auto& g : groups) total += g->StateBytesPerStream() * (size_t)g->NumMembers();
+		for (const auto& g : groups) total += g->StateBytesPerStream() * (size_t)g->NumInUse();
 		return total;
 	}
 }

@@ -51,7 +51,18 @@ namespace na
 		// `count` streams of the same model at once (one state reset / prewarm launch per model group); returns the first id
 		int AddStreams(const std::shared_ptr<const LoadedModel>& model, float quality, int count, bool prewarm, bool onDemand = false);
 
-		int NumStreams() const { return (int)streams.size(); }
+		// Stream lifecycle (the reference's unit of lifetime is the model instance: NeuralAudioCApi.cpp:38-42 DeleteModel, CompositeModel.h:17-23):
+		// RemoveStreams frees the state slots of streams [first, first + count) in every model group (also inside packed virtual streams)
+		// and retires their ids; the rows keep their place in the [streams][n] arrays (input ignored, host-buffer output zero).  A later
+		// AddStreams recycles retired ids -- the lowest retired id for count == 1, a run of `count` consecutive retired ids if there is
+		// one -- before it appends new rows, and recycled state slots start from the same fresh / prewarmed state as new ones.
+		// Not real-time safe (like AddStreams): call between buffers.
+		void RemoveStreams(int first, int count);
+		bool IsLive(int stream) const { return stream >= 0 && stream < (int)streams.size() && streams[(size_t)stream].live; }
+
+		int NumStreams() const { return (int)streams.size(); } // rows of the [streams][n] arrays (retired ids included)
+		int NumLiveStreams() const { return (int)streams.size() - (int)retired.size(); }
+		unsigned StreamPrewarmedMask(int stream) const; // bit k: submodel k of the stream had its prewarm
 
 		// ScalableCompositeModel::SetQualityScaleFactor (CompositeModel.h:176-181): switches the active submodel,
 		// the inactive one keeps its state untouched.
@@ -106,9 +117,13 @@ namespace na
 			int active = 0;
 			float quality = 1.0f;
 			bool onDemand = false;
+			bool live = true;
 			std::vector<char> prewarmed; // per submodel: had its initial prewarm
 		};
-		bool allGroupsFuse = false; // set by ProcessDevice: the batch runs as ONE launch per buffer (no hipGraph involved)
+		std::vector<int> retired; // sorted ids of removed streams
+		int AllocateIds(int count);
+		int LaunchUnitsAfterSwitch(const ModelGroup* leaving, const ModelGroup* entering) const;
+		void ZeroRetiredRows(float* hostRows, size_t n) const;
 
 		ModelGroup* GroupFor(const std::shared_ptr<const ModelDesc>& desc, int packHint = 0);
 		void EnsureStaging(size_t floats);

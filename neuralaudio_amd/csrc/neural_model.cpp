@@ -46,21 +46,26 @@ namespace NeuralAudio
 		fresh->AddStream(model, appliedQuality, prewarmPending, onDemand);
 		batch = std::move(fresh);
 		prewarmPending = false;
+		PublishPrewarmState();
 	}
+
+	void GpuModel::PublishPrewarmState() { prewarmedMask.store(batch->StreamPrewarmedMask(0)); }
 
 	bool GpuModel::HasQualityScaling() { return model->isComposite; }
 
 	float GpuModel::GetQualityScaleFactor() { return model->isComposite ? quality.load() : 1.0f; }
 
-	// CompositeModel::IsModelChangeRealtimeSafe (CompositeModel.h:44-50): a switch to a submodel that already had its prewarm only
-	// re-uploads two pinned index lists asynchronously on the next Process() (no allocation, no synchronisation); in OnDemand mode
-	// the first switch to a submodel prewarms it, which is not real-time safe.  Before any device state exists there is nothing to
-	// switch yet (the first Process()/Prewarm() builds it, and that call is the non-real-time one).
+	// CompositeModel::IsModelChangeRealtimeSafe (CompositeModel.h:44-50): safe when the target submodel already had its prewarm
+	// (HadInitialPrewarm) -- then the switch only re-uploads two pinned index lists asynchronously on the next Process(): no allocation,
+	// no synchronisation, and a one-stream batch always runs as one launch.  In OnDemand mode the first switch to a submodel prewarms it;
+	// a model created without prewarm has no prewarmed submodel at all.  Like the setter this may be called from any thread: it reads
+	// atomics only (the audio thread publishes the prewarm state after every call that can change it).
 	bool GpuModel::IsQualityChangeRealtimeSafe(float newScaleFactor)
 	{
 		if (!model->isComposite) return true;
-		if (!batch) return !onDemand || model->ModelIndexFromQuality(newScaleFactor) == activeIndex.load();
-		return batch->IsQualityChangeRealtimeSafe(0, newScaleFactor);
+		const int idx = model->ModelIndexFromQuality(newScaleFactor);
+		if (idx == activeIndex.load()) return true;
+		return idx >= 0 && idx < 32 && ((prewarmedMask.load() >> idx) & 1u) != 0;
 	}
 
 	// May be called from another thread than Process(): stores only (see neural_model_impl.h)
@@ -77,6 +82,7 @@ namespace NeuralAudio
 		if (q == appliedQuality) return;
 		appliedQuality = q;
 		batch->SetQuality(0, q);
+		PublishPrewarmState();
 	}
 
 	bool GpuModel::IsStatic()
@@ -109,6 +115,7 @@ namespace NeuralAudio
 		}
 		ApplyPendingQuality();
 		batch->Prewarm(0);
+		PublishPrewarmState();
 	}
 
 	// ------------------------------------------------------------------------------------------ loader

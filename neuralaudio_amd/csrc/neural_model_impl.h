@@ -43,6 +43,10 @@ namespace NeuralAudio
 		// setter only stores; the audio thread applies the switch at the top of its next Process().
 		std::atomic<float> quality{ 1.0f };
 		std::atomic<int> activeIndex{ 0 };
+		// bit k: submodel k had its prewarm (CompositeModel::HadInitialPrewarm).  Written by the audio thread after it touched the batch,
+		// read by IsQualityChangeRealtimeSafe() from any thread -- which therefore never looks at the batch itself.
+		std::atomic<unsigned> prewarmedMask{ 0 };
+		void PublishPrewarmState(); // audio thread
 		float appliedQuality = 1.0f; // audio thread only
 		bool onDemand = false;
 		bool prewarmPending;

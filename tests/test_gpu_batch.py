@@ -382,8 +382,22 @@ def test_ondemand_composite_load_mode(na):
     assert O.rms(y1 - O.oracle_from_file("BossWN-a2.nam", quality=1.0).process(x[:256])) < TOL_RMS
     assert O.rms(y0 - O.oracle_from_file("BossWN-a2.nam", quality=0.0).process(x[256:])) < TOL_RMS
     la = na.NeuralModelLoader().CreateFromFile(_path("BossWN-a2.nam"))
+    assert la.IsQualityChangeRealtimeSafe(0.1)  # LoadAll: everything prewarmed at load -- also before the first Process()
     la.Process(x[:128])
-    assert la.IsQualityChangeRealtimeSafe(0.1)  # LoadAll: everything prewarmed at load
+    assert la.IsQualityChangeRealtimeSafe(0.1)
+    # HadInitialPrewarm (CompositeModel.h:44-50) in LoadAll mode too: a model created WITHOUT prewarm has no prewarmed submodel to switch to
+    cold = na.NeuralModelLoader().CreateFromFile(_path("BossWN-a2.nam"), doPrewarm=False)
+    assert cold.IsQualityChangeRealtimeSafe(1.0) and not cold.IsQualityChangeRealtimeSafe(0.1)
+    cold.Process(x[:128])
+    assert not cold.IsQualityChangeRealtimeSafe(0.1)
+    cold.Prewarm()
+    assert cold.IsQualityChangeRealtimeSafe(0.1)
+    # a mixed batch that takes several launches per buffer re-captures its hipGraph on a switch: reported as not real-time safe
+    b = na.Batch(0)
+    b.AddStreams(la, 2, quality=1.0)
+    assert b.IsQualityChangeRealtimeSafe(0, 0.1)  # both submodels ride in one frame-kernel launch
+    b.AddStreams(na.NeuralModelLoader().CreateFromFile(_path("BossLSTM-1x16.nam")), 1)
+    assert not b.IsQualityChangeRealtimeSafe(0, 0.1)  # WaveNet launch + recurrent launch: two units
 
 
 def test_quality_setter_from_another_thread(na, loader):

@@ -74,7 +74,8 @@ def test_lstm_shapes_beyond_the_official_ones(na, hidden, layers):
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_random_batch_operations_track_per_stream_oracles(na, seed):
     """A stateful walk over the batch API: streams of four model kinds join at random times (prewarmed or fresh), A2 streams switch
-    quality mid-run, single streams are re-prewarmed, buffer sizes are ragged -- every stream must keep matching its own oracle,
+    quality mid-run, single streams are re-prewarmed, streams LEAVE and their ids / state slots are recycled by later joins (also
+    inside packed virtual streams of the narrow models), buffer sizes are ragged -- every stream must keep matching its own oracle,
     which is driven through the same sequence.  (CompositeModel.h:94-100,176-181 semantics for the quality switch: the active
     submodel processes, the inactive one's state stays frozen.)"""
     import json
@@ -108,20 +109,28 @@ def test_random_batch_operations_track_per_stream_oracles(na, seed):
             return self.subs[self.active].process(x)
 
     b = na.Batch(0)
-    refs = []
+    refs = []  # row -> Ref, None for a retired id
     worst = 0.0
-    for step in range(14):
-        op = rng.integers(0, 4) if refs else 0
-        if op == 0 or len(refs) < 3:  # add 1-3 streams of a random kind
+    for step in range(18):
+        live = [i for i, r in enumerate(refs) if r is not None]
+        op = rng.integers(0, 5) if live else 0
+        if op == 0 or len(live) < 3:  # add 1-3 streams of a random kind: retired ids are recycled first, new rows are appended otherwise
             kind = str(rng.choice(list(models)))
             q = float(rng.choice([0.0, 0.3, 0.5, 0.51, 1.0]))
             pre = bool(rng.integers(0, 2))
             count = int(rng.integers(1, 4))
+            holes = [i for i, r in enumerate(refs) if r is None]
+            runs = [h for h in holes if all((h + k) in holes for k in range(count))]
+            expect = runs[0] if runs else len(refs)
             first = b.AddStreams(models[kind], count, quality=q, doPrewarm=pre)
-            assert first == len(refs)
-            refs.extend(Ref(kind, q, pre) for _ in range(count))
+            assert first == expect, (first, expect, holes, count)
+            for k in range(count):
+                if first + k < len(refs):
+                    refs[first + k] = Ref(kind, q, pre)
+                else:
+                    refs.append(Ref(kind, q, pre))
         elif op == 1:  # quality switch on a random A2 stream
-            idx = [i for i, r in enumerate(refs) if r.kind == "a2"]
+            idx = [i for i in live if refs[i].kind == "a2"]
             if idx:
                 i = int(rng.choice(idx))
                 q = float(rng.choice([0.0, 0.5, 0.75, 1.0]))
@@ -129,15 +138,26 @@ def test_random_batch_operations_track_per_stream_oracles(na, seed):
                 refs[i].active = O.quality_to_submodel(a2json, q)
                 assert b.GetActiveSubModel(i) == refs[i].active
         elif op == 2:  # re-prewarm one stream (all of its submodels, like NeuralModel::Prewarm on a LoadAll composite)
-            i = int(rng.integers(0, len(refs)))
+            i = int(rng.choice(live))
             b.Prewarm(i)
             for sub in refs[i].subs:
                 sub.prewarm()
+        elif op == 3 and len(live) > 3:  # a stream leaves (NeuralAudioCApi.cpp:38-42 DeleteModel): its id is retired, its state slots are recycled
+            i = int(rng.choice(live))
+            b.RemoveStreams(i, 1)
+            refs[i] = None
+            while refs and refs[-1] is None:  # trailing retired rows leave the arrays
+                refs.pop()
+            assert b.NumStreams() == len(refs) and b.NumLiveStreams() == sum(r is not None for r in refs)
+            assert i >= len(refs) or not b.IsLive(i)
         n = int(rng.choice([1, 31, 64, 100, 128, 129, 300]))
         x = np.stack([O.signal_noise(n, 10000 * seed + 100 * step + s) for s in range(len(refs))])
         y = b.Process(x)
         for s, r in enumerate(refs):
+            if r is None:
+                assert not np.any(y[s]), (step, s)  # a retired row reads as silence
+                continue
             err = O.rms(y[s] - r.process(x[s]))
             worst = max(worst, err)
             assert err < 5e-6, (step, s, r.kind, err)
-    assert len(refs) >= 3
+    assert sum(r is not None for r in refs) >= 3

@@ -138,8 +138,8 @@ def test_default_kernel_family_and_pack_factor_of_every_official_architecture(na
     expect = {
         "standard": ("WaveNetSpecKernel", 1),
         "lite": ("WaveNetSpecKernel", 1),                                            # padded to 16 / 8 channels
-        "feather": ("WaveNetSpecKernel", 2) if streams > 1024 else ("WaveNetFrameKernel", 1),
-        "nano": ("WaveNetSpecKernel", 4) if streams > 1024 else ("WaveNetFrameKernel", 1),
+        "feather": ("WaveNetSpecKernel", 2),                                         # narrow static models always run packed
+        "nano": ("WaveNetSpecKernel", 4),
         "a2": ("WaveNetFrameKernel", 1),
         "lstm1x16": ("RecurrentDppKernel", 1),
         "lstm2x8": ("RecurrentDppKernel", 1),
@@ -231,3 +231,58 @@ def test_out_of_range_samples_are_clamped_and_the_stream_recovers(na, loader, ba
         yh = _run(b, xh[None, :], [128] * 40)[0]
         yo = O.oracle_from_file("BossWN-standard.nam").process(xh)
         assert O.rms(yh - yo) < 2e-5 * max(1.0, O.rms(yo))  # (values of 3e4 carry 7e-3 absolute error at 22 bits, 2e-3 at 24)
+
+
+@pytest.mark.skipif(FORCED, reason="forced kernel family")
+def test_layout_does_not_depend_on_the_add_pattern_and_slots_are_recycled(na, loader):
+    """4096 Nano streams added ONE BY ONE run packed like one bulk add (same pack factor, same kernel, same outputs, same speed class);
+    streams that leave free their positions inside the virtual streams, later joins recycle ids and positions and start from a fresh
+    prewarmed state while their neighbours carry on."""
+    import time
+    m = loader.CreateFromFile(_path("BossWN-nano.nam"), doPrewarm=False)
+    S = 4096
+    rng = np.random.default_rng(9)
+    base = (0.3 * rng.standard_normal((5, 128 * 3))).clip(-1, 1).astype(np.float32)
+    x = base[np.arange(S) % 5]
+    one = na.Batch(0)
+    for s in range(S):
+        assert one.AddStreams(m, 1) == s
+    bulk = na.Batch(0)
+    bulk.AddStreams(m, S)
+    assert one.StreamPackFactor(0) == one.StreamPackFactor(S - 1) == bulk.StreamPackFactor(0) == 4
+    assert one.StreamKernelName(S - 1) == bulk.StreamKernelName(0) == "WaveNetSpecKernel"
+    assert one.StateBytes() == bulk.StateBytes()
+    ya, yb = _run(one, x, [128, 128, 128]), _run(bulk, x, [128, 128, 128])
+    assert np.array_equal(ya, yb)
+
+    def timed(b):
+        xb = np.ascontiguousarray(x[:, :128])
+        for _ in range(5):
+            b.Process(xb)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            b.Process(xb)
+        return (time.perf_counter() - t0) / 20
+    ta, tb = timed(one), timed(bulk)
+    assert ta < 1.25 * tb + 50e-6, (ta, tb)  # (host-buffer calls: copies dominate; the launches are the same)
+    bulk.close()
+
+    # leave / rejoin: ids 5, 6 (positions 1, 2 of virtual stream 1), a whole virtual stream (8..11), and the last id
+    b = one
+    fresh = O.oracle_from_file("BossWN-nano.nam")
+    keep = O.oracle_from_file("BossWN-nano.nam")
+    keep.process(x[4][:384])
+    keep.process(x[4][:128])  # (stream 4 also went through the 25 timing buffers of x[:, :128])
+    for _ in range(24):
+        keep.process(x[4][:128])
+    b.RemoveStreams(5, 2)
+    b.RemoveStreams(8, 4)
+    b.RemoveStreams(S - 1, 1)
+    assert b.NumStreams() == S - 1 and b.NumLiveStreams() == S - 7
+    assert b.AddStreams(m, 1) == 5 and b.AddStreams(m, 4) == 8 and b.AddStreams(m, 1) == 6 and b.AddStreams(m, 2) == S - 1
+    assert b.NumStreams() == S + 1 and b.NumLiveStreams() == S + 1
+    x2 = (0.3 * rng.standard_normal((S + 1, 128))).clip(-1, 1).astype(np.float32)
+    y2 = b.Process(x2)
+    for s in (5, 6, 8, 11, S - 1, S):
+        assert O.rms(y2[s] - O.oracle_from_file("BossWN-nano.nam").process(x2[s])) < TOL_RMS, s  # recycled: fresh prewarmed state
+    assert O.rms(y2[4] - keep.process(x2[4])) < TOL_RMS  # the neighbour in virtual stream 1 never noticed
