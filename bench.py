@@ -244,13 +244,41 @@ def main():
     tstream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream handle
     torch.cuda.set_stream(tstream)
     batch = na.Batch(local_rank, hip_stream=tstream.cuda_stream)
-    if args.workload == "config5":
-        # quality sweep 0 -> 1 over the streams: half run the 3-channel submodel, half the 8-channel one
-        for q in (0.0, 0.25, 0.5, 0.75, 1.0, 0.1, 0.6, 0.9):
-            batch.AddStreams(models[0], S // 8, quality=q)
+    # The stream list of the workload as (model, quality, count) entries, architecture-sorted.  One GPU (or the headline workload):
+    # every rank runs its own S streams (weak scaling).  Mixed workloads on several GPUs: the entries describe the GLOBAL list of
+    # S x world streams, which is cut by cost into one contiguous range per rank -- NA_ShardByCost, the C++ host's partition
+    # (csrc/multi_gpu.cpp) -- so a rank that gets the expensive models gets fewer streams; no rank sees the same mix.
+    def entries_for(total):
+        if args.workload == "config5":
+            # quality sweep 0 -> 1 over the streams: half run the 3-channel submodel, half the 8-channel one
+            qs = (0.0, 0.1, 0.25, 0.5, 0.6, 0.75, 0.9, 1.0)
+            return [(models[0], q, total // 8 + (1 if k < total % 8 else 0)) for k, q in enumerate(qs)]
+        return [(mdl, quality, total // len(models) + (1 if k < total % len(models) else 0)) for k, mdl in enumerate(models)]
+
+    shard_info = None
+    if distributed and len(entries_for(8)) > 1:
+        from neuralaudio_amd import capi
+        from neuralaudio_amd.sharding import shard_ranges
+        lib = capi.load_library()
+        entries = entries_for(S * world)
+        costs = []
+        for mdl, q, c in entries:
+            costs += [float(lib.NA_ModelStreamCost(mdl._h, float(q)))] * c
+        ranges = shard_ranges(costs, world)
+        a, b = ranges[rank]
+        first = 0
+        for mdl, q, c in entries:
+            lo, hi = max(first, a), min(first + c, b)
+            if hi > lo:
+                batch.AddStreams(mdl, hi - lo, quality=q)
+            first += c
+        S_global = S * world
+        S = b - a
+        shard_info = {"global_streams": S_global, "ranges": [list(r) for r in ranges], "cost_per_rank": [round(sum(costs[r0:r1]), 1) for r0, r1 in ranges]}
     else:
-        for k, mdl in enumerate(models):
-            batch.AddStreams(mdl, S // len(models) + (1 if k < S % len(models) else 0), quality=quality)
+        S_global = S * world
+        for mdl, q, c in entries_for(S):
+            batch.AddStreams(mdl, c, quality=q)
 
     # synthetic 48 kHz buffers (bench-C of SURVEY 8d): clip(0.25*N(0,1), +-1), per-rank seed; a ring of 8 distinct buffers
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -305,8 +333,8 @@ def main():
     finite = bool(torch.isfinite(y).all().item())
 
     if rank == 0:
-        samples_per_step = S * BLOCK
-        total_samples = samples_per_step * args.steps * world
+        samples_per_step = S * BLOCK                      # this rank's launch (roofline bookkeeping)
+        total_samples = S_global * BLOCK * args.steps     # whole job
         value = total_samples / elapsed / 1e6  # Msamples/s, whole job
         bytes_per_sample = batch.AlgorithmicBytesPerSample(BLOCK)
         flops_per_sample = 2.0 * batch.MacsPerSample()
@@ -347,6 +375,8 @@ def main():
                 "streams_per_gpu": S,
                 "block": BLOCK,
                 "parallelism": "independent streams sharded across %d GPU(s), no data-path collective" % world,
+                # mixed workloads on several GPUs: the global list cut by cost (NA_ShardByCost), [begin, end) per rank
+                "shards": shard_info,
             },
             "realtime_streams_48k": value * 1e6 / 48000.0,
             "msamples_per_s_per_gpu": value / world,

@@ -99,6 +99,29 @@ NA_EXTERN double NA_BatchStateBytes(NA_Batch* batch);
 NA_EXTERN int NA_BatchStreamPackFactor(NA_Batch* batch, int stream);
 /* the kernel that runs the stream (its rocprof name without template arguments; static string, "" on a bad argument) */
 NA_EXTERN const char* NA_BatchStreamKernelName(NA_Batch* batch, int stream);
+/* ---- multi-GPU host: one batch + one host thread + one HIP stream per device ------------------------------------------------
+ * The GLOBAL stream list (order of the NA_MultiAddStreams calls: sort it by architecture) is cut into contiguous ranges of near-equal
+ * cost, one per entry of `devices` (an index may repeat).  Streams are independent (the reference runs one NeuralModel per stream,
+ * NeuralModel.h:127), so there is no data-path collective: every shard uploads, processes and downloads its own rows of the caller's
+ * [streams][n] arrays. */
+typedef struct NA_MultiBatch NA_MultiBatch;
+NA_EXTERN NA_MultiBatch* NA_MultiCreate(const int* devices, int numDevices);
+NA_EXTERN void NA_MultiDestroy(NA_MultiBatch* multi);
+NA_EXTERN int NA_MultiAddStreams(NA_MultiBatch* multi, NeuralModel* model, float quality, int count, int doPrewarm); /* first global id */
+NA_EXTERN int NA_MultiCommit(NA_MultiBatch* multi);   /* shard + create the device state (implied by the first Process / Submit) */
+NA_EXTERN int NA_MultiNumStreams(NA_MultiBatch* multi);
+NA_EXTERN int NA_MultiNumShards(NA_MultiBatch* multi);
+NA_EXTERN int NA_MultiShardRange(NA_MultiBatch* multi, int shard, int* begin, int* end, int* device);
+NA_EXTERN int NA_MultiProcess(NA_MultiBatch* multi, const float* in, float* out, size_t n);   /* host [streams][n]; synchronous */
+NA_EXTERN int NA_MultiSubmit(NA_MultiBatch* multi, const float* in, size_t n);                /* pipelined, like NA_BatchSubmit */
+NA_EXTERN int NA_MultiCollect(NA_MultiBatch* multi, int ticket, float* out);
+NA_EXTERN int NA_MultiSetQuality(NA_MultiBatch* multi, int stream, float quality);
+/* the partition itself: bounds[0 .. parts] of contiguous ranges of items [0, n) with near-equal total cost (every range keeps at least
+ * one item while items remain).  One-process-per-GPU hosts (bench.py over torch.distributed / RCCL) call it with their rank. */
+NA_EXTERN int NA_ShardByCost(const double* cost, int n, int parts, int* bounds);
+/* relative cost of one stream of `model` at `quality` (what the sharder balances): estimated microseconds per 1024 streams x 128 frames */
+NA_EXTERN double NA_ModelStreamCost(NeuralModel* model, float quality);
+
 /* Range contract of the kernel that runs the stream: input samples beyond +-limit are clamped, NaN reads as silence.  +inf for the f32
  * kernels (they follow the reference's f32 chain at any amplitude); a per-model bound <= 32752 for the f16-split WaveNet kernels, whose
  * values carry an f16 exponent -- far above any audio level (0 on a bad argument). */

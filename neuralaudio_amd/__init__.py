@@ -13,7 +13,7 @@ import numpy as np
 
 from . import capi
 
-__all__ = ["NeuralModelLoader", "NeuralModel", "Batch", "EModelLoadMode", "EMathMode", "ECompositeModelLoadMode", "device_count",
+__all__ = ["NeuralModelLoader", "NeuralModel", "Batch", "MultiBatch", "EModelLoadMode", "EMathMode", "ECompositeModelLoadMode", "device_count",
            "NeuralAudioError"]
 
 
@@ -313,6 +313,63 @@ class Batch:
     def close(self):
         if self._h:
             self._lib.NA_BatchDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiBatch:
+    """The C++ multi-GPU host (csrc/multi_gpu.cpp): one batch + one host thread per entry of `devices`, the global stream list sharded
+    across them by cost.  Rows of the [streams][n] arrays are global stream ids."""
+
+    def __init__(self, devices):
+        self._lib = capi.load_library()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = self._lib.NA_MultiCreate(arr, len(devices))
+        if not self._h:
+            raise NeuralAudioError(capi.last_error())
+
+    def AddStreams(self, model, count=1, quality=1.0, doPrewarm=True):
+        first = self._lib.NA_MultiAddStreams(self._h, model._h, float(quality), int(count), 1 if doPrewarm else 0)
+        if first < 0:
+            raise NeuralAudioError(capi.last_error())
+        return first
+
+    def Commit(self):
+        if self._lib.NA_MultiCommit(self._h) != 0:
+            raise NeuralAudioError(capi.last_error())
+
+    def NumStreams(self):
+        return int(self._lib.NA_MultiNumStreams(self._h))
+
+    def ShardRanges(self):
+        out = []
+        for s in range(int(self._lib.NA_MultiNumShards(self._h))):
+            b, e, d = C.c_int(), C.c_int(), C.c_int()
+            if self._lib.NA_MultiShardRange(self._h, s, C.byref(b), C.byref(e), C.byref(d)) != 0:
+                raise NeuralAudioError(capi.last_error())
+            out.append((b.value, e.value, d.value))
+        return out
+
+    def Process(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.ndim == 2 and x.shape[0] == self.NumStreams(), "expected [streams, n]"
+        y = np.empty_like(x)
+        if self._lib.NA_MultiProcess(self._h, _fptr(x), _fptr(y), x.shape[1]) != 0:
+            raise NeuralAudioError(capi.last_error())
+        return y
+
+    def SetQuality(self, stream, q):
+        if self._lib.NA_MultiSetQuality(self._h, int(stream), float(q)) != 0:
+            raise NeuralAudioError(capi.last_error())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.NA_MultiDestroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "neuralaudio_amd.h"
+#include "multi_gpu.h"
 #include "neural_model_impl.h"
 #include "wavenet_launch.h"
 #include "wavenet_plan.h"
@@ -23,6 +24,11 @@ struct NeuralModelLoader
 struct NA_Batch
 {
 	na::GpuBatch* batch;
+};
+
+struct NA_MultiBatch
+{
+	na::MultiGpuBatch* multi;
 };
 
 namespace
@@ -477,6 +483,104 @@ float NA_BatchStreamInputLimit(NA_Batch* batch, int stream)
 {
 	try { return batch ? batch->batch->StreamInputLimit(stream) : 0.0f; }
 	catch (...) { return 0.0f; }
+}
+
+// ---- multi-GPU host (multi_gpu.h) ---------------------------------------------------------------------------------------------
+int NA_ShardByCost(const double* cost, int n, int parts, int* bounds)
+{
+	return Guard([&] {
+		if (!cost && n > 0) throw std::runtime_error("NA_ShardByCost: bad argument");
+		if (!bounds) throw std::runtime_error("NA_ShardByCost: bad argument");
+		const std::vector<int> b = na::ShardByCost(cost, n, parts);
+		for (size_t i = 0; i < b.size(); i++) bounds[i] = b[i];
+	});
+}
+
+double NA_ModelStreamCost(NeuralModel* model, float quality)
+{
+	double c = -1.0;
+	Guard([&] {
+		NeuralAudio::GpuModel* gm = model ? dynamic_cast<NeuralAudio::GpuModel*>(model->model) : nullptr;
+		if (!gm) throw std::runtime_error("NA_ModelStreamCost: model was not created by this library");
+		c = na::EstimateStreamCost(*gm->GetLoadedModel(), quality);
+	});
+	return c;
+}
+
+NA_MultiBatch* NA_MultiCreate(const int* devices, int numDevices)
+{
+	NA_MultiBatch* mb = nullptr;
+	Guard([&] {
+		if (!devices || numDevices < 1) throw std::runtime_error("NA_MultiCreate: bad argument");
+		na::MultiGpuBatch* m = new na::MultiGpuBatch(std::vector<int>(devices, devices + numDevices));
+		mb = new NA_MultiBatch{ m };
+	});
+	return mb;
+}
+
+void NA_MultiDestroy(NA_MultiBatch* mb)
+{
+	if (!mb) return;
+	Guard([&] { delete mb->multi; });
+	delete mb;
+}
+
+int NA_MultiAddStreams(NA_MultiBatch* mb, NeuralModel* model, float quality, int count, int doPrewarm)
+{
+	int first = -1;
+	const int rc = Guard([&] {
+		NeuralAudio::GpuModel* gm = (mb && model) ? dynamic_cast<NeuralAudio::GpuModel*>(model->model) : nullptr;
+		if (!gm || count < 1) throw std::runtime_error("NA_MultiAddStreams: bad argument");
+		first = mb->multi->AddStreams(gm->GetLoadedModel(), quality, count, doPrewarm != 0, gm->IsOnDemand());
+	});
+	return rc == 0 ? first : -1;
+}
+
+int NA_MultiCommit(NA_MultiBatch* mb)
+{
+	if (!mb) return -1;
+	return Guard([&] { mb->multi->Commit(); });
+}
+
+int NA_MultiNumStreams(NA_MultiBatch* mb) { return mb ? mb->multi->NumStreams() : -1; }
+int NA_MultiNumShards(NA_MultiBatch* mb) { return mb ? mb->multi->NumShards() : -1; }
+
+int NA_MultiShardRange(NA_MultiBatch* mb, int shard, int* begin, int* end, int* device)
+{
+	if (!mb) return -1;
+	return Guard([&] {
+		int b = 0, e = 0, d = 0;
+		mb->multi->ShardRange(shard, b, e, d);
+		if (begin) *begin = b;
+		if (end) *end = e;
+		if (device) *device = d;
+	});
+}
+
+int NA_MultiProcess(NA_MultiBatch* mb, const float* in, float* out, size_t n)
+{
+	if (!mb || !in || !out) return -1;
+	return Guard([&] { mb->multi->Process(in, out, n); });
+}
+
+int NA_MultiSubmit(NA_MultiBatch* mb, const float* in, size_t n)
+{
+	int ticket = -1;
+	if (!mb || !in) return -1;
+	const int rc = Guard([&] { ticket = mb->multi->Submit(in, n); });
+	return rc == 0 ? ticket : -1;
+}
+
+int NA_MultiCollect(NA_MultiBatch* mb, int ticket, float* out)
+{
+	if (!mb) return -1;
+	return Guard([&] { mb->multi->Collect(ticket, out); });
+}
+
+int NA_MultiSetQuality(NA_MultiBatch* mb, int stream, float quality)
+{
+	if (!mb) return -1;
+	return Guard([&] { mb->multi->SetQuality(stream, quality); });
 }
 
 void NA_DebugSetWaveNetSpec(int on) { na::SetWaveNetSpecEnabled(on != 0); }

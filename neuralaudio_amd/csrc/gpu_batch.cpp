@@ -801,6 +801,33 @@ namespace na
 
 namespace na
 {
+	// Cost of one stream for the multi-GPU sharder: time = per-launch skeleton + bytes (WaveNet) / multiply-accumulates (recurrent),
+	// two-point fits per kernel family to the round-3 measurements (us per 1024 streams x 128 frames): specialised / split chains
+	// 22.3 + 0.0143 B (Standard 41.6, Lite 33.7), f32 frame kernel 31.6 + 0.0164 B (A2-Lite 46.6, A2-Full 71.4), LDS-free recurrent
+	// kernel 8.4 + 0.0107 MAC (LSTM 1x16 20.2, 2x16 42.1), runtime-shaped kernels by their measured per-block times.
+	double EstimateStreamCost(const LoadedModel& model, float quality)
+	{
+		if (model.subModels.empty()) return 1.0;
+		const int idx = model.isComposite ? model.ModelIndexFromQuality(quality) : 0;
+		const ModelDesc& d = *model.subModels[(size_t)idx].desc;
+		if (d.kind == MODEL_WAVENET)
+		{
+			const WaveNetPlan plan = BuildWaveNetPlan(d.wavenet);
+			const double B = plan.AlgorithmicBytesPerSample(WN_MAX_FRAMES);
+			if (plan.genericOnly) return 1000.0 * plan.maxChannels / 32.0; // 1.0 ms per block at 32 channels (<= 256 streams)
+			const bool composite = model.isComposite;
+			const bool split = plan.splitFastT == 2 || (!composite && (WaveNetPackFactor(d.wavenet) > 1 || WaveNetWantsPadding(d.wavenet)));
+			return split ? 22.3 + 0.0143 * B : 31.6 + 0.0164 * B;
+		}
+		const LSTMDesc& l = d.lstm;
+		const double gates = (l.cell == CELL_GRU) ? 3.0 : 4.0;
+		double macs = 0.0;
+		for (int k = 0; k < l.numLayers; k++) macs += gates * l.hiddenSize * ((k == 0 ? 1 : l.hiddenSize) + l.hiddenSize);
+		macs += l.hiddenSize;
+		const bool dpp = l.tail.empty() && l.numLayers <= 2 && (l.hiddenSize <= 16 || (l.numLayers == 1 && l.hiddenSize <= 32));
+		return dpp ? 8.4 + 0.0107 * macs : 60.0 + 0.06 * macs;
+	}
+
 	// ------------------------------------------------------------------------------------------ GpuBatch
 
 	GpuBatch::GpuBatch(int dev, hipStream_t borrowedStream) : device(dev)

@@ -30,6 +30,10 @@ namespace na
 	// returns the number of visible HIP devices (0 when there is no GPU / no driver); never throws
 	int VisibleDeviceCount();
 
+	// Relative cost of one stream of a model (what the multi-GPU sharder balances, multi_gpu.h): microseconds per 1024 streams x 128
+	// frames of the kernel family that runs it, fitted to the round-3 measurements; host-side only (no device needed)
+	double EstimateStreamCost(const LoadedModel& model, float quality);
+
 	class ModelGroup; // one per distinct ModelDesc: packed weights + state of all its streams
 
 	class GpuBatch
@@ -95,6 +99,7 @@ namespace na
 		// that slot is submitted again, kPipelineSlots submissions later).
 		float* NextInput(size_t n);
 		const float* OutputView(int ticket) const;
+		size_t SlotFrames(int ticket) const { return (ticket >= 0 && ticket < kPipelineSlots) ? pipe[ticket].n : 0; } // frames per row of that submission
 
 		void Synchronize();
 		hipStream_t GetStream() const { return stream; }

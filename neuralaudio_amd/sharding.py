@@ -6,15 +6,32 @@ arch-sorted stream list, balanced by per-stream cost, one process per GPU; state
 GPUs and there is NO data-path collective.  torch.distributed (RCCL) is only used for the optional
 fan-in of outputs / timing barriers.
 """
+import ctypes as C
 from typing import List, Sequence, Tuple
 
 
 def shard_ranges(costs: Sequence[float], world_size: int) -> List[Tuple[int, int]]:
     """Split streams [0, len(costs)) into `world_size` contiguous ranges with near-equal total cost.
 
-    costs[i] is the relative per-sample cost of stream i (e.g. algorithmic bytes or MACs per sample).
+    costs[i] is the relative per-sample cost of stream i (e.g. NA_ModelStreamCost of its model).
     Returns [(begin, end)] per rank; ranges are contiguous, ordered, disjoint and cover everything.
+    This is the C++ host's partition (libNeuralAudioCAPI: NA_ShardByCost, csrc/multi_gpu.cpp) -- the one-process-per-GPU hosts
+    (bench.py) and the single-process multi-GPU host (NA_Multi*) shard with the same code.
     """
+    from . import capi
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    lib = capi.load_library()
+    n = len(costs)
+    arr = (C.c_double * max(n, 1))(*[float(c) for c in costs])
+    bounds = (C.c_int * (world_size + 1))()
+    if lib.NA_ShardByCost(arr, n, world_size, bounds) != 0:
+        raise RuntimeError(capi.last_error())
+    return [(int(bounds[r]), int(bounds[r + 1])) for r in range(world_size)]
+
+
+def shard_ranges_reference(costs: Sequence[float], world_size: int) -> List[Tuple[int, int]]:
+    """The same partition in plain Python (tests compare the two)."""
     n = len(costs)
     if world_size < 1:
         raise ValueError("world_size must be >= 1")
@@ -31,8 +48,12 @@ def shard_ranges(costs: Sequence[float], world_size: int) -> List[Tuple[int, int
             while end < n and acc + costs[end] <= target + 1e-9:
                 acc += costs[end]
                 end += 1
-            # leave at least one stream for each remaining rank when possible
-            end = min(end, max(begin, n - (world_size - rank - 1)))
+            # at least one stream per rank while streams remain: take one even if it alone overshoots the share,
+            # and leave one for each remaining rank
+            cap = max(begin, n - (world_size - rank - 1))
+            if end == begin and end < cap:
+                end += 1
+            end = min(end, cap)
             acc = float(sum(costs[:end]))
         ranges.append((begin, end))
         begin = end

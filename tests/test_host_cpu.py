@@ -533,3 +533,46 @@ def test_a2_engine_selection_predicates(na):
             assert variant(edit) == 2, k
     for a1 in ("BossWN-standard.nam", "BossWN-nano.nam", "BossLSTM-1x16.nam"):
         assert classify(O.load_json(a1)) == 0
+
+
+def test_shard_by_cost_matches_the_python_restatement_and_covers_everything():
+    """NA_ShardByCost (csrc/multi_gpu.cpp) is the partition both multi-GPU hosts use (the C++ NA_Multi* host and bench.py's
+    one-process-per-GPU ranks through neuralaudio_amd.sharding): contiguous, ordered, disjoint, complete, near-equal cost, at least one
+    item per range while items remain -- and identical to the plain-Python restatement."""
+    import numpy as np
+    from neuralaudio_amd.sharding import shard_ranges, shard_ranges_reference
+    rng = np.random.default_rng(0)
+    cases = [([1.0] * 8192, 8), ([41.6] * 4096 + [20.2] * 4096, 8), ([46.6] * 8192 + [71.4] * 8192, 8), ([1.0, 3.0, 1.0, 1.0, 2.0, 1.0, 1.0], 2),
+             ([5.0], 4), ([], 3), ([0.0] * 10, 3), ([1.0] * 3, 8)]
+    for _ in range(40):
+        n = int(rng.integers(1, 400))
+        cases.append((list(rng.choice([20.2, 33.7, 41.6, 71.4], size=n) * rng.uniform(0.5, 2.0)), int(rng.integers(1, 9))))
+    for costs, parts in cases:
+        got = shard_ranges(costs, parts)
+        assert got == shard_ranges_reference(costs, parts), (costs[:8], parts, got)
+        assert len(got) == parts and got[0][0] == 0 and got[-1][1] == len(costs)
+        assert all(a <= b for a, b in got) and all(got[i][1] == got[i + 1][0] for i in range(parts - 1))
+        if len(costs) >= parts:
+            assert all(b > a for a, b in got), (parts, got)
+    # balance: 8 ranks over config 5's global list (A2 ch3 then ch8): the ranks holding the expensive half get fewer streams
+    costs = [46.6] * 8192 + [71.4] * 8192
+    r = shard_ranges(costs, 8)
+    loads = [sum(costs[a:b]) for a, b in r]
+    assert max(loads) / min(loads) < 1.01 and (r[0][1] - r[0][0]) > (r[-1][1] - r[-1][0])
+
+
+def test_stream_cost_estimates_rank_the_official_models(models_dir):
+    import ctypes as C
+    from neuralaudio_amd import capi
+    lib = capi.load_library()
+    loader = lib.CreateLoader()
+    cost = {}
+    for name in ("BossWN-standard.nam", "BossWN-feather.nam", "BossWN-nano.nam", "BossLSTM-1x16.nam", "BossLSTM-2x8.nam", "BossWN-a2.nam"):
+        m = lib.NA_CreateModelFromFileUtf8(loader, os.path.join(models_dir, name).encode(), 0)
+        assert m
+        cost[name] = lib.NA_ModelStreamCost(m, C.c_float(1.0))
+        if "a2" in name:
+            cost["a2-lite"] = lib.NA_ModelStreamCost(m, C.c_float(0.0))
+    assert cost["BossWN-standard.nam"] > cost["BossWN-feather.nam"] > cost["BossWN-nano.nam"] > 0
+    assert cost["BossWN-a2.nam"] > cost["a2-lite"] > cost["BossLSTM-1x16.nam"] > 0
+    assert 35.0 < cost["BossWN-standard.nam"] < 50.0 and 15.0 < cost["BossLSTM-1x16.nam"] < 25.0  # (us per 1024 streams x 128 frames)
