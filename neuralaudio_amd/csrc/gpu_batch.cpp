@@ -188,6 +188,8 @@ namespace na
 			return false;
 		}
 
+		bool ListsDirty() const { return activeDirty; }
+
 		int NumActive() const
 		{
 			int c = 0;
@@ -199,9 +201,10 @@ namespace na
 		// added (AddMember is the non-real-time side); the copy is asynchronous on the batch stream from one of two pinned staging
 		// buffers, so a quality switch costs the audio thread two small enqueues and no synchronisation (the reference switches an
 		// atomic index, CompositeModel.h:49-63).  Never called inside a graph capture.
-		virtual void SyncActiveLists()
+		// returns true when the lists were re-uploaded
+		virtual bool SyncActiveLists()
 		{
-			if (!activeDirty) return;
+			if (!activeDirty) return false;
 			hSlots.clear();
 			hRows.clear();
 			for (size_t m = 0; m < memberRow.size(); m++)
@@ -220,6 +223,7 @@ namespace na
 			for (size_t i = 1; i < hSlots.size() && contiguous; i++)
 				contiguous = hSlots[i] == hSlots[0] + (int)i && hRows[i] == hRows[0] + (int)i;
 			activeDirty = false;
+			return true;
 		}
 
 	protected:
@@ -545,14 +549,10 @@ namespace na
 
 			// Packed groups: the launch lists name VIRTUAL streams -- slot = member / pack -- and hold `pack` rows each (-1: no member in
 			// that position yet).  Members of a static model are always active, so a virtual stream runs as soon as it has one member.
-			void SyncActiveLists() override
+			bool SyncActiveLists() override
 			{
-				if (pack <= 1)
-				{
-					ModelGroup::SyncActiveLists();
-					return;
-				}
-				if (!activeDirty) return;
+				if (pack <= 1) return ModelGroup::SyncActiveLists();
+				if (!activeDirty) return false;
 				hSlots.clear();
 				hRows.clear();
 				const size_t numSlots = (memberRow.size() + (size_t)pack - 1) / (size_t)pack;
@@ -576,6 +576,7 @@ namespace na
 				if (!hSlots.empty()) UploadLists();
 				contiguous = false; // the packed kernel always reads the lists
 				activeDirty = false;
+				return true;
 			}
 
 		protected:
@@ -850,6 +851,8 @@ namespace na
 	GpuBatch::~GpuBatch()
 	{
 		(void)hipSetDevice(device);
+		for (PipeSlot& p : pipe)
+			if (p.own) (void)hipStreamSynchronize(p.own);
 		if (stream) (void)hipStreamSynchronize(stream);
 		groups.clear();
 		if (hostStage) (void)hipHostFree(hostStage);
@@ -862,7 +865,10 @@ namespace na
 			if (p.uploaded) (void)hipEventDestroy(p.uploaded);
 			if (p.computed) (void)hipEventDestroy(p.computed);
 			if (p.downloaded) (void)hipEventDestroy(p.downloaded);
+			if (p.own) (void)hipStreamDestroy(p.own);
 		}
+		if (mainDone) (void)hipEventDestroy(mainDone);
+
 		if (copyIn) (void)hipStreamDestroy(copyIn);
 		if (copyOut) (void)hipStreamDestroy(copyOut);
 		for (auto& e : graphCache) (void)hipGraphExecDestroy(e.exec);
@@ -911,6 +917,7 @@ namespace na
 		if (!model || model->subModels.empty()) throw std::runtime_error("neuralaudio_amd: AddStream with an empty model");
 		if (count < 1) throw std::runtime_error("neuralaudio_amd: AddStreams with count < 1");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
+		DrainPipeline(); // (state arrays may be re-allocated below)
 		topologyVersion++;
 		const int active = model->isComposite ? model->ModelIndexFromQuality(quality) : 0;
 		const size_t numSub = model->subModels.size();
@@ -950,6 +957,13 @@ namespace na
 		return first;
 	}
 
+	// every buffer still in flight on a slot stream (pipelined interface) is done after this
+	void GpuBatch::DrainPipeline()
+	{
+		for (PipeSlot& p : pipe)
+			if (p.own) CheckHip(hipStreamSynchronize(p.own), "hipStreamSynchronize");
+	}
+
 	void GpuBatch::RemoveStreams(int first, int count)
 	{
 		if (count < 1 || first < 0 || (size_t)first + (size_t)count > streams.size()) throw std::runtime_error("neuralaudio_amd: RemoveStreams: id range outside the batch");
@@ -957,6 +971,7 @@ namespace na
 			if (!streams[(size_t)(first + i)].live) throw std::runtime_error("neuralaudio_amd: RemoveStreams: stream was already removed");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		// the slots may be handed out again right away: nothing of theirs may still be in flight
+		DrainPipeline();
 		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 		topologyVersion++;
 		for (int i = 0; i < count; i++)
@@ -1053,6 +1068,7 @@ namespace na
 	void GpuBatch::Prewarm(int s)
 	{
 		CheckHip(hipSetDevice(device), "hipSetDevice");
+		DrainPipeline();
 		StreamRef& ref = streams.at((size_t)s);
 		if (!ref.live) return;
 		// LoadAll: every submodel is prewarmed (CompositeModel.h:111-118); OnDemand: the current one (:104-109)
@@ -1068,11 +1084,30 @@ namespace na
 	{
 		if (n == 0 || streams.empty()) return;
 		CheckHip(hipSetDevice(device), "hipSetDevice");
+		if (pipelineUsed)
+		{
+			// buffers submitted through the pipelined interface run on per-slot streams: this call's kernels come after theirs ...
+			if (lastKernelStream != stream && lastKernelEvent) CheckHip(hipStreamWaitEvent(stream, lastKernelEvent, 0), "hipStreamWaitEvent");
+		}
+		ProcessDeviceOn(stream, dIn, dOut, n, inStride, outStride);
+		if (pipelineUsed)
+		{
+			// ... and the next submitted buffer after this call's
+			if (!mainDone) CheckHip(hipEventCreateWithFlags(&mainDone, hipEventDisableTiming), "hipEventCreate");
+			CheckHip(hipEventRecord(mainDone, stream), "hipEventRecord");
+			lastKernelEvent = mainDone;
+			lastKernelStream = stream;
+		}
+	}
+
+	// `launch` != the batch stream is only used for a batch that runs as ONE launch per buffer (Submit checks)
+	void GpuBatch::ProcessDeviceOn(hipStream_t launch, const float* dIn, float* dOut, size_t n, long inStride, long outStride)
+	{
 		int activeGroups = 0;
 		for (auto& g : groups) activeGroups += (g->NumActive() > 0);
 		if (activeGroups <= 1)
 		{
-			for (auto& g : groups) g->Process(dIn, dOut, inStride, outStride, n, stream);
+			for (auto& g : groups) g->Process(dIn, dOut, inStride, outStride, n, launch);
 			return;
 		}
 		// Mixed batch.  Groups that can share a launch are fused: all WaveNet groups on the frame kernel into one launch, all LSTM / GRU
@@ -1155,11 +1190,11 @@ namespace na
 			for (int l = 0; l < NUM_WN_LISTS; l++)
 				if (!fusedWn[l].empty())
 				{
-					launchWnList(l, stream);
+					launchWnList(l, launch);
 					return;
 				}
-			if (!fusedRec.empty()) launchRec(stream);
-			else singles[0]->Process(dIn, dOut, inStride, outStride, n, stream);
+			if (!fusedRec.empty()) launchRec(launch);
+			else singles[0]->Process(dIn, dOut, inStride, outStride, n, launch);
 			return;
 		}
 		{
@@ -1239,6 +1274,8 @@ namespace na
 		stageFloats = floats;
 	}
 
+	// (Splitting the buffer into chunks so that host copies overlap the DMA was measured and dropped: every extra asynchronous copy /
+	// event costs more than it hides -- 1024 x 128 frames: 114 us per call as one piece, 134 / 186 / 282 us in 2 / 4 / 8 chunks.)
 	void GpuBatch::ProcessHost(const float* in, float* out, size_t n)
 	{
 		if (n == 0 || streams.empty()) return;
@@ -1278,11 +1315,6 @@ namespace na
 	{
 		if (n == 0 || streams.empty()) throw std::runtime_error("neuralaudio_amd: Submit on an empty batch / buffer");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
-		if (!copyIn)
-		{
-			CheckHip(hipStreamCreateWithFlags(&copyIn, hipStreamNonBlocking), "hipStreamCreate");
-			CheckHip(hipStreamCreateWithFlags(&copyOut, hipStreamNonBlocking), "hipStreamCreate");
-		}
 		const int ticket = nextSlot;
 		PipeSlot& p = pipe[ticket];
 		if (p.busy) throw std::runtime_error("neuralaudio_amd: Submit with every pipeline slot in flight (Collect the oldest ticket first)");
@@ -1308,6 +1340,50 @@ namespace na
 			nextSlot = (nextSlot + 1) % kPipelineSlots;
 			return ticket;
 		}
+		// One launch per buffer (the usual case): the whole buffer -- upload, kernel, download -- rides on the slot's OWN stream, in order,
+		// with no event between them; the only cross-stream edge is the stream state: this buffer's kernel waits for the previous
+		// buffer's.  The upload of buffer k + 1 (its stream's first operation) overlaps the kernel of buffer k, the download of buffer k
+		// (behind its kernel) overlaps the kernel of buffer k + 1.  Per buffer: 2 copies, 1 launch, 1 event wait, 1 event record --
+		// the round-2 path cost 2 more waits and 2 more records on the compute stream, 15 us per buffer (tools/microbench/host_pipe_probe.cpp).
+		if (LaunchUnitsAfterSwitch(nullptr, nullptr) <= 1)
+		{
+			if (!p.own) CheckHip(hipStreamCreateWithFlags(&p.own, hipStreamNonBlocking), "hipStreamCreate");
+			bool listsChanged = false, dirty = false;
+			for (auto& g : groups) dirty = dirty || (g->NumActive() > 0 && g->ListsDirty());
+			if (dirty)
+			{
+				// the index lists are re-uploaded on the batch stream: not before the kernels still reading the old ones are done
+				if (lastKernelEvent && lastKernelStream != stream) CheckHip(hipStreamWaitEvent(stream, lastKernelEvent, 0), "hipStreamWaitEvent");
+				for (auto& g : groups)
+					if (g->NumActive() > 0) listsChanged = g->SyncActiveLists() || listsChanged;
+			}
+			if (listsChanged || submitTopology != topologyVersion || !pipelineUsed)
+			{
+				// everything the batch stream still has in flight for this batch (state resets of new streams, index lists) comes first
+				if (!mainDone) CheckHip(hipEventCreateWithFlags(&mainDone, hipEventDisableTiming), "hipEventCreate");
+				CheckHip(hipEventRecord(mainDone, stream), "hipEventRecord");
+				CheckHip(hipStreamWaitEvent(p.own, mainDone, 0), "hipStreamWaitEvent");
+				submitTopology = topologyVersion;
+			}
+			pipelineUsed = true;
+			CheckHip(hipMemcpyAsync(p.dev, p.hostIn, total * sizeof(float), hipMemcpyHostToDevice, p.own), "hipMemcpyAsync H2D");
+			if (lastKernelEvent && lastKernelStream != p.own) CheckHip(hipStreamWaitEvent(p.own, lastKernelEvent, 0), "hipStreamWaitEvent");
+			ProcessDeviceOn(p.own, p.dev, p.dev, n, (long)n, (long)n);
+			CheckHip(hipEventRecord(p.computed, p.own), "hipEventRecord");
+			lastKernelEvent = p.computed;
+			lastKernelStream = p.own;
+			CheckHip(hipMemcpyAsync(p.hostOut, p.dev, total * sizeof(float), hipMemcpyDeviceToHost, p.own), "hipMemcpyAsync D2H");
+			p.onOwnStream = true;
+			p.busy = true;
+			nextSlot = (nextSlot + 1) % kPipelineSlots;
+			return ticket;
+		}
+		// several launch units per buffer (a captured hipGraph on the batch stream): copies on the copy streams, events in between
+		if (!copyIn)
+		{
+			CheckHip(hipStreamCreateWithFlags(&copyIn, hipStreamNonBlocking), "hipStreamCreate");
+			CheckHip(hipStreamCreateWithFlags(&copyOut, hipStreamNonBlocking), "hipStreamCreate");
+		}
 		CheckHip(hipMemcpyAsync(p.dev, p.hostIn, total * sizeof(float), hipMemcpyHostToDevice, copyIn), "hipMemcpyAsync H2D");
 		CheckHip(hipEventRecord(p.uploaded, copyIn), "hipEventRecord");
 		CheckHip(hipStreamWaitEvent(stream, p.uploaded, 0), "hipStreamWaitEvent");
@@ -1316,6 +1392,7 @@ namespace na
 		CheckHip(hipStreamWaitEvent(copyOut, p.computed, 0), "hipStreamWaitEvent");
 		CheckHip(hipMemcpyAsync(p.hostOut, p.dev, total * sizeof(float), hipMemcpyDeviceToHost, copyOut), "hipMemcpyAsync D2H");
 		CheckHip(hipEventRecord(p.downloaded, copyOut), "hipEventRecord");
+		p.onOwnStream = false;
 		p.busy = true;
 		nextSlot = (nextSlot + 1) % kPipelineSlots;
 		return ticket;
@@ -1325,7 +1402,8 @@ namespace na
 	{
 		if (ticket < 0 || ticket >= kPipelineSlots || !pipe[ticket].busy) throw std::runtime_error("neuralaudio_amd: Collect with an invalid ticket");
 		PipeSlot& p = pipe[ticket];
-		CheckHip(hipEventSynchronize(p.downloaded), "hipEventSynchronize");
+		if (p.onOwnStream) CheckHip(hipStreamSynchronize(p.own), "hipStreamSynchronize"); // the download is the stream's last operation
+		else CheckHip(hipEventSynchronize(p.downloaded), "hipEventSynchronize");
 		if (!retired.empty()) ZeroRetiredRows(p.hostOut, p.n);
 		if (out) memcpy(out, p.hostOut, streams.size() * p.n * sizeof(float)); // nullptr: the caller reads OutputView() in place
 		p.busy = false;
@@ -1350,6 +1428,7 @@ namespace na
 	void GpuBatch::Synchronize()
 	{
 		CheckHip(hipSetDevice(device), "hipSetDevice");
+		DrainPipeline();
 		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 	}
 

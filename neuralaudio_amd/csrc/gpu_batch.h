@@ -168,8 +168,17 @@ namespace na
 			float* dev = nullptr;
 			size_t floats = 0, n = 0;
 			hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
+			hipStream_t own = nullptr; // upload, kernel and download of this slot's buffer, in order (batches that run as one launch)
+			bool onOwnStream = false;
 			bool busy = false;
 		};
+		void DrainPipeline();
+		void ProcessDeviceOn(hipStream_t launch, const float* dIn, float* dOut, size_t n, long inStride, long outStride);
+		// ordering between the batch stream and the slot streams: the stream state makes every kernel launch depend on the previous one
+		bool pipelineUsed = false;
+		hipEvent_t lastKernelEvent = nullptr, mainDone = nullptr;
+		hipStream_t lastKernelStream = nullptr;
+		unsigned long submitTopology = 0;
 		PipeSlot pipe[kPipelineSlots];
 		hipStream_t copyIn = nullptr, copyOut = nullptr;
 		int nextSlot = 0;
