@@ -1,18 +1,23 @@
 // wavenet_generic_kernels.hip -- the runtime-shaped WaveNet block kernel: any channel count up to 64, any kernel sizes / dilations /
-// layer counts, dense heads -- what the reference's dynamic engine accepts beyond the official architectures
-// (NeuralAudio/WaveNetDynamic.h:229-254,445-468, InternalModel.h:177-248; same arithmetic as WaveNet.h:768-799, 632-661, 462-494).
+// layer counts, dense or conv heads -- what the reference's dynamic engine accepts beyond the official architectures
+// (NeuralAudio/WaveNetDynamic.h:67-83, 229-254, 445-468, InternalModel.h:177-248; same arithmetic as WaveNet.h:768-799, 632-661, 462-494).
 //
-// It is the counterpart of the runtime-shaped LSTM / GRU kernels: slow next to the shaped kernels (every weight is a scalar load per
-// use, no matrix pipe) but it runs what they cannot -- layer arrays wider than 16 channels -- instead of a load error.  It walks the
-// natural-layout tensor table the prewarm kernel uses (WnPrewarmLayer: offsets into the flat weight array in the reference's order,
-// WaveNet.h:700-719) and keeps the frame kernel's stream-state format (f32 quads, tile layout), so prewarm / reset are shared.
+// It runs what the shaped kernels cannot -- layer arrays wider than 16 channels -- and these are exactly the layers north_star wants on
+// the matrix pipe ("MFMA only for the widest WaveNet layer GEMMs"): every mat-mul of a layer (conv taps, 1x1, rechannel, dense head) is
+// v_mfma_f32_16x16x32_f16 with the three-product f16 split of the shaped kernels (wavenet_split_dev.h: W x = Wh xh + Wh xl + Wl xh,
+// f32 accumulation).  It walks the natural-layout tensor table the prewarm kernel uses (WnPrewarmLayer: offsets into the flat weight
+// array in the reference's order, WaveNet.h:700-719) and keeps the frame kernel's stream-state format (f32 quads, tile layout), so
+// prewarm / reset are shared.
 //
-//   workgroup = one stream, thread = one frame of the 128-frame block;
-//   LDS: x[C][128] layer input (updated in place), z[C][128] accumulators / activations, head[C][128] head accumulator, t[C][128] the
-//   tap being accumulated, and a [C][C] weight buffer (one tap's matrix, then the 1x1: the inner loops read four weights per
-//   broadcast ds_read_b128 instead of a scalar load per term);
-//   a layer = publish x to its ring -> per tap: stage its weight matrix, gather the tap's input column of every frame once (LDS for
-//   in-block frames, the layer's HBM ring for earlier ones), accumulate all outputs -> activation, head += z -> 1x1 + residual into x.
+//   workgroup = one stream = 512 threads = 8 waves; wave w owns the 16-frame tile w of the 128-frame block for the mat-muls
+//   (lane = (frame j, channel group q): result registers = 4 channels of the lane's own frame); for gathers and ring traffic thread
+//   (f = tid & 127, cq = tid >> 7) moves the channel groups g = cq, cq + 4, ... of frame f;
+//   LDS: X[G][128] layer input, T[G][128] the tap being gathered, HEAD[G][128] head accumulator -- float4 per (4-channel group,
+//   frame) -- and the A operands of ONE matrix, split to f16 hi / lo ONCE per workgroup while they are staged ([row block][k block][hi,
+//   lo][64 lanes] x 16 bytes);
+//   a layer = publish X to its ring -> per tap: stage the tap's matrix, gather the tap's input (LDS for in-block frames, the layer's HBM
+//   ring for earlier ones), MFMA into register accumulators -> bias + mix-in + activation + head accumulate in the result lanes (the
+//   activation's split quad IS the 1x1's B operand: no LDS round trip) -> stage the 1x1 -> MFMA -> residual into X.
 #include <algorithm>
 #include <cstdlib>
 
@@ -20,13 +25,16 @@
 
 #include "wavenet_dev.h"
 #include "wavenet_launch.h"
+#include "wavenet_split_dev.h"
 
 namespace na
 {
 	namespace gn
 	{
 		constexpr int FRAMES = WN_MAX_FRAMES;
+		constexpr int NTHREADS = 512;
 		typedef float f32x4 __attribute__((ext_vector_type(4)));
+		using sp::u32x4;
 
 		// Activation.h:83-91
 		__device__ __forceinline__ float FastTanh(float x)
@@ -43,11 +51,8 @@ namespace na
 			return FastTanh(v);
 		}
 
-		// float index of (ring position p, channel c) in the tile layout with G channel groups: float4 ((p >> 4) G + c / 4) 16 + (p & 15)
-		__device__ __forceinline__ size_t RingElem(int ringOffF4, int G, int p, int c)
-		{
-			return ((size_t)ringOffF4 + (size_t)(((p >> 4) * G + (c >> 2)) * 16 + (p & 15))) * 4 + (size_t)(c & 3);
-		}
+		// float4 index of (ring position p, channel group g) in the tile layout with G channel groups: ((p >> 4) G + g) 16 + (p & 15)
+		__device__ __forceinline__ size_t RingQuad(int ringOffF4, int G, int p, int g) { return (size_t)ringOffF4 + (size_t)(((p >> 4) * G + g) * 16 + (p & 15)); }
 
 		struct Args
 		{
@@ -65,30 +70,83 @@ namespace na
 			int slot0, row0;
 		};
 
-		__global__ void __launch_bounds__(FRAMES) WaveNetGenericKernel(const Args a, const float* __restrict__ in, float* __restrict__ out, long inStride,
+		// W[o][c] = w[off + (o * cin + c) * stride + k]  (conv tap k: stride = K; dense: stride = 1, k = 0) -> the A operands of the
+		// [cout x cin] matrix: operand (rb, kb, hi | lo), lane (i = row 16 rb + i, q = channels 16 kb + 4 q .. + 3).  Split once, here.
+		__device__ __forceinline__ void StageMatrix(u32x4* ops, const float* __restrict__ w, int off, int stride, int k, int cout, int cin, int nbo, int nbk)
+		{
+			for (int idx = threadIdx.x; idx < nbo * nbk * 64; idx += NTHREADS)
+			{
+				const int lane = idx & 63, blk = idx >> 6, rb = blk / nbk, kb = blk % nbk;
+				const int o = 16 * rb + (lane & 15), c0 = 16 * kb + 4 * (lane >> 4);
+				sp::f32x4 v;
+				v.x = (o < cout && c0 + 0 < cin) ? w[off + ((size_t)o * cin + c0 + 0) * stride + k] : 0.0f;
+				v.y = (o < cout && c0 + 1 < cin) ? w[off + ((size_t)o * cin + c0 + 1) * stride + k] : 0.0f;
+				v.z = (o < cout && c0 + 2 < cin) ? w[off + ((size_t)o * cin + c0 + 2) * stride + k] : 0.0f;
+				v.w = (o < cout && c0 + 3 < cin) ? w[off + ((size_t)o * cin + c0 + 3) * stride + k] : 0.0f;
+				const u32x4 s = sp::SplitQuad(v);                       // [h01 | h23 | l01 | l23]
+				ops[(blk * 2 + 0) * 64 + lane] = u32x4{ s.x, s.y, s.x, s.y }; // Wh against the h AND the l half of the operand
+				ops[(blk * 2 + 1) * 64 + lane] = u32x4{ s.z, s.w, 0u, 0u };   // Wl against the h half
+			}
+		}
+
+		// acc[rb] += M[16 rb .. + 16][all k blocks] * b[kb]   (b[kb] = split quad of channels 16 kb + 4 q .. of the lane's frame)
+		template <int NB>
+		__device__ __forceinline__ void MatMul(const u32x4* ops, int nbo, int nbk, int lane, const u32x4 (&b)[NB], sp::f32x4 (&acc)[NB])
+		{
+#pragma unroll
+			for (int rb = 0; rb < NB; rb++)
+			{
+				if (rb >= nbo) break;
+#pragma unroll
+				for (int kb = 0; kb < NB; kb++)
+				{
+					if (kb >= nbk) break;
+					const int blk = rb * nbk + kb;
+					acc[rb] = sp::Mfma(ops[(blk * 2 + 0) * 64 + lane], b[kb], acc[rb]);
+					acc[rb] = sp::Mfma(ops[(blk * 2 + 1) * 64 + lane], b[kb], acc[rb]);
+				}
+			}
+		}
+
+		__device__ __forceinline__ f32x4 Load4(const float* __restrict__ w, int off, int c0, int count)
+		{
+			f32x4 v;
+			v.x = (c0 + 0 < count) ? w[off + c0 + 0] : 0.0f;
+			v.y = (c0 + 1 < count) ? w[off + c0 + 1] : 0.0f;
+			v.z = (c0 + 2 < count) ? w[off + c0 + 2] : 0.0f;
+			v.w = (c0 + 3 < count) ? w[off + c0 + 3] : 0.0f;
+			return v;
+		}
+
+		template <int NB>
+		__global__ void __launch_bounds__(NTHREADS) WaveNetGenericKernel(const Args a, const float* __restrict__ in, float* __restrict__ out, long inStride,
 			long outStride, int n)
 		{
 			extern __shared__ __attribute__((aligned(16))) float lds[];
-			const int C = a.maxC;
-			float* x = lds;                  // [C][FRAMES]
-			float* z = x + (size_t)C * FRAMES;
-			float* head = z + (size_t)C * FRAMES;
-			float* t = head + (size_t)C * FRAMES;  // [C][FRAMES]: the tap being accumulated, gathered per frame
-			float* wl = t + (size_t)C * FRAMES;    // [C * C]: one tap's weight matrix / the 1x1 matrix
-			const int f = threadIdx.x;
+			const int GQ = (a.maxC + 3) / 4;                          // channel groups of the widest array
+			f32x4* X = reinterpret_cast<f32x4*>(lds);                 // [GQ][FRAMES]
+			f32x4* T = X + (size_t)GQ * FRAMES;
+			f32x4* HEAD = T + (size_t)GQ * FRAMES;
+			u32x4* ops = reinterpret_cast<u32x4*>(HEAD + (size_t)GQ * FRAMES); // [NB * NB][2][64]
+			float* condL = reinterpret_cast<float*>(ops + NB * NB * 2 * 64);  // [FRAMES]
+			const int tid = threadIdx.x;
+			const int f = tid & (FRAMES - 1), cq = tid >> 7;          // gather / ring role
+			const int lane = tid & 63, wave = tid >> 6;               // mat-mul role: tile = wave
+			const int j = lane & 15, q = lane >> 4, tf = 16 * wave + j; // the lane's frame
 			const int sidx = blockIdx.x;
 			const int slot = a.slots ? a.slots[sidx] : a.slot0 + sidx;
 			const int row = a.slots ? a.rows[sidx] : a.row0 + sidx;
 			float* st = a.state + (size_t)slot * (size_t)a.stateF4 * 4;
+			f32x4* stq = reinterpret_cast<f32x4*>(st);
 			int* header = reinterpret_cast<int*>(st);
-			const float cond = (f < n) ? in[(size_t)row * inStride + f] : 0.0f; // WaveNet.h:770 (input -> condition)
-			for (int c = 0; c < C; c++)
+			if (cq == 0) condL[f] = (f < n) ? in[(size_t)row * inStride + f] : 0.0f; // WaveNet.h:770 (input -> condition)
+			for (int g = cq; g < GQ; g += 4)
 			{
-				x[c * FRAMES + f] = 0.0f;
-				z[c * FRAMES + f] = 0.0f;
-				head[c * FRAMES + f] = 0.0f; // :772 headArray.SetZero()
+				X[g * FRAMES + f] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+				HEAD[g * FRAMES + f] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // :772 headArray.SetZero()
 			}
 			__syncthreads();
+			const float cond = condL[tf];
 
 			const float* __restrict__ w = a.w;
 			for (int li = 0; li < a.numLayers; li++)
@@ -97,19 +155,38 @@ namespace na
 				if (L.kind == 0)
 				{
 					const int cin = L.cin; // == cout
+					const int Gl = (cin + 3) / 4, nb = (cin + 15) / 16;
 					if (L.rechannel >= 0)
 					{
-						// rechannel (:637): array 0 from the condition (input_size == 1), later arrays from the previous array's output (in x)
-						for (int o = 0; o < cin; o++)
+						// rechannel (:637): array 0 from the condition (input_size == 1), later arrays from the previous array's output (in X)
+						if (li == 0 && L.rech_in == 1)
 						{
-							float v = 0.0f;
-							if (L.rech_in == 1 && li == 0) v = w[L.rechannel + o] * cond;
-							else
-								for (int c = 0; c < L.rech_in; c++) v += w[L.rechannel + o * L.rech_in + c] * x[c * FRAMES + f];
-							z[o * FRAMES + f] = v;
+							for (int rb = 0; rb < nb; rb++)
+							{
+								const int g = 4 * rb + q;
+								if (g < Gl) X[g * FRAMES + tf] = Load4(w, L.rechannel, 4 * g, cin) * cond;
+							}
 						}
-						for (int o = 0; o < cin; o++) x[o * FRAMES + f] = z[o * FRAMES + f]; // own frame only: no barrier needed in between
+						else
+						{
+							const int nbk = (L.rech_in + 15) / 16, Gin = (L.rech_in + 3) / 4;
+							__syncthreads(); // the operand buffer is free (the previous array's head mat-mul is done everywhere)
+							StageMatrix(ops, w, L.rechannel, 1, 0, cin, L.rech_in, nb, nbk);
+							u32x4 b[NB];
+#pragma unroll
+							for (int kb = 0; kb < NB; kb++)
+								b[kb] = (kb < nbk && 4 * kb + q < Gin) ? sp::SplitQuad(X[(4 * kb + q) * FRAMES + tf]) : u32x4{ 0, 0, 0, 0 };
+							__syncthreads(); // operands staged; every wave has read its own frames of the old X
+							sp::f32x4 acc[NB];
+#pragma unroll
+							for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+							MatMul<NB>(ops, nb, nbk, lane, b, acc);
+#pragma unroll
+							for (int rb = 0; rb < NB; rb++)
+								if (rb < nb && 4 * rb + q < Gl) X[(4 * rb + q) * FRAMES + tf] = acc[rb];
+						}
 					}
+					__syncthreads(); // X of every frame is complete; the operand buffer is free
 					// the layer input of this block -> its ring (history for LATER blocks: only the last R - FRAMES frames can be read back)
 					const int R = a.ringFrames[L.ring_id], G = a.ringG[L.ring_id], roff = a.ringOffF4[L.ring_id];
 					const int pos0 = header[L.ring_id];
@@ -117,105 +194,171 @@ namespace na
 						int p = pos0 + f;
 						if (p >= R) p -= R;
 						if (f < n && f >= n - (R - FRAMES))
-							for (int c = 0; c < cin; c++) st[RingElem(roff, G, p, c)] = x[c * FRAMES + f];
+							for (int g = cq; g < Gl; g += 4) stq[RingQuad(roff, G, p, g)] = X[g * FRAMES + f];
 					}
-					// dilated conv + bias + mix-in (:139-290, :288-289, :471), tap by tap: the tap's weight matrix goes to LDS ([out][in], from
-					// [(o cin + c) K + k]), every thread gathers the tap's input column of ITS frame once (LDS for in-block frames, the ring
-					// for earlier ones) into t, then accumulates all outputs in its own column of z
+					// dilated conv (:139-290), tap by tap: stage the tap's [cin x cin] matrix as split A operands, gather the tap's input
+					// (LDS for in-block frames, the ring for earlier ones), accumulate on the matrix pipe
 					const int K = L.ksize;
-					for (int o = 0; o < cin; o++) z[o * FRAMES + f] = w[L.bconv + o] + w[L.wmix + o] * cond;
+					sp::f32x4 acc[NB];
+#pragma unroll
+					for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 					for (int k = 0; k < K; k++)
 					{
-						__syncthreads(); // k == 0: every thread's x is complete; k > 0: the previous tap's weights are no longer read
-						for (int i = f; i < cin * cin; i += FRAMES) wl[i] = w[L.wconv + (size_t)i * K + k];
+						if (k > 0) __syncthreads(); // the previous tap's operands and gathered inputs are no longer read
+						StageMatrix(ops, w, L.wconv, K, k, cin, cin, nb, nb);
 						const int off = f - L.dilation * (K - 1 - k); // tap k reads the frame d (K-1-k) back
 						if (off >= 0)
-							for (int c = 0; c < cin; c++) t[c * FRAMES + f] = x[c * FRAMES + off];
+							for (int g = cq; g < Gl; g += 4) T[g * FRAMES + f] = X[g * FRAMES + off];
 						else
 						{
 							int p = pos0 + off; // off >= -(R - FRAMES): one wrap
 							if (p < 0) p += R;
-							for (int c = 0; c < cin; c++) t[c * FRAMES + f] = st[RingElem(roff, G, p, c)];
+							for (int g = cq; g < Gl; g += 4) T[g * FRAMES + f] = stq[RingQuad(roff, G, p, g)];
 						}
-						__syncthreads(); // the tap's weights are staged (t is read by its own thread only)
-						for (int o = 0; o < cin; o++)
+						__syncthreads();
+						u32x4 b[NB];
+#pragma unroll
+						for (int kb = 0; kb < NB; kb++) b[kb] = (kb < nb && 4 * kb + q < Gl) ? sp::SplitQuad(T[(4 * kb + q) * FRAMES + tf]) : u32x4{ 0, 0, 0, 0 };
+						MatMul<NB>(ops, nb, nb, lane, b, acc);
+					}
+					// bias + mix-in (:288-289, :471), activation (:473-480), head accumulate (:482) -- in the lanes that hold the results; the
+					// activation's split quad is the 1x1's B operand (result rows 16 rb + 4 q .. of the lane's frame = k block rb, group q)
+					u32x4 zs[NB];
+#pragma unroll
+					for (int rb = 0; rb < NB; rb++)
+					{
+						zs[rb] = u32x4{ 0, 0, 0, 0 };
+						const int g = 4 * rb + q;
+						if (rb < nb && g < Gl)
 						{
-							const float* wr = wl + o * cin;
-							float acc = z[o * FRAMES + f];
-							int c = 0;
-							if ((cin & 3) == 0) // rows of the weight buffer are 16-byte aligned: four weights per (broadcast) LDS read
-								for (; c < cin; c += 4)
-								{
-									const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + c);
-									acc = __builtin_fmaf(w4.x, t[c * FRAMES + f], acc);
-									acc = __builtin_fmaf(w4.y, t[(c + 1) * FRAMES + f], acc);
-									acc = __builtin_fmaf(w4.z, t[(c + 2) * FRAMES + f], acc);
-									acc = __builtin_fmaf(w4.w, t[(c + 3) * FRAMES + f], acc);
-								}
-							for (; c < cin; c++) acc = __builtin_fmaf(wr[c], t[c * FRAMES + f], acc);
-							z[o * FRAMES + f] = acc;
+							const f32x4 bc = Load4(w, L.bconv, 4 * g, cin), wm = Load4(w, L.wmix, 4 * g, cin);
+							f32x4 zv;
+							zv.x = (4 * g + 0 < cin) ? Activate(acc[rb].x + bc.x + wm.x * cond, L.act) : 0.0f;
+							zv.y = (4 * g + 1 < cin) ? Activate(acc[rb].y + bc.y + wm.y * cond, L.act) : 0.0f;
+							zv.z = (4 * g + 2 < cin) ? Activate(acc[rb].z + bc.z + wm.z * cond, L.act) : 0.0f;
+							zv.w = (4 * g + 3 < cin) ? Activate(acc[rb].w + bc.w + wm.w * cond, L.act) : 0.0f;
+							HEAD[g * FRAMES + tf] += zv;
+							zs[rb] = sp::SplitQuad(sp::f32x4{ zv.x, zv.y, zv.z, zv.w });
 						}
 					}
-					// activation (:473-480), head accumulate (:482)
-					for (int o = 0; o < cin; o++)
-					{
-						const float zv = Activate(z[o * FRAMES + f], L.act);
-						z[o * FRAMES + f] = zv;
-						head[o * FRAMES + f] += zv;
-					}
-					__syncthreads(); // every tap gathered: x may be overwritten; the weight buffer is free
-					// 1x1 matrix -> LDS (natural [out][in]); 1x1 + bias + residual (:486-491); the last layer's output feeds the next array's
-					// rechannel (or nothing)
-					for (int i = f; i < cin * cin; i += FRAMES) wl[i] = w[L.w1 + i];
+					__syncthreads(); // every wave is done with the last tap's operands
+					// 1x1 + bias + residual (:486-491); the last layer's output feeds the next array's rechannel (or nothing)
+					StageMatrix(ops, w, L.w1, 1, 0, cin, cin, nb, nb);
 					__syncthreads();
-					for (int o = 0; o < cin; o++)
+#pragma unroll
+					for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+					MatMul<NB>(ops, nb, nb, lane, zs, acc);
+#pragma unroll
+					for (int rb = 0; rb < NB; rb++)
 					{
-						const float* wr = wl + o * cin;
-						float y = w[L.b1 + o] + x[o * FRAMES + f];
-						int c = 0;
-						if ((cin & 3) == 0)
-							for (; c < cin; c += 4)
-							{
-								const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + c);
-								y = __builtin_fmaf(w4.x, z[c * FRAMES + f], y);
-								y = __builtin_fmaf(w4.y, z[(c + 1) * FRAMES + f], y);
-								y = __builtin_fmaf(w4.z, z[(c + 2) * FRAMES + f], y);
-								y = __builtin_fmaf(w4.w, z[(c + 3) * FRAMES + f], y);
-							}
-						for (; c < cin; c++) y = __builtin_fmaf(wr[c], z[c * FRAMES + f], y);
-						x[o * FRAMES + f] = y;
+						const int g = 4 * rb + q;
+						if (rb < nb && g < Gl)
+						{
+							const f32x4 b1 = Load4(w, L.b1, 4 * g, cin);
+							X[g * FRAMES + tf] += f32x4{ acc[rb].x + b1.x, acc[rb].y + b1.y, acc[rb].z + b1.z, acc[rb].w + b1.w };
+						}
 					}
-					__syncthreads(); // the weight buffer is rewritten by the next layer's staging
-					// (own-frame accesses only from here to the next publish: no barrier)
+					// (the next stage starts with a barrier: X complete, operand buffer free)
 				}
 				else
 				{
-					// head rechannel (K = 1, :658-660): becomes the next array's head accumulator (:785-789) or, for the last array, the output
+					// head rechannel (:658-660): becomes the next array's head accumulator (:785-789) or, for the last array, the output.
+					// K = 1: a dense layer on the frame's own head column (matrix pipe); K > 1 (a conv head like A2's, on the last array):
+					// the head accumulator has its own ring -- publish, then every tap reads the frame (K-1-k) head_dilation back, from LDS
+					// inside the block and from the ring before it (thread = frame; the head has few output channels).
 					const bool last = (li == a.numLayers - 1);
-					for (int o = 0; o < L.cout; o++)
+					const int Gin = (L.cin + 3) / 4, nbk = (L.cin + 15) / 16, nbo = (L.cout + 15) / 16, Gout = (L.cout + 3) / 4;
+					__syncthreads(); // HEAD of every frame is complete, the operand buffer is free
+					if (L.ksize > 1)
 					{
-						float acc = (L.bconv >= 0) ? w[L.bconv + o] : 0.0f;
-						for (int c = 0; c < L.cin; c++) acc += w[L.wconv + o * L.cin + c] * head[c * FRAMES + f];
-						z[o * FRAMES + f] = acc;
-					}
-					if (last)
-					{
-						if (f < n) out[(size_t)row * outStride + f] = a.headScale * z[f]; // :793-798: head channel 0
+						const int R = a.ringFrames[L.ring_id], G = a.ringG[L.ring_id], roff = a.ringOffF4[L.ring_id];
+						const int pos0 = header[L.ring_id];
+						int p = pos0 + f;
+						if (p >= R) p -= R;
+						if (f < n && f >= n - (R - FRAMES))
+							for (int g = cq; g < Gin; g += 4) stq[RingQuad(roff, G, p, g)] = HEAD[g * FRAMES + f];
+						float res[4] = { 0.0f, 0.0f, 0.0f, 0.0f }; // up to 4 head outputs per pass (conv heads have one)
+						if (cq == 0)
+						{
+							for (int o = 0; o < L.cout && o < 4; o++)
+							{
+								float accv = (L.bconv >= 0) ? w[L.bconv + o] : 0.0f;
+								for (int k = 0; k < L.ksize; k++)
+								{
+									const int off = f - L.dilation * (L.ksize - 1 - k);
+									int pq = pos0 + off;
+									if (pq < 0) pq += R;
+									for (int g = 0; g < Gin; g++)
+									{
+										const f32x4 hv = (off >= 0) ? HEAD[g * FRAMES + off] : stq[RingQuad(roff, G, pq, g)];
+										const size_t wo = (size_t)L.wconv + ((size_t)o * L.cin + 4 * g) * L.ksize + k;
+										accv += w[wo] * hv.x;
+										if (4 * g + 1 < L.cin) accv += w[wo + L.ksize] * hv.y;
+										if (4 * g + 2 < L.cin) accv += w[wo + 2 * L.ksize] * hv.z;
+										if (4 * g + 3 < L.cin) accv += w[wo + 3 * L.ksize] * hv.w;
+									}
+								}
+								res[o] = accv;
+							}
+						}
+						__syncthreads(); // every tap read: HEAD may be overwritten
+						if (cq == 0)
+						{
+							if (last) { if (f < n) out[(size_t)row * outStride + f] = a.headScale * res[0]; } // :793-798: head channel 0
+							else HEAD[f] = f32x4{ res[0], res[1], res[2], res[3] };
+						}
+						if (!last) // (ValidateWaveNetDesc only admits a conv head on the last array; kept total for completeness)
+							for (int g = cq; g < GQ; g += 4)
+								if (g > 0) HEAD[g * FRAMES + f] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 					}
 					else
 					{
-						for (int o = 0; o < C; o++) head[o * FRAMES + f] = (o < L.cout) ? z[o * FRAMES + f] : 0.0f;
+						StageMatrix(ops, w, L.wconv, 1, 0, L.cout, L.cin, nbo, nbk);
+						u32x4 b[NB];
+#pragma unroll
+						for (int kb = 0; kb < NB; kb++)
+							b[kb] = (kb < nbk && 4 * kb + q < Gin) ? sp::SplitQuad(HEAD[(4 * kb + q) * FRAMES + tf]) : u32x4{ 0, 0, 0, 0 };
+						__syncthreads();
+						sp::f32x4 acc[NB];
+#pragma unroll
+						for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+						MatMul<NB>(ops, nbo, nbk, lane, b, acc);
+						if (last)
+						{
+							if (q == 0 && tf < n) out[(size_t)row * outStride + tf] = a.headScale * (acc[0].x + ((L.bconv >= 0) ? w[L.bconv] : 0.0f)); // :793-798
+						}
+						else
+						{
+#pragma unroll
+							for (int rb = 0; rb < NB; rb++)
+							{
+								const int g = 4 * rb + q;
+								if (g < GQ)
+								{
+									f32x4 v = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+									if (rb < nbo && g < Gout)
+									{
+										const f32x4 bb = (L.bconv >= 0) ? Load4(w, L.bconv, 4 * g, L.cout) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+										v = f32x4{ acc[rb].x + bb.x, acc[rb].y + bb.y, acc[rb].z + bb.z, acc[rb].w + bb.w };
+										if (4 * g + 1 >= L.cout) v.y = 0.0f;
+										if (4 * g + 2 >= L.cout) v.z = 0.0f;
+										if (4 * g + 3 >= L.cout) v.w = 0.0f;
+									}
+									HEAD[g * FRAMES + tf] = v; // the lane owns (group, frame): read above, written here
+								}
+							}
+						}
 					}
 				}
 			}
 			__syncthreads();
 			// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
-			if (f < a.nrings)
+			if (tid < a.nrings)
 			{
-				const int R = a.ringFrames[f];
-				int p = header[f] + n;
+				const int R = a.ringFrames[tid];
+				int p = header[tid] + n;
 				if (p >= R) p -= R;
-				header[f] = p;
+				header[tid] = p;
 			}
 		}
 	}
@@ -242,15 +385,24 @@ namespace na
 		a.rows = rows;
 		a.slot0 = slot0;
 		a.row0 = row0;
-		// LDS: four [C][128] float arrays + one [C][C] weight matrix (C = 64: 144 KB)
-		const size_t ldsBytes = ((size_t)4 * maxChannels * gn::FRAMES + (size_t)maxChannels * maxChannels) * sizeof(float);
+		// LDS: three [G][128] float4 arrays + the split A operands of one matrix ([nb x nb][hi, lo][64] x 16 B) + the condition row
+		// (64 channels: 96 + 32 KB, 32 channels: 48 + 8 KB -> two workgroups per CU)
+		const int nb = (maxChannels + 15) / 16, gq = (maxChannels + 3) / 4;
+		const size_t ldsBytes = (size_t)3 * gq * gn::FRAMES * 16 + (size_t)nb * nb * 2 * 64 * 16 + gn::FRAMES * sizeof(float);
 		static bool attrSet = false;
 		if (!attrSet)
 		{
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			attrSet = true;
 		}
-		hipLaunchKernelGGL(gn::WaveNetGenericKernel, dim3((unsigned)numStreams), dim3(gn::FRAMES), ldsBytes, stream, a, in, out, inStride, outStride, n);
+		// NB = 16-channel blocks per matrix side
+		if (nb <= 1) hipLaunchKernelGGL(gn::WaveNetGenericKernel<1>, dim3((unsigned)numStreams), dim3(gn::NTHREADS), ldsBytes, stream, a, in, out, inStride, outStride, n);
+		else if (nb == 2) hipLaunchKernelGGL(gn::WaveNetGenericKernel<2>, dim3((unsigned)numStreams), dim3(gn::NTHREADS), ldsBytes, stream, a, in, out, inStride, outStride, n);
+		else if (nb == 3) hipLaunchKernelGGL(gn::WaveNetGenericKernel<3>, dim3((unsigned)numStreams), dim3(gn::NTHREADS), ldsBytes, stream, a, in, out, inStride, outStride, n);
+		else hipLaunchKernelGGL(gn::WaveNetGenericKernel<4>, dim3((unsigned)numStreams), dim3(gn::NTHREADS), ldsBytes, stream, a, in, out, inStride, outStride, n);
 		return hipGetLastError();
 	}
 }

@@ -59,8 +59,6 @@ namespace na
 			if (cfg.channels < 1 || cfg.headSize < 1 || cfg.inputSize < 1) throw std::runtime_error("WaveNet layer array with a zero-sized dimension");
 			if (cfg.channels > WN_GENERIC_MAX_CHANNELS || cfg.headSize > WN_GENERIC_MAX_CHANNELS || cfg.inputSize > WN_GENERIC_MAX_CHANNELS)
 				throw std::runtime_error("WaveNet channels > 64 are not supported");
-			if ((cfg.channels > 16 || cfg.headSize > 16 || cfg.inputSize > 16) && cfg.headKernelSize != 1)
-				throw std::runtime_error("WaveNet channels > 16 with a head kernel > 1 are not supported (the runtime-shaped kernel has dense heads only)");
 			if (cfg.conditionSize != 1) throw std::runtime_error("WaveNet condition_size != 1 is not supported");
 			if (cfg.kernelSizes.size() != cfg.dilations.size() || cfg.kernelSizes.empty())
 				throw std::runtime_error("WaveNet kernel_sizes/dilations mismatch");
@@ -544,7 +542,7 @@ namespace na
 					pw.wconv = Take((size_t)cfg.headSize * C * cfg.headKernelSize);
 					pw.bconv = cfg.hasHeadBias ? Take((size_t)cfg.headSize) : -1;
 					pw.wmix = -1; pw.w1 = -1; pw.b1 = -1;
-					pw.ring_id = -1;
+					pw.ring_id = (cfg.headKernelSize > 1) ? AddRing(C, (cfg.headKernelSize - 1) * cfg.headDilation) : -1; // a conv head keeps its own history
 					pw.rechannel = -1;
 					pw.dilation = cfg.headDilation;
 					plan.prewarm.push_back(pw);
@@ -564,7 +562,7 @@ namespace na
 				for (const WnArrayCfg& cfg : desc.arrays)
 				{
 					plan.maxChannels = std::max(plan.maxChannels, std::max(cfg.channels, std::max(cfg.headSize, cfg.inputSize)));
-					if (cfg.headKernelSize != 1) plan.genericOk = false;
+					(void)cfg; // (conv heads run on the runtime-shaped kernel too since round 3)
 				}
 				if (plan.maxChannels > 16)
 				{

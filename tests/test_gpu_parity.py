@@ -233,6 +233,25 @@ def test_wavenet_wider_than_16_channels_matches_oracle(na, loader, channels, hea
     assert np.max(np.abs(y2 - y)) < 1e-6
 
 
+@pytest.mark.parametrize("channels,act", [(24, O.ACT_LEAKYRELU), (40, O.ACT_TANH), (64, O.ACT_LEAKYRELU)])
+def test_wide_wavenet_with_a_conv_head_matches_oracle(na, loader, channels, act):
+    """A single wide layer array with an A2-style conv head (kernel 16, bias; the head accumulator keeps its own history ring): the
+    reference's dynamic engine takes any such shape (WaveNetDynamic.h:67-83 Conv1D, :229-254, :445-468); here it runs on the
+    runtime-shaped kernel, whose layer mat-muls are on the matrix pipe."""
+    arrays = [dict(input_size=1, condition_size=1, head_size=1, head_kernel_size=16, head_dilation=1, channels=channels, has_head_bias=True,
+                   activation=act, kernel_sizes=[6, 3, 15, 2, 6], dilations=[1, 17, 13, 101, 239])]
+    w = O.synth_wavenet_weights(arrays, seed=100 + channels)
+    m = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam")
+    assert m is not None
+    x = O.signal_noise(128 * 12 + 50, 6)
+    y = np.concatenate([m.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
+    yo = O.OracleWaveNet(arrays, w).process(x)
+    assert O.rms(yo) > 1e-4 and O.rms(y - yo) < 2e-6 * max(1.0, O.rms(yo)), (channels, O.rms(y - yo), O.rms(yo))
+    m2 = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam")
+    y2 = np.concatenate([m2.Process(x[i:i + 53]) for i in range(0, x.size, 53)])
+    assert np.max(np.abs(y2 - y)) < 2e-6 * max(1.0, float(np.abs(y).max()))
+
+
 def test_generic_keras_stack_files_match_committed_torch_vectors(na, loader):
     """HIP path vs an INDEPENDENT implementation: tests/golden/keras_stacks_torch.npz holds torch.nn.LSTM / GRU / Linear outputs for three
     committed synthetic keras stacks (RTNeural is absent: parity unpinned)."""
