@@ -667,6 +667,27 @@ namespace na
 				dW.Upload(w, stream);
 				dInit.Upload(init, stream);
 				dev.w = dW.Get();
+				{
+					// the gate matrices once more, transposed into [quad of inputs][row][4] (lstm_dev.h: LstmModelDev::wT)
+					const int H = lstm.hiddenSize, gateRows = ((lstm.cell == CELL_GRU) ? 3 : 4) * H;
+					dev.rowsPad = (gateRows + 63) / 64 * 64;
+					std::vector<float> wt;
+					for (int l = 0; l < lstm.numLayers; l++)
+					{
+						const int I = (l == 0) ? 1 : H, W = I + H, Qi = (I + 3) / 4, Qh = (H + 3) / 4;
+						dev.layerOffT[l] = (int)wt.size();
+						wt.resize(wt.size() + (size_t)(Qi + Qh) * dev.rowsPad * 4, 0.0f);
+						float* dst = wt.data() + dev.layerOffT[l];
+						const std::vector<float>& src = lstm.layers[(size_t)l].w; // row-major [gateRows][W]
+						for (int r = 0; r < gateRows; r++)
+						{
+							for (int k = 0; k < I; k++) dst[((size_t)(k / 4) * dev.rowsPad + r) * 4 + (k % 4)] = src[(size_t)r * W + k];
+							for (int k = 0; k < H; k++) dst[((size_t)(Qi + k / 4) * dev.rowsPad + r) * 4 + (k % 4)] = src[(size_t)r * W + I + k];
+						}
+					}
+					dWT.Upload(wt, stream);
+					dev.wT = dWT.Get();
+				}
 				dev.cell = (lstm.cell == CELL_GRU) ? LSTM_CELL_GRU : LSTM_CELL_LSTM;
 				dev.numLayers = lstm.numLayers;
 				dev.hidden = lstm.hiddenSize;
@@ -790,7 +811,7 @@ namespace na
 
 		private:
 			LstmModelDev dev = {};
-			DevArray<float> dW, dInit, dZeros;
+			DevArray<float> dW, dWT, dInit, dZeros;
 			DevArray<float> state;
 			std::vector<float> init;
 			int numElems = 0;

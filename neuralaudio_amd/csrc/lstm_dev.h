@@ -24,18 +24,30 @@ namespace na
 	//   LSTM: any hidden size / layer count whose lane = stream working set fits the 160 KB LDS (LstmGenericKernel); the usual sizes
 	//   have shaped kernels.  GRU: likewise (GruGenericKernel; GruWaveKernel / DPP instances for 1-2 layers of 8, 12, 16, 20).
 	// tailWidth: widest dense layer of a generic keras stack (0: the classic 1-unit head); such a model may have no recurrent layer
-	inline bool LstmShapeSupported(int hidden, int numLayers, int tailWidth = 0)
+	//   Round 3: the runtime-shaped wave kernel streams weights that do not fit the LDS from L2 (RecurrentWaveRtKernel, weights
+	//   transposed for coalesced reads), so every shape up to RECURRENT_WAVE_MAX_HIDDEN units has a real-time kernel whatever the
+	//   weight size (LSTMDynamic.h:95-108,166-179 runs any size on the CPU).
+	constexpr int RECURRENT_WAVE_MAX_HIDDEN = 128;
+	inline bool RecurrentWaveShape(int hidden, int numLayers, int tailWidth)
+	{
+		return hidden >= 1 && hidden <= RECURRENT_WAVE_MAX_HIDDEN && numLayers >= (tailWidth > 0 ? 0 : 1) && numLayers <= LSTM_MAX_LAYERS &&
+			tailWidth <= LSTM_MAX_TAIL_WIDTH;
+	}
+	// the lane = stream kernels' bound (LstmGenericKernel / GruGenericKernel: state of 64 streams in LDS)
+	inline bool LstmLaneKernelShape(int hidden, int numLayers, int tailWidth = 0)
 	{
 		if (hidden < 1 || numLayers < (tailWidth > 0 ? 0 : 1) || numLayers > LSTM_MAX_LAYERS || tailWidth > LSTM_MAX_TAIL_WIDTH) return false;
 		const long bytes = (64L * (LSTM_MAX_FRAMES + 1) + (long)numLayers * 2 * hidden * 64 + (long)hidden * 64 + 2L * tailWidth * 64) * 4;
 		return bytes <= 160L * 1024;
 	}
-	inline bool GruShapeSupported(int hidden, int numLayers, int tailWidth = 0)
+	inline bool GruLaneKernelShape(int hidden, int numLayers, int tailWidth = 0)
 	{
 		if (hidden < 1 || numLayers < 1 || numLayers > LSTM_MAX_LAYERS || tailWidth > LSTM_MAX_TAIL_WIDTH) return false;
 		const long bytes = (64L * (LSTM_MAX_FRAMES + 1) + (long)numLayers * hidden * 64 + 6L * hidden * 64 + 2L * tailWidth * 64) * 4; // GruGenericKernel's LDS
 		return bytes <= 160L * 1024;
 	}
+	inline bool LstmShapeSupported(int hidden, int numLayers, int tailWidth = 0) { return LstmLaneKernelShape(hidden, numLayers, tailWidth) || RecurrentWaveShape(hidden, numLayers, tailWidth); }
+	inline bool GruShapeSupported(int hidden, int numLayers, int tailWidth = 0) { return GruLaneKernelShape(hidden, numLayers, tailWidth) || (numLayers >= 1 && RecurrentWaveShape(hidden, numLayers, tailWidth)); }
 
 	struct LstmModelDev
 	{
@@ -54,5 +66,11 @@ namespace na
 		int tailLayers;
 		int tailOff[LSTM_MAX_TAIL], tailIn[LSTM_MAX_TAIL], tailOut[LSTM_MAX_TAIL], tailAct[LSTM_MAX_TAIL];
 		int tailWidth; // widest layer
+		// the same gate matrices transposed for the wave kernel's L2-streamed mode (weights larger than the LDS): per layer
+		// [Qi + Qh][rowsPad][4] floats -- quad q of row r = weights of inputs 4q .. 4q + 3 (input part padded to Qi = ceil(I / 4) quads, hidden
+		// part to Qh = ceil(H / 4)), rows padded to a multiple of 64: the 64 lanes of a wave read 64 consecutive rows of one quad = 1 KB
+		const float* wT;
+		int layerOffT[LSTM_MAX_LAYERS]; // float offsets into wT
+		int rowsPad;
 	};
 }

@@ -342,18 +342,114 @@ namespace na
 	// ------------------------------------------------------------------------------------------------------------
 	__device__ __forceinline__ int OddStride(int w) { return w | 1; }
 
-	static size_t RecurrentWaveRtLdsFloats(const LstmModelDev& m)
+	static size_t RecurrentWaveRtLdsFloats(const LstmModelDev& m, bool weightsInLds = true)
 	{
 		const int H = m.hidden, L = m.numLayers;
 		const int rowsPerLayer = (m.cell == LSTM_CELL_GRU ? 3 : 4) * H, biases = (m.cell == LSTM_CELL_GRU ? 6 : 4) * H;
 		size_t f = (size_t)LSTM_MAX_FRAMES + (size_t)2 * L * H + (size_t)6 * H + (size_t)2 * (L > 0 ? H : 1) * 64 +
 			(size_t)2 * (m.tailLayers > 0 ? m.tailWidth : 0) * 64;
-		for (int l = 0; l < L; l++) f += (size_t)rowsPerLayer * (size_t)(((l == 0 ? 1 : H) + H) | 1) + (size_t)biases;
+		if (weightsInLds)
+			for (int l = 0; l < L; l++) f += (size_t)rowsPerLayer * (size_t)(((l == 0 ? 1 : H) + H) | 1) + (size_t)biases;
 		return f;
 	}
 
+	// The dot products of the lane's gate rows r = lane + 64 i (i < RPL) from the transposed L2-resident weights (LstmModelDev::wT), all
+	// rows of the lane side by side: per quad of inputs RPL independent 1 KB weight loads per wave and one set of broadcast state reads
+	// (the rows of a lane were evaluated one after the other at first: LSTM 2x64 2.97 ms per block; side by side the loads of all rows
+	// are in flight together).  Input part and hidden part apart (the GRU keeps them apart; the LSTM adds them).  Same term order per
+	// row as the LDS path: k = 0 .. I-1, then 0 .. H-1 (padding terms are zeros).
+	typedef float rt_f4 __attribute__((ext_vector_type(4)));
+	template <int RPL>
+	__device__ __forceinline__ void RowsDotL2(const float* __restrict__ wTl, int rowsPad, int lane, int I, int H, const float* sIn, const float* sH, float (&ai)[RPL],
+		float (&ah)[RPL])
+	{
+		const int Qi = (I + 3) / 4, Qh = (H + 3) / 4;
+		const rt_f4* wq = reinterpret_cast<const rt_f4*>(wTl) + lane;
+		for (int q = 0; q < Qi; q++)
+		{
+			const float s0 = sIn[4 * q], s1 = (4 * q + 1 < I) ? sIn[4 * q + 1] : 0.0f, s2 = (4 * q + 2 < I) ? sIn[4 * q + 2] : 0.0f, s3 = (4 * q + 3 < I) ? sIn[4 * q + 3] : 0.0f;
+#pragma unroll
+			for (int i = 0; i < RPL; i++)
+			{
+				const rt_f4 w4 = wq[(size_t)q * rowsPad + 64 * i];
+				ai[i] += w4.x * s0;
+				ai[i] += w4.y * s1;
+				ai[i] += w4.z * s2;
+				ai[i] += w4.w * s3;
+			}
+		}
+		wq += (size_t)Qi * rowsPad;
+#pragma unroll 2
+		for (int q = 0; q < Qh; q++)
+		{
+			const float s0 = sH[4 * q], s1 = (4 * q + 1 < H) ? sH[4 * q + 1] : 0.0f, s2 = (4 * q + 2 < H) ? sH[4 * q + 2] : 0.0f, s3 = (4 * q + 3 < H) ? sH[4 * q + 3] : 0.0f;
+#pragma unroll
+			for (int i = 0; i < RPL; i++)
+			{
+				const rt_f4 w4 = wq[(size_t)q * rowsPad + 64 * i];
+				ah[i] += w4.x * s0;
+				ah[i] += w4.y * s1;
+				ah[i] += w4.z * s2;
+				ah[i] += w4.w * s3;
+			}
+		}
+	}
+
+	// gate pre-activations of one layer from L2-streamed weights -> gates[] (LSTM: activated; GRU: ai | ah), RPL = rows per lane
+	template <int RPL>
+	__device__ __forceinline__ void GateRowsL2(const LstmModelDev& m, int l, int lane, const float* sIn, const float* sH, float* gates)
+	{
+		const int H = m.hidden, I = (l == 0) ? 1 : H, W = I + H;
+		const bool gru = m.cell == LSTM_CELL_GRU;
+		const int rows = (gru ? 3 : 4) * H;
+		const float* bias = m.w + m.layerOff[l] + (size_t)rows * W;
+		float ai[RPL], ah[RPL];
+#pragma unroll
+		for (int i = 0; i < RPL; i++)
+		{
+			const int r = lane + 64 * i;
+			ai[i] = (gru && r < rows) ? bias[r] : 0.0f;
+			ah[i] = (gru && r < rows) ? bias[3 * H + r] : 0.0f;
+		}
+		RowsDotL2<RPL>(m.wT + m.layerOffT[l], m.rowsPad, lane, I, H, sIn, sH, ai, ah);
+#pragma unroll
+		for (int i = 0; i < RPL; i++)
+		{
+			const int r = lane + 64 * i;
+			if (r >= rows) continue;
+			if (gru)
+			{
+				gates[r] = ai[i];
+				gates[3 * H + r] = ah[i];
+			}
+			else
+			{
+				const float acc = (ai[i] + ah[i]) + bias[r];
+				const bool isG = (r >= 2 * H) && (r < 3 * H); // rows [2H, 3H) are the cell candidate (tanh), the others sigmoid (LSTM.h:33-36,94-99)
+				gates[r] = isG ? LstmTanh(acc, m.math) : LstmSigmoid(acc, m.math);
+			}
+		}
+	}
+
+	__device__ __forceinline__ void GateRowsL2Dispatch(const LstmModelDev& m, int l, int lane, const float* sIn, const float* sH, float* gates)
+	{
+		const int rpl = (((m.cell == LSTM_CELL_GRU) ? 3 : 4) * m.hidden + 63) / 64;
+		switch (rpl)
+		{
+		case 1: GateRowsL2<1>(m, l, lane, sIn, sH, gates); break;
+		case 2: GateRowsL2<2>(m, l, lane, sIn, sH, gates); break;
+		case 3: GateRowsL2<3>(m, l, lane, sIn, sH, gates); break;
+		case 4: GateRowsL2<4>(m, l, lane, sIn, sH, gates); break;
+		case 5: GateRowsL2<5>(m, l, lane, sIn, sH, gates); break;
+		case 6: GateRowsL2<6>(m, l, lane, sIn, sH, gates); break;
+		case 7: GateRowsL2<7>(m, l, lane, sIn, sH, gates); break;
+		default: GateRowsL2<8>(m, l, lane, sIn, sH, gates); break;
+		}
+	}
+
+	// l2w: the gate matrices are streamed from L2 (m.wT) instead of living in LDS -- for weights larger than the LDS (LSTM 2x64: 197 KB)
 	__global__ void __launch_bounds__(64) RecurrentWaveRtKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
-		const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
+		const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n, int l2w)
 	{
 		extern __shared__ __attribute__((aligned(16))) float lds[];
 		const int H = m.hidden, L = m.numLayers;
@@ -377,6 +473,7 @@ namespace na
 		float* outRow = out + (size_t)row * outStride;
 
 		// weights -> LDS (global layout per layer: W row-major [G H][I + H], then the biases: LSTM bias[4H]; GRU b_in[3H], b_rec[3H])
+		if (!l2w)
 		{
 			float* dst = wl;
 			for (int l = 0; l < L; l++)
@@ -405,9 +502,11 @@ namespace na
 				const int I = (l == 0) ? 1 : H, W = I + H, stride = OddStride(W);
 				const float* sIn = (l == 0) ? (xin + f) : (hvec + (l - 1) * H); // LSTM.h:168 / :170-180
 				float* sH = hvec + l * H;
-				const float* bias = wlay + (size_t)G * H * stride;
+				const float* bias = wlay + (size_t)G * H * stride; // (LDS mode)
+				if (l2w) GateRowsL2Dispatch(m, l, lane, sIn, sH, gates);
 				if (!gru)
 				{
+					if (!l2w)
 					for (int r = lane; r < 4 * H; r += 64)
 					{
 						const float* wr = wlay + (size_t)r * stride;
@@ -433,6 +532,7 @@ namespace na
 				else
 				{
 					// keras GRU, reset_after (gru_kernels.hip GruLayerStep): input and recurrent pre-activations kept apart
+					if (!l2w)
 					for (int r = lane; r < 3 * H; r += 64)
 					{
 						const float* wr = wlay + (size_t)r * stride;
@@ -490,9 +590,17 @@ namespace na
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err)
 	{
 		static const bool off = getenv("NA_LSTM_NO_WAVE_RT") != nullptr; // tuning knob / tests: the lane = stream kernels for every shape
-		if (off || m.hidden > 64 || m.numLayers < 0 || (m.numLayers == 0 && m.tailLayers == 0)) return false;
-		const size_t ldsBytes = RecurrentWaveRtLdsFloats(m) * sizeof(float);
-		if (ldsBytes > 160 * 1024) return false;
+		if (off || m.hidden > RECURRENT_WAVE_MAX_HIDDEN || m.numLayers < 0 || (m.numLayers == 0 && m.tailLayers == 0)) return false;
+		size_t ldsBytes = RecurrentWaveRtLdsFloats(m) * sizeof(float);
+		// weights larger than the LDS (LSTM 2x64: 197 KB): streamed from L2, transposed for coalesced reads (NA_REC_L2W=1 forces the mode)
+		static const bool forceL2 = getenv("NA_REC_L2W") != nullptr && atoi(getenv("NA_REC_L2W")) != 0;
+		const int l2w = (ldsBytes > 160 * 1024 || (forceL2 && m.numLayers > 0)) ? 1 : 0;
+		if (l2w)
+		{
+			if (m.wT == nullptr) return false;
+			ldsBytes = RecurrentWaveRtLdsFloats(m, false) * sizeof(float);
+			if (ldsBytes > 160 * 1024) return false;
+		}
 		static bool attrSet = false;
 		if (!attrSet)
 		{
@@ -500,7 +608,7 @@ namespace na
 			attrSet = true;
 		}
 		hipLaunchKernelGGL(RecurrentWaveRtKernel, dim3((unsigned)numStreams), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows, in, out, inStride,
-			outStride, n);
+			outStride, n, l2w);
 		err = hipGetLastError();
 		return true;
 	}

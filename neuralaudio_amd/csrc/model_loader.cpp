@@ -343,11 +343,11 @@ namespace na
 		{
 			if (!GruShapeSupported(d.hiddenSize, d.numLayers, tailWidth))
 				throw std::runtime_error("GRU " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
-					" is not supported (1-8 layers; the per-stream state must fit the 160 KB LDS)");
+					" is not supported (1-8 layers of up to 128 units, or a per-stream state that fits the 160 KB LDS)");
 		}
 		else if (!LstmShapeSupported(d.hiddenSize, d.numLayers, tailWidth))
 			throw std::runtime_error("LSTM " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
-				" is not supported (1-8 layers; the per-stream state must fit the 160 KB LDS)");
+				" is not supported (1-8 layers of up to 128 units, or a per-stream state that fits the 160 KB LDS)");
 	}
 
 	namespace

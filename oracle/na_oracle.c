@@ -683,7 +683,7 @@ void na_oracle_gru_free(na_oracle_gru* m)
 static void gru_layer_step(na_oracle_gru* m, int l, const float* x)
 {
 	const int H = m->hidden, I = (l == 0) ? 1 : H;
-	float ai[3 * 64], ah[3 * 64]; /* H <= 64 */
+	float ai[3 * 256], ah[3 * 256]; /* H <= 256 */
 	float* h = m->h[l];
 	for (int r = 0; r < 3 * H; r++) {
 		float a = 0.0f, b = 0.0f;

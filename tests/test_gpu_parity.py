@@ -179,9 +179,12 @@ def test_recurrent_models_through_tiny_and_ragged_buffers(na, kind, layers, hidd
     assert O.rms(np.concatenate(out) - want) < 5e-6
 
 
-@pytest.mark.parametrize("layers,hidden", [(1, 3), (1, 18), (3, 16), (2, 40), (2, 64)])
+@pytest.mark.parametrize("layers,hidden", [(1, 3), (1, 18), (3, 16), (2, 40), (2, 64), (1, 128), (2, 96), (3, 128)])
 def test_runtime_shaped_lstm_matches_oracle(na, loader, layers, hidden):
-    """Hidden sizes / layer counts without a shaped kernel run on the runtime-shaped one (LSTMDynamic.h:95-108 accepts any)."""
+    """Hidden sizes / layer counts without a shaped kernel run on the runtime-shaped one (LSTMDynamic.h:95-108 accepts any); shapes
+    whose weights exceed the LDS (2x64 and up) stream them from L2, up to 128 units."""
+    if os.environ.get("NA_LSTM_NO_WAVE_RT") and (hidden > 64 or layers * hidden > 128):
+        pytest.skip("beyond the lane = stream kernel's LDS bound")
     w = O.synth_lstm_weights(layers, hidden, seed=100 + hidden)
     m = loader.CreateFromString(O.nam_json_lstm(layers, hidden, w), ".nam")
     assert m is not None
@@ -250,6 +253,45 @@ def test_wide_wavenet_with_a_conv_head_matches_oracle(na, loader, channels, act)
     m2 = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam")
     y2 = np.concatenate([m2.Process(x[i:i + 53]) for i in range(0, x.size, 53)])
     assert np.max(np.abs(y2 - y)) < 2e-6 * max(1.0, float(np.abs(y).max()))
+
+
+def test_large_recurrent_models_run_in_real_time(na, loader):
+    """LSTM 2x64 (197 KB of weights: more than the LDS) took 251 ms per 128-sample block on the lane = stream kernel in round 2 -- not
+    real time (a block lasts 2.67 ms at 48 kHz; LSTMDynamic.h:95-108,166-179 runs any size in real time on a CPU).  With the weights
+    streamed from L2 the wave kernel must stay under 2 ms for 64 streams; keras GRU 1x64 and LSTM 1x128 likewise."""
+    import json
+    import time
+    if os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_LSTM_LANE_KERNEL"):
+        pytest.skip("forced lane = stream kernels")
+    w = O.synth_lstm_weights(2, 64, seed=164)
+    models = [loader.CreateFromString(O.nam_json_lstm(2, 64, w), ".nam"), loader.CreateFromString(O.nam_json_lstm(1, 128, O.synth_lstm_weights(1, 128, seed=9)), ".nam"),
+              loader.CreateFromString(json.dumps(O.synth_keras_gru(2, 64, seed=75)), ".json")]
+    for m in models:
+        assert m is not None
+        b = na.Batch(0)
+        b.AddStreams(m, 64)
+        x = np.stack([O.signal_noise(128, 60 + s) for s in range(64)])
+        for _ in range(3):
+            b.Process(x)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            b.Process(x)
+        per_block = (time.perf_counter() - t0) / 10
+        assert per_block < 2e-3, per_block
+        b.close()
+
+
+@pytest.mark.parametrize("layers,hidden", [(1, 64), (2, 64), (1, 128)])
+def test_large_keras_gru_matches_oracle(na, loader, layers, hidden):
+    import json
+    if os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_LSTM_LANE_KERNEL"):
+        pytest.skip("forced lane = stream kernels")
+    j = O.synth_keras_gru(layers, hidden, seed=31 + hidden)
+    m = loader.CreateFromString(json.dumps(j), ".json")
+    assert m is not None
+    x = O.signal_noise(300, 8)
+    y = np.concatenate([m.Process(x[i:i + 100]) for i in range(0, x.size, 100)])
+    assert O.rms(y - O.OracleGRU(j).process(x)) < 5e-6
 
 
 def test_generic_keras_stack_files_match_committed_torch_vectors(na, loader):

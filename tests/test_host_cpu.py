@@ -193,17 +193,18 @@ def test_lstm_shapes_accepted_or_rejected_at_load(na, tmp_path):
     """Any hidden size the reference's dynamic LSTM takes loads (runtime-shaped kernel); what has no kernel fails at load, with a reason."""
     loader = na.NeuralModelLoader()
     path = tmp_path / "m.nam"
-    for layers, hidden in ((1, 3), (1, 18), (3, 16), (2, 64)):
+    for layers, hidden in ((1, 3), (1, 18), (3, 16), (2, 64), (3, 128)):  # (up to 128 units whatever the weight size: streamed from L2)
         path.write_text(O.nam_json_lstm(layers, hidden, O.synth_lstm_weights(layers, hidden, seed=hidden)))
         assert loader.CreateFromFile(str(path), doPrewarm=False) is not None
     path.write_text(O.nam_json_lstm(2, 192, O.synth_lstm_weights(2, 192, seed=1)))
     with pytest.raises(na.NeuralAudioError, match="LSTM 2x192 is not supported"):
         loader.CreateFromFile(str(path), doPrewarm=False)
     gru = tmp_path / "gru.json"
-    gru.write_text(json.dumps(O.synth_keras_gru(3, 16, seed=3)))
-    assert loader.CreateFromFile(str(gru), doPrewarm=False) is not None  # any shape: runtime-shaped GRU kernel
-    gru.write_text(json.dumps(O.synth_keras_gru(1, 96, seed=3)))
-    with pytest.raises(na.NeuralAudioError, match="GRU 1x96 is not supported"):
+    for layers, hidden in ((3, 16), (1, 96), (2, 128)):
+        gru.write_text(json.dumps(O.synth_keras_gru(layers, hidden, seed=3)))
+        assert loader.CreateFromFile(str(gru), doPrewarm=False) is not None  # any shape up to 128 units: runtime-shaped GRU kernel
+    gru.write_text(json.dumps(O.synth_keras_gru(1, 160, seed=3)))
+    with pytest.raises(na.NeuralAudioError, match="GRU 1x160 is not supported"):
         loader.CreateFromFile(str(gru), doPrewarm=False)
 
 
