@@ -316,7 +316,11 @@ namespace na
 			const WnFamily o = WaveNetFamilyOverride();
 			if (o == WN_FAMILY_GENERIC && !plan.genericOk) return WN_FAMILY_FRAME; // (conv heads: not in the runtime-shaped kernel)
 			if (o != WN_FAMILY_AUTO) return o;
-			return plan.splitFastT == 2 ? WN_FAMILY_SPLIT : WN_FAMILY_FRAME;
+			if (plan.splitFastT == 2) return WN_FAMILY_SPLIT;
+			// the A2 submodels have compile-time specialised chains on the split kernels' state format (wavenet_spec_kernels.hip; round 3:
+			// 2048-stream quality sweep 120 us on the frame kernel); blocks that are not 128 / 64 frames fall to the stage interpreter
+			const int spec = WaveNetSpecArchId(plan.sstages.data(), (int)plan.sstages.size(), plan.stateF4, (int)(plan.wsplit.size() / 8));
+			return (spec == WN_SPEC_A2FULL || spec == WN_SPEC_A2LITE) ? WN_FAMILY_SPLIT : WN_FAMILY_FRAME;
 		}
 
 		class WaveNetGroup : public ModelGroup

@@ -153,5 +153,7 @@ namespace na
 		WN_SPEC_STD = 1,    // A1 Standard: 16 / 8 channels, dilations 1..512 twice
 		WN_SPEC_LITE = 2,   // the lite dilation lists at 16 / 8 channels (A1 Lite padded, two packed Feather streams)
 		WN_SPEC_LITE16 = 3, // ... at 16 / 16 channels (four packed Nano streams)
+		WN_SPEC_A2FULL = 4, // A2 "Full": one array of 23 layers (K = 6 / 15), 8 channels, conv head of 16 taps, LeakyReLU
+		WN_SPEC_A2LITE = 5, // A2 "Lite": the same with 3 channels (padded to 4; four tiles share an MFMA)
 	};
 }

@@ -30,6 +30,9 @@ namespace na
 	{
 		using namespace sp;
 
+#ifndef NA_SPK_AUX2
+#define NA_SPK_AUX2 0 // tuning builds: 1 = read the aux operand again for the 1x1 instead of keeping it in registers across the layer
+#endif
 		typedef __attribute__((address_space(3))) char* LdsPtr;
 		__device__ __forceinline__ u32x4 LdsRead16(unsigned addr) { return *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>((LdsPtr)(size_t)addr); }
 		__device__ __forceinline__ u32x2 LdsRead8(unsigned addr) { return *reinterpret_cast<__attribute__((address_space(3))) const u32x2*>((LdsPtr)(size_t)addr); }
@@ -37,21 +40,30 @@ namespace na
 
 		// ---- the architectures (virtual models: after padding / stream packing, wavenet_plan.cpp) ---------------------------------
 		// NeuralModel.cpp:71-76 dilation tables; channels are those of the lane modes the plans fill completely
-		struct ArchStd // A1 Standard (16 -> 8)
+		// every A1 architecture: kernel size 3 everywhere, dense head, tanh, 2 tiles per wave, stage operand blocks of <= 10 KB
+		struct ArchA1Base
+		{
+			static constexpr int K(int, int) { return 3; }
+			static constexpr int HEADK = 1;
+			static constexpr bool LEAKY = false;
+			static constexpr int T = 2, CHUNK = 10;
+			static constexpr bool COARSE = false; // (dilations are powers of two: at most three wave classes per layer, 53 KB of code)
+		};
+		struct ArchStd : ArchA1Base // A1 Standard (16 -> 8)
 		{
 			static constexpr int NA = 2;
 			static constexpr int CH[2] = { 16, 8 };
 			static constexpr int NLA[2] = { 10, 10 };
 			static constexpr int DIL[2][16] = { { 1, 2, 4, 8, 16, 32, 64, 128, 256, 512 }, { 1, 2, 4, 8, 16, 32, 64, 128, 256, 512 } };
 		};
-		struct ArchLite // the "lite" dilation lists at 16 / 8 channels: A1 Lite padded (12 / 6), two Feather streams packed (8 / 4 each)
+		struct ArchLite : ArchA1Base // the "lite" dilation lists at 16 / 8 channels: A1 Lite padded (12 / 6), two Feather streams packed (8 / 4 each)
 		{
 			static constexpr int NA = 2;
 			static constexpr int CH[2] = { 16, 8 };
 			static constexpr int NLA[2] = { 7, 13 };
 			static constexpr int DIL[2][16] = { { 1, 2, 4, 8, 16, 32, 64 }, { 128, 256, 512, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512 } };
 		};
-		struct ArchLite16 // ... at 16 / 16 channels: four Nano streams packed (4 / 2 each, the second array padded to 4 per stream)
+		struct ArchLite16 : ArchA1Base // ... at 16 / 16 channels: four Nano streams packed (4 / 2 each, the second array padded to 4 per stream)
 		{
 			static constexpr int NA = 2;
 			static constexpr int CH[2] = { 16, 16 };
@@ -59,10 +71,29 @@ namespace na
 			static constexpr int DIL[2][16] = { { 1, 2, 4, 8, 16, 32, 64 }, { 128, 256, 512, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512 } };
 		};
 
+		// A2 (NeuralModel.cpp:389-421, InternalModel.h:18-20): one array of 23 layers, kernel sizes 6 / 15, a conv head of 16 taps with bias,
+		// LeakyReLU.  "Full": 8 channels (lane mode 2, 2 tiles per wave).  "Lite": 3 channels padded to 4 (lane mode 1: four tiles share
+		// an MFMA, so a wave owns 4 tiles = 64 frames and a stream takes half the waves).  Operand blocks move through LDS in chunks of
+		// <= 16 KB (a K = 6 layer is one chunk, a K = 15 layer three).
+		struct ArchA2Base
+		{
+			static constexpr int NA = 1;
+			static constexpr int NLA[2] = { 23, 0 };
+			static constexpr int DIL[2][32] = { { 1, 3, 7, 17, 41, 101, 239, 1, 3, 7, 17, 41, 101, 239, 1, 13, 1, 3, 7, 17, 41, 101, 239 }, { 0 } };
+			static constexpr int K(int, int l) { return (l == 14 || l == 15) ? 15 : 6; }
+			static constexpr int HEADK = 16;
+			static constexpr bool LEAKY = true;
+			static constexpr int CHUNK = 16;
+			static constexpr bool COARSE = true;
+		};
+		struct ArchA2Full : ArchA2Base { static constexpr int CH[2] = { 8, 0 }; static constexpr int T = 2; };
+		struct ArchA2Lite : ArchA2Base { static constexpr int CH[2] = { 4, 0 }; static constexpr int T = 4; };
+
 		// architectures that may share one launch (same stage count, same LDS map): GroupArgs::arch picks the member per workgroup
 		struct FamStd { typedef ArchStd A0; typedef ArchStd A1; static constexpr int N = 1; };
 		struct FamLite { typedef ArchLite A0; typedef ArchLite A1; static constexpr int N = 1; };
 		struct FamLitePacked { typedef ArchLite A0; typedef ArchLite16 A1; static constexpr int N = 2; };
+		struct FamA2 { typedef ArchA2Full A0; typedef ArchA2Lite A1; static constexpr int N = 2; };
 
 		enum TapClass { TAP_LDS = 0, TAP_HIST = 1, TAP_BOTH = 2 };
 
@@ -79,45 +110,84 @@ namespace na
 			static constexpr int GPof(int a) { return A::CH[a] / 4; } // lane mode == channel groups (full modes only)
 			static constexpr bool FirstOfArr(int L) { return InArr(L) == 0; }
 			static constexpr bool LastOfArr(int L) { return InArr(L) == A::NLA[ArrOf(L)] - 1; }
-			static constexpr int RingFrames(int L) { return (2 * Dil(L) + 15) / 16 * 16 + FRAMES; } // K = 3; wavenet_plan.cpp AddRing
+			static constexpr int KS(int L) { return A::K(ArrOf(L), InArr(L)); }
+			static constexpr int HEADK = A::HEADK;
+			static constexpr int NRINGS = NL + (HEADK > 1 ? 1 : 0); // one per layer (+ the conv head's)
+			// ring L < NL: input history of layer L; ring NL: the head accumulator's (wavenet_plan.cpp AddRing: roundup16((K - 1) d) + 128)
+			static constexpr int RingFrames(int L) { return L < NL ? ((KS(L) - 1) * Dil(L) + 15) / 16 * 16 + FRAMES : (HEADK - 1 + 15) / 16 * 16 + FRAMES; }
+			static constexpr int RingG(int L) { return GPof(L < NL ? ArrOf(L) : NA - 1); }
 			static constexpr int RingOff(int L) // quads
 			{
 				int o = WN_HEADER_F4;
-				for (int l = 0; l < L; l++) o += RingFrames(l) * GPof(ArrOf(l));
+				for (int l = 0; l < L; l++) o += RingFrames(l) * RingG(l);
 				return o;
 			}
-			static constexpr int StateF4 = (RingOff(NL) + 15) / 16 * 16;
+			static constexpr int StateF4 = (RingOff(NRINGS) + 15) / 16 * 16;
 			static constexpr int StageOfLayer(int L) { return 1 + L + ArrOf(L); }
 			static constexpr int FirstLayerOfArr(int a) { int L = 0; for (int i = 0; i < a; i++) L += A::NLA[i]; return L; }
 			static constexpr int LinkStage(int a) { return FirstLayerOfArr(a) + a; } // the link in front of array a >= 1
 			static constexpr int LinkNC(int a) { const int Po = 4 / GPof(a - 1), Pn = 4 / GPof(a); return Po > Pn ? Po : Pn; }
+			static constexpr int LayerOfStage(int s) // -1: not a layer stage
+			{
+				for (int L = 0; L < NL; L++)
+					if (StageOfLayer(L) == s) return L;
+				return -1;
+			}
 			static constexpr int StageOps(int s)
 			{
 				if (s == 0) return 1;
-				if (s == NSTAGES - 1) return 3;
+				if (s == NSTAGES - 1) return 2 * HEADK + 1;
 				for (int a = 1; a < NA; a++)
 					if (s == LinkStage(a)) return 4 * LinkNC(a) + 1;
-				return 10; // 2 K + 4, K = 3
+				return 2 * KS(LayerOfStage(s)) + 4;
 			}
-			static constexpr int MaxOps() { int m = 0; for (int s = 0; s < NSTAGES; s++) m = StageOps(s) > m ? StageOps(s) : m; return m; }
 			static constexpr int AOff(int s) { int o = 0; for (int i = 0; i < s; i++) o += StageOps(i) * 64; return o; } // quads
 			static constexpr int WsplitQuads = AOff(NSTAGES);
+			// A stage's operands move through LDS in chunks of <= CHUNK operands (a 1 KB operand each).  A block that fits is one chunk;
+			// a larger one (K = 15 layer: 34, conv head: 33) is cut into tap chunks -- whole (hi, lo) pairs, evenly sized -- and a tail
+			// chunk with what follows the taps (aux / 1x1 operands, head bias).
+			static constexpr int CHUNK = A::CHUNK;
+			static constexpr int TapOps(int s) { return s == NSTAGES - 1 ? 2 * HEADK : 2 * KS(LayerOfStage(s)); }
+			static constexpr bool Chunked(int s) { return StageOps(s) > CHUNK; }
+			static constexpr int TapChunks(int s) { return (TapOps(s) + CHUNK - 1) / CHUNK; }
+			static constexpr int NumChunks(int s) { return Chunked(s) ? TapChunks(s) + 1 : 1; }
+			static constexpr int ChunkBegin(int s, int c)
+			{
+				if (!Chunked(s)) return 0;
+				if (c >= TapChunks(s)) return TapOps(s);
+				const int pairs = TapOps(s) / 2, n = TapChunks(s);
+				return 2 * ((pairs * c + n - 1) / n); // pairs split as evenly as possible
+			}
+			static constexpr int ChunkEnd(int s, int c) { return !Chunked(s) ? StageOps(s) : (c >= TapChunks(s) ? StageOps(s) : ChunkBegin(s, c + 1)); }
+			static constexpr int ChunkIndex(int s, int c) { int n = 0; for (int i = 0; i < s; i++) n += NumChunks(i); return n + c; } // LDS buffer = index & 1
+			static constexpr int MaxChunkOps()
+			{
+				int m = 0;
+				for (int s = 0; s < NSTAGES; s++)
+					for (int c = 0; c < NumChunks(s); c++) m = (ChunkEnd(s, c) - ChunkBegin(s, c)) > m ? (ChunkEnd(s, c) - ChunkBegin(s, c)) : m;
+				return m;
+			}
+			static constexpr int MaxGP() { int m = 0; for (int a = 0; a < NA; a++) m = GPof(a) > m ? GPof(a) : m; return m; }
 		};
 
-		// launch shape: NF frames per block, T = 2 tiles per wave, SPB streams per workgroup sharing the staged weights
+		// launch shape: NF frames per block, T tiles per wave (FW = 16 T frames), SPB streams per workgroup sharing the staged weights.
+		// SPB_ counts streams of 4 waves-per-128-frames (T = 2): an architecture with T = 4 takes half the waves per stream and puts twice
+		// the streams into the workgroup, so every member of a family launches the same number of threads.
 		template <class A_, int NF_, int SPB_, bool PK_>
 		struct Cfg
 		{
 			typedef A_ A;
 			typedef Tab<A_> TB;
-			static constexpr int NF = NF_, SPB = SPB_, T = 2, WPS = NF_ / 32, NTHREADS = 64 * WPS * SPB;
+			static constexpr int NF = NF_, T = A_::T, FW = 16 * T, WPS = NF_ / FW, SPB = SPB_ * T / 2, NTHREADS = 64 * WPS * SPB;
+			static_assert(WPS >= 1 && WPS * FW == NF_, "block length is a whole number of waves");
 			static constexpr bool PK = PK_;
-			static constexpr int MAXOPS = 10; // the same LDS map for every architecture (members of a family share a launch)
-			static_assert(TB::MaxOps() <= MAXOPS, "stage operand block");
+			static constexpr int MAXOPS = A_::CHUNK; // operands per LDS weight buffer
+			static_assert(TB::MaxChunkOps() <= MAXOPS, "stage operand chunk");
+			static constexpr int HPF = 5;            // shifted taps whose ring history is prefetched a layer ahead (K = 3: both, K = 6: all five)
 			// LDS map (bytes)
 			static constexpr int AUX_OFF = 0;                                   // [SPB][FRAMES] quads, PK: [SPB][4][FRAMES] x 8 bytes
-			static constexpr int IMG_OFF = AUX_OFF + SPB * FRAMES * (PK_ ? 32 : 16); // [SPB][2][4][PLANE] quads
-			static constexpr int IMG_ONE = 4 * PLANE * 16;                      // one image: 4 planes
+			static constexpr int IMG_OFF = AUX_OFF + SPB * FRAMES * (PK_ ? 32 : 16); // [SPB][2][planes][PLANE] quads
+			static constexpr int IMG_ONE = TB::MaxGP() * PLANE * 16;            // one image: a plane per channel group
 			static constexpr int WBUF_OFF = IMG_OFF + SPB * 2 * IMG_ONE;        // [2][MAXOPS] operands of 1 KB
 			static constexpr int WBUF_ONE = MAXOPS * 1024;
 			static constexpr int IDOP_OFF = WBUF_OFF + 2 * WBUF_ONE;            // identity operand
@@ -126,13 +196,14 @@ namespace na
 			static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 		};
 
-		// geometry of lane mode GP with T = 2 tiles per wave: P tiles share one MFMA ("set"), S sets per wave
-		template <int GP>
+		// geometry of lane mode GP with T tiles per wave: P tiles share one MFMA ("set"), S sets per wave
+		template <int GP, int T>
 		struct Geo
 		{
-			static_assert(GP == 4 || GP == 2, "full lane modes of 16 / 8 channels");
+			static_assert(GP == 4 || GP == 2 || GP == 1, "full lane modes of 16 / 8 / 4 channels");
 			static constexpr int P = 4 / GP;
-			static constexpr int S = 2 / P;
+			static_assert(T % P == 0, "every tile slot of a set is a tile of the wave");
+			static constexpr int S = T / P;
 		};
 
 		// Where do the frames [F0 + 16 P i, + 16 P) of set i of the wave starting at F0 lie relative to the block start, `shift` frames back?
@@ -142,23 +213,37 @@ namespace na
 			return hi < 0 ? TAP_HIST : (lo >= 0 ? TAP_LDS : TAP_BOTH);
 		}
 
-		// everything about layer L that depends on the wave: classes of its two shifted taps and of the next layer's (history prefetch)
+		// The class a wave uses for a tap.  Exact per wave by default.  Architectures whose dilations are not tile multiples (A2) would get a
+		// different tap pattern -- hence a different unrolled body -- on nearly every wave of a layer: four bodies per layer, 166 KB of code
+		// against a 64 KB instruction cache shared by two CUs (measured: waves waiting thousands of cycles for their body's first fetch,
+		// A2 "Full" 164 us per 1024 streams).  With COARSE wave 0 keeps its exact classes and waves 1 .. share one body: a tap they do not
+		// agree on runs as TAP_BOTH on all of them (always correct: predicated ring load + clamped LDS read, two more MFMAs).
+		template <class C>
+		constexpr int WaveTapClass(int w, int P, int i, int shift)
+		{
+			if (!C::A::COARSE || w == 0 || C::WPS <= 2) return TapClassOf(C::FW * w, P, i, shift);
+			const int first = TapClassOf(C::FW * 1, P, i, shift);
+			for (int v = 2; v < C::WPS; v++)
+				if (TapClassOf(C::FW * v, P, i, shift) != first) return TAP_BOTH;
+			return first;
+		}
+
+		// everything about layer L that depends on the wave: classes of its shifted taps and of the next layer's prefetched ones
 		template <class C, int L>
 		struct LayerSig
 		{
 			typedef typename C::TB TB;
-			static constexpr int GP = TB::GPof(TB::ArrOf(L)), P = Geo<GP>::P, S = Geo<GP>::S, d = TB::Dil(L);
+			static constexpr int GP = TB::GPof(TB::ArrOf(L)), P = Geo<GP, C::T>::P, S = Geo<GP, C::T>::S, d = TB::Dil(L), K = TB::KS(L);
 			static constexpr bool NEXT = !TB::LastOfArr(L); // a layer of the same array follows (its history is requested during this one)
-			static constexpr int dn = NEXT ? TB::Dil(NEXT ? L + 1 : L) : 0;
-			static constexpr unsigned Of(int w)
+			static constexpr int LN = NEXT ? L + 1 : L;
+			static constexpr int dn = NEXT ? TB::Dil(LN) : 0, Kn = NEXT ? TB::KS(LN) : 1;
+			static constexpr unsigned long long Of(int w)
 			{
-				unsigned s = 0;
-				for (int k = 0; k < 2; k++)
-					for (int i = 0; i < S; i++)
-					{
-						s = s * 4 + (unsigned)TapClassOf(32 * w, P, i, d * (2 - k));
-						s = s * 4 + (unsigned)(NEXT ? TapClassOf(32 * w, P, i, dn * (2 - k)) : 0);
-					}
+				unsigned long long s = 0;
+				for (int k = 0; k < K - 1; k++)
+					for (int i = 0; i < S; i++) s = s * 3 + (unsigned)WaveTapClass<C>(w, P, i, d * (K - 1 - k));
+				for (int k = 0; k < Kn - 1 && k < C::HPF; k++)
+					for (int i = 0; i < S; i++) s = s * 3 + (unsigned)WaveTapClass<C>(w, P, i, dn * (Kn - 1 - k));
 				return s;
 			}
 			static constexpr int Rep(int w) { int r = w; for (int v = w - 1; v >= 0; v--) if (Of(v) == Of(w)) r = v; return r; }
@@ -192,7 +277,7 @@ namespace na
 		template <class C, int GP>
 		struct Lanes
 		{
-			int fl;          // frame within the wave's 32, set 0: 16 p + j
+			int fl;          // frame within the wave's FW, set 0: 16 p + j
 			int cg;          // channel group
 			unsigned img;    // LDS byte address of (plane cg, frame F0 + fl) in image 0 of this stream
 			unsigned aux;    // LDS byte address of the aux entry of frame F0 + fl (PK: of the stream owning channel group cg)
@@ -204,7 +289,7 @@ namespace na
 				const int p = q / GP;
 				cg = q % GP;
 				fl = 16 * p + j;
-				const int f = 32 * cx.wave + fl;
+				const int f = C::FW * cx.wave + fl;
 				img = (unsigned)(C::IMG_OFF + cx.sub * 2 * C::IMG_ONE + (cg * PLANE + GUARD + f) * 16);
 				ring = (unsigned)((fl * GP + cg) * 16);
 				if constexpr (C::PK) aux = (unsigned)(C::AUX_OFF + ((cx.sub * 4 + (cg >> gs)) * FRAMES + f) * 8);
@@ -215,7 +300,7 @@ namespace na
 		template <class C, int GP>
 		__device__ __forceinline__ u32x4 AuxRead(const Lanes<C, GP>& ln, int i)
 		{
-			constexpr int P = Geo<GP>::P;
+			constexpr int P = Geo<GP, C::T>::P;
 			if constexpr (C::PK)
 			{
 				const u32x2 v = LdsRead8(ln.aux + (unsigned)(16 * P * i * 8));
@@ -229,11 +314,11 @@ namespace na
 			f32x4 xc[2];       // layer input (residual stream), f32
 			f32x4 hd[2];       // head accumulator
 			u32x4 xs[2];       // split quad of xc: the unshifted conv tap's operand
-			u32x4 hist[2][2];  // ring history of the current layer's shifted taps [tap][set]
+			u32x4 hist[5][2];  // ring history of the current layer's first HPF shifted taps [tap][set]
 		};
 
 		// Byte offset of ring position (base + fl) mod R, channel group cg, relative to the ring's start: `base` in [0, R) is wave-uniform, the
-		// lane part fl < 32 is folded into Lanes::ring, so the wrap is one unsigned min on the byte offset (3 VALU per access); the
+		// lane part fl < FW is folded into Lanes::ring, so the wrap is one unsigned min on the byte offset (3 VALU per access); the
 		// ring's start rides in the instruction's scalar offset.
 		template <int GP, int R>
 		__device__ __forceinline__ int RingWrap(unsigned laneRing, int base)
@@ -242,101 +327,106 @@ namespace na
 			return (int)__builtin_elementwise_min(a, a - (unsigned)(R * GP * 16));
 		}
 
-		// Ring history of layer L's shifted tap k for set i (frames before the block start).  One load instruction whatever the class --
-		// every wave issues the same number of VMEM operations per stage, so the vmcnt waits can be counted -- with an out-of-range
-		// offset where this wave (TAP_LDS) or this lane (TAP_BOTH, frames inside the block) needs nothing: such a load returns zeros.
-		// (The scalar offset of a buffer instruction is not part of its range check: an out-of-range vector offset drops the access, and
-		// so does the zero-sized resource of a shadow wave, whatever the scalar offset.)
-		template <class C, int L, int WR>
-		__device__ __forceinline__ u32x4 HistLoad(const Ctx& cx, unsigned laneRing, int fl, int k, int i)
+		// Ring history of ring RG (a layer's input ring, or the conv head's) for the frames `shift` before set i's (frames before the block
+		// start).  One load instruction whatever the class -- every wave issues the same number of VMEM operations per stage, so the vmcnt
+		// waits can be counted -- with an out-of-range offset where this wave (TAP_LDS) or this lane (TAP_BOTH, frames inside the block)
+		// needs nothing: such a load returns zeros.  (The scalar offset of a buffer instruction is not part of its range check: an
+		// out-of-range vector offset drops the access, and so does the zero-sized resource of a shadow wave, whatever the scalar offset.)
+		template <class C, int RG, int WR>
+		__device__ __forceinline__ u32x4 HistLoadAt(const Ctx& cx, unsigned laneRing, int fl, int shift, int i)
 		{
 			typedef typename C::TB TB;
-			constexpr int GP = TB::GPof(TB::ArrOf(L)), P = Geo<GP>::P, R = TB::RingFrames(L), OFF = TB::RingOff(L);
-			const int shift = TB::Dil(L) * (2 - k);
-			const int cls = TapClassOf(32 * WR, P, i, shift);
+			constexpr int GP = TB::RingG(RG), P = Geo<GP, C::T>::P, R = TB::RingFrames(RG), OFF = TB::RingOff(RG);
+			const int cls = WaveTapClass<C>(WR, P, i, shift);
 			if ((NA_ABL & 4) || cls == TAP_LDS) return RingLoad(cx.srsrc, OOB);
-			const int pos0 = __builtin_amdgcn_readlane(cx.myPos, L);
-			int base = pos0 - shift + 32 * cx.wave + 16 * P * i; // wave-uniform; in (-R, 2R)
+			const int pos0 = __builtin_amdgcn_readlane(cx.myPos, RG);
+			int base = pos0 - shift + C::FW * cx.wave + 16 * P * i; // wave-uniform; in (-R, 2R)
 			if (base < 0) base += R;
 			if (base >= R) base -= R;
 			const int addr = RingWrap<GP, R>(laneRing, base);
 			if (cls == TAP_HIST) return RingLoad(cx.srsrc, addr, OFF * 16);
-			return RingLoad(cx.srsrc, (32 * cx.wave + 16 * P * i + fl < shift) ? addr : OOB, OFF * 16);
+			return RingLoad(cx.srsrc, (C::FW * cx.wave + 16 * P * i + fl < shift) ? addr : OOB, OFF * 16);
 		}
 
-		// does any wave of the block need the ring history of (layer L, tap k, set i)?  (wave 0 has the earliest frames)
+		// shift of layer L's tap k
 		template <class C, int L>
-		constexpr bool HistNeeded(int k, int i)
-		{
-			typedef typename C::TB TB;
-			constexpr int GP = TB::GPof(TB::ArrOf(L)), P = Geo<GP>::P;
-			return TapClassOf(0, P, i, TB::Dil(L) * (2 - k)) != TAP_LDS;
-		}
+		constexpr int ShiftOf(int k) { return C::TB::Dil(L) * (C::TB::KS(L) - 1 - k); }
+
+		// does any wave of the block need the ring history of a tap `shift` back for set i?  (wave 0 has the earliest frames)
+		template <class C, int GP>
+		constexpr bool HistNeededAt(int shift, int i) { return TapClassOf(0, Geo<GP, C::T>::P, i, shift) != TAP_LDS; }
+
+		// prefetched taps of layer L: k < min(K - 1, HPF)
+		template <class C, int L>
+		constexpr int PrefetchTaps() { return (C::TB::KS(L) - 1) < C::HPF ? (C::TB::KS(L) - 1) : C::HPF; }
 		template <class C, int L>
 		constexpr int HistLoadsOf()
 		{
 			typedef typename C::TB TB;
-			constexpr int S = Geo<TB::GPof(TB::ArrOf(L))>::S;
+			constexpr int GP = TB::GPof(TB::ArrOf(L)), S = Geo<GP, C::T>::S;
 			int n = 0;
-			for (int k = 0; k < 2; k++)
-				for (int i = 0; i < S; i++) n += HistNeeded<C, L>(k, i) ? 1 : 0;
+			for (int k = 0; k < PrefetchTaps<C, L>(); k++)
+				for (int i = 0; i < S; i++) n += HistNeededAt<C, GP>(ShiftOf<C, L>(k), i) ? 1 : 0;
 			return n;
 		}
 
 		template <class C, int L, int WR>
 		__device__ __forceinline__ void HistPrefetch(const Ctx& cx, unsigned laneRing, int fl, State& st)
 		{
-			constexpr int S = Geo<C::TB::GPof(C::TB::ArrOf(L))>::S;
+			constexpr int GP = C::TB::GPof(C::TB::ArrOf(L)), S = Geo<GP, C::T>::S;
 #pragma unroll
-			for (int k = 0; k < 2; k++)
+			for (int k = 0; k < PrefetchTaps<C, L>(); k++)
 #pragma unroll
 				for (int i = 0; i < S; i++)
-					if (HistNeeded<C, L>(k, i)) st.hist[k][i] = HistLoad<C, L, WR>(cx, laneRing, fl, k, i);
+					if (HistNeededAt<C, GP>(ShiftOf<C, L>(k), i)) st.hist[k][i] = HistLoadAt<C, L, WR>(cx, laneRing, fl, ShiftOf<C, L>(k), i);
 		}
 
-		// The input of layer LN (produced by the stage in front of it) -> the LDS image (in-block taps of LN, if it has any) and LN's HBM
-		// ring (history for LATER blocks: only the last R - 128 frames of a block are ever read back).  Ring stores that no wave of the
-		// block needs are not issued at all; the others are one instruction on every wave (out-of-range offset where nothing is kept).
-		template <class C, int LN>
+		// A stage's output -> the LDS image (in-block taps of the reader, if it has any) and ring RG (history for LATER blocks: only the
+		// last R - 128 frames of a block are ever read back).  Ring stores that no wave of the block needs are not issued at all; the
+		// others are one instruction on every wave (out-of-range offset where nothing is kept).  MINSHIFT: the reader's smallest tap shift.
+		template <class C, int RG>
 		constexpr bool StoreNeeded(int i)
 		{
 			typedef typename C::TB TB;
-			constexpr int GP = TB::GPof(TB::ArrOf(LN)), P = Geo<GP>::P, KEEP = TB::RingFrames(LN) - FRAMES;
-			return (C::NF - 32) + 16 * P * (i + 1) - 1 >= C::NF - KEEP; // the last wave's last frame of set i
+			constexpr int P = Geo<TB::RingG(RG), C::T>::P, KEEP = TB::RingFrames(RG) - FRAMES;
+			return (C::NF - C::FW) + 16 * P * (i + 1) - 1 >= C::NF - KEEP; // the last wave's last frame of set i
 		}
-		template <class C, int LN>
+		template <class C, int RG>
 		constexpr int StoresOf()
 		{
-			constexpr int S = Geo<C::TB::GPof(C::TB::ArrOf(LN))>::S;
+			constexpr int S = Geo<C::TB::RingG(RG), C::T>::S;
 			int n = 0;
-			for (int i = 0; i < S; i++) n += StoreNeeded<C, LN>(i) ? 1 : 0;
+			for (int i = 0; i < S; i++) n += StoreNeeded<C, RG>(i) ? 1 : 0;
 			return n;
 		}
 
-		template <class C, int LN, int GP>
+		template <class C, int RG, int GP, int MINSHIFT>
 		__device__ __forceinline__ void Publish(const Ctx& cx, const Lanes<C, GP>& ln, u32x4 v, int i, int imgWrite)
 		{
 			typedef typename C::TB TB;
-			constexpr int P = Geo<GP>::P, R = TB::RingFrames(LN), OFF = TB::RingOff(LN), KEEP = R - FRAMES;
-			static_assert(GP == TB::GPof(TB::ArrOf(LN)), "lane mode of the receiving layer");
-			if (!(NA_ABL & 64) && TB::Dil(LN) < C::NF) // the next layer reads in-block frames of other lanes
+			constexpr int P = Geo<GP, C::T>::P, R = TB::RingFrames(RG), OFF = TB::RingOff(RG), KEEP = R - FRAMES;
+			static_assert(GP == TB::RingG(RG), "lane mode of the receiving ring");
+			if (!(NA_ABL & 64) && MINSHIFT < C::NF) // the reader takes in-block frames of other lanes
 				LdsWrite16(ln.img + (unsigned)(imgWrite * C::IMG_ONE + 16 * P * i * 16), v);
-			if ((NA_ABL & 4) || !StoreNeeded<C, LN>(i)) return;
-			const int pos0 = __builtin_amdgcn_readlane(cx.myPos, LN);
-			int base = pos0 + 32 * cx.wave + 16 * P * i; // < 2R
+			if ((NA_ABL & 4) || !StoreNeeded<C, RG>(i)) return;
+			const int pos0 = __builtin_amdgcn_readlane(cx.myPos, RG);
+			int base = pos0 + C::FW * cx.wave + 16 * P * i; // < 2R
 			if (base >= R) base -= R;
 			const int addr = RingWrap<GP, R>(ln.ring, base);
 			if (KEEP >= C::NF) RingStore(cx.srsrc, v, addr, OFF * 16);
-			else RingStore(cx.srsrc, v, (32 * cx.wave + 16 * P * i + ln.fl >= C::NF - KEEP) ? addr : OOB, OFF * 16);
+			else RingStore(cx.srsrc, v, (C::FW * cx.wave + 16 * P * i + ln.fl >= C::NF - KEEP) ? addr : OOB, OFF * 16);
 		}
 
-		// Stage s + 1's A operands -> the other LDS weight buffer by LDS-DMA (lane l's 16 bytes land at base + 16 l; no VGPRs, no ds_write),
-		// issued at the start of stage s, awaited just before its closing barrier.  Operand count and offsets are constants: exactly
-		// ceil(ops * 64 / NTHREADS) loads per thread, the last one partly out of range.
-		template <class C, int SN>
+		// The next chunk of A operands (chunk CN of stage SN) -> the other LDS weight buffer by LDS-DMA (lane l's 16 bytes land at base +
+		// 16 l; no VGPRs, no ds_write), issued at the start of the chunk before it, awaited just before that one's closing barrier.
+		// Operand count and offsets are constants: exactly ceil(ops * 64 / NTHREADS) loads per thread.
+		template <class C, int SN, int CN>
 		struct Stager
 		{
-			static constexpr int QUADS = C::TB::StageOps(SN) * 64;
+			typedef typename C::TB TB;
+			static constexpr int QUADS = (TB::ChunkEnd(SN, CN) - TB::ChunkBegin(SN, CN)) * 64;
+			static constexpr int SRC = TB::AOff(SN) + TB::ChunkBegin(SN, CN) * 64;
+			static constexpr int BUF = TB::ChunkIndex(SN, CN) & 1;
 			static constexpr int NCOPY = (QUADS + C::NTHREADS - 1) / C::NTHREADS;
 			static __device__ __forceinline__ void Begin(const Ctx& cx)
 			{
@@ -348,9 +438,9 @@ namespace na
 					// WRITES (zeros), so a wave with nothing to stage aims at the dump slot -- same instruction count on every wave.
 					const int i0 = c * C::NTHREADS + cx.waveAll * 64; // first quad of this wave's slice (wave-uniform)
 					const bool mine = i0 < QUADS;
-					const unsigned dst = mine ? (unsigned)(C::WBUF_OFF + (SN & 1) * C::WBUF_ONE) + (unsigned)i0 * 16u : (unsigned)C::DUMP_OFF;
+					const unsigned dst = mine ? (unsigned)(C::WBUF_OFF + BUF * C::WBUF_ONE) + (unsigned)i0 * 16u : (unsigned)C::DUMP_OFF;
 					__builtin_amdgcn_raw_ptr_buffer_load_lds(cx.wrsrc, (__attribute__((address_space(3))) void*)(LdsPtr)(size_t)dst, 16,
-						mine ? (C::TB::AOff(SN) + i0 + cx.lane) * 16 : OOB, 0, 0, 0);
+						mine ? (SRC + i0 + cx.lane) * 16 : OOB, 0, 0, 0);
 				}
 			}
 			// LATER = VMEM operations this wave issued after Begin() (they may stay in flight)
@@ -361,121 +451,183 @@ namespace na
 				__builtin_amdgcn_s_waitcnt((LATER & 15) | ((LATER >> 4) << 14) | (7 << 4) | (15 << 8));
 			}
 		};
-
-		template <class C>
-		__device__ __forceinline__ u32x4 WOp(const Ctx& cx, int s, int m)
+		// the chunk after (s, c)
+		template <class C, int s, int c>
+		struct NextChunk
 		{
-			return LdsRead16((unsigned)(C::WBUF_OFF + (s & 1) * C::WBUF_ONE + ((NA_ABL & 128) ? 0 : m) * 1024) + (unsigned)cx.lane * 16u);
+			static constexpr bool SAME = c + 1 < C::TB::NumChunks(s);
+			static constexpr int S = SAME ? s : s + 1, CN = SAME ? c + 1 : 0;
+			typedef Stager<C, S, CN> St;
+		};
+
+		// operand m of stage s (must lie in the chunk that is in LDS: chunk c)
+		template <class C>
+		__device__ __forceinline__ u32x4 WOp(const Ctx& cx, int s, int c, int m)
+		{
+			const int buf = C::TB::ChunkIndex(s, c) & 1, local = m - C::TB::ChunkBegin(s, c);
+			return LdsRead16((unsigned)(C::WBUF_OFF + buf * C::WBUF_ONE + ((NA_ABL & 128) ? 0 : local) * 1024) + (unsigned)cx.lane * 16u);
+		}
+
+		__device__ __forceinline__ f32x4 ActivateTanh(f32x4 a)
+		{
+			if (NA_PK_TANH)
+			{
+				const f32x2 lo = FastTanh2(f32x2{ a.x, a.y }), hi = FastTanh2(f32x2{ a.z, a.w });
+				return f32x4{ lo.x, lo.y, hi.x, hi.y };
+			}
+			return f32x4{ FastTanh(a.x), FastTanh(a.y), FastTanh(a.z), FastTanh(a.w) };
+		}
+
+		// One shifted conv tap of ring RG's reader for set i: the frames `shift` back, as classified for wave WR -- ring history (registers),
+		// LDS image, or both (the conv is linear in the operand: the ring part is zero for in-block lanes and vice versa).
+		template <class C, int RG, int GP, int WR>
+		__device__ __forceinline__ f32x4 ConvTap(const Ctx& cx, const Lanes<C, GP>& ln, int imgRead, int shift, int i, u32x4 ah, u32x4 al, u32x4 hist, f32x4 acc)
+		{
+			constexpr int P = Geo<GP, C::T>::P;
+			const int cls = WaveTapClass<C>(WR, P, i, shift);
+			if (cls != TAP_LDS)
+			{
+				acc = Mfma(ah, hist, acc);
+				acc = Mfma(al, hist, acc);
+			}
+			if (cls != TAP_HIST)
+			{
+				u32x4 b;
+				if (NA_ABL & 256) b = u32x4{ (unsigned)shift, 0, 0, 0 };
+				else if (cls == TAP_LDS) b = LdsRead16(ln.img + (unsigned)(imgRead * C::IMG_ONE) + (unsigned)((16 * P * i - shift) * 16));
+				else
+				{
+					// straddling: lanes whose frame lies before the block read the zero guard quad in front of frame 0
+					int off = C::FW * cx.wave + 16 * P * i + ln.fl - shift;
+					off = off < -1 ? -1 : off;
+					b = LdsRead16((unsigned)(C::IMG_OFF + imgRead * C::IMG_ONE + GUARD * 16) + (unsigned)(cx.sub * 2 * C::IMG_ONE) + (unsigned)((ln.cg * PLANE + off) * 16));
+				}
+				acc = Mfma(ah, b, acc);
+				acc = Mfma(al, b, acc);
+			}
+			return acc;
 		}
 
 		// ---- one layer (WaveNetLayerT::Process, WaveNet.h:462-494) for the waves whose tap classes are those of wave WR ----------------
-		template <class C, int L, int WR>
-		__device__ __forceinline__ void LayerBody(const Ctx& cx, const Lanes<C, C::TB::GPof(C::TB::ArrOf(L))>& ln, State& st)
+		// Operands of the stage: taps 0 .. K-1 as (hi, lo) pairs (tap K-1 is the unshifted one), aux = (mix-in, conv bias), 1x1 (hi, lo), its
+		// bias.  They are in LDS chunk by chunk (Tab::ChunkBegin / ChunkEnd): chunk c + 1 (or the next stage's first) is staged while
+		// chunk c is used, and every chunk is closed by a barrier.  A K <= 6 layer is ONE chunk.
+		template <class C, int L, int WR, int c>
+		__device__ __forceinline__ void LayerChunk(const Ctx& cx, const Lanes<C, C::TB::GPof(C::TB::ArrOf(L))>& ln, State& st, u32x4 (&ax)[LayerSig<C, L>::S],
+			f32x4 (&acc)[LayerSig<C, L>::S])
 		{
 			typedef typename C::TB TB;
 			typedef LayerSig<C, L> SG;
-			constexpr int GP = SG::GP, P = SG::P, S = SG::S, d = SG::d, s = TB::StageOfLayer(L);
-			constexpr int imgRead = s & 1, imgWrite = (s + 1) & 1;
-			SPK_STAMP(s, 0);
-			Stager<C, s + 1>::Begin(cx);
-
-			u32x4 ax[S];
-#pragma unroll
-			for (int i = 0; i < S; i++) ax[i] = AuxRead<C, GP>(ln, i);
-
-			// dilated conv (WaveNet.h:139-290): tap k reads the frame d (2 - k) back; bias and mix-in arrive through the aux operand
-			f32x4 acc[S];
-#pragma unroll
-			for (int i = 0; i < S; i++) acc[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-			for (int k = 0; k < 2; k++)
+			constexpr int GP = SG::GP, S = SG::S, K = SG::K, s = TB::StageOfLayer(L), NCH = TB::NumChunks(s), CB = TB::ChunkBegin(s, c), CE = TB::ChunkEnd(s, c);
+			constexpr int imgRead = s & 1, imgWrite = (s + 1) & 1, LN = SG::LN;
+			constexpr bool LASTLAYER = TB::LastOfArr(L) && TB::ArrOf(L) == TB::NA - 1;
+			constexpr int NEXTMINSHIFT = SG::NEXT ? TB::Dil(LN) : (1 << 20); // the reader's smallest tap shift: is the LDS image needed?
+			constexpr bool OWN = 2 * (K - 1) >= CB && 2 * (K - 1) < CE;  // the unshifted tap's operands are in this chunk (every shifted tap is consumed by then)
+			constexpr bool TAIL = 2 * K >= CB && 2 * K < CE;             // aux / 1x1 operands are in this chunk
+			constexpr int LATER = ((OWN && SG::NEXT) ? HistLoadsOf<C, LN>() : 0) + ((TAIL && SG::NEXT && !LASTLAYER) ? StoresOf<C, LN>() : 0);
+			typedef typename NextChunk<C, s, c>::St NextStager;
+			NextStager::Begin(cx);
+			if constexpr (c == 0)
 			{
-				constexpr int dd = d;
-				const int shift = dd * (2 - k);
-				const u32x4 ah = WOp<C>(cx, s, 2 * k), al = WOp<C>(cx, s, 2 * k + 1);
+#pragma unroll
+				for (int i = 0; i < S; i++) ax[i] = AuxRead<C, GP>(ln, i);
+			}
+			// dilated conv (WaveNet.h:139-290): tap k reads the frame d (K-1-k) back; bias and mix-in arrive through the aux operand.
+			// History of taps beyond the prefetched ones (K = 15 layers): all loads of the chunk first, then the MFMAs
+			constexpr int KLO = CB / 2, KHI = (CE / 2 < K - 1) ? CE / 2 : K - 1; // shifted taps of this chunk: [KLO, KHI)
+			constexpr int NX = (KHI > C::HPF) ? KHI - (KLO > C::HPF ? KLO : C::HPF) : 0;
+			u32x4 hx[NX > 0 ? NX : 1][S];
+#pragma unroll
+			for (int k = KLO; k < KHI; k++)
+			{
+				if (k < C::HPF) continue;
+#pragma unroll
+				for (int i = 0; i < S; i++)
+					if (WaveTapClass<C>(WR, SG::P, i, ShiftOf<C, L>(k)) != TAP_LDS) hx[k - (KLO > C::HPF ? KLO : C::HPF)][i] = HistLoadAt<C, L, WR>(cx, ln.ring, ln.fl, ShiftOf<C, L>(k), i);
+			}
+#pragma unroll
+			for (int k = KLO; k < KHI; k++)
+			{
+				const u32x4 ah = WOp<C>(cx, s, c, 2 * k), al = WOp<C>(cx, s, c, 2 * k + 1);
 #pragma unroll
 				for (int i = 0; i < S; i++)
 				{
-					const int cls = TapClassOf(32 * WR, P, i, shift);
-					if (cls != TAP_LDS)
-					{
-						acc[i] = Mfma(ah, st.hist[k][i], acc[i]);
-						acc[i] = Mfma(al, st.hist[k][i], acc[i]);
-					}
-					if (cls != TAP_HIST)
-					{
-						u32x4 b;
-						if (NA_ABL & 256) b = u32x4{ (unsigned)shift, 0, 0, 0 };
-						else if (cls == TAP_LDS) b = LdsRead16(ln.img + (unsigned)(imgRead * C::IMG_ONE) + (unsigned)((16 * P * i - shift) * 16));
-						else
-						{
-							// straddling (wave 0, shift < 16 P): lanes whose frame lies before the block read the zero guard quad in front of frame 0
-							int off = 16 * P * i + ln.fl - shift; // the wave is wave 0: F0 = 0
-							off = off < -1 ? -1 : off;
-							b = LdsRead16((unsigned)(C::IMG_OFF + imgRead * C::IMG_ONE + GUARD * 16) + (unsigned)(cx.sub * 2 * C::IMG_ONE) + (unsigned)((ln.cg * PLANE + off) * 16));
-						}
-						acc[i] = Mfma(ah, b, acc[i]);
-						acc[i] = Mfma(al, b, acc[i]);
-					}
+					u32x4 h = u32x4{ 0, 0, 0, 0 };
+					if (WaveTapClass<C>(WR, SG::P, i, ShiftOf<C, L>(k)) != TAP_LDS)
+						h = (k < C::HPF) ? st.hist[k < C::HPF ? k : 0][i] : hx[k >= C::HPF ? k - (KLO > C::HPF ? KLO : C::HPF) : 0][i];
+					acc[i] = ConvTap<C, L, GP, WR>(cx, ln, imgRead, ShiftOf<C, L>(k), i, ah, al, h, acc[i]);
 				}
 			}
-			// history of the NEXT layer's shifted taps (the registers are free again)
-			if constexpr (SG::NEXT) HistPrefetch<C, SG::NEXT ? L + 1 : L, WR>(cx, ln.ring, ln.fl, st);
+			if constexpr (OWN)
 			{
-				// unshifted tap = the layer input itself (registers) and the aux operand: (mix-in, conv bias) * (cond, 1)   (:288-289, :471)
-				const u32x4 ah = WOp<C>(cx, s, 4), al = WOp<C>(cx, s, 5), xa = WOp<C>(cx, s, 6);
+				// history of the NEXT layer's prefetched taps (the registers are free again)
+				if constexpr (SG::NEXT) HistPrefetch<C, LN, WR>(cx, ln.ring, ln.fl, st);
+				// unshifted tap = the layer input itself (registers)
+				const u32x4 ah = WOp<C>(cx, s, c, 2 * K - 2), al = WOp<C>(cx, s, c, 2 * K - 1);
 #pragma unroll
 				for (int i = 0; i < S; i++)
 				{
 					acc[i] = Mfma(ah, st.xs[i], acc[i]);
 					acc[i] = Mfma(al, st.xs[i], acc[i]);
-					acc[i] = Mfma(xa, ax[i], acc[i]);
 				}
 			}
-			SPK_STAMP(s, 1);
-			// activation (:473-480)
-			f32x4 z[S];
+			if constexpr (TAIL)
+			{
+				// aux operand: (mix-in, conv bias) * (cond, 1)   (:288-289, :471); activation (:473-480); head accumulate (:482) on the
+				// matrix pipe: head += I (zh + zl); 1x1 + bias + residual (:486-491)
+				const u32x4 xa = WOp<C>(cx, s, c, 2 * K);
 #pragma unroll
-			for (int i = 0; i < S; i++)
-			{
-				if (NA_PK_TANH)
+				for (int i = 0; i < S; i++) acc[i] = Mfma(xa, ax[i], acc[i]);
+				SPK_STAMP(s, 1);
+				f32x4 z[S];
+#pragma unroll
+				for (int i = 0; i < S; i++)
 				{
-					const f32x2 lo = FastTanh2(f32x2{ acc[i].x, acc[i].y }), hi = FastTanh2(f32x2{ acc[i].z, acc[i].w });
-					z[i] = f32x4{ lo.x, lo.y, hi.x, hi.y };
+					if constexpr (C::A::LEAKY) z[i] = f32x4{ LeakyReLU(acc[i].x), LeakyReLU(acc[i].y), LeakyReLU(acc[i].z), LeakyReLU(acc[i].w) };
+					else z[i] = ActivateTanh(acc[i]);
 				}
-				else z[i] = f32x4{ FastTanh(acc[i].x), FastTanh(acc[i].y), FastTanh(acc[i].z), FastTanh(acc[i].w) };
-			}
-			SPK_STAMP(s, 2);
-			// head accumulate (:482) on the matrix pipe: head += I (zh + zl); 1x1 + bias + residual (:486-491)
-			{
+				SPK_STAMP(s, 2);
 				const u32x4 idop = LdsRead16((unsigned)C::IDOP_OFF + (unsigned)cx.lane * 16u);
-				const u32x4 w1h = WOp<C>(cx, s, 7), w1l = WOp<C>(cx, s, 8), b1a = WOp<C>(cx, s, 9);
+				const u32x4 w1h = WOp<C>(cx, s, c, 2 * K + 1), w1l = WOp<C>(cx, s, c, 2 * K + 2), b1a = WOp<C>(cx, s, c, 2 * K + 3);
 #pragma unroll
 				for (int i = 0; i < S; i++)
 				{
 					const u32x4 zs = SplitQuad(z[i]);
 					st.hd[i] = Mfma(idop, zs, st.hd[i]);
-					if constexpr (!(TB::LastOfArr(L) && TB::ArrOf(L) == TB::NA - 1)) // NeedOutput (WaveNet.h:643,785): the very last layer's 1x1 is dead
+					if constexpr (!LASTLAYER) // NeedOutput (WaveNet.h:643,785): the very last layer's 1x1 is dead
 					{
 						f32x4 y = st.xc[i];
 						y = Mfma(w1h, zs, y);
 						y = Mfma(w1l, zs, y);
-						y = Mfma(b1a, ax[i], y);
+						y = Mfma(b1a, NA_SPK_AUX2 ? AuxRead<C, GP>(ln, i) : ax[i], y);
 						st.xc[i] = y;
 						if constexpr (SG::NEXT)
 						{
 							st.xs[i] = SplitQuad(y);
-							Publish<C, SG::NEXT ? L + 1 : L, GP>(cx, ln, st.xs[i], i, imgWrite);
+							Publish<C, LN, GP, NEXTMINSHIFT>(cx, ln, st.xs[i], i, imgWrite);
 						}
 					}
 				}
+				SPK_STAMP(s, 3);
 			}
-			SPK_STAMP(s, 3);
 			// the DMA data must be in LDS before the closing barrier lets other waves read it
-			Stager<C, s + 1>::template End<(SG::NEXT ? HistLoadsOf<C, SG::NEXT ? L + 1 : L>() + StoresOf<C, SG::NEXT ? L + 1 : L>() : 0)>();
+			NextStager::template End<LATER>();
 			SPK_STAMP(s, 4);
 			BlockBarrier<C::NTHREADS / 64>();
-			SPK_STAMP(s, 5);
+			if constexpr (c + 1 < NCH) LayerChunk<C, L, WR, c + 1>(cx, ln, st, ax, acc);
+		}
+
+		template <class C, int L, int WR>
+		__device__ __forceinline__ void LayerBody(const Ctx& cx, const Lanes<C, C::TB::GPof(C::TB::ArrOf(L))>& ln, State& st)
+		{
+			constexpr int S = LayerSig<C, L>::S;
+			SPK_STAMP(C::TB::StageOfLayer(L), 0);
+			u32x4 ax[S];
+			f32x4 acc[S];
+#pragma unroll
+			for (int i = 0; i < S; i++) acc[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+			LayerChunk<C, L, WR, 0>(cx, ln, st, ax, acc);
+			SPK_STAMP(C::TB::StageOfLayer(L), 5);
 		}
 
 		template <class C, int L, int W>
@@ -499,14 +651,14 @@ namespace na
 		__device__ __forceinline__ void FirstHistDispatch(const Ctx& cx, unsigned laneRing, int fl, State& st)
 		{
 			typedef typename C::TB TB;
-			constexpr int P = Geo<TB::GPof(TB::ArrOf(L))>::P, S = Geo<TB::GPof(TB::ArrOf(L))>::S;
+			constexpr int GP = TB::GPof(TB::ArrOf(L)), P = Geo<GP, C::T>::P, S = Geo<GP, C::T>::S;
 			if constexpr (W < C::WPS)
 			{
 				constexpr bool same = [] {
 					bool r = true;
 					for (int w = W + 1; w < C::WPS; w++)
-						for (int k = 0; k < 2; k++)
-							for (int i = 0; i < S; i++) r = r && TapClassOf(32 * w, P, i, TB::Dil(L) * (2 - k)) == TapClassOf(32 * W, P, i, TB::Dil(L) * (2 - k));
+						for (int k = 0; k < PrefetchTaps<C, L>(); k++)
+							for (int i = 0; i < S; i++) r = r && WaveTapClass<C>(w, P, i, ShiftOf<C, L>(k)) == WaveTapClass<C>(W, P, i, ShiftOf<C, L>(k));
 					return r;
 				}();
 				if constexpr (same) HistPrefetch<C, L, W>(cx, laneRing, fl, st);
@@ -522,10 +674,10 @@ namespace na
 		template <class C>
 		__device__ __forceinline__ void RechStage(const Ctx& cx, const Lanes<C, C::TB::GPof(0)>& ln, State& st)
 		{
-			constexpr int GP = C::TB::GPof(0), S = Geo<GP>::S;
+			constexpr int GP = C::TB::GPof(0), S = Geo<GP, C::T>::S;
 			SPK_STAMP(0, 0);
-			Stager<C, 1>::Begin(cx);
-			const u32x4 ra = WOp<C>(cx, 0, 0);
+			Stager<C, 1, 0>::Begin(cx);
+			const u32x4 ra = WOp<C>(cx, 0, 0, 0);
 #pragma unroll
 			for (int i = 0; i < S; i++)
 			{
@@ -535,11 +687,11 @@ namespace na
 				st.xc[i] = x;
 				st.hd[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
 				st.xs[i] = SplitQuad(x);
-				Publish<C, 0, GP>(cx, ln, st.xs[i], i, 1);
+				Publish<C, 0, GP, C::TB::Dil(0)>(cx, ln, st.xs[i], i, 1);
 			}
 			FirstHistDispatch<C, 0, 0>(cx, ln.ring, ln.fl, st);
 			SPK_STAMP(0, 1); SPK_STAMP(0, 2); SPK_STAMP(0, 3);
-			Stager<C, 1>::template End<StoresOf<C, 0>() + HistLoadsOf<C, 0>()>();
+			Stager<C, 1, 0>::template End<StoresOf<C, 0>() + HistLoadsOf<C, 0>()>();
 			SPK_STAMP(0, 4);
 			BlockBarrier<C::NTHREADS / 64>();
 			SPK_STAMP(0, 5);
@@ -552,9 +704,10 @@ namespace na
 		{
 			typedef typename C::TB TB;
 			constexpr int GPO = TB::GPof(AN - 1), GPN = TB::GPof(AN), Po = 4 / GPO, Pn = 4 / GPN, NC = Po > Pn ? Po : Pn;
-			constexpr int So = Geo<GPO>::S, Sn = Geo<GPN>::S, s = TB::LinkStage(AN), LN = TB::FirstLayerOfArr(AN);
+			constexpr int So = Geo<GPO, C::T>::S, Sn = Geo<GPN, C::T>::S, s = TB::LinkStage(AN), LN = TB::FirstLayerOfArr(AN);
+			static_assert(C::T == 2, "array links are written for two tiles per wave");
 			SPK_STAMP(s, 0);
-			Stager<C, s + 1>::Begin(cx);
+			Stager<C, s + 1, 0>::Begin(cx);
 			u32x4 hs[So], xq[So];
 #pragma unroll
 			for (int i = 0; i < So; i++)
@@ -569,16 +722,16 @@ namespace na
 				hn[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 				xn[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 				// head bias of the previous array (a zero operand when it has none): any stream's aux operand carries the ones it multiplies
-				hn[i] = Mfma(WOp<C>(cx, s, 4 * NC), AuxRead<C, GPN>(ln, i), hn[i]);
+				hn[i] = Mfma(WOp<C>(cx, s, 0, 4 * NC), AuxRead<C, GPN>(ln, i), hn[i]);
 			}
 #pragma unroll
 			for (int t = 0; t < 2; t++)
 			{
 				const int u = t % NC, so = t / Po, sn = t / Pn;
-				hn[sn] = Mfma(WOp<C>(cx, s, 4 * u), hs[so], hn[sn]);
-				hn[sn] = Mfma(WOp<C>(cx, s, 4 * u + 1), hs[so], hn[sn]);
-				xn[sn] = Mfma(WOp<C>(cx, s, 4 * u + 2), xq[so], xn[sn]);
-				xn[sn] = Mfma(WOp<C>(cx, s, 4 * u + 3), xq[so], xn[sn]);
+				hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
+				hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u + 1), hs[so], hn[sn]);
+				xn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u + 2), xq[so], xn[sn]);
+				xn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u + 3), xq[so], xn[sn]);
 			}
 #pragma unroll
 			for (int i = 0; i < Sn; i++)
@@ -586,44 +739,116 @@ namespace na
 				st.hd[i] = hn[i];
 				st.xc[i] = xn[i];
 				st.xs[i] = SplitQuad(xn[i]);
-				Publish<C, LN, GPN>(cx, ln, st.xs[i], i, (s + 1) & 1);
+				Publish<C, LN, GPN, TB::Dil(LN)>(cx, ln, st.xs[i], i, (s + 1) & 1);
 			}
 			FirstHistDispatch<C, LN, 0>(cx, ln.ring, ln.fl, st);
 			SPK_STAMP(s, 1); SPK_STAMP(s, 2); SPK_STAMP(s, 3);
-			Stager<C, s + 1>::template End<StoresOf<C, LN>() + HistLoadsOf<C, LN>()>();
+			Stager<C, s + 1, 0>::template End<StoresOf<C, LN>() + HistLoadsOf<C, LN>()>();
 			SPK_STAMP(s, 4);
 			BlockBarrier<C::NTHREADS / 64>();
 			SPK_STAMP(s, 5);
 		}
 
-		// last array's head: out = scale * (W_h head + b)[0]  (WaveNet.h:658-660, :793-798); one output row per tile slot (PK: per stream)
-		template <class C>
-		__device__ __forceinline__ void HeadStage(const Ctx& cx, const Lanes<C, C::TB::GPof(C::TB::NA - 1)>& ln, State& st, float* __restrict__ out, size_t outBase,
+		// last array's head: out = scale * (conv_K(head) + b)[0]  (WaveNet.h:658-660, :793-798); K = 1 (A1) straight from the registers,
+		// K > 1 (A2: 16) through the LDS image / the head ring like a layer conv, the operands chunk by chunk.  One output row per tile
+		// slot (PK: per stream).
+		template <class C, int WR>
+		__device__ __forceinline__ void HeadBody(const Ctx& cx, const Lanes<C, C::TB::GPof(C::TB::NA - 1)>& ln, State& st, float* __restrict__ out, size_t outBase,
 			const long (&outRow)[4], int pack, float headScale, bool live)
 		{
 			typedef typename C::TB TB;
-			constexpr int GP = TB::GPof(TB::NA - 1), P = Geo<GP>::P, S = Geo<GP>::S, s = TB::NSTAGES - 1;
-			const u32x4 ah = WOp<C>(cx, s, 0), al = WOp<C>(cx, s, 1), ba = WOp<C>(cx, s, 2);
+			constexpr int GP = TB::GPof(TB::NA - 1), P = Geo<GP, C::T>::P, S = Geo<GP, C::T>::S, s = TB::NSTAGES - 1, K = TB::HEADK, NCH = TB::NumChunks(s), RG = TB::NL;
+			constexpr int imgHead = (s + 1) & 1;
+			u32x4 hs[S];
+			f32x4 acc[S];
 #pragma unroll
 			for (int i = 0; i < S; i++)
 			{
-				const u32x4 hs = SplitQuad(st.hd[i]);
-				f32x4 acc = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-				acc = Mfma(ah, hs, acc);
-				acc = Mfma(al, hs, acc);
-				acc = Mfma(ba, AuxRead<C, GP>(ln, i), acc);
-				const int f = 32 * cx.wave + 16 * P * i + ln.fl;
-				if (live && ln.cg == 0)
-				{
-					if constexpr (C::PK)
-					{
-						const float v[4] = { acc.x, acc.y, acc.z, acc.w };
+				hs[i] = SplitQuad(st.hd[i]);
+				acc[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+			}
 #pragma unroll
-						for (int q = 0; q < 4; q++)
-							if (q < pack && outRow[q] >= 0) out[outRow[q] + f] = headScale * v[q];
+			for (int c = 0; c < NCH; c++)
+			{
+				if constexpr (K > 1)
+				{
+					if (c + 1 < NCH)
+					{
+						if (c == 0) Stager<C, s, 1>::Begin(cx);
+						else if (c + 1 < NCH) Stager<C, s, (NCH > 2 ? 2 : 1)>::Begin(cx);
 					}
-					else out[outBase + f] = headScale * acc.x;
+					if (c == 0)
+					{
+						// the head accumulator of this block -> LDS image + head ring, then every wave may read its neighbours' frames
+#pragma unroll
+						for (int i = 0; i < S; i++) Publish<C, RG, GP, 1>(cx, ln, hs[i], i, imgHead);
+						BlockBarrier<C::NTHREADS / 64>();
+					}
+#pragma unroll
+					for (int k = 0; k < K - 1; k++)
+					{
+						if (2 * k < TB::ChunkBegin(s, c) || 2 * k >= TB::ChunkEnd(s, c)) continue;
+						const u32x4 ah = WOp<C>(cx, s, c, 2 * k), al = WOp<C>(cx, s, c, 2 * k + 1);
+#pragma unroll
+						for (int i = 0; i < S; i++)
+						{
+							u32x4 h = u32x4{ 0, 0, 0, 0 };
+							if (WaveTapClass<C>(WR, P, i, K - 1 - k) != TAP_LDS) h = HistLoadAt<C, RG, WR>(cx, ln.ring, ln.fl, K - 1 - k, i);
+							acc[i] = ConvTap<C, RG, GP, WR>(cx, ln, imgHead, K - 1 - k, i, ah, al, h, acc[i]);
+						}
+					}
 				}
+				if (2 * (K - 1) >= TB::ChunkBegin(s, c) && 2 * (K - 1) < TB::ChunkEnd(s, c))
+				{
+					const u32x4 ah = WOp<C>(cx, s, c, 2 * K - 2), al = WOp<C>(cx, s, c, 2 * K - 1);
+#pragma unroll
+					for (int i = 0; i < S; i++)
+					{
+						acc[i] = Mfma(ah, hs[i], acc[i]);
+						acc[i] = Mfma(al, hs[i], acc[i]);
+					}
+				}
+				if (2 * K >= TB::ChunkBegin(s, c) && 2 * K < TB::ChunkEnd(s, c))
+				{
+					// bias (a zero operand when the head has none), scale, output row(s)
+					const u32x4 ba = WOp<C>(cx, s, c, 2 * K);
+#pragma unroll
+					for (int i = 0; i < S; i++)
+					{
+						acc[i] = Mfma(ba, AuxRead<C, GP>(ln, i), acc[i]);
+						const int f = C::FW * cx.wave + 16 * P * i + ln.fl;
+						if (live && ln.cg == 0)
+						{
+							if constexpr (C::PK)
+							{
+								const float v[4] = { acc[i].x, acc[i].y, acc[i].z, acc[i].w };
+#pragma unroll
+								for (int q = 0; q < 4; q++)
+									if (q < pack && outRow[q] >= 0) out[outRow[q] + f] = headScale * v[q];
+							}
+							else out[outBase + f] = headScale * acc[i].x;
+						}
+					}
+				}
+				if (c + 1 < NCH)
+				{
+					__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8)); // the next chunk has landed (vmcnt 0: nothing else is worth keeping in flight here)
+					BlockBarrier<C::NTHREADS / 64>();
+				}
+			}
+		}
+
+		template <class C>
+		__device__ __forceinline__ void HeadDispatch(const Ctx& cx, const Lanes<C, C::TB::GPof(C::TB::NA - 1)>& ln, State& st, float* __restrict__ out, size_t outBase,
+			const long (&outRow)[4], int pack, float headScale, bool live)
+		{
+			// a dense head is the same on every wave; a conv head's taps (shifts 1 .. K - 1 < FW) straddle the block start on wave 0 and lie
+			// inside the block on every other wave
+			if constexpr (C::TB::HEADK == 1 || C::WPS == 1) HeadBody<C, 0>(cx, ln, st, out, outBase, outRow, pack, headScale, live);
+			else
+			{
+				if (cx.wave == 0) HeadBody<C, 0>(cx, ln, st, out, outBase, outRow, pack, headScale, live);
+				else HeadBody<C, C::WPS - 1>(cx, ln, st, out, outBase, outRow, pack, headScale, live);
 			}
 		}
 
@@ -644,31 +869,21 @@ namespace na
 			else LinkStage<C, AN>(cx, ln, st);
 			RunLayers<C, TB::FirstLayerOfArr(AN), TB::FirstLayerOfArr(AN) + C::A::NLA[AN]>(cx, ln, st);
 			if constexpr (AN + 1 < TB::NA) RunArrays<C, AN + 1>(cx, st, out, outBase, outRow, pack, headScale, live);
-			else HeadStage<C>(cx, ln, st, out, outBase, outRow, pack, headScale, live);
+			else HeadDispatch<C>(cx, ln, st, out, outBase, outRow, pack, headScale, live);
 		}
 
-		// grid = active (virtual) streams / SPB; workgroup = SPB streams x WPS waves of 2 tiles; n == NF frames.  F = architecture family
-		// (the groups of one launch may be different members of it).  Dynamic LDS = Cfg::LDS_BYTES, addressed absolutely from 0 (the kernel
-		// has no static LDS), so every LDS offset of the chain is an instruction immediate.
-		template <class F, int NF, int SPB, bool PK>
-		__global__ void __launch_bounds__(64 * (NF / 32) * SPB) __attribute__((amdgpu_waves_per_eu(4))) WaveNetSpecKernel(const LaunchArgs args, const float* __restrict__ in,
-			float* __restrict__ out, long inStride, long outStride
+		// One workgroup of architecture C: prologue (aux operands of the block, zero guards, identity operand, stage 0's operand), the
+		// layer chain, cursor update.
+		template <class C>
+		__device__ __forceinline__ void RunWorkgroup(const GroupArgs& ga, int groupBlock, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride
 #ifdef NA_SP_TRACE
-			, long long* __restrict__ trace, int traceBlock
+			, long long* trace
 #endif
 			)
 		{
-			typedef Cfg<typename F::A0, NF, SPB, PK> C;
-			typedef Cfg<typename F::A1, NF, SPB, PK> C1;
-			extern __shared__ __attribute__((aligned(16))) char dynSmem[];
-			asm volatile("" : : "s"((unsigned)(size_t)(LdsPtr)dynSmem)); // the dynamic LDS segment is in use (and starts at 0)
-
-			int gi = 0;
-			for (int i = 1; i < args.numGroups; i++)
-				if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
-			const GroupArgs& ga = args.g[gi];
-			const int groupBlock = (int)blockIdx.x - ga.firstBlock;
-
+			typedef typename C::TB TB;
+			constexpr bool PK = C::PK;
+			constexpr int SPB = C::SPB, NF = C::NF;
 			const int lane = threadIdx.x & 63;
 			const int waveAll = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 			const int sub = waveAll / C::WPS, wave = waveAll % C::WPS;
@@ -689,7 +904,7 @@ namespace na
 			cx.myPos = header[lane];
 			cx.wave = wave; cx.sub = sub; cx.waveAll = waveAll; cx.lane = lane;
 #ifdef NA_SP_TRACE
-			cx.trace = ((int)blockIdx.x == traceBlock) ? trace : nullptr;
+			cx.trace = trace;
 			cx.nwaves = C::NTHREADS / 64;
 			if (cx.trace != nullptr && lane == 0) cx.trace[((C::TB::NSTAGES * 8 + 0) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
 #endif
@@ -733,7 +948,7 @@ namespace na
 				}
 			}
 			// zero quad in front of frame 0 of every plane of both block images
-			for (int i = threadIdx.x; i < SPB * 2 * 4; i += C::NTHREADS) LdsWrite16((unsigned)(C::IMG_OFF + (i * PLANE + GUARD - 1) * 16), u32x4{ 0, 0, 0, 0 });
+			for (int i = threadIdx.x; i < SPB * 2 * TB::MaxGP(); i += C::NTHREADS) LdsWrite16((unsigned)(C::IMG_OFF + (i * PLANE + GUARD - 1) * 16), u32x4{ 0, 0, 0, 0 });
 			// identity A operand: row i x k-block q = i / 4: 1.0 against the h AND the l half of channel i % 4
 			if (threadIdx.x < 64)
 			{
@@ -748,8 +963,7 @@ namespace na
 			BlockBarrier<C::NTHREADS / 64>();
 
 			State st;
-			if (F::N > 1 && ga.arch == 1) RunArrays<C1, 0>(cx, st, out, (size_t)row * outStride, outRow, pack, ga.headScale, live);
-			else RunArrays<C, 0>(cx, st, out, (size_t)row * outStride, outRow, pack, ga.headScale, live);
+			RunArrays<C, 0>(cx, st, out, (size_t)row * outStride, outRow, pack, ga.headScale, live);
 
 #ifdef NA_SP_TRACE
 			if (cx.trace != nullptr && lane == 0) cx.trace[((C::TB::NSTAGES * 8 + 1) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
@@ -762,6 +976,39 @@ namespace na
 				if (p >= R) p -= R;
 				header[lane] = p;
 			}
+		}
+
+		// grid = sum over the groups of ceil(active (virtual) streams / SPB of the group's architecture); workgroup = SPB streams x WPS
+		// waves of T tiles; n == NF frames.  F = architecture family (the groups of one launch may be different members of it; all members
+		// launch the same number of threads).  Dynamic LDS = the largest Cfg::LDS_BYTES, addressed absolutely from 0 (the kernel has no
+		// static LDS), so every LDS offset of the chain is an instruction immediate.
+		template <class F, int NF, int SPB, bool PK>
+		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(4))) WaveNetSpecKernel(const LaunchArgs args,
+			const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride
+#ifdef NA_SP_TRACE
+			, long long* __restrict__ trace, int traceBlock
+#endif
+			)
+		{
+			typedef Cfg<typename F::A0, NF, SPB, PK> C;
+			typedef Cfg<typename F::A1, NF, SPB, PK> C1;
+			static_assert(C::NTHREADS == C1::NTHREADS, "members of a family launch the same workgroup");
+			extern __shared__ __attribute__((aligned(16))) char dynSmem[];
+			asm volatile("" : : "s"((unsigned)(size_t)(LdsPtr)dynSmem)); // the dynamic LDS segment is in use (and starts at 0)
+
+			int gi = 0;
+			for (int i = 1; i < args.numGroups; i++)
+				if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
+			const GroupArgs& ga = args.g[gi];
+			const int groupBlock = (int)blockIdx.x - ga.firstBlock;
+#ifdef NA_SP_TRACE
+			long long* tr = ((int)blockIdx.x == traceBlock) ? trace : nullptr;
+			if (F::N > 1 && ga.arch == 1) RunWorkgroup<C1>(ga, groupBlock, in, out, inStride, outStride, tr);
+			else RunWorkgroup<C>(ga, groupBlock, in, out, inStride, outStride, tr);
+#else
+			if (F::N > 1 && ga.arch == 1) RunWorkgroup<C1>(ga, groupBlock, in, out, inStride, outStride);
+			else RunWorkgroup<C>(ga, groupBlock, in, out, inStride, outStride);
+#endif
 		}
 
 		// ---- host ----------------------------------------------------------------------------------------------------------------
@@ -777,9 +1024,9 @@ namespace na
 			{
 				const WnSplitStage& d = st[TB::StageOfLayer(L)];
 				const int a = TB::ArrOf(L);
-				if (d.type != WN_ST_LAYER || d.Gp != TB::GPof(a) || d.G != TB::GPof(a) || d.ksize != 3 || d.dilation != TB::Dil(L)) return false;
+				if (d.type != WN_ST_LAYER || d.Gp != TB::GPof(a) || d.G != TB::GPof(a) || d.ksize != TB::KS(L) || d.dilation != TB::Dil(L)) return false;
 				if (d.ring_id != L || d.ring_off != TB::RingOff(L) || d.ring_frames != TB::RingFrames(L)) return false;
-				if (d.flags & (WN_FLAG_LEAKY | WN_FLAG_STD_TANH)) return false;
+				if (((d.flags & WN_FLAG_LEAKY) != 0) != A::LEAKY || (d.flags & WN_FLAG_STD_TANH)) return false;
 				if (!TB::LastOfArr(L) && (d.out_ring_id != L + 1 || !(d.flags & WN_FLAG_PUBLISH))) return false;
 			}
 			for (int a = 1; a < TB::NA; a++)
@@ -788,13 +1035,16 @@ namespace na
 				if (d.type != WN_ST_ARRAY_LINK || d.Gp != TB::GPof(a - 1) || d.ksize != TB::GPof(a) || d.out_ring_id != TB::FirstLayerOfArr(a)) return false;
 			}
 			const WnSplitStage& h = st[nstages - 1];
-			return h.type == WN_ST_HEAD_DENSE_OUT && h.ksize == 1 && h.Gp == TB::GPof(TB::NA - 1);
+			if (h.ksize != TB::HEADK || h.Gp != TB::GPof(TB::NA - 1)) return false;
+			if (TB::HEADK == 1) return h.type == WN_ST_HEAD_DENSE_OUT;
+			return h.type == WN_ST_HEAD_CONV_OUT && h.dilation == 1 && h.ring_id == TB::NL && h.ring_off == TB::RingOff(TB::NL) && h.ring_frames == TB::RingFrames(TB::NL);
 		}
 
 		template <class F, int NF, int SPB, bool PK>
 		static hipError_t Launch(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, hipStream_t stream)
 		{
 			typedef Cfg<typename F::A0, NF, SPB, PK> C;
+			typedef Cfg<typename F::A1, NF, SPB, PK> C1;
 			LaunchArgs args = {};
 			args.numGroups = numGroups;
 			int blocks = 0;
@@ -812,26 +1062,28 @@ namespace na
 				a.maxG = m.max_G;
 				a.firstBlock = blocks;
 				a.pack = g.pack > 1 ? g.pack : 1;
-				a.arch = (F::N > 1 && m.spec_arch == WN_SPEC_LITE16) ? 1 : 0;
+				a.arch = (F::N > 1 && (m.spec_arch == WN_SPEC_LITE16 || m.spec_arch == WN_SPEC_A2LITE)) ? 1 : 0;
 				// channel groups per real stream of the first / the last array (packed launches: which stream's condition a channel group sees)
 				const int c0 = a.arch == 1 ? F::A1::CH[0] : F::A0::CH[0], c1 = a.arch == 1 ? F::A1::CH[1] : F::A0::CH[1];
 				a.gps0 = std::max(1, c0 / 4 / a.pack);
 				a.gps1 = std::max(1, c1 / 4 / a.pack);
 				if (a.pack > 1 && !PK) return hipErrorInvalidValue;
 				if (PK && g.slots == nullptr) return hipErrorInvalidValue;
-				blocks += (g.numStreams + SPB - 1) / SPB;
+				const int spbArch = a.arch == 1 ? C1::SPB : C::SPB; // streams per workgroup of this group's architecture
+				blocks += (g.numStreams + spbArch - 1) / spbArch;
 			}
-			if (C::LDS_BYTES > 64 * 1024)
+			constexpr int LDS_BYTES = C::LDS_BYTES > C1::LDS_BYTES ? C::LDS_BYTES : C1::LDS_BYTES;
+			if (LDS_BYTES > 64 * 1024)
 			{
 				static bool granted = false; // per instantiation
 				if (!granted)
 				{
-					const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(WaveNetSpecKernel<F, NF, SPB, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+					const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(WaveNetSpecKernel<F, NF, SPB, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 					if (e != hipSuccess) return e;
 					granted = true;
 				}
 			}
-			hipLaunchKernelGGL((WaveNetSpecKernel<F, NF, SPB, PK>), dim3((unsigned)blocks), dim3(64 * (NF / 32) * SPB), C::LDS_BYTES, stream, args, in, out, inStride, outStride
+			hipLaunchKernelGGL((WaveNetSpecKernel<F, NF, SPB, PK>), dim3((unsigned)blocks), dim3(C::NTHREADS), LDS_BYTES, stream, args, in, out, inStride, outStride
 #ifdef NA_SP_TRACE
 				, GetWaveNetTraceBuffer(), []() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }()
 #endif
@@ -848,7 +1100,9 @@ namespace na
 #else
 			if (n == 128) return spb >= 2 ? Launch<F, 128, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream) : Launch<F, 128, 1, PK>(groups, numGroups, in, out, inStride, outStride, stream);
 			if (n == 64) return spb >= 2 ? Launch<F, 64, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream) : Launch<F, 64, 1, PK>(groups, numGroups, in, out, inStride, outStride, stream);
-			return spb >= 2 ? Launch<F, 32, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream) : Launch<F, 32, 1, PK>(groups, numGroups, in, out, inStride, outStride, stream);
+			if constexpr (F::A0::T == 2 && F::A1::T == 2)
+				return spb >= 2 ? Launch<F, 32, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream) : Launch<F, 32, 1, PK>(groups, numGroups, in, out, inStride, outStride, stream);
+			else return hipErrorNotSupported; // (a wave of a 4-tile architecture covers 64 frames)
 #endif
 		}
 	}
@@ -868,6 +1122,8 @@ namespace na
 		if (spk::Matches<spk::ArchStd>(stages, nstages, stateF4, wsplitQuads)) return WN_SPEC_STD;
 		if (spk::Matches<spk::ArchLite>(stages, nstages, stateF4, wsplitQuads)) return WN_SPEC_LITE;
 		if (spk::Matches<spk::ArchLite16>(stages, nstages, stateF4, wsplitQuads)) return WN_SPEC_LITE16;
+		if (spk::Matches<spk::ArchA2Full>(stages, nstages, stateF4, wsplitQuads)) return WN_SPEC_A2FULL;
+		if (spk::Matches<spk::ArchA2Lite>(stages, nstages, stateF4, wsplitQuads)) return WN_SPEC_A2LITE;
 		return WN_SPEC_NONE;
 	}
 
@@ -880,15 +1136,17 @@ namespace na
 		if (!WaveNetSpecEnabled()) return hipErrorNotSupported; // tuning / tests: the interpreter for everything
 		const int arch = groups[0].model->spec_arch;
 		if (arch == WN_SPEC_NONE) return hipErrorNotSupported;
-		const bool liteFamily = arch == WN_SPEC_LITE || arch == WN_SPEC_LITE16;
+		auto familyOf = [](int a) { return (a == WN_SPEC_LITE || a == WN_SPEC_LITE16) ? 1 : ((a == WN_SPEC_A2FULL || a == WN_SPEC_A2LITE) ? 2 : 0); };
+		const int fam = familyOf(arch);
 		int total = 0;
-		bool packed = false;
+		bool packed = false, lite16 = false;
 		for (int i = 0; i < numGroups; i++)
 		{
 			const int a = groups[i].model->spec_arch;
-			if (groups[i].numStreams <= 0 || (liteFamily ? (a != WN_SPEC_LITE && a != WN_SPEC_LITE16) : a != arch)) return hipErrorNotSupported;
+			if (groups[i].numStreams <= 0 || a == WN_SPEC_NONE || familyOf(a) != fam || (fam == 0 && a != arch)) return hipErrorNotSupported;
 			total += groups[i].numStreams;
 			packed = packed || groups[i].pack > 1;
+			lite16 = lite16 || a == WN_SPEC_LITE16;
 		}
 		// a packed launch reads the index lists of every group (a plain group riding along is pack = 1)
 		if (packed)
@@ -900,10 +1158,10 @@ namespace na
 		if (arch != WN_SPEC_STD || packed) return hipErrorNotSupported;
 		return spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
 #else
-		if (!liteFamily) return packed ? hipErrorNotSupported : spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
+		if (fam == 0) return packed ? hipErrorNotSupported : spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
+		if (fam == 2) return packed ? hipErrorNotSupported : spk::LaunchNF<spk::FamA2, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
 		if (packed) return spk::LaunchNF<spk::FamLitePacked, true>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
-		for (int i = 0; i < numGroups; i++)
-			if (groups[i].model->spec_arch != WN_SPEC_LITE) return hipErrorNotSupported; // (16 / 16 only exists packed)
+		if (lite16) return hipErrorNotSupported; // (16 / 16 only exists packed)
 		return spk::LaunchNF<spk::FamLite, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
 #endif
 	}

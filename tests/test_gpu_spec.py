@@ -101,6 +101,40 @@ def test_specialised_chain_is_bit_identical_to_the_interpreter(na, loader, spec_
 
 
 @pytest.mark.skipif(FORCED, reason="forced kernel family")
+@pytest.mark.parametrize("streams", [5, 1030])
+def test_a2_chains_are_bit_identical_to_the_interpreter_and_match_the_oracles(na, loader, spec_switch, streams):
+    """Both A2 submodels (8 channels: two tiles per wave; 3 channels: four tiles per wave) in ONE launch of the A2 family: kernel sizes 6 and
+    15 with their operand blocks chunked through LDS, dilations that are not tile multiples (straddling taps on many waves), the conv
+    head with its own ring, LeakyReLU -- against the stage interpreter's generic flavour bit for bit, and against the oracles."""
+    m = loader.CreateFromFile(_path("BossWN-a2.nam"), doPrewarm=False)
+    rng = np.random.default_rng(21)
+    qs = [0.0, 1.0, 0.3, 0.9]
+    for sizes in ([128] * 5, [64] * 6, [128, 37, 64, 100, 128, 1, 64, 128]):
+        total = sum(sizes)
+        base = (0.3 * rng.standard_normal((7, total))).clip(-1, 1).astype(np.float32)
+        x = base[np.arange(streams) % 7]
+        ys = []
+        for on in (True, False):
+            spec_switch(on)
+            b = na.Batch(0)
+            for k in range(4):
+                b.AddStreams(m, streams // 4 + (1 if k < streams % 4 else 0), quality=qs[k])
+            assert b.NumStreams() == streams
+            ys.append(_run(b, x, sizes))
+            b.close()
+        spec_switch(True)
+        assert np.all(np.isfinite(ys[0]))
+        assert np.array_equal(ys[0], ys[1]), (streams, sizes, float(np.abs(ys[0] - ys[1]).max()))
+        first = 0
+        for k in range(4):
+            c = streams // 4 + (1 if k < streams % 4 else 0)
+            for s_ in {first, first + c - 1}:
+                if c > 0:
+                    assert O.rms(ys[0][s_] - O.oracle_from_file("BossWN-a2.nam", quality=qs[k]).process(x[s_])) < TOL_RMS, (k, s_)
+            first += c
+
+
+@pytest.mark.skipif(FORCED, reason="forced kernel family")
 def test_config3_mixed_packed_launch_is_bit_identical_to_the_interpreter(na, loader, spec_switch):
     """Lite (padded, pack 1) + Feather (pack 2) + Nano (pack 4): one launch of the packed chain, two architectures of the lite family."""
     lite, arrays, w = _lite(loader)
@@ -140,7 +174,7 @@ def test_default_kernel_family_and_pack_factor_of_every_official_architecture(na
         "lite": ("WaveNetSpecKernel", 1),                                            # padded to 16 / 8 channels
         "feather": ("WaveNetSpecKernel", 2),                                         # narrow static models always run packed
         "nano": ("WaveNetSpecKernel", 4),
-        "a2": ("WaveNetFrameKernel", 1),
+        "a2": ("WaveNetSpecKernel", 1),
         "lstm1x16": ("RecurrentDppKernel", 1),
         "lstm2x8": ("RecurrentDppKernel", 1),
     }
