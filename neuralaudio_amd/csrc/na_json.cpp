@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <charconv>
+#include <clocale>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -111,12 +113,38 @@ namespace na
 			if (res.ec == std::errc::invalid_argument || res.ptr != p) Fail("bad number");
 			if (res.ec == std::errc::result_out_of_range)
 			{
-				// from_chars leaves the value untouched on overflow / underflow; nlohmann keeps +-inf / 0 there
+				// from_chars leaves the value untouched on overflow / underflow -- and libstdc++ 11 reports subnormal results as out of
+				// range too.  Decide by the decimal magnitude of the literal (position of its first non-zero digit + exponent), which needs no
+				// locale: far below DBL_MIN -> 0 (with the sign), far above DBL_MAX -> +-inf (what nlohmann keeps), in between (subnormals,
+				// the edges) -> strtod on a copy whose decimal point is the current locale's.
 				const bool neg = (*s == '-');
-				const char* e = s;
-				while (e < p && *e != 'e' && *e != 'E') e++;
-				const bool tiny = (e < p && e + 1 < p && e[1] == '-');
-				v.number = tiny ? 0.0 : (neg ? -HUGE_VAL : HUGE_VAL);
+				const char* q = s + ((*s == '-') ? 1 : 0);
+				long exp10 = 0, firstDigit = 0, intDigits = 0;
+				bool seenNonZero = false, inFrac = false;
+				long fracZeros = 0;
+				for (; q < p && *q != 'e' && *q != 'E'; q++)
+				{
+					if (*q == '.') { inFrac = true; continue; }
+					if (!seenNonZero)
+					{
+						if (*q != '0') { seenNonZero = true; firstDigit = inFrac ? -(fracZeros + 1) : 0; }
+						else if (inFrac) fracZeros++;
+					}
+					if (!inFrac && seenNonZero) intDigits++;
+				}
+				if (q < p) exp10 = std::strtol(q + 1, nullptr, 10);
+				// decimal exponent of the leading digit: d.ddd x 10^mag
+				const long mag = exp10 + (intDigits > 0 ? intDigits - 1 : firstDigit);
+				if (!seenNonZero || mag < -330) v.number = neg ? -0.0 : 0.0;
+				else if (mag > 310) v.number = neg ? -HUGE_VAL : HUGE_VAL;
+				else
+				{
+					std::string copy(s, p);
+					const char point = *std::localeconv()->decimal_point;
+					for (char& ch : copy)
+						if (ch == '.') ch = point;
+					v.number = std::strtod(copy.c_str(), nullptr); // subnormal or +-inf at the edges
+				}
 			}
 			v.numberIsInteger = isInt;
 			return v;

@@ -356,6 +356,26 @@ def test_metadata_values_are_dumped_like_nlohmann(na, tmp_path):
     assert m.GetMetadata("nested") == '{"alpha":[1.5,2,"x"],"mid":null,"zeta":1}'
 
 
+def test_numbers_beyond_the_double_range_follow_the_literal_not_its_spelling(na, tmp_path):
+    """Out-of-range literals: underflow -> 0 whatever the spelling (plain decimals and positive exponents with many leading
+    zeros included), overflow -> +-inf, subnormals keep their value (libstdc++'s from_chars reports them as out of range)."""
+    loader = na.NeuralModelLoader()
+    j = O.load_json("BossWN-nano.nam")
+    text = json.dumps(j)
+    extra = ('"u1": 1e-400, "u2": 0.' + "0" * 400 + '1, "u3": 0.' + "0" * 400 + '1e+20, "o1": 1e400, "o2": -1' + "0" * 400 + '.0, '
+             '"sub": 4.9406564584124654e-324, "sub2": 2.5e-310, "edge": 1.7976931348623157e308, ')
+    text = text.replace('"metadata": {', '"metadata": {' + extra, 1)
+    p = tmp_path / "m.nam"
+    p.write_text(text)
+    m = loader.CreateFromFile(str(p), doPrewarm=False)
+    assert m is not None
+    assert float(m.GetMetadata("u1")) == 0.0 and float(m.GetMetadata("u2")) == 0.0 and float(m.GetMetadata("u3")) == 0.0
+    assert m.GetMetadata("o1") in ("null", "inf", "Infinity") or float(m.GetMetadata("o1")) == float("inf")
+    assert m.GetMetadata("o2") in ("null", "-inf", "-Infinity") or float(m.GetMetadata("o2")) == float("-inf")
+    assert float(m.GetMetadata("sub")) == 5e-324 and float(m.GetMetadata("sub2")) == 2.5e-310
+    assert float(m.GetMetadata("edge")) == 1.7976931348623157e308
+
+
 def test_a2_features_outside_the_internal_path_are_rejected(na, tmp_path):
     """NAMIsA2Standard (NeuralModel.cpp:188-317) sends such files to NAM Core; without that back-end they must not load silently."""
     loader = na.NeuralModelLoader()
