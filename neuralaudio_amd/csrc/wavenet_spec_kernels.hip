@@ -48,6 +48,7 @@ namespace na
 			static constexpr bool LEAKY = false;
 			static constexpr int T = 2, CHUNK = 10;
 			static constexpr bool COARSE = false; // (dilations are powers of two: at most three wave classes per layer, 53 KB of code)
+			static constexpr bool GUARDHIST = false;
 		};
 		struct ArchStd : ArchA1Base // A1 Standard (16 -> 8)
 		{
@@ -85,6 +86,7 @@ namespace na
 			static constexpr bool LEAKY = true;
 			static constexpr int CHUNK = 16;
 			static constexpr bool COARSE = true;
+			static constexpr bool GUARDHIST = true;
 		};
 		struct ArchA2Full : ArchA2Base { static constexpr int CH[2] = { 8, 0 }; static constexpr int T = 2; };
 		struct ArchA2Lite : ArchA2Base { static constexpr int CH[2] = { 4, 0 }; static constexpr int T = 4; };
@@ -218,9 +220,19 @@ namespace na
 		// against a 64 KB instruction cache shared by two CUs (measured: waves waiting thousands of cycles for their body's first fetch,
 		// A2 "Full" 164 us per 1024 streams).  With COARSE wave 0 keeps its exact classes and waves 1 .. share one body: a tap they do not
 		// agree on runs as TAP_BOTH on all of them (always correct: predicated ring load + clamped LDS read, two more MFMAs).
+		// A ring whose reader looks at most GUARD = 16 frames back (d (K - 1) <= 16: the first layers of every array, the conv head): the
+		// stage in front of the reader copies those 16 frames from the ring into the guard quads in front of frame 0 of the LDS image, so
+		// EVERY tap of EVERY wave is a plain LDS read -- no per-tap history loads, no straddling taps, one body for all waves.
+		// Only where a stage is long enough to hide the copy: it reads frames the PREVIOUS launch stored (always an HBM access) and has to be
+		// in LDS by the end of the stage in front of the reader -- one stage of latency hiding instead of the two a register prefetch gets.
+		// Measured: A2 (K = 6 / 15 layers) config 5 104.6 -> 87.9 us; A1 Standard (K = 3: short stages) 41.6 -> 48.3 us.  So A::GUARDHIST.
+		template <class C, int RG>
+		constexpr bool SmallRing() { return C::A::GUARDHIST && C::TB::RingFrames(RG) - FRAMES <= GUARD; }
+
 		template <class C>
-		constexpr int WaveTapClass(int w, int P, int i, int shift)
+		constexpr int WaveTapClass(int w, int P, int i, int shift, bool small)
 		{
+			if (small) return TAP_LDS;
 			if (!C::A::COARSE || w == 0 || C::WPS <= 2) return TapClassOf(C::FW * w, P, i, shift);
 			const int first = TapClassOf(C::FW * 1, P, i, shift);
 			for (int v = 2; v < C::WPS; v++)
@@ -241,9 +253,9 @@ namespace na
 			{
 				unsigned long long s = 0;
 				for (int k = 0; k < K - 1; k++)
-					for (int i = 0; i < S; i++) s = s * 3 + (unsigned)WaveTapClass<C>(w, P, i, d * (K - 1 - k));
+					for (int i = 0; i < S; i++) s = s * 3 + (unsigned)WaveTapClass<C>(w, P, i, d * (K - 1 - k), SmallRing<C, L>());
 				for (int k = 0; k < Kn - 1 && k < C::HPF; k++)
-					for (int i = 0; i < S; i++) s = s * 3 + (unsigned)WaveTapClass<C>(w, P, i, dn * (Kn - 1 - k));
+					for (int i = 0; i < S; i++) s = s * 3 + (unsigned)WaveTapClass<C>(w, P, i, dn * (Kn - 1 - k), SmallRing<C, LN>());
 				return s;
 			}
 			static constexpr int Rep(int w) { int r = w; for (int v = w - 1; v >= 0; v--) if (Of(v) == Of(w)) r = v; return r; }
@@ -337,7 +349,7 @@ namespace na
 		{
 			typedef typename C::TB TB;
 			constexpr int GP = TB::RingG(RG), P = Geo<GP, C::T>::P, R = TB::RingFrames(RG), OFF = TB::RingOff(RG);
-			const int cls = WaveTapClass<C>(WR, P, i, shift);
+			const int cls = WaveTapClass<C>(WR, P, i, shift, SmallRing<C, RG>());
 			if ((NA_ABL & 4) || cls == TAP_LDS) return RingLoad(cx.srsrc, OOB);
 			const int pos0 = __builtin_amdgcn_readlane(cx.myPos, RG);
 			int base = pos0 - shift + C::FW * cx.wave + 16 * P * i; // wave-uniform; in (-R, 2R)
@@ -354,7 +366,7 @@ namespace na
 
 		// does any wave of the block need the ring history of a tap `shift` back for set i?  (wave 0 has the earliest frames)
 		template <class C, int GP>
-		constexpr bool HistNeededAt(int shift, int i) { return TapClassOf(0, Geo<GP, C::T>::P, i, shift) != TAP_LDS; }
+		constexpr bool HistNeededAt(int shift, int i, bool small) { return !small && TapClassOf(0, Geo<GP, C::T>::P, i, shift) != TAP_LDS; }
 
 		// prefetched taps of layer L: k < min(K - 1, HPF)
 		template <class C, int L>
@@ -366,7 +378,7 @@ namespace na
 			constexpr int GP = TB::GPof(TB::ArrOf(L)), S = Geo<GP, C::T>::S;
 			int n = 0;
 			for (int k = 0; k < PrefetchTaps<C, L>(); k++)
-				for (int i = 0; i < S; i++) n += HistNeededAt<C, GP>(ShiftOf<C, L>(k), i) ? 1 : 0;
+				for (int i = 0; i < S; i++) n += HistNeededAt<C, GP>(ShiftOf<C, L>(k), i, SmallRing<C, L>()) ? 1 : 0;
 			return n;
 		}
 
@@ -378,7 +390,7 @@ namespace na
 			for (int k = 0; k < PrefetchTaps<C, L>(); k++)
 #pragma unroll
 				for (int i = 0; i < S; i++)
-					if (HistNeededAt<C, GP>(ShiftOf<C, L>(k), i)) st.hist[k][i] = HistLoadAt<C, L, WR>(cx, laneRing, fl, ShiftOf<C, L>(k), i);
+					if (HistNeededAt<C, GP>(ShiftOf<C, L>(k), i, SmallRing<C, L>())) st.hist[k][i] = HistLoadAt<C, L, WR>(cx, laneRing, fl, ShiftOf<C, L>(k), i);
 		}
 
 		// A stage's output -> the LDS image (in-block taps of the reader, if it has any) and ring RG (history for LATER blocks: only the
@@ -415,6 +427,42 @@ namespace na
 			const int addr = RingWrap<GP, R>(ln.ring, base);
 			if (KEEP >= C::NF) RingStore(cx.srsrc, v, addr, OFF * 16);
 			else RingStore(cx.srsrc, v, (C::FW * cx.wave + 16 * P * i + ln.fl >= C::NF - KEEP) ? addr : OOB, OFF * 16);
+		}
+
+		// The 16 frames in front of the block from ring RG (the last 16 the previous block stored) -> guard quads of the reader's LDS image,
+		// by LDS-DMA (no registers: a load into VGPRs was sunk next to its use by the scheduler and its latency paid in every layer), issued
+		// at the START of the stage in front of the reader -- that image is not read during this stage -- and awaited with the stage's weight
+		// DMA before the closing barrier.  Wave 0 of the stream moves them: lanes 0..15 = frames, one instruction per channel group plane.
+		// A reader that is not "small" needs the quad in front of frame 0 to be ZERO instead (straddling taps clamp to it).
+		template <class C, int RG, int GP>
+		__device__ __forceinline__ void GuardStage(const Ctx& cx, const Lanes<C, GP>& ln, int imgBuf)
+		{
+			typedef typename C::TB TB;
+			static_assert(GP == TB::RingG(RG), "lane mode of the ring");
+			constexpr int R = TB::RingFrames(RG), OFF = TB::RingOff(RG);
+			if constexpr (!C::A::GUARDHIST) return; // (the prologue's zero guard quads stay zero)
+			if (cx.wave != 0) return;
+			if constexpr (SmallRing<C, RG>())
+			{
+				if (NA_ABL & 4) return;
+				const int pos0 = __builtin_amdgcn_readlane(cx.myPos, RG);
+				int base = pos0 - GUARD;
+				if (base < 0) base += R;
+				if (cx.lane < 16)
+				{
+#pragma unroll
+					for (int cg = 0; cg < GP; cg++)
+					{
+						const int addr = RingWrap<GP, R>((unsigned)((cx.lane * GP + cg) * 16), base);
+						const unsigned dst = (unsigned)(C::IMG_OFF + imgBuf * C::IMG_ONE + cg * PLANE * 16) + (unsigned)(cx.sub * 2 * C::IMG_ONE);
+						__builtin_amdgcn_raw_ptr_buffer_load_lds(cx.srsrc, (__attribute__((address_space(3))) void*)(LdsPtr)(size_t)dst, 16, addr, OFF * 16, 0, 0);
+					}
+				}
+			}
+			else
+			{
+				if ((cx.lane >> 4) < GP && (cx.lane & 15) == 15) LdsWrite16(ln.img + (unsigned)(imgBuf * C::IMG_ONE) - 16u * 16u, u32x4{ 0, 0, 0, 0 }); // frame 15 - 16 = -1
+			}
 		}
 
 		// The next chunk of A operands (chunk CN of stage SN) -> the other LDS weight buffer by LDS-DMA (lane l's 16 bytes land at base +
@@ -484,7 +532,7 @@ namespace na
 		__device__ __forceinline__ f32x4 ConvTap(const Ctx& cx, const Lanes<C, GP>& ln, int imgRead, int shift, int i, u32x4 ah, u32x4 al, u32x4 hist, f32x4 acc)
 		{
 			constexpr int P = Geo<GP, C::T>::P;
-			const int cls = WaveTapClass<C>(WR, P, i, shift);
+			const int cls = WaveTapClass<C>(WR, P, i, shift, SmallRing<C, RG>());
 			if (cls != TAP_LDS)
 			{
 				acc = Mfma(ah, hist, acc);
@@ -526,6 +574,12 @@ namespace na
 			constexpr bool TAIL = 2 * K >= CB && 2 * K < CE;             // aux / 1x1 operands are in this chunk
 			constexpr int LATER = ((OWN && SG::NEXT) ? HistLoadsOf<C, LN>() : 0) + ((TAIL && SG::NEXT && !LASTLAYER) ? StoresOf<C, LN>() : 0);
 			typedef typename NextChunk<C, s, c>::St NextStager;
+			if constexpr (c == 0)
+			{
+				// what the next reader (the next layer, or the conv head after the last layer) finds in front of frame 0 of its image
+				if constexpr (SG::NEXT) GuardStage<C, LN, GP>(cx, ln, imgWrite);
+				else if constexpr (LASTLAYER && TB::HEADK > 1) GuardStage<C, TB::NL, GP>(cx, ln, (TB::NSTAGES - 1 + 1) & 1);
+			}
 			NextStager::Begin(cx);
 			if constexpr (c == 0)
 			{
@@ -543,7 +597,7 @@ namespace na
 				if (k < C::HPF) continue;
 #pragma unroll
 				for (int i = 0; i < S; i++)
-					if (WaveTapClass<C>(WR, SG::P, i, ShiftOf<C, L>(k)) != TAP_LDS) hx[k - (KLO > C::HPF ? KLO : C::HPF)][i] = HistLoadAt<C, L, WR>(cx, ln.ring, ln.fl, ShiftOf<C, L>(k), i);
+					if (WaveTapClass<C>(WR, SG::P, i, ShiftOf<C, L>(k), SmallRing<C, L>()) != TAP_LDS) hx[k - (KLO > C::HPF ? KLO : C::HPF)][i] = HistLoadAt<C, L, WR>(cx, ln.ring, ln.fl, ShiftOf<C, L>(k), i);
 			}
 #pragma unroll
 			for (int k = KLO; k < KHI; k++)
@@ -553,7 +607,7 @@ namespace na
 				for (int i = 0; i < S; i++)
 				{
 					u32x4 h = u32x4{ 0, 0, 0, 0 };
-					if (WaveTapClass<C>(WR, SG::P, i, ShiftOf<C, L>(k)) != TAP_LDS)
+					if (WaveTapClass<C>(WR, SG::P, i, ShiftOf<C, L>(k), SmallRing<C, L>()) != TAP_LDS)
 						h = (k < C::HPF) ? st.hist[k < C::HPF ? k : 0][i] : hx[k >= C::HPF ? k - (KLO > C::HPF ? KLO : C::HPF) : 0][i];
 					acc[i] = ConvTap<C, L, GP, WR>(cx, ln, imgRead, ShiftOf<C, L>(k), i, ah, al, h, acc[i]);
 				}
@@ -640,7 +694,8 @@ namespace na
 				else if constexpr (SG::LastRep(W)) LayerBody<C, L, W>(cx, ln, st);
 				else
 				{
-					if ((SG::MaskOf(W) >> cx.wave) & 1u) LayerBody<C, L, W>(cx, ln, st);
+					constexpr unsigned MASK = SG::MaskOf(W); // (a constant expression: evaluated by the compiler, not by the wave)
+					if ((MASK >> cx.wave) & 1u) LayerBody<C, L, W>(cx, ln, st);
 					else LayerDispatch<C, L, W + 1>(cx, ln, st);
 				}
 			}
@@ -658,7 +713,7 @@ namespace na
 					bool r = true;
 					for (int w = W + 1; w < C::WPS; w++)
 						for (int k = 0; k < PrefetchTaps<C, L>(); k++)
-							for (int i = 0; i < S; i++) r = r && WaveTapClass<C>(w, P, i, ShiftOf<C, L>(k)) == WaveTapClass<C>(W, P, i, ShiftOf<C, L>(k));
+							for (int i = 0; i < S; i++) r = r && WaveTapClass<C>(w, P, i, ShiftOf<C, L>(k), SmallRing<C, L>()) == WaveTapClass<C>(W, P, i, ShiftOf<C, L>(k), SmallRing<C, L>());
 					return r;
 				}();
 				if constexpr (same) HistPrefetch<C, L, W>(cx, laneRing, fl, st);
@@ -676,6 +731,7 @@ namespace na
 		{
 			constexpr int GP = C::TB::GPof(0), S = Geo<GP, C::T>::S;
 			SPK_STAMP(0, 0);
+			GuardStage<C, 0, GP>(cx, ln, 1);
 			Stager<C, 1, 0>::Begin(cx);
 			const u32x4 ra = WOp<C>(cx, 0, 0, 0);
 #pragma unroll
@@ -707,6 +763,7 @@ namespace na
 			constexpr int So = Geo<GPO, C::T>::S, Sn = Geo<GPN, C::T>::S, s = TB::LinkStage(AN), LN = TB::FirstLayerOfArr(AN);
 			static_assert(C::T == 2, "array links are written for two tiles per wave");
 			SPK_STAMP(s, 0);
+			GuardStage<C, LN, GPN>(cx, ln, (s + 1) & 1);
 			Stager<C, s + 1, 0>::Begin(cx);
 			u32x4 hs[So], xq[So];
 #pragma unroll
@@ -779,7 +836,8 @@ namespace na
 					}
 					if (c == 0)
 					{
-						// the head accumulator of this block -> LDS image + head ring, then every wave may read its neighbours' frames
+						// the head accumulator of this block -> LDS image + head ring (and the 16 frames before the block into the image's guard),
+						// then every wave may read its neighbours' frames
 #pragma unroll
 						for (int i = 0; i < S; i++) Publish<C, RG, GP, 1>(cx, ln, hs[i], i, imgHead);
 						BlockBarrier<C::NTHREADS / 64>();
@@ -793,7 +851,7 @@ namespace na
 						for (int i = 0; i < S; i++)
 						{
 							u32x4 h = u32x4{ 0, 0, 0, 0 };
-							if (WaveTapClass<C>(WR, P, i, K - 1 - k) != TAP_LDS) h = HistLoadAt<C, RG, WR>(cx, ln.ring, ln.fl, K - 1 - k, i);
+							if (WaveTapClass<C>(WR, P, i, K - 1 - k, SmallRing<C, RG>()) != TAP_LDS) h = HistLoadAt<C, RG, WR>(cx, ln.ring, ln.fl, K - 1 - k, i);
 							acc[i] = ConvTap<C, RG, GP, WR>(cx, ln, imgHead, K - 1 - k, i, ah, al, h, acc[i]);
 						}
 					}
@@ -844,7 +902,7 @@ namespace na
 		{
 			// a dense head is the same on every wave; a conv head's taps (shifts 1 .. K - 1 < FW) straddle the block start on wave 0 and lie
 			// inside the block on every other wave
-			if constexpr (C::TB::HEADK == 1 || C::WPS == 1) HeadBody<C, 0>(cx, ln, st, out, outBase, outRow, pack, headScale, live);
+			if constexpr (C::TB::HEADK == 1 || C::WPS == 1 || SmallRing<C, C::TB::NL>()) HeadBody<C, 0>(cx, ln, st, out, outBase, outRow, pack, headScale, live);
 			else
 			{
 				if (cx.wave == 0) HeadBody<C, 0>(cx, ln, st, out, outBase, outRow, pack, headScale, live);

@@ -183,7 +183,7 @@ def test_recurrent_models_through_tiny_and_ragged_buffers(na, kind, layers, hidd
 def test_runtime_shaped_lstm_matches_oracle(na, loader, layers, hidden):
     """Hidden sizes / layer counts without a shaped kernel run on the runtime-shaped one (LSTMDynamic.h:95-108 accepts any); shapes
     whose weights exceed the LDS (2x64 and up) stream them from L2, up to 128 units."""
-    if os.environ.get("NA_LSTM_NO_WAVE_RT") and (hidden > 64 or layers * hidden > 128):
+    if (os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_LSTM_LANE_KERNEL")) and (hidden > 64 or layers * hidden > 128):
         pytest.skip("beyond the lane = stream kernel's LDS bound")
     w = O.synth_lstm_weights(layers, hidden, seed=100 + hidden)
     m = loader.CreateFromString(O.nam_json_lstm(layers, hidden, w), ".nam")
