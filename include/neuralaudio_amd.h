@@ -134,6 +134,10 @@ NA_EXTERN int NA_DebugPackedWeights(NeuralModel* model, int* packFactor, float* 
 /* tests / tuning: 0 = WaveNet models with a compile-time specialised layer chain run on the stage interpreter instead (same stream state,
  * bit-identical results); process-wide, set it only while no other thread is processing */
 NA_EXTERN void NA_DebugSetWaveNetSpec(int on);
+/* Tests / tuning: the stream count of one recurrent launch from which the four-streams-per-wave kernel is used (0: never; default 3072,
+ * environment NA_REC_QUAD_MIN); returns the previous value.  NA_DebugRecurrentQuadLaunches: launches of that kernel so far. */
+NA_EXTERN int NA_DebugSetRecurrentQuadMin(int streams);
+NA_EXTERN long long NA_DebugRecurrentQuadLaunches(void);
 /* tuning aid: device buffer (long long[stages*4*waves]) that workgroup 0 of the WaveNet kernel stamps with the shader clock; NULL = off */
 NA_EXTERN void NA_DebugSetTraceBuffer(void* deviceBuffer);
 

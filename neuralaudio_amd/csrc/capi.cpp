@@ -8,6 +8,7 @@
 #include "neuralaudio_amd.h"
 #include "multi_gpu.h"
 #include "neural_model_impl.h"
+#include "lstm_launch.h"
 #include "wavenet_launch.h"
 #include "wavenet_plan.h"
 
@@ -584,6 +585,10 @@ int NA_MultiSetQuality(NA_MultiBatch* mb, int stream, float quality)
 }
 
 void NA_DebugSetWaveNetSpec(int on) { na::SetWaveNetSpecEnabled(on != 0); }
+
+int NA_DebugSetRecurrentQuadMin(int streams) { return na::SetRecurrentQuadMinStreams(streams); }
+
+long long NA_DebugRecurrentQuadLaunches(void) { return (long long)na::RecurrentQuadLaunches(); }
 
 void NA_DebugSetTraceBuffer(void* deviceBuffer) { na::SetWaveNetTraceBuffer(reinterpret_cast<long long*>(deviceBuffer)); }
 

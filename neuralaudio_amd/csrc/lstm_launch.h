@@ -25,6 +25,11 @@ namespace na
 		int slot0, row0;
 	};
 	bool RecurrentDppSupported(const LstmModelDev& m);
+	// four streams per wave (RecurrentQuadKernel) for launches of at least this many streams of LSTMs up to 2x16; tests / tuning
+	bool RecurrentQuadSupported(const LstmModelDev& m);
+	int RecurrentQuadMinStreams();
+	int SetRecurrentQuadMinStreams(int streams); // returns the previous value
+	long RecurrentQuadLaunches();
 	// The runtime-shaped one-wave-per-stream kernel (lstm_kernels.hip): LSTM or GRU cells, hidden <= 64, any layer count, classic head or
 	// dense chain, as long as the weights of all layers fit the LDS.  false: not launched (the lane = stream kernels take the model).
 	bool LaunchRecurrentWaveRt(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,

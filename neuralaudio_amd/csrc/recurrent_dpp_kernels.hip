@@ -6,6 +6,7 @@
 //
 // Reference arithmetic: LSTMModelT/LSTMLayerT::Process (NeuralAudio/LSTM.h:164-191, 87-100), FastMath (Activation.h:83-96);
 // keras GRU = RTNeural's GRULayer (NeuralAudio/RTNeuralModel.h:300,417-421; third-party, parity unpinned -- see gru_kernels.hip).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -739,6 +740,301 @@ namespace na
 		int noSkew; // tuning / tests (NA_REC_NOSKEW): two-layer H = 8 LSTMs on the sequential body
 	};
 
+	// ------------------------------------------------------------------------------------------------------------
+	// Large batches (thousands of streams: more waves than the chip has SIMDs, so the launch is bound by instruction issue and not by
+	// the latency of a lone wave): FOUR streams per wave.  lane = 16 * stream + unit and every lane owns ALL FOUR gate rows of its unit,
+	// as two packed pairs (i, f) and (g, o): a row sum is v_pk_fma_f32 over the 16 state values of the lane's stream -- 2 x 17 packed
+	// instructions per sample for four streams, where the one-stream layout spends 17 (and its DPP terms cost ~6 cycles each, measured,
+	// against ~4.3 for a plain or packed VALU instruction).  The state reaches the lanes through LDS: every lane writes the h of its unit
+	// (the entry the dense head reads afterwards anyway) and reads the 16 values of its stream back as four 16-byte broadcasts.  The gates
+	// of a unit meet in one lane (no lane swaps), the activations run on packed pairs with the gate's identity in per-component constants,
+	// tanh(c) on full lanes.  ~80 instructions per sample for four streams against 52 per stream.  The dependent chain of a wave is
+	// longer, so the one-stream layout stays the choice for batches that leave SIMDs idle (LaunchRecurrentDpp picks by the stream count).
+	// Row sums run over the columns in the reference's order (input, then h[0 .. hr - 1]; LSTM.h:87-100), not rotated by the unit as in
+	// the one-stream layout: the two layouts agree to rounding (~1e-7), not bit for bit.  Hidden sizes below 16 are zero-padded.
+	// ------------------------------------------------------------------------------------------------------------
+	typedef float quad_f2 __attribute__((ext_vector_type(2)));
+	constexpr int QUAD_CHUNK = 16;                      // samples between two head passes (bounds the LDS of a wave)
+	constexpr int QUAD_XROW = LSTM_MAX_FRAMES + 4;      // input samples of one stream in LDS (+4: the float4 reads may run past the block)
+	constexpr int QUAD_HP = 20;                         // floats per h entry: 16 units + padding (16-byte aligned rows, spread over the banks)
+	constexpr int QUAD_HROW = (QUAD_CHUNK + 1) * QUAD_HP; // output-layer h of one stream: the state before the chunk, then after each of its samples
+	constexpr int QUAD_LDS_FLOATS = 4 * QUAD_XROW + 4 * QUAD_HROW + 4 * QUAD_HP; // + the layer-0 h of two-layer models
+
+	__device__ __forceinline__ quad_f2 QuadFma(quad_f2 a, quad_f2 b, quad_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+	__device__ __forceinline__ quad_f2 QuadSplat(float v) { return quad_f2{ v, v }; }
+
+	// GateAct on a pair of gate rows: component 0 / 1 take the constants of their own gate (sigmoid or tanh)
+	template <bool STD>
+	struct QuadGateK
+	{
+		quad_f2 a, b, c, B; // FastMath: aA, bA, cA, B of GateK<false>; StdMath: a = k, b = A, c unused
+	};
+	template <bool STD>
+	__device__ __forceinline__ QuadGateK<STD> MakeQuadGateK(bool g0, bool g1)
+	{
+		const GateK<STD> k0 = MakeGateK<STD>(g0), k1 = MakeGateK<STD>(g1);
+		QuadGateK<STD> K;
+		if constexpr (STD)
+		{
+			K.a = quad_f2{ k0.k, k1.k };
+			K.b = quad_f2{ k0.A, k1.A };
+			K.c = quad_f2{ 0.0f, 0.0f };
+			K.B = quad_f2{ k0.B, k1.B };
+		}
+		else
+		{
+			K.a = quad_f2{ k0.aA, k1.aA };
+			K.b = quad_f2{ k0.bA, k1.bA };
+			K.c = quad_f2{ k0.cA, k1.cA };
+			K.B = quad_f2{ k0.B, k1.B };
+		}
+		return K;
+	}
+	template <bool STD>
+	__device__ __forceinline__ quad_f2 QuadGateAct(quad_f2 y, const QuadGateK<STD>& K)
+	{
+		if constexpr (STD)
+		{
+			const quad_f2 e = y * K.a;
+			const quad_f2 r = quad_f2{ __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(e.x) + 1.0f), __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(e.y) + 1.0f) };
+			return QuadFma(r, K.b, K.B);
+		}
+		else
+		{
+			// (same expression tree as GateAct<false>, two rows at a time)
+			const quad_f2 ay = quad_f2{ fabsf(y.x), fabsf(y.y) };
+			const quad_f2 y2 = y * y;
+			const quad_f2 p = QuadFma(y2, QuadFma(ay, K.c, K.b), QuadFma(ay, K.a, K.a));
+			const quad_f2 den = QuadFma(QuadSplat(2.44506634652299f) + y2, QuadFma(QuadSplat(0.814642734961073f), y2, ay), QuadSplat(2.44506634652299f));
+			const quad_f2 r = quad_f2{ __builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y) };
+			return QuadFma(y * p, r, K.B);
+		}
+	}
+
+	template <int L, bool STD>
+	__device__ __forceinline__ void LstmQuadBody(const RecurrentGroupArgs& ga, int idx0, const float* __restrict__ in, float* __restrict__ out, long inStride,
+		long outStride, int n, float* lds)
+	{
+		constexpr int H = 16, HP = QUAD_HP;
+		const LstmModelDev& m = ga.m;
+		float* __restrict__ state = ga.state;
+		const int capacity = ga.capacity;
+		const int lane = threadIdx.x, unit = lane & 15, sub = lane >> 4;
+		const int hr = m.hidden;
+		const bool real = unit < hr;
+		const bool live = idx0 + sub < ga.numStreams; // a short last wave: the surplus rows repeat the last stream and store nothing
+		const int idx = live ? idx0 + sub : ga.numStreams - 1;
+		const int slot = ga.slots ? ga.slots[idx] : ga.slot0 + idx;
+		const int row = ga.slots ? ga.rows[idx] : ga.row0 + idx;
+		const QuadGateK<STD> KIF = MakeQuadGateK<STD>(false, false), KGO = MakeQuadGateK<STD>(true, false);
+		const float sS = GateRowScale<STD>(false), sT = GateRowScale<STD>(true); // (the inner 0.5 of a sigmoid rides in its row: see GateAct)
+
+		// layer 0: W row-major [4 hr][1 + hr], then bias[4 hr] (LSTM.h:42-56); gate blocks i, f, g, o.  Pair IF = rows (i, f), GO = (g, o)
+		const float* w0 = m.w + m.layerOff[0];
+		const int W0 = 1 + hr;
+		auto pairOf = [&](const float* w, int rowStride, int col, bool on, int qa, float sa, int qb, float sb) {
+			return quad_f2{ sa * LoadIf(w, (size_t)(qa * hr + unit) * rowStride + col, on), sb * LoadIf(w, (size_t)(qb * hr + unit) * rowStride + col, on) };
+		};
+		const quad_f2 wxIF = pairOf(w0, W0, 0, real, 0, sS, 1, sS), wxGO = pairOf(w0, W0, 0, real, 2, sT, 3, sS);
+		const quad_f2 b0IF = quad_f2{ sS * LoadIf(w0, (size_t)4 * hr * W0 + 0 * hr + unit, real), sS * LoadIf(w0, (size_t)4 * hr * W0 + 1 * hr + unit, real) };
+		const quad_f2 b0GO = quad_f2{ sT * LoadIf(w0, (size_t)4 * hr * W0 + 2 * hr + unit, real), sS * LoadIf(w0, (size_t)4 * hr * W0 + 3 * hr + unit, real) };
+		quad_f2 wh0IF[H], wh0GO[H];
+#pragma unroll
+		for (int k = 0; k < H; k++)
+		{
+			wh0IF[k] = pairOf(w0, W0, 1 + k, real && k < hr, 0, sS, 1, sS);
+			wh0GO[k] = pairOf(w0, W0, 1 + k, real && k < hr, 2, sT, 3, sS);
+		}
+		// layer 1: W [4 hr][hr + hr]: input = layer-0 h, then own h
+		constexpr int H1 = L > 1 ? H : 1;
+		quad_f2 wi1IF[H1], wi1GO[H1], wh1IF[H1], wh1GO[H1], b1IF = QuadSplat(0.0f), b1GO = QuadSplat(0.0f);
+		if constexpr (L > 1)
+		{
+			const float* w1 = m.w + m.layerOff[1];
+			const int W1 = 2 * hr;
+#pragma unroll
+			for (int k = 0; k < H; k++)
+			{
+				const bool on = real && k < hr;
+				wi1IF[k] = pairOf(w1, W1, k, on, 0, sS, 1, sS);
+				wi1GO[k] = pairOf(w1, W1, k, on, 2, sT, 3, sS);
+				wh1IF[k] = pairOf(w1, W1, hr + k, on, 0, sS, 1, sS);
+				wh1GO[k] = pairOf(w1, W1, hr + k, on, 2, sT, 3, sS);
+			}
+			b1IF = quad_f2{ sS * LoadIf(w1, (size_t)4 * hr * W1 + 0 * hr + unit, real), sS * LoadIf(w1, (size_t)4 * hr * W1 + 1 * hr + unit, real) };
+			b1GO = quad_f2{ sT * LoadIf(w1, (size_t)4 * hr * W1 + 2 * hr + unit, real), sS * LoadIf(w1, (size_t)4 * hr * W1 + 3 * hr + unit, real) };
+		}
+
+		// LDS: the input block of the four streams [stream][QUAD_XROW]; the output layer's h [stream][entry][HP]; layer-0 h of two-layer models
+		float* xin = lds;
+		float* hout = lds + 4 * QUAD_XROW;
+		float* h0buf = hout + 4 * QUAD_HROW;
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			const float* inRow = in + (size_t)__builtin_amdgcn_readlane(row, 16 * s) * inStride;
+			for (int f = lane; f < n + 4; f += 64) xin[s * QUAD_XROW + f] = f < n ? inRow[f] : 0.0f;
+		}
+		float h[L], c[L];
+#pragma unroll
+		for (int l = 0; l < L; l++)
+		{
+			h[l] = LoadIf(state, (size_t)(l * 2 * hr + unit) * capacity + slot, real);
+			c[l] = LoadIf(state, (size_t)(l * 2 * hr + hr + unit) * capacity + slot, real);
+		}
+		float* hw = hout + sub * QUAD_HROW + unit;        // this lane's word of an entry of the output layer's h
+		const float* hrd = hout + sub * QUAD_HROW;        // the 16 values of an entry
+		float* h0w = h0buf + sub * HP + unit;
+		const float* h0rd = h0buf + sub * HP;
+		hw[0] = h[L - 1];
+		if constexpr (L > 1) *h0w = h[0];
+		RecurrentWaveSync();
+
+		auto read16 = [&](const float* p, float (&v)[H]) {
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+			{
+				const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+				v[4 * q + 0] = t.x;
+				v[4 * q + 1] = t.y;
+				v[4 * q + 2] = t.z;
+				v[4 * q + 3] = t.w;
+			}
+		};
+		auto cell = [&](quad_f2 aIF, quad_f2 aGO, float& cc) {
+			const quad_f2 gIF = QuadGateAct<STD>(aIF, KIF), gGO = QuadGateAct<STD>(aGO, KGO);
+			cc = __builtin_fmaf(gIF.y, cc, gIF.x * gGO.x);
+			return gGO.y * (STD ? StdTanh(cc) : LstmRcpTanh(cc));
+		};
+		float hv0[H]; // h of layer 0, all units of this lane's stream
+		read16(L > 1 ? h0rd : hrd, hv0);
+		// one sample: entry e of hout = the output layer's h after sample e - 1 of the chunk
+		auto step = [&](float x, int e) {
+			quad_f2 aIF = QuadFma(wxIF, QuadSplat(x), b0IF), aGO = QuadFma(wxGO, QuadSplat(x), b0GO); // LSTM.h:168 -- column 0 is the input sample
+#pragma unroll
+			for (int k = 0; k < H; k++)
+			{
+				aIF = QuadFma(wh0IF[k], QuadSplat(hv0[k]), aIF);
+				aGO = QuadFma(wh0GO[k], QuadSplat(hv0[k]), aGO);
+			}
+			h[0] = cell(aIF, aGO, c[0]);
+			if constexpr (L == 1)
+			{
+				hw[(e + 1) * HP] = h[0];
+				RecurrentWaveSync();
+				read16(hrd + (e + 1) * HP, hv0);
+			}
+			else
+			{
+				*h0w = h[0];
+				float hv1[H];
+				read16(hrd + e * HP, hv1);
+				RecurrentWaveSync();
+				read16(h0rd, hv0);
+				quad_f2 bIF = b1IF, bGO = b1GO; // LSTM.h:170-180
+#pragma unroll
+				for (int k = 0; k < H; k++)
+				{
+					bIF = QuadFma(wi1IF[k], QuadSplat(hv0[k]), bIF);
+					bGO = QuadFma(wi1GO[k], QuadSplat(hv0[k]), bGO);
+				}
+#pragma unroll
+				for (int k = 0; k < H; k++)
+				{
+					bIF = QuadFma(wh1IF[k], QuadSplat(hv1[k]), bIF);
+					bGO = QuadFma(wh1GO[k], QuadSplat(hv1[k]), bGO);
+				}
+				h[1] = cell(bIF, bGO, c[1]);
+				hw[(e + 1) * HP] = h[1];
+				RecurrentWaveSync();
+			}
+		};
+
+		const float* xs = xin + sub * QUAD_XROW;
+		const float* headW = m.w + m.headOff;
+		for (int f0 = 0; f0 < n; f0 += QUAD_CHUNK)
+		{
+			const int cn = min(QUAD_CHUNK, n - f0);
+			int f = 0;
+			for (; f + 4 <= cn; f += 4)
+			{
+				const float4 xv = *reinterpret_cast<const float4*>(xs + f0 + f);
+				step(xv.x, f + 0);
+				step(xv.y, f + 1);
+				step(xv.z, f + 2);
+				step(xv.w, f + 3);
+			}
+			for (; f < cn; f++) step(xs[f0 + f], f);
+			// dense head of the chunk (LSTM.h:182-189): output o = QUAD_CHUNK * stream + sample, one per lane
+			{
+				const int s = lane / QUAD_CHUNK, ff = lane % QUAD_CHUNK;
+				const float* hs = hout + s * QUAD_HROW + (ff + 1) * HP;
+				float acc = 0.0f;
+#pragma unroll
+				for (int k = 0; k < H; k++) acc += LoadIf(headW, (size_t)k, k < hr) * hs[k];
+				const int orow = __builtin_amdgcn_ds_bpermute(4 * (16 * s), row);
+				if (ff < cn && idx0 + s < ga.numStreams) out[(size_t)orow * outStride + f0 + ff] = acc + headW[hr];
+			}
+			RecurrentWaveSync();
+			hw[0] = h[L - 1]; // entry 0 of the next chunk
+			RecurrentWaveSync();
+		}
+		if (real && live)
+		{
+#pragma unroll
+			for (int l = 0; l < L; l++)
+			{
+				state[(size_t)(l * 2 * hr + unit) * capacity + slot] = h[l];
+				state[(size_t)(l * 2 * hr + hr + unit) * capacity + slot] = c[l];
+			}
+		}
+	}
+
+	// grid = sum over the groups of ceil(streams / 4), block = 64 (four streams per wave); groups: LSTM, L layers, hidden <= 16.
+	// One kernel per layer count: the weights of the gate rows live in registers (L = 1: ~100 VGPRs, four to five waves per SIMD; L = 2:
+	// 256, two waves) and a common kernel would run every model at the occupancy of the largest.
+	template <int L>
+	__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L == 1 ? 3 : 1))) RecurrentQuadKernel(const RecurrentLaunchArgs args,
+		const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
+	{
+		__shared__ __attribute__((aligned(16))) float lds[QUAD_LDS_FLOATS];
+		int gi = 0;
+		for (int i = 1; i < args.numGroups; i++)
+			if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
+		const RecurrentGroupArgs& ga = args.g[gi];
+		const int idx0 = 4 * ((int)blockIdx.x - ga.firstBlock);
+		if (ga.m.math == LSTM_MATH_STD) LstmQuadBody<L, true>(ga, idx0, in, out, inStride, outStride, n, lds);
+		else LstmQuadBody<L, false>(ga, idx0, in, out, inStride, outStride, n, lds);
+	}
+
+	bool RecurrentQuadSupported(const LstmModelDev& m)
+	{
+		// One layer.  (Two layers were measured: the second layer's 128 weight registers per lane leave one wave per SIMD and the layout
+		// loses to the one-stream kernel -- 2x16 x 8192: 199 vs 205 us, 2x8: 174 vs 95 us.  The body keeps the L = 2 code for reference.)
+		return m.tailLayers == 0 && m.cell == LSTM_CELL_LSTM && m.hidden >= 1 && m.hidden <= 16 && m.numLayers == 1;
+	}
+
+	// streams in one launch from which the four-streams-per-wave layout is used (0: never); NA_REC_QUAD_MIN, tests: SetRecurrentQuadMinStreams
+	static std::atomic<int> gQuadMin{ -1 };
+	static std::atomic<long> gQuadLaunches{ 0 };
+	int RecurrentQuadMinStreams()
+	{
+		int v = gQuadMin.load(std::memory_order_relaxed);
+		if (v < 0)
+		{
+			v = getenv("NA_REC_QUAD_MIN") ? atoi(getenv("NA_REC_QUAD_MIN")) : 3072;
+			gQuadMin.store(v, std::memory_order_relaxed);
+		}
+		return v;
+	}
+	int SetRecurrentQuadMinStreams(int streams)
+	{
+		const int before = RecurrentQuadMinStreams();
+		gQuadMin.store(streams < 0 ? 0 : streams, std::memory_order_relaxed);
+		return before;
+	}
+	long RecurrentQuadLaunches() { return gQuadLaunches.load(std::memory_order_relaxed); }
+
 	// grid = all streams of all groups, block = 64 (one wave per stream)
 	__global__ void __launch_bounds__(64) RecurrentDppKernel(const RecurrentLaunchArgs args, const float* __restrict__ in, float* __restrict__ out, long inStride,
 		long outStride, int n)
@@ -836,6 +1132,21 @@ namespace na
 			a.numStreams = groups[i].numStreams;
 			a.firstBlock = blocks;
 			blocks += groups[i].numStreams;
+		}
+		// a batch with more waves than the chip can hold at three per SIMD: four streams per wave (all groups must have the layout)
+		bool quad = RecurrentQuadMinStreams() > 0 && blocks >= RecurrentQuadMinStreams();
+		for (int i = 0; i < numGroups; i++) quad = quad && RecurrentQuadSupported(groups[i].model) && groups[i].model.numLayers == groups[0].model.numLayers;
+		if (quad)
+		{
+			blocks = 0;
+			for (int i = 0; i < numGroups; i++)
+			{
+				args.g[i].firstBlock = blocks;
+				blocks += (groups[i].numStreams + 3) / 4;
+			}
+			gQuadLaunches.fetch_add(1, std::memory_order_relaxed);
+			hipLaunchKernelGGL(RecurrentQuadKernel<1>, dim3((unsigned)blocks), dim3(64), 0, stream, args, in, out, inStride, outStride, n);
+			return hipGetLastError();
 		}
 		bool any32 = false;
 		for (int i = 0; i < numGroups; i++) any32 |= groups[i].model.hidden > 16;

@@ -1,0 +1,118 @@
+"""GPU tests of the four-streams-per-wave recurrent kernel (RecurrentQuadKernel: one-layer LSTMs of up to 16 units in launches of thousands
+of streams).
+Parity against the oracle with the tolerance of test_gpu_parity.py (5e-6 RMS); against the one-stream-per-wave kernel (which adds the
+terms of a gate row in another order) to rounding."""
+import numpy as np
+import pytest
+
+import na_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def na():
+    import neuralaudio_amd
+    if neuralaudio_amd.device_count() < 1:
+        pytest.fail("no HIP device visible: the product path has no CPU fallback")
+    return neuralaudio_amd
+
+
+@pytest.fixture()
+def quad(na):
+    """sets the stream count from which the four-streams-per-wave layout is used; restores the default afterwards"""
+    from neuralaudio_amd import capi
+    lib = capi.load_library()
+    before = lib.NA_DebugSetRecurrentQuadMin(3072)
+    yield lib
+    lib.NA_DebugSetRecurrentQuadMin(before)
+
+
+def _inputs(S, N):
+    base = np.stack([O.signal_noise(N, 40 + k) for k in range(7)])
+    gain = (0.1 + 0.9 * ((np.arange(S) * 37) % 11) / 10.0).astype(np.float32)
+    return (base[np.arange(S) % 7] * gain[:, None]).astype(np.float32)
+
+
+@pytest.mark.parametrize("layers,hidden,std", [(1, 16, False), (1, 16, True), (1, 12, False), (1, 8, False), (1, 5, True), (1, 1, False)])
+def test_quad_kernel_matches_oracle_and_the_one_stream_kernel(na, quad, layers, hidden, std):
+    ld = na.NeuralModelLoader()
+    if std:
+        ld.SetLSTMMathMode(na.EMathMode.StdMath)
+    w = O.synth_lstm_weights(layers, hidden, seed=700 + 10 * hidden + layers)
+    m = ld.CreateFromString(O.nam_json_lstm(layers, hidden, w), ".nam", doPrewarm=True)
+    S, sizes = 3075, [128, 37, 128, 3, 300]  # not a multiple of four streams; ragged blocks, one above the 128-sample chunk
+    x = _inputs(S, sum(sizes))
+
+    def run(min_streams):
+        quad.NA_DebugSetRecurrentQuadMin(min_streams)
+        b = na.Batch(0)
+        b.AddStreams(m, S)
+        out, pos = [], 0
+        for n in sizes:
+            out.append(b.Process(np.ascontiguousarray(x[:, pos:pos + n])))
+            pos += n
+        return np.concatenate(out, axis=1)
+
+    before = quad.NA_DebugRecurrentQuadLaunches()
+    yq = run(3072)
+    assert quad.NA_DebugRecurrentQuadLaunches() - before >= len(sizes)  # the kernel under test really ran
+    mid = quad.NA_DebugRecurrentQuadLaunches()
+    y1 = run(0)
+    assert quad.NA_DebugRecurrentQuadLaunches() == mid
+    assert np.max(np.abs(yq - y1)) < 3e-6  # the two lane layouts add the terms of a row in different orders
+    for s in (0, 1, 2, 3, 1500, S - 3, S - 2, S - 1):
+        want = O.OracleLSTM.from_nam(layers, hidden, w, math_mode=O.MATH_STD if std else O.MATH_FAST).process(x[s])
+        assert O.rms(yq[s] - want) < 5e-6, (s, O.rms(yq[s] - want))
+
+
+def test_quad_kernel_with_two_models_removed_streams_and_recycled_slots(na, quad):
+    """Several groups in one launch (index lists instead of contiguous ranges after streams left), a group of fewer than four streams."""
+    ld = na.NeuralModelLoader()
+    wa, wb = O.synth_lstm_weights(1, 16, seed=11), O.synth_lstm_weights(1, 12, seed=12)
+    ma = ld.CreateFromString(O.nam_json_lstm(1, 16, wa), ".nam", doPrewarm=True)
+    mb = ld.CreateFromString(O.nam_json_lstm(1, 12, wb), ".nam", doPrewarm=True)
+    quad.NA_DebugSetRecurrentQuadMin(64)
+    b = na.Batch(0)
+    ia = b.AddStreams(ma, 70)
+    ib = b.AddStreams(mb, 3)
+    n, blocks = 96, 3
+    x = _inputs(73, n * blocks)
+    before = quad.NA_DebugRecurrentQuadLaunches()
+    y0 = b.Process(np.ascontiguousarray(x[:, :n]))
+    assert quad.NA_DebugRecurrentQuadLaunches() > before
+    gone = [ia + 5, ia + 6, ia + 40, ib + 1]
+    b.RemoveStreams(ia + 5, 2)
+    b.RemoveStreams(ia + 40, 1)
+    b.RemoveStreams(ib + 1, 1)
+    y1 = b.Process(np.ascontiguousarray(x[:, n:2 * n]))
+    back = b.AddStreams(ma, 2)  # recycled ids and state slots: fresh state
+    assert back == ia + 5
+    y2 = b.Process(np.ascontiguousarray(x[:, 2 * n:]))
+    oa = lambda: O.OracleLSTM.from_nam(1, 16, wa)
+    ob = lambda: O.OracleLSTM.from_nam(1, 12, wb)
+    for s in range(73):
+        o = oa() if s < 70 else ob()
+        want = o.process(x[s])
+        assert O.rms(y0[s] - want[:n]) < 5e-6
+        if s in gone:
+            continue
+        assert O.rms(y1[s] - want[n:2 * n]) < 5e-6, s
+        assert O.rms(y2[s] - want[2 * n:]) < 5e-6, s
+    for k in range(2):  # the re-added streams took the ids of the first two leavers and start from a fresh (prewarmed) state
+        s = back + k
+        want = oa().process(x[s, 2 * n:])
+        assert O.rms(y2[s] - want) < 5e-6, s
+
+
+def test_two_layer_models_stay_on_the_one_stream_layout(na, quad):
+    ld = na.NeuralModelLoader()
+    m = ld.CreateFromFile(O.os.path.join(O.MODELS_DIR, "BossLSTM-2x8.nam"), doPrewarm=True)
+    quad.NA_DebugSetRecurrentQuadMin(1)
+    b = na.Batch(0)
+    b.AddStreams(m, 9)
+    x = _inputs(9, 64)
+    before = quad.NA_DebugRecurrentQuadLaunches()
+    y = b.Process(x)
+    assert quad.NA_DebugRecurrentQuadLaunches() == before
+    assert O.rms(y[8] - O.oracle_from_file("BossLSTM-2x8.nam").process(x[8])) < 5e-6
