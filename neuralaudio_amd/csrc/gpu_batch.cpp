@@ -1302,6 +1302,20 @@ namespace na
 		stageFloats = floats;
 	}
 
+	// Direct mode (the default; NA_HOST_DIRECT=0 selects the copy engines): the kernels read the block straight from the pinned host buffer
+	// and write their output straight into it (every kernel touches `in` once in its prologue and `out` once in its head), so a buffer
+	// is ONE launch instead of copy + launch + copy.  The 2 x 512 KB of a 1024 x 128 block still cross PCIe, inside the kernel, but the
+	// two asynchronous copies (each ~10 us of latency before its first byte moves) and the waits between them are gone.  Measured on
+	// MI355X with this round's kernels (tools/HostPipeBench, 1024 streams x 128 frames; round 2 had it the other way round for the
+	// pipelined path, 66.8 vs 61.9 us, and kept the copies):
+	//   A1 Standard  Submit..Collect in place 91.8 -> 59.4 us (p50), pipelined 52.9 -> 51.4 us per buffer;  64 streams: 44.9 -> 28.9 us
+	//   Nano / Feather / LSTM 1x16 / 2x8      75.8 / 74.6 / 69.4 / 71.2 -> 54.0 / 52.4 / 49.9 / 50.5 us;  A2 96.9 -> 68.4;  4096 Standard 262 -> 180
+	static bool HostDirect()
+	{
+		static const bool direct = getenv("NA_HOST_DIRECT") == nullptr || atoi(getenv("NA_HOST_DIRECT")) != 0;
+		return direct;
+	}
+
 	// (Splitting the buffer into chunks so that host copies overlap the DMA was measured and dropped: every extra asynchronous copy /
 	// event costs more than it hides -- 1024 x 128 frames: 114 us per call as one piece, 134 / 186 / 282 us in 2 / 4 / 8 chunks.)
 	void GpuBatch::ProcessHost(const float* in, float* out, size_t n)
@@ -1311,9 +1325,18 @@ namespace na
 		const size_t total = streams.size() * n;
 		EnsureStaging(total);
 		memcpy(hostStage, in, total * sizeof(float));
-		CheckHip(hipMemcpyAsync(devStage, hostStage, total * sizeof(float), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
-		ProcessDevice(devStage, devStage, n, (long)n, (long)n);
-		CheckHip(hipMemcpyAsync(hostStage, devStage, total * sizeof(float), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H");
+		if (HostDirect())
+		{
+			float* dStage = nullptr;
+			CheckHip(hipHostGetDevicePointer(reinterpret_cast<void**>(&dStage), hostStage, 0), "hipHostGetDevicePointer");
+			ProcessDevice(dStage, dStage, n, (long)n, (long)n);
+		}
+		else
+		{
+			CheckHip(hipMemcpyAsync(devStage, hostStage, total * sizeof(float), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+			ProcessDevice(devStage, devStage, n, (long)n, (long)n);
+			CheckHip(hipMemcpyAsync(hostStage, devStage, total * sizeof(float), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H");
+		}
 		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 		memcpy(out, hostStage, total * sizeof(float));
 		ZeroRetiredRows(out, n);
@@ -1350,13 +1373,7 @@ namespace na
 		EnsurePipeSlot(p, total);
 		p.n = n;
 		if (in) memcpy(p.hostIn, in, total * sizeof(float)); // nullptr: the caller filled NextInput() in place
-		// Direct mode (opt-in, NA_HOST_DIRECT=1): the kernels read the block straight from the pinned host buffer and write their output
-		// straight into the other one (every kernel touches `in` once in its prologue and `out` once in its head): one launch and one
-		// event per buffer instead of two copies, three event records and two cross-stream waits.  Measured on MI355X, 1024 streams x
-		// 128 frames, tools/HostPipeBench: A1 Standard 66.8 us per buffer against 61.9 through the copy engines (the 2 x 512 KB then
-		// cross PCIe inside the kernel, ~10 us each way at the head and the tail of a launch whose workgroups all run in one round),
-		// LSTM 1x16 41.1 against 48.8 with two buffers in flight but 36.3 with three -- hence not the default.
-		static const bool direct = getenv("NA_HOST_DIRECT") != nullptr && atoi(getenv("NA_HOST_DIRECT")) != 0;
+		const bool direct = HostDirect(); // (see ProcessHost)
 		if (direct)
 		{
 			float *dIn = nullptr, *dOut = nullptr;
@@ -1364,6 +1381,7 @@ namespace na
 			CheckHip(hipHostGetDevicePointer(reinterpret_cast<void**>(&dOut), p.hostOut, 0), "hipHostGetDevicePointer");
 			ProcessDevice(dIn, dOut, n, (long)n, (long)n);
 			CheckHip(hipEventRecord(p.downloaded, stream), "hipEventRecord");
+			p.onOwnStream = false;
 			p.busy = true;
 			nextSlot = (nextSlot + 1) % kPipelineSlots;
 			return ticket;
