@@ -1040,8 +1040,12 @@ namespace na
 		// waves of T tiles; n == NF frames.  F = architecture family (the groups of one launch may be different members of it; all members
 		// launch the same number of threads).  Dynamic LDS = the largest Cfg::LDS_BYTES, addressed absolutely from 0 (the kernel has no
 		// static LDS), so every LDS offset of the chain is an instruction immediate.
+		// waves per SIMD the kernel is compiled for: 4 (128 VGPRs) for the full-size workgroups, 2 for the half-size ones (see the launcher)
+#ifndef NA_SPK_OCC
+#define NA_SPK_OCC(spb) ((spb) == 1 ? 2 : 4)
+#endif
 		template <class F, int NF, int SPB, bool PK>
-		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(4))) WaveNetSpecKernel(const LaunchArgs args,
+		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(NA_SPK_OCC(SPB)))) WaveNetSpecKernel(const LaunchArgs args,
 			const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride
 #ifdef NA_SP_TRACE
 			, long long* __restrict__ trace, int traceBlock
@@ -1196,13 +1200,11 @@ namespace na
 		if (arch == WN_SPEC_NONE) return hipErrorNotSupported;
 		auto familyOf = [](int a) { return (a == WN_SPEC_LITE || a == WN_SPEC_LITE16) ? 1 : ((a == WN_SPEC_A2FULL || a == WN_SPEC_A2LITE) ? 2 : 0); };
 		const int fam = familyOf(arch);
-		int total = 0;
 		bool packed = false, lite16 = false;
 		for (int i = 0; i < numGroups; i++)
 		{
 			const int a = groups[i].model->spec_arch;
 			if (groups[i].numStreams <= 0 || a == WN_SPEC_NONE || familyOf(a) != fam || (fam == 0 && a != arch)) return hipErrorNotSupported;
-			total += groups[i].numStreams;
 			packed = packed || groups[i].pack > 1;
 			lite16 = lite16 || a == WN_SPEC_LITE16;
 		}
@@ -1210,8 +1212,23 @@ namespace na
 		if (packed)
 			for (int i = 0; i < numGroups; i++)
 				if (groups[i].slots == nullptr) return hipErrorNotSupported;
+		// Streams per workgroup.  The half-size workgroups (SPB = 1: four waves) are compiled for two waves per SIMD, i.e. with 256 VGPRs
+		// (NA_SPK_OCC): a launch that cannot fill the chip anyway is bound by the latency of its few waves, and the registers let the
+		// compiler keep a layer's LDS reads in flight (Nano x 1024 = 256 packed streams 25.1 -> 22.6 us, Feather x 1024 24.3 -> 22.2,
+		// Standard x 512 25.4 -> 23.4).  They are used while every workgroup is resident at that occupancy: at most two per CU.
 		static const int spbEnv = getenv("NA_SP_SPB") ? atoi(getenv("NA_SP_SPB")) : 0;
-		const int spb = spbEnv > 0 ? spbEnv : (total >= 512 ? 2 : 1);
+		static const int residentHalf = [] {
+			int dev = 0, cus = 0;
+			if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+			return 2 * cus;
+		}();
+		int halfGroups = 0; // workgroups of the launch at SPB = 1 (an A2-Lite workgroup holds two streams there: T = 4)
+		for (int i = 0; i < numGroups; i++)
+		{
+			const int per = groups[i].model->spec_arch == WN_SPEC_A2LITE ? 2 : 1;
+			halfGroups += (groups[i].numStreams + per - 1) / per;
+		}
+		const int spb = spbEnv > 0 ? spbEnv : (halfGroups > residentHalf ? 2 : 1);
 #ifdef NA_SP_QUICK
 		if (arch != WN_SPEC_STD || packed) return hipErrorNotSupported;
 		return spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
