@@ -1110,9 +1110,10 @@ namespace na
 			LaunchArgs args = {};
 			args.numGroups = numGroups;
 			int blocks = 0;
+			static const bool reverse = getenv("NA_SP_REVERSE") != nullptr; // tuning: the groups' workgroups in the opposite dispatch order
 			for (int i = 0; i < numGroups; i++)
 			{
-				const WnFrameGroup& g = groups[i];
+				const WnFrameGroup& g = groups[reverse ? numGroups - 1 - i : i];
 				const WnModelDev& m = *g.model;
 				GroupArgs& a = args.g[i];
 				a.stages = m.sstages; a.wsplit = m.wsplit; a.ringFrames = m.ring_frames;
