@@ -433,7 +433,7 @@ def main():
                                              "Msamples/s": S * BLOCK / hj["us_per_buffer_zero_copy"],
                                              "what": "tools/HostPipeBench (C++ host over the C ABI, its own batch on the same GPU): pinned host buffers in / out "
                                                      "(NA_BatchNextInput + NA_BatchSubmit / NA_BatchCollect + NA_BatchOutputView), 2 buffers in flight, "
-                                                     "%d streams x %d samples: upload, kernels and download overlap" % (S, BLOCK),
+                                                     "%d streams x %d samples: the kernels read and write the pinned host blocks themselves (NA_HOST_DIRECT=0: copy engines)" % (S, BLOCK),
                                              "with_host_copies_ms_per_buffer": hj["us_per_buffer_copying"] * 1e-3,
                                              "blocking_call_latency_us": hj["blocking_latency_us"]}
                 else:
