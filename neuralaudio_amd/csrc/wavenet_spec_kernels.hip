@@ -49,9 +49,22 @@ namespace na
 			static constexpr int T = 2, CHUNK = 10;
 			static constexpr bool COARSE = false; // (dilations are powers of two: at most three wave classes per layer, 53 KB of code)
 			static constexpr bool GUARDHIST = false;
+			static constexpr int SKEW = 0;
 		};
+#ifndef NA_SPK_SKEW
+#define NA_SPK_SKEW 0
+#endif
 		struct ArchStd : ArchA1Base // A1 Standard (16 -> 8)
 		{
+			// Tuning experiment (make KEXTRA=-DNA_SPK_SKEW=5; NOT the default): the two streams of a workgroup run SKEW stages apart
+			// (Cfg::SKEW).  The layers of an array are light (d <= 32: bound by instruction issue) and then heavy (d >= 64: both taps of
+			// every frame come from HBM), and in lock-step every workgroup of the launch is in the same phase -- the memory system idles
+			// through the light layers and the SIMDs through the heavy ones; five stages apart, one stream's heavy layers fall on the other's
+			// light ones.  Measured: 44.3 us against 43.3 in lock-step (profiles/r03_ablation.txt).  The memory system is then loaded all the
+			// time, and the few ring loads of a LIGHT stage -- prefetched one stage ahead, all the 128 VGPRs allow -- come back after
+			// ~1.5 us instead of ~0.5: every slot waits for its light stream (per-slot timeline: both streams done after ~2700 cycles,
+			// barrier released after ~4400).
+			static constexpr int SKEW = NA_SPK_SKEW;
 			static constexpr int NA = 2;
 			static constexpr int CH[2] = { 16, 8 };
 			static constexpr int NLA[2] = { 10, 10 };
@@ -87,6 +100,7 @@ namespace na
 			static constexpr int CHUNK = 16;
 			static constexpr bool COARSE = true;
 			static constexpr bool GUARDHIST = true;
+			static constexpr int SKEW = 0;
 		};
 		struct ArchA2Full : ArchA2Base { static constexpr int CH[2] = { 8, 0 }; static constexpr int T = 2; };
 		struct ArchA2Lite : ArchA2Base { static constexpr int CH[2] = { 4, 0 }; static constexpr int T = 4; };
@@ -186,13 +200,19 @@ namespace na
 			static constexpr int MAXOPS = A_::CHUNK; // operands per LDS weight buffer
 			static_assert(TB::MaxChunkOps() <= MAXOPS, "stage operand chunk");
 			static constexpr int HPF = 5;            // shifted taps whose ring history is prefetched a layer ahead (K = 3: both, K = 6: all five)
+			// stages between the two streams of a workgroup (0: lock-step, one set of weight buffers for the workgroup); skewed streams stage
+			// their own operands with their own waves into their own pair of buffers
+			static constexpr int SKEW = (SPB == 2 && !PK_ && T == 2 && A_::SKEW > 0) ? A_::SKEW : 0;
+			static constexpr int NWB = SKEW > 0 ? SPB : 1;          // weight buffer pairs
+			static constexpr int STG_THREADS = NTHREADS / NWB;      // threads that stage one pair
 			// LDS map (bytes)
-			static constexpr int AUX_OFF = 0;                                   // [SPB][FRAMES] quads, PK: [SPB][4][FRAMES] x 8 bytes
-			static constexpr int IMG_OFF = AUX_OFF + SPB * FRAMES * (PK_ ? 32 : 16); // [SPB][2][planes][PLANE] quads
+			static constexpr bool AUX16 = !PK_ && SKEW == 0;                    // aux entries as whole quads (one LDS read, no unpacking)
+			static constexpr int AUX_OFF = 0;                                   // [SPB][FRAMES] quads; PK: [SPB][4][FRAMES] x 8 bytes; skewed: [SPB][FRAMES] x 8
+			static constexpr int IMG_OFF = AUX_OFF + SPB * FRAMES * (PK_ ? 32 : (AUX16 ? 16 : 8)); // [SPB][2][planes][PLANE] quads
 			static constexpr int IMG_ONE = TB::MaxGP() * PLANE * 16;            // one image: a plane per channel group
-			static constexpr int WBUF_OFF = IMG_OFF + SPB * 2 * IMG_ONE;        // [2][MAXOPS] operands of 1 KB
+			static constexpr int WBUF_OFF = IMG_OFF + SPB * 2 * IMG_ONE;        // [NWB][2][MAXOPS] operands of 1 KB
 			static constexpr int WBUF_ONE = MAXOPS * 1024;
-			static constexpr int IDOP_OFF = WBUF_OFF + 2 * WBUF_ONE;            // identity operand
+			static constexpr int IDOP_OFF = WBUF_OFF + NWB * 2 * WBUF_ONE;      // identity operand
 			static constexpr int DUMP_OFF = IDOP_OFF + 1024;                    // where the LDS-DMA of a wave with nothing to stage lands
 			static constexpr int LDS_BYTES = DUMP_OFF + 1024;
 			static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
@@ -272,6 +292,8 @@ namespace na
 			int wave, sub, waveAll;       // wave within the stream's block, stream within the workgroup (wave-uniform)
 			int lane;
 			int gs0, gs1;                 // packed launches: log2(channel groups per real stream) of array 0 / the other arrays
+			unsigned wbuf;                // LDS byte address of this wave's weight buffer pair (skewed streams: the stream's own)
+			int stgWave;                  // wave index among the waves that stage into that pair
 #ifdef NA_SP_TRACE
 			long long* trace;             // tuning aid (make SUFFIX=_trace EXTRA=-DNA_SP_TRACE, tools/trace_split_timeline.py): nullptr unless this is the traced workgroup
 			int nwaves;
@@ -305,7 +327,7 @@ namespace na
 				img = (unsigned)(C::IMG_OFF + cx.sub * 2 * C::IMG_ONE + (cg * PLANE + GUARD + f) * 16);
 				ring = (unsigned)((fl * GP + cg) * 16);
 				if constexpr (C::PK) aux = (unsigned)(C::AUX_OFF + ((cx.sub * 4 + (cg >> gs)) * FRAMES + f) * 8);
-				else aux = (unsigned)(C::AUX_OFF + (cx.sub * FRAMES + f) * 16);
+				else aux = (unsigned)(C::AUX_OFF + (cx.sub * FRAMES + f) * (C::AUX16 ? 16 : 8));
 			}
 		};
 
@@ -313,12 +335,13 @@ namespace na
 		__device__ __forceinline__ u32x4 AuxRead(const Lanes<C, GP>& ln, int i)
 		{
 			constexpr int P = Geo<GP, C::T>::P;
-			if constexpr (C::PK)
+			// [cond_h, 1 | cond_l, 1 | cond_h, 0 | 0, 0] (see FillSplitAux in wavenet_plan.cpp): the whole quad, or from the 8 bytes kept per frame
+			if constexpr (C::AUX16) return LdsRead16(ln.aux + (unsigned)(16 * P * i * 16));
+			else
 			{
 				const u32x2 v = LdsRead8(ln.aux + (unsigned)(16 * P * i * 8));
 				return u32x4{ v.x, v.y, v.x & 0xffffu, 0u };
 			}
-			else return LdsRead16(ln.aux + (unsigned)(16 * P * i * 16));
 		}
 
 		struct State
@@ -475,7 +498,7 @@ namespace na
 			static constexpr int QUADS = (TB::ChunkEnd(SN, CN) - TB::ChunkBegin(SN, CN)) * 64;
 			static constexpr int SRC = TB::AOff(SN) + TB::ChunkBegin(SN, CN) * 64;
 			static constexpr int BUF = TB::ChunkIndex(SN, CN) & 1;
-			static constexpr int NCOPY = (QUADS + C::NTHREADS - 1) / C::NTHREADS;
+			static constexpr int NCOPY = (QUADS + C::STG_THREADS - 1) / C::STG_THREADS;
 			static __device__ __forceinline__ void Begin(const Ctx& cx)
 			{
 				if (NA_ABL & 16) return;
@@ -484,9 +507,9 @@ namespace na
 				{
 					// operands are 64 quads: a wave's 1 KB slice is one whole operand or lies beyond the block.  An out-of-range LDS-DMA load still
 					// WRITES (zeros), so a wave with nothing to stage aims at the dump slot -- same instruction count on every wave.
-					const int i0 = c * C::NTHREADS + cx.waveAll * 64; // first quad of this wave's slice (wave-uniform)
+					const int i0 = c * C::STG_THREADS + cx.stgWave * 64; // first quad of this wave's slice (wave-uniform)
 					const bool mine = i0 < QUADS;
-					const unsigned dst = mine ? (unsigned)(C::WBUF_OFF + BUF * C::WBUF_ONE) + (unsigned)i0 * 16u : (unsigned)C::DUMP_OFF;
+					const unsigned dst = mine ? cx.wbuf + (unsigned)(BUF * C::WBUF_ONE) + (unsigned)i0 * 16u : (unsigned)C::DUMP_OFF;
 					__builtin_amdgcn_raw_ptr_buffer_load_lds(cx.wrsrc, (__attribute__((address_space(3))) void*)(LdsPtr)(size_t)dst, 16,
 						mine ? (SRC + i0 + cx.lane) * 16 : OOB, 0, 0, 0);
 				}
@@ -513,7 +536,7 @@ namespace na
 		__device__ __forceinline__ u32x4 WOp(const Ctx& cx, int s, int c, int m)
 		{
 			const int buf = C::TB::ChunkIndex(s, c) & 1, local = m - C::TB::ChunkBegin(s, c);
-			return LdsRead16((unsigned)(C::WBUF_OFF + buf * C::WBUF_ONE + ((NA_ABL & 128) ? 0 : local) * 1024) + (unsigned)cx.lane * 16u);
+			return LdsRead16(cx.wbuf + (unsigned)(buf * C::WBUF_ONE + ((NA_ABL & 128) ? 0 : local) * 1024) + (unsigned)cx.lane * 16u);
 		}
 
 		__device__ __forceinline__ f32x4 ActivateTanh(f32x4 a)
@@ -961,6 +984,8 @@ namespace na
 			cx.wrsrc = MakeRsrc(ga.wsplit, (unsigned)ga.wsplitQuads * 16u);
 			cx.myPos = header[lane];
 			cx.wave = wave; cx.sub = sub; cx.waveAll = waveAll; cx.lane = lane;
+			cx.wbuf = (unsigned)(C::WBUF_OFF + (C::SKEW > 0 ? sub : 0) * 2 * C::WBUF_ONE);
+			cx.stgWave = C::SKEW > 0 ? wave : waveAll;
 #ifdef NA_SP_TRACE
 			cx.trace = trace;
 			cx.nwaves = C::NTHREADS / 64;
@@ -998,11 +1023,15 @@ namespace na
 			{
 				for (int i = wave * 64 + lane; i < FRAMES; i += C::WPS * 64)
 				{
-					// [cond_h, 1 | cond_l, 1 | cond_h, 0 | 0, 0] (see FillSplitAux in wavenet_plan.cpp)
+					// [cond_h, 1 | cond_l, 1 | cond_h, 0 | 0, 0] (see FillSplitAux in wavenet_plan.cpp; 8-byte entries: AuxRead rebuilds the second half)
 					const float c = (i < NF) ? ClampCond(in[(size_t)row * inStride + i], ga.condLimit) : 0.0f;
 					const _Float16 ch = (_Float16)c, cl = (_Float16)(c - (float)ch);
 					const f16x2 a = { ch, (_Float16)1.0f }, b = { cl, (_Float16)1.0f }, d = { ch, (_Float16)0.0f };
-					LdsWrite16((unsigned)(C::AUX_OFF + (sub * FRAMES + i) * 16), u32x4{ __builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, d), 0u });
+					if constexpr (C::AUX16)
+						LdsWrite16((unsigned)(C::AUX_OFF + (sub * FRAMES + i) * 16), u32x4{ __builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, d), 0u });
+					else
+						*reinterpret_cast<__attribute__((address_space(3))) u32x2*>((LdsPtr)(size_t)(unsigned)(C::AUX_OFF + (sub * FRAMES + i) * 8)) =
+							u32x2{ __builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b) };
 				}
 			}
 			// zero quad in front of frame 0 of every plane of both block images
@@ -1015,13 +1044,24 @@ namespace na
 				const unsigned lo = (q == (i >> 2)) ? (((i & 3) == 0) ? one : ((i & 3) == 1) ? (one << 16) : 0u) : 0u;
 				const unsigned hi = (q == (i >> 2)) ? (((i & 3) == 2) ? one : ((i & 3) == 3) ? (one << 16) : 0u) : 0u;
 				LdsWrite16((unsigned)C::IDOP_OFF + (unsigned)lane * 16u, u32x4{ lo, hi, lo, hi });
-				// stage 0's single operand (offset 0 of every weight image)
-				LdsWrite16((unsigned)C::WBUF_OFF + (unsigned)lane * 16u, BufLoad(cx.wrsrc, lane * 16));
 			}
+			// stage 0's single operand (offset 0 of every weight image), into every pair of weight buffers
+			if (cx.stgWave == 0) LdsWrite16(cx.wbuf + (unsigned)lane * 16u, BufLoad(cx.wrsrc, lane * 16));
 			BlockBarrier<C::NTHREADS / 64>();
 
+			// skewed streams: stream 1 starts SKEW stages (= barriers) after stream 0 and ends as many after it
+			if constexpr (C::SKEW > 0)
+			{
+				if (sub != 0)
+					for (int k = 0; k < C::SKEW; k++) BlockBarrier<C::NTHREADS / 64>();
+			}
 			State st;
 			RunArrays<C, 0>(cx, st, out, (size_t)row * outStride, outRow, pack, ga.headScale, live);
+			if constexpr (C::SKEW > 0)
+			{
+				if (sub == 0)
+					for (int k = 0; k < C::SKEW; k++) BlockBarrier<C::NTHREADS / 64>();
+			}
 
 #ifdef NA_SP_TRACE
 			if (cx.trace != nullptr && lane == 0) cx.trace[((C::TB::NSTAGES * 8 + 1) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
