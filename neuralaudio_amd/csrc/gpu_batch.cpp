@@ -1325,12 +1325,10 @@ namespace na
 		const size_t total = streams.size() * n;
 		EnsureStaging(total);
 		memcpy(hostStage, in, total * sizeof(float));
-		if (HostDirect())
-		{
-			float* dStage = nullptr;
-			CheckHip(hipHostGetDevicePointer(reinterpret_cast<void**>(&dStage), hostStage, 0), "hipHostGetDevicePointer");
+		float* dStage = nullptr;
+		// (a pinned block the device cannot address -- not seen on MI355X -- goes through the copy engines instead of failing)
+		if (HostDirect() && hipHostGetDevicePointer(reinterpret_cast<void**>(&dStage), hostStage, 0) == hipSuccess && dStage != nullptr)
 			ProcessDevice(dStage, dStage, n, (long)n, (long)n);
-		}
 		else
 		{
 			CheckHip(hipMemcpyAsync(devStage, hostStage, total * sizeof(float), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
@@ -1374,11 +1372,10 @@ namespace na
 		p.n = n;
 		if (in) memcpy(p.hostIn, in, total * sizeof(float)); // nullptr: the caller filled NextInput() in place
 		const bool direct = HostDirect(); // (see ProcessHost)
-		if (direct)
+		float *dIn = nullptr, *dOut = nullptr;
+		if (direct && hipHostGetDevicePointer(reinterpret_cast<void**>(&dIn), p.hostIn, 0) == hipSuccess && dIn != nullptr &&
+			hipHostGetDevicePointer(reinterpret_cast<void**>(&dOut), p.hostOut, 0) == hipSuccess && dOut != nullptr)
 		{
-			float *dIn = nullptr, *dOut = nullptr;
-			CheckHip(hipHostGetDevicePointer(reinterpret_cast<void**>(&dIn), p.hostIn, 0), "hipHostGetDevicePointer");
-			CheckHip(hipHostGetDevicePointer(reinterpret_cast<void**>(&dOut), p.hostOut, 0), "hipHostGetDevicePointer");
 			ProcessDevice(dIn, dOut, n, (long)n, (long)n);
 			CheckHip(hipEventRecord(p.downloaded, stream), "hipEventRecord");
 			p.onOwnStream = false;
