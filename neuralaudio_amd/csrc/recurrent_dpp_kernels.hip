@@ -990,7 +990,117 @@ namespace na
 		}
 	}
 
-	// grid = sum over the groups of ceil(streams / 4), block = 64 (four streams per wave); groups: LSTM, L layers, hidden <= 16.
+	// One keras GRU layer of up to 16 units (reset_after form, RTNeural GRULayer; see GruDppCell) on the same four-streams-per-wave layout:
+	// the z and r rows of a unit as one packed pair, the recurrent sum of the candidate row as (even terms, odd terms) against the
+	// (h[k], h[k + 1]) pairs the LDS read-back delivers anyway.  ~50 instructions per sample for four streams (one-stream layout: ~45 per
+	// stream).  sigmoid / tanh on the exp2 / rcp units like every GRU kernel here (StdSigmoid, StdTanh).
+	__device__ __forceinline__ void GruQuadBody(const RecurrentGroupArgs& ga, int idx0, const float* __restrict__ in, float* __restrict__ out, long inStride,
+		long outStride, int n, float* lds)
+	{
+		constexpr int H = 16, HP = QUAD_HP;
+		const LstmModelDev& m = ga.m;
+		float* __restrict__ state = ga.state;
+		const int capacity = ga.capacity;
+		const int lane = threadIdx.x, unit = lane & 15, sub = lane >> 4;
+		const int hr = m.hidden;
+		const bool real = unit < hr;
+		const bool live = idx0 + sub < ga.numStreams;
+		const int idx = live ? idx0 + sub : ga.numStreams - 1;
+		const int slot = ga.slots ? ga.slots[idx] : ga.slot0 + idx;
+		const int row = ga.slots ? ga.rows[idx] : ga.row0 + idx;
+
+		// W row-major [3 hr][1 + hr] (rows z | r | c), b_in[3 hr], b_rec[3 hr]
+		const float* w0 = m.w + m.layerOff[0];
+		const int W0 = 1 + hr;
+		const size_t bIn = (size_t)3 * hr * W0, bRec = bIn + (size_t)3 * hr;
+		const int rz = unit, rr = hr + unit, rc = 2 * hr + unit;
+		const quad_f2 wxZR = quad_f2{ LoadIf(w0, (size_t)rz * W0, real), LoadIf(w0, (size_t)rr * W0, real) };
+		const quad_f2 bZR = quad_f2{ LoadIf(w0, bIn + rz, real) + LoadIf(w0, bRec + rz, real), LoadIf(w0, bIn + rr, real) + LoadIf(w0, bRec + rr, real) };
+		const float wxC = LoadIf(w0, (size_t)rc * W0, real), biC = LoadIf(w0, bIn + rc, real), bhC = LoadIf(w0, bRec + rc, real);
+		quad_f2 whZR[H], whC[H / 2];
+#pragma unroll
+		for (int k = 0; k < H; k++) whZR[k] = quad_f2{ LoadIf(w0, (size_t)rz * W0 + 1 + k, real && k < hr), LoadIf(w0, (size_t)rr * W0 + 1 + k, real && k < hr) };
+#pragma unroll
+		for (int k = 0; k < H / 2; k++)
+			whC[k] = quad_f2{ LoadIf(w0, (size_t)rc * W0 + 1 + 2 * k, real && 2 * k < hr), LoadIf(w0, (size_t)rc * W0 + 2 + 2 * k, real && 2 * k + 1 < hr) };
+
+		float* xin = lds;
+		float* hout = lds + 4 * QUAD_XROW;
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			const float* inRow = in + (size_t)__builtin_amdgcn_readlane(row, 16 * s) * inStride;
+			for (int f = lane; f < n + 4; f += 64) xin[s * QUAD_XROW + f] = f < n ? inRow[f] : 0.0f;
+		}
+		float h = LoadIf(state, (size_t)unit * capacity + slot, real);
+		float* hw = hout + sub * QUAD_HROW + unit;
+		const float* hrd = hout + sub * QUAD_HROW;
+		hw[0] = h;
+		RecurrentWaveSync();
+
+		quad_f2 hv[H / 2]; // (h[2k], h[2k + 1]) of this lane's stream
+		auto read16 = [&](const float* p) {
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+			{
+				const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+				hv[2 * q] = quad_f2{ t.x, t.y };
+				hv[2 * q + 1] = quad_f2{ t.z, t.w };
+			}
+		};
+		read16(hrd);
+		auto step = [&](float x, int e) {
+			quad_f2 aZR = QuadFma(wxZR, QuadSplat(x), bZR);
+			quad_f2 aC = quad_f2{ bhC, 0.0f };
+#pragma unroll
+			for (int k = 0; k < H / 2; k++)
+			{
+				aZR = QuadFma(whZR[2 * k], QuadSplat(hv[k].x), aZR);
+				aZR = QuadFma(whZR[2 * k + 1], QuadSplat(hv[k].y), aZR);
+				aC = QuadFma(whC[k], hv[k], aC);
+			}
+			const quad_f2 e2 = aZR * QuadSplat(-1.4426950408889634f);
+			const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(e2.x)), r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(e2.y));
+			const float c = StdTanh(__builtin_fmaf(r, aC.x + aC.y, __builtin_fmaf(wxC, x, biC)));
+			h = __builtin_fmaf(z, h - c, c); // (1 - z) c + z h
+			hw[(e + 1) * HP] = h;
+			RecurrentWaveSync();
+			read16(hrd + (e + 1) * HP);
+		};
+
+		const float* xs = xin + sub * QUAD_XROW;
+		const float* headW = m.w + m.headOff;
+		for (int f0 = 0; f0 < n; f0 += QUAD_CHUNK)
+		{
+			const int cn = min(QUAD_CHUNK, n - f0);
+			int f = 0;
+			for (; f + 4 <= cn; f += 4)
+			{
+				const float4 xv = *reinterpret_cast<const float4*>(xs + f0 + f);
+				step(xv.x, f + 0);
+				step(xv.y, f + 1);
+				step(xv.z, f + 2);
+				step(xv.w, f + 3);
+			}
+			for (; f < cn; f++) step(xs[f0 + f], f);
+			{
+				const int s = lane / QUAD_CHUNK, ff = lane % QUAD_CHUNK;
+				const float* hs = hout + s * QUAD_HROW + (ff + 1) * HP;
+				float acc = 0.0f;
+#pragma unroll
+				for (int k = 0; k < H; k++) acc += LoadIf(headW, (size_t)k, k < hr) * hs[k];
+				const int orow = __builtin_amdgcn_ds_bpermute(4 * (16 * s), row);
+				if (ff < cn && idx0 + s < ga.numStreams) out[(size_t)orow * outStride + f0 + ff] = acc + headW[hr];
+			}
+			RecurrentWaveSync();
+			hw[0] = h;
+			RecurrentWaveSync();
+			read16(hrd); // (the same values: keeps the entry the next chunk starts from and the registers in one place)
+		}
+		if (real && live) state[(size_t)unit * capacity + slot] = h;
+	}
+
+	// grid = sum over the groups of ceil(streams / 4), block = 64 (four streams per wave); groups: LSTM (L layers) or keras GRU (one layer), hidden <= 16.
 	// One kernel per layer count: the weights of the gate rows live in registers (L = 1: ~100 VGPRs, four to five waves per SIMD; L = 2:
 	// 256, two waves) and a common kernel would run every model at the occupancy of the largest.
 	template <int L>
@@ -1003,7 +1113,8 @@ namespace na
 			if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
 		const RecurrentGroupArgs& ga = args.g[gi];
 		const int idx0 = 4 * ((int)blockIdx.x - ga.firstBlock);
-		if (ga.m.math == LSTM_MATH_STD) LstmQuadBody<L, true>(ga, idx0, in, out, inStride, outStride, n, lds);
+		if (L == 1 && ga.m.cell == LSTM_CELL_GRU) GruQuadBody(ga, idx0, in, out, inStride, outStride, n, lds);
+		else if (ga.m.math == LSTM_MATH_STD) LstmQuadBody<L, true>(ga, idx0, in, out, inStride, outStride, n, lds);
 		else LstmQuadBody<L, false>(ga, idx0, in, out, inStride, outStride, n, lds);
 	}
 
@@ -1011,7 +1122,7 @@ namespace na
 	{
 		// One layer.  (Two layers were measured: the second layer's 128 weight registers per lane leave one wave per SIMD and the layout
 		// loses to the one-stream kernel -- 2x16 x 8192: 199 vs 205 us, 2x8: 174 vs 95 us.  The body keeps the L = 2 code for reference.)
-		return m.tailLayers == 0 && m.cell == LSTM_CELL_LSTM && m.hidden >= 1 && m.hidden <= 16 && m.numLayers == 1;
+		return m.tailLayers == 0 && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU) && m.hidden >= 1 && m.hidden <= 16 && m.numLayers == 1;
 	}
 
 	// streams in one launch from which the four-streams-per-wave layout is used (0: never); NA_REC_QUAD_MIN, tests: SetRecurrentQuadMinStreams

@@ -116,3 +116,31 @@ def test_two_layer_models_stay_on_the_one_stream_layout(na, quad):
     y = b.Process(x)
     assert quad.NA_DebugRecurrentQuadLaunches() == before
     assert O.rms(y[8] - O.oracle_from_file("BossLSTM-2x8.nam").process(x[8])) < 5e-6
+
+
+@pytest.mark.parametrize("hidden", [16, 12, 7, 1])
+def test_quad_kernel_runs_keras_gru_layers(na, quad, hidden):
+    """One keras GRU layer + dense(1) head (RTNeural semantics: parity unpinned) on the four-streams-per-wave layout."""
+    import json
+    gj = O.synth_keras_gru(1, hidden, seed=40 + hidden)
+    m = na.NeuralModelLoader().CreateFromString(json.dumps(gj), ".json", doPrewarm=True)
+    S, sizes = 3077, [128, 61, 128, 2, 200]
+    x = _inputs(S, sum(sizes))
+
+    def run(min_streams):
+        quad.NA_DebugSetRecurrentQuadMin(min_streams)
+        b = na.Batch(0)
+        b.AddStreams(m, S)
+        out, pos = [], 0
+        for n in sizes:
+            out.append(b.Process(np.ascontiguousarray(x[:, pos:pos + n])))
+            pos += n
+        return np.concatenate(out, axis=1)
+
+    before = quad.NA_DebugRecurrentQuadLaunches()
+    yq = run(3072)
+    assert quad.NA_DebugRecurrentQuadLaunches() - before >= len(sizes)
+    y1 = run(0)
+    assert np.max(np.abs(yq - y1)) < 3e-6
+    for s in (0, 3, 1700, S - 2, S - 1):
+        assert O.rms(yq[s] - O.OracleGRU(gj).process(x[s])) < 5e-6, s

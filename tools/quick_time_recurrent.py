@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """us per 128-sample step of a recurrent model at several batch sizes, on both lane layouts of the LDS-free kernel:
-tools/quick_time_recurrent.py [model file under tests/golden/models | lstm:<layers>:<hidden>] [stream counts ...]"""
+tools/quick_time_recurrent.py [model file under tests/golden/models | lstm:<layers>:<hidden> | gru:<layers>:<hidden>] [stream counts ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,7 +12,12 @@ name = sys.argv[1] if len(sys.argv) > 1 else "BossLSTM-1x16.nam"
 counts = [int(v) for v in sys.argv[2:]] or [1024, 2048, 4096, 8192, 16384]
 lib = capi.load_library()
 dev = torch.device("cuda", 0)
-if name.startswith("lstm:"):
+if name.startswith("gru:"):
+    import json
+    import na_oracle as O
+    _, layers, hidden = name.split(":")
+    m = na.NeuralModelLoader().CreateFromString(json.dumps(O.synth_keras_gru(int(layers), int(hidden), seed=3)), ".json", doPrewarm=False)
+elif name.startswith("lstm:"):
     import na_oracle as O
     _, layers, hidden = name.split(":")
     m = na.NeuralModelLoader().CreateFromString(O.nam_json_lstm(int(layers), int(hidden), O.synth_lstm_weights(int(layers), int(hidden), seed=3)), ".nam", doPrewarm=False)
