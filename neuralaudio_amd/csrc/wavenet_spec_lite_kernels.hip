@@ -1,0 +1,20 @@
+// wavenet_spec_lite_kernels.hip -- the specialised chains of the "lite" dilation lists (A1 Lite padded to 16 / 8 channels; two Feather or
+// four Nano streams packed into one virtual stream): kernels of FamLite and FamLitePacked.  See wavenet_spec_kernels.hip.
+#include "wavenet_spec_impl.h"
+
+namespace na
+{
+	namespace spk
+	{
+		hipError_t LaunchSpecLite(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, bool packed,
+			hipStream_t stream)
+		{
+#ifdef NA_SP_QUICK
+			return hipErrorNotSupported;
+#else
+			if (packed) return LaunchNF<FamLitePacked, true>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
+			return LaunchNF<FamLite, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
+#endif
+		}
+	}
+}
