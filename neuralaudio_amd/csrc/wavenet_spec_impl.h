@@ -529,9 +529,14 @@ namespace na
 			return LdsRead16(cx.wbuf + (unsigned)(buf * C::WBUF_ONE + ((NA_ABL & 128) ? 0 : local) * 1024) + (unsigned)cx.lane * 16u);
 		}
 
+		// PACKED: two values per v_pk_* instruction (half the instructions -- what a launch of few waves wants, every instruction costs a
+		// lone wave its ~5 cycles); unpacked: plain VALU instructions, which issue beside the MFMAs of the SIMD's other waves where packed
+		// f32 math does not -- what the full-size workgroups want at four waves per SIMD (A1 Standard 41.8 -> 40.9 us,
+		// Lite 35.0 -> 34.5; Nano x 1024 on the half-size workgroups 23.4 -> 23.5 the other way).  Same expression tree, same results.
+		template <bool PACKED>
 		__device__ __forceinline__ f32x4 ActivateTanh(f32x4 a)
 		{
-			if (NA_PK_TANH)
+			if (PACKED)
 			{
 				const f32x2 lo = FastTanh2(f32x2{ a.x, a.y }), hi = FastTanh2(f32x2{ a.z, a.w });
 				return f32x4{ lo.x, lo.y, hi.x, hi.y };
@@ -651,7 +656,7 @@ namespace na
 				for (int i = 0; i < S; i++)
 				{
 					if constexpr (C::A::LEAKY) z[i] = f32x4{ LeakyReLU(acc[i].x), LeakyReLU(acc[i].y), LeakyReLU(acc[i].z), LeakyReLU(acc[i].w) };
-					else z[i] = ActivateTanh(acc[i]);
+					else z[i] = ActivateTanh<(NA_PK_TANH != 0) && (C::NTHREADS < 512)>(acc[i]);
 				}
 				SPK_STAMP(s, 2);
 				const u32x4 idop = LdsRead16((unsigned)C::IDOP_OFF + (unsigned)cx.lane * 16u);
