@@ -794,7 +794,8 @@ namespace na
 				// (four streams per wave from RecurrentQuadMinStreams() streams in ONE launch: a batch of several recurrent models decides on
 				// their total, this name on the group's own count)
 				if (RecurrentDppSupported(dev))
-					return (RecurrentQuadSupported(dev) && RecurrentQuadMinStreams() > 0 && (int)hSlots.size() >= RecurrentQuadMinStreams()) ? "RecurrentQuadKernel" : "RecurrentDppKernel";
+					return (RecurrentQuadSupported(dev) && RecurrentQuadMinStreams() > 0 &&
+						(int)hSlots.size() >= (dev.cell == LSTM_CELL_GRU ? RecurrentQuadMinStreams() * 2 / 3 : RecurrentQuadMinStreams())) ? "RecurrentQuadKernel" : "RecurrentDppKernel";
 				return dev.cell == LSTM_CELL_GRU ? "GruWaveKernel / RecurrentWaveRtKernel / GruGenericKernel" : "LstmWaveKernel / RecurrentWaveRtKernel / LstmBlockKernel / LstmGenericKernel";
 			}
 

@@ -1245,7 +1245,12 @@ namespace na
 			blocks += groups[i].numStreams;
 		}
 		// a batch with more waves than the chip can hold at three per SIMD: four streams per wave (all groups must have the layout)
-		bool quad = RecurrentQuadMinStreams() > 0 && blocks >= RecurrentQuadMinStreams();
+		// (the GRU body is the shorter one: a lone wave of it takes 27 us per block against 37 for the LSTM body, and it overtakes the
+		// one-stream layout from ~2000 streams instead of ~2800 -- a launch of GRUs only switches at two thirds of the stream count)
+		bool allGru = true;
+		for (int i = 0; i < numGroups; i++) allGru = allGru && groups[i].model.cell == LSTM_CELL_GRU;
+		const int quadMin = allGru ? RecurrentQuadMinStreams() * 2 / 3 : RecurrentQuadMinStreams();
+		bool quad = RecurrentQuadMinStreams() > 0 && blocks >= quadMin;
 		for (int i = 0; i < numGroups; i++) quad = quad && RecurrentQuadSupported(groups[i].model) && groups[i].model.numLayers == groups[0].model.numLayers;
 		if (quad)
 		{
