@@ -758,7 +758,7 @@ namespace na
 	constexpr int QUAD_XROW = LSTM_MAX_FRAMES + 4;      // input samples of one stream in LDS (+4: the float4 reads may run past the block)
 	constexpr int QUAD_HP = 20;                         // floats per h entry: 16 units + padding (16-byte aligned rows, spread over the banks)
 	constexpr int QUAD_HROW = (QUAD_CHUNK + 1) * QUAD_HP; // output-layer h of one stream: the state before the chunk, then after each of its samples
-	constexpr int QUAD_LDS_FLOATS = 4 * QUAD_XROW + 4 * QUAD_HROW + 4 * QUAD_HP; // + the layer-0 h of two-layer models
+	constexpr int QUAD_LDS_FLOATS = 4 * QUAD_XROW + 4 * QUAD_HROW;
 
 	__device__ __forceinline__ quad_f2 QuadFma(quad_f2 a, quad_f2 b, quad_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 	__device__ __forceinline__ quad_f2 QuadSplat(float v) { return quad_f2{ v, v }; }
@@ -811,7 +811,7 @@ namespace na
 		}
 	}
 
-	template <int L, bool STD>
+	template <bool STD>
 	__device__ __forceinline__ void LstmQuadBody(const RecurrentGroupArgs& ga, int idx0, const float* __restrict__ in, float* __restrict__ out, long inStride,
 		long outStride, int n, float* lds)
 	{
@@ -845,49 +845,20 @@ namespace na
 			wh0IF[k] = pairOf(w0, W0, 1 + k, real && k < hr, 0, sS, 1, sS);
 			wh0GO[k] = pairOf(w0, W0, 1 + k, real && k < hr, 2, sT, 3, sS);
 		}
-		// layer 1: W [4 hr][hr + hr]: input = layer-0 h, then own h
-		constexpr int H1 = L > 1 ? H : 1;
-		quad_f2 wi1IF[H1], wi1GO[H1], wh1IF[H1], wh1GO[H1], b1IF = QuadSplat(0.0f), b1GO = QuadSplat(0.0f);
-		if constexpr (L > 1)
-		{
-			const float* w1 = m.w + m.layerOff[1];
-			const int W1 = 2 * hr;
-#pragma unroll
-			for (int k = 0; k < H; k++)
-			{
-				const bool on = real && k < hr;
-				wi1IF[k] = pairOf(w1, W1, k, on, 0, sS, 1, sS);
-				wi1GO[k] = pairOf(w1, W1, k, on, 2, sT, 3, sS);
-				wh1IF[k] = pairOf(w1, W1, hr + k, on, 0, sS, 1, sS);
-				wh1GO[k] = pairOf(w1, W1, hr + k, on, 2, sT, 3, sS);
-			}
-			b1IF = quad_f2{ sS * LoadIf(w1, (size_t)4 * hr * W1 + 0 * hr + unit, real), sS * LoadIf(w1, (size_t)4 * hr * W1 + 1 * hr + unit, real) };
-			b1GO = quad_f2{ sT * LoadIf(w1, (size_t)4 * hr * W1 + 2 * hr + unit, real), sS * LoadIf(w1, (size_t)4 * hr * W1 + 3 * hr + unit, real) };
-		}
-
-		// LDS: the input block of the four streams [stream][QUAD_XROW]; the output layer's h [stream][entry][HP]; layer-0 h of two-layer models
+		// LDS: the input block of the four streams [stream][QUAD_XROW]; their h [stream][entry][HP]
 		float* xin = lds;
 		float* hout = lds + 4 * QUAD_XROW;
-		float* h0buf = hout + 4 * QUAD_HROW;
 #pragma unroll
 		for (int s = 0; s < 4; s++)
 		{
 			const float* inRow = in + (size_t)__builtin_amdgcn_readlane(row, 16 * s) * inStride;
 			for (int f = lane; f < n + 4; f += 64) xin[s * QUAD_XROW + f] = f < n ? inRow[f] : 0.0f;
 		}
-		float h[L], c[L];
-#pragma unroll
-		for (int l = 0; l < L; l++)
-		{
-			h[l] = LoadIf(state, (size_t)(l * 2 * hr + unit) * capacity + slot, real);
-			c[l] = LoadIf(state, (size_t)(l * 2 * hr + hr + unit) * capacity + slot, real);
-		}
-		float* hw = hout + sub * QUAD_HROW + unit;        // this lane's word of an entry of the output layer's h
+		float h = LoadIf(state, (size_t)unit * capacity + slot, real);
+		float c = LoadIf(state, (size_t)(hr + unit) * capacity + slot, real);
+		float* hw = hout + sub * QUAD_HROW + unit;        // this lane's word of an entry of h
 		const float* hrd = hout + sub * QUAD_HROW;        // the 16 values of an entry
-		float* h0w = h0buf + sub * HP + unit;
-		const float* h0rd = h0buf + sub * HP;
-		hw[0] = h[L - 1];
-		if constexpr (L > 1) *h0w = h[0];
+		hw[0] = h;
 		RecurrentWaveSync();
 
 		auto read16 = [&](const float* p, float (&v)[H]) {
@@ -906,9 +877,9 @@ namespace na
 			cc = __builtin_fmaf(gIF.y, cc, gIF.x * gGO.x);
 			return gGO.y * (STD ? StdTanh(cc) : LstmRcpTanh(cc));
 		};
-		float hv0[H]; // h of layer 0, all units of this lane's stream
-		read16(L > 1 ? h0rd : hrd, hv0);
-		// one sample: entry e of hout = the output layer's h after sample e - 1 of the chunk
+		float hv0[H]; // h, all units of this lane's stream
+		read16(hrd, hv0);
+		// one sample: entry e of hout = h after sample e - 1 of the chunk
 		auto step = [&](float x, int e) {
 			quad_f2 aIF = QuadFma(wxIF, QuadSplat(x), b0IF), aGO = QuadFma(wxGO, QuadSplat(x), b0GO); // LSTM.h:168 -- column 0 is the input sample
 #pragma unroll
@@ -917,37 +888,10 @@ namespace na
 				aIF = QuadFma(wh0IF[k], QuadSplat(hv0[k]), aIF);
 				aGO = QuadFma(wh0GO[k], QuadSplat(hv0[k]), aGO);
 			}
-			h[0] = cell(aIF, aGO, c[0]);
-			if constexpr (L == 1)
-			{
-				hw[(e + 1) * HP] = h[0];
-				RecurrentWaveSync();
-				read16(hrd + (e + 1) * HP, hv0);
-			}
-			else
-			{
-				*h0w = h[0];
-				float hv1[H];
-				read16(hrd + e * HP, hv1);
-				RecurrentWaveSync();
-				read16(h0rd, hv0);
-				quad_f2 bIF = b1IF, bGO = b1GO; // LSTM.h:170-180
-#pragma unroll
-				for (int k = 0; k < H; k++)
-				{
-					bIF = QuadFma(wi1IF[k], QuadSplat(hv0[k]), bIF);
-					bGO = QuadFma(wi1GO[k], QuadSplat(hv0[k]), bGO);
-				}
-#pragma unroll
-				for (int k = 0; k < H; k++)
-				{
-					bIF = QuadFma(wh1IF[k], QuadSplat(hv1[k]), bIF);
-					bGO = QuadFma(wh1GO[k], QuadSplat(hv1[k]), bGO);
-				}
-				h[1] = cell(bIF, bGO, c[1]);
-				hw[(e + 1) * HP] = h[1];
-				RecurrentWaveSync();
-			}
+			h = cell(aIF, aGO, c);
+			hw[(e + 1) * HP] = h;
+			RecurrentWaveSync();
+			read16(hrd + (e + 1) * HP, hv0);
 		};
 
 		const float* xs = xin + sub * QUAD_XROW;
@@ -976,17 +920,13 @@ namespace na
 				if (ff < cn && idx0 + s < ga.numStreams) out[(size_t)orow * outStride + f0 + ff] = acc + headW[hr];
 			}
 			RecurrentWaveSync();
-			hw[0] = h[L - 1]; // entry 0 of the next chunk
+			hw[0] = h; // entry 0 of the next chunk
 			RecurrentWaveSync();
 		}
 		if (real && live)
 		{
-#pragma unroll
-			for (int l = 0; l < L; l++)
-			{
-				state[(size_t)(l * 2 * hr + unit) * capacity + slot] = h[l];
-				state[(size_t)(l * 2 * hr + hr + unit) * capacity + slot] = c[l];
-			}
+			state[(size_t)unit * capacity + slot] = h;
+			state[(size_t)(hr + unit) * capacity + slot] = c;
 		}
 	}
 
@@ -1100,11 +1040,9 @@ namespace na
 		if (real && live) state[(size_t)unit * capacity + slot] = h;
 	}
 
-	// grid = sum over the groups of ceil(streams / 4), block = 64 (four streams per wave); groups: LSTM (L layers) or keras GRU (one layer), hidden <= 16.
-	// One kernel per layer count: the weights of the gate rows live in registers (L = 1: ~100 VGPRs, four to five waves per SIMD; L = 2:
-	// 256, two waves) and a common kernel would run every model at the occupancy of the largest.
-	template <int L>
-	__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L == 1 ? 3 : 1))) RecurrentQuadKernel(const RecurrentLaunchArgs args,
+	// grid = sum over the groups of ceil(streams / 4), block = 64 (four streams per wave); groups: one-layer LSTM or keras GRU, hidden <= 16.
+	// (The gate weights live in registers: ~150 VGPRs, three waves per SIMD.)
+	__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) RecurrentQuadKernel(const RecurrentLaunchArgs args,
 		const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n)
 	{
 		__shared__ __attribute__((aligned(16))) float lds[QUAD_LDS_FLOATS];
@@ -1113,15 +1051,15 @@ namespace na
 			if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
 		const RecurrentGroupArgs& ga = args.g[gi];
 		const int idx0 = 4 * ((int)blockIdx.x - ga.firstBlock);
-		if (L == 1 && ga.m.cell == LSTM_CELL_GRU) GruQuadBody(ga, idx0, in, out, inStride, outStride, n, lds);
-		else if (ga.m.math == LSTM_MATH_STD) LstmQuadBody<L, true>(ga, idx0, in, out, inStride, outStride, n, lds);
-		else LstmQuadBody<L, false>(ga, idx0, in, out, inStride, outStride, n, lds);
+		if (ga.m.cell == LSTM_CELL_GRU) GruQuadBody(ga, idx0, in, out, inStride, outStride, n, lds);
+		else if (ga.m.math == LSTM_MATH_STD) LstmQuadBody<true>(ga, idx0, in, out, inStride, outStride, n, lds);
+		else LstmQuadBody<false>(ga, idx0, in, out, inStride, outStride, n, lds);
 	}
 
 	bool RecurrentQuadSupported(const LstmModelDev& m)
 	{
-		// One layer.  (Two layers were measured: the second layer's 128 weight registers per lane leave one wave per SIMD and the layout
-		// loses to the one-stream kernel -- 2x16 x 8192: 199 vs 205 us, 2x8: 174 vs 95 us.  The body keeps the L = 2 code for reference.)
+		// One layer.  (Two layers were built and measured: the second layer's 128 weight registers per lane leave one wave per SIMD and the
+		// layout loses to the one-stream kernel -- 2x16 x 8192: 199 vs 205 us, 2x8: 174 vs 95 us.)
 		return m.tailLayers == 0 && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU) && m.hidden >= 1 && m.hidden <= 16 && m.numLayers == 1;
 	}
 
@@ -1251,7 +1189,7 @@ namespace na
 		for (int i = 0; i < numGroups; i++) allGru = allGru && groups[i].model.cell == LSTM_CELL_GRU;
 		const int quadMin = allGru ? RecurrentQuadMinStreams() * 2 / 3 : RecurrentQuadMinStreams();
 		bool quad = RecurrentQuadMinStreams() > 0 && blocks >= quadMin;
-		for (int i = 0; i < numGroups; i++) quad = quad && RecurrentQuadSupported(groups[i].model) && groups[i].model.numLayers == groups[0].model.numLayers;
+		for (int i = 0; i < numGroups; i++) quad = quad && RecurrentQuadSupported(groups[i].model);
 		if (quad)
 		{
 			blocks = 0;
@@ -1261,7 +1199,7 @@ namespace na
 				blocks += (groups[i].numStreams + 3) / 4;
 			}
 			gQuadLaunches.fetch_add(1, std::memory_order_relaxed);
-			hipLaunchKernelGGL(RecurrentQuadKernel<1>, dim3((unsigned)blocks), dim3(64), 0, stream, args, in, out, inStride, outStride, n);
+			hipLaunchKernelGGL(RecurrentQuadKernel, dim3((unsigned)blocks), dim3(64), 0, stream, args, in, out, inStride, outStride, n);
 			return hipGetLastError();
 		}
 		bool any32 = false;
