@@ -1075,12 +1075,13 @@ namespace na
 		// waves of T tiles; n == NF frames.  F = architecture family (the groups of one launch may be different members of it; all members
 		// launch the same number of threads).  Dynamic LDS = the largest Cfg::LDS_BYTES, addressed absolutely from 0 (the kernel has no
 		// static LDS), so every LDS offset of the chain is an instruction immediate.
-		// waves per SIMD the kernel is compiled for: 4 (128 VGPRs) for the full-size workgroups, 2 for the half-size ones (see the launcher)
+		// waves per SIMD the kernel is compiled for = what two resident workgroups per CU put on a SIMD: 2 NF SPB threads per workgroup -> 4
+		// for the full-size workgroups (128 VGPRs), 2 for the half-size ones and for 64-frame blocks (256 VGPRs), 1 below (see the launcher)
 #ifndef NA_SPK_OCC
-#define NA_SPK_OCC(spb) ((spb) == 1 ? 2 : 4)
+#define NA_SPK_OCC(nf, spb) (((nf) * (spb) / 64) < 1 ? 1 : ((nf) * (spb) / 64))
 #endif
 		template <class F, int NF, int SPB, bool PK>
-		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(NA_SPK_OCC(SPB)))) WaveNetSpecKernel(const LaunchArgs args,
+		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(NA_SPK_OCC(NF, SPB)))) WaveNetSpecKernel(const LaunchArgs args,
 			const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride
 #ifdef NA_SP_TRACE
 			, long long* __restrict__ trace, int traceBlock
