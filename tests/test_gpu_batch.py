@@ -174,7 +174,7 @@ def test_one_launch_serves_every_recurrent_layout(na, loader):
     x = np.stack([O.signal_noise(n * blocks, 700 + s) for s in range(len(oracles))])
     y = _run_blocks(b, x, n)
     for s in range(len(oracles)):
-        if not os.environ.get("NA_REC_NO_DPP32") and not os.environ.get("NA_LSTM_NO_DPP") and not os.environ.get("NA_LSTM_LANE_KERNEL"):
+        if not os.environ.get("NA_REC_NO_DPP32") and not os.environ.get("NA_LSTM_NO_DPP") and not os.environ.get("NA_LSTM_LANE_KERNEL") and not os.environ.get("NA_REC_QUAD_MIN"):
             assert b.StreamKernelName(s) == "RecurrentDppKernel"
         assert O.rms(y[s] - oracles[s]().process(x[s])) < 5e-6, (s, specs)
 

@@ -187,7 +187,10 @@ def test_default_kernel_family_and_pack_factor_of_every_official_architecture(na
         b = na.Batch(0)
         b.AddStreams(m, streams, doPrewarm=False)
         got = (b.StreamKernelName(0), b.StreamPackFactor(0))
-        assert got == expect[name], (name, streams, got)
+        want = expect[name]
+        if name == "lstm1x16" and streams >= 3072:
+            want = ("RecurrentQuadKernel", 1)  # one-layer LSTMs in launches of thousands of streams: four streams per wave
+        assert got == want, (name, streams, got)
         assert (b.StreamKernelName(streams - 1), b.StreamPackFactor(streams - 1)) == got
         b.close()
 
