@@ -372,6 +372,22 @@ namespace na
 				dWpk.Upload(plan.wpk, stream);
 				dPrewarm.Upload(plan.prewarm, stream);
 				dWeights.Upload(plan.isVirtual() ? plan.packedWeights : d->wavenet.weights, stream);
+				if (family == WN_FAMILY_GENERIC)
+				{
+					// the runtime-shaped kernel reads a layer conv tap by tap as a [cout x cin] matrix: its copy of the weights keeps every
+					// layer conv tap-major ([k][out][in] instead of the reference's [out][in][k], WaveNet.h:99-111), so that a lane's four
+					// input channels are one 16-byte load and a row is contiguous
+					std::vector<float> wg = d->wavenet.weights;
+					for (const WnPrewarmLayer& pw : plan.prewarm)
+					{
+						if (pw.kind != 0 || pw.ksize <= 1) continue;
+						const size_t base = (size_t)pw.wconv, K = (size_t)pw.ksize, CO = (size_t)pw.cout, CI = (size_t)pw.cin;
+						for (size_t o = 0; o < CO; o++)
+							for (size_t c = 0; c < CI; c++)
+								for (size_t k = 0; k < K; k++) wg[base + (k * CO + o) * CI + c] = d->wavenet.weights[base + (o * CI + c) * K + k];
+					}
+					dWeightsGen.Upload(wg, stream);
+				}
 				dSStages.Upload(plan.sstages, stream);
 				dWsplit.Upload(plan.wsplit, stream);
 
@@ -504,7 +520,7 @@ namespace na
 						CheckHip(LaunchWaveNetSplitFused(&g, 1, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "WaveNetSplitKernel");
 					}
 					else if (which == WN_FAMILY_GENERIC)
-						CheckHip(LaunchWaveNetGeneric(dPrewarm.Get(), (int)plan.prewarm.size(), dWeights.Get(), dRingOff.Get(), dRingFrames.Get(), dRingG.Get(),
+						CheckHip(LaunchWaveNetGeneric(dPrewarm.Get(), (int)plan.prewarm.size(), dWeightsGen.Get(), dRingOff.Get(), dRingFrames.Get(), dRingG.Get(),
 							(int)plan.rings.size(), plan.stateF4, plan.maxChannels, plan.headScale, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive,
 							contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "WaveNetGenericKernel");
 					else
@@ -627,6 +643,7 @@ namespace na
 			DevArray<float> dWpk;
 			DevArray<WnPrewarmLayer> dPrewarm;
 			DevArray<float> dWeights;
+			DevArray<float> dWeightsGen; // WN_FAMILY_GENERIC: layer convs tap-major
 			DevArray<int> dRingOff, dRingFrames, dRingG;
 			DevArray<float> dCols;
 			DevArray<WnSplitStage> dSStages;

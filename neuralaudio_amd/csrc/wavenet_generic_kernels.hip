@@ -70,23 +70,81 @@ namespace na
 			int slot0, row0;
 		};
 
-		// W[o][c] = w[off + (o * cin + c) * stride + k]  (conv tap k: stride = K; dense: stride = 1, k = 0) -> the A operands of the
-		// [cout x cin] matrix: operand (rb, kb, hi | lo), lane (i = row 16 rb + i, q = channels 16 kb + 4 q .. + 3).  Split once, here.
-		__device__ __forceinline__ void StageMatrix(u32x4* ops, const float* __restrict__ w, int off, int stride, int k, int cout, int cin, int nbo, int nbk)
+		// W[o][c] = w[off + o * cin + c] -> the A operands of the [cout x cin] matrix: operand (rb, kb, hi | lo), lane (i = row 16 rb + i, q = channels 16 kb + 4 q .. + 3).  Split once per
+		// workgroup.  Two halves so that the weights of the NEXT mat-mul travel (global -> registers: StageLoad) while the current one
+		// runs, and are split and written to LDS (StageCommit) once its operands are free: a layer is 4 .. K + 1 dependent mat-muls, and
+		// with the load in front of each of them 30 % of the kernel was weight-load latency (64 / 32 channels: 306 -> 213 us without loads).
+		// workgroup barrier that orders LDS traffic only: the weight loads of the next mat-mul (StageLoad) stay in flight across it --
+		// __syncthreads() would wait for them.  (No thread of the block reads global memory another one wrote in this launch: ring
+		// stores are history for LATER blocks.)
+		__device__ __forceinline__ void LdsBarrier()
 		{
-			for (int idx = threadIdx.x; idx < nbo * nbk * 64; idx += NTHREADS)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+			__builtin_amdgcn_s_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+		}
+		// a row-major [cout x cin] matrix at w[off] (the weight copy of this kernel keeps layer convs tap-major: tap k of a conv at wconv
+		// is the matrix at wconv + k cout cin; gpu_batch.cpp)
+		struct MatRef
+		{
+			int off, cout, cin, nbo, nbk;
+		};
+		typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4))); // a 16-byte load from a 4-byte aligned address
+		template <int NB>
+		struct StagedRegs
+		{
+			static constexpr int ITEMS = (NB * NB * 64 + NTHREADS - 1) / NTHREADS;
+			sp::f32x4 v[ITEMS];
+		};
+		template <int NB>
+		__device__ __forceinline__ void StageLoad(StagedRegs<NB>& r, const float* __restrict__ w, const MatRef& m)
+		{
+#pragma unroll
+			for (int it = 0; it < StagedRegs<NB>::ITEMS; it++)
 			{
-				const int lane = idx & 63, blk = idx >> 6, rb = blk / nbk, kb = blk % nbk;
+				const int idx = threadIdx.x + it * NTHREADS;
+				const int lane = idx & 63, blk = idx >> 6, rb = blk / m.nbk, kb = blk % m.nbk;
 				const int o = 16 * rb + (lane & 15), c0 = 16 * kb + 4 * (lane >> 4);
-				sp::f32x4 v;
-				v.x = (o < cout && c0 + 0 < cin) ? w[off + ((size_t)o * cin + c0 + 0) * stride + k] : 0.0f;
-				v.y = (o < cout && c0 + 1 < cin) ? w[off + ((size_t)o * cin + c0 + 1) * stride + k] : 0.0f;
-				v.z = (o < cout && c0 + 2 < cin) ? w[off + ((size_t)o * cin + c0 + 2) * stride + k] : 0.0f;
-				v.w = (o < cout && c0 + 3 < cin) ? w[off + ((size_t)o * cin + c0 + 3) * stride + k] : 0.0f;
-				const u32x4 s = sp::SplitQuad(v);                       // [h01 | h23 | l01 | l23]
-				ops[(blk * 2 + 0) * 64 + lane] = u32x4{ s.x, s.y, s.x, s.y }; // Wh against the h AND the l half of the operand
-				ops[(blk * 2 + 1) * 64 + lane] = u32x4{ s.z, s.w, 0u, 0u };   // Wl against the h half
+				const bool on = idx < m.nbo * m.nbk * 64 && o < m.cout;
+				const float* p = w + m.off + (size_t)o * m.cin + c0;
+				sp::f32x4 v = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+				if (on && c0 + 3 < m.cin)
+				{
+					const f32x4u t = *reinterpret_cast<const f32x4u*>(p);
+					v = sp::f32x4{ t.x, t.y, t.z, t.w };
+				}
+				else if (on)
+				{
+					v.x = (c0 + 0 < m.cin) ? p[0] : 0.0f;
+					v.y = (c0 + 1 < m.cin) ? p[1] : 0.0f;
+					v.z = (c0 + 2 < m.cin) ? p[2] : 0.0f;
+				}
+				r.v[it] = v;
 			}
+		}
+		template <int NB>
+		__device__ __forceinline__ void StageCommit(u32x4* ops, const StagedRegs<NB>& r, const MatRef& m)
+		{
+#pragma unroll
+			for (int it = 0; it < StagedRegs<NB>::ITEMS; it++)
+			{
+				const int idx = threadIdx.x + it * NTHREADS;
+				if (idx < m.nbo * m.nbk * 64)
+				{
+					const int lane = idx & 63, blk = idx >> 6;
+					const u32x4 s = sp::SplitQuad(r.v[it]);                     // [h01 | h23 | l01 | l23]
+					ops[(blk * 2 + 0) * 64 + lane] = u32x4{ s.x, s.y, s.x, s.y }; // Wh against the h AND the l half of the operand
+					ops[(blk * 2 + 1) * 64 + lane] = u32x4{ s.z, s.w, 0u, 0u };   // Wl against the h half
+				}
+			}
+		}
+		template <int NB>
+		__device__ __forceinline__ void StageMatrix(u32x4* ops, const float* __restrict__ w, int off, int cout, int cin, int nbo, int nbk)
+		{
+			const MatRef m = { off, cout, cin, nbo, nbk };
+			StagedRegs<NB> r;
+			StageLoad<NB>(r, w, m);
+			StageCommit<NB>(ops, r, m);
 		}
 
 		// acc[rb] += M[16 rb .. + 16][all k blocks] * b[kb]   (b[kb] = split quad of channels 16 kb + 4 q .. of the lane's frame)
@@ -149,6 +207,8 @@ namespace na
 			const float cond = condL[tf];
 
 			const float* __restrict__ w = a.w;
+			StagedRegs<NB> pre;   // weights of the next mat-mul, under way while the current one runs
+			bool havePre = false; // (workgroup-uniform)
 			for (int li = 0; li < a.numLayers; li++)
 			{
 				const WnPrewarmLayer L = a.layers[li];
@@ -171,7 +231,7 @@ namespace na
 						{
 							const int nbk = (L.rech_in + 15) / 16, Gin = (L.rech_in + 3) / 4;
 							__syncthreads(); // the operand buffer is free (the previous array's head mat-mul is done everywhere)
-							StageMatrix(ops, w, L.rechannel, 1, 0, cin, L.rech_in, nb, nbk);
+							StageMatrix<NB>(ops, w, L.rechannel, cin, L.rech_in, nb, nbk);
 							u32x4 b[NB];
 #pragma unroll
 							for (int kb = 0; kb < NB; kb++)
@@ -204,8 +264,10 @@ namespace na
 					for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 					for (int k = 0; k < K; k++)
 					{
-						if (k > 0) __syncthreads(); // the previous tap's operands and gathered inputs are no longer read
-						StageMatrix(ops, w, L.wconv, K, k, cin, cin, nb, nb);
+						if (k > 0) LdsBarrier(); // the previous tap's operands and gathered inputs are no longer read
+						const MatRef mk = { L.wconv + k * cin * cin, cin, cin, nb, nb };
+						if (!havePre) StageLoad<NB>(pre, w, mk); // (the first tap behind a rechannel / head stage: nothing was under way)
+						StageCommit<NB>(ops, pre, mk);
 						const int off = f - L.dilation * (K - 1 - k); // tap k reads the frame d (K-1-k) back
 						if (off >= 0)
 							for (int g = cq; g < Gl; g += 4) T[g * FRAMES + f] = X[g * FRAMES + off];
@@ -215,7 +277,12 @@ namespace na
 							if (p < 0) p += R;
 							for (int g = cq; g < Gl; g += 4) T[g * FRAMES + f] = stq[RingQuad(roff, G, p, g)];
 						}
-						__syncthreads();
+						// the next mat-mul's weights set out now (behind the gather's ring loads: memory operations return in order, and the
+						// gather's must not queue behind them): the next tap's, or the 1x1's behind the last tap
+						const MatRef mn = (k + 1 < K) ? MatRef{ L.wconv + (k + 1) * cin * cin, cin, cin, nb, nb } : MatRef{ L.w1, cin, cin, nb, nb };
+						StageLoad<NB>(pre, w, mn);
+						havePre = true;
+						LdsBarrier();
 						u32x4 b[NB];
 #pragma unroll
 						for (int kb = 0; kb < NB; kb++) b[kb] = (kb < nb && 4 * kb + q < Gl) ? sp::SplitQuad(T[(4 * kb + q) * FRAMES + tf]) : u32x4{ 0, 0, 0, 0 };
@@ -241,10 +308,22 @@ namespace na
 							zs[rb] = sp::SplitQuad(sp::f32x4{ zv.x, zv.y, zv.z, zv.w });
 						}
 					}
-					__syncthreads(); // every wave is done with the last tap's operands
+					LdsBarrier(); // every wave is done with the last tap's operands
 					// 1x1 + bias + residual (:486-491); the last layer's output feeds the next array's rechannel (or nothing)
-					StageMatrix(ops, w, L.w1, 1, 0, cin, cin, nb, nb);
-					__syncthreads();
+					StageCommit<NB>(ops, pre, MatRef{ L.w1, cin, cin, nb, nb });
+					havePre = false;
+					if (li + 1 < a.numLayers)
+					{
+						// the first tap of the next layer, when nothing else is staged in between (same array: no rechannel, no head)
+						const WnPrewarmLayer N = a.layers[li + 1];
+						if (N.kind == 0 && N.rechannel < 0)
+						{
+							const int nbn = (N.cin + 15) / 16;
+							StageLoad<NB>(pre, w, MatRef{ N.wconv, N.cin, N.cin, nbn, nbn });
+							havePre = true;
+						}
+					}
+					LdsBarrier();
 #pragma unroll
 					for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 					MatMul<NB>(ops, nb, nb, lane, zs, acc);
@@ -313,7 +392,7 @@ namespace na
 					}
 					else
 					{
-						StageMatrix(ops, w, L.wconv, 1, 0, L.cout, L.cin, nbo, nbk);
+						StageMatrix<NB>(ops, w, L.wconv, L.cout, L.cin, nbo, nbk);
 						u32x4 b[NB];
 #pragma unroll
 						for (int kb = 0; kb < NB; kb++)
