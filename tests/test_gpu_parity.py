@@ -277,7 +277,7 @@ def test_large_recurrent_models_run_in_real_time(na, loader):
         for _ in range(10):
             b.Process(x)
         per_block = (time.perf_counter() - t0) / 10
-        assert per_block < 2e-3, per_block
+        assert per_block < 2.5e-3, per_block  # the block lasts 2.667 ms at 48 kHz (measured: 1.5 ms for the 2x64 LSTM, 2.0 for 1x128)
         b.close()
 
 
