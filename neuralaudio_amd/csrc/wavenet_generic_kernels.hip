@@ -216,6 +216,18 @@ namespace na
 				{
 					const int cin = L.cin; // == cout
 					const int Gl = (cin + 3) / 4, nb = (cin + 15) / 16;
+					// the layer's bias / mix-in vectors for the rows this lane will hold, loaded now: they are used behind the mat-muls, and a load
+					// issued there is a memory round trip on the critical path of every layer
+					f32x4 bcv[NB], wmv[NB], b1v[NB];
+#pragma unroll
+					for (int rb = 0; rb < NB; rb++)
+					{
+						const int g = 4 * rb + q;
+						const bool on = rb < nb && g < Gl;
+						bcv[rb] = on ? Load4(w, L.bconv, 4 * g, cin) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+						wmv[rb] = on ? Load4(w, L.wmix, 4 * g, cin) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+						b1v[rb] = on ? Load4(w, L.b1, 4 * g, cin) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+					}
 					if (L.rechannel >= 0)
 					{
 						// rechannel (:637): array 0 from the condition (input_size == 1), later arrays from the previous array's output (in X)
@@ -298,7 +310,7 @@ namespace na
 						const int g = 4 * rb + q;
 						if (rb < nb && g < Gl)
 						{
-							const f32x4 bc = Load4(w, L.bconv, 4 * g, cin), wm = Load4(w, L.wmix, 4 * g, cin);
+							const f32x4 bc = bcv[rb], wm = wmv[rb];
 							f32x4 zv;
 							zv.x = (4 * g + 0 < cin) ? Activate(acc[rb].x + bc.x + wm.x * cond, L.act) : 0.0f;
 							zv.y = (4 * g + 1 < cin) ? Activate(acc[rb].y + bc.y + wm.y * cond, L.act) : 0.0f;
@@ -333,7 +345,7 @@ namespace na
 						const int g = 4 * rb + q;
 						if (rb < nb && g < Gl)
 						{
-							const f32x4 b1 = Load4(w, L.b1, 4 * g, cin);
+							const f32x4 b1 = b1v[rb];
 							X[g * FRAMES + tf] += f32x4{ acc[rb].x + b1.x, acc[rb].y + b1.y, acc[rb].z + b1.z, acc[rb].w + b1.w };
 						}
 					}
