@@ -12,11 +12,11 @@
 //   workgroup = one stream = 512 threads = 8 waves; wave w owns the 16-frame tile w of the 128-frame block for the mat-muls
 //   (lane = (frame j, channel group q): result registers = 4 channels of the lane's own frame); for gathers and ring traffic thread
 //   (f = tid & 127, cq = tid >> 7) moves the channel groups g = cq, cq + 4, ... of frame f;
-//   LDS: X[G][128] layer input, T[G][128] the tap being gathered, HEAD[G][128] head accumulator -- float4 per (4-channel group,
+//   LDS: X[G][128] layer input, HEAD[G][128] head accumulator -- float4 per (4-channel group,
 //   frame) -- and the A operands of ONE matrix, split to f16 hi / lo ONCE per workgroup while they are staged ([row block][k block][hi,
 //   lo][64 lanes] x 16 bytes);
-//   a layer = publish X to its ring -> per tap: stage the tap's matrix, gather the tap's input (LDS for in-block frames, the layer's HBM
-//   ring for earlier ones), MFMA into register accumulators -> bias + mix-in + activation + head accumulate in the result lanes (the
+//   a layer = publish X to its ring, load the ring history its taps need -> per tap: stage the tap's matrix, read the tap's input where
+//   the mat-mul wants it (X for in-block frames, the prefetched ring history for earlier ones), MFMA into register accumulators -> bias + mix-in + activation + head accumulate in the result lanes (the
 //   activation's split quad IS the 1x1's B operand: no LDS round trip) -> stage the 1x1 -> MFMA -> residual into X.
 #include <algorithm>
 #include <cstdlib>
@@ -183,8 +183,7 @@ namespace na
 			extern __shared__ __attribute__((aligned(16))) float lds[];
 			const int GQ = (a.maxC + 3) / 4;                          // channel groups of the widest array
 			f32x4* X = reinterpret_cast<f32x4*>(lds);                 // [GQ][FRAMES]
-			f32x4* T = X + (size_t)GQ * FRAMES;
-			f32x4* HEAD = T + (size_t)GQ * FRAMES;
+			f32x4* HEAD = X + (size_t)GQ * FRAMES;
 			u32x4* ops = reinterpret_cast<u32x4*>(HEAD + (size_t)GQ * FRAMES); // [NB * NB][2][64]
 			float* condL = reinterpret_cast<float*>(ops + NB * NB * 2 * 64);  // [FRAMES]
 			const int tid = threadIdx.x;
@@ -274,31 +273,60 @@ namespace na
 					sp::f32x4 acc[NB];
 #pragma unroll
 					for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
-					for (int k = 0; k < K; k++)
+					// A tap's B operand is the layer input `shift` frames back, read where the mat-mul wants it (lane = frame of the wave's tile,
+					// channel group 4 kb + q): from X inside the block, from the ring before it.  The ring part of up to three taps (K <= 3: every
+					// A1-shaped model) is loaded HERE, ahead of the whole tap loop, so that its HBM round trip runs behind the first mat-muls.
+					auto histOf = [&](int k, f32x4 (&h)[NB]) {
+						const int src = tf - L.dilation * (K - 1 - k);
+						int p = pos0 + src; // src >= -(R - FRAMES): one wrap
+						if (p < 0) p += R;
+#pragma unroll
+						for (int kb = 0; kb < NB; kb++)
+						{
+							const int g = 4 * kb + q;
+							h[kb] = (src < 0 && kb < nb && g < Gl) ? stq[RingQuad(roff, G, p, g)] : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+						}
+					};
+					f32x4 hist0[NB], hist1[NB], hist2[NB];
+					if (K <= 3)
 					{
-						if (k > 0) LdsBarrier(); // the previous tap's operands and gathered inputs are no longer read
+						histOf(0, hist0);
+						if (K > 1) histOf(1, hist1);
+						if (K > 2) histOf(2, hist2);
+					}
+					auto tap = [&](int k, const f32x4 (&h)[NB]) {
+						if (k > 0) LdsBarrier(); // the previous tap's operands are no longer read
 						const MatRef mk = { L.wconv + k * cin * cin, cin, cin, nb, nb };
 						if (!havePre) StageLoad<NB>(pre, w, mk); // (the first tap behind a rechannel / head stage: nothing was under way)
 						StageCommit<NB>(ops, pre, mk);
-						const int off = f - L.dilation * (K - 1 - k); // tap k reads the frame d (K-1-k) back
-						if (off >= 0)
-							for (int g = cq; g < Gl; g += 4) T[g * FRAMES + f] = X[g * FRAMES + off];
-						else
-						{
-							int p = pos0 + off; // off >= -(R - FRAMES): one wrap
-							if (p < 0) p += R;
-							for (int g = cq; g < Gl; g += 4) T[g * FRAMES + f] = stq[RingQuad(roff, G, p, g)];
-						}
-						// the next mat-mul's weights set out now (behind the gather's ring loads: memory operations return in order, and the
-						// gather's must not queue behind them): the next tap's, or the 1x1's behind the last tap
+						// the next mat-mul's weights set out now: the next tap's, or the 1x1's behind the last tap
 						const MatRef mn = (k + 1 < K) ? MatRef{ L.wconv + (k + 1) * cin * cin, cin, cin, nb, nb } : MatRef{ L.w1, cin, cin, nb, nb };
 						StageLoad<NB>(pre, w, mn);
 						havePre = true;
 						LdsBarrier();
+						const int src = tf - L.dilation * (K - 1 - k); // tap k reads the frame d (K-1-k) back
 						u32x4 b[NB];
 #pragma unroll
-						for (int kb = 0; kb < NB; kb++) b[kb] = (kb < nb && 4 * kb + q < Gl) ? sp::SplitQuad(T[(4 * kb + q) * FRAMES + tf]) : u32x4{ 0, 0, 0, 0 };
+						for (int kb = 0; kb < NB; kb++)
+						{
+							const int g = 4 * kb + q;
+							b[kb] = (kb < nb && g < Gl) ? sp::SplitQuad(src >= 0 ? X[g * FRAMES + src] : h[kb]) : u32x4{ 0, 0, 0, 0 };
+						}
 						MatMul<NB>(ops, nb, nb, lane, b, acc);
+					};
+					if (K <= 3)
+					{
+						tap(0, hist0);
+						if (K > 1) tap(1, hist1);
+						if (K > 2) tap(2, hist2);
+					}
+					else
+					{
+						for (int k = 0; k < K; k++)
+						{
+							histOf(k, hist0);
+							tap(k, hist0);
+						}
 					}
 					// bias + mix-in (:288-289, :471), activation (:473-480), head accumulate (:482) -- in the lanes that hold the results; the
 					// activation's split quad is the 1x1's B operand (result rows 16 rb + 4 q .. of the lane's frame = k block rb, group q)
@@ -476,10 +504,10 @@ namespace na
 		a.rows = rows;
 		a.slot0 = slot0;
 		a.row0 = row0;
-		// LDS: three [G][128] float4 arrays + the split A operands of one matrix ([nb x nb][hi, lo][64] x 16 B) + the condition row
-		// (64 channels: 96 + 32 KB, 32 channels: 48 + 8 KB -> two workgroups per CU)
+		// LDS: two [G][128] float4 arrays + the split A operands of one matrix ([nb x nb][hi, lo][64] x 16 B) + the condition row
+		// (64 channels: 64 + 32 KB, 48 channels: 48 + 18 KB -> two workgroups per CU, 32 channels: 32 + 8 KB -> three)
 		const int nb = (maxChannels + 15) / 16, gq = (maxChannels + 3) / 4;
-		const size_t ldsBytes = (size_t)3 * gq * gn::FRAMES * 16 + (size_t)nb * nb * 2 * 64 * 16 + gn::FRAMES * sizeof(float);
+		const size_t ldsBytes = (size_t)2 * gq * gn::FRAMES * 16 + (size_t)nb * nb * 2 * 64 * 16 + gn::FRAMES * sizeof(float);
 		static bool attrSet = false;
 		if (!attrSet)
 		{
