@@ -184,8 +184,12 @@ namespace na
 			const int GQ = (a.maxC + 3) / 4;                          // channel groups of the widest array
 			f32x4* X = reinterpret_cast<f32x4*>(lds);                 // [GQ][FRAMES]
 			f32x4* HEAD = X + (size_t)GQ * FRAMES;
-			u32x4* ops = reinterpret_cast<u32x4*>(HEAD + (size_t)GQ * FRAMES); // [NB * NB][2][64]
-			float* condL = reinterpret_cast<float*>(ops + NB * NB * 2 * 64);  // [FRAMES]
+			// two operand buffers, used in turn by consecutive mat-muls: a matrix is committed into the one the mat-mul before the last read,
+			// and the barrier between every commit and its mat-mul is the only one the operands need
+			constexpr int OPS_ONE = NB * NB * 2 * 64;
+			u32x4* ops0 = reinterpret_cast<u32x4*>(HEAD + (size_t)GQ * FRAMES); // [2][NB * NB][2][64]
+			float* condL = reinterpret_cast<float*>(ops0 + 2 * OPS_ONE);      // [FRAMES]
+			int par = 0; // mat-muls so far (workgroup-uniform)
 			const int tid = threadIdx.x;
 			const int f = tid & (FRAMES - 1), cq = tid >> 7;          // gather / ring role
 			const int lane = tid & 63, wave = tid >> 6;               // mat-mul role: tile = wave
@@ -242,6 +246,7 @@ namespace na
 						{
 							const int nbk = (L.rech_in + 15) / 16, Gin = (L.rech_in + 3) / 4;
 							__syncthreads(); // the operand buffer is free (the previous array's head mat-mul is done everywhere)
+							u32x4* ops = ops0 + (par++ & 1) * OPS_ONE;
 							StageMatrix<NB>(ops, w, L.rechannel, cin, L.rech_in, nb, nbk);
 							u32x4 b[NB];
 #pragma unroll
@@ -295,7 +300,7 @@ namespace na
 						if (K > 2) histOf(2, hist2);
 					}
 					auto tap = [&](int k, const f32x4 (&h)[NB]) {
-						if (k > 0) LdsBarrier(); // the previous tap's operands are no longer read
+						u32x4* ops = ops0 + (par++ & 1) * OPS_ONE;
 						const MatRef mk = { L.wconv + k * cin * cin, cin, cin, nb, nb };
 						if (!havePre) StageLoad<NB>(pre, w, mk); // (the first tap behind a rechannel / head stage: nothing was under way)
 						StageCommit<NB>(ops, pre, mk);
@@ -348,8 +353,8 @@ namespace na
 							zs[rb] = sp::SplitQuad(sp::f32x4{ zv.x, zv.y, zv.z, zv.w });
 						}
 					}
-					LdsBarrier(); // every wave is done with the last tap's operands
 					// 1x1 + bias + residual (:486-491); the last layer's output feeds the next array's rechannel (or nothing)
+					u32x4* ops = ops0 + (par++ & 1) * OPS_ONE;
 					StageCommit<NB>(ops, pre, MatRef{ L.w1, cin, cin, nb, nb });
 					havePre = false;
 					if (li + 1 < a.numLayers)
@@ -432,6 +437,7 @@ namespace na
 					}
 					else
 					{
+						u32x4* ops = ops0 + (par++ & 1) * OPS_ONE;
 						StageMatrix<NB>(ops, w, L.wconv, L.cout, L.cin, nbo, nbk);
 						u32x4 b[NB];
 #pragma unroll
@@ -504,10 +510,10 @@ namespace na
 		a.rows = rows;
 		a.slot0 = slot0;
 		a.row0 = row0;
-		// LDS: two [G][128] float4 arrays + the split A operands of one matrix ([nb x nb][hi, lo][64] x 16 B) + the condition row
-		// (64 channels: 64 + 32 KB, 48 channels: 48 + 18 KB -> two workgroups per CU, 32 channels: 32 + 8 KB -> three)
+		// LDS: two [G][128] float4 arrays + the split A operands of two matrices ([nb x nb][hi, lo][64] x 16 B each) + the condition row
+		// (64 channels: 64 + 64 KB, 48 channels: 48 + 36 KB, 32 channels: 32 + 16 KB -> three workgroups per CU)
 		const int nb = (maxChannels + 15) / 16, gq = (maxChannels + 3) / 4;
-		const size_t ldsBytes = (size_t)2 * gq * gn::FRAMES * 16 + (size_t)nb * nb * 2 * 64 * 16 + gn::FRAMES * sizeof(float);
+		const size_t ldsBytes = (size_t)2 * gq * gn::FRAMES * 16 + (size_t)2 * nb * nb * 2 * 64 * 16 + gn::FRAMES * sizeof(float);
 		static bool attrSet = false;
 		if (!attrSet)
 		{
