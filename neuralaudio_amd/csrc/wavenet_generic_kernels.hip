@@ -176,8 +176,11 @@ namespace na
 			return v;
 		}
 
-		template <int NB>
-		__global__ void __launch_bounds__(NTHREADS) WaveNetGenericKernel(const Args a, const float* __restrict__ in, float* __restrict__ out, long inStride,
+		// OCC = waves per SIMD the kernel is compiled for.  2 (256 VGPRs) is the faster code for one workgroup per CU; models of up to 32
+		// channels fit two workgroups into a CU's LDS, and a batch with more streams than CUs wants the 128-VGPR build (4) so that two
+		// ARE resident (32 / 16 channels: 256 streams 107 vs 122 us, 512 streams 208 vs 157, 1024 streams 423 vs 308).
+		template <int NB, int OCC>
+		__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC))) WaveNetGenericKernel(const Args a, const float* __restrict__ in, float* __restrict__ out, long inStride,
 			long outStride, int n)
 		{
 			extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -514,20 +517,24 @@ namespace na
 		// (64 channels: 64 + 64 KB, 48 channels: 48 + 36 KB, 32 channels: 32 + 16 KB -> three workgroups per CU)
 		const int nb = (maxChannels + 15) / 16, gq = (maxChannels + 3) / 4;
 		const size_t ldsBytes = (size_t)2 * gq * gn::FRAMES * 16 + (size_t)2 * nb * nb * 2 * 64 * 16 + gn::FRAMES * sizeof(float);
-		static bool attrSet = false;
-		if (!attrSet)
+		static int numCUs = 0;
+		if (numCUs == 0)
 		{
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			attrSet = true;
+			int dev = 0;
+			if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || numCUs <= 0) numCUs = 256;
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		}
 		// NB = 16-channel blocks per matrix side
-		if (nb <= 1) hipLaunchKernelGGL(gn::WaveNetGenericKernel<1>, dim3((unsigned)numStreams), dim3(gn::NTHREADS), ldsBytes, stream, a, in, out, inStride, outStride, n);
-		else if (nb == 2) hipLaunchKernelGGL(gn::WaveNetGenericKernel<2>, dim3((unsigned)numStreams), dim3(gn::NTHREADS), ldsBytes, stream, a, in, out, inStride, outStride, n);
-		else if (nb == 3) hipLaunchKernelGGL(gn::WaveNetGenericKernel<3>, dim3((unsigned)numStreams), dim3(gn::NTHREADS), ldsBytes, stream, a, in, out, inStride, outStride, n);
-		else hipLaunchKernelGGL(gn::WaveNetGenericKernel<4>, dim3((unsigned)numStreams), dim3(gn::NTHREADS), ldsBytes, stream, a, in, out, inStride, outStride, n);
+		const dim3 grid((unsigned)numStreams), block(gn::NTHREADS);
+		if (nb <= 1) hipLaunchKernelGGL((gn::WaveNetGenericKernel<1, 4>), grid, block, ldsBytes, stream, a, in, out, inStride, outStride, n);
+		else if (nb == 2 && numStreams > numCUs) hipLaunchKernelGGL((gn::WaveNetGenericKernel<2, 4>), grid, block, ldsBytes, stream, a, in, out, inStride, outStride, n);
+		else if (nb == 2) hipLaunchKernelGGL((gn::WaveNetGenericKernel<2, 2>), grid, block, ldsBytes, stream, a, in, out, inStride, outStride, n);
+		else if (nb == 3) hipLaunchKernelGGL((gn::WaveNetGenericKernel<3, 2>), grid, block, ldsBytes, stream, a, in, out, inStride, outStride, n);
+		else hipLaunchKernelGGL((gn::WaveNetGenericKernel<4, 2>), grid, block, ldsBytes, stream, a, in, out, inStride, outStride, n);
 		return hipGetLastError();
 	}
 }
