@@ -435,7 +435,9 @@ def main():
                                                      "(NA_BatchNextInput + NA_BatchSubmit / NA_BatchCollect + NA_BatchOutputView), 2 buffers in flight, "
                                                      "%d streams x %d samples: the kernels read and write the pinned host blocks themselves (NA_HOST_DIRECT=0: copy engines)" % (S, BLOCK),
                                              "with_host_copies_ms_per_buffer": hj["us_per_buffer_copying"] * 1e-3,
-                                             "blocking_call_latency_us": hj["blocking_latency_us"]}
+                                             "blocking_call_latency_us": hj["blocking_latency_us"],
+                                             "blocking_call_on_registered_blocks_us": hj.get("registered_blocking_latency_us"),
+                                             "submit_collect_in_place_us": hj.get("in_place_latency_us")}
                 else:
                     out["pcie_inclusive"] = {"ms_per_buffer": None, "what": "HostPipeBench failed: " + r.stderr.strip()[-300:]}
         if world == 1 and not args.no_cpu_baseline and args.workload not in ("config4", "config5"):

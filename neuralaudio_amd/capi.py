@@ -25,7 +25,7 @@ NA_SYMBOLS = [
     "NA_GetModelVersion", "NA_BatchCreate", "NA_BatchDestroy", "NA_BatchAddStreams", "NA_BatchNumStreams",
     "NA_BatchSetQuality", "NA_BatchGetActiveSubModel", "NA_BatchPrewarm", "NA_BatchProcess", "NA_BatchProcessDevice",
     "NA_BatchSynchronize", "NA_BatchGetHipStream", "NA_BatchAlgorithmicBytesPerSample", "NA_BatchMacsPerSample",
-    "NA_BatchStateBytes", "NA_BatchStreamPackFactor", "NA_BatchStreamKernelName", "NA_DebugSetTraceBuffer", "NA_DebugSetWaveNetSpec", "NA_DebugSetRecurrentQuadMin", "NA_DebugRecurrentQuadLaunches", "NA_BatchStreamInputLimit", "NA_BatchRemoveStreams", "NA_MultiCreate", "NA_MultiDestroy", "NA_MultiAddStreams", "NA_MultiCommit", "NA_MultiNumStreams", "NA_MultiNumShards", "NA_MultiShardRange", "NA_MultiProcess", "NA_MultiSubmit", "NA_MultiCollect", "NA_MultiSetQuality", "NA_ShardByCost", "NA_ModelStreamCost", "NA_BatchNumLiveStreams", "NA_BatchIsLive", "NA_SetWaveNetMathMode", "NA_SetLSTMMathMode", "NA_SetCompositeModelLoadMode",
+    "NA_BatchStateBytes", "NA_BatchStreamPackFactor", "NA_BatchStreamKernelName", "NA_DebugSetTraceBuffer", "NA_DebugSetWaveNetSpec", "NA_DebugSetRecurrentQuadMin", "NA_DebugRecurrentQuadLaunches", "NA_RegisterHostBuffer", "NA_UnregisterHostBuffer", "NA_BatchStreamInputLimit", "NA_BatchRemoveStreams", "NA_MultiCreate", "NA_MultiDestroy", "NA_MultiAddStreams", "NA_MultiCommit", "NA_MultiNumStreams", "NA_MultiNumShards", "NA_MultiShardRange", "NA_MultiProcess", "NA_MultiSubmit", "NA_MultiCollect", "NA_MultiSetQuality", "NA_ShardByCost", "NA_ModelStreamCost", "NA_BatchNumLiveStreams", "NA_BatchIsLive", "NA_SetWaveNetMathMode", "NA_SetLSTMMathMode", "NA_SetCompositeModelLoadMode",
     "NA_IsQualityChangeRealtimeSafe", "NA_ProcessChecked", "NA_BatchSubmit", "NA_BatchCollect", "NA_BatchNextInput", "NA_BatchOutputView", "NA_BatchIsQualityChangeRealtimeSafe", "NA_DebugClassifyNam", "NA_DebugPackedWeights",
 ]
 
@@ -94,6 +94,8 @@ def load_library():
         "NA_DebugSetWaveNetSpec": (None, [C.c_int]),
         "NA_DebugSetRecurrentQuadMin": (C.c_int, [C.c_int]),
         "NA_DebugRecurrentQuadLaunches": (C.c_longlong, []),
+        "NA_RegisterHostBuffer": (C.c_int, [C.c_void_p, C.c_size_t]),
+        "NA_UnregisterHostBuffer": (C.c_int, [C.c_void_p]),
         "NA_BatchStreamInputLimit": (C.c_float, [vp, C.c_int]),
         "NA_BatchRemoveStreams": (C.c_int, [vp, C.c_int, C.c_int]),
         "NA_MultiCreate": (vp, [C.POINTER(C.c_int), C.c_int]),

@@ -429,6 +429,16 @@ int NA_BatchProcess(NA_Batch* batch, const float* in, float* out, size_t n)
 	return Guard([&] { batch->batch->ProcessHost(in, out, n); });
 }
 
+int NA_RegisterHostBuffer(void* ptr, size_t bytes)
+{
+	return Guard([&] {
+		std::string error;
+		if (!na::RegisterHostBuffer(ptr, bytes, error)) throw std::runtime_error(error);
+	});
+}
+
+int NA_UnregisterHostBuffer(void* ptr) { return na::UnregisterHostBuffer(ptr) ? 0 : -1; }
+
 int NA_BatchSubmit(NA_Batch* batch, const float* in, size_t n)
 {
 	int ticket = -1;

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -1334,6 +1335,55 @@ namespace na
 		return direct;
 	}
 
+	// ---- registered host blocks ----
+	namespace
+	{
+		struct HostBlock
+		{
+			char* host;
+			char* dev;
+			size_t bytes;
+		};
+		std::mutex gHostBlocksMutex;
+		std::vector<HostBlock> gHostBlocks;
+	}
+	bool RegisterHostBuffer(void* p, size_t bytes, std::string& error)
+	{
+		if (!p || bytes == 0) { error = "neuralaudio_amd: RegisterHostBuffer with an empty block"; return false; }
+		hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+		if (e != hipSuccess) { error = std::string("neuralaudio_amd: hipHostRegister: ") + hipGetErrorString(e); return false; }
+		void* d = nullptr;
+		e = hipHostGetDevicePointer(&d, p, 0);
+		if (e != hipSuccess || !d)
+		{
+			(void)hipHostUnregister(p);
+			error = std::string("neuralaudio_amd: hipHostGetDevicePointer: ") + hipGetErrorString(e);
+			return false;
+		}
+		std::lock_guard<std::mutex> lock(gHostBlocksMutex);
+		gHostBlocks.push_back({ static_cast<char*>(p), static_cast<char*>(d), bytes });
+		return true;
+	}
+	bool UnregisterHostBuffer(void* p)
+	{
+		std::lock_guard<std::mutex> lock(gHostBlocksMutex);
+		for (size_t i = 0; i < gHostBlocks.size(); i++)
+		{
+			if (gHostBlocks[i].host != p) continue;
+			gHostBlocks.erase(gHostBlocks.begin() + (long)i);
+			return hipHostUnregister(p) == hipSuccess;
+		}
+		return false;
+	}
+	void* RegisteredDevicePointer(const void* p, size_t bytes)
+	{
+		const char* c = static_cast<const char*>(p);
+		std::lock_guard<std::mutex> lock(gHostBlocksMutex);
+		for (const HostBlock& b : gHostBlocks)
+			if (c >= b.host && c + bytes <= b.host + b.bytes) return b.dev + (c - b.host);
+		return nullptr;
+	}
+
 	// (Splitting the buffer into chunks so that host copies overlap the DMA was measured and dropped: every extra asynchronous copy /
 	// event costs more than it hides -- 1024 x 128 frames: 114 us per call as one piece, 134 / 186 / 282 us in 2 / 4 / 8 chunks.)
 	void GpuBatch::ProcessHost(const float* in, float* out, size_t n)
@@ -1341,6 +1391,19 @@ namespace na
 		if (n == 0 || streams.empty()) return;
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		const size_t total = streams.size() * n;
+		if (HostDirect())
+		{
+			// blocks the caller registered: the kernels run on them as they are (no staging copies: 81 -> ~62 us for 1024 x 128)
+			float* dIn = static_cast<float*>(RegisteredDevicePointer(in, total * sizeof(float)));
+			float* dOut = static_cast<float*>(RegisteredDevicePointer(out, total * sizeof(float)));
+			if (dIn && dOut)
+			{
+				ProcessDevice(dIn, dOut, n, (long)n, (long)n);
+				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+				ZeroRetiredRows(out, n);
+				return;
+			}
+		}
 		EnsureStaging(total);
 		memcpy(hostStage, in, total * sizeof(float));
 		float* dStage = nullptr;

@@ -18,6 +18,13 @@
 
 namespace na
 {
+	// Host blocks the caller registered (NA_RegisterHostBuffer: hipHostRegister, mapped): ProcessHost runs the kernels directly on them --
+	// no staging copies.  RegisteredDevicePointer: the device address of `p` when [p, p + bytes) lies inside a registered block of
+	// `device`'s process, else nullptr.
+	bool RegisterHostBuffer(void* p, size_t bytes, std::string& error);
+	bool UnregisterHostBuffer(void* p);
+	void* RegisteredDevicePointer(const void* p, size_t bytes);
+
 	class HipError : public std::runtime_error
 	{
 	public:

@@ -569,3 +569,41 @@ def test_packed_narrow_streams_match_oracle_stream_by_stream(na, loader, name, f
     for s in (0, 2, 3):
         yo = O.oracle_from_file(name).process(np.concatenate([x[s], x2[s]]))[n_total:]
         assert O.rms(y2[s] - yo) < TOL_RMS, s
+
+
+def test_registered_host_blocks_are_processed_in_place(na, loader):
+    """NA_RegisterHostBuffer: NA_BatchProcess on pointers inside a registered block runs the kernels on the caller's memory (no staging
+    copies) -- same results as through the staging path, also for a sub-range of the block, retired rows read as silence, and an
+    unregistered pointer goes back to the copies."""
+    import ctypes as C
+    from neuralaudio_amd import capi
+    lib = capi.load_library()
+    m = loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=True)
+    S, n = 37, 128
+    x = np.stack([O.signal_noise(3 * n, 900 + s) for s in range(S)])
+
+    def run(registered):
+        b = na.Batch(0)
+        b.AddStreams(m, S)
+        b.RemoveStreams(5, 1)
+        # one block holding [in | out] back to back: the call gets pointers INSIDE it
+        block = np.zeros((2, S, n), dtype=np.float32)
+        if registered:
+            assert lib.NA_RegisterHostBuffer(block.ctypes.data_as(C.c_void_p), block.nbytes) == 0
+        outs = []
+        for k in range(3):
+            block[0] = x[:, k * n:(k + 1) * n]
+            block[1] = 7.0  # must be overwritten (retired rows: zeroed)
+            rc = lib.NA_BatchProcess(b._h, block[0].ctypes.data_as(C.POINTER(C.c_float)), block[1].ctypes.data_as(C.POINTER(C.c_float)), n)
+            assert rc == 0
+            outs.append(block[1].copy())
+        if registered:
+            assert lib.NA_UnregisterHostBuffer(block.ctypes.data_as(C.c_void_p)) == 0
+            assert lib.NA_UnregisterHostBuffer(block.ctypes.data_as(C.c_void_p)) != 0  # (already gone)
+        b.close()
+        return np.concatenate(outs, axis=1)
+
+    y_reg, y_copy = run(True), run(False)
+    assert np.array_equal(y_reg, y_copy)
+    assert not np.any(y_reg[5])
+    assert O.rms(y_reg[36] - O.oracle_from_file("BossWN-standard.nam").process(x[36])) < TOL_RMS
