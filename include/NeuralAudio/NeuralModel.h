@@ -52,13 +52,29 @@ namespace NeuralAudio
 	public:
 		virtual ~NeuralModel() {}
 
-		// --- identity / capabilities -----------------------------------------------------------------
+		// The virtuals are declared in the reference's order (NeuralModel.h:40-134), so the vtable slots agree with a host compiled against
+		// the reference header (Itanium ABI: slots follow declaration order; tests/vtable_slots.cpp checks them).
 		virtual EModelLoadMode GetLoadMode() { return EModelLoadMode::Internal; }
+
+		// --- quality scaling (A2 slimmable containers) ------------------------------------------------
+		virtual bool HasQualityScaling() { return false; }
+		virtual float GetQualityScaleFactor() { return 1.0f; }
+		virtual bool IsQualityChangeRealtimeSafe(float newScaleFactor) { (void)newScaleFactor; return true; }
+		virtual void SetQualityScaleFactor(float scaleFactor) { (void)scaleFactor; }
+
 		virtual bool IsStatic() { return false; }                  // true for the official fixed architectures
-		virtual std::string GetModelVersion() { return modelVersion; }
+		virtual void SetMaxAudioBufferSize(const int maxSize) { (void)maxSize; }
+
+		// --- level calibration --------------------------------------------------------------------------
+		virtual void SetAudioInputLevelDBu(float audioDBu) { audioInputLevelDBu = audioDBu; }
+		virtual float GetAudioInputLevelDBu() { return audioInputLevelDBu; }
+		virtual float GetRecommendedInputDBAdjustment() { return audioInputLevelDBu - modelInputLevelDBu; }
+		virtual float GetRecommendedOutputDBAdjustment() { return -18 - modelLoudnessDB; }
+
+		// --- identity ---------------------------------------------------------------------------------------
 		virtual float GetSampleRate() { return sampleRate; }
 		virtual int GetReceptiveFieldSize() { return -1; }         // -1: unbounded memory (LSTM)
-
+		virtual std::string GetModelVersion() { return modelVersion; }
 		// value is the JSON text of the metadata field ("" when absent)
 		virtual std::string GetMetadata(const std::string& fieldName)
 		{
@@ -67,20 +83,7 @@ namespace NeuralAudio
 			return "";
 		}
 
-		// --- quality scaling (A2 slimmable containers) ------------------------------------------------
-		virtual bool HasQualityScaling() { return false; }
-		virtual float GetQualityScaleFactor() { return 1.0f; }
-		virtual bool IsQualityChangeRealtimeSafe(float newScaleFactor) { (void)newScaleFactor; return true; }
-		virtual void SetQualityScaleFactor(float scaleFactor) { (void)scaleFactor; }
-
-		// --- level calibration --------------------------------------------------------------------------
-		virtual void SetAudioInputLevelDBu(float audioDBu) { audioInputLevelDBu = audioDBu; }
-		virtual float GetAudioInputLevelDBu() { return audioInputLevelDBu; }
-		virtual float GetRecommendedInputDBAdjustment() { return audioInputLevelDBu - modelInputLevelDBu; }
-		virtual float GetRecommendedOutputDBAdjustment() { return -18 - modelLoudnessDB; }
-
 		// --- audio ----------------------------------------------------------------------------------------
-		virtual void SetMaxAudioBufferSize(const int maxSize) { (void)maxSize; }
 		// input/output: caller-owned, >= numSamples floats each; input == output is allowed.
 		virtual void Process(float* input, float* output, size_t numSamples) { (void)input; (void)output; (void)numSamples; }
 		// (re-)establish the zero-input steady state

@@ -127,10 +127,23 @@ NA_EXTERN int NA_ShardByCost(const double* cost, int n, int parts, int* bounds);
 /* relative cost of one stream of `model` at `quality` (what the sharder balances): estimated microseconds per 1024 streams x 128 frames */
 NA_EXTERN double NA_ModelStreamCost(NeuralModel* model, float quality);
 
+/* Host side only (no GPU needed): the kernel family a batch of `streams` streams of `model` would run on -- "f16-split", "frame" (f32),
+ * "generic" (wide arrays) or "recurrent" -- with the facts behind the choice: the input limit of the f16-split range proof, whether the
+ * proof holds (every value stays inside the f16 range for inputs within the limit, limit >= 8), whether the weights fit the operand
+ * format, and the stream-packing factor.  A WaveNet model that fails the proof runs on the f32 frame kernel.  0 on success. */
+NA_EXTERN int NA_ModelKernelInfo(NeuralModel* model, float quality, int streams, char* kernelBuf, int bufSize, float* inputLimit, int* rangeProven,
+	int* weightsOk, int* packFactor);
+
 /* Range contract of the kernel that runs the stream: input samples beyond +-limit are clamped, NaN reads as silence.  +inf for the f32
  * kernels (they follow the reference's f32 chain at any amplitude); a per-model bound <= 32752 for the f16-split WaveNet kernels, whose
  * values carry an f16 exponent -- far above any audio level (0 on a bad argument). */
 NA_EXTERN float NA_BatchStreamInputLimit(NA_Batch* batch, int stream);
+/* Models the f16-split kernels run WITHOUT a static range proof (LeakyReLU: the official A2 shapes) saturate a value that leaves the f16
+ * range instead of overflowing, and count it: the number of (wave, block) pairs of this stream in which that happened since its last
+ * reset / prewarm.  0 = the stream's output is the reference's to the usual tolerance; > 0 = some block was computed with clamped values
+ * (the stream recovers one receptive field later).  Always 0 for proven models and the f32 kernels.  Synchronises the batch stream: a
+ * diagnostic, not for the audio path.  Negative on a bad argument. */
+NA_EXTERN int NA_BatchStreamRangeEvents(NA_Batch* batch, int stream);
 /* NAMIsA2 (bit 0) / NAMIsA2Standard (bit 1) of a .nam document (NeuralModel.cpp:159-168, 188-317); negative on a parse error */
 NA_EXTERN int NA_DebugClassifyNam(const char* jsonText);
 /* stream packing, host side only: pack factor of the model in a large batch (1: none); flat weights of the packed virtual model into

@@ -108,6 +108,16 @@ class NeuralModel:
     def IsQualityChangeRealtimeSafe(self, q):
         return bool(self._lib.NA_IsQualityChangeRealtimeSafe(self._h, float(q)))
 
+    def KernelInfo(self, quality=1.0, streams=1):
+        """Host side only: the kernel family a batch of `streams` streams would run on and the f16-split range proof behind the choice."""
+        name = C.create_string_buffer(64)
+        lim = C.c_float(0.0)
+        proven, wok, pack = C.c_int(0), C.c_int(0), C.c_int(0)
+        if self._lib.NA_ModelKernelInfo(self._h, float(quality), int(streams), name, 64, C.byref(lim), C.byref(proven), C.byref(wok), C.byref(pack)) != 0:
+            raise NeuralAudioError(capi.last_error())
+        return {"kernel": name.value.decode(), "input_limit": float(lim.value), "range_proven": bool(proven.value), "weights_ok": bool(wok.value),
+                "pack": int(pack.value)}
+
     def close(self):
         if self._h:
             self._lib.DeleteModel(self._h)
@@ -309,6 +319,12 @@ class Batch:
 
     def StreamPackFactor(self, stream):
         return int(self._lib.NA_BatchStreamPackFactor(self._h, int(stream)))
+
+    def StreamRangeEvents(self, stream):
+        r = int(self._lib.NA_BatchStreamRangeEvents(self._h, int(stream)))
+        if r < 0:
+            raise NeuralAudioError(capi.last_error())
+        return r
 
     def close(self):
         if self._h:

@@ -518,6 +518,39 @@ double NA_ModelStreamCost(NeuralModel* model, float quality)
 	return c;
 }
 
+// Host side only (no GPU needed): which WaveNet kernel family a batch of `streams` streams of the model would run on, and the static
+// range proof of the f16-split kernels behind the choice (wavenet_plan.cpp)
+int NA_ModelKernelInfo(NeuralModel* model, float quality, int streams, char* kernelBuf, int bufSize, float* inputLimit, int* rangeProven, int* weightsOk, int* packFactor)
+{
+	int r = -1;
+	Guard([&] {
+		NeuralAudio::GpuModel* gm = model ? dynamic_cast<NeuralAudio::GpuModel*>(model->model) : nullptr;
+		if (!gm) throw std::runtime_error("NA_ModelKernelInfo: model was not created by this library");
+		const na::ModelKernelInfo info = na::PredictModelKernel(*gm->GetLoadedModel(), quality, streams);
+		if (kernelBuf && bufSize > 0)
+		{
+			strncpy(kernelBuf, info.kernel, (size_t)bufSize - 1);
+			kernelBuf[bufSize - 1] = 0;
+		}
+		if (inputLimit) *inputLimit = info.inputLimit;
+		if (rangeProven) *rangeProven = info.rangeProven ? 1 : 0;
+		if (weightsOk) *weightsOk = info.weightsOk ? 1 : 0;
+		if (packFactor) *packFactor = info.pack;
+		r = 0;
+	});
+	return r;
+}
+
+int NA_BatchStreamRangeEvents(NA_Batch* b, int stream)
+{
+	int r = -1;
+	Guard([&] {
+		if (!b) throw std::runtime_error("NA_BatchStreamRangeEvents: null batch");
+		r = b->batch->StreamRangeEvents(stream);
+	});
+	return r;
+}
+
 NA_MultiBatch* NA_MultiCreate(const int* devices, int numDevices)
 {
 	NA_MultiBatch* mb = nullptr;

@@ -170,6 +170,8 @@ namespace na
 		// -2 a launch of its own
 		virtual int LaunchClass() const { return -2; }
 		virtual int PackFactor() const { return 1; } // real streams per kernel-level stream (WaveNet stream packing)
+		// f16-split kernels without a static range proof: (wave, block) pairs in which a value of this member's stream was saturated
+		virtual int RangeEvents(int member) { (void)member; return 0; }
 		virtual float InputLimit() const { return INFINITY; } // samples beyond +-limit are clamped by the kernel (f16-split WaveNet kernels)
 		virtual const char* KernelName() const = 0;  // the kernel that runs this group's streams (rocprof name, without template arguments)
 		// WaveNet groups on the frame kernel can share ONE launch with other such groups (a heterogeneous batch without stream
@@ -311,12 +313,28 @@ namespace na
 		// per wave (every array has 5..8 or 13..16 channels, K = 3: Standard 50 vs 60 us); narrow (Feather, Nano: <= 4-channel
 		// arrays) and large-kernel (A2) models are faster on the frame kernel (33 / 30 / 71 us vs 44 / 44 / 133 us); a 12-channel model (Lite)
 		// is too as it is (46 vs 50 us), but padded to 16 / 8 channels it runs the fast split flavour (PadFor below: 42.6 us).
+		// May the f16-split kernels run this plan at all?  Their values are (hi, lo) pairs of f16: the plan builder proves statically that
+		// with inputs inside +-condLimit (>= kSplitMinInputLimit) nothing leaves the f16 range and that the weights fit the operand format
+		// (wavenet_plan.cpp).  A model that fails the proof runs on the f32 frame kernel -- no clamp, no overflow, the
+		// reference's own number format -- and NA_BatchStreamKernelName says so.  One exception: the official A2 shapes (LeakyReLU: the
+		// worst-case bound grows with the product of 23 layers' row sums and fails for every trained model) stay on their chains, which
+		// saturate instead of overflowing and count the event (wavenet_split_dev.h SplitQuadSat, NA_BatchStreamRangeEvents).
+		bool SplitAllowed(const WaveNetPlan& plan)
+		{
+			if (plan.genericOnly || !plan.splitWeightsOk || plan.rings.size() > (size_t)WN_RANGE_EVENT_SLOT) return false;
+			if (plan.splitRangeProven) return true;
+			const int spec = WaveNetSpecArchId(plan.sstages.data(), (int)plan.sstages.size(), plan.stateF4, (int)(plan.wsplit.size() / 8));
+			return spec == WN_SPEC_A2FULL || spec == WN_SPEC_A2LITE;
+		}
+
 		WnFamily FamilyFor(const WaveNetPlan& plan)
 		{
 			if (plan.genericOnly) return WN_FAMILY_GENERIC; // > 16 channels: the runtime-shaped kernel is the only one that runs it
 			const WnFamily o = WaveNetFamilyOverride();
 			if (o == WN_FAMILY_GENERIC && !plan.genericOk) return WN_FAMILY_FRAME; // (conv heads: not in the runtime-shaped kernel)
+			if (o == WN_FAMILY_SPLIT && !SplitAllowed(plan)) return WN_FAMILY_FRAME; // (the range proof outranks the tuning knob)
 			if (o != WN_FAMILY_AUTO) return o;
+			if (!SplitAllowed(plan)) return WN_FAMILY_FRAME;
 			if (plan.splitFastT == 2) return WN_FAMILY_SPLIT;
 			// the A2 submodels have compile-time specialised chains on the split kernels' state format (wavenet_spec_kernels.hip; round 3:
 			// 2048-stream quality sweep 120 us on the frame kernel); blocks that are not 128 / 64 frames fall to the stage interpreter
@@ -342,7 +360,10 @@ namespace na
 				for (const WnArrayCfg& cfg : wn.arrays)
 					if (cfg.channels > 16) return 1;
 				const int P = WaveNetPackFactor(wn);
-				return P < 2 ? 1 : P;
+				if (P < 2) return 1;
+				// packing means the f16-split kernels: only for a model that passes their range proof (block-diagonal packing keeps every
+				// row sum, so the real model's proof is the virtual model's)
+				return SplitAllowed(BuildWaveNetPlan(wn)) ? P : 1;
 			}
 
 			// Padding without packing (wavenet_plan.cpp WaveNetWantsPadding): a model whose arrays do not fill their lane mode (A1 Lite:
@@ -354,7 +375,7 @@ namespace na
 				const WnFamily o = WaveNetFamilyOverride();
 				if (off || (o != WN_FAMILY_AUTO && o != WN_FAMILY_SPLIT)) return false;
 				ValidateWaveNetDesc(wn);
-				return WaveNetWantsPadding(wn);
+				return WaveNetWantsPadding(wn) && SplitAllowed(BuildWaveNetPlan(wn));
 			}
 
 			// packHint: 0 = never pack (submodel of a container), otherwise the number of streams the creating AddStreams call brings
@@ -429,6 +450,7 @@ namespace na
 				dev.max_G = plan.maxG;
 				dev.split_fast_T = plan.splitFastT;
 				dev.cond_limit = plan.condLimit;
+				dev.saturate = plan.splitRangeProven ? 0 : 1;
 				dev.spec_arch = family == WN_FAMILY_SPLIT ? WaveNetSpecArchId(plan.sstages.data(), (int)plan.sstages.size(), plan.stateF4, (int)(plan.wsplit.size() / 8)) : WN_SPEC_NONE;
 			}
 
@@ -561,6 +583,15 @@ namespace na
 			}
 			int PackFactor() const override { return pack; }
 			float InputLimit() const override { return family == WN_FAMILY_SPLIT ? plan.condLimit : INFINITY; }
+			int RangeEvents(int member) override
+			{
+				if (family != WN_FAMILY_SPLIT || !dev.saturate || !InUse(member)) return 0;
+				int count = 0;
+				const float* slot = state.Get() + (size_t)(member / pack) * (size_t)plan.stateF4 * 4;
+				CheckHip(hipMemcpyAsync(&count, reinterpret_cast<const int*>(slot) + WN_RANGE_EVENT_SLOT, sizeof(int), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H");
+				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+				return count;
+			}
 			const char* KernelName() const override
 			{
 				// (a model with a specialised chain runs it for blocks of 128 / 64 / 32 frames, the interpreter for other lengths)
@@ -849,6 +880,33 @@ namespace na
 
 namespace na
 {
+	// Host side only (no device): which kernel family a batch would pick for `streams` streams of this submodel -- the constructor logic
+	// of WaveNetGroup (pack / pad / range proof / FamilyFor) -- and the facts of the range proof behind the choice.
+	ModelKernelInfo PredictModelKernel(const LoadedModel& model, float quality, int streams)
+	{
+		ModelKernelInfo info;
+		if (model.subModels.empty()) return info;
+		const int idx = model.isComposite ? model.ModelIndexFromQuality(quality) : 0;
+		const ModelDesc& d = *model.subModels[(size_t)idx].desc;
+		if (d.kind != MODEL_WAVENET)
+		{
+			info.kernel = "recurrent";
+			return info;
+		}
+		const WaveNetPlan real = BuildWaveNetPlan(d.wavenet);
+		info.inputLimit = real.condLimit;
+		info.rangeProven = real.splitRangeProven;
+		info.weightsOk = real.splitWeightsOk;
+		const int packHint = (!model.isComposite && model.subModels.size() == 1) ? streams : 0;
+		const int pack = WaveNetGroup::PackFor(d.wavenet, packHint);
+		const bool isVirtual = pack > 1 || WaveNetGroup::PadFor(d.wavenet);
+		const WnFamily fam = isVirtual ? WN_FAMILY_SPLIT : FamilyFor(real);
+		info.pack = pack;
+		info.kernel = fam == WN_FAMILY_SPLIT ? "f16-split" : (fam == WN_FAMILY_GENERIC ? "generic" : "frame");
+		if (fam != WN_FAMILY_SPLIT) info.inputLimit = INFINITY;
+		return info;
+	}
+
 	// Cost of one stream for the multi-GPU sharder: time = per-launch skeleton + bytes (WaveNet) / multiply-accumulates (recurrent),
 	// two-point fits per kernel family to the round-3 measurements (us per 1024 streams x 128 frames): specialised / split chains
 	// 22.3 + 0.0143 B (Standard 41.6, Lite 33.7), f32 frame kernel 31.6 + 0.0164 B (A2-Lite 46.6, A2-Full 71.4), LDS-free recurrent
@@ -972,36 +1030,72 @@ namespace na
 		std::vector<std::vector<int>> newMembers(numSub);
 		for (size_t k = 0; k < numSub; k++) subGroups[k] = GroupFor(model->subModels[k].desc, (!model->isComposite && numSub == 1) ? count : 0);
 		const int first = AllocateIds(count);
-		for (int i = 0; i < count; i++)
+		// Everything below may throw (hipMalloc inside AddMember / Reset / Prewarm).  A failed call must leave the batch as it was: the
+		// members it created are removed again, the ids go back to `retired` (rows appended by AllocateIds leave the arrays).
+		int built = 0; // rows [first, first + built) are complete StreamRefs
+		std::vector<std::pair<ModelGroup*, int>> partial; // members of the row under construction
+		try
 		{
-			StreamRef ref;
-			ref.model = model;
-			ref.quality = quality;
-			ref.active = active;
-			ref.onDemand = onDemand;
-			ref.live = true;
-			ref.prewarmed.assign(numSub, 0);
-			const int row = first + i;
+			for (int i = 0; i < count; i++)
+			{
+				StreamRef ref;
+				ref.model = model;
+				ref.quality = quality;
+				ref.active = active;
+				ref.onDemand = onDemand;
+				ref.live = true;
+				ref.prewarmed.assign(numSub, 0);
+				const int row = first + i;
+				partial.clear();
+				for (size_t k = 0; k < numSub; k++)
+				{
+					const int member = subGroups[k]->AddMember();
+					partial.push_back({ subGroups[k], member });
+					newMembers[k].push_back(member);
+				}
+				ref.members = partial;
+				partial.clear();
+				ref.members[(size_t)active].first->SetActive(ref.members[(size_t)active].second, row);
+				streams[(size_t)row] = ref;
+				built = i + 1;
+			}
+			// fresh state for every new member, then prewarm: every submodel (LoadAll, CompositeModel.h:111-118) or only the active one
+			// (OnDemand, :104-109 -- the others are prewarmed when a quality change first selects them, :52-60)
 			for (size_t k = 0; k < numSub; k++)
 			{
-				const int member = subGroups[k]->AddMember();
-				newMembers[k].push_back(member);
-				ref.members.push_back({ subGroups[k], member });
+				std::sort(newMembers[k].begin(), newMembers[k].end());
+				subGroups[k]->Reset(newMembers[k]);
+				const bool now = prewarm && (!onDemand || (int)k == active);
+				if (now) subGroups[k]->Prewarm(newMembers[k]);
+				for (int i = 0; i < count; i++) streams[(size_t)(first + i)].prewarmed[k] = now ? 1 : 0;
 			}
-			ref.members[(size_t)active].first->SetActive(ref.members[(size_t)active].second, row);
-			streams[(size_t)row] = ref;
 		}
-		// fresh state for every new member, then prewarm: every submodel (LoadAll, CompositeModel.h:111-118) or only the active one
-		// (OnDemand, :104-109 -- the others are prewarmed when a quality change first selects them, :52-60)
-		for (size_t k = 0; k < numSub; k++)
+		catch (...)
 		{
-			std::sort(newMembers[k].begin(), newMembers[k].end());
-			subGroups[k]->Reset(newMembers[k]);
-			const bool now = prewarm && (!onDemand || (int)k == active);
-			if (now) subGroups[k]->Prewarm(newMembers[k]);
-			for (int i = 0; i < count; i++) streams[(size_t)(first + i)].prewarmed[k] = now ? 1 : 0;
+			for (auto& gm : partial) gm.first->RemoveMember(gm.second);
+			for (int i = 0; i < count; i++)
+			{
+				StreamRef& ref = streams[(size_t)(first + i)];
+				if (i < built)
+					for (auto& gm : ref.members) gm.first->RemoveMember(gm.second);
+				ref = StreamRef();
+				ref.live = false;
+				retired.insert(std::lower_bound(retired.begin(), retired.end(), first + i), first + i);
+			}
+			DropTrailingRetiredRows();
+			throw;
 		}
 		return first;
+	}
+
+	// trailing retired rows leave the [streams][n] arrays altogether (their ids are the largest entries of the sorted `retired` list)
+	void GpuBatch::DropTrailingRetiredRows()
+	{
+		while (!streams.empty() && !streams.back().live)
+		{
+			if (!retired.empty() && retired.back() == (int)streams.size() - 1) retired.pop_back();
+			streams.pop_back();
+		}
 	}
 
 	// every buffer still in flight on a slot stream (pipelined interface) is done after this
@@ -1029,12 +1123,7 @@ namespace na
 			ref.live = false;
 			retired.insert(std::lower_bound(retired.begin(), retired.end(), first + i), first + i);
 		}
-		// trailing retired rows leave the arrays altogether
-		while (!streams.empty() && !streams.back().live)
-		{
-			retired.pop_back();
-			streams.pop_back();
-		}
+		DropTrailingRetiredRows();
 	}
 
 	unsigned GpuBatch::StreamPrewarmedMask(int s) const
@@ -1045,9 +1134,10 @@ namespace na
 		return mask;
 	}
 
-	void GpuBatch::ZeroRetiredRows(float* hostRows, size_t n) const
+	void GpuBatch::ZeroRetiredRows(float* hostRows, size_t n, size_t rows) const
 	{
-		for (int id : retired) memset(hostRows + (size_t)id * n, 0, n * sizeof(float));
+		for (int id : retired)
+			if ((size_t)id < rows) memset(hostRows + (size_t)id * n, 0, n * sizeof(float));
 	}
 
 	void GpuBatch::SetQuality(int s, float quality)
@@ -1400,7 +1490,7 @@ namespace na
 			{
 				ProcessDevice(dIn, dOut, n, (long)n, (long)n);
 				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
-				ZeroRetiredRows(out, n);
+				ZeroRetiredRows(out, n, streams.size());
 				return;
 			}
 		}
@@ -1418,7 +1508,7 @@ namespace na
 		}
 		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 		memcpy(out, hostStage, total * sizeof(float));
-		ZeroRetiredRows(out, n);
+		ZeroRetiredRows(out, n, streams.size());
 	}
 
 	void GpuBatch::EnsurePipeSlot(PipeSlot& p, size_t floats)
@@ -1451,6 +1541,7 @@ namespace na
 		const size_t total = streams.size() * n;
 		EnsurePipeSlot(p, total);
 		p.n = n;
+		p.rows = streams.size(); // Collect sizes its copy by THIS (AddStreams / RemoveStreams may run while the ticket is in flight)
 		if (in) memcpy(p.hostIn, in, total * sizeof(float)); // nullptr: the caller filled NextInput() in place
 		const bool direct = HostDirect(); // (see ProcessHost)
 		float *dIn = nullptr, *dOut = nullptr;
@@ -1528,8 +1619,9 @@ namespace na
 		PipeSlot& p = pipe[ticket];
 		if (p.onOwnStream) CheckHip(hipStreamSynchronize(p.own), "hipStreamSynchronize"); // the download is the stream's last operation
 		else CheckHip(hipEventSynchronize(p.downloaded), "hipEventSynchronize");
-		if (!retired.empty()) ZeroRetiredRows(p.hostOut, p.n);
-		if (out) memcpy(out, p.hostOut, streams.size() * p.n * sizeof(float)); // nullptr: the caller reads OutputView() in place
+		// the slot holds the rows the batch had at Submit: ids retired since then are zeroed only inside that block
+		if (!retired.empty()) ZeroRetiredRows(p.hostOut, p.n, p.rows);
+		if (out) memcpy(out, p.hostOut, p.rows * p.n * sizeof(float)); // nullptr: the caller reads OutputView() in place
 		p.busy = false;
 	}
 
@@ -1592,6 +1684,17 @@ namespace na
 		const StreamRef& ref = streams.at((size_t)s);
 		if (!ref.live) return 0.0f;
 		return ref.members[(size_t)ref.active].first->InputLimit();
+	}
+
+	int GpuBatch::StreamRangeEvents(int s)
+	{
+		const StreamRef& ref = streams.at((size_t)s);
+		if (!ref.live) return 0;
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		DrainPipeline();
+		int total = 0;
+		for (const auto& gm : ref.members) total += gm.first->RangeEvents(gm.second);
+		return total;
 	}
 
 	int GpuBatch::StreamPackFactor(int s) const

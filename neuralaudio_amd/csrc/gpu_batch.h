@@ -7,6 +7,7 @@
 // single-stream NeuralModel (neural_model.cpp) is a GpuBatch with one stream.
 #pragma once
 
+#include <cmath>
 #include <cstddef>
 #include <memory>
 #include <string>
@@ -40,6 +41,17 @@ namespace na
 	// Relative cost of one stream of a model (what the multi-GPU sharder balances, multi_gpu.h): microseconds per 1024 streams x 128
 	// frames of the kernel family that runs it, fitted to the round-3 measurements; host-side only (no device needed)
 	double EstimateStreamCost(const LoadedModel& model, float quality);
+
+	// Host-side prediction of the kernel family for a model (no device needed): "f16-split" | "frame" | "generic" | "recurrent", the
+	// pack factor, and the static range proof of the f16-split kernels (wavenet_plan.h: splitRangeProven / splitWeightsOk / condLimit)
+	struct ModelKernelInfo
+	{
+		const char* kernel = "";
+		int pack = 1;
+		float inputLimit = INFINITY;
+		bool rangeProven = true, weightsOk = true;
+	};
+	ModelKernelInfo PredictModelKernel(const LoadedModel& model, float quality, int streams);
 
 	class ModelGroup; // one per distinct ModelDesc: packed weights + state of all its streams
 
@@ -107,6 +119,7 @@ namespace na
 		float* NextInput(size_t n);
 		const float* OutputView(int ticket) const;
 		size_t SlotFrames(int ticket) const { return (ticket >= 0 && ticket < kPipelineSlots) ? pipe[ticket].n : 0; } // frames per row of that submission
+		size_t SlotRows(int ticket) const { return (ticket >= 0 && ticket < kPipelineSlots) ? pipe[ticket].rows : 0; } // rows of that submission
 
 		void Synchronize();
 		hipStream_t GetStream() const { return stream; }
@@ -119,6 +132,10 @@ namespace na
 		const char* StreamKernelName(int stream) const; // which kernel runs the stream (rocprof name without template arguments)
 		// range contract: samples beyond +-limit are clamped (NaN reads as silence) by the kernel that runs the stream; +inf for the f32 kernels
 		float StreamInputLimit(int stream) const;
+		// f16-split kernels on a model without a static range proof (the official A2 shapes): how often a value of the stream left the f16
+		// range and was saturated -- (wave, block) pairs since the stream's last reset / prewarm; 0 means the output is the reference's to
+		// the usual tolerance.  Synchronises the batch stream (a diagnostic, not for the audio path).
+		int StreamRangeEvents(int stream);
 		int StreamPackFactor(int stream) const; // > 1: the stream shares a kernel-level stream with others of its model (stream packing)
 
 	private:
@@ -134,8 +151,9 @@ namespace na
 		};
 		std::vector<int> retired; // sorted ids of removed streams
 		int AllocateIds(int count);
+		void DropTrailingRetiredRows();
 		int LaunchUnitsAfterSwitch(const ModelGroup* leaving, const ModelGroup* entering) const;
-		void ZeroRetiredRows(float* hostRows, size_t n) const;
+		void ZeroRetiredRows(float* hostRows, size_t n, size_t rows) const;
 
 		ModelGroup* GroupFor(const std::shared_ptr<const ModelDesc>& desc, int packHint = 0);
 		void EnsureStaging(size_t floats);
@@ -174,6 +192,7 @@ namespace na
 			float* hostOut = nullptr; // pinned
 			float* dev = nullptr;
 			size_t floats = 0, n = 0;
+			size_t rows = 0; // rows of the [streams][n] block this slot was submitted with
 			hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
 			hipStream_t own = nullptr; // upload, kernel and download of this slot's buffer, in order (batches that run as one launch)
 			bool onOwnStream = false;

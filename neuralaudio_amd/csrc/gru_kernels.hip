@@ -11,6 +11,7 @@
 // Mapping: one wave per stream, lane r owns gate row r of every layer (3H <= 64 rows: z | r | c), weights in VGPRs for
 // the whole block, [x; h] broadcast from LDS, the z / r gates meet the c rows through LDS, the dense head is computed for
 // the whole block after the sample loop (same structure as LstmWaveKernel).
+#include "device_once.h"
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
@@ -214,12 +215,8 @@ namespace na
 		{
 			const size_t ldsBytes = ((size_t)64 * (n + 1) + (size_t)m.numLayers * m.hidden * 64 + (size_t)6 * m.hidden * 64 + (size_t)2 * (m.tailLayers > 0 ? m.tailWidth : 0) * 64) * sizeof(float);
 			if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
-			static bool attrSet = false;
-			if (!attrSet)
-			{
-				(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&GruGenericKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-				attrSet = true;
-			}
+			static PerDeviceOnce attr; // (hipFuncSetAttribute applies to the current device's copy of the kernel)
+			(void)attr.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&GruGenericKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
 			hipLaunchKernelGGL(GruGenericKernel, dim3((unsigned)((numStreams + 63) / 64)), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows,
 				numStreams, in, out, inStride, outStride, n);
 			return hipGetLastError();

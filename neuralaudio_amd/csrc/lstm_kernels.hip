@@ -5,6 +5,7 @@
 //   LSTMLayerT::Process   NeuralAudio/LSTM.h:87-100    (g = W[4H x (I+H)] [x;h] + b; i,f,g,o gates)
 //   LSTMLayer::Process    NeuralAudio/LSTMDynamic.h:95-108 (same arithmetic, runtime shaped)
 //   FastMath Tanh/Sigmoid NeuralAudio/Activation.h:83-96
+#include "device_once.h"
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
@@ -601,12 +602,8 @@ namespace na
 			ldsBytes = RecurrentWaveRtLdsFloats(m, false) * sizeof(float);
 			if (ldsBytes > 160 * 1024) return false;
 		}
-		static bool attrSet = false;
-		if (!attrSet)
-		{
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&RecurrentWaveRtKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			attrSet = true;
-		}
+		static PerDeviceOnce attr; // (hipFuncSetAttribute applies to the current device's copy of the kernel)
+		(void)attr.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&RecurrentWaveRtKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
 		hipLaunchKernelGGL(RecurrentWaveRtKernel, dim3((unsigned)numStreams), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows, in, out, inStride,
 			outStride, n, l2w);
 		err = hipGetLastError();
@@ -629,12 +626,8 @@ namespace na
 	{
 		const size_t ldsBytes = ((size_t)64 * (n + 1) + (size_t)m.numLayers * 2 * H * 64) * sizeof(float);
 		if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
-		static bool attrSet = false;
-		if (!attrSet)
-		{
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&LstmBlockKernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			attrSet = true;
-		}
+		static PerDeviceOnce attr; // per instantiation and device
+		(void)attr.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&LstmBlockKernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
 		hipLaunchKernelGGL(LstmBlockKernel<H>, dim3((unsigned)((numStreams + 63) / 64)), dim3(64), ldsBytes, stream, m, state, capacity,
 			slots, rows, numStreams, in, out, inStride, outStride, n);
 		return hipGetLastError();
@@ -741,12 +734,8 @@ namespace na
 	{
 		const size_t ldsBytes = LstmGenericLdsBytes(m.hidden, m.numLayers, n, m.tailLayers > 0 ? m.tailWidth : 0);
 		if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
-		static bool attrSet = false;
-		if (!attrSet)
-		{
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&LstmGenericKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			attrSet = true;
-		}
+		static PerDeviceOnce attr;
+		(void)attr.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&LstmGenericKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
 		hipLaunchKernelGGL(LstmGenericKernel, dim3((unsigned)((numStreams + 63) / 64)), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows,
 			numStreams, in, out, inStride, outStride, n);
 		return hipGetLastError();

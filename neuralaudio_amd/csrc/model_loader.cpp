@@ -2,6 +2,7 @@
 #include "model_loader.h"
 #include "lstm_dev.h"
 
+#include <cstdlib>
 #include <algorithm>
 #include <fstream>
 #include <cmath>
@@ -242,13 +243,26 @@ namespace na
 	// The reference uses them to decide which engine evaluates an A2-format file: the static Internal engine for the standard
 	// architecture, NAM Core for everything else.  Here they decide IsStatic() for A2 files (the rejection of features without
 	// arithmetic on this path is RejectUnsupportedA2Features above).  Note the reference's IsActive(): a MISSING block counts as active.
+	// "A2 format" = file version newer than 0.5.4 (the rule of NeuralModel.cpp:159-168): the dotted version is read as up to three
+	// numbers (a missing or malformed field counts as 0, like a failed stream extraction there) and compared as a tuple
 	bool NAMIsA2(const std::string& version)
 	{
-		int major = 0, minor = 0, patch = 0;
-		char dot;
-		std::stringstream ss(version);
-		ss >> major >> dot >> minor >> dot >> patch;
-		return (major > 0) || (minor > 5) || ((minor == 5) && (patch > 4));
+		long field[3] = { 0, 0, 0 };
+		const char* p = version.c_str();
+		for (int i = 0; i < 3; i++)
+		{
+			char* end = nullptr;
+			const long v = std::strtol(p, &end, 10);
+			if (end == p) break; // no number here: this field and the rest stay 0
+			field[i] = v;
+			if (*end == 0) break;
+			p = end + 1; // the reference skips exactly one separator character, whatever it is
+		}
+		// newer than 0.5.4 -- the reference tests major > 0 || minor > 5 || (minor == 5 && patch > 4), which a tuple comparison
+		// reproduces for every version with major >= 0
+		if (field[0] != 0) return field[0] > 0;
+		if (field[1] != 5) return field[1] > 5;
+		return field[2] > 4;
 	}
 
 	namespace

@@ -47,19 +47,7 @@ namespace na
 			if (d < 0 || d >= visible) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: invalid HIP device index");
 	}
 
-	MultiGpuBatch::~MultiGpuBatch()
-	{
-		for (auto& sp : shards)
-		{
-			Shard& s = *sp;
-			{
-				std::lock_guard<std::mutex> lock(s.m);
-				s.quit = true;
-			}
-			s.cv.notify_all();
-			if (s.worker.joinable()) s.worker.join();
-		}
-	}
+	MultiGpuBatch::~MultiGpuBatch() { StopWorkers(); }
 
 	int MultiGpuBatch::AddStreams(const std::shared_ptr<const LoadedModel>& model, float quality, int count, bool prewarm, bool onDemand)
 	{
@@ -156,19 +144,59 @@ namespace na
 			Shard* s = sp.get();
 			s->worker = std::thread([this, s] { Run(*s); });
 		}
+		// every worker builds its own batch: the streams of the global list that fall into its range, entry by entry.  A shard that fails
+		// (bad device, out of memory) fails the whole Commit: the workers are joined, the shards dropped, and the object is back in its
+		// pre-Commit state -- `committed` is set only when every non-empty range has a batch with exactly its rows.
+		try
+		{
+			Post([this](Shard& s) {
+				if (s.end <= s.begin) return;
+				s.batch.reset(new GpuBatch(s.device));
+				int first = 0;
+				for (const Entry& e : entries)
+				{
+					const int a = std::max(first, s.begin), b = std::min(first + e.count, s.end);
+					if (b > a) s.batch->AddStreams(e.model, e.quality, b - a, e.prewarm, e.onDemand);
+					first += e.count;
+				}
+			});
+			for (auto& sp : shards) CheckShard(*sp);
+		}
+		catch (...)
+		{
+			StopWorkers();
+			throw;
+		}
 		committed = true;
-		// every worker builds its own batch: the streams of the global list that fall into its range, entry by entry
-		Post([this](Shard& s) {
-			if (s.end <= s.begin) return;
-			s.batch.reset(new GpuBatch(s.device));
-			int first = 0;
-			for (const Entry& e : entries)
+	}
+
+	// a non-empty range without a batch of exactly its rows would silently leave the caller's rows untouched
+	void MultiGpuBatch::CheckShard(const Shard& s) const
+	{
+		if (s.end <= s.begin) return;
+		if (!s.batch || s.batch->NumStreams() != s.end - s.begin)
+			throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: a shard has no batch for its stream range");
+	}
+
+	void MultiGpuBatch::StopWorkers()
+	{
+		for (auto& sp : shards)
+		{
+			Shard& s = *sp;
 			{
-				const int a = std::max(first, s.begin), b = std::min(first + e.count, s.end);
-				if (b > a) s.batch->AddStreams(e.model, e.quality, b - a, e.prewarm, e.onDemand);
-				first += e.count;
+				std::lock_guard<std::mutex> lock(s.m);
+				s.quit = true;
 			}
-		});
+			s.cv.notify_all();
+			if (s.worker.joinable()) s.worker.join();
+		}
+		shards.clear();
+	}
+
+	void MultiGpuBatch::CheckUsable() const
+	{
+		if (!broken.empty()) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch is unusable after a failed submission (" + broken + ")");
+		for (const auto& sp : shards) CheckShard(*sp);
 	}
 
 	void MultiGpuBatch::ShardRange(int shard, int& begin, int& end, int& device) const
@@ -182,6 +210,7 @@ namespace na
 	void MultiGpuBatch::Process(const float* in, float* out, size_t n)
 	{
 		if (!committed) Commit();
+		CheckUsable();
 		Post([=](Shard& s) {
 			if (s.batch) s.batch->ProcessHost(in + (size_t)s.begin * n, out + (size_t)s.begin * n, n);
 		});
@@ -191,20 +220,32 @@ namespace na
 	{
 		if (!committed) Commit();
 		// every shard advances its slot ring in lock-step, so one ticket names the same slot everywhere
+		CheckUsable();
 		int ticket = -1;
 		std::mutex tm;
-		Post([&, in, n](Shard& s) {
-			if (!s.batch) return;
-			const int t = s.batch->Submit(in + (size_t)s.begin * n, n);
-			std::lock_guard<std::mutex> lock(tm);
-			if (ticket >= 0 && ticket != t) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: shards out of step");
-			ticket = t;
-		});
+		try
+		{
+			Post([&, in, n](Shard& s) {
+				if (!s.batch) return;
+				const int t = s.batch->Submit(in + (size_t)s.begin * n, n);
+				std::lock_guard<std::mutex> lock(tm);
+				if (ticket >= 0 && ticket != t) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: shards out of step");
+				ticket = t;
+			});
+		}
+		catch (const std::exception& e)
+		{
+			// some shards took the buffer and some did not: their slot rings (and stream states) no longer agree.  Nothing can put the
+			// failed shard's streams back in step, so the object refuses further work instead of returning rows it never computed.
+			broken = e.what();
+			throw;
+		}
 		return ticket;
 	}
 
 	void MultiGpuBatch::Collect(int ticket, float* out)
 	{
+		CheckUsable();
 		Post([=](Shard& s) {
 			if (s.batch) s.batch->Collect(ticket, out ? out + (size_t)s.begin * s.batch->SlotFrames(ticket) : nullptr);
 		});

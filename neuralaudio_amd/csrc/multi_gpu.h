@@ -12,6 +12,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -71,6 +72,9 @@ namespace na
 			std::string error;
 		};
 		void Run(Shard& s);
+		void CheckShard(const Shard& s) const;
+		void CheckUsable() const;
+		void StopWorkers(); // joins the workers (each destroys its batch on its own thread) and drops the shards
 		void Post(const std::function<void(Shard&)>& f); // the same command on every shard's thread, waits for all, rethrows the first error
 
 		std::vector<int> devices;
@@ -78,5 +82,6 @@ namespace na
 		std::vector<std::unique_ptr<Shard>> shards;
 		int total = 0;
 		bool committed = false;
+		std::string broken; // set by a submission that only part of the shards took
 	};
 }

@@ -28,6 +28,9 @@ namespace na
 	constexpr int WN_MAX_FRAMES = WN_TILE * WN_MAX_TILES; // 128 frames per launch
 	constexpr int WN_MAX_RINGS = 64;
 	constexpr int WN_HEADER_F4 = WN_MAX_RINGS / 4; // header size in float4 units
+	// f16-split kernels: header[63] counts "range events" of the stream -- (wave, block) pairs in which a value left the f16 range and was
+	// saturated (only chains without a static range proof can get there; models with 64 rings do not run on those kernels)
+	constexpr int WN_RANGE_EVENT_SLOT = WN_MAX_RINGS - 1;
 
 	enum WnStageType : int
 	{
@@ -145,6 +148,7 @@ namespace na
 		int split_fast_T;     // fewest tiles per wave the fast instantiation can run this model with (2 or 4); 0: needs the generic one
 		int spec_arch;        // WnSpecArch: the compile-time specialised chain that runs this model (wavenet_spec_kernels.hip), 0: none
 		float cond_limit;     // f16-split kernels: input samples are clamped to +-cond_limit (WaveNetPlan::condLimit)
+		int saturate;         // f16-split kernels: 1 = no static range proof (WaveNetPlan::splitRangeProven): saturating split + range events
 	};
 
 	enum WnSpecArch : int

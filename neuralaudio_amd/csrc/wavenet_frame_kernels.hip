@@ -21,6 +21,7 @@
 // Why not the f32 16x16x4 tile mapping (tools/alternates/wavenet_tile_kernels.hip, round 1): measured on MI355X (tools/microbench/mfma_valu_overlap.hip)
 // f32 MFMA runs at the f32 VALU rate and does NOT overlap with VALU work on the same SIMD, so every padded MFMA row and
 // every activation evaluated on a padding lane is pure loss; the tile mapping pads 8-channel layers to 16 rows.
+#include "device_once.h"
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
@@ -1015,13 +1016,10 @@ namespace na
 			auto kernel = WaveNetFrameKernel<WPS, PF, SPB>;
 			if (lds > 64 * 1024)
 			{
-				static size_t granted = 0; // per instantiation
-				if (lds > granted)
-				{
-					const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-					if (e != hipSuccess) return e;
-					granted = lds;
-				}
+				// per instantiation and device: the whole LDS of a CU once (granting it does not change what a launch uses)
+				static PerDeviceOnce attr;
+				const hipError_t e = attr.Run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+				if (e != hipSuccess) return e;
 			}
 			hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WPS * SPB), lds, stream, args, maxA4F4, in, out, inStride, outStride, n,
 				GetWaveNetTraceBuffer(), []() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());

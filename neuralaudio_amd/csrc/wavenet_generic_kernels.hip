@@ -18,6 +18,7 @@
 //   a layer = publish X to its ring, load the ring history its taps need -> per tap: stage the tap's matrix, read the tap's input where
 //   the mat-mul wants it (X for in-block frames, the prefetched ring history for earlier ones), MFMA into register accumulators -> bias + mix-in + activation + head accumulate in the result lanes (the
 //   activation's split quad IS the 1x1's B operand: no LDS round trip) -> stage the 1x1 -> MFMA -> residual into X.
+#include "device_once.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -517,17 +518,15 @@ namespace na
 		// (64 channels: 64 + 64 KB, 48 channels: 48 + 36 KB, 32 channels: 32 + 16 KB -> three workgroups per CU)
 		const int nb = (maxChannels + 15) / 16, gq = (maxChannels + 3) / 4;
 		const size_t ldsBytes = (size_t)2 * gq * gn::FRAMES * 16 + (size_t)2 * nb * nb * 2 * 64 * 16 + gn::FRAMES * sizeof(float);
-		static int numCUs = 0;
-		if (numCUs == 0)
-		{
-			int dev = 0;
-			if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || numCUs <= 0) numCUs = 256;
+		const int numCUs = CurrentDeviceCUs();
+		static PerDeviceOnce attr;
+		(void)attr.Run([] {
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		}
+			return hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetGenericKernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		});
 		// NB = 16-channel blocks per matrix side
 		const dim3 grid((unsigned)numStreams), block(gn::NTHREADS);
 		if (nb <= 1) hipLaunchKernelGGL((gn::WaveNetGenericKernel<1, 4>), grid, block, ldsBytes, stream, a, in, out, inStride, outStride, n);

@@ -257,7 +257,24 @@ namespace na
 			// the "hi" operand carries Wh in all 8 slots, the "lo" operand Wl in the four h slots (zeros against l).
 			// Rows [rowBase, rowBase + cout) x k-blocks [kbBase, kbBase + ceil(cin/4)) receive W(o, c); everything else stays zero, so
 			// several tiles share one MFMA through block-diagonal operands (mode Gp: tile slot p owns rows 4*Gp*p.. and k-blocks Gp*p..).
-			double rangeGain = 1.0, rangeAdd = 0.0, rangeGainMax = 0.0, rangeAddMax = 0.0;
+			// Static range proof of the f16-split kernels.  With the input clamped to +-L every value that is ever split
+			// (residual stream x, activations z, head accumulator) is bounded by G * L + A; the pairs collected here give the largest L for
+			// which all of them stay below half the f16 range.  tanh layers add a bounded amount (|FastMath tanh| <= 1.0081), LeakyReLU layers
+			// (|f(v)| <= |v|) multiply: for them G grows with the worst-case row sums of every layer.
+			double rangeGain = 1.0, rangeAdd = 0.0;       // |x| <= rangeGain * L + rangeAdd
+			double rangeHeadGain = 0.0, rangeHeadAdd = 0.0; // |head accumulator| likewise
+			double linearGain = 1.0, linearGainMax = 0.0;   // the rechannel path alone (input -> array inputs)
+			std::vector<std::pair<double, double>> rangeCons;
+			double weightAbsMax = 0.0;      // largest |w| of the model
+			double matrixPeakMin = 1e300;   // smallest max|w| over its (non-zero) weight matrices
+			void RangeNote(double G, double A) { rangeCons.push_back({ G, A }); }
+			void NoteTensor(int off, size_t count, bool matrix)
+			{
+				double peak = 0.0;
+				for (size_t i = 0; i < count; i++) peak = std::max(peak, std::fabs((double)W(off + (int)i)));
+				weightAbsMax = std::max(weightAbsMax, peak);
+				if (matrix && peak > 0.0) matrixPeakMin = std::min(matrixPeakMin, peak);
+			}
 
 			int NewSplitOps(int count)
 			{
@@ -360,7 +377,10 @@ namespace na
 						}
 						rangeGain = (a == 0 ? 1.0 : rangeGain) * rowMax;
 						rangeAdd = (a == 0 ? 0.0 : rangeAdd) * rowMax;
-						rangeGainMax = std::max(rangeGainMax, rangeGain);
+						RangeNote(rangeGain, rangeAdd);
+						linearGain = (a == 0 ? 1.0 : linearGain) * rowMax;
+						linearGainMax = std::max(linearGainMax, linearGain);
+						NoteTensor(rechOff, (size_t)C * cfg.inputSize, true);
 					}
 					if (a == 0)
 					{
@@ -416,16 +436,45 @@ namespace na
 						const bool lastLayer = (l == numLayers - 1);
 						const bool needOutput = !(lastLayer && lastArray);
 						{
-							// the 1x1 adds at most max_o (sum_c |w1[o][c]| * 1.0081 + |b1[o]|) to the residual stream (|FastMath tanh| <= 1.0081)
-							double grow = 0.0;
+							NoteTensor(wconv, (size_t)C * C * K, true);
+							NoteTensor(bconv, (size_t)C, false);
+							NoteTensor(wmix, (size_t)C * cfg.conditionSize, true);
+							NoteTensor(w1, (size_t)C * C, needOutput); // (the very last 1x1 is dead, WaveNet.h:643,785: trained files hold denormals there)
+							NoteTensor(b1, (size_t)C, false);
+							// |z| <= zG * L + zA: 1.0081 for the rational tanh (the StdMath one: 1); LeakyReLU passes the conv's worst case on
+							double zG = 0.0, zA = 1.0081;
+							if (cfg.activation == ACT_LEAKYRELU)
+							{
+								double convRow = 0.0, mixMax = 0.0, biasMax = 0.0;
+								for (int o = 0; o < C; o++)
+								{
+									double row = 0.0;
+									for (int c = 0; c < C * K; c++) row += std::fabs((double)W(wconv + o * C * K + c));
+									convRow = std::max(convRow, row);
+									double mix = 0.0;
+									for (int c = 0; c < cfg.conditionSize; c++) mix += std::fabs((double)W(wmix + o * cfg.conditionSize + c));
+									mixMax = std::max(mixMax, mix);
+									biasMax = std::max(biasMax, std::fabs((double)W(bconv + o)));
+								}
+								zG = convRow * rangeGain + mixMax;
+								zA = convRow * rangeAdd + biasMax;
+							}
+							RangeNote(zG, zA);
+							rangeHeadGain = (l == 0 && a == 0 ? 0.0 : rangeHeadGain) + zG;
+							rangeHeadAdd = (l == 0 && a == 0 ? 0.0 : rangeHeadAdd) + zA;
+							RangeNote(rangeHeadGain, rangeHeadAdd);
+							// the 1x1 adds at most max_o (sum_c |w1[o][c]| * |z| + |b1[o]|) to the residual stream
+							double rowMax = 0.0, b1Max = 0.0;
 							for (int o = 0; o < C; o++)
 							{
-								double row = std::fabs((double)W(b1 + o));
-								for (int c = 0; c < C; c++) row += 1.0081 * std::fabs((double)W(w1 + o * C + c));
-								grow = std::max(grow, row);
+								double row = 0.0;
+								for (int c = 0; c < C; c++) row += std::fabs((double)W(w1 + o * C + c));
+								rowMax = std::max(rowMax, row);
+								b1Max = std::max(b1Max, std::fabs((double)W(b1 + o)));
 							}
-							rangeAdd += grow;
-							rangeAddMax = std::max(rangeAddMax, rangeAdd);
+							rangeGain += rowMax * zG;
+							rangeAdd += rowMax * zA + b1Max;
+							RangeNote(rangeGain, rangeAdd);
 						}
 
 						WnSplitStage st = EmptySplit(WN_ST_LAYER);
@@ -456,6 +505,23 @@ namespace na
 
 					const int wh = Take((size_t)cfg.headSize * C * cfg.headKernelSize);
 					const int bh = cfg.hasHeadBias ? Take((size_t)cfg.headSize) : -1;
+					NoteTensor(wh, (size_t)cfg.headSize * C * cfg.headKernelSize, true);
+					if (bh >= 0) NoteTensor(bh, (size_t)cfg.headSize, false);
+					if (!lastArray)
+					{
+						// the head rechannel's output is the next array's head accumulator (WaveNet.h:785-789)
+						double rowMax = 0.0, bMax = 0.0;
+						for (int o = 0; o < cfg.headSize; o++)
+						{
+							double row = 0.0;
+							for (int c = 0; c < C * cfg.headKernelSize; c++) row += std::fabs((double)W(wh + o * C * cfg.headKernelSize + c));
+							rowMax = std::max(rowMax, row);
+							if (bh >= 0) bMax = std::max(bMax, std::fabs((double)W(bh + o)));
+						}
+						rangeHeadGain *= rowMax;
+						rangeHeadAdd = rangeHeadAdd * rowMax + bMax;
+						RangeNote(rangeHeadGain, rangeHeadAdd);
+					}
 					if (lastArray)
 					{
 						// only head channel 0 reaches the output (WaveNet.h:793-798): one output row per tile slot
@@ -488,11 +554,25 @@ namespace na
 				}
 				for (const WnSplitStage& st : plan.sstages) plan.maxSplitOps = std::max(plan.maxSplitOps, st.a_ops);
 				// Range contract of the f16-split kernels: the hi half of every value is an f16 (|v| <= 65504).  With the input clamped to
-				// +-condLimit the residual stream stays below half of that: gain * limit + (what the bounded activations can add) <= 32752.
-				// (LeakyReLU models have no such bound on the added part: for them the limit only covers the linear path.)
+				// +-condLimit every split value stays below half of that: G * limit + A <= 32752 for every (G, A) collected above.  A model
+				// for which that leaves less than kSplitMinInputLimit -- or whose weights do not fit the operand format -- is not run by
+				// the f16-split kernels at all (splitRangeProven / splitWeightsOk -> the f32 frame kernel, gpu_batch.cpp FamilyFor).
 				{
-					const double room = std::max(1.0, 32752.0 - rangeAddMax);
-					plan.condLimit = (float)std::min(32752.0, std::max(1.0, room / std::max(1e-6, rangeGainMax)));
+					double limit = 32752.0;
+					for (const auto& c : rangeCons)
+					{
+						const double room = 32752.0 - c.second;
+						limit = std::min(limit, room <= 0.0 ? 0.0 : (c.first > 0.0 ? room / c.first : 32752.0));
+					}
+					plan.splitRangeProven = limit >= kSplitMinInputLimit;
+					// no proof (in practice: LeakyReLU models, whose worst case grows with the product of every layer's row sums): the limit
+					// then covers the rechannel path only, and the kernels that still run such a model -- the official A2 chains -- saturate
+					// at the f16 range and count the event instead of overflowing (wavenet_split_dev.h SplitQuadSat)
+					plan.condLimit = (float)(plan.splitRangeProven ? limit : std::min(32752.0, 32752.0 / std::max(1e-6, linearGainMax)));
+					// weights: |w| <= half the f16 range (hi + lo never overflow); every live weight MATRIX has its largest entry above
+					// 2^-12 -- a split value carries an absolute error of 2^-25 (f16 subnormals), so the entries that matter keep >= 13
+					// bits and nothing that matters is flushed to zero (|w| < 2^-25 is)
+					plan.splitWeightsOk = weightAbsMax <= 32752.0 && (matrixPeakMin >= 1.0 / 4096.0 || matrixPeakMin == 1e300);
 				}
 				// fast instantiation of the kernel: K == 3 everywhere, every array fills its lane mode (G == Gp), 1x1 heads, weight blocks
 				// within the fixed 16 KB staging part

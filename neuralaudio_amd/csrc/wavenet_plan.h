@@ -18,6 +18,8 @@ namespace na
 		int channels;   // real channel count
 	};
 
+	constexpr double kSplitMinInputLimit = 8.0; // +18 dBFS: below this input limit the f16-split kernels do not take a model
+
 	struct WaveNetPlan
 	{
 		std::vector<WnStage> stages;
@@ -39,7 +41,11 @@ namespace na
 		int stateF4 = 0;            // per-stream state in float4 units
 		int maxA4Floats = 0;        // largest per-stage A-operand block of the frame kernel (floats)
 		float headScale = 0.0f;
-		float condLimit = 32752.0f; // f16-split kernels: input samples are clamped to +-condLimit (range contract, DESIGN.md 2.2)
+		float condLimit = 32752.0f; // f16-split kernels: input samples are clamped to +-condLimit (range contract, DESIGN.md 2.5)
+		// static proof of that contract (wavenet_plan.cpp): with inputs inside +-condLimit >= kSplitMinInputLimit no value of the chain leaves
+		// the f16 range, and the weights fit the f16-split operand format.  A plan that fails either runs on the f32 frame kernel.
+		bool splitRangeProven = true;
+		bool splitWeightsOk = true;
 		int receptiveField = 0;
 
 		// roofline bookkeeping: compulsory HBM bytes and MACs per sample at block N

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "device_once.h"
 #include "wavenet_split_dev.h"
 
 namespace na
@@ -342,6 +343,15 @@ namespace na
 			u32x4 hist[5][2];  // ring history of the current layer's first HPF shifted taps [tap][set]
 		};
 
+		// f32 quad -> split quad: plain for the tanh chains (covered by the static range proof, wavenet_plan.cpp), saturating for the
+		// LeakyReLU ones
+		template <class C>
+		__device__ __forceinline__ u32x4 Split(f32x4 v, const Ctx& cx)
+		{
+			if constexpr (C::A::LEAKY) return SplitQuadSat(v, cx.srsrc);
+			else return SplitQuad(v);
+		}
+
 		// Byte offset of ring position (base + fl) mod R, channel group cg, relative to the ring's start: `base` in [0, R) is wave-uniform, the
 		// lane part fl < FW is folded into Lanes::ring, so the wrap is one unsigned min on the byte offset (3 VALU per access); the
 		// ring's start rides in the instruction's scalar offset.
@@ -664,7 +674,7 @@ namespace na
 #pragma unroll
 				for (int i = 0; i < S; i++)
 				{
-					const u32x4 zs = SplitQuad(z[i]);
+					const u32x4 zs = Split<C>(z[i], cx);
 					st.hd[i] = Mfma(idop, zs, st.hd[i]);
 					if constexpr (!LASTLAYER) // NeedOutput (WaveNet.h:643,785): the very last layer's 1x1 is dead
 					{
@@ -675,7 +685,7 @@ namespace na
 						st.xc[i] = y;
 						if constexpr (SG::NEXT)
 						{
-							st.xs[i] = SplitQuad(y);
+							st.xs[i] = Split<C>(y, cx);
 							Publish<C, LN, GP, NEXTMINSHIFT>(cx, ln, st.xs[i], i, imgWrite);
 						}
 					}
@@ -760,7 +770,7 @@ namespace na
 				x = Mfma(ra, ax, x);
 				st.xc[i] = x;
 				st.hd[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
-				st.xs[i] = SplitQuad(x);
+				st.xs[i] = Split<C>(x, cx);
 				Publish<C, 0, GP, C::TB::Dil(0)>(cx, ln, st.xs[i], i, 1);
 			}
 			FirstHistDispatch<C, 0, 0>(cx, ln.ring, ln.fl, st);
@@ -787,8 +797,8 @@ namespace na
 #pragma unroll
 			for (int i = 0; i < So; i++)
 			{
-				hs[i] = SplitQuad(st.hd[i]);
-				xq[i] = SplitQuad(st.xc[i]);
+				hs[i] = Split<C>(st.hd[i], cx);
+				xq[i] = Split<C>(st.xc[i], cx);
 			}
 			f32x4 hn[Sn], xn[Sn];
 #pragma unroll
@@ -813,7 +823,7 @@ namespace na
 			{
 				st.hd[i] = hn[i];
 				st.xc[i] = xn[i];
-				st.xs[i] = SplitQuad(xn[i]);
+				st.xs[i] = Split<C>(xn[i], cx);
 				Publish<C, LN, GPN, TB::Dil(LN)>(cx, ln, st.xs[i], i, (s + 1) & 1);
 			}
 			FirstHistDispatch<C, LN, 0>(cx, ln.ring, ln.fl, st);
@@ -839,7 +849,7 @@ namespace na
 #pragma unroll
 			for (int i = 0; i < S; i++)
 			{
-				hs[i] = SplitQuad(st.hd[i]);
+				hs[i] = Split<C>(st.hd[i], cx);
 				acc[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 			}
 #pragma unroll
@@ -1157,6 +1167,7 @@ namespace na
 				a.nstages = m.nstages; a.nrings = m.nrings; a.stateF4 = m.state_f4; a.wsplitQuads = m.wsplit_quads;
 				a.headScale = m.head_scale;
 				a.condLimit = m.cond_limit;
+				a.saturate = m.saturate;
 				a.numStreams = g.numStreams; a.slot0 = g.slot0; a.row0 = g.row0;
 				a.maxG = m.max_G;
 				a.firstBlock = blocks;
@@ -1174,13 +1185,9 @@ namespace na
 			constexpr int LDS_BYTES = C::LDS_BYTES > C1::LDS_BYTES ? C::LDS_BYTES : C1::LDS_BYTES;
 			if (LDS_BYTES > 64 * 1024)
 			{
-				static bool granted = false; // per instantiation
-				if (!granted)
-				{
-					const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(WaveNetSpecKernel<F, NF, SPB, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-					if (e != hipSuccess) return e;
-					granted = true;
-				}
+				static PerDeviceOnce attr; // per instantiation and device
+				const hipError_t e = attr.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(WaveNetSpecKernel<F, NF, SPB, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); });
+				if (e != hipSuccess) return e;
 			}
 			hipLaunchKernelGGL((WaveNetSpecKernel<F, NF, SPB, PK>), dim3((unsigned)blocks), dim3(C::NTHREADS), LDS_BYTES, stream, args, in, out, inStride, outStride
 #ifdef NA_SP_TRACE

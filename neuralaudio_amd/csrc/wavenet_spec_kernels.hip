@@ -68,11 +68,7 @@ namespace na
 		// compiler keep a layer's LDS reads in flight (Nano x 1024 = 256 packed streams 25.1 -> 22.6 us, Feather x 1024 24.3 -> 22.2,
 		// Standard x 512 25.4 -> 23.4).  They are used while every workgroup is resident at that occupancy: at most two per CU.
 		static const int spbEnv = getenv("NA_SP_SPB") ? atoi(getenv("NA_SP_SPB")) : 0;
-		static const int residentHalf = [] {
-			int dev = 0, cus = 0;
-			if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-			return 2 * cus;
-		}();
+		const int residentHalf = 2 * CurrentDeviceCUs();
 		int halfGroups = 0; // workgroups of the launch at SPB = 1 (an A2-Lite workgroup holds two streams there: T = 4)
 		for (int i = 0; i < numGroups; i++)
 		{

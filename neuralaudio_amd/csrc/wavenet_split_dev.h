@@ -86,6 +86,30 @@ namespace na
 			return q;
 		}
 
+		// Saturating variant for chains the static range proof does not cover (LeakyReLU models: wavenet_plan.cpp): a value
+		// beyond the f16 range is clamped to +-65504 instead of becoming inf (inf - inf = NaN in the lo half would poison the ring for
+		// good), and the wave counts a "range event" in the stream's state header right there (WN_RANGE_EVENT_SLOT; one atomic through
+		// the state resource the wave holds anyway -- the chains have no register to spare for a flag carried to the end of the block, and
+		// the branch is never taken on audio).  Inside the range it is SplitQuad bit for bit.
+		__device__ __forceinline__ u32x4 SplitQuadSat(f32x4 v, __amdgpu_buffer_rsrc_t state)
+		{
+			const float m = 65504.0f;
+			const float top = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+			v.x = __builtin_amdgcn_fmed3f(v.x, -m, m);
+			v.y = __builtin_amdgcn_fmed3f(v.y, -m, m);
+			v.z = __builtin_amdgcn_fmed3f(v.z, -m, m);
+			v.w = __builtin_amdgcn_fmed3f(v.w, -m, m);
+			if (__builtin_amdgcn_ballot_w64(top > m) != 0)
+			{
+				// (a shadow wave's zero-sized resource drops the access)
+				if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+					__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, state, WN_RANGE_EVENT_SLOT * 4, 0, 0);
+				// the stages count their VMEM operations (s_waitcnt vmcnt(N) before a barrier): the extra one must not shift that count
+				__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+			}
+			return SplitQuad(v);
+		}
+
 		// Activation.h:83-91, plain (unpacked) VALU on purpose: packed f32 instructions do not issue beside MFMAs on gfx950
 		// (tools/microbench/mfma_f16_valu_mix.hip).  |x + e*x*|x|| == |x| + e*x^2 since 1 + e|x| > 0; division = num * v_rcp_f32(den).
 		__device__ __forceinline__ float FastTanh(float x)
@@ -177,6 +201,7 @@ namespace na
 			float condLimit; // input samples are clamped to +-condLimit (WnModelDev::cond_limit), NaN reads as silence
 			int arch;       // specialised chains (wavenet_spec_kernels.hip): which member of the launch's architecture family
 			int gps0, gps1; // ... packed launches: channel groups per real stream of the first / the last layer array (1, 2, 4)
+			int saturate;   // stage interpreter: 1 = split with SplitQuadSat and count range events (models without a range proof)
 		};
 
 		struct LaunchArgs

@@ -26,6 +26,7 @@
 //   * bias and the input mix-in ride in the MFMA too: an "aux" operand (cond, 1, 0, 0) per frame against weights (w_mix, bias).
 // A wave owns T consecutive tiles of one stream's block; a workgroup = SPB streams x (8 / T) waves sharing one staged copy of the
 // weights; one LDS-only barrier per layer (the dependency is causal).
+#include "device_once.h"
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
@@ -96,6 +97,7 @@ namespace na
 			int n, nSt;                   // frames in the block; frames this wave may store (0 for a shadow wave)
 			int F0;                       // first frame of this wave
 			int lane, j, q, waveAll;
+			int saturate;                 // wave-uniform: SplitQuadSat instead of SplitQuad (GroupArgs::saturate)
 			float* __restrict__ out;
 			size_t outBase;
 			float headScale;
@@ -202,6 +204,15 @@ namespace na
 			f32x4 xc[T]; // layer input (residual stream), f32; its split quad lives in the LDS block image (the unshifted tap reads it back)
 			f32x4 hd[T]; // head accumulator
 		};
+
+		// f32 quad -> split quad; saturating (and tracking the peak) for models without a static range proof -- same places, same values
+		// as the specialised chains (wavenet_spec_impl.h Split)
+		template <int T>
+		__device__ __forceinline__ u32x4 SplitOf(const Ctx& cx, State<T>& st, f32x4 v)
+		{
+			if (cx.saturate) return SplitQuadSat(v, cx.srsrc);
+			return SplitQuad(v);
+		}
 
 		// The lane index goes through an opaque asm at the start of every stage function: without it the compiler hoists the lane
 		// geometry (frames, channel groups, LDS / ring address parts) of EVERY inlined stage variant to the top of the kernel and
@@ -414,7 +425,7 @@ namespace na
 #pragma unroll
 					for (int i = 0; i < S; i++)
 					{
-						const u32x4 zs = SplitQuad(z[i]);
+						const u32x4 zs = SplitOf(cx, st, z[i]);
 						const u32x4 ax = AuxOf<PK>(cx, f[i], cg[i], gsShift);
 						st.hd[i] = Mfma(idop, zs, st.hd[i]);
 						f32x4 y = st.xc[i];
@@ -423,7 +434,7 @@ namespace na
 						y = Mfma(b1a, ax, y);
 						st.xc[i] = y;
 						// always one store per set (predicated through the offset): fixed VMEM count per layer
-						Publish(cx, imgNext, SplitQuad(y), f[i], cg[i], pub && (!GEN || (live[i] && cg[i] < sd.out_G)), sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0,
+						Publish(cx, imgNext, SplitOf(cx, st, y), f[i], cg[i], pub && (!GEN || (live[i] && cg[i] < sd.out_G)), sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0,
 							pub ? cx.nSt : 0);
 					}
 				}
@@ -462,7 +473,7 @@ namespace na
 				x = Mfma(ra, ax, x);
 				st.xc[i] = x;
 				st.hd[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
-				Publish(cx, imgNext, SplitQuad(x), f, cg, live && cg < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
+				Publish(cx, imgNext, SplitOf(cx, st, x), f, cg, live && cg < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
 			}
 			cur ^= 1;
 			SP_STAMP(1); SP_STAMP(2); SP_STAMP(3);
@@ -496,8 +507,8 @@ namespace na
 			{
 				int f, cg; bool live;
 				FrameOf<GPO, T>(cx, lane, i, f, cg, live);
-				hs[i] = SplitQuad(st.hd[i]);
-				xs[i] = SplitQuad(st.xc[i]);
+				hs[i] = SplitOf(cx, st, st.hd[i]);
+				xs[i] = SplitOf(cx, st, st.xc[i]);
 				if (Geo<GPO, T>::PARTIAL || GPO == 4)
 				{
 					const bool ok = live && cg < sd.G;
@@ -534,7 +545,7 @@ namespace na
 			{
 				st.hd[i] = hn[i];
 				st.xc[i] = xn[i];
-				Publish(cx, imgNext, SplitQuad(xn[i]), fn[i], cgn[i], liven[i] && cgn[i] < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
+				Publish(cx, imgNext, SplitOf(cx, st, xn[i]), fn[i], cgn[i], liven[i] && cgn[i] < sd.out_G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, outPos0, cx.nSt);
 			}
 			cur ^= 1;
 			SP_STAMP(1); SP_STAMP(2); SP_STAMP(3);
@@ -563,7 +574,7 @@ namespace na
 			for (int i = 0; i < S; i++)
 			{
 				FrameOf<GP, T>(cx, lane, i, f[i], cg[i], live[i]);
-				hs[i] = SplitQuad(st.hd[i]);
+				hs[i] = SplitOf(cx, st, st.hd[i]);
 				if (Geo<GP, T>::PARTIAL || GP == 4) hs[i] = (live[i] && cg[i] < G) ? hs[i] : u32x4{ 0, 0, 0, 0 };
 			}
 			f32x4 acc[S];
@@ -686,6 +697,7 @@ namespace na
 			cx.out = out;
 			cx.outBase = (size_t)row * outStride;
 			cx.headScale = ga.headScale;
+			cx.saturate = ga.saturate;
 			cx.trace = ((int)blockIdx.x == traceBlock) ? trace : nullptr;
 			cx.nwaves = NTHREADS / 64;
 #ifdef NA_SP_TRACE
@@ -810,6 +822,7 @@ namespace na
 				a.nstages = m.nstages; a.nrings = m.nrings; a.stateF4 = m.state_f4; a.wsplitQuads = m.wsplit_quads;
 				a.headScale = m.head_scale;
 				a.condLimit = m.cond_limit;
+				a.saturate = m.saturate;
 				a.numStreams = g.numStreams; a.slot0 = g.slot0; a.row0 = g.row0;
 				a.maxG = m.max_G;
 				a.firstBlock = blocks;
@@ -826,13 +839,10 @@ namespace na
 			auto kernel = WaveNetSplitKernel<T, SPB, WPS, GEN, PK>;
 			if (lds > 64 * 1024)
 			{
-				static size_t granted = 0; // per instantiation
-				if (lds > granted)
-				{
-					const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-					if (e != hipSuccess) return e;
-					granted = lds;
-				}
+				// per instantiation and device: the whole LDS of a CU once (granting it does not change what a launch uses)
+				static PerDeviceOnce attr;
+				const hipError_t e = attr.Run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+				if (e != hipSuccess) return e;
 			}
 			hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WPS * SPB), lds, stream, args, maxG, wstride, in, out, inStride, outStride, n, GetWaveNetTraceBuffer(),
 				[]() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());

@@ -30,35 +30,5 @@ def shard_ranges(costs: Sequence[float], world_size: int) -> List[Tuple[int, int
     return [(int(bounds[r]), int(bounds[r + 1])) for r in range(world_size)]
 
 
-def shard_ranges_reference(costs: Sequence[float], world_size: int) -> List[Tuple[int, int]]:
-    """The same partition in plain Python (tests compare the two)."""
-    n = len(costs)
-    if world_size < 1:
-        raise ValueError("world_size must be >= 1")
-    total = float(sum(costs))
-    ranges = []
-    begin = 0
-    acc = 0.0
-    for rank in range(world_size):
-        if rank == world_size - 1:
-            end = n
-        else:
-            target = total * (rank + 1) / world_size
-            end = begin
-            while end < n and acc + costs[end] <= target + 1e-9:
-                acc += costs[end]
-                end += 1
-            # at least one stream per rank while streams remain: take one even if it alone overshoots the share,
-            # and leave one for each remaining rank
-            cap = max(begin, n - (world_size - rank - 1))
-            if end == begin and end < cap:
-                end += 1
-            end = min(end, cap)
-            acc = float(sum(costs[:end]))
-        ranges.append((begin, end))
-        begin = end
-    return ranges
-
-
 def my_range(costs: Sequence[float], rank: int, world_size: int) -> Tuple[int, int]:
     return shard_ranges(costs, world_size)[rank]

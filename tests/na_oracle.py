@@ -404,6 +404,40 @@ def synth_wavenet_weights(arrays, seed):
     return np.concatenate(out).astype(np.float32)
 
 
+def wavenet_tensor_slices(arrays):
+    """(name, array index, layer index or -1, slice into the flat weights) of every tensor, in the reference's order (WaveNet.h:700-719)."""
+    out, pos = [], 0
+
+    def take(name, a, l, n):
+        nonlocal pos
+        out.append((name, a, l, slice(pos, pos + n)))
+        pos += n
+
+    for ai, a in enumerate(arrays):
+        c = a["channels"]
+        take("rechannel", ai, -1, c * a["input_size"])
+        for li, k in enumerate(a["kernel_sizes"]):
+            take("conv", ai, li, c * c * k)
+            take("conv_bias", ai, li, c)
+            take("mixin", ai, li, c * a["condition_size"])
+            take("1x1", ai, li, c * c)
+            take("1x1_bias", ai, li, c)
+        take("head", ai, -1, a["head_size"] * c * a["head_kernel_size"])
+        if a["has_head_bias"]:
+            take("head_bias", ai, -1, a["head_size"])
+    take("head_scale", -1, -1, 1)
+    return out
+
+
+def scale_wavenet_tensors(arrays, weights, factors):
+    """A copy of the flat weights with every tensor called `name` multiplied by factors[name]."""
+    w = np.array(weights, dtype=np.float32, copy=True)
+    for name, _, _, sl in wavenet_tensor_slices(arrays):
+        if name in factors:
+            w[sl] *= np.float32(factors[name])
+    return w
+
+
 def synth_lstm_weights(num_layers, hidden, seed):
     rng = np.random.default_rng(seed)
     out = []

@@ -38,7 +38,7 @@ def _random_arrays(rng):
                  dilations=[int(rng.choice([1, 2, 3, 7, 13, 17, 41, 64, 101, 239])) for _ in range(nl)])]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("NA_FUZZ_ARCH_SEEDS", "24"))))  # (a longer campaign: NA_FUZZ_ARCH_SEEDS=200)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NA_FUZZ_ARCH_SEEDS", "64"))))  # (a longer campaign: NA_FUZZ_ARCH_SEEDS=200)
 def test_random_architecture_matches_oracle(na, seed):
     rng = np.random.default_rng(1000 + seed)
     arrays = _random_arrays(rng)
@@ -73,7 +73,7 @@ def test_lstm_shapes_beyond_the_official_ones(na, hidden, layers):
     assert O.rms(y - O.OracleLSTM.from_nam(layers, hidden, w).process(x)) < 5e-6
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("NA_FUZZ_BATCH_SEEDS", "3"))))  # (a longer campaign: NA_FUZZ_BATCH_SEEDS=60)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NA_FUZZ_BATCH_SEEDS", "12"))))  # (a longer campaign: NA_FUZZ_BATCH_SEEDS=60)
 def test_random_batch_operations_track_per_stream_oracles(na, seed):
     """A stateful walk over the batch API: streams of four model kinds join at random times (prewarmed or fresh), A2 streams switch
     quality mid-run, single streams are re-prewarmed, streams LEAVE and their ids / state slots are recycled by later joins (also

@@ -85,6 +85,80 @@ def test_cpp_api_is_exported_and_a_cpp_host_links(na, tmp_path):
     assert r.stdout.split() == ["0", "48000", "4092", "1"]
 
 
+# declaration order of the virtuals of the reference's class NeuralModel (NeuralAudio/NeuralModel.h:40-134; the two destructor entries
+# take slots 0 and 1)
+REFERENCE_VIRTUAL_ORDER = ["GetLoadMode", "HasQualityScaling", "GetQualityScaleFactor", "IsQualityChangeRealtimeSafe", "SetQualityScaleFactor",
+                           "IsStatic", "SetMaxAudioBufferSize", "SetAudioInputLevelDBu", "GetAudioInputLevelDBu",
+                           "GetRecommendedInputDBAdjustment", "GetRecommendedOutputDBAdjustment", "GetSampleRate", "GetReceptiveFieldSize",
+                           "GetModelVersion", "GetMetadata", "Process", "Prewarm"]
+
+
+def test_vtable_slots_follow_the_reference_header(na, tmp_path):
+    """Binary-level drop-in of the C++ class: every virtual sits in the vtable slot a host compiled against the reference's
+    NeuralModel.h expects (slots follow declaration order), and the object has the reference's data members
+    (5 floats, a string, a vector: NeuralModel.h:139-145)."""
+    exe = tmp_path / "vtable_slots"
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "vtable_slots.cpp"), "-o", str(exe)], check=True)
+    lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    slots = {l.split()[0]: int(l.split()[1]) for l in lines if l and not l.startswith("sizeof")}
+    assert [n for n, _ in sorted(slots.items(), key=lambda kv: kv[1])] == REFERENCE_VIRTUAL_ORDER
+    assert sorted(slots.values()) == list(range(2, 2 + len(REFERENCE_VIRTUAL_ORDER)))
+    # vptr + 5 floats (padded to 8) + std::string + std::vector
+    assert int([l for l in lines if l.startswith("sizeof")][0].split()[1]) == 8 + 24 + 32 + 24
+    ref = "/root/reference/NeuralAudio/NeuralModel.h"
+    if os.path.exists(ref):  # (this container only: the list above against the header itself)
+        text = open(ref).read()
+        body = text[text.index("class NeuralModel"):text.index("class NeuralModelLoader")]
+        assert re.findall(r"virtual\s+[\w:<>]+\s+(\w+)\s*\(", body) == REFERENCE_VIRTUAL_ORDER
+
+
+def test_range_proof_decides_the_wavenet_kernel_family(na):
+    """the f16-split kernels run a model only when the plan builder proves that no value leaves the f16 range for inputs
+    within a limit >= 8 and that the weights fit the operand format; everything else runs on the f32 frame kernel (host-side decision,
+    NA_ModelKernelInfo -- the GPU tests check the kernel that really runs and its parity)."""
+    loader = na.NeuralModelLoader()
+    std = loader.CreateFromFile(os.path.join(O.MODELS_DIR, "BossWN-standard.nam"), doPrewarm=False)
+    info = std.KernelInfo(1.0, 1024)
+    assert info["kernel"] == "f16-split" and info["range_proven"] and info["weights_ok"] and 8.0 <= info["input_limit"] <= 32752.0
+    arrays = O.a1_arrays(16, 8)
+    w = O.synth_wavenet_weights(arrays, seed=5)
+
+    def info_of(weights, arr=arrays, streams=1024):
+        m = loader.CreateFromString(O.nam_json_wavenet_generic(arr, weights), ".nam", doPrewarm=False)
+        assert m is not None
+        return m.KernelInfo(1.0, streams)
+
+    assert info_of(w)["kernel"] == "f16-split"
+    # tanh bounds what a layer adds to the residual stream by the row sums of its 1x1: x 4000 they sum past the f16 range
+    big = info_of(O.scale_wavenet_tensors(arrays, w, {"1x1": 4000.0}))
+    assert big["kernel"] == "frame" and not big["range_proven"] and big["weights_ok"] and big["input_limit"] == float("inf")
+    # a moderate scale only lowers the input limit
+    mid = info_of(O.scale_wavenet_tensors(arrays, w, {"1x1": 30.0}))
+    assert mid["kernel"] == "f16-split" and mid["range_proven"] and 8.0 <= mid["input_limit"] < info_of(w)["input_limit"]
+    # weights beyond half the f16 range / a weight matrix below 2^-12: not representable as (hi, lo) f16 pairs
+    assert info_of(O.scale_wavenet_tensors(arrays, w, {"mixin": 1e5}))["weights_ok"] is False
+    assert info_of(O.scale_wavenet_tensors(arrays, w, {"mixin": 1e5}))["kernel"] == "frame"
+    tiny = info_of(O.scale_wavenet_tensors(arrays, w, {"rechannel": 1e-6}))
+    assert tiny["kernel"] == "frame" and not tiny["weights_ok"]
+    # narrow models: no packing without the proof (packing means the f16-split kernels)
+    nano = O.a1_arrays(4, 2)
+    wn = O.synth_wavenet_weights(nano, seed=6)
+    assert info_of(wn, nano, 4096)["pack"] == 4 and info_of(wn, nano, 4096)["kernel"] == "f16-split"
+    bad = info_of(O.scale_wavenet_tensors(nano, wn, {"1x1": 1e4}), nano, 4096)
+    assert bad["pack"] == 1 and bad["kernel"] == "frame"
+    # LeakyReLU: the worst case grows with the product of the layers' row sums.  The official A2 shapes stay on their chains
+    # (saturating arithmetic + NA_BatchStreamRangeEvents); any other LeakyReLU model without a proof runs in f32
+    a2 = loader.CreateFromFile(os.path.join(O.MODELS_DIR, "BossWN-a2.nam"), doPrewarm=False)
+    for q in (0.0, 1.0):
+        ia = a2.KernelInfo(q, 1024)
+        assert ia["kernel"] == "f16-split" and not ia["range_proven"] and ia["weights_ok"] and 8.0 <= ia["input_limit"] <= 32752.0
+    for layers, want in ((2, "f16-split"), (14, "frame")):
+        leaky = [dict(input_size=1, condition_size=1, head_size=1, head_kernel_size=1, head_dilation=1, channels=16, has_head_bias=True,
+                      activation=O.ACT_LEAKYRELU, kernel_sizes=[3] * layers, dilations=[1 << (i % 9) for i in range(layers)])]
+        il = info_of(O.synth_wavenet_weights(leaky, seed=7), leaky)
+        assert il["kernel"] == want and il["range_proven"] == (want == "f16-split"), (layers, il)
+
+
 def test_modeltest_host_builds_and_reports_a_missing_gpu(na):
     """tools/ModelTest (the reference's Utils/ModelTest counterpart) is a C++ host of the exported API; without a device it must say so."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "tools", "ModelTest")], check=True, capture_output=True)
@@ -556,12 +630,43 @@ def test_a2_engine_selection_predicates(na):
         assert classify(O.load_json(a1)) == 0
 
 
+def _shard_ranges_in_python(costs, world_size):
+    """NA_ShardByCost (csrc/multi_gpu.cpp) once more in plain Python: the test below compares the two."""
+    n = len(costs)
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    total = float(sum(costs))
+    ranges = []
+    begin = 0
+    acc = 0.0
+    for rank in range(world_size):
+        if rank == world_size - 1:
+            end = n
+        else:
+            target = total * (rank + 1) / world_size
+            end = begin
+            while end < n and acc + costs[end] <= target + 1e-9:
+                acc += costs[end]
+                end += 1
+            # at least one stream per rank while streams remain: take one even if it alone overshoots the share,
+            # and leave one for each remaining rank
+            cap = max(begin, n - (world_size - rank - 1))
+            if end == begin and end < cap:
+                end += 1
+            end = min(end, cap)
+            acc = float(sum(costs[:end]))
+        ranges.append((begin, end))
+        begin = end
+    return ranges
+
+
+
 def test_shard_by_cost_matches_the_python_restatement_and_covers_everything():
     """NA_ShardByCost (csrc/multi_gpu.cpp) is the partition both multi-GPU hosts use (the C++ NA_Multi* host and bench.py's
     one-process-per-GPU ranks through neuralaudio_amd.sharding): contiguous, ordered, disjoint, complete, near-equal cost, at least one
     item per range while items remain -- and identical to the plain-Python restatement."""
     import numpy as np
-    from neuralaudio_amd.sharding import shard_ranges, shard_ranges_reference
+    from neuralaudio_amd.sharding import shard_ranges
     rng = np.random.default_rng(0)
     cases = [([1.0] * 8192, 8), ([41.6] * 4096 + [20.2] * 4096, 8), ([46.6] * 8192 + [71.4] * 8192, 8), ([1.0, 3.0, 1.0, 1.0, 2.0, 1.0, 1.0], 2),
              ([5.0], 4), ([], 3), ([0.0] * 10, 3), ([1.0] * 3, 8)]
@@ -570,7 +675,7 @@ def test_shard_by_cost_matches_the_python_restatement_and_covers_everything():
         cases.append((list(rng.choice([20.2, 33.7, 41.6, 71.4], size=n) * rng.uniform(0.5, 2.0)), int(rng.integers(1, 9))))
     for costs, parts in cases:
         got = shard_ranges(costs, parts)
-        assert got == shard_ranges_reference(costs, parts), (costs[:8], parts, got)
+        assert got == _shard_ranges_in_python(costs, parts), (costs[:8], parts, got)
         assert len(got) == parts and got[0][0] == 0 and got[-1][1] == len(costs)
         assert all(a <= b for a, b in got) and all(got[i][1] == got[i + 1][0] for i in range(parts - 1))
         if len(costs) >= parts:
