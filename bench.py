@@ -55,57 +55,13 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(workload="standard", seconds_target=12.0):
-    """The oracle ('port' of the reference's Internal CPU path) timed on this box's host cores,
-    ModelTest protocol (blocks of zeros after prewarm, Utils/ModelTest/ModelTest.cpp:59-79)."""
-    import ctypes as C
-    import numpy as np
-    import na_oracle as O  # cpu_baseline leg only
+PORT_NOTE = ("kind 'port' = oracle/na_oracle.c, a scalar C restatement built -O3 -march=native: it has none of the reference's Eigen "
+             "vectorisation / MULTIFRAME_8X8 conv tiling, so it understates the reference's CPU path")
 
-    lib = O.load_native_lib()
-    files = {"standard": "BossWN-standard.nam", "feather": "BossWN-feather.nam", "nano": "BossWN-nano.nam", "a2full": "BossWN-a2.nam",
-             "a2lite": "BossWN-a2.nam", "lstm1x16": "BossLSTM-1x16.nam", "lstm2x8": "BossLSTM-2x8.nam"}
-    if workload == "lite":
-        j = json.loads(synthetic_lite_nam())
-        files = dict(files, lite="synthetic A1 Lite (12/6 channels, seeded weights)")
-    elif workload not in files:
-        raise ValueError("no CPU baseline for workload " + workload)
-    else:
-        j = O.load_json(files[workload])
-    if j["architecture"] == "SlimmableContainer":
-        j = j["config"]["submodels"][O.quality_to_submodel(j, 0.0 if workload == "a2lite" else 1.0)]["model"]
-    w = np.ascontiguousarray(j["weights"], dtype=np.float32)
-    wp = w.ctypes.data_as(C.POINTER(C.c_float))
-    if j["architecture"] == "LSTM":
-        nl, hid = int(j["config"]["num_layers"]), int(j["config"]["hidden_size"])
-        lib.na_oracle_lstm_bench.restype = C.c_double
-        lib.na_oracle_lstm_bench.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_int, C.c_int]
 
-        def run(blocks, threads):
-            return lib.na_oracle_lstm_bench(nl, hid, wp, w.size, BLOCK, blocks, threads)
-    else:
-        arrays = O.wavenet_arrays_from_nam(j)
-        cfgs = O._cfgs(arrays)
-
-        def run(blocks, threads):
-            return lib.na_oracle_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, blocks, threads)
-    cores = usable_cores()
-    # calibrate on a short all-core run, then size the timed run to ~seconds_target of wall time
-    t1 = run(32, 1)
-    single = 32 * BLOCK / t1
-    tc = run(16, cores)
-    per_thread = 16 * BLOCK / tc
-    blocks = max(16, min(int(seconds_target * per_thread / BLOCK), 2000000))
-    t = run(blocks, cores)
-    total = cores * blocks * BLOCK
-    return {
-        "value": total / t / 1e6,
-        "unit": "Msamples/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": "%s: %d threads x %d buffers of %d zero samples each after prewarm (ModelTest protocol), %.1f s wall; "
-                  "single-thread %.3f Msamples/s (%.1fx real-time)" % (files[workload], cores, blocks, BLOCK, t, single / 1e6, single / 48000.0),
-    }
+def _timed_cpu_run(run, label, seconds_target):
+    """run(blocks, threads) -> wall seconds of `threads` independent copies each processing `blocks` buffers of BLOCK zeros."""
+    return _timed_cpu_run(run, files[workload], seconds_target)
 
 
 def synthetic_lite_nam():
@@ -139,11 +95,49 @@ def synthetic_lite_nam():
 
 
 def mixed_cpu_baseline(parts, seconds_target=12.0):
-    """Stream-weighted CPU baseline of a mixed batch: equal stream counts per model -> harmonic mean of the per-model rates."""
-    res = [cpu_baseline(w, seconds_target / len(parts)) for w in parts]
+    """Stream-weighted CPU baseline of a mixed batch: equal stream counts per model -> harmonic mean of the per-model rates.
+    `parts`: workload names, or ready-made (kind, model json) pairs for config 4's synthetic recurrent models."""
+    res = [cpu_baseline(w, seconds_target / len(parts)) if isinstance(w, str) else cpu_baseline_synthetic_recurrent(w[0], w[1], seconds_target / len(parts))
+           for w in parts]
     rate = len(res) / sum(1.0 / r["value"] for r in res)
     return {"value": rate, "unit": "Msamples/s", "cores": res[0]["cores"], "kind": "port",
             "sample": "harmonic mean over equal stream shares of: " + " | ".join(r["sample"] for r in res)}
+
+
+def parity_spot_check(check_rows, x, y, issued, nbuf, mdir):
+    """RMS difference between the kernel's output of the last issued step and the CPU oracle (checker only) for one stream per model."""
+    import numpy as np
+    import na_oracle as O  # checker only
+    y_host = y.cpu().numpy()
+    x_host = None
+    worst, per_model = 0.0, []
+    for row, (kind, spec), q in check_rows:
+        if kind == "file":
+            j = O.load_json(spec)
+            recurrent = j.get("architecture") == "LSTM"
+            ora = O.oracle_from_file(spec, quality=q, prewarm=False)
+            label = spec
+        elif kind == "wavenet_json":
+            j = json.loads(spec)
+            ora = O.OracleWaveNet(O.wavenet_arrays_from_nam(j), np.asarray(j["weights"], dtype=np.float32), prewarm=False)
+            recurrent, label = False, "synthetic A1 Lite"
+        elif kind == "lstm_json":
+            j = json.loads(spec)
+            ora = O.OracleLSTM.from_nam(int(j["config"]["num_layers"]), int(j["config"]["hidden_size"]), np.asarray(j["weights"], dtype=np.float32), prewarm=False)
+            recurrent, label = True, "synthetic LSTM"
+        else:
+            ora = O.OracleGRU(json.loads(spec), prewarm=False)
+            recurrent, label = True, "synthetic GRU"
+        # a WaveNet's state IS its last receptive field of inputs (4092 frames A1, 6346 A2): replay that and a margin from zero history
+        tail = min(issued, 600 if recurrent else (ora.receptive_field + BLOCK - 1) // BLOCK + 2)
+        if x_host is None:
+            x_host = x.cpu().numpy()
+        xin = np.concatenate([x_host[k % nbuf][row] for k in range(issued - tail, issued)])
+        ref = ora.process(xin)[-BLOCK:]
+        err = float(np.sqrt(np.mean((y_host[row].astype(np.float64) - ref.astype(np.float64)) ** 2)))
+        worst = max(worst, err)
+        per_model.append({"model": label, "quality": q, "row": int(row), "rms": err, "replayed_buffers": int(tail), "output_rms": float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))})
+    return {"rms": worst, "per_model": per_model}
 
 
 def spawn_ranks(n):
@@ -174,6 +168,7 @@ def main():
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (default: the BASELINE config)")
     ap.add_argument("--block", type=int, default=BLOCK, help="samples per buffer (default 128 = the BASELINE config; other sizes are exploration only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle spot check of the last timed step")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed sustained load before warm-up so the shader clock reaches steady state")
     ap.add_argument("--workload", default="standard",
                     help="standard (default = the BASELINE metric's config) | lite | feather | nano | a2full | a2lite | lstm1x16 | lstm2x8 | "
@@ -223,9 +218,14 @@ def main():
              "lite": [], "config3": ["BossWN-feather.nam", "BossWN-nano.nam"], "config4": [], "config5": ["BossWN-a2.nam"]}[args.workload]
     quality = 0.0 if args.workload == "a2lite" else 1.0
     models = [loader.CreateFromFile(os.path.join(mdir, f), doPrewarm=False) for f in files]
+    # how the parity spot check builds the CPU oracle of each model: ("file", name) | ("wavenet_json", text) | ("lstm_json", text) | ("gru_json", text)
+    oracle_specs = [("file", f) for f in files]
+    synthetic_json = {}
     if args.workload in ("lite", "config3"):
-        models.insert(0, loader.CreateFromString(synthetic_lite_nam(), ".nam", doPrewarm=False))
+        lite_text = synthetic_lite_nam()
+        models.insert(0, loader.CreateFromString(lite_text, ".nam", doPrewarm=False))
         files = ["synthetic-A1-lite"] + files
+        oracle_specs.insert(0, ("wavenet_json", lite_text))
     if args.workload == "config4":
         # BASELINE configs[3]: LSTM 2x16 + keras GRU (H=16), half/half; no such files ship with the reference -> seeded U(-a, a) weights
         rng = np.random.default_rng(4)
@@ -238,6 +238,8 @@ def main():
                                                                   rng.uniform(-a, a, (2, 3 * H)).tolist()]},
             {"type": "dense", "shape": [None, None, 1], "weights": [rng.uniform(-a, a, (H, 1)).tolist(), [0.0]]}]})
         models = [loader.CreateFromString(lstm, ".nam", doPrewarm=False), loader.CreateFromString(gru, ".json", doPrewarm=False)]
+        oracle_specs = [("lstm_json", lstm), ("gru_json", gru)]
+        synthetic_json = {"lstm": json.loads(lstm), "gru": json.loads(gru)}
     if any(m is None for m in models):
         raise SystemExit("could not load " + str(files))
     # run on torch's current stream so torch.cuda.Event brackets exactly the kernels we launch
@@ -255,6 +257,8 @@ def main():
             return [(models[0], q, total // 8 + (1 if k < total % 8 else 0)) for k, q in enumerate(qs)]
         return [(mdl, quality, total // len(models) + (1 if k < total % len(models) else 0)) for k, mdl in enumerate(models)]
 
+    check_rows = []  # (row of this rank's batch, oracle spec, quality): the first stream of every entry this rank runs
+
     shard_info = None
     if distributed and len(entries_for(8)) > 1:
         from neuralaudio_amd import capi
@@ -270,7 +274,7 @@ def main():
         for mdl, q, c in entries:
             lo, hi = max(first, a), min(first + c, b)
             if hi > lo:
-                batch.AddStreams(mdl, hi - lo, quality=q)
+                check_rows.append((batch.AddStreams(mdl, hi - lo, quality=q), oracle_specs[models.index(mdl)], q))
             first += c
         S_global = S * world
         S = b - a
@@ -278,7 +282,7 @@ def main():
     else:
         S_global = S * world
         for mdl, q, c in entries_for(S):
-            batch.AddStreams(mdl, c, quality=q)
+            check_rows.append((batch.AddStreams(mdl, c, quality=q), oracle_specs[models.index(mdl)], q))
 
     # synthetic 48 kHz buffers (bench-C of SURVEY 8d): clip(0.25*N(0,1), +-1), per-rank seed; a ring of 8 distinct buffers
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -286,8 +290,11 @@ def main():
     x = torch.clamp(0.25 * torch.randn(nbuf, S, BLOCK, generator=g), -1.0, 1.0).to(dev)
     y = torch.empty(S, BLOCK, device=dev)
 
-    def step(i):
-        batch.ProcessDevice(x[i % nbuf].data_ptr(), y.data_ptr(), BLOCK, BLOCK, BLOCK)
+    issued = [0]  # steps issued so far: step k of the process reads buffer k % nbuf, so every stream's whole input history is known
+
+    def step(_i=None):
+        batch.ProcessDevice(x[issued[0] % nbuf].data_ptr(), y.data_ptr(), BLOCK, BLOCK, BLOCK)
+        issued[0] += 1
 
     # Clock ramp (untimed, before the W warm-up steps): a cold MI355X needs ~0.2 s of sustained load before the SMU raises the shader
     # clock to its steady state (measured: 68 us/step in the first 20 ms, 61 us/step after 0.2 s); a real-time audio server is
@@ -320,6 +327,14 @@ def main():
     elapsed = nd.max_over_ranks(time.perf_counter() - t0, device=dev)
     kernel_ms_avg = ev0.elapsed_time(ev1) / args.steps
 
+    # Parity spot check (outside the timed region, on what the timed region left behind): `y` holds the output of the LAST timed step.
+    # The first stream of every model of the batch is replayed on the CPU oracle over the tail of its known input history -- one
+    # receptive field and more for a WaveNet, whose state is exactly that; 600 buffers for a recurrent model, whose state forgets --
+    # and the oracle's last buffer must be the kernel's: the launches that were timed did the work.
+    parity = None
+    if rank == 0 and not args.no_parity_check:
+        parity = parity_spot_check(check_rows, x, y, issued[0], nbuf, mdir)
+
     # diagnostic only (outside the timed region): per-launch spread from one event per launch
     nprobe = min(32, args.steps)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(nprobe + 1)]
@@ -339,17 +354,25 @@ def main():
         bytes_per_sample = batch.AlgorithmicBytesPerSample(BLOCK)
         flops_per_sample = 2.0 * batch.MacsPerSample()
         alg_bytes_per_launch = bytes_per_sample * samples_per_step
+        wall_ms = elapsed / args.steps * 1e3                # the clock `value` is computed from (max over ranks)
         achieved_gbs = alg_bytes_per_launch / (kernel_ms_avg * 1e-3) / 1e9
         achieved_tflops = flops_per_sample * samples_per_step / (kernel_ms_avg * 1e-3) / 1e12
+        # the roof of a workload is the one its algorithmic figures sit closer to -- max(bytes / HBM, flops / FP32).  The
+        # WaveNets are HBM-bound (A1 Standard sits on the ridge: 1348.25 B and 26 512 FLOP per sample are both 0.1685 of their roofs; it
+        # is reported on the HBM roof, the FLOP view rides along as roofline_mfma_f32), LSTM / GRU are FP32-bound (10-12 B per sample).
+        frac_hbm, frac_fp32 = achieved_gbs / HBM_PEAK_GBS, achieved_tflops / FP32_MFMA_PEAK_TFLOPS
+        on_fp32_roof = frac_fp32 > 1.01 * frac_hbm
         # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes from the committed rocprofv3
-        # --pmc passes of this same command (tools/pmc_passes.sh -> profiles/traffic_latest.json), named in traffic_source
+        # --pmc passes of this same command (tools/pmc_passes.sh -> profiles/traffic_latest.json, one entry per workload), named in traffic_source
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and args.workload == "standard" and S == STREAMS_PER_GPU:
+        if os.path.exists(tpath) and BLOCK == 128:
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
-                traffic, traffic_source = tj.get("hbm_bytes_per_launch"), "profiles/traffic_latest.json: " + str(tj.get("source"))
+                te = tj.get("workloads", {}).get(args.workload) if "workloads" in tj else (tj if args.workload == "standard" else None)
+                if te and int(te.get("streams", S)) == S:
+                    traffic, traffic_source = te.get("hbm_bytes_per_launch"), "profiles/traffic_latest.json: " + str(te.get("source"))
             except Exception:
                 traffic = None
         out = {
@@ -384,16 +407,29 @@ def main():
             "kernel_ms_avg": kernel_ms_avg,
             "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
             "output_finite": finite,
+            # oracle spot check of the last timed step (one stream per model; tolerance of the north star: 1e-4 RMS)
+            "parity_rms": parity["rms"] if parity else None,
+            "parity_check": parity,
             "roofline": {
-                "bound": "hbm",
-                "achieved": achieved_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS,
+                # "mfma" = the FLOP roof: FP32 vector peak == dense f32 MFMA peak on MI355X (157.3 TFLOP/s), one roof
+                "bound": "mfma" if on_fp32_roof else "hbm",
+                "achieved": achieved_tflops if on_fp32_roof else achieved_gbs,
+                "peak": FP32_MFMA_PEAK_TFLOPS if on_fp32_roof else HBM_PEAK_GBS,
+                "unit": "TFLOP/s" if on_fp32_roof else "GB/s",
+                # from the HIP-event average of the K timed launches (kernel_ms_avg) ...
+                "frac": frac_fp32 if on_fp32_roof else frac_hbm,
+                # ... and from the wall clock `value` is computed from (ms_per_step: launch gaps and the closing synchronisation included)
+                "frac_wall_clock": (frac_fp32 if on_fp32_roof else frac_hbm) * kernel_ms_avg / wall_ms,
+                "frac_hbm": frac_hbm,
+                "frac_fp32": frac_fp32,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
+                # the same fraction on the bytes the counters saw (A2: the guard copy loads a block's leading 16 frames once for all taps of
+                # a small-dilation layer where the formula counts every tap's history, so measured < algorithmic; padded narrow models: >)
+                "frac_measured_bytes": (traffic / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "algorithmic_bytes_per_sample": bytes_per_sample,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                "algorithmic_flops_per_sample": flops_per_sample,
                 # the kernel that runs stream 0 of the batch (the dominant one of every workload here: the first group is the largest /
                 # the only WaveNet one; FamilyFor(), PackFor(), PadFor() in gpu_batch.cpp decide per model)
                 "kernel": batch.StreamKernelName(0),
@@ -440,9 +476,16 @@ def main():
                                              "submit_collect_in_place_us": hj.get("in_place_latency_us")}
                 else:
                     out["pcie_inclusive"] = {"ms_per_buffer": None, "what": "HostPipeBench failed: " + r.stderr.strip()[-300:]}
-        if world == 1 and not args.no_cpu_baseline and args.workload not in ("config4", "config5"):
+        if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = mixed_cpu_baseline(["lite", "feather", "nano"]) if args.workload == "config3" else cpu_baseline(args.workload)
+                if args.workload == "config3":
+                    out["cpu_baseline"] = mixed_cpu_baseline(["lite", "feather", "nano"])
+                elif args.workload == "config4":
+                    out["cpu_baseline"] = mixed_cpu_baseline([("lstm", synthetic_json["lstm"]), ("gru", synthetic_json["gru"])])
+                elif args.workload == "config5":
+                    out["cpu_baseline"] = mixed_cpu_baseline(["a2lite", "a2full"])  # the quality sweep: half the streams on each submodel
+                else:
+                    out["cpu_baseline"] = cpu_baseline(args.workload)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

@@ -121,6 +121,16 @@ NA_EXTERN int NA_MultiProcess(NA_MultiBatch* multi, const float* in, float* out,
 NA_EXTERN int NA_MultiSubmit(NA_MultiBatch* multi, const float* in, size_t n);                /* pipelined, like NA_BatchSubmit */
 NA_EXTERN int NA_MultiCollect(NA_MultiBatch* multi, int ticket, float* out);
 NA_EXTERN int NA_MultiSetQuality(NA_MultiBatch* multi, int stream, float quality);
+/* Fan-out / fan-in between the devices of a multi batch; call before NA_MultiCommit.  0 (default): host rows -- every shard uploads its
+ * weights from the host and downloads its rows into the caller's array, no GPU talks to another.  1: RCCL over xGMI (librccl.so is
+ * loaded with dlopen at this point; devices must be distinct) -- a model's weight images are replicated from the first shard that holds
+ * it (ncclSend / ncclRecv), NA_MultiProcess gathers every shard's output rows into a [streams][n] device buffer on every GPU (an
+ * all-gather of unequal parts) and serves the host array from shard 0 in one download; NA_MultiGatheredOutput(multi, shard) is that
+ * buffer on the shard's GPU (valid until the next NA_MultiProcess).  The kernels' data path has no collective either way. */
+NA_EXTERN int NA_MultiSetFanIn(NA_MultiBatch* multi, int mode);
+NA_EXTERN const float* NA_MultiGatheredOutput(NA_MultiBatch* multi, int shard);
+/* 1 when librccl.so loads and exports every entry point this library binds (no GPU needed), else 0 with NA_GetLastError() */
+NA_EXTERN int NA_RcclAvailable(void);
 /* the partition itself: bounds[0 .. parts] of contiguous ranges of items [0, n) with near-equal total cost (every range keeps at least
  * one item while items remain).  One-process-per-GPU hosts (bench.py over torch.distributed / RCCL) call it with their rank. */
 NA_EXTERN int NA_ShardByCost(const double* cost, int n, int parts, int* bounds);

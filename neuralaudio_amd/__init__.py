@@ -41,6 +41,11 @@ def device_count():
     return capi.device_count()
 
 
+def rccl_available():
+    """librccl.so loads and exports what the multi-GPU host binds (no GPU needed)."""
+    return bool(capi.load_library().NA_RcclAvailable())
+
+
 def _fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -354,6 +359,11 @@ class MultiBatch:
         if first < 0:
             raise NeuralAudioError(capi.last_error())
         return first
+
+    def SetFanIn(self, mode):
+        """"host" (default): every shard serves its own rows of the host arrays; "rccl": weights replicated and outputs gathered over RCCL."""
+        if self._lib.NA_MultiSetFanIn(self._h, {"host": 0, "rccl": 1}[mode]) != 0:
+            raise NeuralAudioError(capi.last_error())
 
     def Commit(self):
         if self._lib.NA_MultiCommit(self._h) != 0:

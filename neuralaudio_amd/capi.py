@@ -26,7 +26,7 @@ NA_SYMBOLS = [
     "NA_BatchSetQuality", "NA_BatchGetActiveSubModel", "NA_BatchPrewarm", "NA_BatchProcess", "NA_BatchProcessDevice",
     "NA_BatchSynchronize", "NA_BatchGetHipStream", "NA_BatchAlgorithmicBytesPerSample", "NA_BatchMacsPerSample",
     "NA_BatchStateBytes", "NA_BatchStreamPackFactor", "NA_BatchStreamKernelName", "NA_DebugSetTraceBuffer", "NA_DebugSetWaveNetSpec", "NA_DebugSetRecurrentQuadMin", "NA_DebugRecurrentQuadLaunches", "NA_RegisterHostBuffer", "NA_UnregisterHostBuffer", "NA_BatchStreamInputLimit", "NA_BatchRemoveStreams", "NA_MultiCreate", "NA_MultiDestroy", "NA_MultiAddStreams", "NA_MultiCommit", "NA_MultiNumStreams", "NA_MultiNumShards", "NA_MultiShardRange", "NA_MultiProcess", "NA_MultiSubmit", "NA_MultiCollect", "NA_MultiSetQuality", "NA_ShardByCost", "NA_ModelStreamCost", "NA_BatchNumLiveStreams", "NA_BatchIsLive", "NA_SetWaveNetMathMode", "NA_SetLSTMMathMode", "NA_SetCompositeModelLoadMode",
-    "NA_IsQualityChangeRealtimeSafe", "NA_ProcessChecked", "NA_BatchSubmit", "NA_BatchCollect", "NA_BatchNextInput", "NA_BatchOutputView", "NA_BatchIsQualityChangeRealtimeSafe", "NA_DebugClassifyNam", "NA_DebugPackedWeights", "NA_ModelKernelInfo", "NA_BatchStreamRangeEvents",
+    "NA_IsQualityChangeRealtimeSafe", "NA_ProcessChecked", "NA_BatchSubmit", "NA_BatchCollect", "NA_BatchNextInput", "NA_BatchOutputView", "NA_BatchIsQualityChangeRealtimeSafe", "NA_DebugClassifyNam", "NA_DebugPackedWeights", "NA_ModelKernelInfo", "NA_BatchStreamRangeEvents", "NA_MultiSetFanIn", "NA_MultiGatheredOutput", "NA_RcclAvailable",
 ]
 
 _lib = None
@@ -112,6 +112,9 @@ def load_library():
         "NA_ShardByCost": (C.c_int, [C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_int)]),
         "NA_ModelStreamCost": (C.c_double, [vp, C.c_float]),
         "NA_BatchStreamRangeEvents": (C.c_int, [vp, C.c_int]),
+        "NA_MultiSetFanIn": (C.c_int, [vp, C.c_int]),
+        "NA_MultiGatheredOutput": (vp, [vp, C.c_int]),
+        "NA_RcclAvailable": (C.c_int, []),
         "NA_ModelKernelInfo": (C.c_int, [vp, C.c_float, C.c_int, C.c_char_p, C.c_int, fp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "NA_BatchNumLiveStreams": (C.c_int, [vp]),
         "NA_BatchIsLive": (C.c_int, [vp, C.c_int]),

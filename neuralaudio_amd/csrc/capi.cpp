@@ -621,6 +621,36 @@ int NA_MultiCollect(NA_MultiBatch* mb, int ticket, float* out)
 	return Guard([&] { mb->multi->Collect(ticket, out); });
 }
 
+// 0 = host rows (default), 1 = RCCL (see multi_gpu.h FanIn); before NA_MultiCommit / the first NA_MultiProcess
+int NA_MultiSetFanIn(NA_MultiBatch* mb, int mode)
+{
+	if (!mb) return -1;
+	return Guard([&] {
+		if (mode != 0 && mode != 1) throw std::runtime_error("NA_MultiSetFanIn: mode must be 0 (host rows) or 1 (RCCL)");
+		mb->multi->SetFanIn(mode == 1 ? na::MultiGpuBatch::FanIn::Rccl : na::MultiGpuBatch::FanIn::HostRows);
+	});
+}
+
+const float* NA_MultiGatheredOutput(NA_MultiBatch* mb, int shard)
+{
+	const float* p = nullptr;
+	if (!mb) return nullptr;
+	Guard([&] { p = mb->multi->GatheredOutput(shard); });
+	return p;
+}
+
+// 1 when librccl.so can be loaded and exports every entry point the multi-GPU host binds (rccl_dyn.cpp); no GPU needed
+int NA_RcclAvailable(void)
+{
+	int ok = 0;
+	Guard([&] {
+		std::string error;
+		if (na::rccl::Load(error) == nullptr) throw std::runtime_error(error);
+		ok = 1;
+	});
+	return ok;
+}
+
 int NA_MultiSetQuality(NA_MultiBatch* mb, int stream, float quality)
 {
 	if (!mb) return -1;

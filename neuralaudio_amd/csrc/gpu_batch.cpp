@@ -172,6 +172,8 @@ namespace na
 		virtual int PackFactor() const { return 1; } // real streams per kernel-level stream (WaveNet stream packing)
 		// f16-split kernels without a static range proof: (wave, block) pairs in which a value of this member's stream was saturated
 		virtual int RangeEvents(int member) { (void)member; return 0; }
+		// device buffers that hold nothing but the model's (re-laid-out) weights: identical on every device that runs the model
+		virtual void WeightImages(std::vector<std::pair<void*, size_t>>& out) const { (void)out; }
 		virtual float InputLimit() const { return INFINITY; } // samples beyond +-limit are clamped by the kernel (f16-split WaveNet kernels)
 		virtual const char* KernelName() const = 0;  // the kernel that runs this group's streams (rocprof name, without template arguments)
 		// WaveNet groups on the frame kernel can share ONE launch with other such groups (a heterogeneous batch without stream
@@ -363,7 +365,7 @@ namespace na
 				if (P < 2) return 1;
 				// packing means the f16-split kernels: only for a model that passes their range proof (block-diagonal packing keeps every
 				// row sum, so the real model's proof is the virtual model's)
-				return SplitAllowed(BuildWaveNetPlan(wn)) ? P : 1;
+				return SplitAllowed(BuildWaveNetPlan(wn, true)) ? P : 1;
 			}
 
 			// Padding without packing (wavenet_plan.cpp WaveNetWantsPadding): a model whose arrays do not fill their lane mode (A1 Lite:
@@ -375,13 +377,22 @@ namespace na
 				const WnFamily o = WaveNetFamilyOverride();
 				if (off || (o != WN_FAMILY_AUTO && o != WN_FAMILY_SPLIT)) return false;
 				ValidateWaveNetDesc(wn);
-				return WaveNetWantsPadding(wn) && SplitAllowed(BuildWaveNetPlan(wn));
+				return WaveNetWantsPadding(wn) && SplitAllowed(BuildWaveNetPlan(wn, true));
+			}
+
+			// The two state formats size their rings differently (wavenet_plan.cpp AddRing): the plan is built for the f16-split kernels
+			// first, and once more for the others when the family choice (which looks at the stage program, not at the rings) says so
+			static WaveNetPlan PlanForItsFamily(const WaveNetDesc& wn)
+			{
+				WaveNetPlan p = BuildWaveNetPlan(wn, true);
+				if (FamilyFor(p) == WN_FAMILY_SPLIT) return p;
+				return BuildWaveNetPlan(wn, false);
 			}
 
 			// packHint: 0 = never pack (submodel of a container), otherwise the number of streams the creating AddStreams call brings
 			WaveNetGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s, int packHint = 0)
 				: ModelGroup(d, s), pack(PackFor(d->wavenet, packHint)),
-				  plan((pack > 1 || PadFor(d->wavenet)) ? BuildPackedWaveNetPlan(d->wavenet, pack) : BuildWaveNetPlan(d->wavenet)),
+				  plan((pack > 1 || PadFor(d->wavenet)) ? BuildPackedWaveNetPlan(d->wavenet, pack) : PlanForItsFamily(d->wavenet)),
 				  family(plan.isVirtual() ? WN_FAMILY_SPLIT : FamilyFor(plan))
 			{
 				if (plan.isVirtual())
@@ -583,6 +594,15 @@ namespace na
 			}
 			int PackFactor() const override { return pack; }
 			float InputLimit() const override { return family == WN_FAMILY_SPLIT ? plan.condLimit : INFINITY; }
+			void WeightImages(std::vector<std::pair<void*, size_t>>& out) const override
+			{
+				auto add = [&](void* p, size_t bytes) { if (p && bytes) out.push_back({ p, bytes }); };
+				add(dWpack.Get(), dWpack.Count() * sizeof(float));
+				add(dWpk.Get(), dWpk.Count() * sizeof(float));
+				add(dWeights.Get(), dWeights.Count() * sizeof(float));
+				add(dWeightsGen.Get(), dWeightsGen.Count() * sizeof(float));
+				add(dWsplit.Get(), dWsplit.Count() * sizeof(uint16_t));
+			}
 			int RangeEvents(int member) override
 			{
 				if (family != WN_FAMILY_SPLIT || !dev.saturate || !InUse(member)) return 0;
@@ -832,6 +852,11 @@ namespace na
 				return macs + (lstm.tail.empty() ? lstm.hiddenSize : tailMacs);
 			}
 
+			void WeightImages(std::vector<std::pair<void*, size_t>>& out) const override
+			{
+				if (dW.Get()) out.push_back({ dW.Get(), dW.Count() * sizeof(float) });
+				if (dWT.Get()) out.push_back({ dWT.Get(), dWT.Count() * sizeof(float) });
+			}
 			size_t StateBytesPerStream() const override { return (size_t)numElems * sizeof(float); }
 			int LaunchClass() const override
 			{
@@ -893,7 +918,7 @@ namespace na
 			info.kernel = "recurrent";
 			return info;
 		}
-		const WaveNetPlan real = BuildWaveNetPlan(d.wavenet);
+		const WaveNetPlan real = BuildWaveNetPlan(d.wavenet, true);
 		info.inputLimit = real.condLimit;
 		info.rangeProven = real.splitRangeProven;
 		info.weightsOk = real.splitWeightsOk;
@@ -918,7 +943,7 @@ namespace na
 		const ModelDesc& d = *model.subModels[(size_t)idx].desc;
 		if (d.kind == MODEL_WAVENET)
 		{
-			const WaveNetPlan plan = BuildWaveNetPlan(d.wavenet);
+			const WaveNetPlan plan = BuildWaveNetPlan(d.wavenet, true);
 			const double B = plan.AlgorithmicBytesPerSample(WN_MAX_FRAMES);
 			if (plan.genericOnly) return 1000.0 * plan.maxChannels / 32.0; // 1.0 ms per block at 32 channels (<= 256 streams)
 			const bool composite = model.isComposite;
@@ -1509,6 +1534,32 @@ namespace na
 		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 		memcpy(out, hostStage, total * sizeof(float));
 		ZeroRetiredRows(out, n, streams.size());
+	}
+
+	void GpuBatch::ProcessHostToDevice(const float* in, float* dOut, size_t n, long outStride)
+	{
+		if (n == 0 || streams.empty()) return;
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		const size_t total = streams.size() * n;
+		// the previous call's kernels may still be reading the pinned block
+		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		EnsureStaging(total);
+		memcpy(hostStage, in, total * sizeof(float));
+		float* dStage = nullptr;
+		if (HostDirect() && hipHostGetDevicePointer(reinterpret_cast<void**>(&dStage), hostStage, 0) == hipSuccess && dStage != nullptr)
+			ProcessDevice(dStage, dOut, n, (long)n, outStride);
+		else
+		{
+			CheckHip(hipMemcpyAsync(devStage, hostStage, total * sizeof(float), hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D");
+			ProcessDevice(devStage, dOut, n, (long)n, outStride);
+		}
+	}
+
+	void GpuBatch::WeightImages(const LoadedModel& model, std::vector<std::pair<void*, size_t>>& out) const
+	{
+		for (const auto& sub : model.subModels)
+			for (const auto& g : groups)
+				if (g->desc.get() == sub.desc.get()) g->WeightImages(out);
 	}
 
 	void GpuBatch::EnsurePipeSlot(PipeSlot& p, size_t floats)

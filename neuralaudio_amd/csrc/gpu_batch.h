@@ -105,6 +105,12 @@ namespace na
 
 		// in/out are HOST pointers laid out [streams][n]; stages through pinned buffers; synchronous.
 		void ProcessHost(const float* in, float* out, size_t n);
+		// `in`: HOST rows [streams][n] (staged through the pinned block); `dOut`: DEVICE rows, `outStride` floats apart.  Asynchronous on
+		// GetStream() once the input is staged -- the multi-GPU host's RCCL fan-in gathers the shards' device rows (multi_gpu.cpp).
+		void ProcessHostToDevice(const float* in, float* dOut, size_t n, long outStride);
+		// device copies of a model's weight tables (every group of the batch that runs one of `model`'s submodels, in submodel order):
+		// what the multi-GPU host replicates from the first device that holds the model (RCCL fan-out)
+		void WeightImages(const LoadedModel& model, std::vector<std::pair<void*, size_t>>& out) const;
 
 		// Pipelined host-buffer interface: Submit() copies `in` ([streams][n], host) into a pinned slot and enqueues H2D (copy-in
 		// stream), the kernels (batch stream) and D2H (copy-out stream); Collect() waits for that slot and copies the result out.

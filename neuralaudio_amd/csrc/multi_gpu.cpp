@@ -92,6 +92,14 @@ namespace na
 			if (s.quit) break;
 		}
 		lock.unlock();
+		if (s.gathered)
+		{
+			(void)hipSetDevice(s.device);
+			(void)hipFree(s.gathered);
+			s.gathered = nullptr;
+		}
+		if (s.comm && nccl) (void)nccl->CommDestroy(s.comm);
+		s.comm = nullptr;
 		s.batch.reset(); // on the thread that used it
 	}
 
@@ -161,6 +169,7 @@ namespace na
 				}
 			});
 			for (auto& sp : shards) CheckShard(*sp);
+			if (fanIn == FanIn::Rccl) InitRccl();
 		}
 		catch (...)
 		{
@@ -168,6 +177,122 @@ namespace na
 			throw;
 		}
 		committed = true;
+	}
+
+	void MultiGpuBatch::SetFanIn(FanIn mode)
+	{
+		if (committed) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch::SetFanIn after Commit");
+		fanIn = mode;
+	}
+
+	static void CheckNccl(const rccl::Api* api, rccl::Result r, const char* what)
+	{
+		if (r != 0) throw std::runtime_error(std::string("neuralaudio_amd: ") + what + ": " + (api->GetErrorString ? api->GetErrorString(r) : "RCCL error"));
+	}
+
+	// One RCCL rank per shard (ncclCommInitAll: all communicators of this process at once), then the weight fan-out
+	void MultiGpuBatch::InitRccl()
+	{
+		std::string error;
+		nccl = rccl::Load(error);
+		if (!nccl) throw std::runtime_error(error);
+		for (size_t i = 0; i < devices.size(); i++)
+			for (size_t k = i + 1; k < devices.size(); k++)
+				if (devices[i] == devices[k]) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: RCCL fan-in needs one distinct device per shard");
+		for (auto& sp : shards)
+			if (sp->end <= sp->begin) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: RCCL fan-in needs at least one stream per shard");
+		std::vector<rccl::Comm> comms(devices.size(), nullptr);
+		CheckNccl(nccl, nccl->CommInitAll(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+		for (size_t i = 0; i < shards.size(); i++)
+		{
+			shards[i]->rank = (int)i;
+			shards[i]->comm = comms[i];
+		}
+		ReplicateWeights();
+	}
+
+	// Weight fan-out: for every model that more than one shard runs, the first of them sends its device copies of the weight tables to
+	// the others (ncclSend / ncclRecv, all transfers of a rank inside one group).  Every shard has already uploaded the same bytes from
+	// the host -- its constructor needs them to compute the prewarm columns before a communicator exists -- so this replaces N - 1
+	// host uploads' worth of content over xGMI rather than saving them; it is the path a device-resident model source would use.
+	void MultiGpuBatch::ReplicateWeights()
+	{
+		const size_t numShards = shards.size();
+		// holders[e]: shards whose range meets entry e
+		std::vector<std::vector<int>> holders(entries.size());
+		{
+			int first = 0;
+			for (size_t e = 0; e < entries.size(); e++)
+			{
+				for (size_t s = 0; s < numShards; s++)
+					if (std::max(first, shards[s]->begin) < std::min(first + entries[e].count, shards[s]->end)) holders[e].push_back((int)s);
+				first += entries[e].count;
+			}
+		}
+		// one model may appear in several entries: replicate it once
+		std::vector<const LoadedModel*> done;
+		Post([&](Shard& s) {
+			CheckHip(hipSetDevice(s.device), "hipSetDevice");
+			std::vector<const LoadedModel*> seen;
+			CheckNccl(nccl, nccl->GroupStart(), "ncclGroupStart");
+			for (size_t e = 0; e < entries.size(); e++)
+			{
+				const LoadedModel* m = entries[e].model.get();
+				if (std::find(seen.begin(), seen.end(), m) != seen.end()) continue;
+				seen.push_back(m);
+				// every holder of ANY entry of this model, ascending
+				std::vector<int> h;
+				for (size_t k = 0; k < entries.size(); k++)
+					if (entries[k].model.get() == m) h.insert(h.end(), holders[k].begin(), holders[k].end());
+				std::sort(h.begin(), h.end());
+				h.erase(std::unique(h.begin(), h.end()), h.end());
+				if (h.size() < 2 || std::find(h.begin(), h.end(), s.rank) == h.end()) continue;
+				std::vector<std::pair<void*, size_t>> images;
+				s.batch->WeightImages(*m, images);
+				for (const auto& img : images)
+				{
+					if (s.rank == h[0])
+					{
+						for (size_t k = 1; k < h.size(); k++)
+							CheckNccl(nccl, nccl->Send(img.first, img.second, rccl::kUint8, h[k], s.comm, s.batch->GetStream()), "ncclSend");
+					}
+					else CheckNccl(nccl, nccl->Recv(img.first, img.second, rccl::kUint8, h[0], s.comm, s.batch->GetStream()), "ncclRecv");
+				}
+			}
+			CheckNccl(nccl, nccl->GroupEnd(), "ncclGroupEnd");
+			CheckHip(hipStreamSynchronize(s.batch->GetStream()), "hipStreamSynchronize");
+		});
+	}
+
+	const float* MultiGpuBatch::GatheredOutput(int shard) const { return shards.at((size_t)shard)->gathered; }
+
+	// Rccl fan-in: every shard runs its rows into ITS part of a [streams][n] device buffer, the parts travel to every GPU (an
+	// all-gather of unequal parts: one broadcast per shard, all inside one group), and shard 0 downloads the whole array once
+	void MultiGpuBatch::ProcessGathered(const float* in, float* out, size_t n)
+	{
+		const size_t totalFloats = (size_t)total * n;
+		Post([&, in, out, n](Shard& s) {
+			CheckHip(hipSetDevice(s.device), "hipSetDevice");
+			if (s.gatheredFloats < totalFloats)
+			{
+				if (s.gathered) (void)hipFree(s.gathered);
+				s.gathered = nullptr;
+				s.gatheredFloats = 0;
+				CheckHip(hipMalloc(reinterpret_cast<void**>(&s.gathered), totalFloats * sizeof(float)), "hipMalloc");
+				s.gatheredFloats = totalFloats;
+			}
+			hipStream_t st = s.batch->GetStream();
+			s.batch->ProcessHostToDevice(in + (size_t)s.begin * n, s.gathered + (size_t)s.begin * n, n, (long)n);
+			CheckNccl(nccl, nccl->GroupStart(), "ncclGroupStart");
+			for (const auto& rp : shards)
+			{
+				float* part = s.gathered + (size_t)rp->begin * n;
+				CheckNccl(nccl, nccl->Broadcast(part, part, (size_t)(rp->end - rp->begin) * n, rccl::kFloat32, rp->rank, s.comm, st), "ncclBroadcast");
+			}
+			CheckNccl(nccl, nccl->GroupEnd(), "ncclGroupEnd");
+			if (s.rank == 0) CheckHip(hipMemcpyAsync(out, s.gathered, totalFloats * sizeof(float), hipMemcpyDeviceToHost, st), "hipMemcpyAsync D2H");
+			CheckHip(hipStreamSynchronize(st), "hipStreamSynchronize");
+		});
 	}
 
 	// a non-empty range without a batch of exactly its rows would silently leave the caller's rows untouched
@@ -211,6 +336,11 @@ namespace na
 	{
 		if (!committed) Commit();
 		CheckUsable();
+		if (fanIn == FanIn::Rccl)
+		{
+			ProcessGathered(in, out, n);
+			return;
+		}
 		Post([=](Shard& s) {
 			if (s.batch) s.batch->ProcessHost(in + (size_t)s.begin * n, out + (size_t)s.begin * n, n);
 		});
@@ -219,6 +349,7 @@ namespace na
 	int MultiGpuBatch::Submit(const float* in, size_t n)
 	{
 		if (!committed) Commit();
+		if (fanIn == FanIn::Rccl) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: the pipelined interface downloads per shard (HostRows fan-in only)");
 		// every shard advances its slot ring in lock-step, so one ticket names the same slot everywhere
 		CheckUsable();
 		int ticket = -1;

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "gpu_batch.h"
+#include "rccl_dyn.h"
 
 namespace na
 {
@@ -40,6 +41,18 @@ namespace na
 		// Shards the global list by cost, creates the per-device batches (each on its own worker thread) and adds every shard's streams
 		void Commit();
 		bool Committed() const { return committed; }
+
+		// Fan-out / fan-in between the devices.  HostRows (default): every shard uploads its weights from the host and downloads its
+		// rows into the caller's [streams][n] array -- no device talks to another.  Rccl (librccl.so bound at run time, rccl_dyn.h; one
+		// rank per shard, so the devices must be distinct): at Commit() a model's weight images are replicated from the first shard that
+		// holds it to the others over xGMI (ncclSend / ncclRecv inside one group), and Process() gathers the shards' output rows into a
+		// [streams][n] DEVICE buffer on every GPU (one ncclBroadcast per shard inside a group = an all-gather of unequal parts) from
+		// which shard 0 serves the host array in ONE download; GatheredOutput(shard) is the buffer for device-side consumers.  Set
+		// before Commit().  The data path between the kernels needs no collective either way.
+		enum class FanIn { HostRows, Rccl };
+		void SetFanIn(FanIn mode);
+		FanIn GetFanIn() const { return fanIn; }
+		const float* GatheredOutput(int shard) const; // Rccl mode: device pointer to [streams][n] of the last Process() on that shard's GPU
 
 		int NumStreams() const { return total; }
 		int NumShards() const { return (int)shards.size(); }
@@ -70,6 +83,11 @@ namespace na
 			std::function<void()> job; // the pending command (one at a time per shard)
 			bool busy = false, quit = false;
 			std::string error;
+			// Rccl mode
+			int rank = 0;
+			rccl::Comm comm = nullptr;
+			float* gathered = nullptr; // device [total][n] (owned by the worker: allocated / freed on its thread)
+			size_t gatheredFloats = 0;
 		};
 		void Run(Shard& s);
 		void CheckShard(const Shard& s) const;
@@ -83,5 +101,10 @@ namespace na
 		int total = 0;
 		bool committed = false;
 		std::string broken; // set by a submission that only part of the shards took
+		FanIn fanIn = FanIn::HostRows;
+		const rccl::Api* nccl = nullptr;
+		void InitRccl();          // communicators (one per shard) + weight replication
+		void ReplicateWeights();
+		void ProcessGathered(const float* in, float* out, size_t n);
 	};
 }

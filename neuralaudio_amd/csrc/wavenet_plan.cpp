@@ -133,8 +133,9 @@ namespace na
 			size_t cursor = 0; // into desc.weights
 
 			int pack = 1; // > 1: `desc` is a packed virtual model (PackWaveNetDesc) of `pack` streams
+			bool exactRings = false; // rings of the f16-split kernels' state format (see AddRing)
 
-			explicit Builder(const WaveNetDesc& d, int packStreams = 1) : desc(d), pack(packStreams) {}
+			explicit Builder(const WaveNetDesc& d, int packStreams = 1, bool exact = false) : desc(d), pack(packStreams), exactRings(exact) {}
 
 			int Take(size_t n)
 			{
@@ -153,12 +154,21 @@ namespace na
 				return off;
 			}
 
-			int AddRing(int channels, int history)
+			// A layer's input history: a true modulo ring.  A block of n <= 128 frames reads the `history` = (K - 1) d frames in front of it and
+			// writes its own; with roundup16(history) + 128 frames the two never touch the same position inside one launch, whatever n.
+			// Rings of the f16-split kernels' state format (`exactRings`) with a dilation of at least a whole block are EXACTLY `history`
+			// frames long instead: the only position a block both reads and writes is then the one frame f reads for its most-shifted tap
+			// (p + f - history = p + f mod R) and overwrites with its own value -- the same lane of the same wave, load before store in
+			// program order (every other tap of frame f lies d >= 128 > n frames behind a position this block writes).  Not for the first
+			// layer of an array: its ring is written by the rechannel / link stage BEFORE the layer's history is requested.  A1 Standard:
+			// 36 KB less state per stream (315 -> 279 KB): 896 streams' address footprint then fits the 256 MB Infinity Cache.
+			int AddRing(int channels, int history, int dilation, bool firstOfArray = true)
 			{
 				WnRingInfo r;
 				r.channels = channels;
 				r.G = CeilDiv(channels, 4);
-				r.frames = CeilDiv(history, WN_TILE) * WN_TILE + WN_MAX_FRAMES;
+				const bool exact = exactRings && !firstOfArray && dilation >= WN_MAX_FRAMES && history >= dilation && history % WN_TILE == 0;
+				r.frames = exact ? history : CeilDiv(history, WN_TILE) * WN_TILE + WN_MAX_FRAMES;
 				r.offF4 = plan.stateF4;
 				plan.stateF4 += (r.frames / WN_TILE) * r.G * WN_TILE; // tiles * G * 16 float4
 				plan.rings.push_back(r);
@@ -608,7 +618,7 @@ namespace na
 						pw.wmix = Take((size_t)C * cfg.conditionSize);
 						pw.w1 = Take((size_t)C * C);
 						pw.b1 = Take((size_t)C);
-						pw.ring_id = AddRing(C, (K - 1) * cfg.dilations[l]);
+						pw.ring_id = AddRing(C, (K - 1) * cfg.dilations[l], cfg.dilations[l], l == 0);
 						pw.need_output = 1;
 						pw.last_of_array = (l == numLayers - 1) ? 1 : 0;
 						pw.rechannel = (l == 0) ? rechOff : -1;
@@ -622,7 +632,7 @@ namespace na
 					pw.wconv = Take((size_t)cfg.headSize * C * cfg.headKernelSize);
 					pw.bconv = cfg.hasHeadBias ? Take((size_t)cfg.headSize) : -1;
 					pw.wmix = -1; pw.w1 = -1; pw.b1 = -1;
-					pw.ring_id = (cfg.headKernelSize > 1) ? AddRing(C, (cfg.headKernelSize - 1) * cfg.headDilation) : -1; // a conv head keeps its own history
+					pw.ring_id = (cfg.headKernelSize > 1) ? AddRing(C, (cfg.headKernelSize - 1) * cfg.headDilation, cfg.headDilation) : -1; // a conv head keeps its own history
 					pw.rechannel = -1;
 					pw.dilation = cfg.headDilation;
 					plan.prewarm.push_back(pw);
@@ -660,9 +670,9 @@ namespace na
 				{
 					const WnArrayCfg& cfg = desc.arrays[a];
 					for (size_t l = 0; l < cfg.kernelSizes.size(); l++)
-						layerRing[a].push_back(AddRing(cfg.channels, (cfg.kernelSizes[l] - 1) * cfg.dilations[l]));
+						layerRing[a].push_back(AddRing(cfg.channels, (cfg.kernelSizes[l] - 1) * cfg.dilations[l], cfg.dilations[l], l == 0));
 					if (cfg.headKernelSize > 1)
-						headRing[a] = AddRing(cfg.channels, (cfg.headKernelSize - 1) * cfg.headDilation);
+						headRing[a] = AddRing(cfg.channels, (cfg.headKernelSize - 1) * cfg.headDilation, cfg.headDilation);
 				}
 
 				// Pass 2: walk the flat weights and emit stages
@@ -824,9 +834,9 @@ namespace na
 		};
 	}
 
-	WaveNetPlan BuildWaveNetPlan(const WaveNetDesc& desc)
+	WaveNetPlan BuildWaveNetPlan(const WaveNetDesc& desc, bool splitStateFormat)
 	{
-		Builder b(desc);
+		Builder b(desc, 1, splitStateFormat);
 		b.Build();
 		return std::move(b.plan);
 	}
@@ -954,7 +964,7 @@ namespace na
 	{
 		if (P < 1) return BuildWaveNetPlan(desc);
 		const WaveNetDesc v = PackWaveNetDesc(desc, P);
-		Builder b(v, P);
+		Builder b(v, P, true); // (packed / padded plans only ever run on the f16-split kernels)
 		b.Build();
 		b.plan.pack = P;
 		b.plan.packedWeights = v.weights; // the prewarm kernel walks the natural layout of the VIRTUAL model

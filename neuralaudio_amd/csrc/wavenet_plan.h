@@ -56,7 +56,9 @@ namespace na
 	};
 
 	// throws std::runtime_error("Wrong number of weights...") like WaveNet.h:704-709
-	WaveNetPlan BuildWaveNetPlan(const WaveNetDesc& desc);
+	// splitStateFormat: the stream state is laid out for the f16-split kernels (rings of layers with a dilation >= 128 are exactly
+	// (K - 1) d frames long, wavenet_plan.cpp AddRing); false: for the frame / runtime-shaped kernels (every ring roundup16 + 128)
+	WaveNetPlan BuildWaveNetPlan(const WaveNetDesc& desc, bool splitStateFormat = false);
 	// Stream packing (wavenet_plan.cpp): how many streams of this model fit one virtual stream of the f16-split kernel (1: none),
 	// the virtual model, and its plan (WaveNetPlan::pack = P; arrays / rings / stages describe the VIRTUAL model).
 	int WaveNetPackFactor(const WaveNetDesc& desc);

@@ -121,7 +121,15 @@ namespace na
 			static constexpr int HEADK = A::HEADK;
 			static constexpr int NRINGS = NL + (HEADK > 1 ? 1 : 0); // one per layer (+ the conv head's)
 			// ring L < NL: input history of layer L; ring NL: the head accumulator's (wavenet_plan.cpp AddRing: roundup16((K - 1) d) + 128)
-			static constexpr int RingFrames(int L) { return L < NL ? ((KS(L) - 1) * Dil(L) + 15) / 16 * 16 + FRAMES : (HEADK - 1 + 15) / 16 * 16 + FRAMES; }
+			// (wavenet_plan.cpp AddRing: a dilation of at least a whole block -> exactly (K - 1) d frames, else roundup16((K - 1) d) + 128)
+			static constexpr bool ExactRing(int L) { return L < NL && !FirstOfArr(L) && Dil(L) >= FRAMES && KS(L) > 1 && ((KS(L) - 1) * Dil(L)) % 16 == 0; }
+			static constexpr int RingFrames(int L)
+			{
+				if (ExactRing(L)) return (KS(L) - 1) * Dil(L);
+				return L < NL ? ((KS(L) - 1) * Dil(L) + 15) / 16 * 16 + FRAMES : (HEADK - 1 + 15) / 16 * 16 + FRAMES;
+			}
+			// frames of a block a later block can still read: the whole history of an exact ring, R - 128 of the others
+			static constexpr int RingKeep(int L) { return ExactRing(L) ? RingFrames(L) : RingFrames(L) - FRAMES; }
 			static constexpr int RingG(int L) { return GPof(L < NL ? ArrOf(L) : NA - 1); }
 			static constexpr int RingOff(int L) // quads
 			{
@@ -238,7 +246,7 @@ namespace na
 		// in LDS by the end of the stage in front of the reader -- one stage of latency hiding instead of the two a register prefetch gets.
 		// Measured: A2 (K = 6 / 15 layers) config 5 104.6 -> 87.9 us; A1 Standard (K = 3: short stages) 41.6 -> 48.3 us.  So A::GUARDHIST.
 		template <class C, int RG>
-		constexpr bool SmallRing() { return C::A::GUARDHIST && C::TB::RingFrames(RG) - FRAMES <= GUARD; }
+		constexpr bool SmallRing() { return C::A::GUARDHIST && C::TB::RingKeep(RG) <= GUARD; }
 
 		template <class C>
 		constexpr int WaveTapClass(int w, int P, int i, int shift, bool small)
@@ -346,10 +354,14 @@ namespace na
 		// f32 quad -> split quad: plain for the tanh chains (covered by the static range proof, wavenet_plan.cpp), saturating for the
 		// LeakyReLU ones
 		template <class C>
-		__device__ __forceinline__ u32x4 Split(f32x4 v, const Ctx& cx)
+		__device__ __forceinline__ u32x4 Split(f32x4 v)
 		{
-			if constexpr (C::A::LEAKY) return SplitQuadSat(v, cx.srsrc);
+#ifdef NA_NO_SAT // tuning builds: what the saturating split costs the A2 chains (make SUFFIX=_nosat KEXTRA=-DNA_NO_SAT)
+			return SplitQuad(v);
+#else
+			if constexpr (C::A::LEAKY) return SplitQuadSat(v);
 			else return SplitQuad(v);
+#endif
 		}
 
 		// Byte offset of ring position (base + fl) mod R, channel group cg, relative to the ring's start: `base` in [0, R) is wave-uniform, the
@@ -423,7 +435,7 @@ namespace na
 		constexpr bool StoreNeeded(int i)
 		{
 			typedef typename C::TB TB;
-			constexpr int P = Geo<TB::RingG(RG), C::T>::P, KEEP = TB::RingFrames(RG) - FRAMES;
+			constexpr int P = Geo<TB::RingG(RG), C::T>::P, KEEP = TB::RingKeep(RG);
 			return (C::NF - C::FW) + 16 * P * (i + 1) - 1 >= C::NF - KEEP; // the last wave's last frame of set i
 		}
 		template <class C, int RG>
@@ -439,7 +451,7 @@ namespace na
 		__device__ __forceinline__ void Publish(const Ctx& cx, const Lanes<C, GP>& ln, u32x4 v, int i, int imgWrite)
 		{
 			typedef typename C::TB TB;
-			constexpr int P = Geo<GP, C::T>::P, R = TB::RingFrames(RG), OFF = TB::RingOff(RG), KEEP = R - FRAMES;
+			constexpr int P = Geo<GP, C::T>::P, R = TB::RingFrames(RG), OFF = TB::RingOff(RG), KEEP = TB::RingKeep(RG);
 			static_assert(GP == TB::RingG(RG), "lane mode of the receiving ring");
 			if (!(NA_ABL & 64) && MINSHIFT < C::NF) // the reader takes in-block frames of other lanes
 				LdsWrite16(ln.img + (unsigned)(imgWrite * C::IMG_ONE + 16 * P * i * 16), v);
@@ -674,7 +686,7 @@ namespace na
 #pragma unroll
 				for (int i = 0; i < S; i++)
 				{
-					const u32x4 zs = Split<C>(z[i], cx);
+					const u32x4 zs = SplitQuad(z[i]);
 					st.hd[i] = Mfma(idop, zs, st.hd[i]);
 					if constexpr (!LASTLAYER) // NeedOutput (WaveNet.h:643,785): the very last layer's 1x1 is dead
 					{
@@ -685,7 +697,7 @@ namespace na
 						st.xc[i] = y;
 						if constexpr (SG::NEXT)
 						{
-							st.xs[i] = Split<C>(y, cx);
+							st.xs[i] = Split<C>(y);
 							Publish<C, LN, GP, NEXTMINSHIFT>(cx, ln, st.xs[i], i, imgWrite);
 						}
 					}
@@ -770,7 +782,7 @@ namespace na
 				x = Mfma(ra, ax, x);
 				st.xc[i] = x;
 				st.hd[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
-				st.xs[i] = Split<C>(x, cx);
+				st.xs[i] = Split<C>(x);
 				Publish<C, 0, GP, C::TB::Dil(0)>(cx, ln, st.xs[i], i, 1);
 			}
 			FirstHistDispatch<C, 0, 0>(cx, ln.ring, ln.fl, st);
@@ -797,8 +809,8 @@ namespace na
 #pragma unroll
 			for (int i = 0; i < So; i++)
 			{
-				hs[i] = Split<C>(st.hd[i], cx);
-				xq[i] = Split<C>(st.xc[i], cx);
+				hs[i] = Split<C>(st.hd[i]);
+				xq[i] = Split<C>(st.xc[i]);
 			}
 			f32x4 hn[Sn], xn[Sn];
 #pragma unroll
@@ -823,7 +835,7 @@ namespace na
 			{
 				st.hd[i] = hn[i];
 				st.xc[i] = xn[i];
-				st.xs[i] = Split<C>(xn[i], cx);
+				st.xs[i] = Split<C>(xn[i]);
 				Publish<C, LN, GPN, TB::Dil(LN)>(cx, ln, st.xs[i], i, (s + 1) & 1);
 			}
 			FirstHistDispatch<C, LN, 0>(cx, ln.ring, ln.fl, st);
@@ -849,7 +861,7 @@ namespace na
 #pragma unroll
 			for (int i = 0; i < S; i++)
 			{
-				hs[i] = Split<C>(st.hd[i], cx);
+				hs[i] = Split<C>(st.hd[i]);
 				acc[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 			}
 #pragma unroll
@@ -1061,6 +1073,7 @@ namespace na
 					for (int k = 0; k < C::SKEW; k++) BlockBarrier<C::NTHREADS / 64>();
 			}
 			State st;
+			if constexpr (C::A::LEAKY) ClearRangeStatus();
 			RunArrays<C, 0>(cx, st, out, (size_t)row * outStride, outRow, pack, ga.headScale, live);
 			if constexpr (C::SKEW > 0)
 			{
@@ -1071,6 +1084,7 @@ namespace na
 #ifdef NA_SP_TRACE
 			if (cx.trace != nullptr && lane == 0) cx.trace[((C::TB::NSTAGES * 8 + 1) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
 #endif
+			if constexpr (C::A::LEAKY) CountRangeEventFromStatus(header, lane, live);
 			// advance every ring cursor by NF (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
 			if (wave == 0 && live && lane < ga.nrings)
 			{

@@ -86,28 +86,56 @@ namespace na
 			return q;
 		}
 
-		// Saturating variant for chains the static range proof does not cover (LeakyReLU models: wavenet_plan.cpp): a value
-		// beyond the f16 range is clamped to +-65504 instead of becoming inf (inf - inf = NaN in the lo half would poison the ring for
-		// good), and the wave counts a "range event" in the stream's state header right there (WN_RANGE_EVENT_SLOT; one atomic through
-		// the state resource the wave holds anyway -- the chains have no register to spare for a flag carried to the end of the block, and
-		// the branch is never taken on audio).  Inside the range it is SplitQuad bit for bit.
-		__device__ __forceinline__ u32x4 SplitQuadSat(f32x4 v, __amdgpu_buffer_rsrc_t state)
+		// Saturating variant for chains the static range proof does not cover (LeakyReLU models: wavenet_plan.cpp), used
+		// for every value that reaches the stream STATE -- the residual stream (block images, rings) and the head accumulator (head
+		// ring): a value beyond the f16 range is clamped to +-65504 instead of becoming inf (inf - inf = NaN in the lo half would poison
+		// the rings for good; v_med3_f32 also turns a NaN into -65504).  That it happened is remembered by the hardware: the quad's
+		// largest magnitude goes through one f32 -> f16 conversion whose only purpose is to raise the wave's sticky IEEE OVERFLOW flag
+		// (TRAPSTS.EXCP accumulates whether or not traps are enabled) -- no flag register to carry through a chain that has none to
+		// spare -- and the wave counts a "range event" in the stream's state header when it finds the flag set at the end of the block
+		// (CountRangeEventFromStatus).  The activations themselves are split plainly: their conversion raises the same flag, and the
+		// overflow surfaces in the residual stream one mat-mul later.  Inside the range it is SplitQuad bit for bit.
+		__device__ __forceinline__ u32x4 SplitQuadSat(f32x4 v)
 		{
 			const float m = 65504.0f;
-			const float top = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+			float top;
+			asm volatile("v_max3_f32 %0, |%1|, |%2|, |%3|\n\t"
+				"v_max_f32_e64 %0, %0, |%4|\n\t"
+				"v_cvt_f16_f32_e32 %0, %0"
+				: "=&v"(top)
+				: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
 			v.x = __builtin_amdgcn_fmed3f(v.x, -m, m);
 			v.y = __builtin_amdgcn_fmed3f(v.y, -m, m);
 			v.z = __builtin_amdgcn_fmed3f(v.z, -m, m);
 			v.w = __builtin_amdgcn_fmed3f(v.w, -m, m);
-			if (__builtin_amdgcn_ballot_w64(top > m) != 0)
-			{
-				// (a shadow wave's zero-sized resource drops the access)
-				if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
-					__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, state, WN_RANGE_EVENT_SLOT * 4, 0, 0);
-				// the stages count their VMEM operations (s_waitcnt vmcnt(N) before a barrier): the extra one must not shift that count
-				__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
-			}
 			return SplitQuad(v);
+		}
+		// TRAPSTS.EXCP (hardware register 3, bits 8:0): bit 0 invalid (inf - inf), bit 3 overflow.  Cleared at the start of the block, read
+		// at its end: one event per wave and block in which a value left the f16 range (`live`: not a shadow wave of a partial workgroup)
+		__device__ __forceinline__ void ClearRangeStatus() { __builtin_amdgcn_s_setreg((3 | (0 << 6) | ((9 - 1) << 11)), 0); }
+		__device__ __forceinline__ void CountRangeEventFromStatus(int* header, int lane, bool live)
+		{
+			const unsigned excp = __builtin_amdgcn_s_getreg(3 | (0 << 6) | ((9 - 1) << 11));
+			if ((excp & 0x9u) != 0 && live && lane == 0) __hip_atomic_fetch_add(&header[WN_RANGE_EVENT_SLOT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+
+		// the same for the stage interpreter, whose flag the compiler cannot prove wave-uniform (it travels through the stage loop): plain
+		// expressions, the flag where the compiler wants it
+		__device__ __forceinline__ u32x4 SplitQuadSatLoose(f32x4 v, int& hit)
+		{
+			const float m = 65504.0f;
+			const float top = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)), __builtin_fabsf(v.w));
+			hit |= !(top <= m) ? 1 : 0;
+			v.x = __builtin_amdgcn_fmed3f(v.x, -m, m);
+			v.y = __builtin_amdgcn_fmed3f(v.y, -m, m);
+			v.z = __builtin_amdgcn_fmed3f(v.z, -m, m);
+			v.w = __builtin_amdgcn_fmed3f(v.w, -m, m);
+			return SplitQuad(v);
+		}
+		// one event per wave and block in which a value left the f16 range (`live`: not a shadow wave of a partial workgroup)
+		__device__ __forceinline__ void CountRangeEvent(int* header, int hit, int lane, bool live)
+		{
+			if (__builtin_amdgcn_ballot_w64(hit != 0) != 0 && live && lane == 0) __hip_atomic_fetch_add(&header[WN_RANGE_EVENT_SLOT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 
 		// Activation.h:83-91, plain (unpacked) VALU on purpose: packed f32 instructions do not issue beside MFMAs on gfx950

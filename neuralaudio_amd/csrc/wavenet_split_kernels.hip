@@ -203,14 +203,15 @@ namespace na
 		{
 			f32x4 xc[T]; // layer input (residual stream), f32; its split quad lives in the LDS block image (the unshifted tap reads it back)
 			f32x4 hd[T]; // head accumulator
+			int hit;     // saturating runs (Ctx::saturate): this lane saturated a value
 		};
 
-		// f32 quad -> split quad; saturating (and tracking the peak) for models without a static range proof -- same places, same values
-		// as the specialised chains (wavenet_spec_impl.h Split)
+		// f32 quad -> split quad of a value that reaches the stream state; saturating for models without a static range proof -- same
+		// places, same values as the specialised chains (wavenet_spec_impl.h Split)
 		template <int T>
 		__device__ __forceinline__ u32x4 SplitOf(const Ctx& cx, State<T>& st, f32x4 v)
 		{
-			if (cx.saturate) return SplitQuadSat(v, cx.srsrc);
+			if (cx.saturate) return SplitQuadSatLoose(v, st.hit);
 			return SplitQuad(v);
 		}
 
@@ -425,7 +426,7 @@ namespace na
 #pragma unroll
 					for (int i = 0; i < S; i++)
 					{
-						const u32x4 zs = SplitOf(cx, st, z[i]);
+						const u32x4 zs = SplitQuad(z[i]);
 						const u32x4 ax = AuxOf<PK>(cx, f[i], cg[i], gsShift);
 						st.hd[i] = Mfma(idop, zs, st.hd[i]);
 						f32x4 y = st.xc[i];
@@ -748,6 +749,7 @@ namespace na
 			BlockBarrier<NTHREADS / 64>();
 
 			State<T> st;
+			st.hit = 0;
 			int cur = 0;
 			int s = 0;
 			int mode = sd.Gp;
@@ -796,6 +798,7 @@ namespace na
 #ifdef NA_SP_TRACE
 			if (cx.trace != nullptr && lane == 0) cx.trace[((ga.nstages * 8 + 1) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
 #endif
+			if (cx.saturate) CountRangeEvent(header, st.hit, lane, liveStream);
 			// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
 			if (wave == 0 && liveStream && lane < ga.nrings)
 			{

@@ -730,6 +730,9 @@ typedef struct {
 	int num_layers, hidden;
 	const float* weights; size_t num_weights;
 	int block_size, num_blocks;
+	/* is_lstm == 2: keras GRU (na_oracle_gru_create_keras arguments) */
+	const float* const* gru_kernels; const float* const* gru_recurrents; const float* const* gru_biases;
+	const float* gru_head_w; float gru_head_b;
 	pthread_barrier_t* barrier;
 	double seconds;
 } bench_arg;
@@ -749,7 +752,11 @@ static void* bench_thread(void* p)
 	float* out = (float*)calloc((size_t)a->block_size, sizeof(float));
 	na_oracle_wavenet* wn = NULL;
 	na_oracle_lstm* ls = NULL;
-	if (a->is_lstm) {
+	na_oracle_gru* gr = NULL;
+	if (a->is_lstm == 2) {
+		gr = na_oracle_gru_create_keras(a->num_layers, a->hidden, a->gru_kernels, a->gru_recurrents, a->gru_biases, a->gru_head_w, a->gru_head_b);
+		if (gr) na_oracle_gru_prewarm(gr);
+	} else if (a->is_lstm) {
 		ls = na_oracle_lstm_create_nam(a->num_layers, a->hidden, a->weights, a->num_weights, NA_ORACLE_MATH_FAST);
 		if (ls) na_oracle_lstm_prewarm(ls);
 	} else {
@@ -761,11 +768,13 @@ static void* bench_thread(void* p)
 	for (int b = 0; b < a->num_blocks; b++) {
 		if (wn) na_oracle_wavenet_process(wn, in, out, (size_t)a->block_size);
 		else if (ls) na_oracle_lstm_process(ls, in, out, (size_t)a->block_size);
+		else if (gr) na_oracle_gru_process(gr, in, out, (size_t)a->block_size);
 	}
 	a->seconds = now_s() - t0;
 	pthread_barrier_wait(a->barrier);
 	na_oracle_wavenet_free(wn);
 	na_oracle_lstm_free(ls);
+	na_oracle_gru_free(gr);
 	free(in); free(out);
 	return NULL;
 }
@@ -808,6 +817,17 @@ double na_oracle_lstm_bench(int num_layers, int hidden_size, const float* weight
 	bench_arg a;
 	memset(&a, 0, sizeof(a));
 	a.is_lstm = 1; a.num_layers = num_layers; a.hidden = hidden_size; a.weights = weights; a.num_weights = num_weights;
+	a.block_size = block_size; a.num_blocks = num_blocks;
+	return run_bench(a, threads);
+}
+
+double na_oracle_gru_bench(int num_layers, int hidden_size, const float* const* kernels, const float* const* recurrents,
+	const float* const* biases, const float* head_weights, float head_bias, int block_size, int num_blocks, int threads)
+{
+	bench_arg a;
+	memset(&a, 0, sizeof(a));
+	a.is_lstm = 2; a.num_layers = num_layers; a.hidden = hidden_size;
+	a.gru_kernels = kernels; a.gru_recurrents = recurrents; a.gru_biases = biases; a.gru_head_w = head_weights; a.gru_head_b = head_bias;
 	a.block_size = block_size; a.num_blocks = num_blocks;
 	return run_bench(a, threads);
 }

@@ -119,6 +119,8 @@ double na_oracle_wavenet_bench(int num_arrays, const na_oracle_wn_array_cfg* cfg
 	size_t num_weights, int block_size, int num_blocks, int threads);
 double na_oracle_lstm_bench(int num_layers, int hidden_size, const float* weights, size_t num_weights,
 	int block_size, int num_blocks, int threads);
+double na_oracle_gru_bench(int num_layers, int hidden_size, const float* const* kernels, const float* const* recurrents,
+	const float* const* biases, const float* head_weights, float head_bias, int block_size, int num_blocks, int threads);
 
 #ifdef __cplusplus
 }

@@ -68,3 +68,50 @@ def test_hostpipebench_multi_gpu_mode_two_threads_on_one_gpu():
     a, b = j["shards"]
     assert a["begin"] == 0 and a["end"] == b["begin"] and b["end"] == 512
     assert a["end"] - a["begin"] < 256  # Standard streams cost about twice an LSTM 1x16 stream: the cut lies inside the first half
+
+
+def test_rccl_fan_in_with_one_rank_matches_the_host_row_path(na):
+    """The RCCL mode of the multi-GPU host on what this box has: ONE rank (ncclCommInitAll over one device, the gather of one part, the
+    single download from the gathered device buffer).  Bit-identical to the default host-row path; with two distinct GPUs the same code
+    replicates the weights over xGMI and gathers both shards' rows (skipped below: one GPU)."""
+    if not na.rccl_available():
+        pytest.skip("no RCCL on this box")
+    loader = na.NeuralModelLoader()
+    std = loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=False)
+    lstm = loader.CreateFromFile(_path("BossLSTM-1x16.nam"), doPrewarm=False)
+    ref, multi = na.MultiBatch([0]), na.MultiBatch([0])
+    multi.SetFanIn("rccl")
+    for mb in (ref, multi):
+        mb.AddStreams(std, 9)
+        mb.AddStreams(lstm, 7)
+        mb.Commit()
+    rng = np.random.default_rng(5)
+    for n in (128, 128, 64):
+        x = (0.3 * rng.standard_normal((16, n))).clip(-1, 1).astype(np.float32)
+        assert np.array_equal(multi.Process(x), ref.Process(x))
+    # one rank per DEVICE: two shards on one GPU cannot form a communicator
+    dup = na.MultiBatch([0, 0])
+    dup.SetFanIn("rccl")
+    dup.AddStreams(std, 4)
+    with pytest.raises(na.NeuralAudioError, match="distinct device"):
+        dup.Commit()
+    for mb in (ref, multi, dup):
+        mb.close()
+
+
+def test_rccl_fan_in_across_two_gpus(na):
+    if na.device_count() < 2 or not na.rccl_available():
+        pytest.skip("needs two GPUs and RCCL")
+    loader = na.NeuralModelLoader()
+    std = loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=False)
+    nano = loader.CreateFromFile(_path("BossWN-nano.nam"), doPrewarm=False)
+    one, multi = na.Batch(0), na.MultiBatch([0, 1])
+    multi.SetFanIn("rccl")
+    for m, c in ((std, 40), (nano, 64)):
+        assert one.AddStreams(m, c) == multi.AddStreams(m, c)
+    multi.Commit()
+    rng = np.random.default_rng(6)
+    for _ in range(3):
+        x = (0.3 * rng.standard_normal((104, 128))).clip(-1, 1).astype(np.float32)
+        assert np.array_equal(multi.Process(x), one.Process(x))
+    multi.close()

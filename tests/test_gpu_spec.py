@@ -323,3 +323,107 @@ def test_layout_does_not_depend_on_the_add_pattern_and_slots_are_recycled(na, lo
     for s in (5, 6, 8, 11, S - 1, S):
         assert O.rms(y2[s] - O.oracle_from_file("BossWN-nano.nam").process(x2[s])) < TOL_RMS, s  # recycled: fresh prewarmed state
     assert O.rms(y2[4] - keep.process(x2[4])) < TOL_RMS  # the neighbour in virtual stream 1 never noticed
+
+
+def _process_blocks(batch, x, block=128):
+    return np.concatenate([batch.Process(np.ascontiguousarray(x[None, a:a + block]))[0] for a in range(0, x.size, block)])
+
+
+@pytest.mark.skipif(FORCED, reason="forced kernel family")
+@pytest.mark.parametrize("case,factors,want", [
+    ("as trained", {}, "WaveNetSpecKernel"),
+    ("1x1 x 30: smaller input limit, still proven", {"1x1": 30.0}, "WaveNetSpecKernel"),
+    ("1x1 x 4000: tanh layers can add more than the f16 range holds", {"1x1": 4000.0}, "WaveNetFrameKernel"),
+    ("mix-in x 1e5: weights beyond the operand format", {"mixin": 1e5}, "WaveNetFrameKernel"),
+    ("all weights x 1e-3: matrices below the precision floor of the split", {"rechannel": 1e-3, "conv": 1e-3, "mixin": 1e-3, "1x1": 1e-3, "head": 1e-3}, "WaveNetFrameKernel"),
+    ("rechannel x 1e-6 against 1x1 x 1e3", {"rechannel": 1e-6, "1x1": 1e3}, "WaveNetFrameKernel"),
+])
+def test_models_without_a_range_proof_run_on_the_f32_kernel(na, loader, case, factors, want):
+    """the f16-split kernels take a model only with a static proof that no value leaves the f16 range for inputs within
+    the limit and that its weights fit the (hi, lo) f16 operand format.  A1 Standard with weights scaled from 1e-6 to 4000: whatever
+    the proof decides, the stream follows the f32 oracle (relative to the output level), NA_BatchStreamKernelName shows the kernel, and
+    the fallback has no input clamp."""
+    arrays = O.a1_arrays(16, 8)
+    w = O.scale_wavenet_tensors(arrays, O.synth_wavenet_weights(arrays, seed=21), factors)
+    m = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam", doPrewarm=True)
+    assert m is not None
+    b = na.Batch(0)
+    b.AddStreams(m, 1)
+    assert b.StreamKernelName(0) == want, (case, b.StreamKernelName(0))
+    assert (b.StreamInputLimit(0) == float("inf")) == (want == "WaveNetFrameKernel")
+    x = O.signal_noise(128 * 12, seed=8)
+    y = _process_blocks(b, x)
+    yo = O.OracleWaveNet(arrays, w).process(x)
+    assert np.all(np.isfinite(y))
+    # These models are badly conditioned on purpose (a residual stream of 1e3 .. 1e4 in front of an unsaturated tanh): the f32 oracle
+    # itself is only so close to exact arithmetic, so the kernel is held to the oracle's own distance from a float64 evaluation
+    # (tests/ref_np.py) -- at most 8 x for the 22-bit split values, 3 x for the f32 kernel -- relative to the output level
+    y64 = ref_np.wavenet_forward(arrays, w, x)
+    g, o, level = O.rms(y - y64), O.rms(yo - y64), O.rms(y64)
+    assert level > 0 and g <= (8.0 if want == "WaveNetSpecKernel" else 3.0) * o + 2e-6 * level, (case, g, o, level)
+    assert b.StreamRangeEvents(0) == 0
+    b.close()
+
+
+def _a2_style_weights(channels, conv_gain, seed):
+    """A2-shaped seeded weights with every layer conv scaled by `conv_gain` and the biases scaled down, so that what the layers do to the
+    signal is what the input level makes of it (measured with tests/ref_np.py at conv_gain 10: the residual stream peaks at 1.6e6 /
+    7.7e6 times the input amplitude for 8 / 3 channels)."""
+    arrays = O.a2_arrays(channels)
+    w = O.synth_wavenet_weights(arrays, seed=seed)
+    return arrays, O.scale_wavenet_tensors(arrays, w, {"conv": conv_gain, "conv_bias": 1e-6, "1x1_bias": 1e-6, "head_bias": 1e-6})
+
+
+@pytest.mark.skipif(FORCED, reason="forced kernel family")
+@pytest.mark.parametrize("channels", [8, 3])
+def test_a2_chain_saturates_counts_the_event_and_recovers(na, loader, channels):
+    """LeakyReLU chains have no static range proof (the worst case is the product of 23 layers' row sums), so the official A2 shapes run
+    with saturating arithmetic: an A2-shaped model whose layers amplify (gain > 1 per layer, > 1e6 over the chain) follows the f32 oracle
+    while the signal is quiet (amplitude 1e-5: internal peaks of 16 .. 80); a full-scale passage drives the residual stream past 65504 -- the values are clamped (no inf, no NaN: the
+    rings are not poisoned), NA_BatchStreamRangeEvents counts it -- and one receptive field after the passage the stream is back on the
+    oracle."""
+    arrays, w = _a2_style_weights(channels, 10.0, seed=40 + channels)
+    m = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam", doPrewarm=True)
+    assert m is not None
+    info = m.KernelInfo(1.0, 1)
+    assert info["kernel"] == "f16-split" and not info["range_proven"]
+    ora = O.OracleWaveNet(arrays, w)
+    rf = ora.receptive_field
+    assert rf == 6346
+    b = na.Batch(0)
+    b.AddStreams(m, 1)
+    assert b.StreamKernelName(0) == "WaveNetSpecKernel"
+    quiet = (1e-5 * O.signal_noise(128 * 20, seed=3)).astype(np.float32)
+    loud = O.signal_noise(128 * 4, seed=4)
+    back = (1e-5 * O.signal_noise(128 * 60, seed=5)).astype(np.float32)
+    y1, o1 = _process_blocks(b, quiet), ora.process(quiet)
+    assert O.rms(o1) > 0 and O.rms(y1 - o1) <= 1e-4 * O.rms(o1) + 1e-9, (O.rms(y1 - o1), O.rms(o1))
+    assert b.StreamRangeEvents(0) == 0
+    y2, o2 = _process_blocks(b, loud), ora.process(loud)
+    assert np.all(np.isfinite(y2)) and np.all(np.isfinite(o2))
+    assert b.StreamRangeEvents(0) > 0, (float(np.abs(o2).max()),)
+    y3, o3 = _process_blocks(b, back), ora.process(back)
+    assert np.all(np.isfinite(y3))
+    tail = ((rf + 127) // 128 + 1) * 128
+    assert O.rms(y3[tail:] - o3[tail:]) <= 1e-4 * O.rms(o3[tail:]) + 1e-9, (O.rms(y3[tail:] - o3[tail:]), O.rms(o3[tail:]))
+    events = b.StreamRangeEvents(0)
+    _process_blocks(b, back[:1280])
+    assert b.StreamRangeEvents(0) == events  # nothing new once the signal is quiet again
+    # the stage interpreter (other block lengths) saturates and counts the same way
+    _process_blocks(b, loud[:300], block=100)
+    assert b.StreamRangeEvents(0) > events
+    b.close()
+
+
+@pytest.mark.skipif(FORCED, reason="forced kernel family")
+def test_real_a2_model_raises_no_range_events_on_audio(na, loader):
+    """The trained A2 container at full-scale input: no value comes near the f16 range (both submodels, 1024 streams)."""
+    m = loader.CreateFromFile(_path("BossWN-a2.nam"), doPrewarm=True)
+    b = na.Batch(0)
+    b.AddStreams(m, 8, quality=0.0)
+    b.AddStreams(m, 8, quality=1.0)
+    x = np.stack([O.signal_noise(128 * 8, seed=60 + s) * 4.0 for s in range(16)]).clip(-1, 1).astype(np.float32)
+    for a in range(0, x.shape[1], 128):
+        b.Process(np.ascontiguousarray(x[:, a:a + 128]))
+    assert [b.StreamRangeEvents(s) for s in range(16)] == [0] * 16
+    b.close()

@@ -159,6 +159,23 @@ def test_range_proof_decides_the_wavenet_kernel_family(na):
         assert il["kernel"] == want and il["range_proven"] == (want == "f16-split"), (layers, il)
 
 
+def test_rccl_is_bound_at_run_time_and_the_library_does_not_link_it(na):
+    """The multi-GPU host's RCCL fan-out / fan-in (csrc/multi_gpu.cpp, rccl_dyn.cpp): librccl.so is loaded with dlopen when a multi
+    batch asks for it -- every entry point resolves against the installed library (no GPU needed for that) -- and the product library
+    itself still links only libamdhip64 (single-GPU hosts never load RCCL)."""
+    from neuralaudio_amd import capi
+    needed = subprocess.run(["readelf", "-d", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    libs = re.findall(r"Shared library: \[([^\]]+)\]", needed)
+    assert any(l.startswith("libamdhip64") for l in libs) and not any("rccl" in l or "nccl" in l for l in libs), libs
+    if not os.path.exists("/opt/rocm/lib/librccl.so.1"):
+        pytest.skip("no RCCL in this image")
+    assert na.rccl_available(), capi.last_error()
+    # the fan-in mode is a property of a multi batch, fixed at Commit; without a device the batch itself cannot be created
+    if na.device_count() == 0:
+        with pytest.raises(na.NeuralAudioError):
+            na.MultiBatch([0])
+
+
 def test_modeltest_host_builds_and_reports_a_missing_gpu(na):
     """tools/ModelTest (the reference's Utils/ModelTest counterpart) is a C++ host of the exported API; without a device it must say so."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "tools", "ModelTest")], check=True, capture_output=True)
