@@ -397,6 +397,8 @@ def main():
                             ("%s (%s, quality %.1f), %d batched streams per GPU, 128-sample buffers" % (args.workload, "+".join(files), quality, S)),
                 "streams_per_gpu": S,
                 "block": BLOCK,
+                # address footprint of the streams' state: what decides whether the rings live in the 256 MB Infinity Cache between launches
+                "state_mb_per_gpu": batch.StateBytes() / 1e6,
                 "parallelism": "independent streams sharded across %d GPU(s), no data-path collective" % world,
                 # mixed workloads on several GPUs: the global list cut by cost (NA_ShardByCost), [begin, end) per rank
                 "shards": shard_info,

@@ -344,6 +344,16 @@ namespace na
 			return (spec == WN_SPEC_A2FULL || spec == WN_SPEC_A2LITE) ? WN_FAMILY_SPLIT : WN_FAMILY_FRAME;
 		}
 
+		// Frames of the next launch of a buffer with `left` frames to go.  Models with compact rings (wavenet_dev.h) take 128, 64 or at
+		// most 32 frames per launch -- the lengths for which a block never reads a ring position it writes; everything else 128 at a time
+		// (the reference chunks at 64, InternalModel.h:104-117; results do not depend on the chunking).
+		int NextWaveNetChunk(size_t left, bool compactRings)
+		{
+			if (left >= (size_t)WN_MAX_FRAMES) return WN_MAX_FRAMES;
+			if (!compactRings) return (int)left;
+			return left >= 64 ? 64 : (left >= 32 ? 32 : (int)left);
+		}
+
 		class WaveNetGroup : public ModelGroup
 		{
 		public:
@@ -462,6 +472,7 @@ namespace na
 				dev.split_fast_T = plan.splitFastT;
 				dev.cond_limit = plan.condLimit;
 				dev.saturate = plan.splitRangeProven ? 0 : 1;
+				dev.compact_rings = (family == WN_FAMILY_SPLIT && plan.compactRings) ? 1 : 0;
 				dev.spec_arch = family == WN_FAMILY_SPLIT ? WaveNetSpecArchId(plan.sstages.data(), (int)plan.sstages.size(), plan.stateF4, (int)(plan.wsplit.size() / 8)) : WN_SPEC_NONE;
 			}
 
@@ -541,12 +552,10 @@ namespace na
 				SyncActiveLists();
 				const int numActive = (int)hSlots.size();
 				if (numActive == 0) return;
-				// any n: chunks of <= 128 frames per launch (the reference chunks at 64, InternalModel.h:104-117;
-				// results do not depend on the chunking)
 				size_t offset = 0;
 				while (n > 0)
 				{
-					const int chunk = (int)std::min<size_t>(n, (size_t)WN_MAX_FRAMES);
+					const int chunk = NextWaveNetChunk(n, dev.compact_rings != 0);
 					const WnFamily which = family;
 					if (which == WN_FAMILY_SPLIT)
 					{
@@ -1321,10 +1330,12 @@ namespace na
 		}
 		auto launchWnList = [&](int which, hipStream_t s) {
 			const std::vector<WnFrameGroup>& list = fusedWn[which];
+			bool compact = false;
+			for (const WnFrameGroup& g : list) compact = compact || g.model->compact_rings != 0;
 			size_t offset = 0, left = n;
 			while (left > 0)
 			{
-				const int chunk = (int)std::min<size_t>(left, (size_t)WN_MAX_FRAMES);
+				const int chunk = NextWaveNetChunk(left, compact);
 				for (size_t first = 0; first < list.size(); first += WN_FRAME_MAX_GROUPS)
 					CheckHip((which == 0 ? LaunchWaveNetFrameFused : LaunchWaveNetSplitFused)(list.data() + first,
 						(int)std::min<size_t>(list.size() - first, (size_t)WN_FRAME_MAX_GROUPS), dIn + offset, dOut + offset, inStride, outStride, chunk, s),

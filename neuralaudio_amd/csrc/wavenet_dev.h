@@ -16,7 +16,8 @@
 //     [0, 16)            header: 64 ints, header[r] = write cursor (frame index) of ring r
 //     ring r             ring_frames[r]/16 tiles of G[r] channel groups, true modulo ring of the
 //                        INPUT of conv layer r (what ChannelHistoryBuffer holds in the reference,
-//                        WaveNet.h:30-83), ring_frames = roundup16((K-1)*dilation) + 128.
+//                        WaveNet.h:30-83), ring_frames = roundup16((K-1)*dilation) + 128 ("roomy"; the f16-split state
+//                        format also has exact and compact rings, see WnRingKeep below).
 #pragma once
 
 #include <cstdint>
@@ -31,6 +32,19 @@ namespace na
 	// f16-split kernels: header[63] counts "range events" of the stream -- (wave, block) pairs in which a value left the f16 range and was
 	// saturated (only chains without a static range proof can get there; models with 64 rings do not run on those kernels)
 	constexpr int WN_RANGE_EVENT_SLOT = WN_MAX_RINGS - 1;
+
+	// Ring geometry (wavenet_plan.cpp AddRing).  H = roundup16 of a layer's history (K - 1) d:
+	//   roomy    R = H + 128     every state format; a block of any n <= 128 frames never reads a position it writes
+	//   exact    R = (K - 1) d   f16-split format, d >= 128, not the first layer of an array: the one shared position is read and
+	//                            overwritten by the same lane, load first
+	//   compact  R = 3 H         f16-split format, H <= 32 (A1-style models: K <= 3, dense heads): a block reads [p - H, p) and writes
+	//                            its last H frames [p + n - H, p + n); for n in {1 .. 32, 64, 128} the two never meet modulo 3 H --
+	//                            the host cuts other buffer lengths into such pieces (WaveNetPlan::compactRings)
+	// How many frames at the end of a block a later block can still read: everything else of a block is never stored.
+	constexpr int WN_COMPACT_MAX_HISTORY = 32;
+	constexpr int WnRingKeep(int ringFrames) { return ringFrames < WN_MAX_FRAMES ? ringFrames / 3 : ringFrames - WN_MAX_FRAMES; }
+	// the buffer lengths a model with compact rings takes in one launch
+	constexpr bool WnCompactSafeFrames(int n) { return (n >= 1 && n <= 32) || n == 64 || n == 128; }
 
 	enum WnStageType : int
 	{
@@ -148,6 +162,7 @@ namespace na
 		int split_fast_T;     // fewest tiles per wave the fast instantiation can run this model with (2 or 4); 0: needs the generic one
 		int spec_arch;        // WnSpecArch: the compile-time specialised chain that runs this model (wavenet_spec_kernels.hip), 0: none
 		float cond_limit;     // f16-split kernels: input samples are clamped to +-cond_limit (WaveNetPlan::condLimit)
+		int compact_rings;    // f16-split state format: some ring is a compact one -- launches take WnCompactSafeFrames() lengths only
 		int saturate;         // f16-split kernels: 1 = no static range proof (WaveNetPlan::splitRangeProven): saturating split + range events
 	};
 

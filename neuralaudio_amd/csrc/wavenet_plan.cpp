@@ -134,6 +134,7 @@ namespace na
 
 			int pack = 1; // > 1: `desc` is a packed virtual model (PackWaveNetDesc) of `pack` streams
 			bool exactRings = false; // rings of the f16-split kernels' state format (see AddRing)
+			bool compactOk = false;  // ... and every layer has K <= 3 with dense heads: short histories get compact rings
 
 			explicit Builder(const WaveNetDesc& d, int packStreams = 1, bool exact = false) : desc(d), pack(packStreams), exactRings(exact) {}
 
@@ -168,7 +169,13 @@ namespace na
 				r.channels = channels;
 				r.G = CeilDiv(channels, 4);
 				const bool exact = exactRings && !firstOfArray && dilation >= WN_MAX_FRAMES && history >= dilation && history % WN_TILE == 0;
-				r.frames = exact ? history : CeilDiv(history, WN_TILE) * WN_TILE + WN_MAX_FRAMES;
+				// Short histories (A1's d = 1 .. 16 layers: 16 or 32 frames) in rings of three times their length instead of + 128: for the
+				// block lengths the host then restricts itself to, the frames a block reads and the ones it writes never share a position
+				// (wavenet_dev.h WnRingKeep).  A1 Standard: another 43 KB per stream (279 -> 236 KB): 1024 streams = 242 MB.
+				const int H = CeilDiv(history, WN_TILE) * WN_TILE;
+				const bool compact = compactOk && history > 0 && H <= WN_COMPACT_MAX_HISTORY;
+				if (compact) plan.compactRings = true;
+				r.frames = exact ? history : (compact ? 3 * H : H + WN_MAX_FRAMES);
 				r.offF4 = plan.stateF4;
 				plan.stateF4 += (r.frames / WN_TILE) * r.G * WN_TILE; // tiles * G * 16 float4
 				plan.rings.push_back(r);
@@ -647,6 +654,13 @@ namespace na
 
 				plan.arrays = desc.arrays;
 				plan.receptiveField = desc.ReceptiveFieldSize();
+				compactOk = exactRings;
+				for (const WnArrayCfg& cfg : desc.arrays)
+				{
+					if (cfg.headKernelSize != 1) compactOk = false;
+					for (int k : cfg.kernelSizes)
+						if (k > 3) compactOk = false;
+				}
 				plan.stateF4 = WN_HEADER_F4;
 				plan.genericOk = true;
 				for (const WnArrayCfg& cfg : desc.arrays)

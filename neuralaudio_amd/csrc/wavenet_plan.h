@@ -44,6 +44,7 @@ namespace na
 		float condLimit = 32752.0f; // f16-split kernels: input samples are clamped to +-condLimit (range contract)
 		// static proof of that contract (wavenet_plan.cpp): with inputs inside +-condLimit >= kSplitMinInputLimit no value of the chain leaves
 		// the f16 range, and the weights fit the f16-split operand format.  A plan that fails either runs on the f32 frame kernel.
+		bool compactRings = false;  // some ring is a compact one: launches take buffer lengths of WnCompactSafeFrames() only
 		bool splitRangeProven = true;
 		bool splitWeightsOk = true;
 		int receptiveField = 0;

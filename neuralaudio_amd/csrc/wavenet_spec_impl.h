@@ -41,6 +41,7 @@ namespace na
 			static constexpr bool COARSE = false; // (dilations are powers of two: at most three wave classes per layer, 53 KB of code)
 			static constexpr bool GUARDHIST = false;
 			static constexpr int SKEW = 0;
+			static constexpr bool COMPACT = true; // K <= 3 everywhere, dense heads: histories of <= 32 frames live in compact rings (wavenet_plan.cpp AddRing)
 		};
 #ifndef NA_SPK_SKEW
 #define NA_SPK_SKEW 0
@@ -92,6 +93,7 @@ namespace na
 			static constexpr bool COARSE = true;
 			static constexpr bool GUARDHIST = true;
 			static constexpr int SKEW = 0;
+			static constexpr bool COMPACT = false;
 		};
 		struct ArchA2Full : ArchA2Base { static constexpr int CH[2] = { 8, 0 }; static constexpr int T = 2; };
 		struct ArchA2Lite : ArchA2Base { static constexpr int CH[2] = { 4, 0 }; static constexpr int T = 4; };
@@ -123,13 +125,16 @@ namespace na
 			// ring L < NL: input history of layer L; ring NL: the head accumulator's (wavenet_plan.cpp AddRing: roundup16((K - 1) d) + 128)
 			// (wavenet_plan.cpp AddRing: a dilation of at least a whole block -> exactly (K - 1) d frames, else roundup16((K - 1) d) + 128)
 			static constexpr bool ExactRing(int L) { return L < NL && !FirstOfArr(L) && Dil(L) >= FRAMES && KS(L) > 1 && ((KS(L) - 1) * Dil(L)) % 16 == 0; }
+			static constexpr int HistFrames(int L) { return L < NL ? ((KS(L) - 1) * Dil(L) + 15) / 16 * 16 : (HEADK - 1 + 15) / 16 * 16; } // roundup16((K - 1) d)
+			static constexpr bool CompactRing(int L) { return A::COMPACT && L < NL && KS(L) > 1 && HistFrames(L) <= WN_COMPACT_MAX_HISTORY; }
 			static constexpr int RingFrames(int L)
 			{
 				if (ExactRing(L)) return (KS(L) - 1) * Dil(L);
-				return L < NL ? ((KS(L) - 1) * Dil(L) + 15) / 16 * 16 + FRAMES : (HEADK - 1 + 15) / 16 * 16 + FRAMES;
+				if (CompactRing(L)) return 3 * HistFrames(L);
+				return HistFrames(L) + FRAMES;
 			}
 			// frames of a block a later block can still read: the whole history of an exact ring, R - 128 of the others
-			static constexpr int RingKeep(int L) { return ExactRing(L) ? RingFrames(L) : RingFrames(L) - FRAMES; }
+			static constexpr int RingKeep(int L) { return ExactRing(L) ? RingFrames(L) : (CompactRing(L) ? HistFrames(L) : RingFrames(L) - FRAMES); }
 			static constexpr int RingG(int L) { return GPof(L < NL ? ArrOf(L) : NA - 1); }
 			static constexpr int RingOff(int L) // quads
 			{
@@ -213,7 +218,8 @@ namespace na
 			static constexpr int WBUF_ONE = MAXOPS * 1024;
 			static constexpr int IDOP_OFF = WBUF_OFF + NWB * 2 * WBUF_ONE;      // identity operand
 			static constexpr int DUMP_OFF = IDOP_OFF + 1024;                    // where the LDS-DMA of a wave with nothing to stage lands
-			static constexpr int LDS_BYTES = DUMP_OFF + 1024;
+			static constexpr int FLAG_OFF = DUMP_OFF + 1024;                    // [SPB] x 16 bytes: "a value of this stream was saturated" (LeakyReLU chains)
+			static constexpr int LDS_BYTES = FLAG_OFF + 16 * SPB;
 			static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 		};
 
@@ -354,12 +360,12 @@ namespace na
 		// f32 quad -> split quad: plain for the tanh chains (covered by the static range proof, wavenet_plan.cpp), saturating for the
 		// LeakyReLU ones
 		template <class C>
-		__device__ __forceinline__ u32x4 Split(f32x4 v)
+		__device__ __forceinline__ u32x4 Split(f32x4 v, const Ctx& cx)
 		{
 #ifdef NA_NO_SAT // tuning builds: what the saturating split costs the A2 chains (make SUFFIX=_nosat KEXTRA=-DNA_NO_SAT)
 			return SplitQuad(v);
 #else
-			if constexpr (C::A::LEAKY) return SplitQuadSat(v);
+			if constexpr (C::A::LEAKY) return SplitQuadSat(v, (unsigned)(C::FLAG_OFF + 16 * cx.sub));
 			else return SplitQuad(v);
 #endif
 		}
@@ -457,8 +463,20 @@ namespace na
 				LdsWrite16(ln.img + (unsigned)(imgWrite * C::IMG_ONE + 16 * P * i * 16), v);
 			if ((NA_ABL & 4) || !StoreNeeded<C, RG>(i)) return;
 			const int pos0 = __builtin_amdgcn_readlane(cx.myPos, RG);
-			int base = pos0 + C::FW * cx.wave + 16 * P * i; // < 2R
-			if (base >= R) base -= R;
+			int base;
+			if constexpr (TB::CompactRing(RG))
+			{
+				// a ring shorter than the block: the kept frames (the last KEEP of the block) are counted back from the cursor AFTER the
+				// block, (pos0 + NF) mod R; frame f sits NF - f <= KEEP frames behind it.  (Only the sets that keep something use `base`.)
+				int end = pos0 + C::NF % R;
+				if (end >= R) end -= R;
+				base = end - C::NF + C::FW * cx.wave + 16 * P * i + R; // position of the set's first frame + R: in [0, 2R) for a keeping set
+			}
+			else
+			{
+				base = pos0 + C::FW * cx.wave + 16 * P * i; // < 2R
+				if (base >= R) base -= R;
+			}
 			const int addr = RingWrap<GP, R>(ln.ring, base);
 			if (KEEP >= C::NF) RingStore(cx.srsrc, v, addr, OFF * 16);
 			else RingStore(cx.srsrc, v, (C::FW * cx.wave + 16 * P * i + ln.fl >= C::NF - KEEP) ? addr : OOB, OFF * 16);
@@ -697,7 +715,7 @@ namespace na
 						st.xc[i] = y;
 						if constexpr (SG::NEXT)
 						{
-							st.xs[i] = Split<C>(y);
+							st.xs[i] = Split<C>(y, cx);
 							Publish<C, LN, GP, NEXTMINSHIFT>(cx, ln, st.xs[i], i, imgWrite);
 						}
 					}
@@ -782,7 +800,7 @@ namespace na
 				x = Mfma(ra, ax, x);
 				st.xc[i] = x;
 				st.hd[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // WaveNet.h:772 headArray.SetZero()
-				st.xs[i] = Split<C>(x);
+				st.xs[i] = Split<C>(x, cx);
 				Publish<C, 0, GP, C::TB::Dil(0)>(cx, ln, st.xs[i], i, 1);
 			}
 			FirstHistDispatch<C, 0, 0>(cx, ln.ring, ln.fl, st);
@@ -809,8 +827,8 @@ namespace na
 #pragma unroll
 			for (int i = 0; i < So; i++)
 			{
-				hs[i] = Split<C>(st.hd[i]);
-				xq[i] = Split<C>(st.xc[i]);
+				hs[i] = Split<C>(st.hd[i], cx);
+				xq[i] = Split<C>(st.xc[i], cx);
 			}
 			f32x4 hn[Sn], xn[Sn];
 #pragma unroll
@@ -835,7 +853,7 @@ namespace na
 			{
 				st.hd[i] = hn[i];
 				st.xc[i] = xn[i];
-				st.xs[i] = Split<C>(xn[i]);
+				st.xs[i] = Split<C>(xn[i], cx);
 				Publish<C, LN, GPN, TB::Dil(LN)>(cx, ln, st.xs[i], i, (s + 1) & 1);
 			}
 			FirstHistDispatch<C, LN, 0>(cx, ln.ring, ln.fl, st);
@@ -861,7 +879,7 @@ namespace na
 #pragma unroll
 			for (int i = 0; i < S; i++)
 			{
-				hs[i] = Split<C>(st.hd[i]);
+				hs[i] = Split<C>(st.hd[i], cx);
 				acc[i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 			}
 #pragma unroll
@@ -1062,6 +1080,10 @@ namespace na
 				const unsigned hi = (q == (i >> 2)) ? (((i & 3) == 2) ? one : ((i & 3) == 3) ? (one << 16) : 0u) : 0u;
 				LdsWrite16((unsigned)C::IDOP_OFF + (unsigned)lane * 16u, u32x4{ lo, hi, lo, hi });
 			}
+			if constexpr (C::A::LEAKY)
+			{
+				if (threadIdx.x < SPB) *reinterpret_cast<__attribute__((address_space(3))) unsigned*>((LdsPtr)(size_t)(unsigned)(C::FLAG_OFF + 16 * threadIdx.x)) = 0u;
+			}
 			// stage 0's single operand (offset 0 of every weight image), into every pair of weight buffers
 			if (cx.stgWave == 0) LdsWrite16(cx.wbuf + (unsigned)lane * 16u, BufLoad(cx.wrsrc, lane * 16));
 			BlockBarrier<C::NTHREADS / 64>();
@@ -1073,7 +1095,6 @@ namespace na
 					for (int k = 0; k < C::SKEW; k++) BlockBarrier<C::NTHREADS / 64>();
 			}
 			State st;
-			if constexpr (C::A::LEAKY) ClearRangeStatus();
 			RunArrays<C, 0>(cx, st, out, (size_t)row * outStride, outRow, pack, ga.headScale, live);
 			if constexpr (C::SKEW > 0)
 			{
@@ -1084,13 +1105,20 @@ namespace na
 #ifdef NA_SP_TRACE
 			if (cx.trace != nullptr && lane == 0) cx.trace[((C::TB::NSTAGES * 8 + 1) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
 #endif
-			if constexpr (C::A::LEAKY) CountRangeEventFromStatus(header, lane, live);
+			if constexpr (C::A::LEAKY)
+			{
+				// every wave of the stream is through its last split: the closing wave reads the stream's flag word
+				BlockBarrier<C::NTHREADS / 64>();
+				if (wave == 0) CountRangeEvent(header, (int)*reinterpret_cast<__attribute__((address_space(3))) unsigned*>((LdsPtr)(size_t)(unsigned)(C::FLAG_OFF + 16 * sub)), lane, live);
+			}
 			// advance every ring cursor by NF (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
 			if (wave == 0 && live && lane < ga.nrings)
 			{
 				const int R = ga.ringFrames[lane];
 				int p = cx.myPos + NF;
 				if (p >= R) p -= R;
+				if (p >= R) p -= R;
+				if (p >= R) p -= R; // (compact rings are shorter than a block: R >= 48)
 				header[lane] = p;
 			}
 		}

@@ -89,34 +89,26 @@ namespace na
 		// Saturating variant for chains the static range proof does not cover (LeakyReLU models: wavenet_plan.cpp), used
 		// for every value that reaches the stream STATE -- the residual stream (block images, rings) and the head accumulator (head
 		// ring): a value beyond the f16 range is clamped to +-65504 instead of becoming inf (inf - inf = NaN in the lo half would poison
-		// the rings for good; v_med3_f32 also turns a NaN into -65504).  That it happened is remembered by the hardware: the quad's
-		// largest magnitude goes through one f32 -> f16 conversion whose only purpose is to raise the wave's sticky IEEE OVERFLOW flag
-		// (TRAPSTS.EXCP accumulates whether or not traps are enabled) -- no flag register to carry through a chain that has none to
-		// spare -- and the wave counts a "range event" in the stream's state header when it finds the flag set at the end of the block
-		// (CountRangeEventFromStatus).  The activations themselves are split plainly: their conversion raises the same flag, and the
-		// overflow surfaces in the residual stream one mat-mul later.  Inside the range it is SplitQuad bit for bit.
-		__device__ __forceinline__ u32x4 SplitQuadSat(f32x4 v)
+		// the rings for good; v_med3_f32 also turns a NaN into -65504).  A lane that clamped something drops a 1 into the stream's flag word
+		// in LDS (`flagAddr`: a branch that audio never takes, no register carried through a chain that has none to spare); the wave that
+		// closes the block counts a "range event" in the stream's state header when the word is set (CountRangeEvent).  The activations
+		// themselves are split plainly: an overflow there surfaces in the residual stream one mat-mul later.  Inside the range it is
+		// SplitQuad bit for bit.  (The wave's sticky IEEE overflow flag, TRAPSTS.EXCP, would have been the free way to remember: with the
+		// default exception mask v_cvt_f16_f32(1e6) leaves it clear on gfx950 -- tools/microbench/trapsts_probe.hip.)
+		__device__ __forceinline__ u32x4 SplitQuadSat(f32x4 v, unsigned flagAddr)
 		{
 			const float m = 65504.0f;
+			// largest magnitude of the quad: two instructions (the plain expression costs four: fabs is canonicalised through v_max(|a|, |a|))
 			float top;
-			asm volatile("v_max3_f32 %0, |%1|, |%2|, |%3|\n\t"
-				"v_max_f32_e64 %0, %0, |%4|\n\t"
-				"v_cvt_f16_f32_e32 %0, %0"
-				: "=&v"(top)
-				: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+			asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(top) : "v"(v.x), "v"(v.y), "v"(v.z));
+			asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(top) : "v"(top), "v"(v.w));
+			if (!(top <= m)) // (a NaN counts)
+				*reinterpret_cast<__attribute__((address_space(3))) unsigned*>((__attribute__((address_space(3))) char*)(size_t)flagAddr) = 1u;
 			v.x = __builtin_amdgcn_fmed3f(v.x, -m, m);
 			v.y = __builtin_amdgcn_fmed3f(v.y, -m, m);
 			v.z = __builtin_amdgcn_fmed3f(v.z, -m, m);
 			v.w = __builtin_amdgcn_fmed3f(v.w, -m, m);
 			return SplitQuad(v);
-		}
-		// TRAPSTS.EXCP (hardware register 3, bits 8:0): bit 0 invalid (inf - inf), bit 3 overflow.  Cleared at the start of the block, read
-		// at its end: one event per wave and block in which a value left the f16 range (`live`: not a shadow wave of a partial workgroup)
-		__device__ __forceinline__ void ClearRangeStatus() { __builtin_amdgcn_s_setreg((3 | (0 << 6) | ((9 - 1) << 11)), 0); }
-		__device__ __forceinline__ void CountRangeEventFromStatus(int* header, int lane, bool live)
-		{
-			const unsigned excp = __builtin_amdgcn_s_getreg(3 | (0 << 6) | ((9 - 1) << 11));
-			if ((excp & 0x9u) != 0 && live && lane == 0) __hip_atomic_fetch_add(&header[WN_RANGE_EVENT_SLOT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 
 		// the same for the stage interpreter, whose flag the compiler cannot prove wave-uniform (it travels through the stage loop): plain

@@ -148,17 +148,28 @@ namespace na
 			return v;
 		}
 
+		// write cursor of a ring after a block of n <= 128 frames (rings may be shorter than a block: compact rings, wavenet_dev.h)
+		__device__ __forceinline__ int RingAdvance(int pos0, int n, int R)
+		{
+			int p = pos0 + n;
+			if (p >= R) p -= R;
+			if (p >= R) p -= R;
+			if (p >= R) p -= R; // n <= 128, R >= 48
+			return p;
+		}
+
 		// layer output -> LDS block image (in-block taps of the next layer) and -> the next layer's HBM ring (history for LATER blocks:
-		// only the last R - FRAMES frames of a block can ever be read back).  One store instruction on every path.
-		__device__ __forceinline__ void Publish(const Ctx& cx, u32x4* imgNext, u32x4 v, int f, int cg, bool liveLane, int outRingOff, int outR, int outG, int outPos0, int nSt)
+		// only the last WnRingKeep(R) frames of a block can ever be read back).  One store instruction on every path.  A kept frame's ring
+		// position is counted back from the cursor AFTER the block (outPosEnd = RingAdvance(cursor, n, R)): n - f <= R frames behind it.
+		__device__ __forceinline__ void Publish(const Ctx& cx, u32x4* imgNext, u32x4 v, int f, int cg, bool liveLane, int outRingOff, int outR, int outG, int outPosEnd, int nSt)
 		{
 			if (!(NA_ABL & 64) && liveLane) imgNext[ImgIdx(cg, f)] = v;
 			if (NA_ABL & 4) return;
-			const int firstKept = nSt - (outR - FRAMES);
-			unsigned p = (unsigned)(outPos0 + f);
-			p = __builtin_elementwise_min(p, p - (unsigned)outR);
+			const int firstKept = nSt - WnRingKeep(outR);
+			int p = outPosEnd - (cx.n - f);
+			p = p < 0 ? p + outR : p;
 			const bool keep = liveLane && (f < nSt) && (f >= firstKept);
-			RingStore(cx.srsrc, v, (!(NA_ABL & (512 | 1024)) && keep) ? RingByte(outRingOff, outG, (int)p, cg) : OOB);
+			RingStore(cx.srsrc, v, (!(NA_ABL & (512 | 1024)) && keep) ? RingByte(outRingOff, outG, p, cg) : OOB);
 		}
 
 		// Stages the NEXT stage's A-operand block into the other LDS weight buffer with LDS-DMA loads (buffer_load_dwordx4 ... lds: lane l's
@@ -291,7 +302,7 @@ namespace na
 				const int K = GEN ? sd.ksize : 3, d = sd.dilation, G = GEN ? sd.G : GP;
 				const bool mask = GEN && (Geo<GP, T>::PARTIAL || G < GP); // wave-uniform: some lanes have no channel group / no tile of their own
 				const int inPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
-				const int outPos0 = (sd.out_ring_id >= 0) ? __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id) : 0;
+				const int outPos0 = (sd.out_ring_id >= 0) ? RingAdvance(__builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id), cx.n, sd.out_ring_frames) : 0; // cursor AFTER the block
 				const int gsShift = PK ? (sd.reserved >> 1) : 0; // channel groups per packed stream: 1, 2, 4 -> 0, 1, 2
 
 				// dilated conv (WaveNet.h:139-290): tap k reads the frame d*(K-1-k) back; accumulation starts from zero, bias and mix-in
@@ -462,7 +473,7 @@ namespace na
 			stager.Begin(cx, (s + 1) & 1, sdn);
 			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + lane;
 			u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
-			const int outPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id);
+			const int outPos0 = RingAdvance(__builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id), cx.n, sd.out_ring_frames); // cursor AFTER the block
 			const u32x4 ra = wl[0];
 #pragma unroll
 			for (int i = 0; i < S; i++)
@@ -500,7 +511,7 @@ namespace na
 			stager.Begin(cx, (s + 1) & 1, sdn);
 			const u32x4* wl = cx.wbuf + (s & 1) * cx.wstride + lane;
 			u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
-			const int outPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id);
+			const int outPos0 = RingAdvance(__builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id), cx.n, sd.out_ring_frames); // cursor AFTER the block
 
 			u32x4 hs[So], xs[So];
 #pragma unroll
@@ -586,7 +597,7 @@ namespace na
 				u32x4* imgNext = cx.img + (cur ^ 1) * cx.imgStride;
 				const int pos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
 #pragma unroll
-				for (int i = 0; i < S; i++) Publish(cx, imgNext, hs[i], f[i], cg[i], live[i] && cg[i] < G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, pos0, cx.nSt);
+				for (int i = 0; i < S; i++) Publish(cx, imgNext, hs[i], f[i], cg[i], live[i] && cg[i] < G, sd.out_ring_off, sd.out_ring_frames, sd.out_G, RingAdvance(pos0, cx.n, sd.out_ring_frames), cx.nSt);
 				cur ^= 1;
 				BlockBarrier<NTHREADS / 64>();
 				for (int k = 0; k < K - 1; k++)
@@ -802,10 +813,7 @@ namespace na
 			// advance every ring cursor by n (ChannelHistoryBuffer::AdvanceFrames, WaveNet.h:59-65, as a true modulo ring)
 			if (wave == 0 && liveStream && lane < ga.nrings)
 			{
-				const int R = ga.ringFrames[lane];
-				int p = cx.myPos + n;
-				if (p >= R) p -= R;
-				header[lane] = p;
+				header[lane] = RingAdvance(cx.myPos, n, ga.ringFrames[lane]);
 			}
 		}
 

@@ -357,18 +357,19 @@ def test_models_without_a_range_proof_run_on_the_f32_kernel(na, loader, case, fa
     assert np.all(np.isfinite(y))
     # These models are badly conditioned on purpose (a residual stream of 1e3 .. 1e4 in front of an unsaturated tanh): the f32 oracle
     # itself is only so close to exact arithmetic, so the kernel is held to the oracle's own distance from a float64 evaluation
-    # (tests/ref_np.py) -- at most 8 x for the 22-bit split values, 3 x for the f32 kernel -- relative to the output level
-    y64 = ref_np.wavenet_forward(arrays, w, x)
+    # (tests/ref_np.py; the oracle is 0.1 % .. 25 % off on the scaled ones) -- at most 8 x for the 22-bit split values, 4 x for the
+    # f32 kernel, whose sums run in another order
+    y64, _ = ref_np.wavenet_forward(arrays, w, x)
     g, o, level = O.rms(y - y64), O.rms(yo - y64), O.rms(y64)
-    assert level > 0 and g <= (8.0 if want == "WaveNetSpecKernel" else 3.0) * o + 2e-6 * level, (case, g, o, level)
+    assert level > 0 and g <= (8.0 if want == "WaveNetSpecKernel" else 4.0) * o + 2e-6 * level, (case, g, o, level)
     assert b.StreamRangeEvents(0) == 0
     b.close()
 
 
 def _a2_style_weights(channels, conv_gain, seed):
     """A2-shaped seeded weights with every layer conv scaled by `conv_gain` and the biases scaled down, so that what the layers do to the
-    signal is what the input level makes of it (measured with tests/ref_np.py at conv_gain 10: the residual stream peaks at 1.6e6 /
-    7.7e6 times the input amplitude for 8 / 3 channels)."""
+    signal is what the input level makes of it (measured with tests/ref_np.py at conv_gain 4: the residual stream peaks at 49 / 118
+    times the input amplitude for 8 / 3 channels, the head accumulator at 137 / 325 times)."""
     arrays = O.a2_arrays(channels)
     w = O.synth_wavenet_weights(arrays, seed=seed)
     return arrays, O.scale_wavenet_tensors(arrays, w, {"conv": conv_gain, "conv_bias": 1e-6, "1x1_bias": 1e-6, "head_bias": 1e-6})
@@ -378,26 +379,33 @@ def _a2_style_weights(channels, conv_gain, seed):
 @pytest.mark.parametrize("channels", [8, 3])
 def test_a2_chain_saturates_counts_the_event_and_recovers(na, loader, channels):
     """LeakyReLU chains have no static range proof (the worst case is the product of 23 layers' row sums), so the official A2 shapes run
-    with saturating arithmetic: an A2-shaped model whose layers amplify (gain > 1 per layer, > 1e6 over the chain) follows the f32 oracle
-    while the signal is quiet (amplitude 1e-5: internal peaks of 16 .. 80); a full-scale passage drives the residual stream past 65504 -- the values are clamped (no inf, no NaN: the
-    rings are not poisoned), NA_BatchStreamRangeEvents counts it -- and one receptive field after the passage the stream is back on the
-    oracle."""
-    arrays, w = _a2_style_weights(channels, 10.0, seed=40 + channels)
+    with saturating arithmetic: an A2-shaped model whose layers amplify (gain > 1 per layer, 50 .. 300 over the chain) follows the f32
+    oracle at audio level; a passage at 3000 x full scale -- inside the input limit, which only covers the linear path of such a model --
+    drives the residual stream past 65504: the values are clamped (no inf, no NaN: the rings are not poisoned),
+    NA_BatchStreamRangeEvents counts it, and one receptive field after the passage the stream is back on the oracle.  Errors are judged
+    against a float64 evaluation (tests/ref_np.py): the amplifying chain multiplies everybody's rounding."""
+    arrays, w = _a2_style_weights(channels, 4.0, seed=40 + channels)
     m = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam", doPrewarm=True)
     assert m is not None
     info = m.KernelInfo(1.0, 1)
-    assert info["kernel"] == "f16-split" and not info["range_proven"]
+    assert info["kernel"] == "f16-split" and not info["range_proven"] and info["input_limit"] > 3000.0
     ora = O.OracleWaveNet(arrays, w)
     rf = ora.receptive_field
     assert rf == 6346
     b = na.Batch(0)
     b.AddStreams(m, 1)
     assert b.StreamKernelName(0) == "WaveNetSpecKernel"
-    quiet = (1e-5 * O.signal_noise(128 * 20, seed=3)).astype(np.float32)
-    loud = O.signal_noise(128 * 4, seed=4)
-    back = (1e-5 * O.signal_noise(128 * 60, seed=5)).astype(np.float32)
+    quiet, loud, back = O.signal_noise(128 * 20, seed=3), (3000.0 * O.signal_noise(128 * 4, seed=4)).astype(np.float32), O.signal_noise(128 * 60, seed=5)
+    y64, _ = ref_np.wavenet_forward(arrays, w, np.concatenate([quiet, loud, back]))
+    t1, t2 = y64[:quiet.size], y64[quiet.size + loud.size:]
+
+    def close(y, o, t):
+        g, e, level = O.rms(y - t), O.rms(o - t), O.rms(t)
+        return level > 0 and g <= 8.0 * e + 1e-5 * level, (g, e, level)
+
     y1, o1 = _process_blocks(b, quiet), ora.process(quiet)
-    assert O.rms(o1) > 0 and O.rms(y1 - o1) <= 1e-4 * O.rms(o1) + 1e-9, (O.rms(y1 - o1), O.rms(o1))
+    ok, detail = close(y1, o1, t1)
+    assert ok, detail
     assert b.StreamRangeEvents(0) == 0
     y2, o2 = _process_blocks(b, loud), ora.process(loud)
     assert np.all(np.isfinite(y2)) and np.all(np.isfinite(o2))
@@ -405,10 +413,11 @@ def test_a2_chain_saturates_counts_the_event_and_recovers(na, loader, channels):
     y3, o3 = _process_blocks(b, back), ora.process(back)
     assert np.all(np.isfinite(y3))
     tail = ((rf + 127) // 128 + 1) * 128
-    assert O.rms(y3[tail:] - o3[tail:]) <= 1e-4 * O.rms(o3[tail:]) + 1e-9, (O.rms(y3[tail:] - o3[tail:]), O.rms(o3[tail:]))
+    ok, detail = close(y3[tail:], o3[tail:], t2[tail:])
+    assert ok, detail
     events = b.StreamRangeEvents(0)
     _process_blocks(b, back[:1280])
-    assert b.StreamRangeEvents(0) == events  # nothing new once the signal is quiet again
+    assert b.StreamRangeEvents(0) == events  # nothing new once the signal is back at audio level
     # the stage interpreter (other block lengths) saturates and counts the same way
     _process_blocks(b, loud[:300], block=100)
     assert b.StreamRangeEvents(0) > events
