@@ -77,6 +77,12 @@ namespace na
 			static constexpr int DIL[2][16] = { { 1, 2, 4, 8, 16, 32, 64 }, { 128, 256, 512, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512 } };
 		};
 
+		// The same with ONE tile per wave: eight waves per 128-frame stream instead of four.  For launches of at most one virtual stream per
+		// CU (Nano x <= 1024): such a launch is a chain of 23 short stages bound by what its few waves can issue, and half the work per
+		// wave halves the stage (both arrays are 16 channels wide: every tile has an MFMA of its own, so nothing is shared between the
+		// tiles of a wave that splitting them would lose).  Same state, same arithmetic per frame.
+		struct ArchLite16T1 : ArchLite16 { static constexpr int T = 1; };
+
 		// A2 (NeuralModel.cpp:389-421, InternalModel.h:18-20): one array of 23 layers, kernel sizes 6 / 15, a conv head of 16 taps with bias,
 		// LeakyReLU.  "Full": 8 channels (lane mode 2, 2 tiles per wave).  "Lite": 3 channels padded to 4 (lane mode 1: four tiles share
 		// an MFMA, so a wave owns 4 tiles = 64 frames and a stream takes half the waves).  Operand blocks move through LDS in chunks of
@@ -103,6 +109,7 @@ namespace na
 		struct FamLite { typedef ArchLite A0; typedef ArchLite A1; static constexpr int N = 1; };
 		struct FamLitePacked { typedef ArchLite A0; typedef ArchLite16 A1; static constexpr int N = 2; };
 		struct FamA2 { typedef ArchA2Full A0; typedef ArchA2Lite A1; static constexpr int N = 2; };
+		struct FamLite16T1 { typedef ArchLite16T1 A0; typedef ArchLite16T1 A1; static constexpr int N = 1; };
 
 		enum TapClass { TAP_LDS = 0, TAP_HIST = 1, TAP_BOTH = 2 };
 
@@ -819,7 +826,7 @@ namespace na
 			typedef typename C::TB TB;
 			constexpr int GPO = TB::GPof(AN - 1), GPN = TB::GPof(AN), Po = 4 / GPO, Pn = 4 / GPN, NC = Po > Pn ? Po : Pn;
 			constexpr int So = Geo<GPO, C::T>::S, Sn = Geo<GPN, C::T>::S, s = TB::LinkStage(AN), LN = TB::FirstLayerOfArr(AN);
-			static_assert(C::T == 2, "array links are written for two tiles per wave");
+			static_assert(C::T == 1 || C::T == 2, "array links are written for one or two tiles per wave");
 			SPK_STAMP(s, 0);
 			GuardStage<C, LN, GPN>(cx, ln, (s + 1) & 1);
 			Stager<C, s + 1, 0>::Begin(cx);
@@ -840,7 +847,7 @@ namespace na
 				hn[i] = Mfma(WOp<C>(cx, s, 0, 4 * NC), AuxRead<C, GPN>(ln, i), hn[i]);
 			}
 #pragma unroll
-			for (int t = 0; t < 2; t++)
+			for (int t = 0; t < C::T; t++)
 			{
 				const int u = t % NC, so = t / Po, sn = t / Pn;
 				hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
@@ -1132,8 +1139,11 @@ namespace na
 #ifndef NA_SPK_OCC
 #define NA_SPK_OCC(nf, spb) (((nf) * (spb) / 64) < 1 ? 1 : ((nf) * (spb) / 64))
 #endif
+		// (one tile per wave: launched with at most one workgroup per CU, i.e. half the waves per SIMD of the same thread count)
+		template <class F, int NF, int SPB>
+		constexpr int OccOf() { return F::A0::T == 1 ? (NA_SPK_OCC(NF, SPB) / 2 < 1 ? 1 : NA_SPK_OCC(NF, SPB) / 2) : NA_SPK_OCC(NF, SPB); }
 		template <class F, int NF, int SPB, bool PK>
-		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(NA_SPK_OCC(NF, SPB)))) WaveNetSpecKernel(const LaunchArgs args,
+		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(OccOf<F, NF, SPB>()))) WaveNetSpecKernel(const LaunchArgs args,
 			const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride
 #ifdef NA_SP_TRACE
 			, long long* __restrict__ trace, int traceBlock
@@ -1246,17 +1256,27 @@ namespace na
 			(void)spb; (void)n;
 			return Launch<F, 128, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream);
 #else
+			if constexpr (F::A0::T == 1)
+			{
+				// one tile per wave: one stream per workgroup (SPB_ = 2 in units of four-wave streams), every block length
+				if (n == 128) return Launch<F, 128, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream);
+				if (n == 64) return Launch<F, 64, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream);
+				return Launch<F, 32, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream);
+			}
+			else
+			{
 			if (n == 128) return spb >= 2 ? Launch<F, 128, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream) : Launch<F, 128, 1, PK>(groups, numGroups, in, out, inStride, outStride, stream);
 			if (n == 64) return spb >= 2 ? Launch<F, 64, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream) : Launch<F, 64, 1, PK>(groups, numGroups, in, out, inStride, outStride, stream);
 			if constexpr (F::A0::T == 2 && F::A1::T == 2)
 				return spb >= 2 ? Launch<F, 32, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream) : Launch<F, 32, 1, PK>(groups, numGroups, in, out, inStride, outStride, stream);
 			else return hipErrorNotSupported; // (a wave of a 4-tile architecture covers 64 frames)
+			}
 #endif
 		}
 
 		// (defined in the family's translation unit)
 		hipError_t LaunchSpecLite(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, bool packed,
-			hipStream_t stream);
+			hipStream_t stream, bool oneTilePerWave = false);
 		hipError_t LaunchSpecA2(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream);
 	}
 }

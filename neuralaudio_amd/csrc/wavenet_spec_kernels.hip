@@ -83,7 +83,18 @@ namespace na
 		if (fam == 0) return packed ? hipErrorNotSupported : spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
 		if (fam == 2) return packed ? hipErrorNotSupported : spk::LaunchSpecA2(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
 		if (!packed && lite16) return hipErrorNotSupported; // (16 / 16 only exists packed)
-		return spk::LaunchSpecLite(groups, numGroups, in, out, inStride, outStride, n, spb, packed, stream);
+		// a launch of 16 / 16 virtual streams only (packed Nano) with at most one of them per CU: one tile per wave, eight waves per stream
+		// (Nano x 1024 = 256 virtual streams: a chain of 23 short stages, bound by what its few waves can issue)
+		static const bool noT1 = getenv("NA_SP_NO_T1") != nullptr; // tuning knob
+		bool all16 = packed && !noT1;
+		int virtualStreams = 0;
+		for (int i = 0; i < numGroups; i++)
+		{
+			all16 = all16 && groups[i].model->spec_arch == WN_SPEC_LITE16;
+			virtualStreams += groups[i].numStreams;
+		}
+		const bool t1 = all16 && spbEnv == 0 && virtualStreams <= CurrentDeviceCUs();
+		return spk::LaunchSpecLite(groups, numGroups, in, out, inStride, outStride, n, spb, packed, stream, t1);
 #endif
 	}
 }

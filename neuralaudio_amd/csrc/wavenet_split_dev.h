@@ -98,10 +98,10 @@ namespace na
 		__device__ __forceinline__ u32x4 SplitQuadSat(f32x4 v, unsigned flagAddr)
 		{
 			const float m = 65504.0f;
-			// largest magnitude of the quad: two instructions (the plain expression costs four: fabs is canonicalised through v_max(|a|, |a|))
-			float top;
-			asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(top) : "v"(v.x), "v"(v.y), "v"(v.z));
-			asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(top) : "v"(top), "v"(v.w));
+			// (plain expressions on purpose: `v` usually comes straight out of an MFMA, and the wait states a VALU read of an MFMA result needs
+			// are inserted by the compiler for its own instructions, not for inline assembly -- a hand-written v_max3_f32 here read
+			// half-written accumulators and raised false events)
+			const float top = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)), __builtin_fabsf(v.w));
 			if (!(top <= m)) // (a NaN counts)
 				*reinterpret_cast<__attribute__((address_space(3))) unsigned*>((__attribute__((address_space(3))) char*)(size_t)flagAddr) = 1u;
 			v.x = __builtin_amdgcn_fmed3f(v.x, -m, m);

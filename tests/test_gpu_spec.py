@@ -77,8 +77,11 @@ SEQUENCES = [[128] * 6, [64] * 8, [32] * 8, [128, 37, 64, 100, 32, 128, 1, 64, 1
 
 
 @pytest.mark.skipif(FORCED, reason="forced kernel family")
-@pytest.mark.parametrize("which,streams", [("standard", 3), ("standard", 515), ("lite", 2), ("lite", 513), ("feather", 1030), ("nano", 1031)])
+@pytest.mark.parametrize("which,streams", [("standard", 3), ("standard", 515), ("lite", 2), ("lite", 513), ("feather", 1030), ("nano", 1031),
+                                           ("nano", 6), ("nano", 1003)])
 def test_specialised_chain_is_bit_identical_to_the_interpreter(na, loader, spec_switch, which, streams):
+    """(Nano x 6 / x 1003: at most one packed virtual stream per CU -> the one-tile-per-wave chain, eight waves per stream, partly filled
+    last virtual stream; Nano x 1031: more virtual streams than CUs -> two tiles per wave.)"""
     m, make_oracle = _models(loader, which)
     rng = np.random.default_rng(11)
     for sizes in SEQUENCES:

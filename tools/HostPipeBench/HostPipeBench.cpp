@@ -1,7 +1,7 @@
 // HostPipeBench: PCIe-inclusive throughput of the batched engine from a plain C++ host, through the C ABI only
 // (include/neuralaudio_amd.h): host buffers in, host buffers out, pipelined with NA_BatchSubmit / NA_BatchCollect.
 //   HostPipeBench <model file> [streams=1024] [frames=128] [buffers=2000]
-//   HostPipeBench <model file> [streams] [frames] [buffers] --gpus N [--devices 0,0,...]
+//   HostPipeBench <model file> [streams] [frames] [buffers] --gpus N [--devices 0,0,...] [--fan-in rccl]
 //       the multi-GPU host (NA_Multi*: one batch + one host thread + one HIP stream per device, the global stream list sharded by
 //       cost): `streams` is the GLOBAL count; --devices names the device of every shard explicitly (an index may repeat, e.g. 0,0 runs
 //       two shards on one GPU -- the plumbing test on a single-GPU box).  A second model file may follow --mix: the global list is then
@@ -21,10 +21,12 @@ static double Now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 #define CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "HostPipeBench: %s failed: %s\n", #cond, NA_GetLastError()); return 1; } } while (0)
 
-static int RunMulti(NeuralModelLoader* loader, NeuralModel* model, const char* mixFile, const std::vector<int>& devices, int streams, int frames, int buffers)
+static int RunMulti(NeuralModelLoader* loader, NeuralModel* model, const char* mixFile, const std::vector<int>& devices, int streams, int frames, int buffers, bool rcclFanIn)
 {
 	NA_MultiBatch* multi = NA_MultiCreate(devices.data(), (int)devices.size());
 	CHECK(multi != nullptr);
+	// --fan-in rccl: weights replicated and output rows gathered over RCCL (one rank per shard: distinct devices); blocking calls only
+	if (rcclFanIn) CHECK(NA_MultiSetFanIn(multi, 1) == 0);
 	NeuralModel* second = nullptr;
 	if (mixFile)
 	{
@@ -61,18 +63,28 @@ static int RunMulti(NeuralModelLoader* loader, NeuralModel* model, const char* m
 		if (i >= 30) lat.push_back((Now() - t0) * 1e6);
 	}
 	std::sort(lat.begin(), lat.end());
-	int pending = NA_MultiSubmit(multi, in.data(), (size_t)frames);
-	CHECK(pending >= 0);
-	const double t0 = Now();
-	for (int i = 0; i < buffers; i++)
+	double usPipe = 0.0;
+	if (!rcclFanIn)
 	{
-		const int next = NA_MultiSubmit(multi, in.data(), (size_t)frames);
-		CHECK(next >= 0);
+		int pending = NA_MultiSubmit(multi, in.data(), (size_t)frames);
+		CHECK(pending >= 0);
+		const double t0 = Now();
+		for (int i = 0; i < buffers; i++)
+		{
+			const int next = NA_MultiSubmit(multi, in.data(), (size_t)frames);
+			CHECK(next >= 0);
+			CHECK(NA_MultiCollect(multi, pending, out.data()) == 0);
+			pending = next;
+		}
 		CHECK(NA_MultiCollect(multi, pending, out.data()) == 0);
-		pending = next;
+		usPipe = (Now() - t0) * 1e6 / buffers;
 	}
-	CHECK(NA_MultiCollect(multi, pending, out.data()) == 0);
-	const double usPipe = (Now() - t0) * 1e6 / buffers;
+	else
+	{
+		const double t0 = Now();
+		for (int i = 0; i < buffers; i++) CHECK(NA_MultiProcess(multi, in.data(), out.data(), (size_t)frames) == 0);
+		usPipe = (Now() - t0) * 1e6 / buffers; // (blocking calls back to back: the gathered path has no pipelined form)
+	}
 	std::printf("{\"multi_gpu_host\": true, \"shards\": [");
 	for (int s = 0; s < NA_MultiNumShards(multi); s++)
 	{
@@ -80,9 +92,9 @@ static int RunMulti(NeuralModelLoader* loader, NeuralModel* model, const char* m
 		CHECK(NA_MultiShardRange(multi, s, &b, &e, &d) == 0);
 		std::printf("%s{\"device\": %d, \"begin\": %d, \"end\": %d}", s ? ", " : "", d, b, e);
 	}
-	std::printf("], \"streams\": %d, \"frames\": %d, \"buffers\": %d, \"matches_single_batch\": %s, \"us_per_buffer_pipelined\": %.3f, \"Msamples_per_s\": %.1f, "
+	std::printf("], \"fan_in\": \"%s\", \"streams\": %d, \"frames\": %d, \"buffers\": %d, \"matches_single_batch\": %s, \"us_per_buffer_pipelined\": %.3f, \"Msamples_per_s\": %.1f, "
 		"\"blocking_latency_us\": {\"p50\": %.1f, \"p99\": %.1f}}\n",
-		streams, frames, buffers, identical ? "true" : "false", usPipe, (double)count / usPipe, lat[lat.size() / 2], lat[(size_t)(lat.size() * 0.99)]);
+		rcclFanIn ? "rccl" : "host rows", streams, frames, buffers, identical ? "true" : "false", usPipe, (double)count / usPipe, lat[lat.size() / 2], lat[(size_t)(lat.size() * 0.99)]);
 	NA_MultiDestroy(multi);
 	if (second) DeleteModel(second);
 	return identical ? 0 : 3;
@@ -90,14 +102,16 @@ static int RunMulti(NeuralModelLoader* loader, NeuralModel* model, const char* m
 
 int main(int argc, char** argv)
 {
-	if (argc < 2) { std::fprintf(stderr, "usage: HostPipeBench <model> [streams] [frames] [buffers] [--gpus N] [--devices a,b,...] [--mix <model 2>]\n"); return 2; }
+	if (argc < 2) { std::fprintf(stderr, "usage: HostPipeBench <model> [streams] [frames] [buffers] [--gpus N] [--devices a,b,...] [--mix <model 2>] [--fan-in rccl]\n"); return 2; }
 	std::vector<const char*> pos;
 	std::vector<int> devices;
 	int gpus = 0;
 	const char* mixFile = nullptr;
+	bool rcclFanIn = false;
 	for (int i = 1; i < argc; i++)
 	{
 		if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = std::atoi(argv[++i]);
+		else if (!std::strcmp(argv[i], "--fan-in") && i + 1 < argc) rcclFanIn = !std::strcmp(argv[++i], "rccl");
 		else if (!std::strcmp(argv[i], "--mix") && i + 1 < argc) mixFile = argv[++i];
 		else if (!std::strcmp(argv[i], "--devices") && i + 1 < argc)
 		{
@@ -119,7 +133,7 @@ int main(int argc, char** argv)
 	{
 		if (devices.empty())
 			for (int d = 0; d < gpus; d++) devices.push_back(d);
-		const int rc = RunMulti(loader, model, mixFile, devices, streams, frames, buffers);
+		const int rc = RunMulti(loader, model, mixFile, devices, streams, frames, buffers, rcclFanIn);
 		DeleteModel(model);
 		DeleteLoader(loader);
 		return rc;
