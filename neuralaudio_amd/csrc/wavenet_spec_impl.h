@@ -21,6 +21,17 @@ namespace na
 	{
 		using namespace sp;
 
+// tuning builds: cache policy of the ring traffic of layers with a dilation >= NA_SPK_NT_DIL -- NA_SPK_NT_LD / NA_SPK_NT_ST are the
+// policy immediates of their history loads / ring stores (0 = default policy; 2 = nt; 16 = sc1; 18 = both)
+#ifndef NA_SPK_NT_DIL
+#define NA_SPK_NT_DIL 256
+#endif
+#ifndef NA_SPK_NT_LD
+#define NA_SPK_NT_LD 0
+#endif
+#ifndef NA_SPK_NT_ST
+#define NA_SPK_NT_ST 0
+#endif
 #ifndef NA_SPK_AUX2
 #define NA_SPK_AUX2 0 // tuning builds: 1 = read the aux operand again for the 1x1 instead of keeping it in registers across the layer
 #endif
@@ -404,6 +415,12 @@ namespace na
 			if (base < 0) base += R;
 			if (base >= R) base -= R;
 			const int addr = RingWrap<GP, R>(laneRing, base);
+			constexpr bool LONG = RG < TB::NL && TB::Dil(RG < TB::NL ? RG : 0) >= NA_SPK_NT_DIL;
+			if constexpr (LONG && NA_SPK_NT_LD != 0)
+			{
+				if (cls == TAP_HIST) return RingLoadAux<NA_SPK_NT_LD>(cx.srsrc, addr, OFF * 16);
+				return RingLoadAux<NA_SPK_NT_LD>(cx.srsrc, (C::FW * cx.wave + 16 * P * i + fl < shift) ? addr : OOB, OFF * 16);
+			}
 			if (cls == TAP_HIST) return RingLoad(cx.srsrc, addr, OFF * 16);
 			return RingLoad(cx.srsrc, (C::FW * cx.wave + 16 * P * i + fl < shift) ? addr : OOB, OFF * 16);
 		}
@@ -485,6 +502,13 @@ namespace na
 				if (base >= R) base -= R;
 			}
 			const int addr = RingWrap<GP, R>(ln.ring, base);
+			constexpr bool LONG = RG < TB::NL && TB::Dil(RG < TB::NL ? RG : 0) >= NA_SPK_NT_DIL;
+			if constexpr (LONG && NA_SPK_NT_ST != 0)
+			{
+				if (KEEP >= C::NF) RingStoreAux<NA_SPK_NT_ST>(cx.srsrc, v, addr, OFF * 16);
+				else RingStoreAux<NA_SPK_NT_ST>(cx.srsrc, v, (C::FW * cx.wave + 16 * P * i + ln.fl >= C::NF - KEEP) ? addr : OOB, OFF * 16);
+				return;
+			}
 			if (KEEP >= C::NF) RingStore(cx.srsrc, v, addr, OFF * 16);
 			else RingStore(cx.srsrc, v, (C::FW * cx.wave + 16 * P * i + ln.fl >= C::NF - KEEP) ? addr : OOB, OFF * 16);
 		}

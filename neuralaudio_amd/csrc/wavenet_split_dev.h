@@ -50,6 +50,11 @@ namespace na
 		// nt 2-4 % slower, the others within noise -- default policy)
 		__device__ __forceinline__ u32x4 RingLoad(__amdgpu_buffer_rsrc_t r, int voff, int soff = 0) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); }
 		__device__ __forceinline__ void RingStore(__amdgpu_buffer_rsrc_t r, u32x4 v, int voff, int soff = 0) { __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0); }
+		// tuning builds (NA_SPK_NT): the same with a cache-policy immediate (1 sc0, 2 nt, 16 sc1) for the rings of the long dilations
+		template <int AUX>
+		__device__ __forceinline__ u32x4 RingLoadAux(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX); }
+		template <int AUX>
+		__device__ __forceinline__ void RingStoreAux(__amdgpu_buffer_rsrc_t r, u32x4 v, int voff, int soff) { __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, AUX); }
 
 		// ---- arithmetic -------------------------------------------------------------------------------------------------------
 
