@@ -61,6 +61,84 @@ PORT_NOTE = ("kind 'port' = oracle/na_oracle.c, a scalar C restatement built -O3
 
 def _timed_cpu_run(run, label, seconds_target):
     """run(blocks, threads) -> wall seconds of `threads` independent copies each processing `blocks` buffers of BLOCK zeros."""
+    cores = usable_cores()
+    # calibrate on a short all-core run, then size the timed run to ~seconds_target of wall time
+    t1 = run(32, 1)
+    single = 32 * BLOCK / t1
+    tc = run(16, cores)
+    per_thread = 16 * BLOCK / tc
+    blocks = max(16, min(int(seconds_target * per_thread / BLOCK), 2000000))
+    t = run(blocks, cores)
+    total = cores * blocks * BLOCK
+    return {
+        "value": total / t / 1e6,
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%s: %d threads x %d buffers of %d zero samples each after prewarm (ModelTest protocol), %.1f s wall; "
+                  "single-thread %.3f Msamples/s (%.1fx real-time); %s" % (label, cores, blocks, BLOCK, t, single / 1e6, single / 48000.0, PORT_NOTE),
+    }
+
+
+def cpu_baseline_synthetic_recurrent(kind, model_json, seconds_target):
+    """config 4's seeded models (no such files ship with the reference): NAM LSTM 2x16 / keras GRU 1x16 through the oracle's bench loops."""
+    import ctypes as C
+    import numpy as np
+    import na_oracle as O  # cpu_baseline leg only
+
+    lib = O.load_native_lib()
+    fp = C.POINTER(C.c_float)
+    if kind == "lstm":
+        w = np.ascontiguousarray(model_json["weights"], dtype=np.float32)
+        nl, hid = int(model_json["config"]["num_layers"]), int(model_json["config"]["hidden_size"])
+        return _timed_cpu_run(lambda blocks, threads: lib.na_oracle_lstm_bench(nl, hid, w.ctypes.data_as(fp), w.size, BLOCK, blocks, threads),
+                              "synthetic NAM LSTM %dx%d" % (nl, hid), seconds_target)
+    layers = model_json["layers"]
+    nl, hid = len(layers) - 1, int(layers[0]["shape"][-1])
+    keep = [[np.ascontiguousarray(np.array(layers[i]["weights"][k], dtype=np.float32).ravel()) for i in range(nl)] for k in range(3)]
+    hw = np.ascontiguousarray(np.array(layers[-1]["weights"][0], dtype=np.float32).ravel())
+    hb = float(layers[-1]["weights"][1][0])
+    ptrs = [(fp * nl)(*[a.ctypes.data_as(fp) for a in keep[k]]) for k in range(3)]
+    lib.na_oracle_gru_bench.restype = C.c_double
+    lib.na_oracle_gru_bench.argtypes = [C.c_int, C.c_int, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), fp, C.c_float, C.c_int, C.c_int, C.c_int]
+    return _timed_cpu_run(lambda blocks, threads: lib.na_oracle_gru_bench(nl, hid, ptrs[0], ptrs[1], ptrs[2], hw.ctypes.data_as(fp), hb, BLOCK, blocks, threads),
+                          "synthetic keras GRU %dx%d (RTNeural arithmetic: parity unpinned)" % (nl, hid), seconds_target)
+
+
+def cpu_baseline(workload="standard", seconds_target=12.0):
+    """The oracle ('port' of the reference's Internal CPU path) timed on this box's host cores,
+    ModelTest protocol (blocks of zeros after prewarm, Utils/ModelTest/ModelTest.cpp:59-79)."""
+    import ctypes as C
+    import numpy as np
+    import na_oracle as O  # cpu_baseline leg only
+
+    lib = O.load_native_lib()
+    files = {"standard": "BossWN-standard.nam", "feather": "BossWN-feather.nam", "nano": "BossWN-nano.nam", "a2full": "BossWN-a2.nam",
+             "a2lite": "BossWN-a2.nam", "lstm1x16": "BossLSTM-1x16.nam", "lstm2x8": "BossLSTM-2x8.nam"}
+    if workload == "lite":
+        j = json.loads(synthetic_lite_nam())
+        files = dict(files, lite="synthetic A1 Lite (12/6 channels, seeded weights)")
+    elif workload not in files:
+        raise ValueError("no CPU baseline for workload " + workload)
+    else:
+        j = O.load_json(files[workload])
+    if j["architecture"] == "SlimmableContainer":
+        j = j["config"]["submodels"][O.quality_to_submodel(j, 0.0 if workload == "a2lite" else 1.0)]["model"]
+    w = np.ascontiguousarray(j["weights"], dtype=np.float32)
+    wp = w.ctypes.data_as(C.POINTER(C.c_float))
+    if j["architecture"] == "LSTM":
+        nl, hid = int(j["config"]["num_layers"]), int(j["config"]["hidden_size"])
+        lib.na_oracle_lstm_bench.restype = C.c_double
+        lib.na_oracle_lstm_bench.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_int, C.c_int]
+
+        def run(blocks, threads):
+            return lib.na_oracle_lstm_bench(nl, hid, wp, w.size, BLOCK, blocks, threads)
+    else:
+        arrays = O.wavenet_arrays_from_nam(j)
+        cfgs = O._cfgs(arrays)
+
+        def run(blocks, threads):
+            return lib.na_oracle_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, blocks, threads)
     return _timed_cpu_run(run, files[workload], seconds_target)
 
 

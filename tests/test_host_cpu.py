@@ -719,3 +719,22 @@ def test_stream_cost_estimates_rank_the_official_models(models_dir):
     assert cost["BossWN-standard.nam"] > cost["BossWN-feather.nam"] > cost["BossWN-nano.nam"] > 0
     assert cost["BossWN-a2.nam"] > cost["a2-lite"] > cost["BossLSTM-1x16.nam"] > 0
     assert 35.0 < cost["BossWN-standard.nam"] < 50.0 and 15.0 < cost["BossLSTM-1x16.nam"] < 25.0  # (us per 1024 streams x 128 frames)
+
+
+def test_bench_cpu_baseline_legs_run(na):
+    """bench.py's cpu_baseline leg (the oracle timed on the host cores: the only place outside tests / smoke() that may call it) for
+    every kind of workload the bench line carries one for -- single models, the mixed batches, config 4's seeded recurrent models."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import numpy as np
+    r = bench.cpu_baseline("standard", 0.2)
+    assert r["value"] > 0 and r["kind"] == "port" and r["cores"] >= 1 and "MULTIFRAME_8X8" in r["sample"]
+    assert bench.mixed_cpu_baseline(["a2lite", "a2full"], 0.3)["value"] > 0
+    rng = np.random.default_rng(4)
+    H, a = 8, 0.25
+    lw = np.concatenate([rng.uniform(-a, a, 4 * H * (1 + H) + 4 * H + 2 * H), rng.uniform(-a, a, H + 1)])
+    lstm = {"architecture": "LSTM", "config": {"input_size": 1, "hidden_size": H, "num_layers": 1}, "weights": [float(v) for v in lw]}
+    gru = {"layers": [{"type": "gru", "shape": [None, None, H], "weights": [rng.uniform(-a, a, (1, 3 * H)).tolist(), rng.uniform(-a, a, (H, 3 * H)).tolist(),
+                                                                              rng.uniform(-a, a, (2, 3 * H)).tolist()]},
+                      {"type": "dense", "shape": [None, None, 1], "weights": [rng.uniform(-a, a, (H, 1)).tolist(), [0.0]]}]}
+    assert bench.mixed_cpu_baseline([("lstm", lstm), ("gru", gru)], 0.3)["value"] > 0
