@@ -14,7 +14,7 @@ namespace na
 {
 	constexpr int LSTM_MAX_LAYERS = 8;
 	constexpr int LSTM_MAX_FRAMES = 128;
-	constexpr int LSTM_MAX_TAIL = 4;        // dense layers of a generic keras stack
+	constexpr int LSTM_MAX_TAIL = 8;        // dense layers of a generic keras stack (after lowering: activation / batchnorm / prelu layers become dense ones)
 	constexpr int LSTM_MAX_TAIL_WIDTH = 64; // units per dense layer
 
 	enum { LSTM_CELL_LSTM = 0, LSTM_CELL_GRU = 1 };

@@ -458,6 +458,16 @@ namespace na
 			return desc;
 		}
 
+		int KerasActivation(const std::string& act, const char* what)
+		{
+			if (act.empty() || act == "linear") return DENSE_LINEAR;
+			if (act == "tanh") return DENSE_TANH;
+			if (act == "relu") return DENSE_RELU;
+			if (act == "sigmoid") return DENSE_SIGMOID;
+			if (act == "elu") return DENSE_ELU;
+			throw std::runtime_error(std::string("keras ") + what + " activation '" + act + "' is not supported");
+		}
+
 		// One keras dense layer: weights [in][out], bias [out], optional activation (RTNeural json_parser: a Dense layer followed by an
 		// activation layer).  Throws on an activation this library has no kernel for.
 		DenseLayerDesc ReadKerasDense(const Json& layer, int in)
@@ -472,14 +482,141 @@ namespace na
 			d.w.assign(kernel.size(), 0.0f);
 			for (int k = 0; k < d.in; k++)
 				for (int o = 0; o < d.out; o++) d.w[(size_t)o * d.in + k] = kernel[(size_t)k * d.out + o];
-			const std::string act = layer.Contains("activation") ? layer.At("activation").AsString() : std::string();
-			if (act.empty() || act == "linear") d.activation = DENSE_LINEAR;
-			else if (act == "tanh") d.activation = DENSE_TANH;
-			else if (act == "relu") d.activation = DENSE_RELU;
-			else if (act == "sigmoid") d.activation = DENSE_SIGMOID;
-			else if (act == "elu") d.activation = DENSE_ELU;
-			else throw std::runtime_error("keras dense activation '" + act + "' is not supported");
+			d.activation = KerasActivation(layer.Contains("activation") ? layer.At("activation").AsString() : std::string(), "dense");
 			return d;
+		}
+
+		// The layer types behind the recurrent part that this library evaluates with its dense-chain kernels.  Besides "dense" (RTNeural
+		// json_parser: a Dense layer + an activation layer) the element-wise layers of RTNeural's parser are LOWERED at load time to dense
+		// layers, so that no kernel has to know them:
+		//   "activation"  joins the dense layer in front of it when that one is linear, else an identity layer carries it
+		//   "batchnorm"   y = gamma (x - mean) / sqrt(var + epsilon) + beta (weights [gamma, beta, mean, var], or [mean, var] without the
+		//                 affine part; epsilon 1e-3 when the file has none): folded into a linear dense layer in front of it, else a
+		//                 diagonal layer
+		//   "prelu"       y = max(x, 0) + alpha min(x, 0) (weights [alpha], per unit or one value) = relu(x) - alpha relu(-x): the rows
+		//                 [W; -W] of a linear dense layer in front of it with relu, then the layer [I | -diag(alpha)] -- twice the
+		//                 width in between (<= 64)
+		// conv1d (a causal convolution over time: it needs state) and softmax have no kernel here: such a model is not accepted.
+		// Third-party arithmetic (RTNeural is absent): parity unpinned, checked by the test suite against a float64 restatement.
+		bool IsKerasTailType(const std::string& t) { return t == "dense" || t == "time-distributed-dense" || t == "activation" || t == "batchnorm" || t == "prelu"; }
+
+		DenseLayerDesc DiagonalDense(const std::vector<float>& scale, const std::vector<float>& shift)
+		{
+			DenseLayerDesc d;
+			d.in = d.out = (int)scale.size();
+			d.w.assign((size_t)d.in * d.out, 0.0f);
+			for (int i = 0; i < d.in; i++) d.w[(size_t)i * d.in + i] = scale[(size_t)i];
+			d.b = shift;
+			d.activation = DENSE_LINEAR;
+			return d;
+		}
+
+		void AppendKerasTailLayer(const Json& layer, int in, std::vector<DenseLayerDesc>& tail)
+		{
+			const std::string type = layer.At("type").AsString();
+			if (type == "dense" || type == "time-distributed-dense")
+			{
+				tail.push_back(ReadKerasDense(layer, in));
+				return;
+			}
+			const bool foldable = !tail.empty() && tail.back().activation == DENSE_LINEAR; // a linear dense layer right in front
+			if (type == "activation")
+			{
+				const int act = KerasActivation(layer.Contains("activation") ? layer.At("activation").AsString() : std::string(), "activation layer");
+				if (foldable) tail.back().activation = act;
+				else
+				{
+					tail.push_back(DiagonalDense(std::vector<float>((size_t)in, 1.0f), std::vector<float>((size_t)in, 0.0f)));
+					tail.back().activation = act;
+				}
+				return;
+			}
+			if (type == "batchnorm")
+			{
+				const Json& w = layer.At("weights");
+				std::vector<float> gamma((size_t)in, 1.0f), beta((size_t)in, 0.0f), mean, var;
+				if (w.Size() >= 4)
+				{
+					gamma.clear(); beta.clear();
+					w.At(0).FlattenNumbers(gamma); w.At(1).FlattenNumbers(beta); w.At(2).FlattenNumbers(mean); w.At(3).FlattenNumbers(var);
+				}
+				else if (w.Size() == 2) { w.At(0).FlattenNumbers(mean); w.At(1).FlattenNumbers(var); }
+				else throw std::runtime_error("keras batchnorm layer has unexpected weight shapes");
+				if ((int)gamma.size() != in || (int)beta.size() != in || (int)mean.size() != in || (int)var.size() != in)
+					throw std::runtime_error("keras batchnorm layer has unexpected weight shapes");
+				const double eps = (layer.Contains("epsilon") && layer.At("epsilon").IsNumber()) ? layer.At("epsilon").AsDouble() : 1e-3;
+				std::vector<float> scale((size_t)in), shift((size_t)in);
+				for (int i = 0; i < in; i++)
+				{
+					const double s = (double)gamma[(size_t)i] / std::sqrt((double)var[(size_t)i] + eps);
+					scale[(size_t)i] = (float)s;
+					shift[(size_t)i] = (float)((double)beta[(size_t)i] - (double)mean[(size_t)i] * s);
+				}
+				if (foldable)
+				{
+					DenseLayerDesc& p = tail.back();
+					for (int o = 0; o < p.out; o++)
+					{
+						for (int k = 0; k < p.in; k++) p.w[(size_t)o * p.in + k] *= scale[(size_t)o];
+						p.b[(size_t)o] = p.b[(size_t)o] * scale[(size_t)o] + shift[(size_t)o];
+					}
+				}
+				else tail.push_back(DiagonalDense(scale, shift));
+				return;
+			}
+			if (type == "prelu")
+			{
+				std::vector<float> alpha;
+				layer.At("weights").At(0).FlattenNumbers(alpha);
+				if (alpha.size() == 1) alpha.assign((size_t)in, alpha[0]);
+				if ((int)alpha.size() != in) throw std::runtime_error("keras prelu layer has unexpected weight shapes");
+				if (2 * in > LSTM_MAX_TAIL_WIDTH) throw std::runtime_error("keras prelu layer wider than " + std::to_string(LSTM_MAX_TAIL_WIDTH / 2) + " units is not supported");
+				DenseLayerDesc a; // [x; -x] (of the linear dense layer in front when there is one), relu
+				if (foldable)
+				{
+					const DenseLayerDesc p = tail.back();
+					tail.pop_back();
+					a.in = p.in; a.out = 2 * in;
+					a.w.assign((size_t)a.out * a.in, 0.0f);
+					a.b.assign((size_t)a.out, 0.0f);
+					for (int o = 0; o < in; o++)
+					{
+						for (int k = 0; k < p.in; k++)
+						{
+							a.w[(size_t)o * a.in + k] = p.w[(size_t)o * p.in + k];
+							a.w[(size_t)(in + o) * a.in + k] = -p.w[(size_t)o * p.in + k];
+						}
+						a.b[(size_t)o] = p.b[(size_t)o];
+						a.b[(size_t)(in + o)] = -p.b[(size_t)o];
+					}
+				}
+				else
+				{
+					a.in = in; a.out = 2 * in;
+					a.w.assign((size_t)a.out * a.in, 0.0f);
+					a.b.assign((size_t)a.out, 0.0f);
+					for (int o = 0; o < in; o++)
+					{
+						a.w[(size_t)o * in + o] = 1.0f;
+						a.w[(size_t)(in + o) * in + o] = -1.0f;
+					}
+				}
+				a.activation = DENSE_RELU;
+				DenseLayerDesc b; // relu(x) - alpha relu(-x)
+				b.in = 2 * in; b.out = in;
+				b.w.assign((size_t)b.out * b.in, 0.0f);
+				b.b.assign((size_t)b.out, 0.0f);
+				for (int o = 0; o < in; o++)
+				{
+					b.w[(size_t)o * b.in + o] = 1.0f;
+					b.w[(size_t)o * b.in + in + o] = -alpha[(size_t)o];
+				}
+				b.activation = DENSE_LINEAR;
+				tail.push_back(std::move(a));
+				tail.push_back(std::move(b));
+				return;
+			}
+			throw std::runtime_error("keras layer type '" + type + "' is not supported");
 		}
 
 		// Generic keras stacks -- what the reference hands to RTNeural's json_parser (NeuralModel.cpp:565-572, RTNeuralModel.h:300):
@@ -487,7 +624,8 @@ namespace na
 		// the output is unit 0 of the last layer (RTNeuralModelDyn::Process, RTNeuralModel.h:417-421).  Arithmetic as RTNeural's with the
 		// reference's FastMathsProvider (RTNeuralModel.h:10-31): accurate tanh, sigmoid = (tanh(x/2)+1)/2 -- so an LSTM in such a
 		// stack runs with the StdMath policy.  Parity unpinned (RTNeural is an absent submodule): tests compare against a numpy
-		// restatement of the Keras definitions.  Other layer types (conv1d, batchnorm, prelu ...) have no kernel: nullptr.
+		// restatement of the Keras definitions.  activation / batchnorm / prelu layers are lowered to dense layers (AppendKerasTailLayer);
+		// conv1d and softmax have no kernel: nullptr.
 		std::shared_ptr<ModelDesc> ReadKerasStack(const Json& modelJson)
 		{
 			const Json& layers = modelJson.At("layers");
@@ -504,7 +642,7 @@ namespace na
 			}
 			if (numRec == total) return nullptr; // no dense layer at the end
 			for (size_t i = numRec; i < total; i++)
-				if (layers.At(i).At("type").AsString() != "dense") return nullptr;
+				if (!IsKerasTailType(layers.At(i).At("type").AsString())) return nullptr;
 
 			std::shared_ptr<ModelDesc> desc;
 			if (numRec > 0)
@@ -556,7 +694,7 @@ namespace na
 			int in = numRec > 0 ? d.hiddenSize : 1;
 			for (size_t i = numRec; i < total; i++)
 			{
-				d.tail.push_back(ReadKerasDense(layers.At(i), in));
+				AppendKerasTailLayer(layers.At(i), in, d.tail);
 				in = d.tail.back().out;
 			}
 			d.headWeights.assign((size_t)std::max(d.hiddenSize, 1), 0.0f); // unused with a tail

@@ -32,6 +32,9 @@ namespace na
 #ifndef NA_SPK_NT_ST
 #define NA_SPK_NT_ST 0
 #endif
+#ifndef NA_SPK_DELAY
+#define NA_SPK_DELAY 0
+#endif
 #ifndef NA_SPK_AUX2
 #define NA_SPK_AUX2 0 // tuning builds: 1 = read the aux operand again for the 1x1 instead of keeping it in registers across the layer
 #endif
@@ -1185,6 +1188,13 @@ namespace na
 				if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
 			const GroupArgs& ga = args.g[gi];
 			const int groupBlock = (int)blockIdx.x - ga.firstBlock;
+#if NA_SPK_DELAY > 0
+			// tuning builds: the second half of the grid (the workgroups that arrive SECOND on their CUs when the launch is one round of two
+			// workgroups per CU) starts NA_SPK_DELAY x 64 cycles late, so that the two workgroups of a CU are out of phase: one in its
+			// issue-bound stages while the other waits for memory in its d >= 64 stages
+			if (blockIdx.x >= gridDim.x / 2)
+				for (int k = 0; k < NA_SPK_DELAY; k += 100) __builtin_amdgcn_s_sleep(100);
+#endif
 #ifdef NA_SP_TRACE
 			long long* tr = ((int)blockIdx.x == traceBlock) ? trace : nullptr;
 			if (F::N > 1 && ga.arch == 1) RunWorkgroup<C1>(ga, groupBlock, in, out, inStride, outStride, tr);

@@ -212,6 +212,15 @@ def keras_stack_forward(model_json, x, prewarm=2048):
                 h = (1.0 - z) * c + z * h
                 state[i][0] = h
                 v = h
+            elif l["type"] == "activation":
+                v = acts[l.get("activation", "") or ""](v)
+            elif l["type"] == "batchnorm":  # inference form; [gamma, beta, mean, var] or [mean, var]; keras default epsilon
+                eps = float(l.get("epsilon", 1e-3))
+                g, b, m, s2 = (W[i][0].ravel(), W[i][1].ravel(), W[i][2].ravel(), W[i][3].ravel()) if len(W[i]) >= 4 else (1.0, 0.0, W[i][0].ravel(), W[i][1].ravel())
+                v = g * (v - m) / np.sqrt(s2 + eps) + b
+            elif l["type"] == "prelu":
+                alpha = W[i][0].ravel()
+                v = np.maximum(v, 0.0) + alpha * np.minimum(v, 0.0)
             else:
                 v = acts[l.get("activation", "") or ""](v @ W[i][0] + W[i][1].ravel())
         out[t] = v[0]
@@ -219,7 +228,8 @@ def keras_stack_forward(model_json, x, prewarm=2048):
 
 
 def synth_keras_stack(spec, seed):
-    """spec: list of ("lstm" | "gru" | "dense", units[, activation]); seeded U(-a, a) weights, a = 1/sqrt(fan-in-ish)."""
+    """spec: list of ("lstm" | "gru" | "dense", units[, activation]) and, behind a layer of `units` units, ("activation", units, name) |
+    ("batchnorm", units[, "noaffine"]) | ("prelu", units[, "scalar"]); seeded U(-a, a) weights, a = 1/sqrt(fan-in-ish)."""
     rng = np.random.default_rng(seed)
     layers = []
     cur = 1
@@ -232,6 +242,15 @@ def synth_keras_stack(spec, seed):
             layers.append({"type": kind, "activation": "tanh", "shape": [None, None, units],
                            "weights": [rng.uniform(-a, a, (cur, g * units)).round(7).tolist(), rng.uniform(-a, a, (units, g * units)).round(7).tolist(),
                                        bias.round(7).tolist()]})
+        elif kind == "activation":
+            layers.append({"type": "activation", "activation": item[2], "shape": [None, None, units], "weights": []})
+        elif kind == "batchnorm":
+            mean, var = rng.uniform(-0.3, 0.3, units).round(7).tolist(), rng.uniform(0.2, 1.5, units).round(7).tolist()
+            w = [mean, var] if len(item) > 2 and item[2] == "noaffine" else [rng.uniform(0.5, 1.5, units).round(7).tolist(), rng.uniform(-0.2, 0.2, units).round(7).tolist(), mean, var]
+            layers.append({"type": "batchnorm", "epsilon": 0.001, "shape": [None, None, units], "weights": w})
+        elif kind == "prelu":
+            alpha = [float(rng.uniform(0.05, 0.4))] if len(item) > 2 and item[2] == "scalar" else rng.uniform(0.05, 0.4, units).round(7).tolist()
+            layers.append({"type": "prelu", "shape": [None, None, units], "weights": [alpha]})
         else:
             layers.append({"type": "dense", "activation": item[2] if len(item) > 2 else "", "shape": [None, None, units],
                            "weights": [rng.uniform(-a, a, (cur, units)).round(7).tolist(), rng.uniform(-a, a, (units,)).round(7).tolist()]})

@@ -196,7 +196,11 @@ def test_runtime_shaped_lstm_matches_oracle(na, loader, layers, hidden):
 
 @pytest.mark.parametrize("spec", [[("lstm", 8), ("dense", 6, "tanh"), ("dense", 1)], [("gru", 12), ("dense", 5, "relu"), ("dense", 3, "sigmoid"), ("dense", 1)],
                                   [("dense", 8, "tanh"), ("dense", 4, "elu"), ("dense", 1)], [("gru", 8), ("gru", 8), ("dense", 2)],
-                                  [("lstm", 16), ("dense", 1, "tanh")], [("lstm", 5), ("lstm", 5), ("dense", 64, "relu"), ("dense", 1)]],
+                                  [("lstm", 16), ("dense", 1, "tanh")], [("lstm", 5), ("lstm", 5), ("dense", 64, "relu"), ("dense", 1)],
+                                  # activation / batchnorm / prelu layers (lowered to dense layers at load, model_loader.cpp AppendKerasTailLayer)
+                                  [("gru", 8), ("dense", 6), ("batchnorm", 6), ("activation", 6, "tanh"), ("dense", 1)],
+                                  [("lstm", 8), ("prelu", 8), ("dense", 4), ("prelu", 4, "scalar"), ("batchnorm", 4, "noaffine"), ("dense", 1)],
+                                  [("dense", 8), ("activation", 8, "relu"), ("batchnorm", 8), ("dense", 1)]],
                          ids=lambda s: "-".join("%s%d%s" % (l[0], l[1], l[2] if len(l) > 2 else "") for l in s))
 def test_generic_keras_stack_matches_numpy_restatement(na, loader, spec):
     """Generic keras stacks (SURVEY 8 f3): the reference evaluates them with RTNeural, which is an absent submodule -- parity unpinned;

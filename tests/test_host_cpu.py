@@ -306,7 +306,11 @@ def test_generic_keras_stacks_accepted_or_rejected_at_load(na, tmp_path):
     loader = na.NeuralModelLoader()
     path = tmp_path / "m.json"
     for spec in ([("lstm", 8), ("dense", 6, "tanh"), ("dense", 1)], [("gru", 12), ("dense", 5, "relu"), ("dense", 3, "sigmoid"), ("dense", 1)],
-                 [("dense", 8, "tanh"), ("dense", 4, "elu"), ("dense", 1)], [("gru", 8), ("dense", 2)], [("lstm", 16), ("dense", 1, "tanh")]):
+                 [("dense", 8, "tanh"), ("dense", 4, "elu"), ("dense", 1)], [("gru", 8), ("dense", 2)], [("lstm", 16), ("dense", 1, "tanh")],
+                 # the element-wise layers of RTNeural's parser, lowered to dense layers at load (model_loader.cpp AppendKerasTailLayer)
+                 [("gru", 8), ("dense", 6), ("batchnorm", 6), ("activation", 6, "tanh"), ("dense", 1)],
+                 [("lstm", 8), ("prelu", 8), ("dense", 4), ("prelu", 4, "scalar"), ("batchnorm", 4, "noaffine"), ("dense", 1)],
+                 [("dense", 8), ("activation", 8, "relu"), ("batchnorm", 8), ("dense", 1)]):
         path.write_text(json.dumps(R.synth_keras_stack(spec, seed=5)))
         m = loader.CreateFromFile(str(path), doPrewarm=False)
         assert m is not None, spec
@@ -321,6 +325,10 @@ def test_generic_keras_stacks_accepted_or_rejected_at_load(na, tmp_path):
     mixed = R.synth_keras_stack([("gru", 8), ("lstm", 8), ("dense", 1)], seed=7)  # two kinds of recurrent layers: no kernel
     path.write_text(json.dumps(mixed))
     assert loader.CreateFromFile(str(path), doPrewarm=False) is None
+    wide = R.synth_keras_stack([("gru", 8), ("dense", 40), ("prelu", 40), ("dense", 1)], seed=9)  # relu(x) - alpha relu(-x): twice the width in between
+    path.write_text(json.dumps(wide))
+    with pytest.raises(na.NeuralAudioError, match="prelu layer wider than 32 units"):
+        loader.CreateFromFile(str(path), doPrewarm=False)
     conv = R.synth_keras_stack([("dense", 4, "tanh"), ("dense", 1)], seed=8)
     conv["layers"][0]["type"] = "conv1d"
     path.write_text(json.dumps(conv))
