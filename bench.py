@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--block", type=int, default=BLOCK, help="samples per buffer (default 128 = the BASELINE config; other sizes are exploration only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle spot check of the last timed step")
+    ap.add_argument("--caller-stream", action="store_true",
+                    help="create the batch on a stream of the caller (torch's) instead of its own: every launch is ordered on that stream, "
+                         "so a step is ONE launch (the batch's own stream lets a step run as two free-running half-batch launches)")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed sustained load before warm-up so the shader clock reaches steady state")
     ap.add_argument("--workload", default="standard",
                     help="standard (default = the BASELINE metric's config) | lite | feather | nano | a2full | a2lite | lstm1x16 | lstm2x8 | "
@@ -320,10 +323,13 @@ def main():
         synthetic_json = {"lstm": json.loads(lstm), "gru": json.loads(gru)}
     if any(m is None for m in models):
         raise SystemExit("could not load " + str(files))
-    # run on torch's current stream so torch.cuda.Event brackets exactly the kernels we launch
+    # The batch launches on its OWN streams (NA_BatchCreate with a null stream handle): one NA_BatchProcessDevice call = one step may then
+    # run as two free-running launches of half the streams each.  The timed region is bracketed by the library's HIP events on EVERY
+    # stream it launches on (NA_BatchMarkTime / NA_BatchElapsedMs: the longest span) -- torch.cuda.Event would only see torch's stream.
+    # --caller-stream: the round 1-3 arrangement (torch's stream handed in, one launch per step, same events on that one stream).
     tstream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream handle
     torch.cuda.set_stream(tstream)
-    batch = na.Batch(local_rank, hip_stream=tstream.cuda_stream)
+    batch = na.Batch(local_rank, hip_stream=tstream.cuda_stream if args.caller_stream else None)
     # The stream list of the workload as (model, quality, count) entries, architecture-sorted.  One GPU (or the headline workload):
     # every rank runs its own S streams (weak scaling).  Mixed workloads on several GPUs: the entries describe the GLOBAL list of
     # S x world streams, which is cut by cost into one contiguous range per rank -- NA_ShardByCost, the C++ host's partition
@@ -388,22 +394,24 @@ def main():
         step(i)
     torch.cuda.synchronize(dev)
 
-    # Average launch duration from two HIP events on the launch stream bracketing the K timed launches (an event per step would put an
-    # extra timestamp packet between every two launches and stretch the very gaps it measures).
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    # Average step duration from HIP events bracketing the K timed steps on every stream the batch launches on (an event per step would
+    # put an extra timestamp packet between every two launches and stretch the very gaps it measures).  When a step is two free-running
+    # half-batch launches (launches_per_step 2) the two chains overlap: rocprofv3's per-launch average is then the duration of ONE half
+    # launch running beside the other chain (~ the step time), the step time is what the roofline is reported on.
     nd.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    ev0.record(tstream)
+    batch.MarkTime(0)
     for i in range(args.steps):
         step(i)
-    ev1.record(tstream)
+    batch.MarkTime(1)
+    batch.Synchronize()
     torch.cuda.synchronize(dev)
     nd.barrier()
     torch.cuda.synchronize(dev)
     elapsed = nd.max_over_ranks(time.perf_counter() - t0, device=dev)
-    kernel_ms_avg = ev0.elapsed_time(ev1) / args.steps
+    kernel_ms_avg = batch.ElapsedMs() / args.steps  # per STEP (one or two launches)
+    launches_per_step = 2 if batch.UsesHalfLaunches() else 1
 
     # Parity spot check (outside the timed region, on what the timed region left behind): `y` holds the output of the LAST timed step.
     # The first stream of every model of the batch is replayed on the CPU oracle over the tail of its known input history -- one
@@ -413,15 +421,17 @@ def main():
     if rank == 0 and not args.no_parity_check:
         parity = parity_spot_check(check_rows, x, y, issued[0], nbuf, mdir)
 
-    # diagnostic only (outside the timed region): per-launch spread from one event per launch
+    # diagnostic only (outside the timed region): steps on their own, each bracketed and waited for
     nprobe = min(32, args.steps)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(nprobe + 1)]
-    ev[0].record(tstream)
+    kernel_ms = []
     for i in range(nprobe):
+        batch.MarkTime(0)
         step(i)
-        ev[i + 1].record(tstream)
+        batch.MarkTime(1)
+        kernel_ms.append(batch.ElapsedMs())
+    batch.Synchronize()
     torch.cuda.synchronize(dev)
-    kernel_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(nprobe))
+    kernel_ms.sort()
 
     finite = bool(torch.isfinite(y).all().item())
 
@@ -484,8 +494,9 @@ def main():
             "realtime_streams_48k": value * 1e6 / 48000.0,
             "msamples_per_s_per_gpu": value / world,
             "clock_ramp": {"ms": args.ramp_ms, "untimed_steps": ramp_steps},
-            "kernel_ms_avg": kernel_ms_avg,
-            "kernel_ms_median": kernel_ms[len(kernel_ms) // 2],
+            "kernel_ms_avg": kernel_ms_avg,                       # per step, HIP events over the K timed steps on every launch stream
+            "launches_per_step": launches_per_step,               # 2: the step ran as two free-running half-batch launches
+            "kernel_ms_median_isolated": kernel_ms[len(kernel_ms) // 2],  # a step on its own (bracketed and waited for)
             "output_finite": finite,
             # oracle spot check of the last timed step (one stream per model; tolerance of the north star: 1e-4 RMS)
             "parity_rms": parity["rms"] if parity else None,
@@ -496,7 +507,7 @@ def main():
                 "achieved": achieved_tflops if on_fp32_roof else achieved_gbs,
                 "peak": FP32_MFMA_PEAK_TFLOPS if on_fp32_roof else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if on_fp32_roof else "GB/s",
-                # from the HIP-event average of the K timed launches (kernel_ms_avg) ...
+                # per STEP = one NA_BatchProcessDevice call over all streams: from the HIP-event average of the K timed steps (kernel_ms_avg) ...
                 "frac": frac_fp32 if on_fp32_roof else frac_hbm,
                 # ... and from the wall clock `value` is computed from (ms_per_step: launch gaps and the closing synchronisation included)
                 "frac_wall_clock": (frac_fp32 if on_fp32_roof else frac_hbm) * kernel_ms_avg / wall_ms,
@@ -508,7 +519,8 @@ def main():
                 # a small-dilation layer where the formula counts every tap's history, so measured < algorithmic; padded narrow models: >)
                 "frac_measured_bytes": (traffic / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "algorithmic_bytes_per_sample": bytes_per_sample,
-                "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                "algorithmic_bytes_per_launch": alg_bytes_per_launch,  # per step (all launches of one NA_BatchProcessDevice call together)
+                "launches_per_step": launches_per_step,
                 "algorithmic_flops_per_sample": flops_per_sample,
                 # the kernel that runs stream 0 of the batch (the dominant one of every workload here: the first group is the largest /
                 # the only WaveNet one; FamilyFor(), PackFor(), PadFor() in gpu_batch.cpp decide per model)

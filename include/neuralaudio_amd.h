@@ -95,7 +95,17 @@ NA_EXTERN const float* NA_BatchOutputView(NA_Batch* batch, int ticket);
 /* DEVICE pointers, row s = stream s, rows `stride` floats apart; asynchronous on the batch's stream */
 NA_EXTERN int NA_BatchProcessDevice(NA_Batch* batch, const float* dIn, float* dOut, size_t n, long inStride, long outStride);
 NA_EXTERN int NA_BatchSynchronize(NA_Batch* batch);
+/* The batch's HIP stream.  A batch that created its own stream (NA_BatchCreate with hipStream == NULL) may, until this is first called,
+   run a buffer as two free-running launches of half its streams each on internal streams (1024 x A1 Standard x 128: 40.1 -> 37.4 us
+   per step) -- wait with NA_BatchSynchronize (or use the host-buffer entry points, which wait themselves).  After the first call, and on
+   a caller's stream, every launch is ordered on that stream. */
 NA_EXTERN void* NA_BatchGetHipStream(NA_Batch* batch);
+/* Timing marks for benchmarks: HIP events recorded on EVERY stream the batch launches kernels on.  NA_BatchMarkTime(b, 0) ... launches ...
+   NA_BatchMarkTime(b, 1); NA_BatchElapsedMs waits for the second mark and returns the longest mark-to-mark span over those streams (< 0: error). */
+NA_EXTERN int NA_BatchMarkTime(NA_Batch* batch, int which);
+NA_EXTERN float NA_BatchElapsedMs(NA_Batch* batch);
+/* 1: the last NA_BatchProcessDevice call ran as two half-batch launches (see NA_BatchGetHipStream) */
+NA_EXTERN int NA_BatchUsesHalfLaunches(NA_Batch* batch);
 /* roofline bookkeeping (stream-weighted means): compulsory HBM bytes and multiply-accumulates per sample */
 NA_EXTERN double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames);
 NA_EXTERN double NA_BatchMacsPerSample(NA_Batch* batch);

@@ -307,6 +307,25 @@ class Batch:
         if self._lib.NA_BatchSynchronize(self._h) != 0:
             raise NeuralAudioError(capi.last_error())
 
+    def GetHipStream(self):
+        """The batch's HIP stream handle (int).  From the first call on every launch is ordered on it (see NA_BatchGetHipStream)."""
+        return self._lib.NA_BatchGetHipStream(self._h)
+
+    def MarkTime(self, which):
+        """HIP events on every stream the batch launches on (0: start, 1: end); see ElapsedMs."""
+        if self._lib.NA_BatchMarkTime(self._h, int(which)) != 0:
+            raise NeuralAudioError(capi.last_error())
+
+    def ElapsedMs(self):
+        ms = float(self._lib.NA_BatchElapsedMs(self._h))
+        if ms < 0:
+            raise NeuralAudioError(capi.last_error())
+        return ms
+
+    def UsesHalfLaunches(self):
+        """True when the last ProcessDevice call ran as two free-running half-batch launches (own stream, one WaveNet group)."""
+        return bool(self._lib.NA_BatchUsesHalfLaunches(self._h))
+
     def AlgorithmicBytesPerSample(self, block_frames=128):
         return float(self._lib.NA_BatchAlgorithmicBytesPerSample(self._h, int(block_frames)))
 

@@ -483,6 +483,21 @@ int NA_BatchSynchronize(NA_Batch* batch)
 
 void* NA_BatchGetHipStream(NA_Batch* batch) { return batch ? reinterpret_cast<void*>(batch->batch->GetStream()) : nullptr; }
 
+int NA_BatchMarkTime(NA_Batch* batch, int which)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->MarkTime(which); });
+}
+
+float NA_BatchElapsedMs(NA_Batch* batch)
+{
+	if (!batch) return -1.0f;
+	float ms = -1.0f;
+	return Guard([&] { ms = batch->batch->ElapsedMs(); }) == 0 ? ms : -1.0f;
+}
+
+int NA_BatchUsesHalfLaunches(NA_Batch* batch) { return batch && batch->batch->UsesHalfLaunches() ? 1 : 0; }
+
 double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames)
 {
 	return batch ? batch->batch->AlgorithmicBytesPerSample(blockFrames) : 0.0;

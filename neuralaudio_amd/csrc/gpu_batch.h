@@ -128,7 +128,16 @@ namespace na
 		size_t SlotRows(int ticket) const { return (ticket >= 0 && ticket < kPipelineSlots) ? pipe[ticket].rows : 0; } // rows of that submission
 
 		void Synchronize();
-		hipStream_t GetStream() const { return stream; }
+		// Timing marks for bench.py (HIP events on EVERY stream this batch launches kernels on -- the batch stream and the two half-batch
+		// streams): MarkTime(0) ... launches ... MarkTime(1); ElapsedMs() = the longest mark-to-mark span over those streams (after a
+		// Synchronize()).  The caller's own events only see the stream it handed in.
+		bool UsesHalfLaunches() const { return lastStepHalves; }
+		void MarkTime(int which);
+		float ElapsedMs();
+		// The batch's HIP stream.  Handing it out makes the batch order every launch on it from then on: until then a batch that created
+		// its own stream may run a buffer as two free-running half-batch launches on internal streams (see halfStream below) -- nobody
+		// outside can observe the order of work on a stream they never saw; NA_BatchSynchronize / the host-buffer entry points wait for all.
+		hipStream_t GetStream();
 		int GetDevice() const { return device; }
 
 		// roofline bookkeeping for bench.py: stream-weighted algorithmic bytes / MACs per sample
@@ -202,9 +211,25 @@ namespace na
 			hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
 			hipStream_t own = nullptr; // upload, kernel and download of this slot's buffer, in order (batches that run as one launch)
 			bool onOwnStream = false;
+			hipEvent_t halfDone[2] = { nullptr, nullptr }; // two free-running half-batch chains (Submit): this buffer's kernel of each half
+			bool onHalfStreams = false;
 			bool busy = false;
 		};
 		void DrainPipeline();
+		// Two free-running chains for the pipelined host-buffer interface: a batch of one contiguous WaveNet group runs every submitted
+		// buffer as two launches of half the streams, each half on its own HIP stream, in submission order -- the halves never wait for each
+		// other (streams are independent), so the tail of one launch overlaps the other half's work: 40.1 -> 37.4 us per 1024 x 128 buffer
+		// of kernel time (tools/split_launch_probe2.py).  One stream-ordered NA_BatchProcessDevice call cannot do this (it would have to
+		// join the halves every call: 65.9 us); Submit / Collect can -- Collect waits for both halves of its ticket.
+		hipStream_t halfStream[2] = { nullptr, nullptr };
+		bool halfChainsUsed = false;
+		bool lastStepHalves = false; // the last device-pointer / submitted buffer ran as two half-batch launches
+		bool streamObserved = false; // GetStream() was called (or the stream is the caller's): launches are ordered on `stream`
+		ModelGroup* SplittableGroup(size_t n) const;
+		void ProcessDeviceOrdered(const float* dIn, float* dOut, size_t n, long inStride, long outStride);
+		void LaunchHalves(ModelGroup* g, const float* dIn, float* dOut, size_t n, long inStride, long outStride, hipEvent_t* done);
+		void JoinHalves(); // the half-batch chains are done (host-side wait); the next launches go to the batch stream again
+		hipEvent_t marks[3][2] = { { nullptr, nullptr }, { nullptr, nullptr }, { nullptr, nullptr } };
 		void ProcessDeviceOn(hipStream_t launch, const float* dIn, float* dOut, size_t n, long inStride, long outStride);
 		// ordering between the batch stream and the slot streams: the stream state makes every kernel launch depend on the previous one
 		bool pipelineUsed = false;

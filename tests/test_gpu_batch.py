@@ -318,6 +318,93 @@ def test_pipelined_submit_collect_matches_process(na, loader):
         z.Submit(x[:, :n])
 
 
+def test_pipelined_half_chains_match_process_and_mix_with_the_other_entry_points(na, loader):
+    """From 512 streams of one contiguous WaveNet group a submitted buffer runs as TWO launches of half the streams on two free-running
+    HIP streams (gpu_batch.h halfStream): bit for bit what NA_BatchProcess gives, also with an odd stream count, ragged buffer
+    lengths (96 frames = two launches: not split), a synchronous call / a join / a leave between submissions, and three tickets in flight."""
+    m = loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=False)
+    S, n = 1027, 128
+    rng = np.random.default_rng(31)
+    base = (0.3 * rng.standard_normal((11, n * 8))).clip(-1, 1).astype(np.float32)
+    x = base[np.arange(S) % 11]
+    ref, b = na.Batch(0), na.Batch(0)
+    ref.AddStreams(m, S)
+    b.AddStreams(m, S)
+
+    def step(sl, frames=n):
+        blk = np.ascontiguousarray(x[:, sl * n:sl * n + frames])
+        return ref.Process(blk), blk
+
+    tickets, got, want = [], [], []
+    for i in range(4):
+        w, blk = step(i)
+        want.append(w)
+        tickets.append(b.Submit(blk))
+        if len(tickets) == 3:
+            got.append(b.Collect(tickets.pop(0)))
+    while tickets:
+        got.append(b.Collect(tickets.pop(0)))
+    assert np.array_equal(np.concatenate(got, axis=1), np.concatenate(want, axis=1))
+    w, blk = step(4)  # a synchronous call between submissions (drains the half chains first)
+    assert np.array_equal(b.Process(blk), w)
+    w, blk = step(5, 96)  # 96 frames = a 64- and a 32-frame launch: the batch stream path
+    assert np.array_equal(b.Collect(b.Submit(blk)), w)
+    assert ref.AddStreams(m, 2) == b.AddStreams(m, 2) == S  # streams join ...
+    ref.RemoveStreams(3, 1)
+    b.RemoveStreams(3, 1)  # ... and one leaves: the group is no longer contiguous -> index lists, one launch per buffer
+    x2 = np.concatenate([x, x[:2]], axis=0)
+    for i in (6, 7):
+        blk = np.ascontiguousarray(x2[:, i * n:(i + 1) * n])
+        assert np.array_equal(b.Collect(b.Submit(blk)), ref.Process(blk))
+    ref.close()
+    b.close()
+
+
+def test_device_pointer_steps_on_the_batch_own_streams_run_as_free_running_halves(na, loader):
+    """NA_BatchProcessDevice on a batch that created its own stream (and never handed it out): from 512 streams of one contiguous WaveNet
+    group every step is two free-running launches of half the streams each.  Bit for bit the one-launch result (a batch on the
+    caller's stream), through a synchronous host call in between, and ordered on the batch stream once NA_BatchGetHipStream was
+    called.  The timing marks bracket every launch stream."""
+    import torch
+    m = loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=False)
+    S, n, steps = 1026, 128, 6
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.clamp(0.3 * torch.randn(steps, S, n, generator=g), -1.0, 1.0).to(dev)
+    ts = torch.cuda.Stream(device=dev)
+    ref, b = na.Batch(0, hip_stream=ts.cuda_stream), na.Batch(0)
+    ref.AddStreams(m, S)
+    b.AddStreams(m, S)
+    want = torch.empty(steps, S, n, device=dev)
+    got = torch.empty(steps, S, n, device=dev)
+    torch.cuda.synchronize(dev)
+    for k in range(steps):
+        ref.ProcessDevice(x[k].data_ptr(), want[k].data_ptr(), n)
+        assert not ref.UsesHalfLaunches()
+    ref.Synchronize()
+    b.MarkTime(0)
+    for k in range(3):
+        b.ProcessDevice(x[k].data_ptr(), got[k].data_ptr(), n)
+        assert b.UsesHalfLaunches()
+    b.MarkTime(1)
+    ms = b.ElapsedMs()
+    assert 0.0 < ms < 50.0, ms
+    b.Synchronize()
+    assert torch.equal(got[:3], want[:3])
+    # a synchronous host-buffer call joins the chains, runs ordered, and the next device step starts new chains behind it
+    assert np.array_equal(b.Process(x[3].cpu().numpy()), want[3].cpu().numpy())
+    b.ProcessDevice(x[4].data_ptr(), got[4].data_ptr(), n)
+    assert b.UsesHalfLaunches()
+    # the stream handed out: from here on one ordered launch per step
+    assert b.GetHipStream() not in (None, 0)
+    b.ProcessDevice(x[5].data_ptr(), got[5].data_ptr(), n)
+    assert not b.UsesHalfLaunches()
+    b.Synchronize()
+    assert torch.equal(got[4:], want[4:])
+    ref.close()
+    b.close()
+
+
 def test_quality_switch_every_buffer_2048_a2_streams_is_cheap(na, loader):
     """BASELINE configs[4] size on one GPU (2048 A2 streams): flipping the quality of HALF the streams before EVERY buffer must stay a
     real-time operation -- the active-stream lists travel from pinned memory asynchronously, nothing is allocated, synchronised or
