@@ -174,14 +174,6 @@ namespace na
 		virtual int RangeEvents(int member) { (void)member; return 0; }
 		// device buffers that hold nothing but the model's (re-laid-out) weights: identical on every device that runs the model
 		virtual void WeightImages(std::vector<std::pair<void*, size_t>>& out) const { (void)out; }
-		// streams [first, first + count) of the ACTIVE list as one launch on `launchStream` (contiguous groups of one launch per buffer only:
-		// SupportsRange); the pipelined host interface runs a batch as two such halves on two streams
-		virtual bool SupportsRange(size_t n) const { (void)n; return false; }
-		virtual void ProcessRange(int first, int count, const float* dIn, float* dOut, long inStride, long outStride, size_t n, hipStream_t launchStream)
-		{
-			(void)first; (void)count; (void)dIn; (void)dOut; (void)inStride; (void)outStride; (void)n; (void)launchStream;
-			throw std::runtime_error("internal: ProcessRange on a group without range launches");
-		}
 		virtual float InputLimit() const { return INFINITY; } // samples beyond +-limit are clamped by the kernel (f16-split WaveNet kernels)
 		virtual const char* KernelName() const = 0;  // the kernel that runs this group's streams (rocprof name, without template arguments)
 		// WaveNet groups on the frame kernel can share ONE launch with other such groups (a heterogeneous batch without stream
@@ -580,17 +572,6 @@ namespace na
 					offset += (size_t)chunk;
 					n -= (size_t)chunk;
 				}
-			}
-
-			bool SupportsRange(size_t n) const override
-			{
-				return family == WN_FAMILY_SPLIT && pack == 1 && contiguous && !activeDirty && n <= (size_t)WN_MAX_FRAMES &&
-					(size_t)NextWaveNetChunk(n, dev.compact_rings != 0) == n;
-			}
-			void ProcessRange(int first, int count, const float* dIn, float* dOut, long inStride, long outStride, size_t n, hipStream_t launchStream) override
-			{
-				const WnFrameGroup g = { &dev, state.Get(), nullptr, dRows.Get(), count, hSlots[0] + first, hRows[0] + first, pack };
-				CheckHip(LaunchWaveNetSplitFused(&g, 1, dIn, dOut, inStride, outStride, (int)n, launchStream), "WaveNetSplitKernel");
 			}
 
 			bool FusedLaunchArgs(WnFrameGroup& out, int& launchList) override
@@ -1005,6 +986,7 @@ namespace na
 		{
 			CheckHip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
 		}
+		if (const char* e = getenv("NA_HOST_CHAINS")) numChains = std::min(std::max(atoi(e), 2), kMaxChains); // tuning knob
 	}
 
 	GpuBatch::~GpuBatch()
@@ -1190,22 +1172,92 @@ namespace na
 		halfChainsUsed = false;
 	}
 
-	// the two halves of the group's active streams, each on its own stream behind that half's previous launch; `done`: events to record
-	void GpuBatch::LaunchHalves(ModelGroup* g, const float* dIn, float* dOut, size_t n, long inStride, long outStride, hipEvent_t* done)
+	struct GpuBatch::HalfLists
 	{
-		if (!halfChainsUsed || submitTopology != topologyVersion)
+		std::vector<WnFrameGroup> part[GpuBatch::kMaxChains];
+		bool listsUploaded = false; // an index list went to the device on the batch stream while the lists were built
+	};
+
+	// The buffer as two launch lists of half of every group's streams each (see halfStream); false: it runs as ordered launches.
+	bool GpuBatch::PrepareHalves(size_t n)
+	{
+		static const bool off = getenv("NA_HOST_HALVES") != nullptr && atoi(getenv("NA_HOST_HALVES")) == 0; // tuning knob
+		if (off || n > (size_t)WN_MAX_FRAMES) return false;
+		bool dirty = false, packed = false, plain = false;
+		int active = 0;
+		for (const auto& g : groups)
+		{
+			if (g->NumActive() == 0) continue;
+			const int c = g->LaunchClass(); // 1 / 2 / -1: the f16-split kernels' plain launch / packed launch / either (gpu_batch.cpp LaunchClass)
+			if (c != 1 && c != 2 && c != -1) return false;
+			packed = packed || c == 2;
+			plain = plain || c == 1;
+			dirty = dirty || g->ListsDirty();
+			active++;
+		}
+		if (active == 0 || active > WN_FRAME_MAX_GROUPS || (packed && plain)) return false; // (two launches per buffer: not split)
+		// changed index lists are re-uploaded below (asynchronously, on the batch stream): nothing in flight may still read the old ones
+		if (dirty && (halfChainsUsed || pipelineUsed)) DrainPipeline();
+		if (!halfLists) halfLists.reset(new HalfLists());
+		HalfLists& hl = *halfLists;
+		for (auto& part : hl.part) part.clear();
+		hl.listsUploaded = dirty;
+		int total = 0;
+		bool compact = false;
+		for (const auto& g : groups)
+		{
+			if (g->NumActive() == 0) continue;
+			WnFrameGroup a = {};
+			int list = 0;
+			if (!g->FusedLaunchArgs(a, list)) return false;
+			WaveNetGroup* wg = static_cast<WaveNetGroup*>(g.get());
+			if (list < 0 && packed) a.slots = wg->listSlots; // a plain group in the packed launch passes its index lists
+			total += a.numStreams;
+			compact = compact || a.model->compact_rings != 0;
+			// contiguous parts of whole workgroups (two streams each)
+			int first = 0;
+			for (int c = 0; c < numChains; c++)
+			{
+				const int end = c + 1 == numChains ? a.numStreams : std::min(a.numStreams, (int)(((long)a.numStreams * (c + 1) / numChains + 1) & ~1L));
+				if (end <= first) continue;
+				WnFrameGroup part = a;
+				part.numStreams = end - first;
+				part.slot0 += first;
+				part.row0 += first;
+				if (part.slots) part.slots += first;
+				if (part.slots || a.pack > 1) part.rows += (size_t)first * (size_t)a.pack;
+				hl.part[c].push_back(part);
+				first = end;
+			}
+		}
+		// (below 512 kernel-level streams a launch does not fill the chip anyway: nothing to overlap)
+		return total >= 512 && (size_t)NextWaveNetChunk(n, compact) == n;
+	}
+
+	// the two lists of PrepareHalves, each on its own stream behind that half's previous launch; `done`: events to record
+	void GpuBatch::LaunchHalves(const float* dIn, float* dOut, size_t n, long inStride, long outStride, hipEvent_t* done)
+	{
+		HalfLists& hl = *halfLists;
+		if (!halfChainsUsed || submitTopology != topologyVersion || hl.listsUploaded)
 		{
 			// whatever the batch stream (state resets, prewarms of new streams, index lists) or a slot stream still has in flight comes first
 			DrainPipeline();
 			CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 			submitTopology = topologyVersion;
 		}
-		const int count = g->NumActive(), firstHalf = (count / 2 + 1) & ~1; // (whole workgroups of two streams in the first half)
-		for (int h = 0; h < 2; h++)
+		for (int h = 0; h < numChains; h++)
 		{
-			if (!halfStream[h]) CheckHip(hipStreamCreateWithFlags(&halfStream[h], hipStreamNonBlocking), "hipStreamCreate");
-			const int first = h == 0 ? 0 : firstHalf, cnt = h == 0 ? firstHalf : count - firstHalf;
-			if (cnt > 0) g->ProcessRange(first, cnt, dIn, dOut, inStride, outStride, n, halfStream[h]);
+			if (!halfStream[h])
+			{
+				CheckHip(hipStreamCreateWithFlags(&halfStream[h], hipStreamNonBlocking), "hipStreamCreate");
+				if (markOpen)
+				{
+					if (!marks[1 + h][0]) CheckHip(hipEventCreate(&marks[1 + h][0]), "hipEventCreate");
+					CheckHip(hipEventRecord(marks[1 + h][0], halfStream[h]), "hipEventRecord");
+				}
+			}
+			if (!hl.part[h].empty())
+				CheckHip(LaunchWaveNetSplitFused(hl.part[h].data(), (int)hl.part[h].size(), dIn, dOut, inStride, outStride, (int)n, halfStream[h]), "WaveNet kernel (half batch)");
 			if (done) CheckHip(hipEventRecord(done[h], halfStream[h]), "hipEventRecord");
 		}
 		halfChainsUsed = true;
@@ -1216,19 +1268,15 @@ namespace na
 	{
 		if (which < 0 || which > 1) throw std::runtime_error("neuralaudio_amd: MarkTime(0 | 1)");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
-		hipStream_t all[3] = { stream, halfStream[0], halfStream[1] };
-		for (int i = 0; i < 3; i++)
+		// (a chain stream that does not exist yet is created by the first launch that needs it -- 13 ms, not inside a timed window if
+		// nothing will run on it -- and gets its start mark then: LaunchHalves)
+		markOpen = which == 0;
+		for (int i = 0; i <= kMaxChains; i++)
 		{
-			if (!all[i])
-			{
-				// (the half-batch streams are created on first use: a mark before that must still bracket them -- where device-pointer
-				// steps can run on them at all)
-				if (i == 0 || !ownsStream || streamObserved) continue;
-				CheckHip(hipStreamCreateWithFlags(&halfStream[i - 1], hipStreamNonBlocking), "hipStreamCreate");
-				all[i] = halfStream[i - 1];
-			}
+			hipStream_t s = i == 0 ? stream : halfStream[i - 1];
+			if (!s || (which == 1 && !marks[i][0])) continue;
 			if (!marks[i][which]) CheckHip(hipEventCreate(&marks[i][which]), "hipEventCreate");
-			CheckHip(hipEventRecord(marks[i][which], all[i]), "hipEventRecord");
+			CheckHip(hipEventRecord(marks[i][which], s), "hipEventRecord");
 		}
 	}
 
@@ -1236,7 +1284,7 @@ namespace na
 	{
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		float longest = 0.0f;
-		for (int i = 0; i < 3; i++)
+		for (int i = 0; i <= kMaxChains; i++)
 		{
 			if (!marks[i][0] || !marks[i][1]) continue;
 			CheckHip(hipEventSynchronize(marks[i][1]), "hipEventSynchronize");
@@ -1245,26 +1293,6 @@ namespace na
 			longest = std::max(longest, ms);
 		}
 		return longest;
-	}
-
-	// the one group of the batch when a buffer of n frames can run as two launches of half its streams each (see halfStream)
-	ModelGroup* GpuBatch::SplittableGroup(size_t n) const
-	{
-		static const bool off = getenv("NA_HOST_HALVES") != nullptr && atoi(getenv("NA_HOST_HALVES")) == 0; // tuning knob
-		if (off) return nullptr;
-		ModelGroup* only = nullptr;
-		for (const auto& g : groups)
-		{
-			if (g->NumActive() == 0) continue;
-			if (only) return nullptr;
-			only = g.get();
-		}
-		// (below 512 streams a launch does not fill the chip anyway: nothing to overlap)
-		if (!only || only->NumActive() < 512) return nullptr;
-		// changed lists: re-derive them now (the upload is asynchronous on the batch stream; a contiguous group's range launches do not
-		// read the device lists, and any other path launches on the batch stream behind the upload)
-		if (only->ListsDirty()) only->SyncActiveLists();
-		return only->SupportsRange(n) ? only : nullptr;
 	}
 
 	void GpuBatch::RemoveStreams(int first, int count)
@@ -1388,9 +1416,9 @@ namespace na
 		// points wait for all of them).  1024 x A1 Standard x 128 frames: 40.1 -> 37.4 us per step.
 		if (ownsStream && !streamObserved && !pipelineUsed)
 		{
-			if (ModelGroup* g = SplittableGroup(n))
+			if (PrepareHalves(n))
 			{
-				LaunchHalves(g, dIn, dOut, n, inStride, outStride, nullptr);
+				LaunchHalves(dIn, dOut, n, inStride, outStride, nullptr);
 				return;
 			}
 		}
@@ -1762,13 +1790,12 @@ namespace na
 			// (a lone buffer gains nothing from being split -- 55-58 vs 60 us Submit .. Collect -- so only with another ticket in flight)
 			bool othersInFlight = false;
 			for (const PipeSlot& o : pipe) othersInFlight = othersInFlight || (&o != &p && o.busy);
-			ModelGroup* g = (othersInFlight || halfChainsUsed) ? SplittableGroup(n) : nullptr;
-			if (g)
+			if ((othersInFlight || halfChainsUsed) && PrepareHalves(n))
 			{
 				// two free-running half-batch chains (see halfStream): each half in submission order on its own stream
-				for (int h = 0; h < 2; h++)
+				for (int h = 0; h < numChains; h++)
 					if (!p.halfDone[h]) CheckHip(hipEventCreateWithFlags(&p.halfDone[h], hipEventDisableTiming), "hipEventCreate");
-				LaunchHalves(g, dIn, dOut, n, (long)n, (long)n, p.halfDone);
+				LaunchHalves(dIn, dOut, n, (long)n, (long)n, p.halfDone);
 				halfChainsUsed = true;
 				pipelineUsed = true;
 				lastKernelEvent = nullptr; // (ProcessDevice after this drains the half streams itself)
@@ -1854,8 +1881,7 @@ namespace na
 		PipeSlot& p = pipe[ticket];
 		if (p.onHalfStreams)
 		{
-			CheckHip(hipEventSynchronize(p.halfDone[0]), "hipEventSynchronize");
-			CheckHip(hipEventSynchronize(p.halfDone[1]), "hipEventSynchronize");
+			for (int h = 0; h < numChains; h++) CheckHip(hipEventSynchronize(p.halfDone[h]), "hipEventSynchronize");
 		}
 		else if (p.onOwnStream) CheckHip(hipStreamSynchronize(p.own), "hipStreamSynchronize"); // the download is the stream's last operation
 		else CheckHip(hipEventSynchronize(p.downloaded), "hipEventSynchronize");

@@ -201,6 +201,7 @@ namespace na
 		float* devStage = nullptr;
 		size_t stageFloats = 0;
 
+		static constexpr int kMaxChains = 4;
 		struct PipeSlot
 		{
 			float* hostIn = nullptr;  // pinned
@@ -211,25 +212,31 @@ namespace na
 			hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
 			hipStream_t own = nullptr; // upload, kernel and download of this slot's buffer, in order (batches that run as one launch)
 			bool onOwnStream = false;
-			hipEvent_t halfDone[2] = { nullptr, nullptr }; // two free-running half-batch chains (Submit): this buffer's kernel of each half
+			hipEvent_t halfDone[kMaxChains] = {}; // free-running half-batch chains (Submit): this buffer's kernel of each chain
 			bool onHalfStreams = false;
 			bool busy = false;
 		};
 		void DrainPipeline();
-		// Two free-running chains for the pipelined host-buffer interface: a batch of one contiguous WaveNet group runs every submitted
-		// buffer as two launches of half the streams, each half on its own HIP stream, in submission order -- the halves never wait for each
-		// other (streams are independent), so the tail of one launch overlaps the other half's work: 40.1 -> 37.4 us per 1024 x 128 buffer
-		// of kernel time (tools/split_launch_probe2.py).  One stream-ordered NA_BatchProcessDevice call cannot do this (it would have to
-		// join the halves every call: 65.9 us); Submit / Collect can -- Collect waits for both halves of its ticket.
-		hipStream_t halfStream[2] = { nullptr, nullptr };
+		// Two free-running chains: a batch whose active streams all run on the f16-split WaveNet kernels as ONE launch per buffer (one
+		// model, or a mixed / packed batch that shares a fused launch; >= 512 kernel-level streams) can run a buffer as two launches of half
+		// of every group's streams, each half on its own HIP stream, in submission order -- the halves never wait for each other (streams
+		// are independent), so the tail of one launch overlaps the other half's work: 40.1 -> 37.4 us per 1024 x 128 buffer of kernel
+		// time (tools/split_launch_probe2.py).  A call ordered on ONE stream cannot do this (it would have to join the halves every
+		// call: 65.9 us); Submit / Collect can (Collect waits for both halves of its ticket), and so can NA_BatchProcessDevice on a batch
+		// whose stream nobody else has seen.
+		hipStream_t halfStream[kMaxChains] = {};
+		int numChains = 2; // (tuning knob NA_HOST_CHAINS: 2 .. kMaxChains parts instead of halves)
+		bool markOpen = false; // between MarkTime(0) and MarkTime(1): a chain stream created now gets its start mark right away
 		bool halfChainsUsed = false;
 		bool lastStepHalves = false; // the last device-pointer / submitted buffer ran as two half-batch launches
 		bool streamObserved = false; // GetStream() was called (or the stream is the caller's): launches are ordered on `stream`
-		ModelGroup* SplittableGroup(size_t n) const;
+		struct HalfLists; // the two launch lists of the buffer (gpu_batch.cpp)
+		std::unique_ptr<HalfLists> halfLists;
+		bool PrepareHalves(size_t n);
 		void ProcessDeviceOrdered(const float* dIn, float* dOut, size_t n, long inStride, long outStride);
-		void LaunchHalves(ModelGroup* g, const float* dIn, float* dOut, size_t n, long inStride, long outStride, hipEvent_t* done);
+		void LaunchHalves(const float* dIn, float* dOut, size_t n, long inStride, long outStride, hipEvent_t* done);
 		void JoinHalves(); // the half-batch chains are done (host-side wait); the next launches go to the batch stream again
-		hipEvent_t marks[3][2] = { { nullptr, nullptr }, { nullptr, nullptr }, { nullptr, nullptr } };
+		hipEvent_t marks[1 + kMaxChains][2] = {};
 		void ProcessDeviceOn(hipStream_t launch, const float* dIn, float* dOut, size_t n, long inStride, long outStride);
 		// ordering between the batch stream and the slot streams: the stream state makes every kernel launch depend on the previous one
 		bool pipelineUsed = false;

@@ -351,7 +351,7 @@ def test_pipelined_half_chains_match_process_and_mix_with_the_other_entry_points
     assert np.array_equal(b.Collect(b.Submit(blk)), w)
     assert ref.AddStreams(m, 2) == b.AddStreams(m, 2) == S  # streams join ...
     ref.RemoveStreams(3, 1)
-    b.RemoveStreams(3, 1)  # ... and one leaves: the group is no longer contiguous -> index lists, one launch per buffer
+    b.RemoveStreams(3, 1)  # ... and one leaves: the group is no longer contiguous -> the halves are cut out of its index lists
     x2 = np.concatenate([x, x[:2]], axis=0)
     for i in (6, 7):
         blk = np.ascontiguousarray(x2[:, i * n:(i + 1) * n])
@@ -401,6 +401,74 @@ def test_device_pointer_steps_on_the_batch_own_streams_run_as_free_running_halve
     assert not b.UsesHalfLaunches()
     b.Synchronize()
     assert torch.equal(got[4:], want[4:])
+    ref.close()
+    b.close()
+
+
+def _device_steps(batch, x, out, n):
+    for k in range(x.shape[0]):
+        batch.ProcessDevice(x[k].data_ptr(), out[k].data_ptr(), n)
+
+
+def test_mixed_and_packed_batches_run_as_free_running_halves_too(na, loader):
+    """The half-batch launches cut EVERY group of a fused launch in two: a Lite + Feather + Nano batch (padded / packed 2 / packed 4
+    streams per kernel-level stream, one packed launch) and an A2 batch whose streams change quality between steps (index lists
+    re-uploaded while the chains are in flight) give bit for bit what the ordered launches on a caller's stream give."""
+    import torch
+    dev = torch.device("cuda", 0)
+    lite_w = O.synth_wavenet_weights(O.a1_arrays(12, 6), seed=33)
+    lite = loader.CreateFromString(O.nam_json_wavenet_a1(12, 6, lite_w), ".nam", doPrewarm=False)
+    feather = loader.CreateFromFile(_path("BossWN-feather.nam"), doPrewarm=False)
+    nano = loader.CreateFromFile(_path("BossWN-nano.nam"), doPrewarm=False)
+    a2 = loader.CreateFromFile(_path("BossWN-a2.nam"), doPrewarm=False)
+    n, steps = 128, 5
+    ts = torch.cuda.Stream(device=dev)
+    g = torch.Generator(device="cpu").manual_seed(6)
+
+    def pair():
+        return na.Batch(0, hip_stream=ts.cuda_stream), na.Batch(0)
+
+    # (a) config-3 shaped: 601 Lite + 603 Feather + 806 Nano, two streams removed so that the lists are not contiguous
+    ref, b = pair()
+    for bb in (ref, b):
+        bb.AddStreams(lite, 601)
+        bb.AddStreams(feather, 603)
+        bb.AddStreams(nano, 806)
+        bb.RemoveStreams(5, 1)
+        bb.RemoveStreams(1300, 2)
+    S = 601 + 603 + 806
+    x = torch.clamp(0.3 * torch.randn(steps, S, n, generator=g), -1.0, 1.0).to(dev)
+    want, got = torch.zeros(steps, S, n, device=dev), torch.zeros(steps, S, n, device=dev)
+    torch.cuda.synchronize(dev)
+    _device_steps(ref, x, want, n)
+    ref.Synchronize()
+    _device_steps(b, x, got, n)
+    assert b.UsesHalfLaunches() and not ref.UsesHalfLaunches()
+    b.Synchronize()
+    assert torch.equal(got, want)
+    assert float(want[:, 0].abs().max()) > 0 and float(want[:, 5].abs().max()) == 0  # (a removed row stays untouched)
+    ref.close()
+    b.close()
+
+    # (b) 1200 A2 streams, every third one on the small submodel; between the steps a few streams switch (both directions)
+    ref, b = pair()
+    S = 1200
+    for bb in (ref, b):
+        bb.AddStreams(a2, S, quality=1.0)
+        for s in range(0, S, 3):
+            bb.SetQuality(s, 0.0)
+    x = torch.clamp(0.3 * torch.randn(steps, S, n, generator=g), -1.0, 1.0).to(dev)
+    want, got = torch.zeros(steps, S, n, device=dev), torch.zeros(steps, S, n, device=dev)
+    torch.cuda.synchronize(dev)
+    for k in range(steps):
+        for bb, out in ((ref, want), (b, got)):
+            bb.SetQuality(7 * k + 1, 0.0)
+            bb.SetQuality(3 * k, 1.0)
+            bb.ProcessDevice(x[k].data_ptr(), out[k].data_ptr(), n)
+        assert b.UsesHalfLaunches() and not ref.UsesHalfLaunches()
+    ref.Synchronize()
+    b.Synchronize()
+    assert torch.equal(got, want)
     ref.close()
     b.close()
 
