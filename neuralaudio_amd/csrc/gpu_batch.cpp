@@ -1235,7 +1235,7 @@ namespace na
 	}
 
 	// the two lists of PrepareHalves, each on its own stream behind that half's previous launch; `done`: events to record
-	void GpuBatch::LaunchHalves(const float* dIn, float* dOut, size_t n, long inStride, long outStride, hipEvent_t* done)
+	void GpuBatch::LaunchHalves(const float* dIn, float* dOut, size_t n, long inStride, long outStride, hipEvent_t* done, bool hostRows)
 	{
 		HalfLists& hl = *halfLists;
 		if (!halfChainsUsed || submitTopology != topologyVersion || hl.listsUploaded)
@@ -1245,6 +1245,10 @@ namespace na
 			CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 			submitTopology = topologyVersion;
 		}
+		// Workgroup shape: for rows in HBM, sized for what is resident with both chains on the chip (full-size workgroups: 36.7 vs 37.1 us
+		// per 1024 x 128 Standard step); for rows in pinned host memory the half-size workgroups win (43.5-44.4 vs 45.1-46.2 us per buffer
+		// host to host: twice the workgroups keep more PCIe reads in flight)
+		const int sharing = hostRows ? 1 : numChains;
 		for (int h = 0; h < numChains; h++)
 		{
 			if (!halfStream[h])
@@ -1257,7 +1261,7 @@ namespace na
 				}
 			}
 			if (!hl.part[h].empty())
-				CheckHip(LaunchWaveNetSplitFused(hl.part[h].data(), (int)hl.part[h].size(), dIn, dOut, inStride, outStride, (int)n, halfStream[h]), "WaveNet kernel (half batch)");
+				CheckHip(LaunchWaveNetSplitFused(hl.part[h].data(), (int)hl.part[h].size(), dIn, dOut, inStride, outStride, (int)n, halfStream[h], sharing), "WaveNet kernel (half batch)");
 			if (done) CheckHip(hipEventRecord(done[h], halfStream[h]), "hipEventRecord");
 		}
 		halfChainsUsed = true;
@@ -1418,7 +1422,7 @@ namespace na
 		{
 			if (PrepareHalves(n))
 			{
-				LaunchHalves(dIn, dOut, n, inStride, outStride, nullptr);
+				LaunchHalves(dIn, dOut, n, inStride, outStride, nullptr, false);
 				return;
 			}
 		}
@@ -1513,9 +1517,12 @@ namespace na
 			{
 				const int chunk = NextWaveNetChunk(left, compact);
 				for (size_t first = 0; first < list.size(); first += WN_FRAME_MAX_GROUPS)
-					CheckHip((which == 0 ? LaunchWaveNetFrameFused : LaunchWaveNetSplitFused)(list.data() + first,
-						(int)std::min<size_t>(list.size() - first, (size_t)WN_FRAME_MAX_GROUPS), dIn + offset, dOut + offset, inStride, outStride, chunk, s),
+				{
+					const int count = (int)std::min<size_t>(list.size() - first, (size_t)WN_FRAME_MAX_GROUPS);
+					CheckHip(which == 0 ? LaunchWaveNetFrameFused(list.data() + first, count, dIn + offset, dOut + offset, inStride, outStride, chunk, s)
+										: LaunchWaveNetSplitFused(list.data() + first, count, dIn + offset, dOut + offset, inStride, outStride, chunk, s),
 						"WaveNet kernel (fused)");
+				}
 				offset += (size_t)chunk;
 				left -= (size_t)chunk;
 			}
@@ -1757,6 +1764,9 @@ namespace na
 			CheckHip(hipEventCreateWithFlags(&p.uploaded, hipEventDisableTiming), "hipEventCreate");
 			CheckHip(hipEventCreateWithFlags(&p.computed, hipEventDisableTiming), "hipEventCreate");
 			CheckHip(hipEventCreateWithFlags(&p.downloaded, hipEventDisableTiming), "hipEventCreate");
+			// the set-up side of the pipelined interface: the half-batch chains' streams too (creating a HIP stream takes ~13 ms)
+			for (int h = 0; h < numChains; h++)
+				if (!halfStream[h]) CheckHip(hipStreamCreateWithFlags(&halfStream[h], hipStreamNonBlocking), "hipStreamCreate");
 		}
 		if (floats <= p.floats) return;
 		if (p.hostIn) (void)hipHostFree(p.hostIn);
@@ -1790,12 +1800,14 @@ namespace na
 			// (a lone buffer gains nothing from being split -- 55-58 vs 60 us Submit .. Collect -- so only with another ticket in flight)
 			bool othersInFlight = false;
 			for (const PipeSlot& o : pipe) othersInFlight = othersInFlight || (&o != &p && o.busy);
-			if ((othersInFlight || halfChainsUsed) && PrepareHalves(n))
+			// (nor does a submission whose caller has the library copy its rows: the host thread is the bottleneck there, 2 x 512 KB of
+			// memcpy per buffer, and a second launch only adds to it -- 48-50 vs 52-59 us per buffer)
+			if (in == nullptr && (othersInFlight || halfChainsUsed) && PrepareHalves(n))
 			{
 				// two free-running half-batch chains (see halfStream): each half in submission order on its own stream
 				for (int h = 0; h < numChains; h++)
 					if (!p.halfDone[h]) CheckHip(hipEventCreateWithFlags(&p.halfDone[h], hipEventDisableTiming), "hipEventCreate");
-				LaunchHalves(dIn, dOut, n, (long)n, (long)n, p.halfDone);
+				LaunchHalves(dIn, dOut, n, (long)n, (long)n, p.halfDone, true);
 				halfChainsUsed = true;
 				pipelineUsed = true;
 				lastKernelEvent = nullptr; // (ProcessDevice after this drains the half streams itself)

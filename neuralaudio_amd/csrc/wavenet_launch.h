@@ -28,14 +28,16 @@ namespace na
 
 	// Same contract, the f16-split MFMA kernel (wavenet_split_kernels.hip) -- the shipped path.  Its stream state uses split quads in
 	// frame-major rings (see WnSplitStage), so a model group stays on one kernel family for its whole life.
+	// sharing: how many launches of this size run on the chip at the same time (the free-running half-batch chains: 2) -- the
+	// workgroup shape is chosen for what is resident, not for what one launch brings
 	hipError_t LaunchWaveNetSplitFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
-		hipStream_t stream);
+		hipStream_t stream, int sharing = 1);
 
 	// Same contract on the compile-time specialised layer chains of the official architectures (wavenet_spec_kernels.hip): blocks of
 	// exactly 128 / 64 / 32 frames, every group of the launch from one architecture family (WnModelDev::spec_arch); returns
 	// hipErrorNotSupported otherwise -- LaunchWaveNetSplitFused tries it first and falls back to its stage interpreter.
 	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
-		hipStream_t stream);
+		hipStream_t stream, int sharing = 1);
 	bool WaveNetSpecEnabled();
 	void SetWaveNetSpecEnabled(bool on); // process-wide; not for use while launches are being issued from other threads
 	// which specialised chain (WnSpecArch) runs a split-kernel plan, WN_SPEC_NONE if none; host data

@@ -43,7 +43,7 @@ namespace na
 	// Runs the launch on a specialised chain when every group is the SAME official architecture and the block is 128 / 64 / 32 frames;
 	// returns hipErrorNotSupported otherwise (the caller then uses the stage interpreter).
 	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
-		hipStream_t stream)
+		hipStream_t stream, int sharing)
 	{
 		if (numGroups <= 0 || numGroups > WN_FRAME_MAX_GROUPS || (n != 128 && n != 64 && n != 32)) return hipErrorNotSupported;
 		if (!WaveNetSpecEnabled()) return hipErrorNotSupported; // tuning / tests: the interpreter for everything
@@ -66,7 +66,9 @@ namespace na
 		// Streams per workgroup.  The half-size workgroups (SPB = 1: four waves) are compiled for two waves per SIMD, i.e. with 256 VGPRs
 		// (NA_SPK_OCC): a launch that cannot fill the chip anyway is bound by the latency of its few waves, and the registers let the
 		// compiler keep a layer's LDS reads in flight (Nano x 1024 = 256 packed streams 25.1 -> 22.6 us, Feather x 1024 24.3 -> 22.2,
-		// Standard x 512 25.4 -> 23.4).  They are used while every workgroup is resident at that occupancy: at most two per CU.
+		// Standard x 512 25.4 -> 23.4).  They are used while every workgroup is resident at that occupancy: at most two per CU --
+		// counting the workgroups of the launches that share the chip with this one (two free-running half-batch chains of 512 Standard
+		// streams each: 37.1 us per step with the half-size workgroups, 36.7 with the full-size ones; Feather x 1024 = 2 x 256: 21.5 vs 24.8).
 		static const int spbEnv = getenv("NA_SP_SPB") ? atoi(getenv("NA_SP_SPB")) : 0;
 		const int residentHalf = 2 * CurrentDeviceCUs();
 		int halfGroups = 0; // workgroups of the launch at SPB = 1 (an A2-Lite workgroup holds two streams there: T = 4)
@@ -75,7 +77,7 @@ namespace na
 			const int per = groups[i].model->spec_arch == WN_SPEC_A2LITE ? 2 : 1;
 			halfGroups += (groups[i].numStreams + per - 1) / per;
 		}
-		const int spb = spbEnv > 0 ? spbEnv : (halfGroups > residentHalf ? 2 : 1);
+		const int spb = spbEnv > 0 ? spbEnv : (halfGroups * std::max(sharing, 1) > residentHalf ? 2 : 1);
 #ifdef NA_SP_QUICK
 		if (arch != WN_SPEC_STD || packed) return hipErrorNotSupported;
 		return spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);

@@ -862,14 +862,14 @@ namespace na
 	}
 
 	hipError_t LaunchWaveNetSplitFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
-		hipStream_t stream)
+		hipStream_t stream, int sharing)
 	{
 		if (n <= 0 || numGroups <= 0) return hipSuccess;
 		if (n > WN_MAX_FRAMES || numGroups > WN_FRAME_MAX_GROUPS) return hipErrorInvalidValue;
 		{
 			// the official architectures run compile-time specialised chains (wavenet_spec_kernels.hip); this file's stage interpreter takes
 			// everything else: runtime-shaped models, other block lengths, mixed launches
-			const hipError_t e = LaunchWaveNetSpecFused(groups, numGroups, in, out, inStride, outStride, n, stream);
+			const hipError_t e = LaunchWaveNetSpecFused(groups, numGroups, in, out, inStride, outStride, n, stream, sharing);
 			if (e != hipErrorNotSupported) return e;
 		}
 		int total = 0;

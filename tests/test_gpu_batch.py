@@ -335,27 +335,42 @@ def test_pipelined_half_chains_match_process_and_mix_with_the_other_entry_points
         blk = np.ascontiguousarray(x[:, sl * n:sl * n + frames])
         return ref.Process(blk), blk
 
+    def submit(blk):  # in place (a submission the library has to copy stays one launch: the host thread is the bottleneck there)
+        b.NextInput(blk.shape[1])[:] = blk
+        return b.SubmitInput(blk.shape[1])
+
     tickets, got, want = [], [], []
     for i in range(4):
         w, blk = step(i)
         want.append(w)
-        tickets.append(b.Submit(blk))
+        tickets.append(submit(blk))
         if len(tickets) == 3:
             got.append(b.Collect(tickets.pop(0)))
+        if i >= 1:
+            assert _halves_as_expected(b)  # (from the second ticket in flight on)
     while tickets:
         got.append(b.Collect(tickets.pop(0)))
     assert np.array_equal(np.concatenate(got, axis=1), np.concatenate(want, axis=1))
     w, blk = step(4)  # a synchronous call between submissions (drains the half chains first)
     assert np.array_equal(b.Process(blk), w)
     w, blk = step(5, 96)  # 96 frames = a 64- and a 32-frame launch: the batch stream path
-    assert np.array_equal(b.Collect(b.Submit(blk)), w)
+    assert np.array_equal(b.Collect(submit(blk)), w)
+    w, blk = step(6)  # a copying submission between in-place ones
+    t1 = submit(blk)
+    w2, blk2 = step(7)
+    t2 = b.Submit(blk2)
+    assert np.array_equal(b.Collect(t1), w) and np.array_equal(b.Collect(t2), w2)
     assert ref.AddStreams(m, 2) == b.AddStreams(m, 2) == S  # streams join ...
     ref.RemoveStreams(3, 1)
     b.RemoveStreams(3, 1)  # ... and one leaves: the group is no longer contiguous -> the halves are cut out of its index lists
     x2 = np.concatenate([x, x[:2]], axis=0)
     for i in (6, 7):
         blk = np.ascontiguousarray(x2[:, i * n:(i + 1) * n])
-        assert np.array_equal(b.Collect(b.Submit(blk)), ref.Process(blk))
+        ta = submit(blk)
+        blk_b = np.ascontiguousarray(x2[:, (i - 4) * n:(i - 3) * n])
+        tb = submit(blk_b)
+        assert np.array_equal(b.Collect(ta), ref.Process(blk))
+        assert np.array_equal(b.Collect(tb), ref.Process(blk_b))
     ref.close()
     b.close()
 
@@ -385,7 +400,7 @@ def test_device_pointer_steps_on_the_batch_own_streams_run_as_free_running_halve
     b.MarkTime(0)
     for k in range(3):
         b.ProcessDevice(x[k].data_ptr(), got[k].data_ptr(), n)
-        assert b.UsesHalfLaunches()
+        assert _halves_as_expected(b)
     b.MarkTime(1)
     ms = b.ElapsedMs()
     assert 0.0 < ms < 50.0, ms
@@ -394,7 +409,7 @@ def test_device_pointer_steps_on_the_batch_own_streams_run_as_free_running_halve
     # a synchronous host-buffer call joins the chains, runs ordered, and the next device step starts new chains behind it
     assert np.array_equal(b.Process(x[3].cpu().numpy()), want[3].cpu().numpy())
     b.ProcessDevice(x[4].data_ptr(), got[4].data_ptr(), n)
-    assert b.UsesHalfLaunches()
+    assert _halves_as_expected(b)
     # the stream handed out: from here on one ordered launch per step
     assert b.GetHipStream() not in (None, 0)
     b.ProcessDevice(x[5].data_ptr(), got[5].data_ptr(), n)
@@ -403,6 +418,14 @@ def test_device_pointer_steps_on_the_batch_own_streams_run_as_free_running_halve
     assert torch.equal(got[4:], want[4:])
     ref.close()
     b.close()
+
+
+def _halves_as_expected(batch):
+    """Outside a forced-family run (tests/test_gpu_families.py: fallback kernels run ordered launches, the results must still agree)
+    the batch must have run its last step as two half-batch launches."""
+    if any(os.environ.get(k) for k in ("NA_WN_KERNEL", "NA_WN_SPEC", "NA_WN_PACK", "NA_HOST_HALVES", "NA_HOST_DIRECT", "NA_SP_T", "NA_SP_GEN")):
+        return True
+    return batch.UsesHalfLaunches()
 
 
 def _device_steps(batch, x, out, n):
@@ -443,7 +466,7 @@ def test_mixed_and_packed_batches_run_as_free_running_halves_too(na, loader):
     _device_steps(ref, x, want, n)
     ref.Synchronize()
     _device_steps(b, x, got, n)
-    assert b.UsesHalfLaunches() and not ref.UsesHalfLaunches()
+    assert _halves_as_expected(b) and not ref.UsesHalfLaunches()
     b.Synchronize()
     assert torch.equal(got, want)
     assert float(want[:, 0].abs().max()) > 0 and float(want[:, 5].abs().max()) == 0  # (a removed row stays untouched)
@@ -465,7 +488,7 @@ def test_mixed_and_packed_batches_run_as_free_running_halves_too(na, loader):
             bb.SetQuality(7 * k + 1, 0.0)
             bb.SetQuality(3 * k, 1.0)
             bb.ProcessDevice(x[k].data_ptr(), out[k].data_ptr(), n)
-        assert b.UsesHalfLaunches() and not ref.UsesHalfLaunches()
+        assert _halves_as_expected(b) and not ref.UsesHalfLaunches()
     ref.Synchronize()
     b.Synchronize()
     assert torch.equal(got, want)
