@@ -1176,6 +1176,14 @@ namespace na
 	{
 		std::vector<WnFrameGroup> part[GpuBatch::kMaxChains];
 		bool listsUploaded = false; // an index list went to the device on the batch stream while the lists were built
+		// every part is a contiguous range of rows (no index lists, no packed streams): the host can stage and collect a half by itself
+		bool RowRangesOnly() const
+		{
+			for (const auto& list : part)
+				for (const WnFrameGroup& g : list)
+					if (g.slots != nullptr || g.pack > 1) return false;
+			return true;
+		}
 	};
 
 	// The buffer as two launch lists of half of every group's streams each (see halfStream); false: it runs as ordered launches.
@@ -1234,38 +1242,51 @@ namespace na
 		return total >= 512 && (size_t)NextWaveNetChunk(n, compact) == n;
 	}
 
-	// the two lists of PrepareHalves, each on its own stream behind that half's previous launch; `done`: events to record
-	void GpuBatch::LaunchHalves(const float* dIn, float* dOut, size_t n, long inStride, long outStride, hipEvent_t* done, bool hostRows)
+	// the chains are about to take launches: whatever else is in flight for this batch comes first, and their streams exist
+	void GpuBatch::BeginHalves()
 	{
-		HalfLists& hl = *halfLists;
-		if (!halfChainsUsed || submitTopology != topologyVersion || hl.listsUploaded)
+		if (!halfChainsUsed || submitTopology != topologyVersion || halfLists->listsUploaded)
 		{
 			// whatever the batch stream (state resets, prewarms of new streams, index lists) or a slot stream still has in flight comes first
 			DrainPipeline();
 			CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
 			submitTopology = topologyVersion;
 		}
-		// Workgroup shape: for rows in HBM, sized for what is resident with both chains on the chip (full-size workgroups: 36.7 vs 37.1 us
-		// per 1024 x 128 Standard step); for rows in pinned host memory the half-size workgroups win (43.5-44.4 vs 45.1-46.2 us per buffer
-		// host to host: twice the workgroups keep more PCIe reads in flight)
-		const int sharing = hostRows ? 1 : numChains;
 		for (int h = 0; h < numChains; h++)
 		{
-			if (!halfStream[h])
+			if (halfStream[h]) continue;
+			CheckHip(hipStreamCreateWithFlags(&halfStream[h], hipStreamNonBlocking), "hipStreamCreate");
+			if (markOpen)
 			{
-				CheckHip(hipStreamCreateWithFlags(&halfStream[h], hipStreamNonBlocking), "hipStreamCreate");
-				if (markOpen)
-				{
-					if (!marks[1 + h][0]) CheckHip(hipEventCreate(&marks[1 + h][0]), "hipEventCreate");
-					CheckHip(hipEventRecord(marks[1 + h][0], halfStream[h]), "hipEventRecord");
-				}
+				if (!marks[1 + h][0]) CheckHip(hipEventCreate(&marks[1 + h][0]), "hipEventCreate");
+				CheckHip(hipEventRecord(marks[1 + h][0], halfStream[h]), "hipEventRecord");
 			}
-			if (!hl.part[h].empty())
-				CheckHip(LaunchWaveNetSplitFused(hl.part[h].data(), (int)hl.part[h].size(), dIn, dOut, inStride, outStride, (int)n, halfStream[h], sharing), "WaveNet kernel (half batch)");
-			if (done) CheckHip(hipEventRecord(done[h], halfStream[h]), "hipEventRecord");
 		}
 		halfChainsUsed = true;
 		lastStepHalves = true;
+	}
+
+	// list h of PrepareHalves on its own stream, behind that chain's previous launch
+	void GpuBatch::LaunchChain(int h, const float* dIn, float* dOut, size_t n, long inStride, long outStride, bool hostRows)
+	{
+		// Workgroup shape: for rows in HBM, sized for what is resident with both chains on the chip (full-size workgroups: 36.7 vs 37.1 us
+		// per 1024 x 128 Standard step); for rows in pinned host memory the half-size workgroups win (43.5-44.4 vs 45.1-46.2 us per buffer
+		// host to host: twice the workgroups keep more PCIe reads in flight)
+		const std::vector<WnFrameGroup>& part = halfLists->part[h];
+		if (!part.empty())
+			CheckHip(LaunchWaveNetSplitFused(part.data(), (int)part.size(), dIn, dOut, inStride, outStride, (int)n, halfStream[h], hostRows ? 1 : numChains),
+				"WaveNet kernel (half batch)");
+	}
+
+	// the lists of PrepareHalves, each on its own stream; `done`: events to record
+	void GpuBatch::LaunchHalves(const float* dIn, float* dOut, size_t n, long inStride, long outStride, hipEvent_t* done, bool hostRows)
+	{
+		BeginHalves();
+		for (int h = 0; h < numChains; h++)
+		{
+			LaunchChain(h, dIn, dOut, n, inStride, outStride, hostRows);
+			if (done) CheckHip(hipEventRecord(done[h], halfStream[h]), "hipEventRecord");
+		}
 	}
 
 	void GpuBatch::MarkTime(int which)
@@ -1714,10 +1735,33 @@ namespace na
 			}
 		}
 		EnsureStaging(total);
-		memcpy(hostStage, in, total * sizeof(float));
 		float* dStage = nullptr;
+		const bool direct = HostDirect() && hipHostGetDevicePointer(reinterpret_cast<void**>(&dStage), hostStage, 0) == hipSuccess && dStage != nullptr;
+		if (direct && PrepareHalves(n) && halfLists->RowRangesOnly())
+		{
+			// The blocking call in two halves: the rows of the first half are staged and launched, the second half is staged while the
+			// first runs, and the first half's result is copied out while the second still runs -- the two 512 KB host copies of a
+			// 1024 x 128 buffer (2 x 10 us) hide behind the kernels: p50 75-77 -> 60 us.
+			BeginHalves();
+			for (int h = 0; h < numChains; h++)
+			{
+				for (const WnFrameGroup& g : halfLists->part[h])
+					memcpy(hostStage + (size_t)g.row0 * n, in + (size_t)g.row0 * n, (size_t)g.numStreams * n * sizeof(float));
+				LaunchChain(h, dStage, dStage, n, (long)n, (long)n, true);
+			}
+			for (int h = 0; h < numChains; h++)
+			{
+				CheckHip(hipStreamSynchronize(halfStream[h]), "hipStreamSynchronize");
+				for (const WnFrameGroup& g : halfLists->part[h])
+					memcpy(out + (size_t)g.row0 * n, hostStage + (size_t)g.row0 * n, (size_t)g.numStreams * n * sizeof(float));
+			}
+			halfChainsUsed = false; // (both chains are idle again)
+			ZeroRetiredRows(out, n, streams.size());
+			return;
+		}
+		memcpy(hostStage, in, total * sizeof(float));
 		// (a pinned block the device cannot address -- not seen on MI355X -- goes through the copy engines instead of failing)
-		if (HostDirect() && hipHostGetDevicePointer(reinterpret_cast<void**>(&dStage), hostStage, 0) == hipSuccess && dStage != nullptr)
+		if (direct)
 			ProcessDeviceOrdered(dStage, dStage, n, (long)n, (long)n);
 		else
 		{

@@ -234,6 +234,8 @@ namespace na
 		std::unique_ptr<HalfLists> halfLists;
 		bool PrepareHalves(size_t n);
 		void ProcessDeviceOrdered(const float* dIn, float* dOut, size_t n, long inStride, long outStride);
+		void BeginHalves();
+		void LaunchChain(int h, const float* dIn, float* dOut, size_t n, long inStride, long outStride, bool hostRows);
 		void LaunchHalves(const float* dIn, float* dOut, size_t n, long inStride, long outStride, hipEvent_t* done, bool hostRows);
 		void JoinHalves(); // the half-batch chains are done (host-side wait); the next launches go to the batch stream again
 		hipEvent_t marks[1 + kMaxChains][2] = {};
