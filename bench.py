@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--block", type=int, default=BLOCK, help="samples per buffer (default 128 = the BASELINE config; other sizes are exploration only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle spot check of the last timed step")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the host-buffer latency loop and tools/HostPipeBench after the timed region (profiling runs: their launches "
+                         "would be averaged into the kernel statistics and counters)")
     ap.add_argument("--caller-stream", action="store_true",
                     help="create the batch on a stream of the caller (torch's) instead of its own: every launch is ordered on that stream, "
                          "so a step is ONE launch (the batch's own stream lets a step run as two free-running half-batch launches)")
@@ -535,7 +538,7 @@ def main():
                 "algorithmic_flops_per_sample": flops_per_sample,
             },
         }
-        if world == 1:
+        if world == 1 and not args.no_host_path:
             # per-buffer latency through the host-buffer entry point (pinned staging, H2D, kernel, D2H, stream sync) -- the path a
             # real-time host calls once per audio buffer; outside the timed region, reported next to the north star's "< 1 ms per buffer"
             xh = x[0].cpu().numpy()
