@@ -752,7 +752,8 @@ namespace na
 				{
 					// the gate matrices once more, transposed into [quad of inputs][row][4] (lstm_dev.h: LstmModelDev::wT)
 					const int H = lstm.hiddenSize, gateRows = ((lstm.cell == CELL_GRU) ? 3 : 4) * H;
-					dev.rowsPad = (gateRows + 63) / 64 * 64;
+					dev.waves = RecurrentWaveWaves(gateRows);
+					dev.rowsPad = (gateRows + 64 * dev.waves - 1) / (64 * dev.waves) * (64 * dev.waves);
 					std::vector<float> wt;
 					for (int l = 0; l < lstm.numLayers; l++)
 					{

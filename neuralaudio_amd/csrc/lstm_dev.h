@@ -10,6 +10,8 @@
 // (structure-of-arrays over streams so a wave's 64 lanes load/store 256 contiguous bytes).
 #pragma once
 
+#include <cstdlib>
+
 namespace na
 {
 	constexpr int LSTM_MAX_LAYERS = 8;
@@ -27,11 +29,30 @@ namespace na
 	//   Round 3: the runtime-shaped wave kernel streams weights that do not fit the LDS from L2 (RecurrentWaveRtKernel, weights
 	//   transposed for coalesced reads), so every shape up to RECURRENT_WAVE_MAX_HIDDEN units has a real-time kernel whatever the
 	//   weight size (LSTMDynamic.h:95-108,166-179 runs any size on the CPU).
-	constexpr int RECURRENT_WAVE_MAX_HIDDEN = 128;
+	//   Round 4: from 65 gate rows on (LSTM / GRU of more than 16 / 21 units on this kernel) a stream is a WORKGROUP of 2 .. 16 waves that share the
+	//   gate rows (RecurrentWaveWaves; a barrier where the one-wave version has a wave fence), so the limit is 1024 units; beyond 128
+	//   units the 1-unit head is evaluated inside the sample loop (no [samples][H] buffer) and a dense tail needs that buffer to fit.
+	constexpr int RECURRENT_WAVE_MAX_HIDDEN = 1024;
+	constexpr int RECURRENT_HEAD_IN_LOOP_FROM = 129; // hidden sizes from here on: classic head inside the sample loop
+	// waves per stream of the runtime-shaped kernel: one gate row per lane up to 16 waves (the kernel is bound by the latency of its
+	// weight loads from L2, and more waves keep more of them in flight: LSTM 1x256 x 64 streams 2.32 / 1.63 / 1.34 ms per 128-sample
+	// block at four / two / one row per lane, LSTM 1x128 1.22 / 0.90 / 0.68; round 3, one wave: 2.0)
+	inline int RecurrentWaveWaves(int gateRows)
+	{
+		static const int rpl = getenv("NA_REC_RPL") ? atoi(getenv("NA_REC_RPL")) : 1; // tuning knob: gate rows per lane
+		int waves = 1;
+		while (waves < 16 && gateRows > 64 * rpl * waves) waves *= 2;
+		return waves;
+	}
 	inline bool RecurrentWaveShape(int hidden, int numLayers, int tailWidth)
 	{
-		return hidden >= 1 && hidden <= RECURRENT_WAVE_MAX_HIDDEN && numLayers >= (tailWidth > 0 ? 0 : 1) && numLayers <= LSTM_MAX_LAYERS &&
-			tailWidth <= LSTM_MAX_TAIL_WIDTH;
+		if (!(hidden >= 1 && hidden <= RECURRENT_WAVE_MAX_HIDDEN && numLayers >= (tailWidth > 0 ? 0 : 1) && numLayers <= LSTM_MAX_LAYERS &&
+			tailWidth <= LSTM_MAX_TAIL_WIDTH)) return false;
+		// LDS without the weights (they stream from L2 when they do not fit): xin | h, c | gates | [samples][H] of the last layer (small models
+		// and dense tails) | tail scratch
+		const bool hseq = hidden < RECURRENT_HEAD_IN_LOOP_FROM || tailWidth > 0;
+		const long floats = LSTM_MAX_FRAMES + 2L * numLayers * hidden + 6L * hidden + (hseq ? 2L * (numLayers > 0 ? hidden : 1) * 64 : 0) + 2L * tailWidth * 64 + 64;
+		return floats * 4 <= 160L * 1024;
 	}
 	// the lane = stream kernels' bound (LstmGenericKernel / GruGenericKernel: state of 64 streams in LDS)
 	inline bool LstmLaneKernelShape(int hidden, int numLayers, int tailWidth = 0)
@@ -71,6 +92,7 @@ namespace na
 		// part to Qh = ceil(H / 4)), rows padded to a multiple of 64: the 64 lanes of a wave read 64 consecutive rows of one quad = 1 KB
 		const float* wT;
 		int layerOffT[LSTM_MAX_LAYERS]; // float offsets into wT
-		int rowsPad;
+		int rowsPad; // (a multiple of 64 x waves)
+		int waves;   // waves per stream of the runtime-shaped kernel (RecurrentWaveWaves)
 	};
 }

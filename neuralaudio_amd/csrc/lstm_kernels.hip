@@ -347,7 +347,8 @@ namespace na
 	{
 		const int H = m.hidden, L = m.numLayers;
 		const int rowsPerLayer = (m.cell == LSTM_CELL_GRU ? 3 : 4) * H, biases = (m.cell == LSTM_CELL_GRU ? 6 : 4) * H;
-		size_t f = (size_t)LSTM_MAX_FRAMES + (size_t)2 * L * H + (size_t)6 * H + (size_t)2 * (L > 0 ? H : 1) * 64 +
+		const bool hseq = H < RECURRENT_HEAD_IN_LOOP_FROM || m.tailLayers > 0; // (else the head is evaluated inside the sample loop)
+		size_t f = (size_t)LSTM_MAX_FRAMES + (size_t)2 * L * H + (size_t)6 * H + (hseq ? (size_t)2 * (L > 0 ? H : 1) * 64 : 0) +
 			(size_t)2 * (m.tailLayers > 0 ? m.tailWidth : 0) * 64;
 		if (weightsInLds)
 			for (int l = 0; l < L; l++) f += (size_t)rowsPerLayer * (size_t)(((l == 0 ? 1 : H) + H) | 1) + (size_t)biases;
@@ -361,9 +362,10 @@ namespace na
 	// row as the LDS path: k = 0 .. I-1, then 0 .. H-1 (padding terms are zeros).
 	typedef float rt_f4 __attribute__((ext_vector_type(4)));
 	template <int RPL>
-	__device__ __forceinline__ void RowsDotL2(const float* __restrict__ wTl, int rowsPad, int lane, int I, int H, const float* sIn, const float* sH, float (&ai)[RPL],
+	__device__ __forceinline__ void RowsDotL2(const float* __restrict__ wTl, int rowsPad, int lane, int nt, int I, int H, const float* sIn, const float* sH, float (&ai)[RPL],
 		float (&ah)[RPL])
 	{
+		// (lane = thread of the stream's workgroup, nt = its size: row r = lane + nt i)
 		const int Qi = (I + 3) / 4, Qh = (H + 3) / 4;
 		const rt_f4* wq = reinterpret_cast<const rt_f4*>(wTl) + lane;
 		for (int q = 0; q < Qi; q++)
@@ -372,7 +374,7 @@ namespace na
 #pragma unroll
 			for (int i = 0; i < RPL; i++)
 			{
-				const rt_f4 w4 = wq[(size_t)q * rowsPad + 64 * i];
+				const rt_f4 w4 = wq[(size_t)q * rowsPad + nt * i];
 				ai[i] += w4.x * s0;
 				ai[i] += w4.y * s1;
 				ai[i] += w4.z * s2;
@@ -380,14 +382,17 @@ namespace na
 			}
 		}
 		wq += (size_t)Qi * rowsPad;
-#pragma unroll 2
+#ifndef NA_REC_UNROLL
+#define NA_REC_UNROLL 4 // (quads of hidden inputs whose weight loads are in flight together; 8 spills at 128 VGPRs: 4 x slower)
+#endif
+#pragma unroll NA_REC_UNROLL
 		for (int q = 0; q < Qh; q++)
 		{
 			const float s0 = sH[4 * q], s1 = (4 * q + 1 < H) ? sH[4 * q + 1] : 0.0f, s2 = (4 * q + 2 < H) ? sH[4 * q + 2] : 0.0f, s3 = (4 * q + 3 < H) ? sH[4 * q + 3] : 0.0f;
 #pragma unroll
 			for (int i = 0; i < RPL; i++)
 			{
-				const rt_f4 w4 = wq[(size_t)q * rowsPad + 64 * i];
+				const rt_f4 w4 = wq[(size_t)q * rowsPad + nt * i];
 				ah[i] += w4.x * s0;
 				ah[i] += w4.y * s1;
 				ah[i] += w4.z * s2;
@@ -398,7 +403,7 @@ namespace na
 
 	// gate pre-activations of one layer from L2-streamed weights -> gates[] (LSTM: activated; GRU: ai | ah), RPL = rows per lane
 	template <int RPL>
-	__device__ __forceinline__ void GateRowsL2(const LstmModelDev& m, int l, int lane, const float* sIn, const float* sH, float* gates)
+	__device__ __forceinline__ void GateRowsL2(const LstmModelDev& m, int l, int lane, int nt, const float* sIn, const float* sH, float* gates)
 	{
 		const int H = m.hidden, I = (l == 0) ? 1 : H, W = I + H;
 		const bool gru = m.cell == LSTM_CELL_GRU;
@@ -408,15 +413,15 @@ namespace na
 #pragma unroll
 		for (int i = 0; i < RPL; i++)
 		{
-			const int r = lane + 64 * i;
+			const int r = lane + nt * i;
 			ai[i] = (gru && r < rows) ? bias[r] : 0.0f;
 			ah[i] = (gru && r < rows) ? bias[3 * H + r] : 0.0f;
 		}
-		RowsDotL2<RPL>(m.wT + m.layerOffT[l], m.rowsPad, lane, I, H, sIn, sH, ai, ah);
+		RowsDotL2<RPL>(m.wT + m.layerOffT[l], m.rowsPad, lane, nt, I, H, sIn, sH, ai, ah);
 #pragma unroll
 		for (int i = 0; i < RPL; i++)
 		{
-			const int r = lane + 64 * i;
+			const int r = lane + nt * i;
 			if (r >= rows) continue;
 			if (gru)
 			{
@@ -432,24 +437,32 @@ namespace na
 		}
 	}
 
-	__device__ __forceinline__ void GateRowsL2Dispatch(const LstmModelDev& m, int l, int lane, const float* sIn, const float* sH, float* gates)
+	__device__ __forceinline__ void GateRowsL2Dispatch(const LstmModelDev& m, int l, int lane, int nt, const float* sIn, const float* sH, float* gates)
 	{
-		const int rpl = (((m.cell == LSTM_CELL_GRU) ? 3 : 4) * m.hidden + 63) / 64;
+		const int rpl = (((m.cell == LSTM_CELL_GRU) ? 3 : 4) * m.hidden + nt - 1) / nt;
 		switch (rpl)
 		{
-		case 1: GateRowsL2<1>(m, l, lane, sIn, sH, gates); break;
-		case 2: GateRowsL2<2>(m, l, lane, sIn, sH, gates); break;
-		case 3: GateRowsL2<3>(m, l, lane, sIn, sH, gates); break;
-		case 4: GateRowsL2<4>(m, l, lane, sIn, sH, gates); break;
-		case 5: GateRowsL2<5>(m, l, lane, sIn, sH, gates); break;
-		case 6: GateRowsL2<6>(m, l, lane, sIn, sH, gates); break;
-		case 7: GateRowsL2<7>(m, l, lane, sIn, sH, gates); break;
-		default: GateRowsL2<8>(m, l, lane, sIn, sH, gates); break;
+		case 1: GateRowsL2<1>(m, l, lane, nt, sIn, sH, gates); break;
+		case 2: GateRowsL2<2>(m, l, lane, nt, sIn, sH, gates); break;
+		case 3: GateRowsL2<3>(m, l, lane, nt, sIn, sH, gates); break;
+		case 4: GateRowsL2<4>(m, l, lane, nt, sIn, sH, gates); break;
+		case 5: GateRowsL2<5>(m, l, lane, nt, sIn, sH, gates); break;
+		case 6: GateRowsL2<6>(m, l, lane, nt, sIn, sH, gates); break;
+		case 7: GateRowsL2<7>(m, l, lane, nt, sIn, sH, gates); break;
+		default: GateRowsL2<8>(m, l, lane, nt, sIn, sH, gates); break;
 		}
 	}
 
 	// l2w: the gate matrices are streamed from L2 (m.wT) instead of living in LDS -- for weights larger than the LDS (LSTM 2x64: 197 KB)
-	__global__ void __launch_bounds__(64) RecurrentWaveRtKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
+	// MAXT = 64: one wave per stream (wave fences); MAXT = 1024: a workgroup of m.waves waves per stream shares the gate rows (barriers)
+	template <int MAXT>
+	__device__ __forceinline__ void RecurrentRtSync()
+	{
+		if (MAXT == 64) RecurrentRtSync<MAXT>();
+		else __syncthreads();
+	}
+	template <int MAXT>
+	__global__ void __launch_bounds__(MAXT) RecurrentWaveRtKernel(LstmModelDev m, float* __restrict__ state, int capacity, const int* __restrict__ slots,
 		const int* __restrict__ rows, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride, int n, int l2w)
 	{
 		extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -462,12 +475,14 @@ namespace na
 		float* hvec = xin + LSTM_MAX_FRAMES;   // [L][H]
 		float* cvec = hvec + L * H;            // [L][H] (LSTM)
 		float* gates = cvec + L * H;           // LSTM: [4H] activated gates; GRU: ai[3H] | ah[3H]
+		const bool headInLoop = H >= RECURRENT_HEAD_IN_LOOP_FROM && m.tailLayers == 0; // (no [samples][H] buffer then)
 		float* hseq = gates + 6 * H;           // [2][Hs][64]
-		float* tailA = hseq + (size_t)2 * Hs * 64;
+		float* tailA = hseq + (headInLoop ? 0 : (size_t)2 * Hs * 64);
 		float* tailB = tailA + (size_t)(m.tailLayers > 0 ? m.tailWidth : 0) * 64;
 		float* wl = tailB + (size_t)(m.tailLayers > 0 ? m.tailWidth : 0) * 64; // per layer: [G H][stride] then the biases
 
-		const int lane = threadIdx.x;
+		const int lane = threadIdx.x;            // thread of the stream's workgroup
+		const int nt = MAXT == 64 ? 64 : (int)blockDim.x;
 		const int slot = slots[blockIdx.x];
 		const int row = rows[blockIdx.x];
 		const float* inRow = in + (size_t)row * inStride;
@@ -481,19 +496,19 @@ namespace na
 			{
 				const int W = (l == 0 ? 1 : H) + H, stride = OddStride(W);
 				const float* src = m.w + m.layerOff[l];
-				for (int i = lane; i < G * H * W; i += 64) dst[(i / W) * stride + (i % W)] = src[i];
-				for (int i = lane; i < NB; i += 64) dst[(size_t)G * H * stride + i] = src[(size_t)G * H * W + i];
+				for (int i = lane; i < G * H * W; i += nt) dst[(i / W) * stride + (i % W)] = src[i];
+				for (int i = lane; i < NB; i += nt) dst[(size_t)G * H * stride + i] = src[(size_t)G * H * W + i];
 				dst += (size_t)G * H * stride + NB;
 			}
 		}
-		for (int f = lane; f < n; f += 64) xin[f] = inRow[f];
-		for (int i = lane; i < L * H; i += 64)
+		for (int f = lane; f < n; f += nt) xin[f] = inRow[f];
+		for (int i = lane; i < L * H; i += nt)
 		{
 			const int l = i / H, k = i % H;
 			hvec[i] = state[(size_t)(l * 2 * H + k) * capacity + slot];
 			if (!gru) cvec[i] = state[(size_t)(l * 2 * H + H + k) * capacity + slot];
 		}
-		LstmWaveSync();
+		RecurrentRtSync<MAXT>();
 
 		for (int f = 0; f < n; f++)
 		{
@@ -504,11 +519,11 @@ namespace na
 				const float* sIn = (l == 0) ? (xin + f) : (hvec + (l - 1) * H); // LSTM.h:168 / :170-180
 				float* sH = hvec + l * H;
 				const float* bias = wlay + (size_t)G * H * stride; // (LDS mode)
-				if (l2w) GateRowsL2Dispatch(m, l, lane, sIn, sH, gates);
+				if (l2w) GateRowsL2Dispatch(m, l, lane, nt, sIn, sH, gates);
 				if (!gru)
 				{
 					if (!l2w)
-					for (int r = lane; r < 4 * H; r += 64)
+					for (int r = lane; r < 4 * H; r += nt)
 					{
 						const float* wr = wlay + (size_t)r * stride;
 						float acc = 0.0f;
@@ -521,8 +536,8 @@ namespace na
 						const bool isG = (r >= 2 * H) && (r < 3 * H);
 						gates[r] = isG ? LstmTanh(acc, m.math) : LstmSigmoid(acc, m.math);
 					}
-					LstmWaveSync();
-					for (int u = lane; u < H; u += 64)
+					RecurrentRtSync<MAXT>();
+					for (int u = lane; u < H; u += nt)
 					{
 						// LSTM.h:94-99
 						const float c = (gates[H + u] * cvec[l * H + u]) + (gates[u] * gates[2 * H + u]);
@@ -534,7 +549,7 @@ namespace na
 				{
 					// keras GRU, reset_after (gru_kernels.hip GruLayerStep): input and recurrent pre-activations kept apart
 					if (!l2w)
-					for (int r = lane; r < 3 * H; r += 64)
+					for (int r = lane; r < 3 * H; r += nt)
 					{
 						const float* wr = wlay + (size_t)r * stride;
 						float ai = bias[r], ah = bias[3 * H + r];
@@ -545,8 +560,8 @@ namespace na
 						gates[r] = ai;
 						gates[3 * H + r] = ah;
 					}
-					LstmWaveSync();
-					for (int u = lane; u < H; u += 64)
+					RecurrentRtSync<MAXT>();
+					for (int u = lane; u < H; u += nt)
 					{
 						const float z = GruSigmoid(gates[u] + gates[3 * H + u]);
 						const float rr = GruSigmoid(gates[H + u] + gates[4 * H + u]);
@@ -554,16 +569,32 @@ namespace na
 						sH[u] = (1.0f - z) * c + z * sH[u];
 					}
 				}
-				LstmWaveSync();
+				RecurrentRtSync<MAXT>();
 				wlay += (size_t)G * H * stride + NB;
 			}
-			if (L > 0)
-				for (int u = lane; u < H; u += 64) hseq[(size_t)((f >> 6) * H + u) * 64 + (f & 63)] = hvec[(L - 1) * H + u];
+			if (headInLoop)
+			{
+				// LSTM.h:182-189 for this sample, by the first wave: the other waves are already in the next sample's gate rows (they read
+				// h, which changes only behind the next barrier -- and the first wave reaches that barrier after this)
+				if (lane < 64)
+				{
+					const float* headW = m.w + m.headOff;
+					float acc = 0.0f;
+					for (int k = lane; k < H; k += 64) acc += headW[k] * hvec[(L - 1) * H + k];
+					for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+					if (lane == 0) xin[f] = acc + headW[H]; // (xin[f] was consumed by layer 0 of this sample)
+				}
+			}
+			else if (L > 0)
+				for (int u = lane; u < H; u += nt) hseq[(size_t)((f >> 6) * H + u) * 64 + (f & 63)] = hvec[(L - 1) * H + u];
 		}
-		LstmWaveSync();
+		RecurrentRtSync<MAXT>();
 
 		// head / dense chain for the whole block, lane = sample (LSTM.h:182-189; RTNeuralModel.h:417-421)
 		const float* headW = m.w + m.headOff;
+		if (headInLoop)
+			for (int f = lane; f < n; f += nt) outRow[f] = xin[f];
+		else if (lane < 64)
 		for (int pass = 0; pass * 64 < n; pass++)
 		{
 			const int f = pass * 64 + lane;
@@ -578,7 +609,7 @@ namespace na
 			}
 			if (f < n) outRow[f] = y;
 		}
-		for (int i = lane; i < L * H; i += 64)
+		for (int i = lane; i < L * H; i += nt)
 		{
 			const int l = i / H, k = i % H;
 			state[(size_t)(l * 2 * H + k) * capacity + slot] = hvec[i];
@@ -602,10 +633,20 @@ namespace na
 			ldsBytes = RecurrentWaveRtLdsFloats(m, false) * sizeof(float);
 			if (ldsBytes > 160 * 1024) return false;
 		}
-		static PerDeviceOnce attr; // (hipFuncSetAttribute applies to the current device's copy of the kernel)
-		(void)attr.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&RecurrentWaveRtKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-		hipLaunchKernelGGL(RecurrentWaveRtKernel, dim3((unsigned)numStreams), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows, in, out, inStride,
-			outStride, n, l2w);
+		static PerDeviceOnce attr, attrBlock; // (hipFuncSetAttribute applies to the current device's copy of the kernel)
+		const int waves = m.waves > 1 ? m.waves : 1;
+		if (waves == 1)
+		{
+			(void)attr.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&RecurrentWaveRtKernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+			hipLaunchKernelGGL(RecurrentWaveRtKernel<64>, dim3((unsigned)numStreams), dim3(64), ldsBytes, stream, m, state, capacity, slots, rows, in, out, inStride,
+				outStride, n, l2w);
+		}
+		else
+		{
+			(void)attrBlock.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&RecurrentWaveRtKernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+			hipLaunchKernelGGL(RecurrentWaveRtKernel<1024>, dim3((unsigned)numStreams), dim3(64u * (unsigned)waves), ldsBytes, stream, m, state, capacity, slots, rows, in,
+				out, inStride, outStride, n, l2w);
+		}
 		err = hipGetLastError();
 		return true;
 	}

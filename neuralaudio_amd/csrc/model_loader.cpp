@@ -357,11 +357,11 @@ namespace na
 		{
 			if (!GruShapeSupported(d.hiddenSize, d.numLayers, tailWidth))
 				throw std::runtime_error("GRU " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
-					" is not supported (1-8 layers of up to 128 units, or a per-stream state that fits the 160 KB LDS)");
+					" is not supported (1-8 layers of up to 1024 units; a dense tail behind more than 128 units must fit the 160 KB LDS with its [samples][units] buffer)");
 		}
 		else if (!LstmShapeSupported(d.hiddenSize, d.numLayers, tailWidth))
 			throw std::runtime_error("LSTM " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
-				" is not supported (1-8 layers of up to 128 units, or a per-stream state that fits the 160 KB LDS)");
+				" is not supported (1-8 layers of up to 1024 units; a dense tail behind more than 128 units must fit the 160 KB LDS with its [samples][units] buffer)");
 	}
 
 	namespace

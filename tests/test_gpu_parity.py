@@ -285,6 +285,49 @@ def test_large_recurrent_models_run_in_real_time(na, loader):
         b.close()
 
 
+@pytest.mark.parametrize("kind,layers,hidden", [("lstm", 1, 129), ("lstm", 2, 192), ("lstm", 1, 512), ("gru", 1, 160), ("gru", 2, 200), ("lstm", 1, 1024)])
+def test_recurrent_layers_wider_than_128_units_match_oracle(na, loader, kind, layers, hidden):
+    """LSTMDynamic.h:95-108,166-179 takes any size; here up to 1024 units: from 257 gate rows on a stream is a workgroup of 2 .. 16 waves
+    sharing the gate rows (weights streamed from L2), from 129 units on the 1-unit head is evaluated inside the sample loop.
+    Ragged buffers, and a row's sum keeps the oracle's term order whatever the wave count."""
+    import json
+    if os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_LSTM_LANE_KERNEL"):
+        pytest.skip("forced lane = stream kernels")
+    if kind == "lstm":
+        w = O.synth_lstm_weights(layers, hidden, seed=hidden + layers)
+        m = loader.CreateFromString(O.nam_json_lstm(layers, hidden, w), ".nam")
+        ora = O.OracleLSTM.from_nam(layers, hidden, w)
+    else:
+        j = O.synth_keras_gru(layers, hidden, seed=hidden + layers)
+        m = loader.CreateFromString(json.dumps(j), ".json")
+        ora = O.OracleGRU(j)
+    assert m is not None
+    x = O.signal_noise(333, 19)
+    y = np.concatenate([m.Process(x[i:i + 100]) for i in range(0, x.size, 100)])
+    assert np.all(np.isfinite(y))
+    assert O.rms(y - ora.process(x)) < 5e-6 * max(1.0, O.rms(y) * 10)
+
+
+def test_lstm_1x256_runs_in_real_time_for_64_streams(na, loader):
+    """1 MB of gate weights per model, streamed from L2 by four waves per stream: 64 streams x 128 samples inside the 2.67 ms the block lasts."""
+    import time
+    if os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_LSTM_LANE_KERNEL"):
+        pytest.skip("forced lane = stream kernels")
+    m = loader.CreateFromString(O.nam_json_lstm(1, 256, O.synth_lstm_weights(1, 256, seed=4)), ".nam")
+    b = na.Batch(0)
+    b.AddStreams(m, 64)
+    x = np.stack([O.signal_noise(128, 60 + s) for s in range(64)])
+    for _ in range(3):
+        b.Process(x)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        y = b.Process(x)
+    per_block = (time.perf_counter() - t0) / 10
+    assert np.all(np.isfinite(y))
+    assert per_block < 2.5e-3, per_block
+    b.close()
+
+
 @pytest.mark.parametrize("layers,hidden", [(1, 64), (2, 64), (1, 128)])
 def test_large_keras_gru_matches_oracle(na, loader, layers, hidden):
     import json

@@ -284,18 +284,27 @@ def test_lstm_shapes_accepted_or_rejected_at_load(na, tmp_path):
     """Any hidden size the reference's dynamic LSTM takes loads (runtime-shaped kernel); what has no kernel fails at load, with a reason."""
     loader = na.NeuralModelLoader()
     path = tmp_path / "m.nam"
-    for layers, hidden in ((1, 3), (1, 18), (3, 16), (2, 64), (3, 128)):  # (up to 128 units whatever the weight size: streamed from L2)
+    # (up to 1024 units whatever the weight size: streamed from L2, a workgroup of up to 16 waves per stream from 257 gate rows on)
+    for layers, hidden in ((1, 3), (1, 18), (3, 16), (2, 64), (3, 128), (2, 192), (1, 512)):
         path.write_text(O.nam_json_lstm(layers, hidden, O.synth_lstm_weights(layers, hidden, seed=hidden)))
         assert loader.CreateFromFile(str(path), doPrewarm=False) is not None
-    path.write_text(O.nam_json_lstm(2, 192, O.synth_lstm_weights(2, 192, seed=1)))
-    with pytest.raises(na.NeuralAudioError, match="LSTM 2x192 is not supported"):
+    path.write_text(O.nam_json_lstm(1, 1030, O.synth_lstm_weights(1, 1030, seed=1)))
+    with pytest.raises(na.NeuralAudioError, match="LSTM 1x1030 is not supported"):
         loader.CreateFromFile(str(path), doPrewarm=False)
     gru = tmp_path / "gru.json"
-    for layers, hidden in ((3, 16), (1, 96), (2, 128)):
+    for layers, hidden in ((3, 16), (1, 96), (2, 128), (1, 160)):
         gru.write_text(json.dumps(O.synth_keras_gru(layers, hidden, seed=3)))
-        assert loader.CreateFromFile(str(gru), doPrewarm=False) is not None  # any shape up to 128 units: runtime-shaped GRU kernel
-    gru.write_text(json.dumps(O.synth_keras_gru(1, 160, seed=3)))
-    with pytest.raises(na.NeuralAudioError, match="GRU 1x160 is not supported"):
+        assert loader.CreateFromFile(str(gru), doPrewarm=False) is not None  # any shape up to 1024 units: runtime-shaped GRU kernel
+    # a dense TAIL (more than the 1-unit head) behind a wide recurrent layer needs the [samples][units] buffer of the block in LDS:
+    # 2 x 400 x 64 floats do not fit
+    j = O.synth_keras_gru(1, 400, seed=3)
+    j["layers"][-1] = {"type": "dense", "activation": "tanh", "shape": [None, None, 4], "weights": [[[0.01] * 4] * 400, [0.0] * 4]}
+    j["layers"].append({"type": "dense", "activation": "", "shape": [None, None, 1], "weights": [[[0.5]] * 4, [0.0]]})
+    gru.write_text(json.dumps(j))
+    with pytest.raises(na.NeuralAudioError, match="GRU 1x400 is not supported"):
+        loader.CreateFromFile(str(gru), doPrewarm=False)
+    gru.write_text(json.dumps(O.synth_keras_gru(1, 1100, seed=3)))
+    with pytest.raises(na.NeuralAudioError, match="GRU 1x1100 is not supported"):
         loader.CreateFromFile(str(gru), doPrewarm=False)
 
 
