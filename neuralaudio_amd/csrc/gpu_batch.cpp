@@ -625,7 +625,7 @@ namespace na
 			{
 				// (a model with a specialised chain runs it for blocks of 128 / 64 / 32 frames, the interpreter for other lengths)
 				if (family == WN_FAMILY_SPLIT) return (dev.spec_arch != WN_SPEC_NONE && WaveNetSpecEnabled()) ? "WaveNetSpecKernel" : "WaveNetSplitKernel";
-				return family == WN_FAMILY_GENERIC ? "WaveNetGenericKernel" : "WaveNetFrameKernel";
+				return family == WN_FAMILY_GENERIC ? (plan.maxChannels > 64 ? "WaveNetWideKernel" : "WaveNetGenericKernel") : "WaveNetFrameKernel";
 			}
 
 			// Packed groups: the launch lists name VIRTUAL streams -- slot = member / pack -- and hold `pack` rows each (-1: no member in

@@ -117,8 +117,8 @@ namespace na
 	};
 	static_assert(sizeof(WnSplitStage) == 64, "split stage descriptors are 64-byte records");
 
-	constexpr int WN_GENERIC_MAX_CHANNELS = 64; // runtime-shaped block kernel (wavenet_generic_kernels.hip): channels per layer array
-	constexpr int WN_COL_STRIDE = 64;           // floats per ring in the steady-state column table
+	constexpr int WN_GENERIC_MAX_CHANNELS = 128; // runtime-shaped block kernels (wavenet_generic_kernels.hip): channels per layer array (65 .. 128: WaveNetWideKernel)
+	constexpr int WN_COL_STRIDE = 128;          // floats per ring in the steady-state column table
 
 	// Natural-layout tensor table used by the prewarm kernel and the runtime-shaped block kernel (one entry per conv ring).
 	struct WnPrewarmLayer

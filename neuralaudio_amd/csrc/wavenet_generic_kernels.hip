@@ -89,6 +89,7 @@ namespace na
 		struct MatRef
 		{
 			int off, cout, cin, nbo, nbk;
+			int ld = 0; // floats between rows (0: cin) -- a sub-matrix of a wider one
 		};
 		typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4))); // a 16-byte load from a 4-byte aligned address
 		template <int NB>
@@ -107,7 +108,7 @@ namespace na
 				const int lane = idx & 63, blk = idx >> 6, rb = blk / m.nbk, kb = blk % m.nbk;
 				const int o = 16 * rb + (lane & 15), c0 = 16 * kb + 4 * (lane >> 4);
 				const bool on = idx < m.nbo * m.nbk * 64 && o < m.cout;
-				const float* p = w + m.off + (size_t)o * m.cin + c0;
+				const float* p = w + m.off + (size_t)o * (m.ld ? m.ld : m.cin) + c0;
 				sp::f32x4 v = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 				if (on && c0 + 3 < m.cin)
 				{
@@ -490,6 +491,253 @@ namespace na
 				header[tid] = p;
 			}
 		}
+
+		// ------------------------------------------------------------------------------------------------------------------------------
+		// Layer arrays of 65 .. 128 channels (WaveNetDynamic.h:229-254 takes any width).  The split A operands of a 128 x 128 matrix are
+		// 128 KB, so a mat-mul runs as 64 x 64 sub-matrices -- output half oh, input half ih -- staged one at a time into the two operand
+		// buffers of the 64-channel kernel (2 x 32 KB), X[<= 32 groups][128] stays in LDS (64 KB), and the head accumulator, which a lane
+		// only ever touches at its own (frame, channel group) positions, lives in registers.  Same state format, same per-lane layouts,
+		// same arithmetic order per output as the kernel above; dense heads only.  No weight prefetch across mat-muls: a stage is load ->
+		// split -> commit -> barrier -> MFMA (the 64-channel kernel hides the load behind the previous mat-mul; here a 128-channel model is
+		// 4 x the matrix work of a 64-channel one and the loads are a smaller share).
+		template <int OCC>
+		__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(OCC))) WaveNetWideKernel(const Args a, const float* __restrict__ in, float* __restrict__ out,
+			long inStride, long outStride, int n)
+		{
+			constexpr int NB = 4, HB = 2; // 16-channel blocks per half, halves
+			extern __shared__ __attribute__((aligned(16))) float lds[];
+			const int GQ = (a.maxC + 3) / 4;
+			f32x4* X = reinterpret_cast<f32x4*>(lds); // [GQ][FRAMES]
+			constexpr int OPS_ONE = NB * NB * 2 * 64;
+			u32x4* ops0 = reinterpret_cast<u32x4*>(X + (size_t)GQ * FRAMES); // [2][NB * NB][2][64]
+			float* condL = reinterpret_cast<float*>(ops0 + 2 * OPS_ONE);    // [FRAMES]
+			int par = 0; // sub-mat-muls so far (workgroup-uniform)
+			const int tid = threadIdx.x;
+			const int f = tid & (FRAMES - 1), cq = tid >> 7;
+			const int lane = tid & 63, wave = tid >> 6;
+			const int j = lane & 15, q = lane >> 4, tf = 16 * wave + j;
+			const int sidx = blockIdx.x;
+			const int slot = a.slots ? a.slots[sidx] : a.slot0 + sidx;
+			const int row = a.slots ? a.rows[sidx] : a.row0 + sidx;
+			float* st = a.state + (size_t)slot * (size_t)a.stateF4 * 4;
+			f32x4* stq = reinterpret_cast<f32x4*>(st);
+			int* header = reinterpret_cast<int*>(st);
+			if (cq == 0) condL[f] = (f < n) ? in[(size_t)row * inStride + f] : 0.0f;
+			for (int g = cq; g < GQ; g += 4) X[g * FRAMES + f] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+			__syncthreads();
+			const float cond = condL[tf];
+			const float* __restrict__ w = a.w;
+			f32x4 head[HB][NB]; // the lane's head accumulator: group 16 h + 4 rb + q of frame tf (:772 headArray.SetZero())
+#pragma unroll
+			for (int h = 0; h < HB; h++)
+#pragma unroll
+				for (int rb = 0; rb < NB; rb++) head[h][rb] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+
+			// acc[rb] (rows 64 oh + 16 rb ..) += M[those rows][columns of half ih] * b[kb]; M row-major [cout x cin] at w[off]
+			auto subMatMul = [&](int off, int cout, int cin, int oh, int ih, const u32x4 (&b)[NB], sp::f32x4 (&acc)[NB]) {
+				const int co = min(64, cout - 64 * oh), ci = min(64, cin - 64 * ih);
+				if (co <= 0 || ci <= 0) return; // (workgroup-uniform)
+				const int nbo = (co + 15) / 16, nbk = (ci + 15) / 16;
+				u32x4* ops = ops0 + (par++ & 1) * OPS_ONE;
+				const MatRef m = { off + 64 * oh * cin + 64 * ih, co, ci, nbo, nbk, cin };
+				StagedRegs<NB> r;
+				StageLoad<NB>(r, w, m);
+				StageCommit<NB>(ops, r, m);
+				LdsBarrier(); // staged; and every wave is done with the mat-mul before the last, which read the OTHER buffer's predecessor
+				MatMul<NB>(ops, nbo, nbk, lane, b, acc);
+			};
+
+			for (int li = 0; li < a.numLayers; li++)
+			{
+				const WnPrewarmLayer L = a.layers[li];
+				if (L.kind == 0)
+				{
+					const int cin = L.cin; // == cout
+					const int Gl = (cin + 3) / 4, nh = (cin + 63) / 64;
+					if (L.rechannel >= 0)
+					{
+						if (li == 0 && L.rech_in == 1)
+						{
+#pragma unroll
+							for (int oh = 0; oh < HB; oh++)
+#pragma unroll
+								for (int rb = 0; rb < NB; rb++)
+								{
+									const int g = 16 * oh + 4 * rb + q;
+									if (g < Gl) X[g * FRAMES + tf] = Load4(w, L.rechannel, 4 * g, cin) * cond;
+								}
+						}
+						else
+						{
+							// from the previous array's output (in X): every lane reads and writes its own frame only
+							const int Gin = (L.rech_in + 3) / 4, nhi = (L.rech_in + 63) / 64;
+							__syncthreads();
+							u32x4 bq[HB][NB];
+#pragma unroll
+							for (int ih = 0; ih < HB; ih++)
+#pragma unroll
+								for (int kb = 0; kb < NB; kb++)
+								{
+									const int g = 16 * ih + 4 * kb + q;
+									bq[ih][kb] = (g < Gin) ? sp::SplitQuad(X[g * FRAMES + tf]) : u32x4{ 0, 0, 0, 0 };
+								}
+#pragma unroll
+							for (int oh = 0; oh < HB; oh++)
+							{
+								if (oh >= nh) break;
+								sp::f32x4 acc[NB];
+#pragma unroll
+								for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+								for (int ih = 0; ih < HB; ih++)
+									if (ih < nhi) subMatMul(L.rechannel, cin, L.rech_in, oh, ih, bq[ih], acc);
+#pragma unroll
+								for (int rb = 0; rb < NB; rb++)
+								{
+									const int g = 16 * oh + 4 * rb + q;
+									if (g < Gl) X[g * FRAMES + tf] = acc[rb];
+								}
+							}
+							for (int g = Gl + cq; g < GQ; g += 4) X[g * FRAMES + f] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f }; // (a narrower array behind a wider one)
+						}
+					}
+					__syncthreads(); // X of every frame is complete
+					const int R = a.ringFrames[L.ring_id], G = a.ringG[L.ring_id], roff = a.ringOffF4[L.ring_id];
+					const int pos0 = header[L.ring_id];
+					{
+						int p = pos0 + f;
+						if (p >= R) p -= R;
+						if (f < n && f >= n - (R - FRAMES))
+							for (int g = cq; g < Gl; g += 4) stq[RingQuad(roff, G, p, g)] = X[g * FRAMES + f];
+					}
+					const int K = L.ksize;
+					u32x4 zq[HB][NB];
+#pragma unroll
+					for (int oh = 0; oh < HB; oh++)
+					{
+#pragma unroll
+						for (int rb = 0; rb < NB; rb++) zq[oh][rb] = u32x4{ 0, 0, 0, 0 };
+						if (oh >= nh) continue;
+						sp::f32x4 acc[NB];
+#pragma unroll
+						for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+						for (int k = 0; k < K; k++)
+						{
+							const int src = tf - L.dilation * (K - 1 - k); // tap k reads the frame d (K-1-k) back: X inside the block, the ring before it
+							int p = pos0 + src;
+							if (p < 0) p += R;
+#pragma unroll
+							for (int ih = 0; ih < HB; ih++)
+							{
+								if (ih >= nh) break;
+								u32x4 b[NB];
+#pragma unroll
+								for (int kb = 0; kb < NB; kb++)
+								{
+									const int g = 16 * ih + 4 * kb + q;
+									b[kb] = (g < Gl) ? sp::SplitQuad(src >= 0 ? X[g * FRAMES + src] : stq[RingQuad(roff, G, p, g)]) : u32x4{ 0, 0, 0, 0 };
+								}
+								subMatMul(L.wconv + k * cin * cin, cin, cin, oh, ih, b, acc);
+							}
+						}
+						// bias + mix-in, activation, head accumulate (:288-289, :471-482): in the lanes that hold the results
+#pragma unroll
+						for (int rb = 0; rb < NB; rb++)
+						{
+							const int g = 16 * oh + 4 * rb + q;
+							if (g < Gl)
+							{
+								const f32x4 bc = Load4(w, L.bconv, 4 * g, cin), wm = Load4(w, L.wmix, 4 * g, cin);
+								f32x4 zv;
+								zv.x = (4 * g + 0 < cin) ? Activate(acc[rb].x + bc.x + wm.x * cond, L.act) : 0.0f;
+								zv.y = (4 * g + 1 < cin) ? Activate(acc[rb].y + bc.y + wm.y * cond, L.act) : 0.0f;
+								zv.z = (4 * g + 2 < cin) ? Activate(acc[rb].z + bc.z + wm.z * cond, L.act) : 0.0f;
+								zv.w = (4 * g + 3 < cin) ? Activate(acc[rb].w + bc.w + wm.w * cond, L.act) : 0.0f;
+								head[oh][rb] += zv;
+								zq[oh][rb] = sp::SplitQuad(sp::f32x4{ zv.x, zv.y, zv.z, zv.w });
+							}
+						}
+					}
+					// 1x1 + bias + residual (:486-491): every wave is past its taps (the barriers of the 1x1's own stages), X may change
+#pragma unroll
+					for (int oh = 0; oh < HB; oh++)
+					{
+						if (oh >= nh) break;
+						sp::f32x4 acc[NB];
+#pragma unroll
+						for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+						for (int ih = 0; ih < HB; ih++)
+							if (ih < nh) subMatMul(L.w1, cin, cin, oh, ih, zq[ih], acc);
+#pragma unroll
+						for (int rb = 0; rb < NB; rb++)
+						{
+							const int g = 16 * oh + 4 * rb + q;
+							if (g < Gl)
+							{
+								const f32x4 b1 = Load4(w, L.b1, 4 * g, cin);
+								X[g * FRAMES + tf] += f32x4{ acc[rb].x + b1.x, acc[rb].y + b1.y, acc[rb].z + b1.z, acc[rb].w + b1.w };
+							}
+						}
+					}
+				}
+				else
+				{
+					// head rechannel (:658-660), dense (K = 1): the next array's head accumulator (:785-789) or, for the last array, the output
+					const bool last = (li == a.numLayers - 1);
+					const int Gin = (L.cin + 3) / 4, Gout = (L.cout + 3) / 4, nhi = (L.cin + 63) / 64, nho = (L.cout + 63) / 64;
+					u32x4 bq[HB][NB];
+#pragma unroll
+					for (int ih = 0; ih < HB; ih++)
+#pragma unroll
+						for (int kb = 0; kb < NB; kb++)
+							bq[ih][kb] = (16 * ih + 4 * kb + q < Gin) ? sp::SplitQuad(sp::f32x4{ head[ih][kb].x, head[ih][kb].y, head[ih][kb].z, head[ih][kb].w }) : u32x4{ 0, 0, 0, 0 };
+#pragma unroll
+					for (int oh = 0; oh < HB; oh++)
+					{
+						sp::f32x4 acc[NB];
+#pragma unroll
+						for (int rb = 0; rb < NB; rb++) acc[rb] = sp::f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+						if (oh < nho)
+						{
+#pragma unroll
+							for (int ih = 0; ih < HB; ih++)
+								if (ih < nhi) subMatMul(L.wconv, L.cout, L.cin, oh, ih, bq[ih], acc);
+						}
+						if (last)
+						{
+							if (oh == 0 && q == 0 && tf < n) out[(size_t)row * outStride + tf] = a.headScale * (acc[0].x + ((L.bconv >= 0) ? w[L.bconv] : 0.0f)); // :793-798
+						}
+						else
+						{
+#pragma unroll
+							for (int rb = 0; rb < NB; rb++)
+							{
+								const int g = 16 * oh + 4 * rb + q;
+								f32x4 v = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+								if (oh < nho && g < Gout)
+								{
+									const f32x4 bb = (L.bconv >= 0) ? Load4(w, L.bconv, 4 * g, L.cout) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+									v = f32x4{ acc[rb].x + bb.x, acc[rb].y + bb.y, acc[rb].z + bb.z, acc[rb].w + bb.w };
+									if (4 * g + 1 >= L.cout) v.y = 0.0f;
+									if (4 * g + 2 >= L.cout) v.z = 0.0f;
+									if (4 * g + 3 >= L.cout) v.w = 0.0f;
+								}
+								head[oh][rb] = v;
+							}
+						}
+					}
+				}
+			}
+			__syncthreads();
+			if (tid < a.nrings)
+			{
+				const int R = a.ringFrames[tid];
+				int p = header[tid] + n;
+				if (p >= R) p -= R;
+				header[tid] = p;
+			}
+		}
 	}
 
 	hipError_t LaunchWaveNetGeneric(const WnPrewarmLayer* layers, int numLayers, const float* weights, const int* ringOffF4, const int* ringFrames,
@@ -514,6 +762,15 @@ namespace na
 		a.rows = rows;
 		a.slot0 = slot0;
 		a.row0 = row0;
+		if (maxChannels > 64)
+		{
+			// 65 .. 128 channels: X + two 64 x 64 operand buffers + the condition row (128 channels: 64 + 64 KB)
+			const size_t wideBytes = (size_t)((maxChannels + 3) / 4) * gn::FRAMES * 16 + (size_t)2 * 4 * 4 * 2 * 64 * 16 + gn::FRAMES * sizeof(float);
+			static PerDeviceOnce attrWide;
+			(void)attrWide.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&gn::WaveNetWideKernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+			hipLaunchKernelGGL((gn::WaveNetWideKernel<2>), dim3((unsigned)numStreams), dim3(gn::NTHREADS), wideBytes, stream, a, in, out, inStride, outStride, n);
+			return hipGetLastError();
+		}
 		// LDS: two [G][128] float4 arrays + the split A operands of two matrices ([nb x nb][hi, lo][64] x 16 B each) + the condition row
 		// (64 channels: 64 + 64 KB, 48 channels: 48 + 36 KB, 32 channels: 32 + 16 KB -> three workgroups per CU)
 		const int nb = (maxChannels + 15) / 16, gq = (maxChannels + 3) / 4;

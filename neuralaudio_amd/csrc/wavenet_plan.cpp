@@ -58,7 +58,9 @@ namespace na
 			const WnArrayCfg& cfg = desc.arrays[a];
 			if (cfg.channels < 1 || cfg.headSize < 1 || cfg.inputSize < 1) throw std::runtime_error("WaveNet layer array with a zero-sized dimension");
 			if (cfg.channels > WN_GENERIC_MAX_CHANNELS || cfg.headSize > WN_GENERIC_MAX_CHANNELS || cfg.inputSize > WN_GENERIC_MAX_CHANNELS)
-				throw std::runtime_error("WaveNet channels > 64 are not supported");
+				throw std::runtime_error("WaveNet channels > 128 are not supported");
+			if (cfg.headKernelSize > 1 && (cfg.channels > 64 || cfg.headSize > 64))
+				throw std::runtime_error("WaveNet: a conv head on a layer array wider than 64 channels is not supported");
 			if (cfg.conditionSize != 1) throw std::runtime_error("WaveNet condition_size != 1 is not supported");
 			if (cfg.kernelSizes.size() != cfg.dilations.size() || cfg.kernelSizes.empty())
 				throw std::runtime_error("WaveNet kernel_sizes/dilations mismatch");

@@ -26,13 +26,13 @@ namespace na
 
 	// ------------------------------------------------------------------------------------------
 	// Prewarm (WaveNet.h:746-766): zero-input steady state.  Every layer input is a constant column
-	// that depends only on the weights, so it is computed once per MODEL by one wave (lane = channel),
+	// that depends only on the weights, so it is computed once per MODEL by one small workgroup (thread = channel),
 	// in the reference's natural weight layout, then broadcast into every stream's rings.
 	// ------------------------------------------------------------------------------------------
-	__global__ void __launch_bounds__(64) WaveNetPrewarmColumnsKernel(const WnPrewarmLayer* __restrict__ layers, int numLayers,
+	__global__ void __launch_bounds__(WN_COL_STRIDE) WaveNetPrewarmColumnsKernel(const WnPrewarmLayer* __restrict__ layers, int numLayers,
 		const float* __restrict__ w, float* __restrict__ cols /* [ring][WN_COL_STRIDE] */)
 	{
-		constexpr int CW = WN_COL_STRIDE; // 64 = one lane per channel
+		constexpr int CW = WN_COL_STRIDE; // 128 = one thread per channel
 		__shared__ float x[CW], z[CW], head[CW], lin[CW];
 		const int i = threadIdx.x;
 		x[i] = 0.0f; z[i] = 0.0f; head[i] = 0.0f; lin[i] = 0.0f; // condition = 0 (:748), headArray zero (:750)
@@ -146,7 +146,7 @@ namespace na
 	hipError_t LaunchWaveNetPrewarmColumns(const WnPrewarmLayer* layers, int numLayers, const float* weights, float* cols,
 		hipStream_t stream)
 	{
-		hipLaunchKernelGGL(WaveNetPrewarmColumnsKernel, dim3(1), dim3(64), 0, stream, layers, numLayers, weights, cols);
+		hipLaunchKernelGGL(WaveNetPrewarmColumnsKernel, dim3(1), dim3(WN_COL_STRIDE), 0, stream, layers, numLayers, weights, cols);
 		return hipGetLastError();
 	}
 

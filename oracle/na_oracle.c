@@ -182,7 +182,7 @@ static const float* dense_set_weights(dense* d, const float* it)
 static void dense_process(const dense* d, const float* in, float* out, int frames, int acc)
 {
 	const int cin = d->cin, cout = d->cout;
-	float tmp[64];
+	float tmp[cout > 0 ? cout : 1]; /* (any width: the dynamic engine takes layer arrays wider than 64 channels) */
 	for (int f = 0; f < frames; f++) {
 		const float* x = in + (size_t)f * cin;
 		float* o = out + (size_t)f * cout;

@@ -240,6 +240,54 @@ def test_wavenet_wider_than_16_channels_matches_oracle(na, loader, channels, hea
     assert np.max(np.abs(y2 - y)) < 1e-6
 
 
+@pytest.mark.parametrize("channels,head,act", [(80, 72, O.ACT_TANH), (100, 50, O.ACT_TANH), (128, 64, O.ACT_TANH), (128, 128, O.ACT_LEAKYRELU), (66, 3, O.ACT_TANH)])
+def test_wavenet_of_65_to_128_channels_matches_oracle(na, loader, channels, head, act):
+    """WaveNetDynamic.h:229-254 takes any width; layer arrays of 65 .. 128 channels run on WaveNetWideKernel (64 x 64 sub-matrices through
+    the matrix pipe, head accumulator in registers): parity vs the oracle with a second array that rechannels from the wide one, chunk
+    invariance, a prewarmed start, several streams per batch."""
+    arrays = [dict(input_size=1, condition_size=1, head_size=head, head_kernel_size=1, head_dilation=1, channels=channels, has_head_bias=False,
+                   activation=act, kernel_sizes=[3, 3, 2, 3], dilations=[1, 7, 64, 200]),
+              dict(input_size=channels, condition_size=1, head_size=1, head_kernel_size=1, head_dilation=1, channels=head, has_head_bias=True,
+                   activation=act, kernel_sizes=[3, 5], dilations=[3, 40])]
+    w = O.synth_wavenet_weights(arrays, seed=channels)
+    m = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam")
+    assert m is not None
+    x = O.signal_noise(700, 5)
+    y = np.concatenate([m.Process(x[i:i + 128]) for i in range(0, x.size, 128)])
+    yo = O.OracleWaveNet(arrays, w).process(x)
+    assert O.rms(yo) > 1e-5 and O.rms(y - yo) < 2e-6 * max(1.0, O.rms(yo)), (channels, O.rms(y - yo), O.rms(yo))
+    m2 = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, w), ".nam")
+    y2 = np.concatenate([m2.Process(x[i:i + 37]) for i in range(0, x.size, 37)])
+    assert np.max(np.abs(y2 - y)) < 1e-6 * max(1.0, float(np.abs(y).max()))
+    b = na.Batch(0)
+    b.AddStreams(m, 5)
+    xs = np.stack([O.signal_noise(256, 70 + s) for s in range(5)])
+    ys = np.concatenate([b.Process(xs[:, :128]), b.Process(xs[:, 128:])], axis=1)
+    assert b.StreamKernelName(0) == "WaveNetWideKernel"
+    for s_ in (0, 4):
+        assert O.rms(ys[s_] - O.OracleWaveNet(arrays, w).process(xs[s_])) < 2e-6 * max(1.0, O.rms(yo))
+    b.close()
+
+
+def test_128_channel_wavenet_runs_in_real_time_for_64_streams(na, loader):
+    import time
+    arrays = [dict(input_size=1, condition_size=1, head_size=1, head_kernel_size=1, head_dilation=1, channels=128, has_head_bias=True,
+                   activation=O.ACT_TANH, kernel_sizes=[3] * 10, dilations=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512])]
+    m = loader.CreateFromString(O.nam_json_wavenet_generic(arrays, O.synth_wavenet_weights(arrays, seed=1)), ".nam", doPrewarm=False)
+    b = na.Batch(0)
+    b.AddStreams(m, 64)
+    x = np.stack([O.signal_noise(128, 60 + s) for s in range(64)])
+    for _ in range(3):
+        b.Process(x)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        y = b.Process(x)
+    per_block = (time.perf_counter() - t0) / 10
+    assert np.all(np.isfinite(y))
+    assert per_block < 2.5e-3, per_block  # the block lasts 2.667 ms at 48 kHz
+    b.close()
+
+
 @pytest.mark.parametrize("channels,act", [(24, O.ACT_LEAKYRELU), (40, O.ACT_TANH), (64, O.ACT_LEAKYRELU)])
 def test_wide_wavenet_with_a_conv_head_matches_oracle(na, loader, channels, act):
     """A single wide layer array with an A2-style conv head (kernel 16, bias; the head accumulator keeps its own history ring): the

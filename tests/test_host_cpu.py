@@ -258,8 +258,15 @@ def test_missing_and_malformed_files(na, tmp_path):
     short.write_text(O.nam_json_wavenet_generic(arr, O.synth_wavenet_weights(arr, seed=2)))
     assert loader.CreateFromFile(str(short), doPrewarm=False) is not None  # > 16 channels: the runtime-shaped kernel (WaveNetDynamic.h)
     arr = [dict(O.a1_arrays(4, 2)[0], channels=80, head_size=1)]
+    short.write_text(O.nam_json_wavenet_generic(arr, O.synth_wavenet_weights(arr, seed=2)))
+    assert loader.CreateFromFile(str(short), doPrewarm=False) is not None  # 65 .. 128 channels: WaveNetWideKernel
+    arr = [dict(O.a1_arrays(4, 2)[0], channels=144, head_size=1)]
     short.write_text(O.nam_json_wavenet_generic(arr, [0.0]))
-    with pytest.raises(na.NeuralAudioError, match="channels > 64"):  # kernel limits are load-time errors too
+    with pytest.raises(na.NeuralAudioError, match="channels > 128"):  # kernel limits are load-time errors too
+        loader.CreateFromFile(str(short), doPrewarm=False)
+    arr = [dict(O.a1_arrays(4, 2)[0], channels=80, head_size=1, head_kernel_size=4)]
+    short.write_text(O.nam_json_wavenet_generic(arr, [0.0]))
+    with pytest.raises(na.NeuralAudioError, match="conv head on a layer array wider than 64"):
         loader.CreateFromFile(str(short), doPrewarm=False)
     conv = tmp_path / "conv.json"
     conv.write_text(json.dumps({"in_shape": [None, None, 1], "layers": [{"type": "conv1d", "shape": [None, None, 8], "weights": []},
