@@ -17,7 +17,7 @@ namespace na
 	constexpr int LSTM_MAX_LAYERS = 8;
 	constexpr int LSTM_MAX_FRAMES = 128;
 	constexpr int LSTM_MAX_TAIL = 8;        // dense layers of a generic keras stack (after lowering: activation / batchnorm / prelu layers become dense ones)
-	constexpr int LSTM_MAX_TAIL_WIDTH = 64; // units per dense layer
+	constexpr int LSTM_MAX_TAIL_WIDTH = 256; // units per dense layer (two [width][64] scratch arrays in LDS: the shape predicates below check the fit)
 
 	enum { LSTM_CELL_LSTM = 0, LSTM_CELL_GRU = 1 };
 	enum { LSTM_MATH_FAST = 0, LSTM_MATH_STD = 1 };

@@ -200,7 +200,10 @@ def test_runtime_shaped_lstm_matches_oracle(na, loader, layers, hidden):
                                   # activation / batchnorm / prelu layers (lowered to dense layers at load, model_loader.cpp AppendKerasTailLayer)
                                   [("gru", 8), ("dense", 6), ("batchnorm", 6), ("activation", 6, "tanh"), ("dense", 1)],
                                   [("lstm", 8), ("prelu", 8), ("dense", 4), ("prelu", 4, "scalar"), ("batchnorm", 4, "noaffine"), ("dense", 1)],
-                                  [("dense", 8), ("activation", 8, "relu"), ("batchnorm", 8), ("dense", 1)]],
+                                  [("dense", 8), ("activation", 8, "relu"), ("batchnorm", 8), ("dense", 1)],
+                                  # dense layers wider than 64 units (round 4: up to 256)
+                                  [("lstm", 8), ("dense", 128, "tanh"), ("dense", 1)], [("dense", 200, "relu"), ("dense", 96, "tanh"), ("dense", 1)],
+                                  [("gru", 24), ("dense", 256, "sigmoid"), ("dense", 100), ("prelu", 100), ("dense", 1)]],
                          ids=lambda s: "-".join("%s%d%s" % (l[0], l[1], l[2] if len(l) > 2 else "") for l in s))
 def test_generic_keras_stack_matches_numpy_restatement(na, loader, spec):
     """Generic keras stacks (SURVEY 8 f3): the reference evaluates them with RTNeural, which is an absent submodule -- parity unpinned;

@@ -336,14 +336,16 @@ def test_generic_keras_stacks_accepted_or_rejected_at_load(na, tmp_path):
     with pytest.raises(na.NeuralAudioError, match="activation 'softmax' is not supported"):
         loader.CreateFromFile(str(path), doPrewarm=False)
     path.write_text(json.dumps(R.synth_keras_stack([("gru", 8), ("dense", 100, "tanh"), ("dense", 1)], seed=6)))
-    with pytest.raises(na.NeuralAudioError, match="wider than 64 units"):
+    assert loader.CreateFromFile(str(path), doPrewarm=False) is not None  # (dense layers up to 256 units since round 4)
+    path.write_text(json.dumps(R.synth_keras_stack([("gru", 8), ("dense", 300, "tanh"), ("dense", 1)], seed=6)))
+    with pytest.raises(na.NeuralAudioError, match="wider than 256 units"):
         loader.CreateFromFile(str(path), doPrewarm=False)
     mixed = R.synth_keras_stack([("gru", 8), ("lstm", 8), ("dense", 1)], seed=7)  # two kinds of recurrent layers: no kernel
     path.write_text(json.dumps(mixed))
     assert loader.CreateFromFile(str(path), doPrewarm=False) is None
-    wide = R.synth_keras_stack([("gru", 8), ("dense", 40), ("prelu", 40), ("dense", 1)], seed=9)  # relu(x) - alpha relu(-x): twice the width in between
+    wide = R.synth_keras_stack([("gru", 8), ("dense", 140), ("prelu", 140), ("dense", 1)], seed=9)  # relu(x) - alpha relu(-x): twice the width in between
     path.write_text(json.dumps(wide))
-    with pytest.raises(na.NeuralAudioError, match="prelu layer wider than 32 units"):
+    with pytest.raises(na.NeuralAudioError, match="prelu layer wider than 128 units"):
         loader.CreateFromFile(str(path), doPrewarm=False)
     conv = R.synth_keras_stack([("dense", 4, "tanh"), ("dense", 1)], seed=8)
     conv["layers"][0]["type"] = "conv1d"
