@@ -1440,7 +1440,7 @@ namespace na
 		// A batch on its own stream that nobody has seen: a buffer of one contiguous WaveNet group runs as two free-running half-batch
 		// launches (the order of work on the internal streams is not observable from outside; Synchronize() and the host-buffer entry
 		// points wait for all of them).  1024 x A1 Standard x 128 frames: 40.1 -> 37.4 us per step.
-		if (ownsStream && !streamObserved && !pipelineUsed)
+		if (ownsStream && !streamObserved)
 		{
 			if (PrepareHalves(n))
 			{
@@ -1879,6 +1879,7 @@ namespace na
 		// the round-2 path cost 2 more waits and 2 more records on the compute stream, 15 us per buffer (tools/microbench/host_pipe_probe.cpp).
 		if (LaunchUnitsAfterSwitch(nullptr, nullptr) <= 1)
 		{
+			JoinHalves(); // (device-pointer steps may have run as half-batch chains: this buffer's kernel comes after both)
 			if (!p.own) CheckHip(hipStreamCreateWithFlags(&p.own, hipStreamNonBlocking), "hipStreamCreate");
 			bool listsChanged = false, dirty = false;
 			for (auto& g : groups) dirty = dirty || (g->NumActive() > 0 && g->ListsDirty());

@@ -496,6 +496,86 @@ def test_mixed_and_packed_batches_run_as_free_running_halves_too(na, loader):
     b.close()
 
 
+@pytest.mark.parametrize("kind", ["standard", "a2", "narrow"])
+def test_random_joins_leaves_switches_between_free_running_steps_match_ordered_launches(na, loader, kind):
+    """Seeded random walks over a batch large enough for the half-batch chains: streams leave and join (ids and state slots recycled,
+    index lists re-uploaded), A2 streams switch quality, a stream is re-prewarmed, host-buffer calls and pipelined submissions are
+    mixed in -- between device-pointer steps that run as two free-running chains.  Every step must be bit for bit what a batch on a
+    caller's stream (ordered launches) produces under the same operations."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng({"standard": 11, "a2": 12, "narrow": 13}[kind])
+    if kind == "standard":
+        parts = [(loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=False), 700)]
+    elif kind == "a2":
+        parts = [(loader.CreateFromFile(_path("BossWN-a2.nam"), doPrewarm=False), 1300)]
+    else:
+        parts = [(loader.CreateFromFile(_path("BossWN-feather.nam"), doPrewarm=False), 900), (loader.CreateFromFile(_path("BossWN-nano.nam"), doPrewarm=False), 1500)]
+    ts = torch.cuda.Stream(device=dev)
+    ref, b = na.Batch(0, hip_stream=ts.cuda_stream), na.Batch(0)
+    for bb in (ref, b):
+        for m, count in parts:
+            bb.AddStreams(m, count, quality=1.0)
+    n, cap = 128, sum(c for _, c in parts) + 64
+    g = torch.Generator(device="cpu").manual_seed(3)
+    halves_seen = 0
+    for step in range(14):
+        op = int(rng.integers(0, 7))
+        rows = ref.NumStreams()
+        live = [s for s in range(rows) if ref.IsLive(s)]
+        if op == 0 and len(live) > 600:
+            first = int(rng.choice(live[:-4]))
+            cnt = 1 + int(rng.integers(0, 3))
+            if all(ref.IsLive(s) for s in range(first, first + cnt)):
+                for bb in (ref, b):
+                    bb.RemoveStreams(first, cnt)
+        elif op == 1 and rows < cap - 8:
+            m = parts[int(rng.integers(0, len(parts)))][0]
+            cnt = 1 + int(rng.integers(0, 4))
+            assert ref.AddStreams(m, cnt, quality=1.0) == b.AddStreams(m, cnt, quality=1.0)
+        elif op == 2 and kind == "a2":
+            for s_ in rng.choice(live, size=40, replace=False):
+                q = float(rng.integers(0, 2))
+                for bb in (ref, b):
+                    bb.SetQuality(int(s_), q)
+        elif op == 3:
+            s_ = int(rng.choice(live))
+            for bb in (ref, b):
+                bb.Prewarm(s_)
+        rows = ref.NumStreams()
+        assert rows == b.NumStreams()
+        x = torch.clamp(0.3 * torch.randn(rows, n, generator=g), -1.0, 1.0)
+        if op == 4:  # a blocking host-buffer call
+            want, got = ref.Process(x.numpy()), b.Process(x.numpy())
+            assert np.array_equal(want, got), (kind, step, "Process")
+            continue
+        if op == 5:  # two pipelined submissions in place
+            xa, xb = x.numpy(), np.ascontiguousarray(x.numpy()[:, ::-1])
+            outs = []
+            for bb in (ref, b):
+                bb.NextInput(n)[:] = xa
+                t1 = bb.SubmitInput(n)
+                bb.NextInput(n)[:] = xb
+                t2 = bb.SubmitInput(n)
+                outs.append((bb.Collect(t1), bb.Collect(t2)))
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (kind, step, "Submit")
+            continue
+        xd = x.to(dev)
+        want, got = torch.zeros(rows, n, device=dev), torch.zeros(rows, n, device=dev)
+        torch.cuda.synchronize(dev)
+        ref.ProcessDevice(xd.data_ptr(), want.data_ptr(), n)
+        b.ProcessDevice(xd.data_ptr(), got.data_ptr(), n)
+        halves_seen += int(b.UsesHalfLaunches())
+        ref.Synchronize()
+        b.Synchronize()
+        assert torch.equal(want, got), (kind, step, op)
+    assert not ref.UsesHalfLaunches()
+    if not any(os.environ.get(k) for k in ("NA_WN_KERNEL", "NA_WN_SPEC", "NA_WN_PACK", "NA_HOST_HALVES", "NA_HOST_DIRECT", "NA_SP_T", "NA_SP_GEN")):
+        assert halves_seen >= 3, halves_seen
+    ref.close()
+    b.close()
+
+
 def test_quality_switch_every_buffer_2048_a2_streams_is_cheap(na, loader):
     """BASELINE configs[4] size on one GPU (2048 A2 streams): flipping the quality of HALF the streams before EVERY buffer must stay a
     real-time operation -- the active-stream lists travel from pinned memory asynchronously, nothing is allocated, synchronised or
