@@ -401,19 +401,23 @@ def main():
     # put an extra timestamp packet between every two launches and stretch the very gaps it measures).  When a step is two free-running
     # half-batch launches (launches_per_step 2) the two chains overlap: rocprofv3's per-launch average is then the duration of ONE half
     # launch running beside the other chain (~ the step time), the step time is what the roofline is reported on.
+    batch.MarkTime(0)  # (dry run: the marks' events are created on first use -- 90 us that do not belong to the K steps)
+    batch.MarkTime(1)
     nd.barrier()
     torch.cuda.synchronize(dev)
+    batch.MarkTime(0)  # on the idle streams: the span below starts here
     t0 = time.perf_counter()
-    batch.MarkTime(0)
     for i in range(args.steps):
         step(i)
     batch.MarkTime(1)
-    batch.Synchronize()
-    torch.cuda.synchronize(dev)
-    nd.barrier()
-    torch.cuda.synchronize(dev)
+    marks_ms = batch.ElapsedMs()  # polls the closing marks of every launch stream, then ...
+    torch.cuda.synchronize(dev)   # ... device-wide: nothing of the K steps is left anywhere
+    if world > 1:
+        nd.barrier()
+        torch.cuda.synchronize(dev)
     elapsed = nd.max_over_ranks(time.perf_counter() - t0, device=dev)
-    kernel_ms_avg = batch.ElapsedMs() / args.steps  # per STEP (one or two launches)
+    batch.Synchronize()  # (outside the timed region: the batch's own bookkeeping of its chains)
+    kernel_ms_avg = marks_ms / args.steps  # per STEP (one or two launches)
     launches_per_step = 2 if batch.UsesHalfLaunches() else 1
 
     # Parity spot check (outside the timed region, on what the timed region left behind): `y` holds the output of the LAST timed step.
