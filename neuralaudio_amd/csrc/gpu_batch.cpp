@@ -1274,9 +1274,14 @@ namespace na
 		// per 1024 x 128 Standard step); for rows in pinned host memory the half-size workgroups win (43.5-44.4 vs 45.1-46.2 us per buffer
 		// host to host: twice the workgroups keep more PCIe reads in flight)
 		const std::vector<WnFrameGroup>& part = halfLists->part[h];
+		// (trace builds, tools/trace_split_timeline.py: the traced workgroup index exists in every chain's launch -- only chain NA_TRACE_CHAIN stamps)
+		long long* const trace = GetWaveNetTraceBuffer();
+		static const int traceChain = getenv("NA_TRACE_CHAIN") ? atoi(getenv("NA_TRACE_CHAIN")) : 0;
+		if (trace != nullptr && h != traceChain) SetWaveNetTraceBuffer(nullptr);
 		if (!part.empty())
 			CheckHip(LaunchWaveNetSplitFused(part.data(), (int)part.size(), dIn, dOut, inStride, outStride, (int)n, halfStream[h], hostRows ? 1 : numChains),
 				"WaveNet kernel (half batch)");
+		if (trace != nullptr) SetWaveNetTraceBuffer(trace);
 	}
 
 	// the lists of PrepareHalves, each on its own stream; `done`: events to record

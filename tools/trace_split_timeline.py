@@ -14,7 +14,8 @@ dev = torch.device("cuda", 0)
 loader = na.NeuralModelLoader()
 model = loader.CreateFromFile(os.path.join(ROOT, "tests/golden/models", os.environ.get("NA_TRACE_MODEL", "BossWN-standard.nam")), doPrewarm=False)
 ts = torch.cuda.Stream(device=dev); torch.cuda.set_stream(ts)
-batch = na.Batch(0, hip_stream=ts.cuda_stream)
+# NA_TRACE_OWN=1: the batch on its own streams -- a step is two free-running half-batch launches, chain NA_TRACE_CHAIN (0) is stamped
+batch = na.Batch(0) if os.environ.get("NA_TRACE_OWN") else na.Batch(0, hip_stream=ts.cuda_stream)
 batch.AddStreams(model, S)
 x = torch.clamp(0.25 * torch.randn(S, n), -1, 1).to(dev); y = torch.empty_like(x)
 for _ in range(200):
@@ -23,7 +24,7 @@ torch.cuda.synchronize()
 nst, waves = int(os.environ.get("NA_TRACE_STAGES", "23")), int(os.environ.get("NA_TRACE_WAVES", "8"))  # waves per workgroup of the traced instantiation (SPB x WPS)
 trace = torch.zeros((nst + 1) * 8 * waves, dtype=torch.int64, device=dev)
 capi.load_library().NA_DebugSetTraceBuffer(trace.data_ptr())
-for _ in range(3):
+for _ in range(int(os.environ.get("NA_TRACE_STEPS", "3"))):
     batch.ProcessDevice(x.data_ptr(), y.data_ptr(), n)
 torch.cuda.synchronize()
 capi.load_library().NA_DebugSetTraceBuffer(None)
