@@ -1177,6 +1177,7 @@ namespace na
 	{
 		std::vector<WnFrameGroup> part[GpuBatch::kMaxChains];
 		bool listsUploaded = false; // an index list went to the device on the batch stream while the lists were built
+		bool compact = false;       // some group has compact rings: chunk lengths of WnCompactSafeFrames() only
 		// every part is a contiguous range of rows (no index lists, no packed streams): the host can stage and collect a half by itself
 		bool RowRangesOnly() const
 		{
@@ -1191,7 +1192,7 @@ namespace na
 	bool GpuBatch::PrepareHalves(size_t n)
 	{
 		static const bool off = getenv("NA_HOST_HALVES") != nullptr && atoi(getenv("NA_HOST_HALVES")) == 0; // tuning knob
-		if (off || n > (size_t)WN_MAX_FRAMES) return false;
+		if (off) return false;
 		bool dirty = false, packed = false, plain = false;
 		int active = 0;
 		for (const auto& g : groups)
@@ -1240,7 +1241,9 @@ namespace na
 			}
 		}
 		// (below 512 kernel-level streams a launch does not fill the chip anyway: nothing to overlap)
-		return total >= 512 && (size_t)NextWaveNetChunk(n, compact) == n;
+		hl.compact = compact;
+		(void)n; // (any buffer length: a chain runs the chunks of a long buffer one after the other, LaunchChain)
+		return total >= 512;
 	}
 
 	// the chains are about to take launches: whatever else is in flight for this batch comes first, and their streams exist
@@ -1279,8 +1282,18 @@ namespace na
 		static const int traceChain = getenv("NA_TRACE_CHAIN") ? atoi(getenv("NA_TRACE_CHAIN")) : 0;
 		if (trace != nullptr && h != traceChain) SetWaveNetTraceBuffer(nullptr);
 		if (!part.empty())
-			CheckHip(LaunchWaveNetSplitFused(part.data(), (int)part.size(), dIn, dOut, inStride, outStride, (int)n, halfStream[h], hostRows ? 1 : numChains),
-				"WaveNet kernel (half batch)");
+		{
+			// (a buffer longer than a launch takes: the chunks one after the other on this chain -- the chains still never wait for each other)
+			size_t offset = 0, left = n;
+			while (left > 0)
+			{
+				const int chunk = NextWaveNetChunk(left, halfLists->compact);
+				CheckHip(LaunchWaveNetSplitFused(part.data(), (int)part.size(), dIn + offset, dOut + offset, inStride, outStride, chunk, halfStream[h],
+					hostRows ? 1 : numChains), "WaveNet kernel (half batch)");
+				offset += (size_t)chunk;
+				left -= (size_t)chunk;
+			}
+		}
 		if (trace != nullptr) SetWaveNetTraceBuffer(trace);
 	}
 

@@ -321,7 +321,7 @@ def test_pipelined_submit_collect_matches_process(na, loader):
 def test_pipelined_half_chains_match_process_and_mix_with_the_other_entry_points(na, loader):
     """From 512 streams of one contiguous WaveNet group a submitted buffer runs as TWO launches of half the streams on two free-running
     HIP streams (gpu_batch.h halfStream): bit for bit what NA_BatchProcess gives, also with an odd stream count, ragged buffer
-    lengths (96 frames = two launches: not split), a synchronous call / a join / a leave between submissions, and three tickets in flight."""
+    lengths (96 frames = two launches per chain), a synchronous call / a join / a leave between submissions, and three tickets in flight."""
     m = loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=False)
     S, n = 1027, 128
     rng = np.random.default_rng(31)
@@ -353,7 +353,7 @@ def test_pipelined_half_chains_match_process_and_mix_with_the_other_entry_points
     assert np.array_equal(np.concatenate(got, axis=1), np.concatenate(want, axis=1))
     w, blk = step(4)  # a synchronous call between submissions (drains the half chains first)
     assert np.array_equal(b.Process(blk), w)
-    w, blk = step(5, 96)  # 96 frames = a 64- and a 32-frame launch: the batch stream path
+    w, blk = step(5, 96)  # 96 frames = a 64- and a 32-frame launch per chain
     assert np.array_equal(b.Collect(submit(blk)), w)
     w, blk = step(6)  # a copying submission between in-place ones
     t1 = submit(blk)
@@ -418,6 +418,32 @@ def test_device_pointer_steps_on_the_batch_own_streams_run_as_free_running_halve
     assert torch.equal(got[4:], want[4:])
     ref.close()
     b.close()
+
+
+def test_buffers_longer_than_a_launch_run_their_chunks_on_the_chains(na, loader):
+    """A buffer of 352 frames is 128 + 128 + 64 + 32: each chain runs its four launches one after the other, the chains never wait for
+    each other; 96 frames = 64 + 32, and the compact-ring models' safe lengths apply.  Bit for bit the ordered launches."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ts = torch.cuda.Stream(device=dev)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for name, S in (("BossWN-standard.nam", 600), ("BossWN-feather.nam", 1100)):
+        m = loader.CreateFromFile(_path(name), doPrewarm=False)
+        ref, b = na.Batch(0, hip_stream=ts.cuda_stream), na.Batch(0)
+        ref.AddStreams(m, S)
+        b.AddStreams(m, S)
+        for n in (352, 96, 128, 200, 17):
+            x = torch.clamp(0.3 * torch.randn(S, n, generator=g), -1.0, 1.0).to(dev)
+            want, got = torch.zeros(S, n, device=dev), torch.zeros(S, n, device=dev)
+            torch.cuda.synchronize(dev)
+            ref.ProcessDevice(x.data_ptr(), want.data_ptr(), n)
+            b.ProcessDevice(x.data_ptr(), got.data_ptr(), n)
+            assert _halves_as_expected(b) and not ref.UsesHalfLaunches()
+            ref.Synchronize()
+            b.Synchronize()
+            assert torch.equal(want, got), (name, n)
+        ref.close()
+        b.close()
 
 
 def _halves_as_expected(batch):
