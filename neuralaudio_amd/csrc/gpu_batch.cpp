@@ -1194,18 +1194,21 @@ namespace na
 		static const bool off = getenv("NA_HOST_HALVES") != nullptr && atoi(getenv("NA_HOST_HALVES")) == 0; // tuning knob
 		if (off) return false;
 		bool dirty = false, packed = false, plain = false;
-		int active = 0;
+		int active = 0, kernelStreams = 0;
 		for (const auto& g : groups)
 		{
-			if (g->NumActive() == 0) continue;
+			const int members = g->NumActive();
+			if (members == 0) continue;
 			const int c = g->LaunchClass(); // 1 / 2 / -1: the f16-split kernels' plain launch / packed launch / either (gpu_batch.cpp LaunchClass)
 			if (c != 1 && c != 2 && c != -1) return false;
 			packed = packed || c == 2;
 			plain = plain || c == 1;
 			dirty = dirty || g->ListsDirty();
+			kernelStreams += (members + g->PackFactor() - 1) / g->PackFactor();
 			active++;
 		}
 		if (active == 0 || active > WN_FRAME_MAX_GROUPS || (packed && plain)) return false; // (two launches per buffer: not split)
+		if (kernelStreams < 512) return false; // (a small batch: nothing below is worth its host time; the exact count is checked at the end)
 		// changed index lists are re-uploaded below (asynchronously, on the batch stream): nothing in flight may still read the old ones
 		if (dirty && (halfChainsUsed || pipelineUsed)) DrainPipeline();
 		if (!halfLists) halfLists.reset(new HalfLists());
