@@ -1065,23 +1065,30 @@ namespace na
 			cx.gs0 = PK ? ((ga.gps0 >> 1) & 3) : 0;
 			cx.gs1 = PK ? ((ga.gps1 >> 1) & 3) : 0;
 			long outRow[4];
+			int rowOf[4]; // PK: the rows of the (up to four) real streams of this virtual stream, -1: none
 #pragma unroll
 			for (int q = 0; q < 4; q++)
 			{
 				const int r = (PK && live && q < ga.pack) ? ga.rows[sidx * ga.pack + q] : -1;
+				rowOf[q] = r;
 				outRow[q] = r >= 0 ? (long)r * outStride : -1;
 			}
 
 			// input row (WaveNet.h:770 input -> condition) -> the aux operand of every frame
 			if constexpr (PK)
 			{
-				for (int q = 0; q < 4; q++)
+				// (the four rows' samples of a frame are loaded TOGETHER: one after the other -- row index, then sample, four times -- the
+				// prologue of a packed workgroup was eight dependent memory round trips, 6 500 cycles before stage 0 of Nano x 1024)
+				for (int i = wave * 64 + lane; i < FRAMES; i += C::WPS * 64)
 				{
-					const int r = (live && q < ga.pack) ? ga.rows[sidx * ga.pack + q] : -1;
-					for (int i = wave * 64 + lane; i < FRAMES; i += C::WPS * 64)
+					float c[4];
+#pragma unroll
+					for (int q = 0; q < 4; q++) c[q] = (rowOf[q] >= 0 && i < NF) ? in[(size_t)rowOf[q] * inStride + i] : 0.0f;
+#pragma unroll
+					for (int q = 0; q < 4; q++)
 					{
-						const float c = (r >= 0 && i < NF) ? ClampCond(in[(size_t)r * inStride + i], ga.condLimit) : 0.0f;
-						const _Float16 ch = (_Float16)c, cl = (_Float16)(c - (float)ch);
+						const float cc = ClampCond(c[q], ga.condLimit);
+						const _Float16 ch = (_Float16)cc, cl = (_Float16)(cc - (float)ch);
 						const f16x2 a = { ch, (_Float16)1.0f }, b = { cl, (_Float16)1.0f };
 						*reinterpret_cast<__attribute__((address_space(3))) u32x2*>((LdsPtr)(size_t)(unsigned)(C::AUX_OFF + ((sub * 4 + q) * FRAMES + i) * 8)) =
 							u32x2{ __builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b) };
