@@ -824,7 +824,7 @@ namespace na
 			constexpr int GP = C::TB::GPof(0), S = Geo<GP, C::T>::S;
 			SPK_STAMP(0, 0);
 			GuardStage<C, 0, GP>(cx, ln, 1);
-			Stager<C, 1, 0>::Begin(cx);
+			// (stage 1's operands were set out in the prologue, RunWorkgroup; this stage awaits them at its end)
 			const u32x4 ra = WOp<C>(cx, 0, 0, 0);
 #pragma unroll
 			for (int i = 0; i < S; i++)
@@ -1060,6 +1060,9 @@ namespace na
 			cx.nwaves = C::NTHREADS / 64;
 			if (cx.trace != nullptr && lane == 0) cx.trace[((C::TB::NSTAGES * 8 + 0) * cx.nwaves) + waveAll] = (long long)__builtin_readcyclecounter();
 #endif
+			// stage 1's operands set out NOW (LDS-DMA into the second weight buffer; stage 0 awaits them at its end, RechStage) rather than at
+			// the start of stage 0, whose own work is one MFMA (measured: 0.1 us per Standard step, noise level; kept)
+			Stager<C, 1, 0>::Begin(cx);
 			// packed: channel groups per real stream = (channels / pack) / 4 -> shift (1, 2, 4 -> 0, 1, 2)
 			const int pack = PK ? ga.pack : 1;
 			cx.gs0 = PK ? ((ga.gps0 >> 1) & 3) : 0;
