@@ -522,15 +522,16 @@ def test_mixed_and_packed_batches_run_as_free_running_halves_too(na, loader):
     b.close()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NA_CHAIN_WALK_SEEDS", "1"))))  # (soak runs: NA_CHAIN_WALK_SEEDS=16)
 @pytest.mark.parametrize("kind", ["standard", "a2", "narrow"])
-def test_random_joins_leaves_switches_between_free_running_steps_match_ordered_launches(na, loader, kind):
+def test_random_joins_leaves_switches_between_free_running_steps_match_ordered_launches(na, loader, kind, seed):
     """Seeded random walks over a batch large enough for the half-batch chains: streams leave and join (ids and state slots recycled,
     index lists re-uploaded), A2 streams switch quality, a stream is re-prewarmed, host-buffer calls and pipelined submissions are
     mixed in -- between device-pointer steps that run as two free-running chains.  Every step must be bit for bit what a batch on a
     caller's stream (ordered launches) produces under the same operations."""
     import torch
     dev = torch.device("cuda", 0)
-    rng = np.random.default_rng({"standard": 11, "a2": 12, "narrow": 13}[kind])
+    rng = np.random.default_rng({"standard": 11, "a2": 12, "narrow": 13}[kind] + 100 * seed)
     if kind == "standard":
         parts = [(loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=False), 700)]
     elif kind == "a2":
@@ -592,12 +593,12 @@ def test_random_joins_leaves_switches_between_free_running_steps_match_ordered_l
         ref.ProcessDevice(xd.data_ptr(), want.data_ptr(), n)
         b.ProcessDevice(xd.data_ptr(), got.data_ptr(), n)
         halves_seen += int(b.UsesHalfLaunches())
+        assert not ref.UsesHalfLaunches()  # (a device-pointer step on a caller's stream is always ordered)
         ref.Synchronize()
         b.Synchronize()
         assert torch.equal(want, got), (kind, step, op)
-    assert not ref.UsesHalfLaunches()
     if not any(os.environ.get(k) for k in ("NA_WN_KERNEL", "NA_WN_SPEC", "NA_WN_PACK", "NA_HOST_HALVES", "NA_HOST_DIRECT", "NA_SP_T", "NA_SP_GEN")):
-        assert halves_seen >= 3, halves_seen
+        assert halves_seen >= (3 if seed == 0 else 1), halves_seen
     ref.close()
     b.close()
 
