@@ -1131,6 +1131,10 @@ namespace na
 			DropTrailingRetiredRows();
 			throw;
 		}
+		// the half-batch chains' streams on this, the set-up side (creating a HIP stream takes ~13 ms: not inside the first buffer)
+		if (ownsStream && !streamObserved && streams.size() >= 512)
+			for (int h = 0; h < numChains; h++)
+				if (!halfStream[h]) CheckHip(hipStreamCreateWithFlags(&halfStream[h], hipStreamNonBlocking), "hipStreamCreate");
 		return first;
 	}
 
