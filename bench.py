@@ -410,12 +410,13 @@ def main():
     for i in range(args.steps):
         step(i)
     batch.MarkTime(1)
-    marks_ms = batch.ElapsedMs()  # polls the closing marks of every launch stream, then ...
-    torch.cuda.synchronize(dev)   # ... device-wide: nothing of the K steps is left anywhere
+    batch.WaitMarks()            # polls the closing marks of every launch stream, then ...
+    torch.cuda.synchronize(dev)  # ... device-wide: nothing of the K steps is left anywhere
     if world > 1:
         nd.barrier()
         torch.cuda.synchronize(dev)
     elapsed = nd.max_over_ranks(time.perf_counter() - t0, device=dev)
+    marks_ms = batch.ElapsedMs()
     batch.Synchronize()  # (outside the timed region: the batch's own bookkeeping of its chains)
     kernel_ms_avg = marks_ms / args.steps  # per STEP (one or two launches)
     launches_per_step = 2 if batch.UsesHalfLaunches() else 1

@@ -103,6 +103,7 @@ NA_EXTERN void* NA_BatchGetHipStream(NA_Batch* batch);
 /* Timing marks for benchmarks: HIP events recorded on EVERY stream the batch launches kernels on.  NA_BatchMarkTime(b, 0) ... launches ...
    NA_BatchMarkTime(b, 1); NA_BatchElapsedMs waits for the second mark and returns the longest mark-to-mark span over those streams (< 0: error). */
 NA_EXTERN int NA_BatchMarkTime(NA_Batch* batch, int which);
+NA_EXTERN int NA_BatchWaitMarks(NA_Batch* batch); /* polls until the second marks are reached on every stream */
 NA_EXTERN float NA_BatchElapsedMs(NA_Batch* batch);
 /* 1: the last NA_BatchProcessDevice call ran as two half-batch launches (see NA_BatchGetHipStream) */
 NA_EXTERN int NA_BatchUsesHalfLaunches(NA_Batch* batch);

@@ -316,6 +316,11 @@ class Batch:
         if self._lib.NA_BatchMarkTime(self._h, int(which)) != 0:
             raise NeuralAudioError(capi.last_error())
 
+    def WaitMarks(self):
+        """Polls until the marks of MarkTime(1) are reached on every stream the batch launches on."""
+        if self._lib.NA_BatchWaitMarks(self._h) != 0:
+            raise NeuralAudioError(capi.last_error())
+
     def ElapsedMs(self):
         ms = float(self._lib.NA_BatchElapsedMs(self._h))
         if ms < 0:

@@ -489,6 +489,12 @@ int NA_BatchMarkTime(NA_Batch* batch, int which)
 	return Guard([&] { batch->batch->MarkTime(which); });
 }
 
+int NA_BatchWaitMarks(NA_Batch* batch)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->WaitMarks(); });
+}
+
 float NA_BatchElapsedMs(NA_Batch* batch)
 {
 	if (!batch) return -1.0f;

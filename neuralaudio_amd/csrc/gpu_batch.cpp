@@ -1331,6 +1331,15 @@ namespace na
 		}
 	}
 
+	// polls the closing marks (a benchmark's closing wait should not pay the wake-up latency of a blocking synchronisation)
+	void GpuBatch::WaitMarks()
+	{
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		for (int i = 0; i <= kMaxChains; i++)
+			if (marks[i][0] && marks[i][1])
+				while (hipEventQuery(marks[i][1]) == hipErrorNotReady) {}
+	}
+
 	float GpuBatch::ElapsedMs()
 	{
 		CheckHip(hipSetDevice(device), "hipSetDevice");

@@ -133,6 +133,7 @@ namespace na
 		// Synchronize()).  The caller's own events only see the stream it handed in.
 		bool UsesHalfLaunches() const { return lastStepHalves; }
 		void MarkTime(int which);
+		void WaitMarks(); // polls until the marks of MarkTime(1) are reached on every stream
 		float ElapsedMs();
 		// The batch's HIP stream.  Handing it out makes the batch order every launch on it from then on: until then a batch that created
 		// its own stream may run a buffer as two free-running half-batch launches on internal streams (see halfStream below) -- nobody
