@@ -92,13 +92,33 @@ NA_EXTERN int NA_BatchCollect(NA_Batch* batch, int ticket, float* out);
  * result, valid until that slot is submitted again (3 submissions later). */
 NA_EXTERN float* NA_BatchNextInput(NA_Batch* batch, size_t n);
 NA_EXTERN const float* NA_BatchOutputView(NA_Batch* batch, int ticket);
-/* DEVICE pointers, row s = stream s, rows `stride` floats apart; asynchronous on the batch's stream */
+/* DEVICE pointers, row s = stream s, rows `stride` floats apart.  Two contracts, by who owns the stream:
+ *
+ * (a) the batch runs on a stream of the CALLER (NA_BatchCreate with a stream handle), or the caller has fetched the batch's own stream
+ *     (NA_BatchGetHipStream): every launch is ordered on that stream, like any HIP kernel launch -- a producer kernel enqueued on it
+ *     before the call and a consumer enqueued after it need no other synchronisation, and the call may be made from a device-side
+ *     pipeline without any host wait.
+ *
+ * (b) the batch created its own stream (hipStream == NULL) and nobody has fetched it: the library schedules the buffer itself -- as
+ *     two free-running launches of half the streams each on internal streams, or, for large A1 Standard batches, as a command to ONE
+ *     resident launch that stays on the chip and walks consecutive buffers (csrc/gpu_batch_chains.cpp) -- none of which is ordered
+ *     against any stream the caller knows.  The contract is then a HOST-side one:
+ *       - the input rows must be COMPLETE in device memory when NA_BatchProcessDevice is called (synchronise their producer first:
+ *         hipStreamSynchronize / hipEventSynchronize on its stream) and must stay untouched until the step's outputs are valid;
+ *       - the output rows are valid after NA_BatchWaitOutputs (cheap: the resident launch stays up) or NA_BatchSynchronize (everything
+ *         of the batch is idle, the resident launch has left the chip);
+ *       - a caller that re-uses ONE output buffer for consecutive steps can only ever read the rows of the last step it waited for: give
+ *         every step that is in flight its own output rows (up to 63 steps may be in flight; the call blocks beyond that);
+ *       - a device-side producer / consumer that must not wait on the host cannot use (b): create the batch on its stream, contract (a).
+ *     Inside the resident launch the rows are read and written at system scope, so a producer that ran on another stream / XCD between
+ *     two steps is seen without a kernel boundary (tests/test_gpu_resident.py: a producer kernel on a foreign stream rewrites the same
+ *     input buffer before every step). */
 NA_EXTERN int NA_BatchProcessDevice(NA_Batch* batch, const float* dIn, float* dOut, size_t n, long inStride, long outStride);
+/* every buffer handed to NA_BatchProcessDevice so far has been processed: its output rows are valid (host-side wait; contract (b)) */
+NA_EXTERN int NA_BatchWaitOutputs(NA_Batch* batch);
 NA_EXTERN int NA_BatchSynchronize(NA_Batch* batch);
-/* The batch's HIP stream.  A batch that created its own stream (NA_BatchCreate with hipStream == NULL) may, until this is first called,
-   run a buffer as two free-running launches of half its streams each on internal streams (1024 x A1 Standard x 128: 40.1 -> 37.4 us
-   per step) -- wait with NA_BatchSynchronize (or use the host-buffer entry points, which wait themselves).  After the first call, and on
-   a caller's stream, every launch is ordered on that stream. */
+/* The batch's HIP stream.  Fetching it switches a batch that created its own stream from contract (b) to contract (a) for good: the
+   internal launches are joined, and from then on every launch is ordered on this stream. */
 NA_EXTERN void* NA_BatchGetHipStream(NA_Batch* batch);
 /* Timing marks for benchmarks: HIP events recorded on EVERY stream the batch launches kernels on.  NA_BatchMarkTime(b, 0) ... launches ...
    NA_BatchMarkTime(b, 1); NA_BatchElapsedMs waits for the second mark and returns the longest mark-to-mark span over those streams (< 0: error). */
@@ -107,6 +127,8 @@ NA_EXTERN int NA_BatchWaitMarks(NA_Batch* batch); /* polls until the second mark
 NA_EXTERN float NA_BatchElapsedMs(NA_Batch* batch);
 /* 1: the last NA_BatchProcessDevice call ran as two half-batch launches (see NA_BatchGetHipStream) */
 NA_EXTERN int NA_BatchUsesHalfLaunches(NA_Batch* batch);
+/* 1: the last NA_BatchProcessDevice call was a command to the resident launch (contract (b) above; NA_RESIDENT=0 turns it off) */
+NA_EXTERN int NA_BatchUsesResidentLaunch(NA_Batch* batch);
 /* roofline bookkeeping (stream-weighted means): compulsory HBM bytes and multiply-accumulates per sample */
 NA_EXTERN double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames);
 NA_EXTERN double NA_BatchMacsPerSample(NA_Batch* batch);
@@ -177,6 +199,12 @@ NA_EXTERN void NA_DebugSetWaveNetSpec(int on);
  * environment NA_REC_QUAD_MIN); returns the previous value.  NA_DebugRecurrentQuadLaunches: launches of that kernel so far. */
 NA_EXTERN int NA_DebugSetRecurrentQuadMin(int streams);
 NA_EXTERN long long NA_DebugRecurrentQuadLaunches(void);
+/* Tests: which implementation of the NCCL entry points the multi-GPU host binds.  0 = librccl.so (the product).  1 = a loopback table
+ * inside this library (csrc/rccl_loopback.cpp): every rank may sit on the SAME device and a transfer is a device-to-device copy, so the
+ * multi-rank orchestration (communicators, weight fan-out, gathered fan-in, failure teardown) executes on a one-GPU box; it moves no
+ * byte over xGMI.  failSendAt > 0 makes the failSendAt-th ncclSend of the loopback table fail (fault injection), rendezvousMs > 0 is how
+ * long a loopback rank waits for a peer that never posts.  Set it while no multi batch is being committed. */
+NA_EXTERN void NA_DebugSetRcclApi(int mode, int failSendAt, int rendezvousMs);
 /* tuning aid: device buffer (long long[stages*4*waves]) that workgroup 0 of the WaveNet kernel stamps with the shader clock; NULL = off */
 NA_EXTERN void NA_DebugSetTraceBuffer(void* deviceBuffer);
 

@@ -46,6 +46,11 @@ def rccl_available():
     return bool(capi.load_library().NA_RcclAvailable())
 
 
+def debug_set_rccl_api(mode, fail_send_at=0, rendezvous_ms=0):
+    """Tests: 1 = the multi-GPU host binds the in-library loopback table (ranks may share a device) instead of librccl.so; 0 = back."""
+    capi.load_library().NA_DebugSetRcclApi(int(mode), int(fail_send_at), int(rendezvous_ms))
+
+
 def _fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -307,6 +312,15 @@ class Batch:
         if self._lib.NA_BatchSynchronize(self._h) != 0:
             raise NeuralAudioError(capi.last_error())
 
+    def WaitOutputs(self):
+        """Host-side wait until every buffer handed to ProcessDevice so far has been processed (the resident launch stays up)."""
+        if self._lib.NA_BatchWaitOutputs(self._h) != 0:
+            raise NeuralAudioError(capi.last_error())
+
+    def UsesResidentLaunch(self):
+        """True when the last ProcessDevice call was a command to the resident launch (own stream, >= 512 A1 Standard streams)."""
+        return bool(self._lib.NA_BatchUsesResidentLaunch(self._h))
+
     def GetHipStream(self):
         """The batch's HIP stream handle (int).  From the first call on every launch is ordered on it (see NA_BatchGetHipStream)."""
         return self._lib.NA_BatchGetHipStream(self._h)
@@ -412,6 +426,18 @@ class MultiBatch:
         if self._lib.NA_MultiProcess(self._h, _fptr(x), _fptr(y), x.shape[1]) != 0:
             raise NeuralAudioError(capi.last_error())
         return y
+
+    def GatheredOutput(self, shard, n):
+        """RCCL fan-in: the [streams][n] device buffer of the last Process() on `shard`'s GPU, copied to the host (tests)."""
+        ptr = self._lib.NA_MultiGatheredOutput(self._h, int(shard))
+        if not ptr:
+            raise NeuralAudioError("no gathered output (RCCL fan-in only, after Process)")
+        out = np.empty((self.NumStreams(), int(n)), dtype=np.float32)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        if hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 2) != 0:  # hipMemcpyDeviceToHost
+            raise NeuralAudioError("hipMemcpy of the gathered output failed")
+        return out
 
     def SetQuality(self, stream, q):
         if self._lib.NA_MultiSetQuality(self._h, int(stream), float(q)) != 0:

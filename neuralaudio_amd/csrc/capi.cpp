@@ -503,6 +503,13 @@ float NA_BatchElapsedMs(NA_Batch* batch)
 }
 
 int NA_BatchUsesHalfLaunches(NA_Batch* batch) { return batch && batch->batch->UsesHalfLaunches() ? 1 : 0; }
+int NA_BatchUsesResidentLaunch(NA_Batch* batch) { return batch && batch->batch->UsesResidentLaunch() ? 1 : 0; }
+
+int NA_BatchWaitOutputs(NA_Batch* batch)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->WaitOutputs(); });
+}
 
 double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames)
 {
@@ -670,6 +677,12 @@ int NA_RcclAvailable(void)
 		ok = 1;
 	});
 	return ok;
+}
+
+void NA_DebugSetRcclApi(int mode, int failSendAt, int rendezvousMs)
+{
+	na::rccl::LoopbackConfigure(failSendAt, rendezvousMs);
+	na::rccl::SetOverride(mode == 1 ? na::rccl::LoopbackApi() : nullptr);
 }
 
 int NA_MultiSetQuality(NA_MultiBatch* mb, int stream, float quality)

@@ -111,6 +111,13 @@ namespace na
 		// device copies of a model's weight tables (every group of the batch that runs one of `model`'s submodels, in submodel order):
 		// what the multi-GPU host replicates from the first device that holds the model (RCCL fan-out)
 		void WeightImages(const LoadedModel& model, std::vector<std::pair<void*, size_t>>& out) const;
+		// Weight fan-out (multi-GPU host): while SetPeerWeights(true), a model group created by AddStreams allocates its weight images
+		// without uploading them -- a peer device that holds the model sends them -- and the prewarm of its streams waits; WeightsArrived()
+		// says the images are in place (on this batch's stream): device-side derivations and the deferred prewarms run, the mode ends.
+		// Processing before WeightsArrived() is an error of the caller.
+		void SetPeerWeights(bool on) { peerWeights = on; }
+		bool AwaitsWeights() const { return !awaitingWeights.empty(); }
+		void WeightsArrived();
 
 		// Pipelined host-buffer interface: Submit() copies `in` ([streams][n], host) into a pinned slot and enqueues H2D (copy-in
 		// stream), the kernels (batch stream) and D2H (copy-out stream); Collect() waits for that slot and copies the result out.
@@ -128,10 +135,14 @@ namespace na
 		size_t SlotRows(int ticket) const { return (ticket >= 0 && ticket < kPipelineSlots) ? pipe[ticket].rows : 0; } // rows of that submission
 
 		void Synchronize();
+		// every buffer handed to ProcessDevice so far has been processed (host-side wait).  Unlike Synchronize() it leaves the resident
+		// launch on the chip; on a caller's / observed stream it is a synchronisation of that stream.
+		void WaitOutputs();
 		// Timing marks for bench.py (HIP events on EVERY stream this batch launches kernels on -- the batch stream and the two half-batch
 		// streams): MarkTime(0) ... launches ... MarkTime(1); ElapsedMs() = the longest mark-to-mark span over those streams (after a
 		// Synchronize()).  The caller's own events only see the stream it handed in.
 		bool UsesHalfLaunches() const { return lastStepHalves; }
+		bool UsesResidentLaunch() const { return lastStepResident; } // the last device-pointer buffer went through the resident launch
 		void MarkTime(int which);
 		void WaitMarks(); // polls until the marks of MarkTime(1) are reached on every stream
 		float ElapsedMs();
@@ -197,6 +208,9 @@ namespace na
 		unsigned long topologyVersion = 0;
 		std::vector<std::unique_ptr<ModelGroup>> groups;
 		std::vector<StreamRef> streams;
+		bool peerWeights = false;
+		std::vector<ModelGroup*> awaitingWeights;
+		std::vector<std::pair<ModelGroup*, std::vector<int>>> pendingPrewarm;
 
 		float* hostStage = nullptr; // pinned
 		float* devStage = nullptr;
@@ -231,6 +245,19 @@ namespace na
 		bool halfChainsUsed = false;
 		bool lastStepHalves = false; // the last device-pointer / submitted buffer ran as two half-batch launches
 		bool streamObserved = false; // GetStream() was called (or the stream is the caller's): launches are ordered on `stream`
+		// The resident launch (gpu_batch_chains.cpp): one launch that stays on the chip and walks consecutive buffers, fed through a command
+		// ring in pinned host memory -- for the batches the chains serve whose buffer is one launch of 128-frame A1 Standard blocks
+		struct ResidentState;
+		std::unique_ptr<ResidentState> residentState;
+		bool lastStepResident = false;
+		bool TryResident(const float* dIn, float* dOut, size_t n, long inStride, long outStride);
+		bool ResidentConfigure();
+		void ResidentEnsureRunning();
+		void ResidentExitAfterPosted();
+		void ResidentFinishMarked();
+		void DrainResident(); // every posted command has run, the launch is gone (called by everything that touches state or the batch stream)
+		// nothing of this batch is in flight anywhere: resident launch, half-batch chains, pipeline slots, the batch stream
+		void Quiesce();
 		struct HalfLists; // the two launch lists of the buffer (gpu_batch.cpp)
 		std::unique_ptr<HalfLists> halfLists;
 		bool PrepareHalves(size_t n);

@@ -12,6 +12,7 @@
 // the whole block, [x; h] broadcast from LDS, the z / r gates meet the c rows through LDS, the dense head is computed for
 // the whole block after the sample loop (same structure as LstmWaveKernel).
 #include "device_once.h"
+#include "tuning.h"
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
@@ -244,7 +245,7 @@ namespace na
 			if (LaunchRecurrentWaveRt(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
 			return LaunchGruGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 		}
-		static const bool noDpp = getenv("NA_GRU_NO_DPP") != nullptr; // tuning knob: the LDS-broadcast kernel for every shape
+		const bool noDpp = Tuning::Get().gruNoDpp; // tuning knob: the LDS-broadcast kernel for every shape
 		if (!noDpp && RecurrentDppSupported(m))
 		{
 			const RecurrentGroup g = { m, state, capacity, slots, rows, numStreams };

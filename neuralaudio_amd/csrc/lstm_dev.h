@@ -12,6 +12,8 @@
 
 #include <cstdlib>
 
+#include "tuning.h"
+
 namespace na
 {
 	constexpr int LSTM_MAX_LAYERS = 8;
@@ -39,7 +41,7 @@ namespace na
 	// block at four / two / one row per lane, LSTM 1x128 1.22 / 0.90 / 0.68; round 3, one wave: 2.0)
 	inline int RecurrentWaveWaves(int gateRows)
 	{
-		static const int rpl = getenv("NA_REC_RPL") ? atoi(getenv("NA_REC_RPL")) : 1; // tuning knob: gate rows per lane
+		const int rpl = Tuning::Get().recRpl; // tuning knob: gate rows per lane
 		int waves = 1;
 		while (waves < 16 && gateRows > 64 * rpl * waves) waves *= 2;
 		return waves;

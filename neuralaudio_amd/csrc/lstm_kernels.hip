@@ -6,6 +6,7 @@
 //   LSTMLayer::Process    NeuralAudio/LSTMDynamic.h:95-108 (same arithmetic, runtime shaped)
 //   FastMath Tanh/Sigmoid NeuralAudio/Activation.h:83-96
 #include "device_once.h"
+#include "tuning.h"
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
@@ -308,7 +309,7 @@ namespace na
 	static bool LaunchLstmWave(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err)
 	{
-		static const bool noDpp = getenv("NA_LSTM_NO_DPP") != nullptr; // tuning knob: fall back to the LDS-broadcast wave kernel
+		const bool noDpp = Tuning::Get().lstmNoDpp; // tuning knob: fall back to the LDS-broadcast wave kernel
 		if (!noDpp && RecurrentDppSupported(m))
 		{
 			const RecurrentGroup g = { m, state, capacity, slots, rows, numStreams };
@@ -458,7 +459,7 @@ namespace na
 	template <int MAXT>
 	__device__ __forceinline__ void RecurrentRtSync()
 	{
-		if (MAXT == 64) RecurrentRtSync<MAXT>();
+		if (MAXT == 64) LstmWaveSync(); // (one wave: LDS fence + wave barrier)
 		else __syncthreads();
 	}
 	template <int MAXT>
@@ -621,11 +622,11 @@ namespace na
 	bool LaunchRecurrentWaveRt(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err)
 	{
-		static const bool off = getenv("NA_LSTM_NO_WAVE_RT") != nullptr; // tuning knob / tests: the lane = stream kernels for every shape
+		const bool off = Tuning::Get().lstmNoWaveRt; // tuning knob / tests: the lane = stream kernels for every shape
 		if (off || m.hidden > RECURRENT_WAVE_MAX_HIDDEN || m.numLayers < 0 || (m.numLayers == 0 && m.tailLayers == 0)) return false;
 		size_t ldsBytes = RecurrentWaveRtLdsFloats(m) * sizeof(float);
 		// weights larger than the LDS (LSTM 2x64: 197 KB): streamed from L2, transposed for coalesced reads (NA_REC_L2W=1 forces the mode)
-		static const bool forceL2 = getenv("NA_REC_L2W") != nullptr && atoi(getenv("NA_REC_L2W")) != 0;
+		const bool forceL2 = Tuning::Get().recL2w;
 		const int l2w = (ldsBytes > 160 * 1024 || (forceL2 && m.numLayers > 0)) ? 1 : 0;
 		if (l2w)
 		{
@@ -788,7 +789,7 @@ namespace na
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > LSTM_MAX_FRAMES) return hipErrorInvalidValue;
 		{
-			static const bool forceLaneKernel = getenv("NA_LSTM_LANE_KERNEL") != nullptr; // tuning knob
+			const bool forceLaneKernel = Tuning::Get().lstmLaneKernel; // tuning knob
 			hipError_t err = hipSuccess;
 			if (!forceLaneKernel && m.tailLayers == 0 && LaunchLstmWave(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
 			if (!forceLaneKernel && LaunchRecurrentWaveRt(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;

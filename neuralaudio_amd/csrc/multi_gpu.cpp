@@ -157,19 +157,28 @@ namespace na
 		// pre-Commit state -- `committed` is set only when every non-empty range has a batch with exactly its rows.
 		try
 		{
-			Post([this](Shard& s) {
+			// RCCL fan-out: only the FIRST shard that runs a model uploads its weight images from the host; the others size theirs and
+			// receive the content over the communicator (ReplicateWeights), their streams' prewarm waits for it
+			const bool fanOut = fanIn == FanIn::Rccl;
+			for (size_t i = 0; i < shards.size(); i++) shards[i]->rank = (int)i;
+			Post([this, fanOut](Shard& s) {
 				if (s.end <= s.begin) return;
 				s.batch.reset(new GpuBatch(s.device));
 				int first = 0;
 				for (const Entry& e : entries)
 				{
 					const int a = std::max(first, s.begin), b = std::min(first + e.count, s.end);
-					if (b > a) s.batch->AddStreams(e.model, e.quality, b - a, e.prewarm, e.onDemand);
+					if (b > a)
+					{
+						s.batch->SetPeerWeights(fanOut && FirstHolderOf(e.model.get()) != s.rank);
+						s.batch->AddStreams(e.model, e.quality, b - a, e.prewarm, e.onDemand);
+					}
 					first += e.count;
 				}
+				s.batch->SetPeerWeights(false);
 			});
 			for (auto& sp : shards) CheckShard(*sp);
-			if (fanIn == FanIn::Rccl) InitRccl();
+			if (fanOut) InitRccl();
 		}
 		catch (...)
 		{
@@ -194,11 +203,12 @@ namespace na
 	void MultiGpuBatch::InitRccl()
 	{
 		std::string error;
-		nccl = rccl::Load(error);
+		nccl = rccl::Active(error);
 		if (!nccl) throw std::runtime_error(error);
-		for (size_t i = 0; i < devices.size(); i++)
-			for (size_t k = i + 1; k < devices.size(); k++)
-				if (devices[i] == devices[k]) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: RCCL fan-in needs one distinct device per shard");
+		if (!rccl::OverrideActive()) // (the loopback table of the one-GPU tests takes any device list)
+			for (size_t i = 0; i < devices.size(); i++)
+				for (size_t k = i + 1; k < devices.size(); k++)
+					if (devices[i] == devices[k]) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: RCCL fan-in needs one distinct device per shard");
 		for (auto& sp : shards)
 			if (sp->end <= sp->begin) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: RCCL fan-in needs at least one stream per shard");
 		std::vector<rccl::Comm> comms(devices.size(), nullptr);
@@ -211,56 +221,100 @@ namespace na
 		ReplicateWeights();
 	}
 
-	// Weight fan-out: for every model that more than one shard runs, the first of them sends its device copies of the weight tables to
-	// the others (ncclSend / ncclRecv, all transfers of a rank inside one group).  Every shard has already uploaded the same bytes from
-	// the host -- its constructor needs them to compute the prewarm columns before a communicator exists -- so this replaces N - 1
-	// host uploads' worth of content over xGMI rather than saving them; it is the path a device-resident model source would use.
+	// shards whose stream range meets an entry of `model`, ascending (the first one is the model's weight source)
+	std::vector<int> MultiGpuBatch::HoldersOf(const LoadedModel* model) const
+	{
+		std::vector<int> h;
+		int first = 0;
+		for (const Entry& e : entries)
+		{
+			if (e.model.get() == model)
+				for (size_t s = 0; s < shards.size(); s++)
+					if (std::max(first, shards[s]->begin) < std::min(first + e.count, shards[s]->end)) h.push_back((int)s);
+			first += e.count;
+		}
+		std::sort(h.begin(), h.end());
+		h.erase(std::unique(h.begin(), h.end()), h.end());
+		return h;
+	}
+
+	int MultiGpuBatch::FirstHolderOf(const LoadedModel* model) const
+	{
+		const std::vector<int> h = HoldersOf(model);
+		return h.empty() ? -1 : h.front();
+	}
+
+	// Weight fan-out: for every model that more than one shard runs, the first of them (the only one that uploaded the model's weight
+	// tables from the host, Commit) sends its device copies to the others (ncclSend / ncclRecv, all transfers of a rank inside one
+	// group); the receivers then derive what their constructors left open and run their deferred prewarms (GpuBatch::WeightsArrived).
+	// Everything that can fail is done BEFORE a rank opens its group, the ranks' image lists are compared on the host first (a rank
+	// that posted a different count or size would leave its peer waiting), and a group that was opened is always closed: a failure
+	// inside it is reported, never left as peers blocked in their transfers.
 	void MultiGpuBatch::ReplicateWeights()
 	{
-		const size_t numShards = shards.size();
-		// holders[e]: shards whose range meets entry e
-		std::vector<std::vector<int>> holders(entries.size());
+		std::vector<const LoadedModel*> models;
+		for (const Entry& e : entries)
+			if (std::find(models.begin(), models.end(), e.model.get()) == models.end()) models.push_back(e.model.get());
+		struct Plan
 		{
-			int first = 0;
-			for (size_t e = 0; e < entries.size(); e++)
-			{
-				for (size_t s = 0; s < numShards; s++)
-					if (std::max(first, shards[s]->begin) < std::min(first + entries[e].count, shards[s]->end)) holders[e].push_back((int)s);
-				first += entries[e].count;
-			}
+			std::vector<int> holders;
+			std::vector<std::vector<std::pair<void*, size_t>>> images; // per holder (same order)
+		};
+		std::vector<Plan> plans(models.size());
+		for (size_t m = 0; m < models.size(); m++)
+		{
+			plans[m].holders = HoldersOf(models[m]);
+			plans[m].images.resize(plans[m].holders.size());
 		}
-		// one model may appear in several entries: replicate it once
-		std::vector<const LoadedModel*> done;
+		// 1. every holder lists its images (on its own thread: the batch is the worker's)
+		Post([&](Shard& s) {
+			for (size_t m = 0; m < models.size(); m++)
+				for (size_t k = 0; k < plans[m].holders.size(); k++)
+					if (plans[m].holders[k] == s.rank) s.batch->WeightImages(*models[m], plans[m].images[k]);
+		});
+		// 2. cross-rank agreement: same number of images, same sizes
+		for (size_t m = 0; m < models.size(); m++)
+			for (size_t k = 1; k < plans[m].holders.size(); k++)
+			{
+				const auto &a = plans[m].images[0], &b = plans[m].images[k];
+				bool same = a.size() == b.size();
+				for (size_t i = 0; same && i < a.size(); i++) same = a[i].second == b[i].second;
+				if (!same) throw std::runtime_error("neuralaudio_amd: MultiGpuBatch: the shards disagree on a model's weight images (fan-out refused)");
+			}
+		// 3. the transfers
 		Post([&](Shard& s) {
 			CheckHip(hipSetDevice(s.device), "hipSetDevice");
-			std::vector<const LoadedModel*> seen;
+			hipStream_t st = s.batch->GetStream();
 			CheckNccl(nccl, nccl->GroupStart(), "ncclGroupStart");
-			for (size_t e = 0; e < entries.size(); e++)
+			std::string failed;
+			try
 			{
-				const LoadedModel* m = entries[e].model.get();
-				if (std::find(seen.begin(), seen.end(), m) != seen.end()) continue;
-				seen.push_back(m);
-				// every holder of ANY entry of this model, ascending
-				std::vector<int> h;
-				for (size_t k = 0; k < entries.size(); k++)
-					if (entries[k].model.get() == m) h.insert(h.end(), holders[k].begin(), holders[k].end());
-				std::sort(h.begin(), h.end());
-				h.erase(std::unique(h.begin(), h.end()), h.end());
-				if (h.size() < 2 || std::find(h.begin(), h.end(), s.rank) == h.end()) continue;
-				std::vector<std::pair<void*, size_t>> images;
-				s.batch->WeightImages(*m, images);
-				for (const auto& img : images)
+				for (size_t m = 0; m < models.size(); m++)
 				{
-					if (s.rank == h[0])
+					const Plan& p = plans[m];
+					if (p.holders.size() < 2) continue;
+					const size_t me = (size_t)(std::find(p.holders.begin(), p.holders.end(), s.rank) - p.holders.begin());
+					if (me == p.holders.size()) continue;
+					for (const auto& img : p.images[me])
 					{
-						for (size_t k = 1; k < h.size(); k++)
-							CheckNccl(nccl, nccl->Send(img.first, img.second, rccl::kUint8, h[k], s.comm, s.batch->GetStream()), "ncclSend");
+						if (me == 0)
+						{
+							for (size_t k = 1; k < p.holders.size(); k++)
+								CheckNccl(nccl, nccl->Send(img.first, img.second, rccl::kUint8, p.holders[k], s.comm, st), "ncclSend");
+						}
+						else CheckNccl(nccl, nccl->Recv(img.first, img.second, rccl::kUint8, p.holders[0], s.comm, st), "ncclRecv");
 					}
-					else CheckNccl(nccl, nccl->Recv(img.first, img.second, rccl::kUint8, h[0], s.comm, s.batch->GetStream()), "ncclRecv");
 				}
 			}
-			CheckNccl(nccl, nccl->GroupEnd(), "ncclGroupEnd");
-			CheckHip(hipStreamSynchronize(s.batch->GetStream()), "hipStreamSynchronize");
+			catch (const std::exception& e)
+			{
+				failed = e.what();
+			}
+			const rccl::Result closed = nccl->GroupEnd(); // always: the peers' transfers of this group must not be left waiting
+			if (!failed.empty()) throw std::runtime_error(failed);
+			CheckNccl(nccl, closed, "ncclGroupEnd");
+			CheckHip(hipStreamSynchronize(st), "hipStreamSynchronize");
+			s.batch->WeightsArrived();
 		});
 	}
 
@@ -271,6 +325,8 @@ namespace na
 	void MultiGpuBatch::ProcessGathered(const float* in, float* out, size_t n)
 	{
 		const size_t totalFloats = (size_t)total * n;
+		try
+		{
 		Post([&, in, out, n](Shard& s) {
 			CheckHip(hipSetDevice(s.device), "hipSetDevice");
 			if (s.gatheredFloats < totalFloats)
@@ -283,16 +339,36 @@ namespace na
 			}
 			hipStream_t st = s.batch->GetStream();
 			s.batch->ProcessHostToDevice(in + (size_t)s.begin * n, s.gathered + (size_t)s.begin * n, n, (long)n);
+			// (everything fallible that is this rank's own business is done: from here a failure is inside the group, which is closed
+			// whatever happens -- the peers' broadcasts must not be left waiting for this rank)
 			CheckNccl(nccl, nccl->GroupStart(), "ncclGroupStart");
-			for (const auto& rp : shards)
+			std::string failed;
+			try
 			{
-				float* part = s.gathered + (size_t)rp->begin * n;
-				CheckNccl(nccl, nccl->Broadcast(part, part, (size_t)(rp->end - rp->begin) * n, rccl::kFloat32, rp->rank, s.comm, st), "ncclBroadcast");
+				for (const auto& rp : shards)
+				{
+					float* part = s.gathered + (size_t)rp->begin * n;
+					CheckNccl(nccl, nccl->Broadcast(part, part, (size_t)(rp->end - rp->begin) * n, rccl::kFloat32, rp->rank, s.comm, st), "ncclBroadcast");
+				}
 			}
-			CheckNccl(nccl, nccl->GroupEnd(), "ncclGroupEnd");
+			catch (const std::exception& e)
+			{
+				failed = e.what();
+			}
+			const rccl::Result closed = nccl->GroupEnd();
+			if (!failed.empty()) throw std::runtime_error(failed);
+			CheckNccl(nccl, closed, "ncclGroupEnd");
 			if (s.rank == 0) CheckHip(hipMemcpyAsync(out, s.gathered, totalFloats * sizeof(float), hipMemcpyDeviceToHost, st), "hipMemcpyAsync D2H");
 			CheckHip(hipStreamSynchronize(st), "hipStreamSynchronize");
 		});
+		}
+		catch (const std::exception& e)
+		{
+			// some ranks ran the buffer and some did not (or a transfer failed): the shards' stream states no longer agree with the rows
+			// the caller holds -- like a failed Submit, the object refuses further work
+			broken = e.what();
+			throw;
+		}
 	}
 
 	// a non-empty range without a batch of exactly its rows would silently leave the caller's rows untouched

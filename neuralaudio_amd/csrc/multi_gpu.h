@@ -105,6 +105,8 @@ namespace na
 		const rccl::Api* nccl = nullptr;
 		void InitRccl();          // communicators (one per shard) + weight replication
 		void ReplicateWeights();
+		std::vector<int> HoldersOf(const LoadedModel* model) const;
+		int FirstHolderOf(const LoadedModel* model) const;
 		void ProcessGathered(const float* in, float* out, size_t n);
 	};
 }

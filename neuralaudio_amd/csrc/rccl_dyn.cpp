@@ -3,6 +3,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <mutex>
 
 namespace na
@@ -67,6 +68,18 @@ namespace na
 				return nullptr;
 			}
 			return &gApi;
+		}
+
+		namespace
+		{
+			std::atomic<const Api*> gOverride{ nullptr };
+		}
+		void SetOverride(const Api* api) { gOverride.store(api); }
+		bool OverrideActive() { return gOverride.load() != nullptr; }
+		const Api* Active(std::string& error)
+		{
+			if (const Api* o = gOverride.load()) return o;
+			return Load(error);
 		}
 
 		const char* const* SymbolNames(int& count)

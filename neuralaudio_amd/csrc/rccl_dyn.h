@@ -37,6 +37,14 @@ namespace na
 
 		// The process-wide binding: nullptr (and `error` says why) when librccl.so cannot be loaded or lacks a symbol.  Thread-safe.
 		const Api* Load(std::string& error);
+		// The table the multi-GPU host uses: the override if one is set, else Load().  The one override that exists is LoopbackApi()
+		// (rccl_loopback.cpp): every rank on the same device, transfers are device-to-device copies -- so that the multi-rank
+		// orchestration executes on a one-GPU box (tests; NA_DebugSetRcclApi).  Not for use while a multi batch is being committed.
+		const Api* Active(std::string& error);
+		void SetOverride(const Api* api); // nullptr: back to librccl.so
+		bool OverrideActive();
+		const Api* LoopbackApi();
+		void LoopbackConfigure(int failSendAt, int rendezvousMs); // fault injection / rendezvous time-out of the loopback table (tests)
 		// names of the symbols Load() resolves (tests check them against the installed library without a GPU)
 		const char* const* SymbolNames(int& count);
 	}

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dpp_recurrent.h"
+#include "tuning.h"
 #include "lstm_dev.h"
 #include "lstm_launch.h"
 
@@ -1071,7 +1072,7 @@ namespace na
 		int v = gQuadMin.load(std::memory_order_relaxed);
 		if (v < 0)
 		{
-			v = getenv("NA_REC_QUAD_MIN") ? atoi(getenv("NA_REC_QUAD_MIN")) : 3072;
+			v = Tuning::Get().recQuadMin;
 			gQuadMin.store(v, std::memory_order_relaxed);
 		}
 		return v;
@@ -1151,7 +1152,7 @@ namespace na
 	{
 		// hidden sizes below a layout (8 or 16 units per gate block) are padded into it: 12 (the reference's static 1x12 / 2x12) runs as 16
 		// ... and one-layer LSTMs (the reference's static 1x24) / keras GRUs of 17 .. 32 units on the 32-unit layout
-		static const bool no32 = getenv("NA_REC_NO_DPP32") != nullptr;
+		const bool no32 = Tuning::Get().recNoDpp32;
 		if (m.tailLayers != 0) return false; // generic keras stacks run on the runtime-shaped kernels
 		if ((m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU) && m.numLayers == 1 && m.hidden > 16 && m.hidden <= 32) return !no32;
 		return m.hidden >= 1 && m.hidden <= 16 && (m.numLayers == 1 || m.numLayers == 2) && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU);
@@ -1164,7 +1165,7 @@ namespace na
 		if (n > LSTM_MAX_FRAMES || numGroups > RECURRENT_MAX_GROUPS) return hipErrorInvalidValue;
 		RecurrentLaunchArgs args = {};
 		args.numGroups = numGroups;
-		static const bool noSkew = getenv("NA_REC_NOSKEW") != nullptr;
+		const bool noSkew = Tuning::Get().recNoSkew;
 		args.noSkew = noSkew ? 1 : 0;
 		int blocks = 0;
 		for (int i = 0; i < numGroups; i++)

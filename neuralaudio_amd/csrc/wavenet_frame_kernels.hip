@@ -22,6 +22,7 @@
 // f32 MFMA runs at the f32 VALU rate and does NOT overlap with VALU work on the same SIMD, so every padded MFMA row and
 // every activation evaluated on a padding lane is pure loss; the tile mapping pads 8-channel layers to 16 rows.
 #include "device_once.h"
+#include "tuning.h"
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
@@ -1022,7 +1023,7 @@ namespace na
 				if (e != hipSuccess) return e;
 			}
 			hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WPS * SPB), lds, stream, args, maxA4F4, in, out, inStride, outStride, n,
-				GetWaveNetTraceBuffer(), []() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
+				GetWaveNetTraceBuffer(), Tuning::Get().traceBlock);
 			return hipGetLastError();
 		}
 	}
@@ -1040,8 +1041,8 @@ namespace na
 			total += groups[i].numStreams;
 			ldsWeights = std::max(ldsWeights, (size_t)2 * ((groups[i].model->max_a4_floats + 3) / 4) * 16);
 		}
-		static const int prefetch = getenv("NA_FR_PF") ? atoi(getenv("NA_FR_PF")) : 1; // tuning knob: 0 none, 1 history prefetch into registers, 2 into LDS (LDS-DMA)
-		static const int spbEnv = getenv("NA_FR_SPB") ? atoi(getenv("NA_FR_SPB")) : 0;            // tuning knob: streams per workgroup (1, 2, 4)
+		const int prefetch = Tuning::Get().frPrefetch; // tuning knob: 0 none, 1 history prefetch into registers, 2 into LDS (LDS-DMA)
+		const int spbEnv = Tuning::Get().frSpb;            // tuning knob: streams per workgroup (1, 2, 4)
 		// streams per workgroup: two streams share one staged copy of the weights once there are enough streams to cover all 256 CUs
 		// (measured 1024 x Standard: SPB 1 / 2 / 4 = 61.5 / 61.3 / 65.0 us -- at 4 the 8-wave barrier skew eats the saving)
 		const int spb = spbEnv > 0 ? spbEnv : (total >= 512 ? 2 : 1);

@@ -38,6 +38,46 @@ namespace na
 	// hipErrorNotSupported otherwise -- LaunchWaveNetSplitFused tries it first and falls back to its stage interpreter.
 	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream, int sharing = 1);
+	// ---- resident ("persistent") launches of the specialised chains (wavenet_spec_impl.h WaveNetSpecResidentKernel) --------------
+	// One launch stays on the chip and walks consecutive buffers by itself: the host posts a command per buffer into a ring in pinned,
+	// coherent host memory (fields first, then `seq`), every workgroup polls the command it needs next, runs its streams' block and
+	// counts itself done.  Workgroups never wait for each other -- only for the host -- so the launch is live whatever part of its
+	// grid is resident, and a workgroup that finds no command for `idleTicks` (or has reached `exitAfter`) leaves; the host relaunches
+	// when there is work again (gpu_batch_resident.cpp).
+	constexpr int RESIDENT_RING = 64; // commands in flight at most (host-side back-pressure)
+	struct ResidentCmd
+	{
+		const float* in;
+		float* out;
+		long inStride, outStride;
+		unsigned long long seq; // written LAST by the host: the command with this sequence number is complete in memory
+		unsigned long long pad[3];
+	};
+	struct ResidentCtrl // pinned host memory (hipHostMallocCoherent | Mapped)
+	{
+		unsigned long long exitAfter; // host -> device: workgroups leave once they have run this sequence number
+		unsigned long long pad0[7];
+		unsigned long long completed; // device -> host: every workgroup has run the commands up to this one
+		unsigned long long pad1[7];
+		ResidentCmd cmd[RESIDENT_RING];
+	};
+	static_assert(sizeof(ResidentCmd) == 64 && sizeof(ResidentCtrl) == 128 + 64 * RESIDENT_RING, "command ring layout");
+	struct ResidentArgs
+	{
+		ResidentCtrl* ctrl;           // device address of the pinned block
+		unsigned* doneCount;          // [RESIDENT_RING] device memory: workgroups that have run command seq (slot seq % RESIDENT_RING)
+		unsigned* wgDone;             // [grid] device memory: commands this workgroup has run since `base` (a relaunch resumes there)
+		unsigned long long base;      // sequence number of the last command before this generation of launches
+		int numBlocks;                // workgroups' worth of streams per command: workgroup b runs blocks b, b + grid, ...
+		unsigned idleTicks;           // s_memrealtime ticks (100 MHz) without a command after which a workgroup leaves
+	};
+	// Starts (or restarts) the resident launch of a launch list that LaunchWaveNetSpecFused would run as ONE launch of 128-frame blocks;
+	// hipErrorNotSupported otherwise.  grid = min(workgroups of the list, what is resident at the kernel's occupancy); *gridOut says how
+	// many workgroups were launched (wgDone must hold that many counters).
+	hipError_t LaunchWaveNetSpecResident(const WnFrameGroup* groups, int numGroups, int n, const ResidentArgs& ra, hipStream_t stream, int* gridOut);
+	// the grid LaunchWaveNetSpecResident would use (0: the list cannot run resident)
+	int WaveNetSpecResidentGrid(const WnFrameGroup* groups, int numGroups, int n);
+
 	bool WaveNetSpecEnabled();
 	void SetWaveNetSpecEnabled(bool on); // process-wide; not for use while launches are being issued from other threads
 	// which specialised chain (WnSpecArch) runs a split-kernel plan, WN_SPEC_NONE if none; host data

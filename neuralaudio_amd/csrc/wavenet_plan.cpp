@@ -170,7 +170,9 @@ namespace na
 				WnRingInfo r;
 				r.channels = channels;
 				r.G = CeilDiv(channels, 4);
-				const bool exact = exactRings && !firstOfArray && dilation >= WN_MAX_FRAMES && history >= dilation && history % WN_TILE == 0;
+				// (history >= 2 blocks: the stage interpreter keeps WnRingKeep(R) = R - 128 frames of a block, which is the whole block only then --
+			// a K = 2, d = 128 .. 240 ring of exactly its history would lose frames; such a layer keeps the roomy ring)
+			const bool exact = exactRings && !firstOfArray && dilation >= WN_MAX_FRAMES && history >= 2 * WN_MAX_FRAMES && history % WN_TILE == 0;
 				// Short histories (A1's d = 1 .. 16 layers: 16 or 32 frames) in rings of three times their length instead of + 128: for the
 				// block lengths the host then restricts itself to, the frames a block reads and the ones it writes never share a position
 				// (wavenet_dev.h WnRingKeep).  A1 Standard: another 43 KB per stream (279 -> 236 KB): 1024 streams = 242 MB.

@@ -7,12 +7,14 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
 #include "device_once.h"
+#include "tuning.h"
 #include "wavenet_split_dev.h"
 
 namespace na
@@ -42,6 +44,20 @@ namespace na
 		__device__ __forceinline__ u32x4 LdsRead16(unsigned addr) { return *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>((LdsPtr)(size_t)addr); }
 		__device__ __forceinline__ u32x2 LdsRead8(unsigned addr) { return *reinterpret_cast<__attribute__((address_space(3))) const u32x2*>((LdsPtr)(size_t)addr); }
 		__device__ __forceinline__ void LdsWrite16(unsigned addr, u32x4 v) { *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((LdsPtr)(size_t)addr) = v; }
+
+		// input / output rows of a launch: plain accesses between kernel boundaries; at system scope inside a resident launch
+		template <bool COH>
+		__device__ __forceinline__ float LoadIn(const float* p)
+		{
+			if constexpr (COH) return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+			else return *p;
+		}
+		template <bool COH>
+		__device__ __forceinline__ void StoreOut(float* p, float v)
+		{
+			if constexpr (COH) __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			else *p = v;
+		}
 
 		// ---- the architectures (virtual models: after padding / stream packing, wavenet_plan.cpp) ---------------------------------
 		// NeuralModel.cpp:71-76 dilation tables; channels are those of the lane modes the plans fill completely
@@ -145,7 +161,7 @@ namespace na
 			static constexpr int NRINGS = NL + (HEADK > 1 ? 1 : 0); // one per layer (+ the conv head's)
 			// ring L < NL: input history of layer L; ring NL: the head accumulator's (wavenet_plan.cpp AddRing: roundup16((K - 1) d) + 128)
 			// (wavenet_plan.cpp AddRing: a dilation of at least a whole block -> exactly (K - 1) d frames, else roundup16((K - 1) d) + 128)
-			static constexpr bool ExactRing(int L) { return L < NL && !FirstOfArr(L) && Dil(L) >= FRAMES && KS(L) > 1 && ((KS(L) - 1) * Dil(L)) % 16 == 0; }
+			static constexpr bool ExactRing(int L) { return L < NL && !FirstOfArr(L) && Dil(L) >= FRAMES && (KS(L) - 1) * Dil(L) >= 2 * FRAMES && ((KS(L) - 1) * Dil(L)) % 16 == 0; }
 			static constexpr int HistFrames(int L) { return L < NL ? ((KS(L) - 1) * Dil(L) + 15) / 16 * 16 : (HEADK - 1 + 15) / 16 * 16; } // roundup16((K - 1) d)
 			static constexpr bool CompactRing(int L) { return A::COMPACT && L < NL && KS(L) > 1 && HistFrames(L) <= WN_COMPACT_MAX_HISTORY; }
 			static constexpr int RingFrames(int L)
@@ -214,9 +230,12 @@ namespace na
 		// launch shape: NF frames per block, T tiles per wave (FW = 16 T frames), SPB streams per workgroup sharing the staged weights.
 		// SPB_ counts streams of 4 waves-per-128-frames (T = 2): an architecture with T = 4 takes half the waves per stream and puts twice
 		// the streams into the workgroup, so every member of a family launches the same number of threads.
-		template <class A_, int NF_, int SPB_, bool PK_>
+		// COH_: the resident launch (WaveNetSpecResidentKernel) -- input rows are read and output rows written at system scope, because
+		// their producer / consumer runs while this launch is on the chip (no kernel boundary orders the caches)
+		template <class A_, int NF_, int SPB_, bool PK_, bool COH_ = false>
 		struct Cfg
 		{
+			static constexpr bool COH = COH_;
 			typedef A_ A;
 			typedef Tab<A_> TB;
 			static constexpr int NF = NF_, T = A_::T, FW = 16 * T, WPS = NF_ / FW, SPB = SPB_ * T / 2, NTHREADS = 64 * WPS * SPB;
@@ -240,7 +259,8 @@ namespace na
 			static constexpr int IDOP_OFF = WBUF_OFF + NWB * 2 * WBUF_ONE;      // identity operand
 			static constexpr int DUMP_OFF = IDOP_OFF + 1024;                    // where the LDS-DMA of a wave with nothing to stage lands
 			static constexpr int FLAG_OFF = DUMP_OFF + 1024;                    // [SPB] x 16 bytes: "a value of this stream was saturated" (LeakyReLU chains)
-			static constexpr int LDS_BYTES = FLAG_OFF + 16 * SPB;
+			static constexpr int BCAST_OFF = FLAG_OFF + 16 * SPB;                // resident launch: the command wave 0 read, for the other waves (64 bytes)
+			static constexpr int LDS_BYTES = BCAST_OFF + (COH_ ? 64 : 0);
 			static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 		};
 
@@ -974,9 +994,9 @@ namespace na
 								const float v[4] = { acc[i].x, acc[i].y, acc[i].z, acc[i].w };
 #pragma unroll
 								for (int q = 0; q < 4; q++)
-									if (q < pack && outRow[q] >= 0) out[outRow[q] + f] = headScale * v[q];
+									if (q < pack && outRow[q] >= 0) StoreOut<C::COH>(out + outRow[q] + f, headScale * v[q]);
 							}
-							else out[outBase + f] = headScale * acc[i].x;
+							else StoreOut<C::COH>(out + outBase + f, headScale * acc[i].x);
 						}
 					}
 				}
@@ -1029,13 +1049,14 @@ namespace na
 #ifdef NA_SP_TRACE
 			, long long* trace
 #endif
+			, const int tid = (int)threadIdx.x // (the resident launch hands in an opaque copy: nothing derived from it may be hoisted out of its loop)
 			)
 		{
 			typedef typename C::TB TB;
 			constexpr bool PK = C::PK;
 			constexpr int SPB = C::SPB, NF = C::NF;
-			const int lane = threadIdx.x & 63;
-			const int waveAll = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+			const int lane = tid & 63;
+			const int waveAll = __builtin_amdgcn_readfirstlane(tid >> 6);
 			const int sub = waveAll / C::WPS, wave = waveAll % C::WPS;
 
 			// a partial last workgroup: the surplus waves shadow the last stream on a zero-sized state resource (they must keep staging
@@ -1086,7 +1107,7 @@ namespace na
 				{
 					float c[4];
 #pragma unroll
-					for (int q = 0; q < 4; q++) c[q] = (rowOf[q] >= 0 && i < NF) ? in[(size_t)rowOf[q] * inStride + i] : 0.0f;
+					for (int q = 0; q < 4; q++) c[q] = (rowOf[q] >= 0 && i < NF) ? LoadIn<C::COH>(in + (size_t)rowOf[q] * inStride + i) : 0.0f;
 #pragma unroll
 					for (int q = 0; q < 4; q++)
 					{
@@ -1103,7 +1124,7 @@ namespace na
 				for (int i = wave * 64 + lane; i < FRAMES; i += C::WPS * 64)
 				{
 					// [cond_h, 1 | cond_l, 1 | cond_h, 0 | 0, 0] (see FillSplitAux in wavenet_plan.cpp; 8-byte entries: AuxRead rebuilds the second half)
-					const float c = (i < NF) ? ClampCond(in[(size_t)row * inStride + i], ga.condLimit) : 0.0f;
+					const float c = (i < NF) ? ClampCond(LoadIn<C::COH>(in + (size_t)row * inStride + i), ga.condLimit) : 0.0f;
 					const _Float16 ch = (_Float16)c, cl = (_Float16)(c - (float)ch);
 					const f16x2 a = { ch, (_Float16)1.0f }, b = { cl, (_Float16)1.0f }, d = { ch, (_Float16)0.0f };
 					if constexpr (C::AUX16)
@@ -1114,9 +1135,9 @@ namespace na
 				}
 			}
 			// zero quad in front of frame 0 of every plane of both block images
-			for (int i = threadIdx.x; i < SPB * 2 * TB::MaxGP(); i += C::NTHREADS) LdsWrite16((unsigned)(C::IMG_OFF + (i * PLANE + GUARD - 1) * 16), u32x4{ 0, 0, 0, 0 });
+			for (int i = tid; i < SPB * 2 * TB::MaxGP(); i += C::NTHREADS) LdsWrite16((unsigned)(C::IMG_OFF + (i * PLANE + GUARD - 1) * 16), u32x4{ 0, 0, 0, 0 });
 			// identity A operand: row i x k-block q = i / 4: 1.0 against the h AND the l half of channel i % 4
-			if (threadIdx.x < 64)
+			if (tid < 64)
 			{
 				const int i = lane & 15, q = lane >> 4;
 				const unsigned one = 0x3c00u; // f16 1.0
@@ -1126,7 +1147,7 @@ namespace na
 			}
 			if constexpr (C::A::LEAKY)
 			{
-				if (threadIdx.x < SPB) *reinterpret_cast<__attribute__((address_space(3))) unsigned*>((LdsPtr)(size_t)(unsigned)(C::FLAG_OFF + 16 * threadIdx.x)) = 0u;
+				if (tid < SPB) *reinterpret_cast<__attribute__((address_space(3))) unsigned*>((LdsPtr)(size_t)(unsigned)(C::FLAG_OFF + 16 * tid)) = 0u;
 			}
 			// stage 0's single operand (offset 0 of every weight image), into every pair of weight buffers
 			if (cx.stgWave == 0) LdsWrite16(cx.wbuf + (unsigned)lane * 16u, BufLoad(cx.wrsrc, lane * 16));
@@ -1215,6 +1236,122 @@ namespace na
 #endif
 		}
 
+		// ---- the resident launch --------------------------------------------------------------------------------------------------
+		// The same chain, but the launch stays on the chip and walks consecutive buffers itself (wavenet_split_dev.h ResidentCtrl): per
+		// command, workgroup b runs the stream blocks b, b + grid, ... of the launch list, then counts itself done.  Wave 0 polls the
+		// command ring in pinned host memory; the other waves sleep at the barrier behind it.  Nothing here waits for another
+		// workgroup, so the launch makes progress with any part of its grid resident.
+		template <class F, int NF, int SPB, bool PK>
+		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(OccOf<F, NF, SPB>()))) WaveNetSpecResidentKernel(const LaunchArgs args,
+			const ResidentArgs ra)
+		{
+			typedef Cfg<typename F::A0, NF, SPB, PK, true> C;
+			typedef Cfg<typename F::A1, NF, SPB, PK, true> C1;
+			static_assert(C::NTHREADS == C1::NTHREADS && C::BCAST_OFF == C1::BCAST_OFF, "members of a family launch the same workgroup");
+			extern __shared__ __attribute__((aligned(16))) char dynSmem[];
+			asm volatile("" : : "s"((unsigned)(size_t)(LdsPtr)dynSmem));
+			typedef __attribute__((address_space(3))) unsigned long long* Lds64;
+			Lds64 const bc = reinterpret_cast<Lds64>((LdsPtr)(size_t)(unsigned)C::BCAST_OFF);
+			// Nothing is carried in registers from one block to the next (the chain has none to spare: 128 VGPRs, no spills): the
+			// workgroup's position -- commands done, block in progress -- lives in LDS next to the command, and thread 0 reads the launch
+			// arguments afresh (`ra` behind an opaque copy of its address) every time round.
+			//   bc[0] go | bc[1..4] in, out, inStride, outStride | bc[5] commands done by this workgroup | bc[6] block in progress (-1: none)
+			if (threadIdx.x == 0)
+			{
+				bc[5] = ra.base + ra.wgDone[blockIdx.x];
+				bc[6] = ~0ull;
+			}
+			for (;;)
+			{
+				if (threadIdx.x == 0)
+				{
+					int z = 0; // an opaque zero: the arguments are read from the kernarg segment afresh, nothing of them stays in registers
+					asm volatile("" : "+v"(z));
+					const ResidentArgs& r = (&ra)[__builtin_amdgcn_readfirstlane(z)];
+					unsigned long long k = bc[5];
+					long blk = (long)bc[6];
+					unsigned long long go = 1;
+					if (blk >= 0) blk += (long)gridDim.x;
+					if (blk < 0 || blk >= (long)r.numBlocks)
+					{
+						if (blk >= 0)
+						{
+							// the last block of command k + 1 is done (every wave's stores have left it: the closing wait + barrier below)
+							k++;
+							const unsigned slot = (unsigned)(k % RESIDENT_RING);
+							__hip_atomic_store(&r.wgDone[blockIdx.x], (unsigned)(k - r.base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							const unsigned before = __hip_atomic_fetch_add(&r.doneCount[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							if (before == gridDim.x - 1)
+							{
+								// the last workgroup of command k: the slot's counter is free again (the host does not reuse the slot before it
+								// has seen `completed`), and the host may read the output rows
+								__hip_atomic_store(&r.doneCount[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+								__hip_atomic_store(&r.ctrl->completed, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+							}
+						}
+						const ResidentCmd* cmd = &r.ctrl->cmd[(k + 1) % RESIDENT_RING];
+						const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+						while (__hip_atomic_load(&cmd->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != k + 1)
+						{
+							// nothing to do: told to leave behind command k, or idle for too long (the host relaunches when there is work)
+							if (__hip_atomic_load(&r.ctrl->exitAfter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) <= k ||
+								__builtin_amdgcn_s_memrealtime() - t0 > r.idleTicks)
+							{
+								// (a command posted in between is not lost: the relaunch resumes at wgDone)
+								go = __hip_atomic_load(&cmd->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == k + 1 ? 1 : 0;
+								break;
+							}
+							__builtin_amdgcn_s_sleep(8);
+						}
+						if (go)
+						{
+							// (the host wrote the fields before `seq`; these loads are issued after the one that saw it)
+							bc[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&cmd->in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+							bc[2] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&cmd->out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+							bc[3] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&cmd->inStride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+							bc[4] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&cmd->outStride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+						}
+						blk = (long)blockIdx.x;
+					}
+					bc[0] = go;
+					bc[5] = k;
+					bc[6] = (unsigned long long)blk;
+				}
+				BlockBarrier<C::NTHREADS / 64>();
+				if (__builtin_amdgcn_readfirstlane((int)bc[0]) == 0) break;
+				{
+					// (wave-uniform: scalar registers, like kernel arguments)
+					auto uni = [](unsigned long long v) {
+						return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+					};
+					const float* in = reinterpret_cast<const float*>(uni(bc[1]));
+					float* out = reinterpret_cast<float*>(uni(bc[2]));
+					const long inStride = (long)uni(bc[3]), outStride = (long)uni(bc[4]);
+					const int blk = __builtin_amdgcn_readfirstlane((int)bc[6]);
+					int gi = 0;
+					for (int i = 1; i < args.numGroups; i++)
+						if (blk >= args.g[i].firstBlock) gi = i;
+					// (opaque: what the chain derives from the thread index and from the group's tables is derived afresh per block, exactly
+					// like in the one-shot kernel -- hoisted out of this loop it would stay live across the whole chain)
+					asm volatile("" : "+v"(gi));
+					const GroupArgs& ga = args.g[__builtin_amdgcn_readfirstlane(gi)];
+					int tid = (int)threadIdx.x;
+					asm volatile("" : "+v"(tid));
+					const int groupBlock = blk - ga.firstBlock;
+#ifdef NA_SP_TRACE
+					if (F::N > 1 && ga.arch == 1) RunWorkgroup<C1>(ga, groupBlock, in, out, inStride, outStride, nullptr, tid);
+					else RunWorkgroup<C>(ga, groupBlock, in, out, inStride, outStride, nullptr, tid);
+#else
+					if (F::N > 1 && ga.arch == 1) RunWorkgroup<C1>(ga, groupBlock, in, out, inStride, outStride, tid);
+					else RunWorkgroup<C>(ga, groupBlock, in, out, inStride, outStride, tid);
+#endif
+				}
+				// every wave's ring stores, cursors and output rows have left the wave before the next block / the done count
+				__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+				BlockBarrier<C::NTHREADS / 64>();
+			}
+		}
+
 		// ---- host ----------------------------------------------------------------------------------------------------------------
 		template <class A>
 		static bool Matches(const WnSplitStage* st, int nstages, int stateF4, int wsplitQuads)
@@ -1244,15 +1381,16 @@ namespace na
 			return h.type == WN_ST_HEAD_CONV_OUT && h.dilation == 1 && h.ring_id == TB::NL && h.ring_off == TB::RingOff(TB::NL) && h.ring_frames == TB::RingFrames(TB::NL);
 		}
 
+		// the kernarg tables of a launch list; *blocksOut = workgroups it takes
 		template <class F, int NF, int SPB, bool PK>
-		static hipError_t Launch(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, hipStream_t stream)
+		static hipError_t FillLaunchArgs(const WnFrameGroup* groups, int numGroups, LaunchArgs& args, int* blocksOut)
 		{
 			typedef Cfg<typename F::A0, NF, SPB, PK> C;
 			typedef Cfg<typename F::A1, NF, SPB, PK> C1;
-			LaunchArgs args = {};
+			args = {};
 			args.numGroups = numGroups;
 			int blocks = 0;
-			static const bool reverse = getenv("NA_SP_REVERSE") != nullptr; // tuning: the groups' workgroups in the opposite dispatch order
+			const bool reverse = Tuning::Get().spReverse; // tuning: the groups' workgroups in the opposite dispatch order
 			for (int i = 0; i < numGroups; i++)
 			{
 				const WnFrameGroup& g = groups[reverse ? numGroups - 1 - i : i];
@@ -1278,6 +1416,19 @@ namespace na
 				const int spbArch = a.arch == 1 ? C1::SPB : C::SPB; // streams per workgroup of this group's architecture
 				blocks += (g.numStreams + spbArch - 1) / spbArch;
 			}
+			*blocksOut = blocks;
+			return hipSuccess;
+		}
+
+		template <class F, int NF, int SPB, bool PK>
+		static hipError_t Launch(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, hipStream_t stream)
+		{
+			typedef Cfg<typename F::A0, NF, SPB, PK> C;
+			typedef Cfg<typename F::A1, NF, SPB, PK> C1;
+			LaunchArgs args;
+			int blocks = 0;
+			const hipError_t fe = FillLaunchArgs<F, NF, SPB, PK>(groups, numGroups, args, &blocks);
+			if (fe != hipSuccess) return fe;
 			constexpr int LDS_BYTES = C::LDS_BYTES > C1::LDS_BYTES ? C::LDS_BYTES : C1::LDS_BYTES;
 			if (LDS_BYTES > 64 * 1024)
 			{
@@ -1287,9 +1438,48 @@ namespace na
 			}
 			hipLaunchKernelGGL((WaveNetSpecKernel<F, NF, SPB, PK>), dim3((unsigned)blocks), dim3(C::NTHREADS), LDS_BYTES, stream, args, in, out, inStride, outStride
 #ifdef NA_SP_TRACE
-				, GetWaveNetTraceBuffer(), []() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }()
+				, GetWaveNetTraceBuffer(), Tuning::Get().traceBlock
 #endif
 				);
+			return hipGetLastError();
+		}
+
+		// The resident launch of the same list (WaveNetSpecResidentKernel): as many workgroups as are resident at the kernel's occupancy,
+		// at most one per block of the list.  ra.numBlocks is filled in here.  stream == nullptr: only report the grid.
+		template <class F, int NF, int SPB, bool PK>
+		static hipError_t LaunchResident(const WnFrameGroup* groups, int numGroups, ResidentArgs ra, hipStream_t stream, int* gridOut)
+		{
+			typedef Cfg<typename F::A0, NF, SPB, PK, true> C;
+			typedef Cfg<typename F::A1, NF, SPB, PK, true> C1;
+			LaunchArgs args;
+			int blocks = 0;
+			const hipError_t fe = FillLaunchArgs<F, NF, SPB, PK>(groups, numGroups, args, &blocks);
+			if (fe != hipSuccess) return fe;
+			constexpr int LDS_BYTES = C::LDS_BYTES > C1::LDS_BYTES ? C::LDS_BYTES : C1::LDS_BYTES;
+			static PerDeviceOnce attr;
+			static std::atomic<int> perCU[kMaxHipDevices];
+			int device = 0;
+			hipError_t e = hipGetDevice(&device);
+			if (e != hipSuccess) return e;
+			if (device < 0 || device >= kMaxHipDevices) return hipErrorInvalidDevice;
+			e = attr.Run([device] {
+				hipError_t r = hipSuccess;
+				if (LDS_BYTES > 64 * 1024)
+					r = hipFuncSetAttribute(reinterpret_cast<const void*>(WaveNetSpecResidentKernel<F, NF, SPB, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+				if (r != hipSuccess) return r;
+				int nb = 0;
+				r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(WaveNetSpecResidentKernel<F, NF, SPB, PK>), C::NTHREADS, LDS_BYTES);
+				perCU[device].store(nb);
+				return r;
+			});
+			if (e != hipSuccess) return e;
+			const int resident = perCU[device].load() * CurrentDeviceCUs();
+			const int grid = std::min(blocks, resident);
+			*gridOut = grid;
+			if (grid < 1) return hipErrorInvalidValue;
+			if (stream == nullptr) return hipSuccess;
+			ra.numBlocks = blocks;
+			hipLaunchKernelGGL((WaveNetSpecResidentKernel<F, NF, SPB, PK>), dim3((unsigned)grid), dim3(C::NTHREADS), LDS_BYTES, stream, args, ra);
 			return hipGetLastError();
 		}
 

@@ -24,7 +24,7 @@ namespace na
 	static int& SpecSwitch()
 	{
 		// (NA_SP_T / NA_SP_GEN select interpreter variants: they imply it)
-		static int on = ((getenv("NA_WN_SPEC") != nullptr && atoi(getenv("NA_WN_SPEC")) == 0) || getenv("NA_SP_T") != nullptr || getenv("NA_SP_GEN") != nullptr) ? 0 : 1;
+		static int on = Tuning::Get().wnSpecOff ? 0 : 1;
 		return on;
 	}
 	bool WaveNetSpecEnabled() { return SpecSwitch() != 0; }
@@ -38,6 +38,28 @@ namespace na
 		if (spk::Matches<spk::ArchA2Full>(stages, nstages, stateF4, wsplitQuads)) return WN_SPEC_A2FULL;
 		if (spk::Matches<spk::ArchA2Lite>(stages, nstages, stateF4, wsplitQuads)) return WN_SPEC_A2LITE;
 		return WN_SPEC_NONE;
+	}
+
+	// The resident launch (wavenet_split_dev.h ResidentCtrl) of a list that is ONE launch of full-size workgroups: 128-frame blocks of A1
+	// Standard streams (the headline workload; the other families keep their ordinary launches for now).  stream == nullptr: grid only.
+	static hipError_t ResidentDispatch(const WnFrameGroup* groups, int numGroups, int n, const ResidentArgs& ra, hipStream_t stream, int* gridOut)
+	{
+		*gridOut = 0;
+		if (numGroups <= 0 || numGroups > WN_FRAME_MAX_GROUPS || n != 128 || !WaveNetSpecEnabled()) return hipErrorNotSupported;
+		for (int i = 0; i < numGroups; i++)
+			if (groups[i].model->spec_arch != WN_SPEC_STD || groups[i].pack > 1 || groups[i].numStreams <= 0) return hipErrorNotSupported;
+		return spk::LaunchResident<spk::FamStd, 128, 2, false>(groups, numGroups, ra, stream, gridOut);
+	}
+	hipError_t LaunchWaveNetSpecResident(const WnFrameGroup* groups, int numGroups, int n, const ResidentArgs& ra, hipStream_t stream, int* gridOut)
+	{
+		if (stream == nullptr) return hipErrorInvalidValue; // (the null stream would serialise the launch behind everything)
+		return ResidentDispatch(groups, numGroups, n, ra, stream, gridOut);
+	}
+	int WaveNetSpecResidentGrid(const WnFrameGroup* groups, int numGroups, int n)
+	{
+		int grid = 0;
+		ResidentArgs none = {};
+		return ResidentDispatch(groups, numGroups, n, none, nullptr, &grid) == hipSuccess ? grid : 0;
 	}
 
 	// Runs the launch on a specialised chain when every group is the SAME official architecture and the block is 128 / 64 / 32 frames;
@@ -69,7 +91,7 @@ namespace na
 		// Standard x 512 25.4 -> 23.4).  They are used while every workgroup is resident at that occupancy: at most two per CU --
 		// counting the workgroups of the launches that share the chip with this one (two free-running half-batch chains of 512 Standard
 		// streams each: 37.1 us per step with the half-size workgroups, 36.7 with the full-size ones; Feather x 1024 = 2 x 256: 21.5 vs 24.8).
-		static const int spbEnv = getenv("NA_SP_SPB") ? atoi(getenv("NA_SP_SPB")) : 0;
+		const int spbEnv = Tuning::Get().spSpb;
 		const int residentHalf = 2 * CurrentDeviceCUs();
 		int halfGroups = 0; // workgroups of the launch at SPB = 1 (an A2-Lite workgroup holds two streams there: T = 4)
 		for (int i = 0; i < numGroups; i++)
@@ -87,7 +109,7 @@ namespace na
 		if (!packed && lite16) return hipErrorNotSupported; // (16 / 16 only exists packed)
 		// a launch of 16 / 16 virtual streams only (packed Nano) with at most one of them per CU: one tile per wave, eight waves per stream
 		// (Nano x 1024 = 256 virtual streams: a chain of 23 short stages, bound by what its few waves can issue)
-		static const bool noT1 = getenv("NA_SP_NO_T1") != nullptr; // tuning knob
+		const bool noT1 = Tuning::Get().spNoT1; // tuning knob
 		bool all16 = packed && !noT1;
 		int virtualStreams = 0;
 		for (int i = 0; i < numGroups; i++)

@@ -234,5 +234,6 @@ namespace na
 			GroupArgs g[WN_FRAME_MAX_GROUPS];
 			int numGroups;
 		};
+
 	}
 }

@@ -27,6 +27,7 @@
 // A wave owns T consecutive tiles of one stream's block; a workgroup = SPB streams x (8 / T) waves sharing one staged copy of the
 // weights; one LDS-only barrier per layer (the dependency is causal).
 #include "device_once.h"
+#include "tuning.h"
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
@@ -856,7 +857,7 @@ namespace na
 				if (e != hipSuccess) return e;
 			}
 			hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * WPS * SPB), lds, stream, args, maxG, wstride, in, out, inStride, outStride, n, GetWaveNetTraceBuffer(),
-				[]() { const char* e = getenv("NA_TRACE_BLOCK"); return e ? atoi(e) : 0; }());
+				Tuning::Get().traceBlock);
 			return hipGetLastError();
 		}
 	}
@@ -878,9 +879,9 @@ namespace na
 			if (groups[i].numStreams <= 0) return hipErrorInvalidValue;
 			total += groups[i].numStreams;
 		}
-		static const int tEnv = getenv("NA_SP_T") ? atoi(getenv("NA_SP_T")) : 0;       // tuning knob: tiles per wave (2, 4)
-		static const int spbEnv = getenv("NA_SP_SPB") ? atoi(getenv("NA_SP_SPB")) : 0; // tuning knob: streams per workgroup (1, 2)
-		static const bool genEnv = getenv("NA_SP_GEN") != nullptr;                      // tuning knob: always the generic instantiation
+		const int tEnv = Tuning::Get().spT;       // tuning knob: tiles per wave (2, 4)
+		const int spbEnv = Tuning::Get().spSpb;   // tuning knob: streams per workgroup (1, 2)
+		const bool genEnv = Tuning::Get().spGen;  // tuning knob: always the generic instantiation
 		const int spb = spbEnv > 0 ? spbEnv : (total >= 512 ? 2 : 1);
 		const int tiles = (n + 15) / 16;
 		// fast instantiation: every layer of every group has K == 3 and fills its lane mode (the official A1 architectures except Lite);

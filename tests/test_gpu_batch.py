@@ -448,10 +448,10 @@ def test_buffers_longer_than_a_launch_run_their_chunks_on_the_chains(na, loader)
 
 def _halves_as_expected(batch):
     """Outside a forced-family run (tests/test_gpu_families.py: fallback kernels run ordered launches, the results must still agree)
-    the batch must have run its last step as two half-batch launches."""
+    the batch must have run its last step as two half-batch launches -- or, A1 Standard, as a command to the resident launch."""
     if any(os.environ.get(k) for k in ("NA_WN_KERNEL", "NA_WN_SPEC", "NA_WN_PACK", "NA_HOST_HALVES", "NA_HOST_DIRECT", "NA_SP_T", "NA_SP_GEN")):
         return True
-    return batch.UsesHalfLaunches()
+    return batch.UsesHalfLaunches() or batch.UsesResidentLaunch()
 
 
 def _device_steps(batch, x, out, n):
