@@ -218,6 +218,73 @@ def parity_spot_check(check_rows, x, y, issued, nbuf, mdir):
     return {"rms": worst, "per_model": per_model}
 
 
+def rotation_regime(na, model, local_rank, dev, n_rot, bytes_per_sample, steps=120, warmup=24):
+    """The metric's own regime: ONE batch of n_rot x 1024 A1 Standard streams, every step visits the whole
+    n_rot x 249 MB of ring state once -- nothing survives in the 256 MB Infinity Cache from one step to the next.  Same timed-region
+    rules as the headline (library HIP events around the steps, wall clock beside them)."""
+    import torch
+    S = STREAMS_PER_GPU * n_rot
+    b = na.Batch(local_rank)
+    b.AddStreams(model, S)
+    g = torch.Generator(device="cpu").manual_seed(99)
+    nbuf = 2
+    x = torch.clamp(0.25 * torch.randn(nbuf, S, BLOCK, generator=g), -1.0, 1.0).to(dev)
+    y = torch.empty(S, BLOCK, device=dev)
+    torch.cuda.synchronize(dev)
+    for i in range(warmup):
+        b.ProcessDevice(x[i % nbuf].data_ptr(), y.data_ptr(), BLOCK, BLOCK, BLOCK)
+    b.Synchronize()
+    b.MarkTime(0)
+    b.MarkTime(1)
+    torch.cuda.synchronize(dev)
+    b.MarkTime(0)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        b.ProcessDevice(x[i % nbuf].data_ptr(), y.data_ptr(), BLOCK, BLOCK, BLOCK)
+    b.MarkTime(1)
+    b.WaitMarks()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    ms = b.ElapsedMs() / steps
+    mode = "resident" if b.UsesResidentLaunch() else ("half-batch chains" if b.UsesHalfLaunches() else "ordered")
+    b.Synchronize()
+    finite = bool(torch.isfinite(y).all().item())
+    state_mb = b.StateBytes() / 1e6
+    b.close()
+    alg = bytes_per_sample * S * BLOCK
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {
+        "what": "one batch of %d x 1024 = %d A1 Standard streams, 128-sample buffers: every step walks %.0f MB of stream state once "
+                "(Infinity Cache: 256 MB)" % (n_rot, S, state_mb),
+        "streams": S, "steps": steps, "warmup": warmup, "launch_mode": mode,
+        "ms_per_step": ms, "ms_per_step_wall_clock": wall / steps * 1e3,
+        "us_per_1024_step": ms * 1e3 / n_rot,
+        "state_mb_total": state_mb,
+        "achieved_gbs": gbs, "frac": gbs / HBM_PEAK_GBS,
+        "msamples_per_s": S * BLOCK / (ms * 1e-3) / 1e6,
+        # streams one GPU keeps up with in real time: samples per second / 48 000
+        "realtime_streams_48k": S * BLOCK / (ms * 1e-3) / 48000.0,
+        # the north star's per-buffer latency bound, in this regime: one buffer of ALL streams
+        "latency_per_buffer_ms": ms,
+        "output_finite": finite,
+    }
+
+
+def exact_f32_figure(streams):
+    """The same step on the same box with the exact-f32 kernel (NA_WN_KERNEL=frame: v_mfma_f32_4x4x1_16b_f32, f32 values throughout):
+    what strict f32 arithmetic costs on this hardware, one number beside `dtype`."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "300", "--warmup", "50", "--ramp-ms", "150", "--streams", str(streams),
+           "--no-cpu-baseline", "--no-host-path", "--no-parity-check", "--rotate", "0", "--no-exact-f32"]
+    env = dict(os.environ, NA_WN_KERNEL="frame")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"kernel": j["roofline"]["kernel"], "dtype": j["dtype"], "ms_per_step": j["kernel_ms_avg"], "frac": j["roofline"]["frac"],
+                "launch_mode": j.get("launch_mode"), "what": "bench.py under NA_WN_KERNEL=frame on the same box, 300 steps"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def spawn_ranks(n):
     """`bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU)."""
     import socket
@@ -253,6 +320,13 @@ def main():
     ap.add_argument("--caller-stream", action="store_true",
                     help="create the batch on a stream of the caller (torch's) instead of its own: every launch is ordered on that stream, "
                          "so a step is ONE launch (the batch's own stream lets a step run as two free-running half-batch launches)")
+    ap.add_argument("--rotate", type=int, default=8,
+                    help="after the timed region (headline workload, one GPU): ONE batch of N x 1024 Standard streams -- N x 249 MB of stream "
+                         "state, far outside the 256 MB Infinity Cache -- stepped the same way: the regime of the metric itself (10 k+ "
+                         "concurrent real-time streams visit all of their state once per buffer).  Reported as `rotation`; "
+                         "realtime_streams_48k is computed from it.  0: skip")
+    ap.add_argument("--no-exact-f32", action="store_true",
+                    help="skip the same-box run of the exact-f32 kernel (NA_WN_KERNEL=frame) that is reported beside `dtype`")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed sustained load before warm-up so the shader clock reaches steady state")
     ap.add_argument("--workload", default="standard",
                     help="standard (default = the BASELINE metric's config) | lite | feather | nano | a2full | a2lite | lstm1x16 | lstm2x8 | "
@@ -420,6 +494,9 @@ def main():
     batch.Synchronize()  # (outside the timed region: the batch's own bookkeeping of its chains)
     kernel_ms_avg = marks_ms / args.steps  # per STEP (one or two launches)
     launches_per_step = 2 if batch.UsesHalfLaunches() else 1
+    # how a step reached the chip: one ordered launch | two free-running half-batch launches | a command to the resident launch (ONE
+    # dispatch walks all K timed steps: rocprofv3 shows a single long dispatch per timed window, its duration / steps = the step time)
+    launch_mode = "resident" if batch.UsesResidentLaunch() else ("half-batch chains" if batch.UsesHalfLaunches() else "ordered")
 
     # Parity spot check (outside the timed region, on what the timed region left behind): `y` holds the output of the LAST timed step.
     # The first stream of every model of the batch is replayed on the CPU oracle over the tail of its known input history -- one
@@ -504,7 +581,14 @@ def main():
             "clock_ramp": {"ms": args.ramp_ms, "untimed_steps": ramp_steps},
             "kernel_ms_avg": kernel_ms_avg,                       # per step, HIP events over the K timed steps on every launch stream
             "launches_per_step": launches_per_step,               # 2: the step ran as two free-running half-batch launches
+            "launch_mode": launch_mode,
+            "steps_per_dispatch": args.steps if launch_mode == "resident" else 1.0 / launches_per_step,
             "kernel_ms_median_isolated": kernel_ms[len(kernel_ms) // 2],  # a step on its own (bracketed and waited for)
+            # the north star's "per-buffer latency < 1 ms": one buffer of all streams on its own, device pointers in, outputs valid
+            "latency_per_buffer_ms": kernel_ms[len(kernel_ms) // 2],
+            "frac_note": ("roofline.frac is from the library's HIP events around the K timed steps; roofline.frac_wall_clock from the clock `value` "
+                          "is computed from (comparable with a driver's clock around the run; with few steps it carries the fixed cost of "
+                          "opening and closing the timed window)"),
             "output_finite": finite,
             # oracle spot check of the last timed step (one stream per model; tolerance of the north star: 1e-4 RMS)
             "parity_rms": parity["rms"] if parity else None,
@@ -543,6 +627,16 @@ def main():
                 "algorithmic_flops_per_sample": flops_per_sample,
             },
         }
+        if world == 1 and args.workload == "standard" and args.rotate > 0 and BLOCK == 128:
+            try:
+                out["rotation"] = rotation_regime(na, models[0], local_rank, dev, args.rotate, bytes_per_sample)
+                # the stream count the metric asks for comes from THIS regime: all state visited once per buffer, none of it cache-resident
+                out["realtime_streams_48k_cache_resident"] = out["realtime_streams_48k"]
+                out["realtime_streams_48k"] = out["rotation"]["realtime_streams_48k"]
+            except Exception as e:
+                out["rotation"] = {"error": repr(e)}
+        if world == 1 and args.workload == "standard" and not args.no_exact_f32 and BLOCK == 128:
+            out["exact_f32"] = exact_f32_figure(S)
         if world == 1 and not args.no_host_path:
             # per-buffer latency through the host-buffer entry point (pinned staging, H2D, kernel, D2H, stream sync) -- the path a
             # real-time host calls once per audio buffer; outside the timed region, reported next to the north star's "< 1 ms per buffer"

@@ -164,8 +164,8 @@ namespace na
 		std::unique_ptr<ModelGroup> g;
 		if (desc->kind == MODEL_WAVENET) g.reset(new WaveNetGroup(desc, stream, packHint, peerWeights));
 		else if (desc->kind == MODEL_LSTM) g.reset(new LstmGroup(desc, stream, peerWeights));
-		if (peerWeights) awaitingWeights.push_back(g.get());
 		else throw std::runtime_error("neuralaudio_amd: unsupported model kind");
+		if (peerWeights) awaitingWeights.push_back(g.get());
 		groups.push_back(std::move(g));
 		return groups.back().get();
 	}

@@ -121,7 +121,7 @@ def test_multi_rank_rccl_orchestration_runs_on_one_gpu_through_the_loopback_tabl
     lstm = loader.CreateFromFile(_path("BossLSTM-1x16.nam"), doPrewarm=False)
     a2 = loader.CreateFromFile(_path("BossWN-a2.nam"), doPrewarm=False)
     # Standard is cut across the first shards and the LSTM across the last ones: both are replicated; A2 sits in the middle
-    entries = [(std, 60, 1.0), (a2, 16, 0.2), (a2, 16, 1.0), (nano, 40, 1.0), (lstm, 200, 1.0)]
+    entries = [(std, 260, 1.0), (a2, 16, 0.2), (a2, 16, 1.0), (nano, 40, 1.0), (lstm, 120, 1.0)]
     one, multi = na.Batch(0), na.MultiBatch([0] * shards)
     multi.SetFanIn("rccl")
     for m, c, q in entries:
@@ -130,7 +130,7 @@ def test_multi_rank_rccl_orchestration_runs_on_one_gpu_through_the_loopback_tabl
     ranges = multi.ShardRanges()
     S = one.NumStreams()
     assert len(ranges) == shards and ranges[0][0] == 0 and ranges[-1][1] == S
-    assert ranges[0][1] < 60, "the Standard entry must span two shards for the fan-out to have a receiver"
+    assert ranges[0][1] < 260, "the Standard entry must span two shards for the fan-out to have a receiver"
     rng = np.random.default_rng(11)
     for n in (128, 64, 128):
         x = (0.3 * rng.standard_normal((S, n))).clip(-1, 1).astype(np.float32)
