@@ -218,7 +218,7 @@ def parity_spot_check(check_rows, x, y, issued, nbuf, mdir):
     return {"rms": worst, "per_model": per_model}
 
 
-def rotation_regime(na, model, local_rank, dev, n_rot, bytes_per_sample, steps=120, warmup=24):
+def rotation_regime(na, model, local_rank, dev, n_rot, bytes_per_sample, steps=120, warmup=24, resident=False):
     """The metric's own regime: ONE batch of n_rot x 1024 A1 Standard streams, every step visits the whole
     n_rot x 249 MB of ring state once -- nothing survives in the 256 MB Infinity Cache from one step to the next.  Same timed-region
     rules as the headline (library HIP events around the steps, wall clock beside them)."""
@@ -226,6 +226,8 @@ def rotation_regime(na, model, local_rank, dev, n_rot, bytes_per_sample, steps=1
     S = STREAMS_PER_GPU * n_rot
     b = na.Batch(local_rank)
     b.AddStreams(model, S)
+    if resident:
+        b.SetResidentLaunch(True)
     g = torch.Generator(device="cpu").manual_seed(99)
     nbuf = 2
     x = torch.clamp(0.25 * torch.randn(nbuf, S, BLOCK, generator=g), -1.0, 1.0).to(dev)
@@ -285,6 +287,22 @@ def exact_f32_figure(streams):
         return {"error": repr(e)}
 
 
+def resident_launch_figure(streams):
+    """The same step on the same box as commands to the opt-in RESIDENT launch (NA_BatchSetResidentLaunch): sustained
+    step time and the latency of a lone buffer (host clock around post + wait).  Reported beside the default path, never as `value`."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "600", "--warmup", "100", "--ramp-ms", "200", "--streams", str(streams), "--resident",
+           "--no-cpu-baseline", "--no-host-path", "--no-parity-check", "--rotate", "0", "--no-exact-f32"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"launch_mode": j.get("launch_mode"), "ms_per_step": j["kernel_ms_avg"], "frac": j["roofline"]["frac"],
+                "latency_per_buffer_ms": j.get("latency_per_buffer_ms"),
+                "what": "bench.py --resident on the same box, 600 steps: one launch stays on the chip and walks the buffers (commands through a ring in "
+                        "fine-grained device memory); latency = host clock around one NA_BatchProcessDevice + NA_BatchWaitOutputs"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def spawn_ranks(n):
     """`bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU)."""
     import socket
@@ -325,6 +343,8 @@ def main():
                          "state, far outside the 256 MB Infinity Cache -- stepped the same way: the regime of the metric itself (10 k+ "
                          "concurrent real-time streams visit all of their state once per buffer).  Reported as `rotation`; "
                          "realtime_streams_48k is computed from it.  0: skip")
+    ap.add_argument("--resident", action="store_true",
+                    help="opt in to the resident launch (NA_BatchSetResidentLaunch) for the timed batch; default: free-running half-batch chains")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the same-box run of the exact-f32 kernel (NA_WN_KERNEL=frame) that is reported beside `dtype`")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed sustained load before warm-up so the shader clock reaches steady state")
@@ -407,6 +427,8 @@ def main():
     tstream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream handle
     torch.cuda.set_stream(tstream)
     batch = na.Batch(local_rank, hip_stream=tstream.cuda_stream if args.caller_stream else None)
+    if args.resident:
+        batch.SetResidentLaunch(True)
     # The stream list of the workload as (model, quality, count) entries, architecture-sorted.  One GPU (or the headline workload):
     # every rank runs its own S streams (weak scaling).  Mixed workloads on several GPUs: the entries describe the GLOBAL list of
     # S x world streams, which is cut by cost into one contiguous range per rank -- NA_ShardByCost, the C++ host's partition
@@ -509,11 +531,21 @@ def main():
     # diagnostic only (outside the timed region): steps on their own, each bracketed and waited for
     nprobe = min(32, args.steps)
     kernel_ms = []
-    for i in range(nprobe):
-        batch.MarkTime(0)
-        step(i)
-        batch.MarkTime(1)
-        kernel_ms.append(batch.ElapsedMs())
+    if batch.UsesResidentLaunch():
+        # the resident launch has no launch boundary to bracket (a mark would make it leave and come back): post one buffer, wait for its
+        # output rows, host clock around both -- what a real-time caller with ONE buffer in flight sees, command post and completion included
+        batch.WaitOutputs()
+        for i in range(nprobe):
+            t1 = time.perf_counter()
+            step(i)
+            batch.WaitOutputs()
+            kernel_ms.append((time.perf_counter() - t1) * 1e3)
+    else:
+        for i in range(nprobe):
+            batch.MarkTime(0)
+            step(i)
+            batch.MarkTime(1)
+            kernel_ms.append(batch.ElapsedMs())
     batch.Synchronize()
     torch.cuda.synchronize(dev)
     kernel_ms.sort()
@@ -629,7 +661,7 @@ def main():
         }
         if world == 1 and args.workload == "standard" and args.rotate > 0 and BLOCK == 128:
             try:
-                out["rotation"] = rotation_regime(na, models[0], local_rank, dev, args.rotate, bytes_per_sample)
+                out["rotation"] = rotation_regime(na, models[0], local_rank, dev, args.rotate, bytes_per_sample, resident=args.resident)
                 # the stream count the metric asks for comes from THIS regime: all state visited once per buffer, none of it cache-resident
                 out["realtime_streams_48k_cache_resident"] = out["realtime_streams_48k"]
                 out["realtime_streams_48k"] = out["rotation"]["realtime_streams_48k"]
@@ -637,6 +669,8 @@ def main():
                 out["rotation"] = {"error": repr(e)}
         if world == 1 and args.workload == "standard" and not args.no_exact_f32 and BLOCK == 128:
             out["exact_f32"] = exact_f32_figure(S)
+            if not args.resident and not args.caller_stream:
+                out["resident_launch"] = resident_launch_figure(S)
         if world == 1 and not args.no_host_path:
             # per-buffer latency through the host-buffer entry point (pinned staging, H2D, kernel, D2H, stream sync) -- the path a
             # real-time host calls once per audio buffer; outside the timed region, reported next to the north star's "< 1 ms per buffer"

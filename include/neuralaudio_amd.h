@@ -100,9 +100,9 @@ NA_EXTERN const float* NA_BatchOutputView(NA_Batch* batch, int ticket);
  *     pipeline without any host wait.
  *
  * (b) the batch created its own stream (hipStream == NULL) and nobody has fetched it: the library schedules the buffer itself -- as
- *     two free-running launches of half the streams each on internal streams, or, for large A1 Standard batches, as a command to ONE
- *     resident launch that stays on the chip and walks consecutive buffers (csrc/gpu_batch_chains.cpp) -- none of which is ordered
- *     against any stream the caller knows.  The contract is then a HOST-side one:
+ *     two free-running launches of half the streams each on internal streams, or, where NA_BatchSetResidentLaunch asked for it, for
+ *     large A1 Standard batches as a command to ONE resident launch that stays on the chip and walks consecutive buffers
+ *     (csrc/gpu_batch_chains.cpp) -- none of which is ordered against any stream the caller knows.  The contract is then a HOST-side one:
  *       - the input rows must be COMPLETE in device memory when NA_BatchProcessDevice is called (synchronise their producer first:
  *         hipStreamSynchronize / hipEventSynchronize on its stream) and must stay untouched until the step's outputs are valid;
  *       - the output rows are valid after NA_BatchWaitOutputs (cheap: the resident launch stays up) or NA_BatchSynchronize (everything
@@ -127,7 +127,12 @@ NA_EXTERN int NA_BatchWaitMarks(NA_Batch* batch); /* polls until the second mark
 NA_EXTERN float NA_BatchElapsedMs(NA_Batch* batch);
 /* 1: the last NA_BatchProcessDevice call ran as two half-batch launches (see NA_BatchGetHipStream) */
 NA_EXTERN int NA_BatchUsesHalfLaunches(NA_Batch* batch);
-/* 1: the last NA_BatchProcessDevice call was a command to the resident launch (contract (b) above; NA_RESIDENT=0 turns it off) */
+/* Opt-in (off unless the environment says NA_RESIDENT=1): device-pointer buffers of a batch on its own stream whose streams are >= 512
+   A1 Standard models become commands to one resident launch (contract (b) above).  Measured on MI355X: per-buffer
+   latency of a lone buffer 41 - 44 us instead of 43 - 48, sustained throughput 38.5 - 39.7 us per 1024 x 128 step instead of 36.6 -- the
+   chip is power-limited on this kernel, so keeping every slot busy buys clock throttling, not throughput.  0 on success. */
+NA_EXTERN int NA_BatchSetResidentLaunch(NA_Batch* batch, int on);
+/* 1: the last NA_BatchProcessDevice call was a command to the resident launch */
 NA_EXTERN int NA_BatchUsesResidentLaunch(NA_Batch* batch);
 /* roofline bookkeeping (stream-weighted means): compulsory HBM bytes and multiply-accumulates per sample */
 NA_EXTERN double NA_BatchAlgorithmicBytesPerSample(NA_Batch* batch, int blockFrames);

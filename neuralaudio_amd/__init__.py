@@ -317,6 +317,11 @@ class Batch:
         if self._lib.NA_BatchWaitOutputs(self._h) != 0:
             raise NeuralAudioError(capi.last_error())
 
+    def SetResidentLaunch(self, on=True):
+        """Opt in to (or out of) the resident launch for device-pointer buffers of this batch (NA_BatchSetResidentLaunch)."""
+        if self._lib.NA_BatchSetResidentLaunch(self._h, 1 if on else 0) != 0:
+            raise NeuralAudioError(capi.last_error())
+
     def UsesResidentLaunch(self):
         """True when the last ProcessDevice call was a command to the resident launch (own stream, >= 512 A1 Standard streams)."""
         return bool(self._lib.NA_BatchUsesResidentLaunch(self._h))

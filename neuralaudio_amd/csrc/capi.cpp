@@ -503,6 +503,11 @@ float NA_BatchElapsedMs(NA_Batch* batch)
 }
 
 int NA_BatchUsesHalfLaunches(NA_Batch* batch) { return batch && batch->batch->UsesHalfLaunches() ? 1 : 0; }
+int NA_BatchSetResidentLaunch(NA_Batch* batch, int on)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->SetResidentLaunch(on != 0); });
+}
 int NA_BatchUsesResidentLaunch(NA_Batch* batch) { return batch && batch->batch->UsesResidentLaunch() ? 1 : 0; }
 
 int NA_BatchWaitOutputs(NA_Batch* batch)

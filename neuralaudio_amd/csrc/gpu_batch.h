@@ -16,6 +16,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "model_loader.h"
+#include "tuning.h"
 
 namespace na
 {
@@ -142,6 +143,9 @@ namespace na
 		// streams): MarkTime(0) ... launches ... MarkTime(1); ElapsedMs() = the longest mark-to-mark span over those streams (after a
 		// Synchronize()).  The caller's own events only see the stream it handed in.
 		bool UsesHalfLaunches() const { return lastStepHalves; }
+		// Opt-in (default: Tuning residentOn = NA_RESIDENT=1): large A1 Standard batches on the batch's own stream run as commands to ONE
+		// launch that stays on the chip (gpu_batch_chains.cpp) instead of two free-running half-batch launches per buffer.
+		void SetResidentLaunch(bool on);
 		bool UsesResidentLaunch() const { return lastStepResident; } // the last device-pointer buffer went through the resident launch
 		void MarkTime(int which);
 		void WaitMarks(); // polls until the marks of MarkTime(1) are reached on every stream
@@ -250,6 +254,7 @@ namespace na
 		struct ResidentState;
 		std::unique_ptr<ResidentState> residentState;
 		bool lastStepResident = false;
+		bool residentWanted = Tuning::Get().residentOn;
 		bool TryResident(const float* dIn, float* dOut, size_t n, long inStride, long outStride);
 		bool ResidentConfigure();
 		void ResidentEnsureRunning();

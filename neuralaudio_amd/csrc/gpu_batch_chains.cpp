@@ -6,6 +6,7 @@
 //     memory (wavenet_launch.h ResidentCtrl, wavenet_spec_impl.h WaveNetSpecResidentKernel);
 // and the timing marks bench.py brackets its steps with.  Part of class GpuBatch (gpu_batch.h).
 #include "gpu_batch_internal.h"
+#include <immintrin.h>
 
 namespace na
 {
@@ -25,7 +26,13 @@ namespace na
 		constexpr unsigned long long kNever = ~0ull;
 
 		unsigned long long HostLoad(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-		void HostStore(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+		// a word for the launch: the block may be device memory behind the BAR (write-combined on the host side) -- the fence pushes the
+		// store, and everything written before it, out of the core's write-combining buffers
+		void HostStore(unsigned long long* p, unsigned long long v)
+		{
+			__atomic_store_n(p, v, __ATOMIC_RELEASE);
+			_mm_sfence();
+		}
 	}
 
 	// (re)starts the launch of the current generation unless one is still on the stream
@@ -40,10 +47,12 @@ namespace na
 		}
 		ResidentArgs ra = {};
 		ra.ctrl = r.dCtrl;
+		ra.status = r.dStatus;
 		ra.doneCount = r.dDone;
 		ra.wgDone = r.dWgDone;
 		ra.base = r.base;
 		ra.idleTicks = (unsigned)std::max(1, Tuning::Get().residentIdleUs) * 100u; // s_memrealtime: 100 MHz
+		ra.startDelay = (unsigned)std::max(0, Tuning::Get().residentDelayUs) * 100u;
 		int grid = 0;
 		CheckHip(LaunchWaveNetSpecResident(r.list.data(), (int)r.list.size(), WN_MAX_FRAMES, ra, stream, &grid), "WaveNet resident launch");
 		if (grid != r.grid) throw std::runtime_error("neuralaudio_amd: internal: resident grid changed inside a generation");
@@ -89,10 +98,27 @@ namespace na
 		if (grid < 1) return false;
 		if (!r.ctrl)
 		{
-			CheckHip(hipHostMalloc(reinterpret_cast<void**>(&r.ctrl), sizeof(ResidentCtrl), hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc (command ring)");
-			memset(r.ctrl, 0, sizeof(ResidentCtrl));
-			r.ctrl->exitAfter = kNever;
-			CheckHip(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.dCtrl), r.ctrl, 0), "hipHostGetDevicePointer");
+			// the command block: device memory the host can write, where the BAR covers it (wavenet_launch.h ResidentCtrl)
+			int largeBar = 0;
+			if (!Tuning::Get().residentHostRing && hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && largeBar &&
+				hipExtMallocWithFlags(reinterpret_cast<void**>(&r.ctrl), sizeof(ResidentCtrl), hipDeviceMallocFinegrained) == hipSuccess)
+			{
+				r.ctrlInDeviceMemory = true;
+				r.dCtrl = r.ctrl;
+				memset(r.ctrl, 0, sizeof(ResidentCtrl)); // (through the BAR)
+			}
+			else
+			{
+				(void)hipGetLastError();
+				r.ctrl = nullptr;
+				CheckHip(hipHostMalloc(reinterpret_cast<void**>(&r.ctrl), sizeof(ResidentCtrl), hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc (command ring)");
+				memset(r.ctrl, 0, sizeof(ResidentCtrl));
+				CheckHip(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.dCtrl), r.ctrl, 0), "hipHostGetDevicePointer");
+			}
+			HostStore(&r.ctrl->exitAfter, kNever);
+			CheckHip(hipHostMalloc(reinterpret_cast<void**>(&r.status), sizeof(ResidentStatus), hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc (resident status)");
+			memset(r.status, 0, sizeof(ResidentStatus));
+			CheckHip(hipHostGetDevicePointer(reinterpret_cast<void**>(&r.dStatus), r.status, 0), "hipHostGetDevicePointer");
 			CheckHip(hipMalloc(reinterpret_cast<void**>(&r.dDone), RESIDENT_RING * sizeof(unsigned)), "hipMalloc");
 			CheckHip(hipMemsetAsync(r.dDone, 0, RESIDENT_RING * sizeof(unsigned), stream), "hipMemsetAsync");
 		}
@@ -114,7 +140,7 @@ namespace na
 	// The buffer through the resident launch; false: not this batch / this buffer (the caller runs it the other ways).
 	bool GpuBatch::TryResident(const float* dIn, float* dOut, size_t n, long inStride, long outStride)
 	{
-		if (Tuning::Get().residentOff || n % (size_t)WN_MAX_FRAMES != 0) return false;
+		if (!residentWanted || n % (size_t)WN_MAX_FRAMES != 0) return false;
 		if (!residentState) residentState.reset(new ResidentState());
 		ResidentState& r = *residentState;
 		bool dirty = false;
@@ -130,19 +156,27 @@ namespace na
 		{
 			const unsigned long long seq = r.posted + 1;
 			// back-pressure: a slot (and its done counter) is free once the command RESIDENT_RING before it has completed
-			while (seq - HostLoad(&r.ctrl->completed) >= (unsigned long long)RESIDENT_RING - 1) ResidentEnsureRunning();
+			while (seq - HostLoad(&r.status->completed) >= (unsigned long long)RESIDENT_RING - 1) ResidentEnsureRunning();
+			// (write-only on this side: the block may be device memory behind the BAR)
 			ResidentCmd& c = r.ctrl->cmd[seq % RESIDENT_RING];
 			c.in = dIn + offset;
 			c.out = dOut + offset;
 			c.inStride = inStride;
 			c.outStride = outStride;
-			HostStore(&c.seq, seq); // (release: the fields first)
+			c.check = ResidentCmdCheck((unsigned long long)(size_t)(dIn + offset), (unsigned long long)(size_t)(dOut + offset), (unsigned long long)inStride, (unsigned long long)outStride, seq);
+			HostStore(&c.seq, seq);
 			r.posted = seq;
 			ResidentEnsureRunning();
 		}
 		lastStepHalves = false;
 		lastStepResident = true;
 		return true;
+	}
+
+	void GpuBatch::SetResidentLaunch(bool on)
+	{
+		if (!on) DrainResident();
+		residentWanted = on;
 	}
 
 	// Every posted command has run and the launch has left the chip; the next command starts a new generation.
@@ -157,7 +191,7 @@ namespace na
 		{
 			if (r.launched) CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize (resident launch)");
 			r.launched = false;
-			if (HostLoad(&r.ctrl->completed) >= r.posted) break;
+			if (HostLoad(&r.status->completed) >= r.posted) break;
 			ResidentEnsureRunning(); // (it idled out, or left at an earlier exit mark, before it saw the last commands: once more)
 		}
 		HostStore(&r.ctrl->exitAfter, kNever);
@@ -173,7 +207,7 @@ namespace na
 		{
 			// (the launch stays up: only its done count is awaited -- and it goes in again should it have idled out early)
 			ResidentState& r = *residentState;
-			while (HostLoad(&r.ctrl->completed) < r.posted) ResidentEnsureRunning();
+			while (HostLoad(&r.status->completed) < r.posted) ResidentEnsureRunning();
 			return;
 		}
 		if (halfChainsUsed)
@@ -191,7 +225,7 @@ namespace na
 		HostStore(&r.ctrl->exitAfter, r.posted);
 		r.exitRequested = true;
 		r.markPosted = r.posted;
-		if (HostLoad(&r.ctrl->completed) < r.posted) ResidentEnsureRunning();
+		if (HostLoad(&r.status->completed) < r.posted) ResidentEnsureRunning();
 	}
 
 	// the ONE helper behind every entry point that touches stream state, index lists or device allocations
@@ -370,7 +404,7 @@ namespace na
 	{
 		if (!residentState || !residentState->exitRequested) return;
 		ResidentState& r = *residentState;
-		while (HostLoad(&r.ctrl->completed) < r.markPosted)
+		while (HostLoad(&r.status->completed) < r.markPosted)
 		{
 			ResidentEnsureRunning();
 			if (marks[0][1]) CheckHip(hipEventRecord(marks[0][1], stream), "hipEventRecord");

@@ -24,8 +24,13 @@ namespace na
 	// the resident launch of a batch (gpu_batch_chains.cpp): command ring, counters, the launch list it was started with
 	struct GpuBatch::ResidentState
 	{
-		ResidentCtrl* ctrl = nullptr;  // pinned, coherent host block ...
-		ResidentCtrl* dCtrl = nullptr; // ... and its device address
+		// host -> device words: fine-grained device memory written by the host through the BAR (one address for both sides); without a
+		// large BAR a pinned, coherent host block (`ctrl` its host address, `dCtrl` its device address: the workgroups then poll over PCIe)
+		ResidentCtrl* ctrl = nullptr;
+		ResidentCtrl* dCtrl = nullptr;
+		bool ctrlInDeviceMemory = false;
+		ResidentStatus* status = nullptr;  // device -> host word: pinned, coherent host block ...
+		ResidentStatus* dStatus = nullptr; // ... and its device address
 		unsigned* dDone = nullptr;     // [RESIDENT_RING]
 		unsigned* dWgDone = nullptr;   // [wgCapacity]
 		int wgCapacity = 0;
@@ -45,7 +50,8 @@ namespace na
 			if (gen) (void)hipEventDestroy(gen);
 			if (dDone) (void)hipFree(dDone);
 			if (dWgDone) (void)hipFree(dWgDone);
-			if (ctrl) (void)hipHostFree(ctrl);
+			if (ctrl) (void)(ctrlInDeviceMemory ? hipFree(ctrl) : hipHostFree(ctrl));
+			if (status) (void)hipHostFree(status);
 		}
 	};
 

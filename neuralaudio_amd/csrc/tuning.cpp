@@ -51,7 +51,10 @@ namespace na
 			t.hostHalvesOff = IsZero("NA_HOST_HALVES");
 			t.hostDirect = !IsZero("NA_HOST_DIRECT");
 			t.batchSerial = Has("NA_BATCH_SERIAL");
-			t.residentOff = IsZero("NA_RESIDENT");
+			t.residentOn = Int("NA_RESIDENT", 0) != 0;
+			t.residentHostRing = Int("NA_RESIDENT_HOST_RING", 0) != 0;
+			t.residentDelayUs = Int("NA_RESIDENT_DELAY_US", 0);
+			t.residentGrid = Int("NA_RESIDENT_GRID", 0);
 			t.residentIdleUs = Int("NA_RESIDENT_IDLE_US", 200);
 #endif
 			return t;

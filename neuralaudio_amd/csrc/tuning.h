@@ -37,7 +37,10 @@ namespace na
 		bool hostHalvesOff = false; // NA_HOST_HALVES=0
 		bool hostDirect = true;    // NA_HOST_DIRECT=0: copy engines instead of kernels on the pinned block
 		bool batchSerial = false;  // NA_BATCH_SERIAL
-		bool residentOff = false;  // NA_RESIDENT=0: no resident launch (free-running chains instead)
+		bool residentOn = false;   // NA_RESIDENT=1: batches start with the resident launch enabled (NA_BatchSetResidentLaunch; default: free-running chains)
+		bool residentHostRing = false; // NA_RESIDENT_HOST_RING=1: the command ring in pinned host memory even where the BAR maps device memory
+		int residentDelayUs = 0;   // NA_RESIDENT_DELAY_US: start offset of the second workgroup of every CU inside the resident launch
+		int residentGrid = 0;      // NA_RESIDENT_GRID: at most this many workgroups in the resident launch (0: as many as are resident)
 		int residentIdleUs = 200;  // NA_RESIDENT_IDLE_US: a resident workgroup leaves after this long without a command
 
 		static const Tuning& Get();

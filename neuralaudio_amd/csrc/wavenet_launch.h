@@ -39,37 +39,54 @@ namespace na
 	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream, int sharing = 1);
 	// ---- resident ("persistent") launches of the specialised chains (wavenet_spec_impl.h WaveNetSpecResidentKernel) --------------
-	// One launch stays on the chip and walks consecutive buffers by itself: the host posts a command per buffer into a ring in pinned,
-	// coherent host memory (fields first, then `seq`), every workgroup polls the command it needs next, runs its streams' block and
-	// counts itself done.  Workgroups never wait for each other -- only for the host -- so the launch is live whatever part of its
-	// grid is resident, and a workgroup that finds no command for `idleTicks` (or has reached `exitAfter`) leaves; the host relaunches
-	// when there is work again (gpu_batch_resident.cpp).
+	// One launch stays on the chip and walks consecutive buffers by itself: the host posts a command per buffer into a ring, every
+	// workgroup polls the command it needs next, runs its streams' block and counts itself done.  Workgroups never wait for each other
+	// -- only for the host -- so the launch is live whatever part of its grid is resident, and a workgroup that finds no command for
+	// `idleTicks` (or has reached `exitAfter`) leaves; the host relaunches when there is work again (gpu_batch_chains.cpp).
+	// Where the words live (tools/microbench/resident_cmd_probe.hip, profiles/r05_microbench_resident_cmd_probe.txt): 512 workgroups
+	// polling a ring in pinned HOST memory cost 34 - 700 us per command when they all wait and 6 us per command behind 30 us of work
+	// (two dependent PCIe round trips each); a ring in fine-grained DEVICE memory that the host writes through the BAR costs 1.7 us.
+	// So host -> device words (commands, exitAfter) are in device memory, the one device -> host word (`completed`) in host memory:
+	// nobody ever polls across PCIe.
 	constexpr int RESIDENT_RING = 64; // commands in flight at most (host-side back-pressure)
 	struct ResidentCmd
 	{
 		const float* in;
 		float* out;
 		long inStride, outStride;
-		unsigned long long seq; // written LAST by the host: the command with this sequence number is complete in memory
-		unsigned long long pad[3];
+		unsigned long long seq;   // the command's sequence number ...
+		unsigned long long check; // ... and ResidentCmdCheck of the five words above: a torn read of the line does not pass
+		unsigned long long pad[2];
 	};
-	struct ResidentCtrl // pinned host memory (hipHostMallocCoherent | Mapped)
+#ifdef __HIPCC__
+	__host__ __device__
+#endif
+	inline unsigned long long ResidentCmdCheck(unsigned long long in, unsigned long long out, unsigned long long inStride, unsigned long long outStride, unsigned long long seq)
 	{
-		unsigned long long exitAfter; // host -> device: workgroups leave once they have run this sequence number
+		return seq * 0x9E3779B97F4A7C15ull + in * 0xC2B2AE3D27D4EB4Full + out * 0x165667B19E3779F9ull + inStride * 0xD6E8FEB86659FD93ull + outStride * 0xFF51AFD7ED558CCDull + 1ull;
+	}
+	struct ResidentCtrl // host -> device: fine-grained device memory the host writes through the BAR (pinned host memory without a large BAR)
+	{
+		unsigned long long exitAfter; // workgroups leave once they have run this sequence number
 		unsigned long long pad0[7];
-		unsigned long long completed; // device -> host: every workgroup has run the commands up to this one
-		unsigned long long pad1[7];
 		ResidentCmd cmd[RESIDENT_RING];
 	};
-	static_assert(sizeof(ResidentCmd) == 64 && sizeof(ResidentCtrl) == 128 + 64 * RESIDENT_RING, "command ring layout");
+	struct ResidentStatus // device -> host: pinned host memory
+	{
+		unsigned long long completed; // every workgroup has run the commands up to this one
+		unsigned long long pad1[7];
+	};
+	static_assert(sizeof(ResidentCmd) == 64 && sizeof(ResidentCtrl) == 64 + 64 * RESIDENT_RING && sizeof(ResidentStatus) == 64, "command ring layout");
 	struct ResidentArgs
 	{
-		ResidentCtrl* ctrl;           // device address of the pinned block
+		const ResidentCtrl* ctrl;     // device address of the command block
+		ResidentStatus* status;       // device address of the pinned status block
 		unsigned* doneCount;          // [RESIDENT_RING] device memory: workgroups that have run command seq (slot seq % RESIDENT_RING)
 		unsigned* wgDone;             // [grid] device memory: commands this workgroup has run since `base` (a relaunch resumes there)
 		unsigned long long base;      // sequence number of the last command before this generation of launches
 		int numBlocks;                // workgroups' worth of streams per command: workgroup b runs blocks b, b + grid, ...
 		unsigned idleTicks;           // s_memrealtime ticks (100 MHz) without a command after which a workgroup leaves
+		unsigned startDelay;          // ticks the second half of the grid (the second workgroup of every CU) waits before its first command
 	};
 	// Starts (or restarts) the resident launch of a launch list that LaunchWaveNetSpecFused would run as ONE launch of 128-frame blocks;
 	// hipErrorNotSupported otherwise.  grid = min(workgroups of the list, what is resident at the kernel's occupancy); *gridOut says how

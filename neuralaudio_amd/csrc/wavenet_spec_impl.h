@@ -1243,7 +1243,11 @@ namespace na
 		// workgroup, so the launch makes progress with any part of its grid resident.
 		template <class F, int NF, int SPB, bool PK>
 		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(OccOf<F, NF, SPB>()))) WaveNetSpecResidentKernel(const LaunchArgs args,
-			const ResidentArgs ra)
+			const ResidentArgs ra
+#ifdef NA_SP_TRACE
+			, long long* __restrict__ trace, int traceBlock // (row NSTAGES of the stamps: 0 / 1 block entry / exit, 2 closing barrier passed, 3 command taken, 4 closing barrier of the block before)
+#endif
+			)
 		{
 			typedef Cfg<typename F::A0, NF, SPB, PK, true> C;
 			typedef Cfg<typename F::A1, NF, SPB, PK, true> C1;
@@ -1260,6 +1264,13 @@ namespace na
 			{
 				bc[5] = ra.base + ra.wgDone[blockIdx.x];
 				bc[6] = ~0ull;
+				// the second workgroup of every CU starts late, once: next to a partner in another phase of the chain a workgroup runs faster
+				// (its issue-bound stages beside the partner's memory-bound ones), and inside ONE launch the offset is paid once, not per buffer
+				if (ra.startDelay > 0 && 2 * blockIdx.x >= gridDim.x)
+				{
+					const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+					while (__builtin_amdgcn_s_memrealtime() - t0 < ra.startDelay) __builtin_amdgcn_s_sleep(16);
+				}
 			}
 			for (;;)
 			{
@@ -1274,42 +1285,47 @@ namespace na
 					if (blk >= 0) blk += (long)gridDim.x;
 					if (blk < 0 || blk >= (long)r.numBlocks)
 					{
-						if (blk >= 0)
+						// (the last block of command k + 1 is done: every wave's stores have left it -- the closing wait + barrier below)
+						const bool finished = blk >= 0;
+						if (finished) k++;
+						const unsigned slot = (unsigned)(k % RESIDENT_RING);
+						if (finished) __hip_atomic_store(&r.wgDone[blockIdx.x], (unsigned)(k - r.base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						// The first look at the next command and the done count of the last one travel together: one round trip to device
+						// memory.  A command is six words of one line written by the host through the BAR; it is taken when its sequence
+						// number and its check word agree with what was read (a torn or stale line does not pass and is read again).
+						const ResidentCmd* cmd = &r.ctrl->cmd[(k + 1) % RESIDENT_RING];
+						auto word = [](const void* p) { return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+						unsigned long long cIn = word(&cmd->in), cOut = word(&cmd->out), cIs = word(&cmd->inStride), cOs = word(&cmd->outStride);
+						unsigned long long cSeq = word(&cmd->seq), cChk = word(&cmd->check);
+						if (finished)
 						{
-							// the last block of command k + 1 is done (every wave's stores have left it: the closing wait + barrier below)
-							k++;
-							const unsigned slot = (unsigned)(k % RESIDENT_RING);
-							__hip_atomic_store(&r.wgDone[blockIdx.x], (unsigned)(k - r.base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							const unsigned before = __hip_atomic_fetch_add(&r.doneCount[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							if (before == gridDim.x - 1)
 							{
 								// the last workgroup of command k: the slot's counter is free again (the host does not reuse the slot before it
 								// has seen `completed`), and the host may read the output rows
 								__hip_atomic_store(&r.doneCount[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-								__hip_atomic_store(&r.ctrl->completed, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+								__hip_atomic_store(&r.status->completed, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 							}
 						}
-						const ResidentCmd* cmd = &r.ctrl->cmd[(k + 1) % RESIDENT_RING];
 						const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-						while (__hip_atomic_load(&cmd->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != k + 1)
+						bool leaving = false;
+						while (cSeq != k + 1 || cChk != ResidentCmdCheck(cIn, cOut, cIs, cOs, cSeq))
 						{
-							// nothing to do: told to leave behind command k, or idle for too long (the host relaunches when there is work)
-							if (__hip_atomic_load(&r.ctrl->exitAfter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) <= k ||
-								__builtin_amdgcn_s_memrealtime() - t0 > r.idleTicks)
-							{
-								// (a command posted in between is not lost: the relaunch resumes at wgDone)
-								go = __hip_atomic_load(&cmd->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == k + 1 ? 1 : 0;
-								break;
-							}
-							__builtin_amdgcn_s_sleep(8);
+							if (leaving) { go = 0; break; } // (a command posted from now on is not lost: the relaunch resumes at wgDone)
+							// nothing to do: told to leave behind command k, or idle for too long (the host relaunches when there is work) -- after
+							// one more look
+							leaving = word(&r.ctrl->exitAfter) <= k || __builtin_amdgcn_s_memrealtime() - t0 > r.idleTicks;
+							if (!leaving) __builtin_amdgcn_s_sleep(4);
+							cIn = word(&cmd->in), cOut = word(&cmd->out), cIs = word(&cmd->inStride), cOs = word(&cmd->outStride);
+							cSeq = word(&cmd->seq), cChk = word(&cmd->check);
 						}
 						if (go)
 						{
-							// (the host wrote the fields before `seq`; these loads are issued after the one that saw it)
-							bc[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&cmd->in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-							bc[2] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&cmd->out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-							bc[3] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&cmd->inStride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-							bc[4] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&cmd->outStride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+							bc[1] = cIn;
+							bc[2] = cOut;
+							bc[3] = cIs;
+							bc[4] = cOs;
 						}
 						blk = (long)blockIdx.x;
 					}
@@ -1339,8 +1355,14 @@ namespace na
 					asm volatile("" : "+v"(tid));
 					const int groupBlock = blk - ga.firstBlock;
 #ifdef NA_SP_TRACE
-					if (F::N > 1 && ga.arch == 1) RunWorkgroup<C1>(ga, groupBlock, in, out, inStride, outStride, nullptr, tid);
-					else RunWorkgroup<C>(ga, groupBlock, in, out, inStride, outStride, nullptr, tid);
+					long long* tr = ((int)blockIdx.x == traceBlock) ? trace : nullptr;
+					if (tr != nullptr && threadIdx.x == 0)
+					{
+						tr[(C::TB::NSTAGES * 8 + 4) * (C::NTHREADS / 64)] = tr[(C::TB::NSTAGES * 8 + 2) * (C::NTHREADS / 64)]; // (the closing barrier of the block before)
+						tr[(C::TB::NSTAGES * 8 + 3) * (C::NTHREADS / 64)] = (long long)__builtin_readcyclecounter();
+					}
+					if (F::N > 1 && ga.arch == 1) RunWorkgroup<C1>(ga, groupBlock, in, out, inStride, outStride, tr, tid);
+					else RunWorkgroup<C>(ga, groupBlock, in, out, inStride, outStride, tr, tid);
 #else
 					if (F::N > 1 && ga.arch == 1) RunWorkgroup<C1>(ga, groupBlock, in, out, inStride, outStride, tid);
 					else RunWorkgroup<C>(ga, groupBlock, in, out, inStride, outStride, tid);
@@ -1349,6 +1371,9 @@ namespace na
 				// every wave's ring stores, cursors and output rows have left the wave before the next block / the done count
 				__builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
 				BlockBarrier<C::NTHREADS / 64>();
+#ifdef NA_SP_TRACE
+				if ((int)blockIdx.x == traceBlock && trace != nullptr && threadIdx.x == 0) trace[(C::TB::NSTAGES * 8 + 2) * (C::NTHREADS / 64)] = (long long)__builtin_readcyclecounter();
+#endif
 			}
 		}
 
@@ -1474,12 +1499,17 @@ namespace na
 			});
 			if (e != hipSuccess) return e;
 			const int resident = perCU[device].load() * CurrentDeviceCUs();
-			const int grid = std::min(blocks, resident);
+			int grid = std::min(blocks, resident);
+			if (Tuning::Get().residentGrid > 0) grid = std::min(grid, Tuning::Get().residentGrid);
 			*gridOut = grid;
 			if (grid < 1) return hipErrorInvalidValue;
 			if (stream == nullptr) return hipSuccess;
 			ra.numBlocks = blocks;
-			hipLaunchKernelGGL((WaveNetSpecResidentKernel<F, NF, SPB, PK>), dim3((unsigned)grid), dim3(C::NTHREADS), LDS_BYTES, stream, args, ra);
+			hipLaunchKernelGGL((WaveNetSpecResidentKernel<F, NF, SPB, PK>), dim3((unsigned)grid), dim3(C::NTHREADS), LDS_BYTES, stream, args, ra
+#ifdef NA_SP_TRACE
+				, GetWaveNetTraceBuffer(), Tuning::Get().traceBlock
+#endif
+				);
 			return hipGetLastError();
 		}
 

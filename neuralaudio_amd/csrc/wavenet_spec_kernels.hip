@@ -40,28 +40,6 @@ namespace na
 		return WN_SPEC_NONE;
 	}
 
-	// The resident launch (wavenet_split_dev.h ResidentCtrl) of a list that is ONE launch of full-size workgroups: 128-frame blocks of A1
-	// Standard streams (the headline workload; the other families keep their ordinary launches for now).  stream == nullptr: grid only.
-	static hipError_t ResidentDispatch(const WnFrameGroup* groups, int numGroups, int n, const ResidentArgs& ra, hipStream_t stream, int* gridOut)
-	{
-		*gridOut = 0;
-		if (numGroups <= 0 || numGroups > WN_FRAME_MAX_GROUPS || n != 128 || !WaveNetSpecEnabled()) return hipErrorNotSupported;
-		for (int i = 0; i < numGroups; i++)
-			if (groups[i].model->spec_arch != WN_SPEC_STD || groups[i].pack > 1 || groups[i].numStreams <= 0) return hipErrorNotSupported;
-		return spk::LaunchResident<spk::FamStd, 128, 2, false>(groups, numGroups, ra, stream, gridOut);
-	}
-	hipError_t LaunchWaveNetSpecResident(const WnFrameGroup* groups, int numGroups, int n, const ResidentArgs& ra, hipStream_t stream, int* gridOut)
-	{
-		if (stream == nullptr) return hipErrorInvalidValue; // (the null stream would serialise the launch behind everything)
-		return ResidentDispatch(groups, numGroups, n, ra, stream, gridOut);
-	}
-	int WaveNetSpecResidentGrid(const WnFrameGroup* groups, int numGroups, int n)
-	{
-		int grid = 0;
-		ResidentArgs none = {};
-		return ResidentDispatch(groups, numGroups, n, none, nullptr, &grid) == hipSuccess ? grid : 0;
-	}
-
 	// Runs the launch on a specialised chain when every group is the SAME official architecture and the block is 128 / 64 / 32 frames;
 	// returns hipErrorNotSupported otherwise (the caller then uses the stage interpreter).
 	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,

@@ -1,5 +1,6 @@
-"""The resident launch (csrc/gpu_batch_chains.cpp, wavenet_spec_impl.h WaveNetSpecResidentKernel): for a large A1 Standard batch on the
-batch's own stream NA_BatchProcessDevice posts a command to ONE launch that stays on the chip and walks consecutive buffers.  Reference
+"""The resident launch (csrc/gpu_batch_chains.cpp, wavenet_spec_impl.h WaveNetSpecResidentKernel; opt-in: NA_BatchSetResidentLaunch): for a
+large A1 Standard batch on the batch's own stream NA_BatchProcessDevice posts a command to ONE launch that stays on the chip and walks
+consecutive buffers.  Reference
 arithmetic: WaveNetModelT::Process (NeuralAudio/WaveNet.h:768-799) per stream and buffer -- the launch mechanics must not change a bit
 of it: every test compares with ordered one-shot launches of the same chain (a batch on the caller's stream)."""
 import os
@@ -42,6 +43,7 @@ def _pair(na, std, S):
     ref, b = na.Batch(0, hip_stream=ts.cuda_stream), na.Batch(0)
     ref.AddStreams(std, S)
     b.AddStreams(std, S)
+    b.SetResidentLaunch(True)  # (opt-in: the default for such a batch is two free-running half-batch launches)
     return ts, ref, b
 
 
@@ -91,6 +93,7 @@ dev = torch.device("cuda", 0)
 ts = torch.cuda.Stream(device=dev)          # the producer / consumer stream (foreign to the resident batch)
 ref, b = na.Batch(0, hip_stream=ts.cuda_stream), na.Batch(0)
 ref.AddStreams(std, S); b.AddStreams(std, S)
+b.SetResidentLaunch(True)
 g = torch.Generator(device="cpu").manual_seed(8)
 src = torch.clamp(0.3 * torch.randn(steps, S, n, generator=g), -1.0, 1.0).to(dev)
 x = torch.zeros(S, n, device=dev)            # ONE input buffer, rewritten on the device before every step
@@ -185,6 +188,7 @@ def test_timing_marks_bracket_the_resident_steps(na, std):
     y = torch.zeros(S, n, device=dev)
     b = na.Batch(0)
     b.AddStreams(std, S)
+    b.SetResidentLaunch(True)
     torch.cuda.synchronize(dev)
     for _ in range(2):
         b.MarkTime(0)

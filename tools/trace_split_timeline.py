@@ -31,6 +31,10 @@ capi.load_library().NA_DebugSetTraceBuffer(None)
 t = trace.cpu().numpy().astype(np.float64).reshape(nst + 1, 8, waves)
 t0, t1 = t[nst, 0].min(), t[nst, 1].max()
 print("kernel entry -> exit of the traced workgroup: %.0f cycles" % (t1 - t0))
+if t[nst, 3, 0] > 0:  # resident launch (stamps of the LAST block the traced workgroup ran; 2 = the closing barrier of the block before it)
+    print("resident launch: command taken -> block entry %.0f cycles; block exit -> closing barrier %.0f; closing barrier of the previous block -> command taken %.0f"
+          % (t0 - t[nst, 3, 0], t[nst, 2, 0] - t1, t[nst, 3, 0] - t[nst, 4, 0] if t[nst, 4, 0] > 0 else float("nan")))
+    print("block period of the traced workgroup (closing barrier to closing barrier): %.0f cycles" % (t[nst, 2, 0] - t[nst, 4, 0]))
 print("stage  start    conv   activ  1x1+pub  dma-wait  barrier | mean over waves (cycles), layer total = max over waves")
 for s in range(nst):
     u = t[s]
