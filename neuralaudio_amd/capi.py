@@ -10,7 +10,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # NA_LIB_SUFFIX selects a tuning build (tools/ablate.sh); unset in normal use
-LIB_PATH = os.path.join(_HERE, "libNeuralAudioCAPI%s.so" % os.environ.get("NA_LIB_SUFFIX", ""))
+_SUFFIX = os.environ.get("NA_LIB_SUFFIX", "")
+LIB_PATH = (os.path.join(os.path.dirname(_HERE), "tools", "variants", "libNeuralAudioCAPI%s.so" % _SUFFIX) if _SUFFIX
+            else os.path.join(_HERE, "libNeuralAudioCAPI.so"))
 
 LEGACY_SYMBOLS = [
     "CreateLoader", "DeleteLoader", "CreateModelFromFile", "DeleteModel", "SetLSTMLoadMode", "SetWaveNetLoadMode",
