@@ -393,10 +393,19 @@ namespace na
 				return BuildWaveNetPlan(wn, false);
 			}
 
+			// Dense packs (wavenet_plan.cpp WaveNetPackCanBeDense: four Nano streams at 16 / 8 instead of 16 / 16 virtual channels -- half the
+			// ring traffic of the second array, two tiles per MFMA in its thirteen layers).  Faster at every batch size (round 5, us per
+			// 128-frame step dense / 16 x 16: 16 streams 15.3 / 16.0, 1024: 17.7 / 20.0 -- the 16 / 16 layout's one-tile-per-wave chain
+			// included --, 4096: 32.4 / 48.2, 8192: 67.6 / 97.0), so it is the layout of every such group.  NA_WN_DENSE=0: the 16 / 16 layout.
+			static bool DenseFor(const WaveNetDesc& wn, int pack)
+			{
+				return pack > 1 && Tuning::Get().wnDense != 0 && WaveNetPackCanBeDense(wn, pack);
+			}
+
 			// packHint: 0 = never pack (submodel of a container), otherwise the number of streams the creating AddStreams call brings
 			WaveNetGroup(const std::shared_ptr<const ModelDesc>& d, hipStream_t s, int packHint = 0, bool peerWeights = false)
-				: ModelGroup(d, s), columnsPending(peerWeights), pack(PackFor(d->wavenet, packHint)),
-				  plan((pack > 1 || PadFor(d->wavenet)) ? BuildPackedWaveNetPlan(d->wavenet, pack) : PlanForItsFamily(d->wavenet)),
+				: ModelGroup(d, s), columnsPending(peerWeights), pack(PackFor(d->wavenet, packHint)), dense(DenseFor(d->wavenet, pack)),
+				  plan((pack > 1 || PadFor(d->wavenet)) ? BuildPackedWaveNetPlan(d->wavenet, pack, dense) : PlanForItsFamily(d->wavenet)),
 				  family(plan.isVirtual() ? WN_FAMILY_SPLIT : FamilyFor(plan))
 			{
 				if (plan.isVirtual())
@@ -699,6 +708,7 @@ namespace na
 		private:
 			bool columnsPending;  // the weight images arrive from a peer device: the prewarm columns are computed then (WeightsArrived)
 			const int pack;       // real streams per virtual stream (1: no packing)
+			const bool dense;     // ... two streams per channel group in the last array (DenseFor)
 			WaveNetPlan plan;     // pack > 1: of the VIRTUAL model
 			WaveNetPlan realPlan; // pack > 1: of the real model (bookkeeping only)
 			const WnFamily family;

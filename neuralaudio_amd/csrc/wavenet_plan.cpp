@@ -333,6 +333,9 @@ namespace na
 			// Packed plans (several streams of a narrow model as the channel groups of one virtual stream, see PackWaveNetDesc): the aux B
 			// operand of k-block q carries the condition of the stream that owns channel group q, so row o's weights sit in the first
 			// k-block of ITS stream (cpad = padded channels per stream; unpacked: cpad >= cout, i.e. always the cg = 0 k-block).
+			// Dense packs (cpad == 2: two streams A, B share a channel group): the B operand of that k-block is
+			// [cA_h, 1, cA_l, 1, cA_h, cB_h, cB_l, cB_h] -- the rows of the first stream of the pair keep the usual five slots, the rows of the
+			// second one take their ones from slots 1 / 3 and their condition from slots 5 / 6 / 7: the eight k-slots are exactly enough.
 			void FillSplitAux(int op, int Gp, int cout, int condOff, int oneOff, int cpad = 1 << 20)
 			{
 				for (int p = 0; p < 4 / Gp; p++)
@@ -341,9 +344,12 @@ namespace na
 						const float wc = condOff >= 0 ? W(condOff + o) : 0.0f, w1 = oneOff >= 0 ? W(oneOff + o) : 0.0f;
 						const uint16_t wch = FloatToHalfBits(wc), wcl = FloatToHalfBits(wc - HalfBitsToFloat(wch));
 						const uint16_t w1h = FloatToHalfBits(w1), w1l = FloatToHalfBits(w1 - HalfBitsToFloat(w1h));
-						const size_t lane = (size_t)(Gp * p + (o / cpad) * (cpad / 4)) * 16 + (size_t)(4 * Gp * p + o);
+						const bool halfGroups = cpad == 2;
+						const size_t kblock = (size_t)Gp * p + (halfGroups ? (size_t)(o / 4) : (size_t)((o / cpad) * (cpad / 4)));
+						const size_t lane = kblock * 16 + (size_t)(4 * Gp * p + o);
 						uint16_t* e = &plan.wsplit[(size_t)op * 512 + lane * 8];
-						e[0] = wch; e[1] = w1h; e[2] = wch; e[3] = w1l; e[4] = wcl;
+						if (halfGroups && ((o / 2) & 1)) { e[1] = w1h; e[3] = w1l; e[5] = wch; e[6] = wch; e[7] = wcl; }
+						else { e[0] = wch; e[1] = w1h; e[2] = wch; e[3] = w1l; e[4] = wcl; }
 					}
 			}
 
@@ -384,8 +390,8 @@ namespace na
 					const int numLayers = (int)cfg.kernelSizes.size();
 					const bool lastArray = (a == numArrays - 1);
 					plan.maxG = std::max(plan.maxG, G);
-					const int cpad = pack > 1 ? C / pack : (1 << 20); // channels per packed stream (a multiple of 4)
-					const int groupsPerStream = pack > 1 ? cpad / 4 : 4;
+					const int cpad = pack > 1 ? C / pack : (1 << 20); // channels per packed stream (a multiple of 4; 2 in a dense pack)
+					const int groupsPerStream = pack > 1 ? cpad / 4 : 4; // (0: two streams per channel group)
 					const int rechOff = Take((size_t)C * cfg.inputSize);
 					{
 						// range bookkeeping for condLimit: |residual stream| <= gain * |cond| + add through this array's rechannel
@@ -883,14 +889,25 @@ namespace na
 	// P == 1: no packing, only padding -- every layer array is widened to the channel count that fills its lane mode (12 -> 16, 6 -> 8,
 	// 3 -> 4), so that a model like A1 Lite runs the fast flavour of the split kernel (zero rows / columns cost nothing there: the
 	// cost of a layer is its skeleton, not its width).
-	WaveNetDesc PackWaveNetDesc(const WaveNetDesc& desc, int P)
+	// Dense packs: four streams whose LAST array has two channels (Nano: 4 / 2) keep that array at 2 channels per stream -- 8 virtual
+	// channels, two streams per channel group -- instead of padding it to 4: half the ring traffic of the array's thirteen layers and
+	// the 8-channel lane mode (two tiles per MFMA).  Only the last array of a two-array model (its head has one output per stream; an
+	// array in front of another one would hand half channel groups to the link's lane-mode change).
+	bool WaveNetPackCanBeDense(const WaveNetDesc& desc, int P)
+	{
+		return P == 4 && desc.arrays.size() == 2 && desc.arrays[0].channels == 4 && desc.arrays[1].channels == 2;
+	}
+
+	WaveNetDesc PackWaveNetDesc(const WaveNetDesc& desc, int P, bool dense)
 	{
 		WaveNetDesc v;
 		v.mathMode = desc.mathMode;
 		const int numArrays = (int)desc.arrays.size();
+		if (dense && !WaveNetPackCanBeDense(desc, P)) throw std::runtime_error("internal: this WaveNet has no dense pack");
 		std::vector<int> cpad((size_t)numArrays);
 		for (int a = 0; a < numArrays; a++)
-			cpad[(size_t)a] = P > 1 ? CeilDiv(desc.arrays[(size_t)a].channels, 4) * 4 : 4 * LaneMode(desc.arrays[(size_t)a].channels);
+			cpad[(size_t)a] = (dense && a == numArrays - 1) ? desc.arrays[(size_t)a].channels
+				: (P > 1 ? CeilDiv(desc.arrays[(size_t)a].channels, 4) * 4 : 4 * LaneMode(desc.arrays[(size_t)a].channels));
 		size_t pos = 0;
 		auto take = [&](size_t n) { const size_t at = pos; pos += n; return at; };
 		for (int a = 0; a < numArrays; a++)
@@ -978,13 +995,14 @@ namespace na
 		return partial;
 	}
 
-	WaveNetPlan BuildPackedWaveNetPlan(const WaveNetDesc& desc, int P)
+	WaveNetPlan BuildPackedWaveNetPlan(const WaveNetDesc& desc, int P, bool dense)
 	{
 		if (P < 1) return BuildWaveNetPlan(desc);
-		const WaveNetDesc v = PackWaveNetDesc(desc, P);
+		const WaveNetDesc v = PackWaveNetDesc(desc, P, dense);
 		Builder b(v, P, true); // (packed / padded plans only ever run on the f16-split kernels)
 		b.Build();
 		b.plan.pack = P;
+		b.plan.packDense = dense;
 		b.plan.packedWeights = v.weights; // the prewarm kernel walks the natural layout of the VIRTUAL model
 		return std::move(b.plan);
 	}

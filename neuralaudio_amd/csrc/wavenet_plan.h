@@ -34,6 +34,7 @@ namespace na
 		int splitFastT = 0;                // see WnModelDev::split_fast_T
 		int maxChannels = 0;               // widest layer array
 		int pack = 1;                      // streams per virtual stream (BuildPackedWaveNetPlan)
+		bool packDense = false;            // ... and the 2-channel arrays of the streams sit side by side, two streams per channel group (PackWaveNetDesc)
 		bool isVirtual() const { return !packedWeights.empty(); } // packed and / or padded: arrays, rings, stages describe the virtual model
 		std::vector<float> packedWeights;  // pack > 1: flat weights of the virtual model (reference order)
 		bool genericOnly = false;          // > 16 channels: only rings + the natural-layout table are built (runtime-shaped block kernel)
@@ -64,6 +65,9 @@ namespace na
 	// the virtual model, and its plan (WaveNetPlan::pack = P; arrays / rings / stages describe the VIRTUAL model).
 	int WaveNetPackFactor(const WaveNetDesc& desc);
 	bool WaveNetWantsPadding(const WaveNetDesc& desc); // P == 1 "packing": widen the arrays to full lane modes (A1 Lite: 12 / 6 -> 16 / 8)
-	WaveNetDesc PackWaveNetDesc(const WaveNetDesc& desc, int P);
-	WaveNetPlan BuildPackedWaveNetPlan(const WaveNetDesc& desc, int P);
+	// dense: a 2-channel array of a four-stream pack is NOT padded to a channel group per stream -- two streams share one (Nano: 16 / 8
+	// virtual channels instead of 16 / 16; the kernels then feed two conditions through one aux operand, FillSplitAux)
+	bool WaveNetPackCanBeDense(const WaveNetDesc& desc, int P);
+	WaveNetDesc PackWaveNetDesc(const WaveNetDesc& desc, int P, bool dense = false);
+	WaveNetPlan BuildPackedWaveNetPlan(const WaveNetDesc& desc, int P, bool dense = false);
 }

@@ -125,6 +125,23 @@ namespace na
 		const int nF4 = (ringFrames[r] / 16) * G * 16;
 		f32x4* ring = st + ringOffF4[r];
 		const int gs = pack > 1 ? G / pack : G;            // channel groups per real stream
+		if (pack > 1 && gs == 0)
+		{
+			// a dense pack (wavenet_plan.cpp PackWaveNetDesc): G x 4 / pack = 2 channels per stream, two streams per channel group.  Of a
+			// split quad [h0 h1 | h2 h3 | l0 l1 | l2 l3] the first stream of a pair owns dwords 0 and 2, the second one dwords 1 and 3:
+			// plain dword stores (streams of one virtual stream may be filled by different workgroups of this launch)
+			const int cgOwn = sub[blockIdx.x] >> 1, half = sub[blockIdx.x] & 1;
+			float* ringW = reinterpret_cast<float*>(ring);
+			for (int idx = threadIdx.x; idx < nF4; idx += blockDim.x)
+			{
+				if (idx % G != cgOwn) continue;
+				const float* c = cols + r * WN_COL_STRIDE + cgOwn * 4;
+				const f32x4 v = SplitQuadBits(zero ? f32x4{ 0.0f, 0.0f, 0.0f, 0.0f } : f32x4{ c[0], c[1], c[2], c[3] });
+				ringW[(size_t)idx * 4 + half] = half ? v.y : v.x;
+				ringW[(size_t)idx * 4 + 2 + half] = half ? v.w : v.z;
+			}
+			return; // (packed: the cursors are left alone)
+		}
 		const int cgFirst = pack > 1 ? sub[blockIdx.x] * gs : 0;
 		for (int idx = threadIdx.x; idx < nF4; idx += blockDim.x)
 		{

@@ -360,8 +360,9 @@ namespace na
 			int fl;          // frame within the wave's FW, set 0: 16 p + j
 			int cg;          // channel group
 			unsigned img;    // LDS byte address of (plane cg, frame F0 + fl) in image 0 of this stream
-			unsigned aux;    // LDS byte address of the aux entry of frame F0 + fl (PK: of the stream owning channel group cg)
+			unsigned aux;    // LDS byte address of the aux entry of frame F0 + fl (PK: of the stream owning channel group cg; dense: of the first of its two streams)
 			unsigned ring;   // byte offset of (frame fl, group cg) within a frame-major ring of this mode: (fl * GP + cg) * 16
+			bool dual;       // PK, dense pack (gs < 0): two streams share a channel group -- the aux operand carries both conditions (wave-uniform)
 
 			__device__ __forceinline__ void Init(const Ctx& cx, int gs)
 			{
@@ -372,7 +373,8 @@ namespace na
 				const int f = C::FW * cx.wave + fl;
 				img = (unsigned)(C::IMG_OFF + cx.sub * 2 * C::IMG_ONE + (cg * PLANE + GUARD + f) * 16);
 				ring = (unsigned)((fl * GP + cg) * 16);
-				if constexpr (C::PK) aux = (unsigned)(C::AUX_OFF + ((cx.sub * 4 + (cg >> gs)) * FRAMES + f) * 8);
+				dual = C::PK && gs < 0;
+				if constexpr (C::PK) aux = (unsigned)(C::AUX_OFF + ((cx.sub * 4 + (gs < 0 ? 2 * cg : (cg >> gs))) * FRAMES + f) * 8);
 				else aux = (unsigned)(C::AUX_OFF + (cx.sub * FRAMES + f) * (C::AUX16 ? 16 : 8));
 			}
 		};
@@ -386,6 +388,15 @@ namespace na
 			else
 			{
 				const u32x2 v = LdsRead8(ln.aux + (unsigned)(16 * P * i * 8));
+				if constexpr (C::PK)
+				{
+					if (ln.dual)
+					{
+						// [cA_h, 1 | cA_l, 1 | cA_h, cB_h | cB_l, cB_h]: the second stream of the pair is FRAMES entries on (FillSplitAux, dense packs)
+						const u32x2 w = LdsRead8(ln.aux + (unsigned)(16 * P * i * 8) + (unsigned)(FRAMES * 8));
+						return u32x4{ v.x, v.y, (v.x & 0xffffu) | (w.x << 16), (w.y & 0xffffu) | (w.x << 16) };
+					}
+				}
 				return u32x4{ v.x, v.y, v.x & 0xffffu, 0u };
 			}
 		}
@@ -1087,7 +1098,7 @@ namespace na
 			// packed: channel groups per real stream = (channels / pack) / 4 -> shift (1, 2, 4 -> 0, 1, 2)
 			const int pack = PK ? ga.pack : 1;
 			cx.gs0 = PK ? ((ga.gps0 >> 1) & 3) : 0;
-			cx.gs1 = PK ? ((ga.gps1 >> 1) & 3) : 0;
+			cx.gs1 = PK ? (ga.gps1 == 0 ? -1 : ((ga.gps1 >> 1) & 3)) : 0; // (0 channel groups per stream: a dense pack, two streams per group)
 			long outRow[4];
 			int rowOf[4]; // PK: the rows of the (up to four) real streams of this virtual stream, -1: none
 #pragma unroll
@@ -1435,7 +1446,7 @@ namespace na
 				// channel groups per real stream of the first / the last array (packed launches: which stream's condition a channel group sees)
 				const int c0 = a.arch == 1 ? F::A1::CH[0] : F::A0::CH[0], c1 = a.arch == 1 ? F::A1::CH[1] : F::A0::CH[1];
 				a.gps0 = std::max(1, c0 / 4 / a.pack);
-				a.gps1 = std::max(1, c1 / 4 / a.pack);
+				a.gps1 = (a.pack > 1 && c1 < 4 * a.pack) ? 0 : std::max(1, c1 / 4 / a.pack); // (0: a dense pack -- two streams per channel group)
 				if (a.pack > 1 && !PK) return hipErrorInvalidValue;
 				if (PK && g.slots == nullptr) return hipErrorInvalidValue;
 				const int spbArch = a.arch == 1 ? C1::SPB : C::SPB; // streams per workgroup of this group's architecture

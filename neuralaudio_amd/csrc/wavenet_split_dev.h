@@ -225,7 +225,7 @@ namespace na
 			int pack;       // packed launches: real streams per virtual stream; rows[] then holds `pack` rows per virtual stream (-1: unused)
 			float condLimit; // input samples are clamped to +-condLimit (WnModelDev::cond_limit), NaN reads as silence
 			int arch;       // specialised chains (wavenet_spec_kernels.hip): which member of the launch's architecture family
-			int gps0, gps1; // ... packed launches: channel groups per real stream of the first / the last layer array (1, 2, 4)
+			int gps0, gps1; // ... packed launches: channel groups per real stream of the first / the last layer array (1, 2, 4; 0: two streams per group)
 			int saturate;   // stage interpreter: 1 = split with SplitQuadSat and count range events (models without a range proof)
 		};
 

@@ -255,6 +255,12 @@ namespace na
 		{
 			if constexpr (PK)
 			{
+				if (gsShift < 0)
+				{
+					// dense pack: streams 2 cg and 2 cg + 1 share the group -- [cA_h, 1 | cA_l, 1 | cA_h, cB_h | cB_l, cB_h] (wavenet_plan.cpp FillSplitAux)
+					const u32x2 v = cx.auxp[(2 * cg) * FRAMES + (f & (FRAMES - 1))], w = cx.auxp[(2 * cg + 1) * FRAMES + (f & (FRAMES - 1))];
+					return u32x4{ v.x, v.y, (v.x & 0xffffu) | (w.x << 16), (w.y & 0xffffu) | (w.x << 16) };
+				}
 				const u32x2 v = cx.auxp[(cg >> gsShift) * FRAMES + (f & (FRAMES - 1))];
 				return u32x4{ v.x, v.y, v.x & 0xffffu, 0u };
 			}
@@ -304,7 +310,7 @@ namespace na
 				const bool mask = GEN && (Geo<GP, T>::PARTIAL || G < GP); // wave-uniform: some lanes have no channel group / no tile of their own
 				const int inPos0 = __builtin_amdgcn_readlane(cx.myPos, sd.ring_id);
 				const int outPos0 = (sd.out_ring_id >= 0) ? RingAdvance(__builtin_amdgcn_readlane(cx.myPos, sd.out_ring_id), cx.n, sd.out_ring_frames) : 0; // cursor AFTER the block
-				const int gsShift = PK ? (sd.reserved >> 1) : 0; // channel groups per packed stream: 1, 2, 4 -> 0, 1, 2
+				const int gsShift = PK ? (sd.reserved == 0 ? -1 : (sd.reserved >> 1)) : 0; // channel groups per packed stream: 1, 2, 4 -> 0, 1, 2; 0 (dense pack) -> -1
 
 				// dilated conv (WaveNet.h:139-290): tap k reads the frame d*(K-1-k) back; accumulation starts from zero, bias and mix-in
 				// arrive through the aux operand

@@ -21,10 +21,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                  {"NA_HOST_DIRECT": "0"},    # host buffers through the copy engines instead of kernels on the pinned block
                                  {"NA_REC_QUAD_MIN": "1"},   # every recurrent launch that can on the four-streams-per-wave layout, whatever its size
                                  {"NA_HOST_HALVES": "0"},    # no free-running half-batch chains: every buffer as ordered launches on the batch stream
+                                 {"NA_WN_DENSE": "0"},       # four Nano streams at 16 / 16 virtual channels (default: 16 / 8, two streams per channel group)
                                  {"NA_REC_RPL": "4"}],       # runtime-shaped recurrent kernel: four gate rows per lane (a quarter of the waves per stream)
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_forced_family_passes_parity_fuzz_and_batch_suites(env):
-    if os.environ.get("NA_WN_KERNEL") or os.environ.get("NA_LSTM_NO_DPP") or os.environ.get("NA_LSTM_LANE_KERNEL") or os.environ.get("NA_REC_NOSKEW") or os.environ.get("NA_WN_PACK") or os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_WN_SPEC") or os.environ.get("NA_HOST_DIRECT") or os.environ.get("NA_REC_QUAD_MIN") or os.environ.get("NA_HOST_HALVES") or os.environ.get("NA_REC_RPL"):
+    if os.environ.get("NA_WN_KERNEL") or os.environ.get("NA_LSTM_NO_DPP") or os.environ.get("NA_LSTM_LANE_KERNEL") or os.environ.get("NA_REC_NOSKEW") or os.environ.get("NA_WN_PACK") or os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_WN_SPEC") or os.environ.get("NA_HOST_DIRECT") or os.environ.get("NA_REC_QUAD_MIN") or os.environ.get("NA_HOST_HALVES") or os.environ.get("NA_REC_RPL") or os.environ.get("NA_WN_DENSE"):
         pytest.skip("already inside a forced run")
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
