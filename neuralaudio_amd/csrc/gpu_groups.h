@@ -746,8 +746,11 @@ namespace na
 				dev.headOff = (int)w.size();
 				w.insert(w.end(), lstm.headWeights.begin(), lstm.headWeights.begin() + lstm.hiddenSize);
 				w.push_back(lstm.headBias);
-				dev.tailLayers = (int)lstm.tail.size(); // generic keras stack: a chain of dense layers instead of the head
+				dev.tailLayers = (int)lstm.tail.size(); // generic keras stack: a chain of dense / conv1d layers instead of the head
 				dev.tailWidth = 0;
+				dev.tailHistMax = 0;
+				for (const DenseLayerDesc& dl : lstm.tail) dev.tailHistMax = std::max(dev.tailHistMax, dl.History());
+				int convRows = 0; // rows of conv1d input history behind the recurrent state's rows (zero at reset, like RTNeural's model->reset())
 				for (size_t t = 0; t < lstm.tail.size(); t++)
 				{
 					const DenseLayerDesc& dl = lstm.tail[t];
@@ -755,11 +758,16 @@ namespace na
 					dev.tailIn[t] = dl.in;
 					dev.tailOut[t] = dl.out;
 					dev.tailAct[t] = dl.activation;
-					dev.tailWidth = std::max(dev.tailWidth, dl.out);
+					dev.tailK[t] = dl.ksize;
+					dev.tailDil[t] = dl.dilation;
+					dev.tailHistRow[t] = lstm.numLayers * 2 * lstm.hiddenSize + convRows;
+					convRows += dl.History() * dl.in;
+					dev.tailWidth = std::max(dev.tailWidth, dev.tailHistMax > 0 ? std::max(dl.in, dl.out) : dl.out);
 					w.insert(w.end(), dl.w.begin(), dl.w.end());
 					w.insert(w.end(), dl.b.begin(), dl.b.end());
-					tailMacs += (double)dl.in * dl.out;
+					tailMacs += (double)dl.RowLen() * dl.out;
 				}
+				init.insert(init.end(), (size_t)convRows, 0.0f);
 				dW.UploadUnless(peerWeights, w, stream); // (weight images: may be left for a peer device to fill)
 				dInit.Upload(init, stream);
 				dev.w = dW.Get();
@@ -789,7 +797,7 @@ namespace na
 				dev.numLayers = lstm.numLayers;
 				dev.hidden = lstm.hiddenSize;
 				dev.math = (lstm.mathMode == MATH_STD) ? LSTM_MATH_STD : LSTM_MATH_FAST;
-				numElems = lstm.numLayers * 2 * lstm.hiddenSize;
+				numElems = lstm.numLayers * 2 * lstm.hiddenSize + convRows;
 				dZeros.Alloc(LSTM_MAX_FRAMES);
 				CheckHip(hipMemsetAsync(dZeros.Get(), 0, LSTM_MAX_FRAMES * sizeof(float), stream), "hipMemsetAsync");
 			}

@@ -237,12 +237,13 @@ namespace na
 		float* out, long inStride, long outStride, int n, hipStream_t stream)
 	{
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
-		if (n > LSTM_MAX_FRAMES || !GruShapeSupported(m.hidden, m.numLayers, m.tailLayers > 0 ? m.tailWidth : 0)) return hipErrorInvalidValue;
+		if (n > LSTM_MAX_FRAMES || !GruShapeSupported(m.hidden, m.numLayers, m.tailLayers > 0 ? m.tailWidth : 0, m.tailLayers > 0 ? m.tailHistMax : 0)) return hipErrorInvalidValue;
 		if (m.tailLayers > 0)
 		{
 			// generic keras stack: the runtime-shaped wave kernel if the weights fit the LDS, else the lane = stream kernel
 			hipError_t err = hipSuccess;
 			if (LaunchRecurrentWaveRt(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
+			if (m.tailHistMax > 0) return hipErrorNotSupported; // (conv1d tails: the runtime-shaped wave kernel only)
 			return LaunchGruGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream);
 		}
 		const bool noDpp = Tuning::Get().gruNoDpp; // tuning knob: the LDS-broadcast kernel for every shape

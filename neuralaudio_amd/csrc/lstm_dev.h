@@ -10,6 +10,7 @@
 // (structure-of-arrays over streams so a wave's 64 lanes load/store 256 contiguous bytes).
 #pragma once
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "tuning.h"
@@ -20,6 +21,7 @@ namespace na
 	constexpr int LSTM_MAX_FRAMES = 128;
 	constexpr int LSTM_MAX_TAIL = 8;        // dense layers of a generic keras stack (after lowering: activation / batchnorm / prelu layers become dense ones)
 	constexpr int LSTM_MAX_TAIL_WIDTH = 256; // units per dense layer (two [width][64] scratch arrays in LDS: the shape predicates below check the fit)
+	constexpr int LSTM_MAX_TAIL_HISTORY = 1024; // conv1d layers of a keras stack: (taps - 1) x dilation samples of input history at most
 
 	enum { LSTM_CELL_LSTM = 0, LSTM_CELL_GRU = 1 };
 	enum { LSTM_MATH_FAST = 0, LSTM_MATH_STD = 1 };
@@ -46,14 +48,21 @@ namespace na
 		while (waves < 16 && gateRows > 64 * rpl * waves) waves *= 2;
 		return waves;
 	}
-	inline bool RecurrentWaveShape(int hidden, int numLayers, int tailWidth)
+	// tailHistory > 0: the tail has conv1d layers -- it is evaluated layer by layer over the whole block (recurrent_tail.h ConvTail) and its two
+	// scratch arrays are [tailWidth][tailHistory + 128] (tailWidth then covers the widest INPUT of a tail layer as well)
+#ifdef __HIPCC__
+	__host__ __device__
+#endif
+	inline long RecurrentTailScratchFloats(int tailWidth, int tailHistory) { return tailHistory > 0 ? 2L * tailWidth * (tailHistory + LSTM_MAX_FRAMES) : 2L * tailWidth * 64; }
+	inline bool RecurrentWaveShape(int hidden, int numLayers, int tailWidth, int tailHistory = 0)
 	{
 		if (!(hidden >= 1 && hidden <= RECURRENT_WAVE_MAX_HIDDEN && numLayers >= (tailWidth > 0 ? 0 : 1) && numLayers <= LSTM_MAX_LAYERS &&
-			tailWidth <= LSTM_MAX_TAIL_WIDTH)) return false;
+			tailWidth <= std::max(LSTM_MAX_TAIL_WIDTH, tailHistory > 0 ? hidden : 0) && tailHistory <= LSTM_MAX_TAIL_HISTORY)) return false;
 		// LDS without the weights (they stream from L2 when they do not fit): xin | h, c | gates | [samples][H] of the last layer (small models
 		// and dense tails) | tail scratch
 		const bool hseq = hidden < RECURRENT_HEAD_IN_LOOP_FROM || tailWidth > 0;
-		const long floats = LSTM_MAX_FRAMES + 2L * numLayers * hidden + 6L * hidden + (hseq ? 2L * (numLayers > 0 ? hidden : 1) * 64 : 0) + 2L * tailWidth * 64 + 64;
+		const long floats = LSTM_MAX_FRAMES + 2L * numLayers * hidden + 6L * hidden + (hseq ? 2L * (numLayers > 0 ? hidden : 1) * 64 : 0) +
+			RecurrentTailScratchFloats(tailWidth, tailHistory) + 64;
 		return floats * 4 <= 160L * 1024;
 	}
 	// the lane = stream kernels' bound (LstmGenericKernel / GruGenericKernel: state of 64 streams in LDS)
@@ -69,8 +78,15 @@ namespace na
 		const long bytes = (64L * (LSTM_MAX_FRAMES + 1) + (long)numLayers * hidden * 64 + 6L * hidden * 64 + 2L * tailWidth * 64) * 4; // GruGenericKernel's LDS
 		return bytes <= 160L * 1024;
 	}
-	inline bool LstmShapeSupported(int hidden, int numLayers, int tailWidth = 0) { return LstmLaneKernelShape(hidden, numLayers, tailWidth) || RecurrentWaveShape(hidden, numLayers, tailWidth); }
-	inline bool GruShapeSupported(int hidden, int numLayers, int tailWidth = 0) { return GruLaneKernelShape(hidden, numLayers, tailWidth) || (numLayers >= 1 && RecurrentWaveShape(hidden, numLayers, tailWidth)); }
+	// (a tail with conv1d layers -- tailHistory > 0 -- only runs on the runtime-shaped wave kernel)
+	inline bool LstmShapeSupported(int hidden, int numLayers, int tailWidth = 0, int tailHistory = 0)
+	{
+		return (tailHistory == 0 && LstmLaneKernelShape(hidden, numLayers, tailWidth)) || RecurrentWaveShape(hidden, numLayers, tailWidth, tailHistory);
+	}
+	inline bool GruShapeSupported(int hidden, int numLayers, int tailWidth = 0, int tailHistory = 0)
+	{
+		return (tailHistory == 0 && GruLaneKernelShape(hidden, numLayers, tailWidth)) || (numLayers >= 1 && RecurrentWaveShape(hidden, numLayers, tailWidth, tailHistory));
+	}
 
 	struct LstmModelDev
 	{
@@ -88,7 +104,12 @@ namespace na
 		// tailOff[t], then bias[out]; activation codes = DenseActivation (model_desc.h).  Only the runtime-shaped kernels evaluate it.
 		int tailLayers;
 		int tailOff[LSTM_MAX_TAIL], tailIn[LSTM_MAX_TAIL], tailOut[LSTM_MAX_TAIL], tailAct[LSTM_MAX_TAIL];
-		int tailWidth; // widest layer
+		int tailWidth; // widest layer (with conv1d layers: widest input or output of a tail layer)
+		// conv1d layers of the tail (recurrent_tail.h ConvTail): taps / dilation per layer (1 / 1: a dense layer; weights [out][taps][in]), the
+		// state row where the layer's input history starts (history x in rows, oldest sample first, behind the recurrent state's rows) and
+		// the longest history (0: the tail has no conv1d layer)
+		int tailK[LSTM_MAX_TAIL], tailDil[LSTM_MAX_TAIL], tailHistRow[LSTM_MAX_TAIL];
+		int tailHistMax;
 		// the same gate matrices transposed for the wave kernel's L2-streamed mode (weights larger than the LDS): per layer
 		// [Qi + Qh][rowsPad][4] floats -- quad q of row r = weights of inputs 4q .. 4q + 3 (input part padded to Qi = ceil(I / 4) quads, hidden
 		// part to Qh = ceil(H / 4)), rows padded to a multiple of 64: the 64 lanes of a wave read 64 consecutive rows of one quad = 1 KB

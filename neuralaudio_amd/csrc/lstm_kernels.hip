@@ -350,7 +350,7 @@ namespace na
 		const int rowsPerLayer = (m.cell == LSTM_CELL_GRU ? 3 : 4) * H, biases = (m.cell == LSTM_CELL_GRU ? 6 : 4) * H;
 		const bool hseq = H < RECURRENT_HEAD_IN_LOOP_FROM || m.tailLayers > 0; // (else the head is evaluated inside the sample loop)
 		size_t f = (size_t)LSTM_MAX_FRAMES + (size_t)2 * L * H + (size_t)6 * H + (hseq ? (size_t)2 * (L > 0 ? H : 1) * 64 : 0) +
-			(size_t)2 * (m.tailLayers > 0 ? m.tailWidth : 0) * 64;
+			(size_t)RecurrentTailScratchFloats(m.tailLayers > 0 ? m.tailWidth : 0, m.tailLayers > 0 ? m.tailHistMax : 0);
 		if (weightsInLds)
 			for (int l = 0; l < L; l++) f += (size_t)rowsPerLayer * (size_t)(((l == 0 ? 1 : H) + H) | 1) + (size_t)biases;
 		return f;
@@ -479,8 +479,9 @@ namespace na
 		const bool headInLoop = H >= RECURRENT_HEAD_IN_LOOP_FROM && m.tailLayers == 0; // (no [samples][H] buffer then)
 		float* hseq = gates + 6 * H;           // [2][Hs][64]
 		float* tailA = hseq + (headInLoop ? 0 : (size_t)2 * Hs * 64);
-		float* tailB = tailA + (size_t)(m.tailLayers > 0 ? m.tailWidth : 0) * 64;
-		float* wl = tailB + (size_t)(m.tailLayers > 0 ? m.tailWidth : 0) * 64; // per layer: [G H][stride] then the biases
+		const size_t tailOne = (size_t)RecurrentTailScratchFloats(m.tailLayers > 0 ? m.tailWidth : 0, m.tailLayers > 0 ? m.tailHistMax : 0) / 2;
+		float* tailB = tailA + tailOne;
+		float* wl = tailB + tailOne; // per layer: [G H][stride] then the biases
 
 		const int lane = threadIdx.x;            // thread of the stream's workgroup
 		const int nt = MAXT == 64 ? 64 : (int)blockDim.x;
@@ -595,6 +596,11 @@ namespace na
 		const float* headW = m.w + m.headOff;
 		if (headInLoop)
 			for (int f = lane; f < n; f += nt) outRow[f] = xin[f];
+		else if (m.tailLayers > 0 && m.tailHistMax > 0)
+		{
+			// a tail with conv1d layers: layer by layer over the whole block (recurrent_tail.h)
+			if (lane < 64) ConvTail(m, L > 0 ? hseq : nullptr, L > 0 ? H : 0, xin, tailA, tailB, state, capacity, slot, n, lane, outRow);
+		}
 		else if (lane < 64)
 		for (int pass = 0; pass * 64 < n; pass++)
 		{
@@ -794,6 +800,7 @@ namespace na
 			if (!forceLaneKernel && m.tailLayers == 0 && LaunchLstmWave(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
 			if (!forceLaneKernel && LaunchRecurrentWaveRt(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
 		}
+		if (m.tailLayers > 0 && m.tailHistMax > 0) return hipErrorNotSupported; // (conv1d tails: the runtime-shaped wave kernel only)
 		if (m.tailLayers > 0) return LaunchGeneric(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream); // generic keras stack
 #define NA_LSTM_CASE(HH) case HH: return LaunchH<HH>(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream)
 		switch (m.hidden)

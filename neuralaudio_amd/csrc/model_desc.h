@@ -51,14 +51,19 @@ namespace na
 
 	enum RecurrentCell { CELL_LSTM = 0, CELL_GRU = 1 };
 
-	// one keras "dense" layer of a generic stack (RTNeural's Dense + activation layer, RTNeuralModel.h:300)
-	enum DenseActivation { DENSE_LINEAR = 0, DENSE_TANH = 1, DENSE_RELU = 2, DENSE_SIGMOID = 3, DENSE_ELU = 4 };
+	// one keras "dense" or "conv1d" layer of a generic stack (RTNeural's Dense / Conv1D + activation layer, RTNeuralModel.h:300)
+	enum DenseActivation { DENSE_LINEAR = 0, DENSE_TANH = 1, DENSE_RELU = 2, DENSE_SIGMOID = 3, DENSE_ELU = 4, DENSE_SOFTMAX = 5 };
 	struct DenseLayerDesc
 	{
 		int in = 0, out = 0;
 		int activation = DENSE_LINEAR;
-		std::vector<float> w; // row-major [out][in]
+		// conv1d (causal, stride 1): ksize taps `dilation` samples apart, tap k reads the input of (ksize - 1 - k) * dilation samples ago
+		// (Keras Conv1D(padding = "causal")); a dense layer is ksize == 1
+		int ksize = 1, dilation = 1;
+		std::vector<float> w; // row-major [out][ksize * in], a row tap-major: index k * in + i
 		std::vector<float> b; // [out]
+		int RowLen() const { return in * ksize; }
+		int History() const { return (ksize - 1) * dilation; }
 	};
 
 	struct LSTMDesc

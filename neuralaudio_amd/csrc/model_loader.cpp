@@ -339,29 +339,32 @@ namespace na
 
 	void ValidateRecurrentDesc(const LSTMDesc& d)
 	{
-		int tailWidth = 0;
+		int tailWidth = 0, tailHistory = 0;
 		if (!d.tail.empty())
 		{
 			if ((int)d.tail.size() > LSTM_MAX_TAIL) throw std::runtime_error("keras model with more than " + std::to_string(LSTM_MAX_TAIL) + " dense layers is not supported");
 			int in = d.numLayers > 0 ? d.hiddenSize : 1;
+			for (const DenseLayerDesc& t : d.tail) tailHistory = std::max(tailHistory, t.History());
 			for (const DenseLayerDesc& t : d.tail)
 			{
-				if (t.in != in || t.out < 1 || (int)t.w.size() != t.in * t.out || (int)t.b.size() != t.out)
-					throw std::runtime_error("keras dense layer has unexpected weight shapes");
-				if (t.out > LSTM_MAX_TAIL_WIDTH) throw std::runtime_error("keras dense layer wider than " + std::to_string(LSTM_MAX_TAIL_WIDTH) + " units is not supported");
-				tailWidth = std::max(tailWidth, t.out);
+				if (t.in != in || t.out < 1 || t.ksize < 1 || t.dilation < 1 || (int)t.w.size() != t.RowLen() * t.out || (int)t.b.size() != t.out)
+					throw std::runtime_error("keras dense / conv1d layer has unexpected weight shapes");
+				if (t.out > LSTM_MAX_TAIL_WIDTH) throw std::runtime_error("keras dense / conv1d layer wider than " + std::to_string(LSTM_MAX_TAIL_WIDTH) + " units is not supported");
+				if (t.History() > LSTM_MAX_TAIL_HISTORY)
+					throw std::runtime_error("keras conv1d layer with more than " + std::to_string(LSTM_MAX_TAIL_HISTORY) + " samples of history ((kernel_size - 1) x dilation) is not supported");
+				tailWidth = std::max(tailWidth, tailHistory > 0 ? std::max(t.in, t.out) : t.out);
 				in = t.out;
 			}
 		}
 		if (d.cell == CELL_GRU)
 		{
-			if (!GruShapeSupported(d.hiddenSize, d.numLayers, tailWidth))
+			if (!GruShapeSupported(d.hiddenSize, d.numLayers, tailWidth, tailHistory))
 				throw std::runtime_error("GRU " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
-					" is not supported (1-8 layers of up to 1024 units; a dense tail behind more than 128 units must fit the 160 KB LDS with its [samples][units] buffer)");
+					" is not supported (1-8 layers of up to 1024 units; a dense tail behind more than 128 units must fit the 160 KB LDS with its [samples][units] buffer; a tail with conv1d layers with its two [widest layer][history + 128] buffers)");
 		}
-		else if (!LstmShapeSupported(d.hiddenSize, d.numLayers, tailWidth))
+		else if (!LstmShapeSupported(d.hiddenSize, d.numLayers, tailWidth, tailHistory))
 			throw std::runtime_error("LSTM " + std::to_string(d.numLayers) + "x" + std::to_string(d.hiddenSize) +
-				" is not supported (1-8 layers of up to 1024 units; a dense tail behind more than 128 units must fit the 160 KB LDS with its [samples][units] buffer)");
+				" is not supported (1-8 layers of up to 1024 units; a dense tail behind more than 128 units must fit the 160 KB LDS with its [samples][units] buffer; a tail with conv1d layers with its two [widest layer][history + 128] buffers)");
 	}
 
 	namespace
@@ -465,6 +468,7 @@ namespace na
 			if (act == "relu") return DENSE_RELU;
 			if (act == "sigmoid") return DENSE_SIGMOID;
 			if (act == "elu") return DENSE_ELU;
+			if (act == "softmax") return DENSE_SOFTMAX;
 			throw std::runtime_error(std::string("keras ") + what + " activation '" + act + "' is not supported");
 		}
 
@@ -486,6 +490,34 @@ namespace na
 			return d;
 		}
 
+		// One keras conv1d layer (RTNeural json_parser: Conv1D(in, out, kernel_size, dilation) + an activation layer): causal, stride 1, one
+		// group; weights [kernel_size][in][out], bias [out]; "kernel_size" / "dilation" as numbers or one-element lists.
+		DenseLayerDesc ReadKerasConv1D(const Json& layer, int in)
+		{
+			auto lastInt = [&](const char* key, int dflt) {
+				if (!layer.Contains(key)) return dflt;
+				const Json& v = layer.At(key);
+				return v.IsNumber() ? v.AsInt() : v.Back().AsInt();
+			};
+			DenseLayerDesc d;
+			d.in = in;
+			d.out = layer.At("shape").Back().AsInt();
+			d.ksize = lastInt("kernel_size", 1);
+			d.dilation = lastInt("dilation", 1);
+			if (lastInt("strides", 1) != 1 || lastInt("groups", 1) != 1) throw std::runtime_error("keras conv1d layer with a stride or groups is not supported");
+			if (d.ksize < 1 || d.dilation < 1) throw std::runtime_error("keras conv1d layer has unexpected kernel_size / dilation");
+			std::vector<float> kernel;
+			layer.At("weights").At(0).FlattenNumbers(kernel); // [k][in][out]
+			layer.At("weights").At(1).FlattenNumbers(d.b);
+			if (d.out < 1 || (int)kernel.size() != d.ksize * d.in * d.out || (int)d.b.size() != d.out) throw std::runtime_error("keras conv1d layer has unexpected weight shapes");
+			d.w.assign(kernel.size(), 0.0f);
+			for (int k = 0; k < d.ksize; k++)
+				for (int i = 0; i < d.in; i++)
+					for (int o = 0; o < d.out; o++) d.w[((size_t)o * d.ksize + k) * d.in + i] = kernel[((size_t)k * d.in + i) * d.out + o];
+			d.activation = KerasActivation(layer.Contains("activation") ? layer.At("activation").AsString() : std::string(), "conv1d");
+			return d;
+		}
+
 		// The layer types behind the recurrent part that this library evaluates with its dense-chain kernels.  Besides "dense" (RTNeural
 		// json_parser: a Dense layer + an activation layer) the element-wise layers of RTNeural's parser are LOWERED at load time to dense
 		// layers, so that no kernel has to know them:
@@ -496,9 +528,10 @@ namespace na
 		//   "prelu"       y = max(x, 0) + alpha min(x, 0) (weights [alpha], per unit or one value) = relu(x) - alpha relu(-x): the rows
 		//                 [W; -W] of a linear dense layer in front of it with relu, then the layer [I | -diag(alpha)] -- twice the
 		//                 width in between (<= 64)
-		// conv1d (a causal convolution over time: it needs state) and softmax have no kernel here: such a model is not accepted.
+		//   "conv1d"      a causal convolution over time (round 5): a dense layer over `kernel_size` delayed copies of its input; the input
+		//                 history is stream state (recurrent_tail.h ConvTail).  softmax runs across the units of its layer.
 		// Third-party arithmetic (RTNeural is absent): parity unpinned, checked by the test suite against a float64 restatement.
-		bool IsKerasTailType(const std::string& t) { return t == "dense" || t == "time-distributed-dense" || t == "activation" || t == "batchnorm" || t == "prelu"; }
+		bool IsKerasTailType(const std::string& t) { return t == "dense" || t == "time-distributed-dense" || t == "conv1d" || t == "activation" || t == "batchnorm" || t == "prelu"; }
 
 		DenseLayerDesc DiagonalDense(const std::vector<float>& scale, const std::vector<float>& shift)
 		{
@@ -517,6 +550,11 @@ namespace na
 			if (type == "dense" || type == "time-distributed-dense")
 			{
 				tail.push_back(ReadKerasDense(layer, in));
+				return;
+			}
+			if (type == "conv1d")
+			{
+				tail.push_back(ReadKerasConv1D(layer, in));
 				return;
 			}
 			const bool foldable = !tail.empty() && tail.back().activation == DENSE_LINEAR; // a linear dense layer right in front
@@ -557,7 +595,7 @@ namespace na
 					DenseLayerDesc& p = tail.back();
 					for (int o = 0; o < p.out; o++)
 					{
-						for (int k = 0; k < p.in; k++) p.w[(size_t)o * p.in + k] *= scale[(size_t)o];
+						for (int k = 0; k < p.RowLen(); k++) p.w[(size_t)o * p.RowLen() + k] *= scale[(size_t)o];
 						p.b[(size_t)o] = p.b[(size_t)o] * scale[(size_t)o] + shift[(size_t)o];
 					}
 				}
@@ -577,14 +615,16 @@ namespace na
 					const DenseLayerDesc p = tail.back();
 					tail.pop_back();
 					a.in = p.in; a.out = 2 * in;
-					a.w.assign((size_t)a.out * a.in, 0.0f);
+					a.ksize = p.ksize; a.dilation = p.dilation; // (a linear conv1d layer in front folds the same way: its rows are ksize x in long)
+					const int RL = p.RowLen();
+					a.w.assign((size_t)a.out * RL, 0.0f);
 					a.b.assign((size_t)a.out, 0.0f);
 					for (int o = 0; o < in; o++)
 					{
-						for (int k = 0; k < p.in; k++)
+						for (int k = 0; k < RL; k++)
 						{
-							a.w[(size_t)o * a.in + k] = p.w[(size_t)o * p.in + k];
-							a.w[(size_t)(in + o) * a.in + k] = -p.w[(size_t)o * p.in + k];
+							a.w[(size_t)o * RL + k] = p.w[(size_t)o * RL + k];
+							a.w[(size_t)(in + o) * RL + k] = -p.w[(size_t)o * RL + k];
 						}
 						a.b[(size_t)o] = p.b[(size_t)o];
 						a.b[(size_t)(in + o)] = -p.b[(size_t)o];

@@ -15,7 +15,7 @@
                       whose quality flips mid-stream (each submodel only advances while active, CompositeModel.h:94-100).  The reference
                       cannot be built here (no Eigen), so these are NOT reference outputs; they are what the GPU tests hold the HIP path
                       to in addition to the live oracle, so that kernel and oracle cannot drift together unnoticed.
-  keras_stacks_torch.npz  the same for three generic keras stacks (lstm / gru / dense chains): torch.nn.LSTM / GRU / Linear, float64
+  keras_stacks_torch.npz  the same for five generic keras stacks (lstm / gru / dense / conv1d chains, softmax): torch.nn.LSTM / GRU / Linear / Conv1d, float64
   gru_torch.npz       INDEPENDENT-IMPLEMENTATION VECTORS for the keras GRU (RTNeural is absent from the reference tree, so there is no
                       reference output to record): output of torch.nn.GRU (float64, weights permuted from keras z|r|c to torch r|z|n order)
                       + dense head on the committed synthetic model models/synthetic_gru_1x16.json, after 2048 zeros of prewarm.
@@ -93,7 +93,10 @@ def make_gru():
 
 KERAS_STACKS = {"lstm8_dense6tanh_dense1": [("lstm", 8), ("dense", 6, "tanh"), ("dense", 1)],
                 "gru12_dense5relu_dense3sigmoid_dense1": [("gru", 12), ("dense", 5, "relu"), ("dense", 3, "sigmoid"), ("dense", 1)],
-                "dense8tanh_dense4elu_dense1": [("dense", 8, "tanh"), ("dense", 4, "elu"), ("dense", 1)]}
+                "dense8tanh_dense4elu_dense1": [("dense", 8, "tanh"), ("dense", 4, "elu"), ("dense", 1)],
+                # round 5: causal dilated conv1d layers (torch.nn.Conv1d behind a left pad) and softmax
+                "conv8k3d1tanh_conv8k3d2tanh_conv4k2d4relu_dense1": [("conv1d", 8, 3, 1, "tanh"), ("conv1d", 8, 3, 2, "tanh"), ("conv1d", 4, 2, 4, "relu"), ("dense", 1)],
+                "gru12_conv16k4d64elu_dense5softmax_dense1": [("gru", 12), ("conv1d", 16, 4, 64, "elu"), ("dense", 5, "softmax"), ("dense", 1)]}
 
 
 def make_keras_stacks():
@@ -102,7 +105,8 @@ def make_keras_stacks():
     import json
     import torch
     import ref_np as R
-    acts = {"": lambda v: v, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid, "elu": torch.nn.functional.elu}
+    acts = {"": lambda v: v, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid, "elu": torch.nn.functional.elu,
+            "softmax": lambda v: torch.softmax(v, dim=-1)}
     x = O.signal_noise(1024, 20260929)
     out = {"input": x}
     for name, spec in KERAS_STACKS.items():
@@ -129,6 +133,12 @@ def make_keras_stacks():
                     m.bias_ih_l0.copy_(torch.from_numpy(W[2][0][perm].copy()))
                     m.bias_hh_l0.copy_(torch.from_numpy(W[2][1][perm].copy()))
                     v, _ = m(v)
+                elif l["type"] == "conv1d":
+                    K, d = int(l["kernel_size"][-1]), int(l["dilation"][-1])
+                    m = torch.nn.Conv1d(v.shape[-1], H, K, dilation=d).double()
+                    m.weight.copy_(torch.from_numpy(W[0]).permute(2, 1, 0))  # keras [k][in][out] -> torch [out][in][k]
+                    m.bias.copy_(torch.from_numpy(W[1].ravel().copy()))
+                    v = acts[l.get("activation", "") or ""](m(torch.nn.functional.pad(v.transpose(1, 2), ((K - 1) * d, 0))).transpose(1, 2))
                 else:
                     v = acts[l.get("activation", "") or ""](v @ torch.from_numpy(W[0]) + torch.from_numpy(W[1].ravel()))
             out[name] = v[0, 2048:, 0].numpy().astype(np.float32)

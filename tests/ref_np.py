@@ -182,12 +182,23 @@ def keras_stack_forward(model_json, x, prewarm=2048):
     RTNeuralModel.h:10-31).  Output = unit 0 of the last layer; zero initial state, `prewarm` zeros first."""
     layers = model_json["layers"]
     sig = lambda v: 0.5 * (np.tanh(0.5 * v) + 1.0)
+    def softmax(v):
+        e = np.exp(v - np.max(v))
+        return e / np.sum(e)
     acts = {"": lambda v: v, "linear": lambda v: v, "tanh": np.tanh, "relu": lambda v: np.maximum(v, 0.0), "sigmoid": sig,
-            "elu": lambda v: np.where(v > 0, v, np.exp(np.minimum(v, 0.0)) - 1.0)}
+            "elu": lambda v: np.where(v > 0, v, np.exp(np.minimum(v, 0.0)) - 1.0), "softmax": softmax}
+    lastint = lambda v: int(v[-1]) if isinstance(v, (list, tuple)) else int(v)
     state = []
+    width = 1
     for l in layers:
         H = int(l["shape"][-1])
-        state.append([np.zeros(H), np.zeros(H)] if l["type"] in ("lstm", "gru") else None)
+        if l["type"] in ("lstm", "gru"):
+            state.append([np.zeros(H), np.zeros(H)])
+        elif l["type"] == "conv1d":  # the layer's input history, newest last: (kernel_size - 1) * dilation + 1 rows (zero after reset)
+            state.append(np.zeros(((lastint(l["kernel_size"]) - 1) * lastint(l.get("dilation", 1)) + 1, width)))
+        else:
+            state.append(None)
+        width = H
     W = [[np.array(w, dtype=np.float64) for w in l["weights"]] for l in layers]
     xs = np.concatenate([np.zeros(prewarm), np.asarray(x, dtype=np.float64)])
     out = np.empty(xs.size)
@@ -212,6 +223,14 @@ def keras_stack_forward(model_json, x, prewarm=2048):
                 h = (1.0 - z) * c + z * h
                 state[i][0] = h
                 v = h
+            elif l["type"] == "conv1d":
+                # Keras Conv1D(padding="causal", strides=1): y[t] = b + sum_k x[t - (K - 1 - k) d] @ W[k]   (weights [K][in][out], [out])
+                K, d = lastint(l["kernel_size"]), lastint(l.get("dilation", 1))
+                state[i] = np.vstack([state[i][1:], v[None, :]])
+                acc = W[i][1].ravel().copy()
+                for k in range(K):
+                    acc = acc + state[i][-1 - (K - 1 - k) * d] @ W[i][0][k]
+                v = acts[l.get("activation", "") or ""](acc)
             elif l["type"] == "activation":
                 v = acts[l.get("activation", "") or ""](v)
             elif l["type"] == "batchnorm":  # inference form; [gamma, beta, mean, var] or [mean, var]; keras default epsilon
@@ -228,8 +247,9 @@ def keras_stack_forward(model_json, x, prewarm=2048):
 
 
 def synth_keras_stack(spec, seed):
-    """spec: list of ("lstm" | "gru" | "dense", units[, activation]) and, behind a layer of `units` units, ("activation", units, name) |
-    ("batchnorm", units[, "noaffine"]) | ("prelu", units[, "scalar"]); seeded U(-a, a) weights, a = 1/sqrt(fan-in-ish)."""
+    """spec: list of ("lstm" | "gru" | "dense", units[, activation]) | ("conv1d", units, kernel_size, dilation[, activation]) and, behind a layer
+    of `units` units, ("activation", units, name) | ("batchnorm", units[, "noaffine"]) | ("prelu", units[, "scalar"]); seeded U(-a, a) weights,
+    a = 1/sqrt(fan-in-ish)."""
     rng = np.random.default_rng(seed)
     layers = []
     cur = 1
@@ -251,6 +271,11 @@ def synth_keras_stack(spec, seed):
         elif kind == "prelu":
             alpha = [float(rng.uniform(0.05, 0.4))] if len(item) > 2 and item[2] == "scalar" else rng.uniform(0.05, 0.4, units).round(7).tolist()
             layers.append({"type": "prelu", "shape": [None, None, units], "weights": [alpha]})
+        elif kind == "conv1d":  # ("conv1d", units, kernel_size, dilation[, activation])
+            K, d = item[2], item[3]
+            a = 1.0 / np.sqrt(max(units, cur * K))
+            layers.append({"type": "conv1d", "activation": item[4] if len(item) > 4 else "", "shape": [None, None, units], "kernel_size": [K], "dilation": [d],
+                           "weights": [rng.uniform(-a, a, (K, cur, units)).round(7).tolist(), rng.uniform(-a, a, (units,)).round(7).tolist()]})
         else:
             layers.append({"type": "dense", "activation": item[2] if len(item) > 2 else "", "shape": [None, None, units],
                            "weights": [rng.uniform(-a, a, (cur, units)).round(7).tolist(), rng.uniform(-a, a, (units,)).round(7).tolist()]})

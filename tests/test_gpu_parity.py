@@ -203,8 +203,14 @@ def test_runtime_shaped_lstm_matches_oracle(na, loader, layers, hidden):
                                   [("dense", 8), ("activation", 8, "relu"), ("batchnorm", 8), ("dense", 1)],
                                   # dense layers wider than 64 units (round 4: up to 256)
                                   [("lstm", 8), ("dense", 128, "tanh"), ("dense", 1)], [("dense", 200, "relu"), ("dense", 96, "tanh"), ("dense", 1)],
-                                  [("gru", 24), ("dense", 256, "sigmoid"), ("dense", 100), ("prelu", 100), ("dense", 1)]],
-                         ids=lambda s: "-".join("%s%d%s" % (l[0], l[1], l[2] if len(l) > 2 else "") for l in s))
+                                  [("gru", 24), ("dense", 256, "sigmoid"), ("dense", 100), ("prelu", 100), ("dense", 1)],
+                                  # conv1d layers (causal, dilated; their input history is stream state) and softmax (round 5)
+                                  [("conv1d", 8, 3, 1, "tanh"), ("conv1d", 8, 3, 2, "tanh"), ("conv1d", 4, 2, 4, "relu"), ("dense", 1)],
+                                  [("lstm", 8), ("conv1d", 6, 5, 3), ("prelu", 6), ("batchnorm", 6), ("dense", 1, "tanh")],
+                                  [("gru", 12), ("conv1d", 16, 4, 64, "elu"), ("dense", 5, "softmax"), ("dense", 1)],
+                                  [("conv1d", 4, 12, 1), ("activation", 4, "softmax"), ("conv1d", 1, 2, 100, "sigmoid")],
+                                  [("dense", 6, "tanh"), ("conv1d", 3, 3, 170, "tanh"), ("conv1d", 1, 1, 1)]],
+                         ids=lambda s: "-".join("%s%d%s" % (l[0], l[1], "".join(str(v) for v in l[2:])) for l in s))
 def test_generic_keras_stack_matches_numpy_restatement(na, loader, spec):
     """Generic keras stacks (SURVEY 8 f3): the reference evaluates them with RTNeural, which is an absent submodule -- parity unpinned;
     the checker is tests/ref_np.keras_stack_forward (Keras layer definitions, float64, accurate tanh as the reference's
@@ -213,6 +219,8 @@ def test_generic_keras_stack_matches_numpy_restatement(na, loader, spec):
     import ref_np as R
     if (os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_LSTM_LANE_KERNEL")) and max(l[1] for l in spec if l[0] != "lstm" and l[0] != "gru") > 64:
         pytest.skip("dense layers wider than 64 units are beyond the lane = stream kernels' LDS bound")
+    if (os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_LSTM_LANE_KERNEL")) and any(l[0] == "conv1d" for l in spec):
+        pytest.skip("conv1d layers run on the runtime-shaped wave kernel only")
     mj = R.synth_keras_stack(spec, seed=40 + len(spec))
     m = loader.CreateFromString(json.dumps(mj), ".json")
     assert m is not None

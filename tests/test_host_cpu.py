@@ -269,7 +269,7 @@ def test_missing_and_malformed_files(na, tmp_path):
     with pytest.raises(na.NeuralAudioError, match="conv head on a layer array wider than 64"):
         loader.CreateFromFile(str(short), doPrewarm=False)
     conv = tmp_path / "conv.json"
-    conv.write_text(json.dumps({"in_shape": [None, None, 1], "layers": [{"type": "conv1d", "shape": [None, None, 8], "weights": []},
+    conv.write_text(json.dumps({"in_shape": [None, None, 1], "layers": [{"type": "conv2d", "shape": [None, None, 8], "weights": []},
                                                                         {"type": "dense", "shape": [None, None, 1], "weights": []}]}))
     assert loader.CreateFromFile(str(conv)) is None  # keras layer types without a kernel: no model (the reference needs RTNeural for them)
     gru = tmp_path / "gru.json"
@@ -331,10 +331,13 @@ def test_generic_keras_stacks_accepted_or_rejected_at_load(na, tmp_path):
         m = loader.CreateFromFile(str(path), doPrewarm=False)
         assert m is not None, spec
     bad = R.synth_keras_stack([("gru", 8), ("dense", 4, "tanh"), ("dense", 1)], seed=6)
-    bad["layers"][1]["activation"] = "softmax"
+    bad["layers"][1]["activation"] = "gelu"
     path.write_text(json.dumps(bad))
-    with pytest.raises(na.NeuralAudioError, match="activation 'softmax' is not supported"):
+    with pytest.raises(na.NeuralAudioError, match="activation 'gelu' is not supported"):
         loader.CreateFromFile(str(path), doPrewarm=False)
+    bad["layers"][1]["activation"] = "softmax"  # (round 5: across the units of its layer)
+    path.write_text(json.dumps(bad))
+    assert loader.CreateFromFile(str(path), doPrewarm=False) is not None
     path.write_text(json.dumps(R.synth_keras_stack([("gru", 8), ("dense", 100, "tanh"), ("dense", 1)], seed=6)))
     assert loader.CreateFromFile(str(path), doPrewarm=False) is not None  # (dense layers up to 256 units since round 4)
     path.write_text(json.dumps(R.synth_keras_stack([("gru", 8), ("dense", 300, "tanh"), ("dense", 1)], seed=6)))
@@ -347,9 +350,25 @@ def test_generic_keras_stacks_accepted_or_rejected_at_load(na, tmp_path):
     path.write_text(json.dumps(wide))
     with pytest.raises(na.NeuralAudioError, match="prelu layer wider than 128 units"):
         loader.CreateFromFile(str(path), doPrewarm=False)
-    conv = R.synth_keras_stack([("dense", 4, "tanh"), ("dense", 1)], seed=8)
-    conv["layers"][0]["type"] = "conv1d"
+    # conv1d layers (round 5): causal, dilated, behind the recurrent layers or in a stack without any; their limits are load errors
+    for spec in ([("conv1d", 8, 3, 1, "tanh"), ("conv1d", 4, 2, 4, "relu"), ("dense", 1)], [("lstm", 8), ("conv1d", 6, 5, 3), ("prelu", 6), ("batchnorm", 6), ("dense", 1)],
+                 [("gru", 12), ("conv1d", 16, 4, 64, "elu"), ("dense", 5, "softmax"), ("dense", 1)]):
+        path.write_text(json.dumps(R.synth_keras_stack(spec, seed=8)))
+        assert loader.CreateFromFile(str(path), doPrewarm=False) is not None, spec
+    conv = R.synth_keras_stack([("conv1d", 4, 3, 1, "tanh"), ("dense", 1)], seed=8)
+    conv["layers"][0]["strides"] = [2]
     path.write_text(json.dumps(conv))
+    with pytest.raises(na.NeuralAudioError, match="stride or groups"):
+        loader.CreateFromFile(str(path), doPrewarm=False)
+    path.write_text(json.dumps(R.synth_keras_stack([("conv1d", 4, 3, 600), ("dense", 1)], seed=8)))
+    with pytest.raises(na.NeuralAudioError, match="more than 1024 samples of history"):
+        loader.CreateFromFile(str(path), doPrewarm=False)
+    path.write_text(json.dumps(R.synth_keras_stack([("conv1d", 200, 3, 400), ("dense", 1)], seed=8)))  # two [200][800 + 128] buffers: beyond the LDS
+    with pytest.raises(na.NeuralAudioError, match="conv1d layers with its two"):
+        loader.CreateFromFile(str(path), doPrewarm=False)
+    front = R.synth_keras_stack([("conv1d", 4, 3, 1, "tanh"), ("dense", 1)], seed=8)  # a conv1d layer in FRONT of a recurrent one: no kernel
+    front["layers"].insert(1, R.synth_keras_stack([("dense", 4), ("gru", 8)], seed=8)["layers"][1])
+    path.write_text(json.dumps(front))
     assert loader.CreateFromFile(str(path), doPrewarm=False) is None
 
 

@@ -298,7 +298,7 @@ def test_generic_keras_stack_restatement_matches_committed_torch_vectors():
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     d = np.load(os.path.join(here, "keras_stacks_torch.npz"))
     names = [k for k in d.files if k != "input"]
-    assert len(names) == 3
+    assert len(names) == 5  # (three lstm / gru / dense stacks, two with conv1d layers and softmax)
     for name in names:
         with open(os.path.join(here, "models", "synthetic_stack_%s.json" % name)) as f:
             j = json.load(f)

@@ -12,7 +12,7 @@ i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
-  env "$@" rocprofv3 --kernel-trace --pmc $group -f csv -d $OUT/pass$i -o pmc -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check --no-host-path ${NA_PMC_BENCH_ARGS:-} > $OUT/pass$i.log 2>&1
+  env "$@" rocprofv3 --kernel-trace --pmc $group -f csv -d $OUT/pass$i -o pmc -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check --no-host-path --rotate 0 --no-exact-f32 ${NA_PMC_BENCH_ARGS:-} > $OUT/pass$i.log 2>&1
 done <<'GROUPS'
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT

@@ -18,9 +18,11 @@ BARGS="$@"
 export NA_PMC_BENCH_ARGS="$BARGS"
 python $R/bench.py $BARGS > $OUT/bench.json 2> $OUT/bench.err
 rm -rf $OUT/stats
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o prof -- python $R/bench.py --no-cpu-baseline --no-parity-check --no-host-path $BARGS > $OUT/stats.log 2>&1
+# (the traced / counted runs are the timed workload alone: no rotation regime, exact-f32 or resident-launch side runs, whose dispatches of the
+# same kernel would be averaged in)
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o prof -- python $R/bench.py --no-cpu-baseline --no-parity-check --no-host-path --rotate 0 --no-exact-f32 $BARGS > $OUT/stats.log 2>&1
 DB=$(find $OUT/stats -name "*.db" | head -1)
-python $R/tools/rocprof_summary.py "$DB" $OUT/kernel_stats.csv "python bench.py --no-cpu-baseline --no-parity-check --no-host-path $BARGS under rocprofv3 --kernel-trace --stats" 2>> $OUT/stats.log || ls -R $OUT/stats >> $OUT/stats.log
+python $R/tools/rocprof_summary.py "$DB" $OUT/kernel_stats.csv "python bench.py --no-cpu-baseline --no-parity-check --no-host-path --rotate 0 --no-exact-f32 $BARGS under rocprofv3 --kernel-trace --stats" 2>> $OUT/stats.log || ls -R $OUT/stats >> $OUT/stats.log
 bash $R/tools/pmc_passes.sh $TAG/pmc > /dev/null 2>&1
 python $R/tools/pmc_summary.py $OUT/pmc $KPAT > $OUT/pmc_summary.txt
 rm -rf $OUT/stats $OUT/pmc/pass*/  # keep the summaries, not the raw traces
