@@ -11,6 +11,7 @@
 #include "lstm_launch.h"
 #include "wavenet_launch.h"
 #include "wavenet_plan.h"
+#include "tuning.h"
 
 struct NeuralModel
 {
@@ -294,9 +295,10 @@ int NA_DebugPackedWeights(NeuralModel* model, int* packFactor, float* out, int c
 			r = 0;
 			return;
 		}
-		const na::WaveNetDesc v = na::PackWaveNetDesc(wn, P);
+		const bool dense = na::Tuning::Get().wnDense != 0 && na::WaveNetPackCanBeDense(wn, P); // (the layout a batch would give it: four Nano streams at 16 / 8 channels)
+		const na::WaveNetDesc v = na::PackWaveNetDesc(wn, P, dense);
 		na::ValidateWaveNetDesc(v); // weight count and chaining of the virtual model
-		const na::WaveNetPlan plan = na::BuildPackedWaveNetPlan(wn, P);
+		const na::WaveNetPlan plan = na::BuildPackedWaveNetPlan(wn, P, dense);
 		if (plan.pack != P || plan.splitFastT != 2) throw std::runtime_error("NA_DebugPackedWeights: the packed plan is not a fast split-kernel plan");
 		r = (int)v.weights.size();
 		if (out)

@@ -374,7 +374,8 @@ def test_generic_keras_stacks_accepted_or_rejected_at_load(na, tmp_path):
 
 def test_stream_packing_builds_a_block_diagonal_virtual_model(na):
     """Stream packing, host side (no GPU): Nano packs 4 streams, Feather 2, Standard / A2 none; the virtual model's flat weights hold
-    the real model's tensors on the block diagonal, replicated vectors, zeros elsewhere, in the reference's weight order."""
+    the real model's tensors on the block diagonal, replicated vectors, zeros elsewhere, in the reference's weight order.  Nano's pack
+    is dense: 16 / 8 virtual channels (wavenet_plan.cpp WaveNetPackCanBeDense)."""
     import ctypes as C
     from neuralaudio_amd import capi
     lib = capi.load_library()
@@ -399,6 +400,8 @@ def test_stream_packing_builds_a_block_diagonal_virtual_model(na):
         w = np.array(j["weights"], np.float32)
         arrays = O.wavenet_arrays_from_nam(j)
         pad = [4 * ((a["channels"] + 3) // 4) for a in arrays]
+        if P == 4 and [a["channels"] for a in arrays] == [4, 2] and os.environ.get("NA_WN_DENSE") != "0":
+            pad[1] = 2  # dense pack (round 5): the 2-channel arrays of the four streams side by side, two streams per channel group
         pos = vpos = 0
         for ai, a in enumerate(arrays):
             C_, Cp = a["channels"], pad[ai]
