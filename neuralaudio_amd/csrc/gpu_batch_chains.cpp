@@ -140,7 +140,11 @@ namespace na
 	// The buffer through the resident launch; false: not this batch / this buffer (the caller runs it the other ways).
 	bool GpuBatch::TryResident(const float* dIn, float* dOut, size_t n, long inStride, long outStride)
 	{
-		if (!residentWanted || n % (size_t)WN_MAX_FRAMES != 0) return false;
+		if (!residentWanted || n % (size_t)WN_MAX_FRAMES != 0)
+		{
+			DrainResident(); // (a buffer of another length runs as ordinary launches: behind everything the resident launch still holds)
+			return false;
+		}
 		if (!residentState) residentState.reset(new ResidentState());
 		ResidentState& r = *residentState;
 		bool dirty = false;
@@ -151,6 +155,13 @@ namespace na
 			if (!ResidentConfigure()) return false;
 		}
 		if (!r.configured) return false;
+		if (halfChainsUsed)
+		{
+			// an earlier buffer of another length ran as half-batch launches on the chain streams: the command comes behind them
+			for (hipStream_t hs : halfStream)
+				if (hs) CheckHip(hipStreamSynchronize(hs), "hipStreamSynchronize");
+			halfChainsUsed = false;
+		}
 		if (r.exitRequested) DrainResident(); // a closing mark asked the launch to leave: this command starts the next generation
 		for (size_t offset = 0; offset < n; offset += (size_t)WN_MAX_FRAMES)
 		{

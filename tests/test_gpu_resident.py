@@ -201,3 +201,32 @@ def test_timing_marks_bracket_the_resident_steps(na, std):
     b.Synchronize()
     assert bool(torch.isfinite(y).all().item())
     b.close()
+
+
+def test_buffers_of_other_lengths_between_resident_steps_are_ordered_behind_them(na, std):
+    """A buffer that is not a multiple of 128 frames cannot be a command to the resident launch: it runs as ordinary launches -- which must
+    wait for every command still in flight (the same streams' state).  Bit for bit the ordered launches over a ragged sequence."""
+    import torch
+    S = 1024
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(12)
+    ts, ref, b = _pair(na, std, S)
+    lengths = [128, 128, 64, 128, 37, 256, 128, 5, 128, 128]
+    x = torch.clamp(0.3 * torch.randn(S, sum(lengths), generator=g), -1.0, 1.0).to(dev)
+    want, got = torch.zeros_like(x), torch.zeros_like(x)
+    torch.cuda.synchronize(dev)
+    total = x.shape[1]
+    resident = 0
+    for bb, y in ((ref, want), (b, got)):
+        at = 0
+        for n in lengths:
+            bb.ProcessDevice(x[:, at:].data_ptr(), y[:, at:].data_ptr(), n, total, total)
+            if bb is b:
+                resident += int(b.UsesResidentLaunch())
+            at += n
+        bb.Synchronize()
+    assert torch.equal(want, got)
+    if not any(os.environ.get(k) for k in _KNOBS):
+        assert resident == sum(1 for n in lengths if n % 128 == 0)
+    ref.close()
+    b.close()
