@@ -218,7 +218,7 @@ def parity_spot_check(check_rows, x, y, issued, nbuf, mdir):
     return {"rms": worst, "per_model": per_model}
 
 
-def rotation_regime(na, model, local_rank, dev, n_rot, bytes_per_sample, steps=120, warmup=24, resident=False):
+def rotation_regime(na, model, local_rank, dev, n_rot, bytes_per_sample, steps=240, warmup=80, resident=False):
     """The metric's own regime: ONE batch of n_rot x 1024 A1 Standard streams, every step visits the whole
     n_rot x 249 MB of ring state once -- nothing survives in the 256 MB Infinity Cache from one step to the next.  Same timed-region
     rules as the headline (library HIP events around the steps, wall clock beside them)."""

@@ -155,6 +155,9 @@ namespace na
 			if (!ResidentConfigure()) return false;
 		}
 		if (!r.configured) return false;
+		if (pipelineUsed)
+			for (PipeSlot& p : pipe) // (buffers submitted through the pipelined host interface run on per-slot streams: behind them as well)
+				if (p.own) CheckHip(hipStreamSynchronize(p.own), "hipStreamSynchronize");
 		if (halfChainsUsed)
 		{
 			// an earlier buffer of another length ran as half-batch launches on the chain streams: the command comes behind them
