@@ -659,7 +659,7 @@ namespace na
 			if (cls != TAP_LDS)
 			{
 				acc = Mfma(ah, hist, acc);
-				acc = Mfma(al, hist, acc);
+				acc = MfmaLo<1>(al, hist, acc);
 			}
 			if (cls != TAP_HIST)
 			{
@@ -674,7 +674,7 @@ namespace na
 					b = LdsRead16((unsigned)(C::IMG_OFF + imgRead * C::IMG_ONE + GUARD * 16) + (unsigned)(cx.sub * 2 * C::IMG_ONE) + (unsigned)((ln.cg * PLANE + off) * 16));
 				}
 				acc = Mfma(ah, b, acc);
-				acc = Mfma(al, b, acc);
+				acc = MfmaLo<1>(al, b, acc);
 			}
 			return acc;
 		}
@@ -745,7 +745,7 @@ namespace na
 				for (int i = 0; i < S; i++)
 				{
 					acc[i] = Mfma(ah, st.xs[i], acc[i]);
-					acc[i] = Mfma(al, st.xs[i], acc[i]);
+					acc[i] = MfmaLo<1>(al, st.xs[i], acc[i]);
 				}
 			}
 			if constexpr (TAIL)
@@ -775,7 +775,7 @@ namespace na
 					{
 						f32x4 y = st.xc[i];
 						y = Mfma(w1h, zs, y);
-						y = Mfma(w1l, zs, y);
+						y = MfmaLo<2>(w1l, zs, y);
 						y = Mfma(b1a, NA_SPK_AUX2 ? AuxRead<C, GP>(ln, i) : ax[i], y);
 						st.xc[i] = y;
 						if constexpr (SG::NEXT)
@@ -908,10 +908,10 @@ namespace na
 			for (int t = 0; t < C::T; t++)
 			{
 				const int u = t % NC, so = t / Po, sn = t / Pn;
-				hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
-				hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u + 1), hs[so], hn[sn]);
+hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
+				hn[sn] = MfmaLo<4>(WOp<C>(cx, s, 0, 4 * u + 1), hs[so], hn[sn]);
 				xn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u + 2), xq[so], xn[sn]);
-				xn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u + 3), xq[so], xn[sn]);
+				xn[sn] = MfmaLo<4>(WOp<C>(cx, s, 0, 4 * u + 3), xq[so], xn[sn]);
 			}
 #pragma unroll
 			for (int i = 0; i < Sn; i++)
@@ -986,7 +986,7 @@ namespace na
 					for (int i = 0; i < S; i++)
 					{
 						acc[i] = Mfma(ah, hs[i], acc[i]);
-						acc[i] = Mfma(al, hs[i], acc[i]);
+						acc[i] = MfmaLo<8>(al, hs[i], acc[i]);
 					}
 				}
 				if (2 * K >= TB::ChunkBegin(s, c) && 2 * K < TB::ChunkEnd(s, c))

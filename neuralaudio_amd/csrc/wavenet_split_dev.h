@@ -64,6 +64,32 @@ namespace na
 			return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 		}
 
+		// the "lo" product of the three-product split, Wl . xh: its A operand is [Wl | 0 0 0 0] per lane and k-block and only the h half
+		// of the split quad B takes part -- the first 64 bits of either are exactly the operands of the K = 16 instruction (lane (i, q): k =
+		// 4 q .. 4 q + 3), which does the same sixteen products per row in half the passes of the matrix pipe (tuning builds: -DNA_LO16=1)
+#ifndef NA_LO16
+#define NA_LO16 0
+#endif
+		// (SITE: 1 conv taps, 2 the 1x1, 4 array links, 8 heads -- NA_LO16 is a mask of the sites that use the K = 16 instruction)
+		template <int SITE>
+		__device__ __forceinline__ f32x4 MfmaLo(u32x4 a, u32x4 b, f32x4 c)
+		{
+#if NA_LO16
+			if (!(NA_LO16 & SITE)) return Mfma(a, b, c);
+			if (NA_ABL & 2) return f32x4{ c.x + __builtin_bit_cast(float, a.x ^ b.x), c.y, c.z, c.w };
+			typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+			const u32x2 a2 = { a.x, a.y }, b2 = { b.x, b.y };
+			f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a2), __builtin_bit_cast(f16x4_t, b2), c, 0, 0, 0);
+			// the sources stay live past the instruction: with -amdgpu-mfma-vgpr-form this LLVM lets the result of the K = 16 form land on the
+			// registers of a source that dies here (seen: v_mfma_f32_16x16x16_f16 v[18:21], v[54:55], v[18:19], v[20:23] -- the later passes
+			// then read what the first ones wrote; the K = 32 form is protected)
+			asm("" : "+v"(d) : "v"(a), "v"(b));
+			return d;
+#else
+			return Mfma(a, b, c);
+#endif
+		}
+
 		__device__ __forceinline__ unsigned PackHalf2(float a, float b)
 		{
 			const f16x2 h = __builtin_convertvector(f32x2{ a, b }, f16x2); // v_cvt_pk_f16_f32 (round to nearest even)

@@ -334,7 +334,7 @@ namespace na
 							for (int i = 0; i < S; i++)
 							{
 								acc[i] = Mfma(ah, hist[k][i], acc[i]);
-								acc[i] = Mfma(al, hist[k][i], acc[i]);
+								acc[i] = MfmaLo<1>(al, hist[k][i], acc[i]);
 							}
 						}
 						else if (lo >= 0)
@@ -345,7 +345,7 @@ namespace na
 								u32x4 b = imgCur[ImgIdx(cg[i], f[i] - shift)];
 								if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 }; // no garbage (NaN) into the MFMA
 								acc[i] = Mfma(ah, b, acc[i]);
-								acc[i] = Mfma(al, b, acc[i]);
+								acc[i] = MfmaLo<1>(al, b, acc[i]);
 							}
 						}
 						else
@@ -356,9 +356,9 @@ namespace na
 								u32x4 b = TapInBlock(imgCur, f[i] - shift, cg[i]);
 								if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 };
 								acc[i] = Mfma(ah, hist[k][i], acc[i]);
-								acc[i] = Mfma(al, hist[k][i], acc[i]);
+								acc[i] = MfmaLo<1>(al, hist[k][i], acc[i]);
 								acc[i] = Mfma(ah, b, acc[i]);
-								acc[i] = Mfma(al, b, acc[i]);
+								acc[i] = MfmaLo<1>(al, b, acc[i]);
 							}
 						}
 					}
@@ -387,7 +387,7 @@ namespace na
 						u32x4 b = TapOperandInline(cx, imgCur, sd.ring_off, sd.ring_frames, G, inPos0, f[i], cg[i] < G ? cg[i] : 0, shift, lo, lo + 16 * P - 1);
 						if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 };
 						acc[i] = Mfma(ah, b, acc[i]);
-						acc[i] = Mfma(al, b, acc[i]);
+						acc[i] = MfmaLo<1>(al, b, acc[i]);
 					}
 				}
 				{
@@ -401,7 +401,7 @@ namespace na
 						if (mask) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 };
 						const u32x4 ax = AuxOf<PK>(cx, f[i], cg[i], gsShift);
 						acc[i] = Mfma(ah, b, acc[i]);
-						acc[i] = Mfma(al, b, acc[i]);
+						acc[i] = MfmaLo<1>(al, b, acc[i]);
 						acc[i] = Mfma(xa, ax, acc[i]);
 					}
 				}
@@ -449,7 +449,7 @@ namespace na
 						st.hd[i] = Mfma(idop, zs, st.hd[i]);
 						f32x4 y = st.xc[i];
 						y = Mfma(w1h, zs, y);
-						y = Mfma(w1l, zs, y);
+						y = MfmaLo<2>(w1l, zs, y);
 						y = Mfma(b1a, ax, y);
 						st.xc[i] = y;
 						// always one store per set (predicated through the offset): fixed VMEM count per layer
@@ -555,9 +555,9 @@ namespace na
 			{
 				const int u = t % NC, so = t / Po, sn = t / Pn;
 				hn[sn] = Mfma(wl[(4 * u) * 64], hs[so], hn[sn]);
-				hn[sn] = Mfma(wl[(4 * u + 1) * 64], hs[so], hn[sn]);
+				hn[sn] = MfmaLo<4>(wl[(4 * u + 1) * 64], hs[so], hn[sn]);
 				xn[sn] = Mfma(wl[(4 * u + 2) * 64], xs[so], xn[sn]);
-				xn[sn] = Mfma(wl[(4 * u + 3) * 64], xs[so], xn[sn]);
+				xn[sn] = MfmaLo<4>(wl[(4 * u + 3) * 64], xs[so], xn[sn]);
 			}
 #pragma unroll
 			for (int i = 0; i < Sn; i++)
@@ -618,7 +618,7 @@ namespace na
 						u32x4 b = TapOperandInline(cx, imgNext, sd.ring_off, sd.ring_frames, G, pos0, f[i], cg[i] < G ? cg[i] : 0, shift, lo, lo + 16 * P - 1);
 						if (Geo<GP, T>::PARTIAL || GP == 4) b = (live[i] && cg[i] < G) ? b : u32x4{ 0, 0, 0, 0 };
 						acc[i] = Mfma(ah, b, acc[i]);
-						acc[i] = Mfma(al, b, acc[i]);
+						acc[i] = MfmaLo<8>(al, b, acc[i]);
 					}
 				}
 			}
@@ -628,7 +628,7 @@ namespace na
 				for (int i = 0; i < S; i++)
 				{
 					acc[i] = Mfma(ah, hs[i], acc[i]);
-					acc[i] = Mfma(al, hs[i], acc[i]);
+					acc[i] = MfmaLo<8>(al, hs[i], acc[i]);
 					if (sd.flags & WN_FLAG_BIAS)
 					{
 						const u32x4 ax = AuxOf<PK>(cx, f[i], 0, 0); // bias only
