@@ -509,6 +509,20 @@ namespace na
 			while (left > 0)
 			{
 				const int chunk = NextWaveNetChunk(left, compact);
+				// more groups than one launch's kernarg table holds (a batch of many different models): ONE launch with the table in device
+				// memory where the chains have one (128-frame blocks of the A1 families), else launches of eight groups each
+				if (which != 0 && list.size() > (size_t)WN_FRAME_MAX_GROUPS)
+				{
+					const hipError_t te = LaunchWaveNetSpecTable(list.data(), (int)list.size(), dIn + offset, dOut + offset, inStride, outStride, chunk, s, wnTable[which]);
+					if (te == hipSuccess)
+					{
+						offset += (size_t)chunk;
+						left -= (size_t)chunk;
+						continue;
+					}
+					if (te != hipErrorNotSupported) CheckHip(te, "WaveNet kernel (table launch)");
+					(void)hipGetLastError();
+				}
 				for (size_t first = 0; first < list.size(); first += WN_FRAME_MAX_GROUPS)
 				{
 					const int count = (int)std::min<size_t>(list.size() - first, (size_t)WN_FRAME_MAX_GROUPS);

@@ -1,6 +1,8 @@
 // wavenet_launch.h -- host-callable launchers of the WaveNet kernels (wavenet_split_kernels.hip, wavenet_frame_kernels.hip, wavenet_prewarm_kernels.hip)
 #pragma once
 
+#include <vector>
+
 #include <hip/hip_runtime_api.h>
 
 #include "wavenet_dev.h"
@@ -38,6 +40,23 @@ namespace na
 	// hipErrorNotSupported otherwise -- LaunchWaveNetSplitFused tries it first and falls back to its stage interpreter.
 	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream, int sharing = 1);
+	// ---- table launches of the specialised chains (wavenet_spec_impl.h WaveNetSpecTableKernel): any number of model groups in one launch --
+	// The device copy of a launch's group table, owned by the batch (one per launch list); see LaunchWaveNetSpecTable.
+	struct WnLaunchTable
+	{
+		void* dev = nullptr;
+		size_t devBytes = 0;
+		std::vector<char> host; // what `dev` holds
+		WnLaunchTable() = default;
+		WnLaunchTable(const WnLaunchTable&) = delete;
+		WnLaunchTable& operator=(const WnLaunchTable&) = delete;
+		~WnLaunchTable() { if (dev) (void)hipFree(dev); }
+	};
+	// A launch list of MORE than WN_FRAME_MAX_GROUPS groups of one A1 architecture family (all Standard; or lite-family groups, packed or
+	// not) as ONE launch of 128-frame blocks; hipErrorNotSupported otherwise (the caller then cuts the list into launches of eight).
+	hipError_t LaunchWaveNetSpecTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream, WnLaunchTable& table);
+
 	// ---- resident ("persistent") launches of the specialised chains (wavenet_spec_impl.h WaveNetSpecResidentKernel) --------------
 	// One launch stays on the chip and walks consecutive buffers by itself: the host posts a command per buffer into a ring, every
 	// workgroup polls the command it needs next, runs its streams' block and counts itself done.  Workgroups never wait for each other

@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 
 #include "device_once.h"
+#include <cstring>
+#include <vector>
+
 #include "tuning.h"
 #include "wavenet_split_dev.h"
 
@@ -1419,19 +1422,18 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 
 		// the kernarg tables of a launch list; *blocksOut = workgroups it takes
 		template <class F, int NF, int SPB, bool PK>
-		static hipError_t FillLaunchArgs(const WnFrameGroup* groups, int numGroups, LaunchArgs& args, int* blocksOut)
+		static hipError_t FillGroupArgs(const WnFrameGroup* groups, int numGroups, GroupArgs* out, int* blocksOut)
 		{
 			typedef Cfg<typename F::A0, NF, SPB, PK> C;
 			typedef Cfg<typename F::A1, NF, SPB, PK> C1;
-			args = {};
-			args.numGroups = numGroups;
 			int blocks = 0;
 			const bool reverse = Tuning::Get().spReverse; // tuning: the groups' workgroups in the opposite dispatch order
 			for (int i = 0; i < numGroups; i++)
 			{
 				const WnFrameGroup& g = groups[reverse ? numGroups - 1 - i : i];
 				const WnModelDev& m = *g.model;
-				GroupArgs& a = args.g[i];
+				out[i] = {};
+				GroupArgs& a = out[i];
 				a.stages = m.sstages; a.wsplit = m.wsplit; a.ringFrames = m.ring_frames;
 				a.state = reinterpret_cast<u32x4*>(g.state); a.slots = g.slots; a.rows = g.rows;
 				a.nstages = m.nstages; a.nrings = m.nrings; a.stateF4 = m.state_f4; a.wsplitQuads = m.wsplit_quads;
@@ -1454,6 +1456,98 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 			}
 			*blocksOut = blocks;
 			return hipSuccess;
+		}
+
+		template <class F, int NF, int SPB, bool PK>
+		static hipError_t FillLaunchArgs(const WnFrameGroup* groups, int numGroups, LaunchArgs& args, int* blocksOut)
+		{
+			args = {};
+			args.numGroups = numGroups;
+			return FillGroupArgs<F, NF, SPB, PK>(groups, numGroups, args.g, blocksOut);
+		}
+
+		// ---- table launches: any number of model groups in ONE launch ---------------------------------------------------------------
+		// The kernarg segment holds WN_FRAME_MAX_GROUPS groups; a batch of hundreds of DIFFERENT models (every stream its own capture: what a
+		// server sees) would be cut into launches of eight groups each, one after the other -- 1024 models x 1 stream: 128 launches, 2.9 ms
+		// per 128-frame buffer.  Here the group table lives in device memory (rebuilt and uploaded when the batch's topology changes): a
+		// workgroup finds its group by binary search over GroupArgs::firstBlock with scalar loads and copies the entry, the chain is the
+		// same code.  (Table kernels exist for 128-frame blocks of the A1 families; other lengths keep the launches of eight.)
+		template <class F, int NF, int SPB, bool PK>
+		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(OccOf<F, NF, SPB>()))) WaveNetSpecTableKernel(
+			const GroupArgs* __restrict__ table, int numGroups, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride)
+		{
+			typedef Cfg<typename F::A0, NF, SPB, PK> C;
+			typedef Cfg<typename F::A1, NF, SPB, PK> C1;
+			extern __shared__ __attribute__((aligned(16))) char dynSmem[];
+			asm volatile("" : : "s"((unsigned)(size_t)(LdsPtr)dynSmem)); // the dynamic LDS segment is in use (and starts at 0)
+			// (the table is read-only for the launch: constant address space = scalar loads)
+			typedef const __attribute__((address_space(4))) GroupArgs* TablePtr;
+			TablePtr tab = (TablePtr)(size_t)table;
+			int lo = 0, hi = numGroups - 1;
+			while (lo < hi)
+			{
+				const int mid = (lo + hi + 1) >> 1;
+				if (tab[mid].firstBlock <= (int)blockIdx.x) lo = mid;
+				else hi = mid - 1;
+			}
+			// the entry, word by word out of the constant address space (scalar loads the compiler merges)
+			GroupArgs ga;
+			{
+				static_assert(sizeof(GroupArgs) % 4 == 0, "dword copy");
+				typedef const __attribute__((address_space(4))) unsigned* WordPtr;
+				WordPtr src = (WordPtr)(size_t)(table + lo);
+				unsigned* dst = reinterpret_cast<unsigned*>(&ga);
+#pragma unroll
+				for (int i = 0; i < (int)(sizeof(GroupArgs) / 4); i++) dst[i] = src[i];
+			}
+			const int groupBlock = (int)blockIdx.x - ga.firstBlock;
+#ifdef NA_SP_TRACE
+			if (F::N > 1 && ga.arch == 1) RunWorkgroup<C1>(ga, groupBlock, in, out, inStride, outStride, nullptr);
+			else RunWorkgroup<C>(ga, groupBlock, in, out, inStride, outStride, nullptr);
+#else
+			if (F::N > 1 && ga.arch == 1) RunWorkgroup<C1>(ga, groupBlock, in, out, inStride, outStride);
+			else RunWorkgroup<C>(ga, groupBlock, in, out, inStride, outStride);
+#endif
+		}
+
+		// host side of a table launch: the table is rebuilt into `t.host` every call (it is a few stores per group) and uploaded only
+		// when it differs from what the device holds
+		template <class F, int NF, int SPB, bool PK>
+		static hipError_t LaunchTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, hipStream_t stream, WnLaunchTable& t)
+		{
+			typedef Cfg<typename F::A0, NF, SPB, PK> C;
+			typedef Cfg<typename F::A1, NF, SPB, PK> C1;
+			std::vector<GroupArgs> fresh((size_t)numGroups);
+			int blocks = 0;
+			const hipError_t fe = FillGroupArgs<F, NF, SPB, PK>(groups, numGroups, fresh.data(), &blocks);
+			if (fe != hipSuccess) return fe;
+			const size_t bytes = fresh.size() * sizeof(GroupArgs);
+			if (t.dev == nullptr || t.devBytes < bytes)
+			{
+				if (t.dev) (void)hipFree(t.dev);
+				t.dev = nullptr;
+				t.host.clear();
+				const hipError_t me = hipMalloc(&t.dev, bytes + bytes / 2);
+				if (me != hipSuccess) return me;
+				t.devBytes = bytes + bytes / 2;
+			}
+			if (t.host.size() != bytes || memcmp(t.host.data(), fresh.data(), bytes) != 0)
+			{
+				// (pageable source: the copy is staged by the runtime before the call returns; ordered before the launch on `stream`)
+				t.host.assign(reinterpret_cast<const char*>(fresh.data()), reinterpret_cast<const char*>(fresh.data()) + bytes);
+				const hipError_t ce = hipMemcpyAsync(t.dev, t.host.data(), bytes, hipMemcpyHostToDevice, stream);
+				if (ce != hipSuccess) return ce;
+			}
+			constexpr int LDS_BYTES = C::LDS_BYTES > C1::LDS_BYTES ? C::LDS_BYTES : C1::LDS_BYTES;
+			if (LDS_BYTES > 64 * 1024)
+			{
+				static PerDeviceOnce attr; // per instantiation and device
+				const hipError_t e = attr.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(WaveNetSpecTableKernel<F, NF, SPB, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); });
+				if (e != hipSuccess) return e;
+			}
+			hipLaunchKernelGGL((WaveNetSpecTableKernel<F, NF, SPB, PK>), dim3((unsigned)blocks), dim3(C::NTHREADS), LDS_BYTES, stream,
+				reinterpret_cast<const GroupArgs*>(t.dev), numGroups, in, out, inStride, outStride);
+			return hipGetLastError();
 		}
 
 		template <class F, int NF, int SPB, bool PK>
@@ -1553,5 +1647,7 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 		hipError_t LaunchSpecLite(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, bool packed,
 			hipStream_t stream, bool oneTilePerWave = false);
 		hipError_t LaunchSpecA2(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream);
+		hipError_t LaunchSpecLiteTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int spb, bool packed,
+			hipStream_t stream, WnLaunchTable& table);
 	}
 }

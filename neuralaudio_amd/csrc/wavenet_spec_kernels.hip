@@ -40,6 +40,43 @@ namespace na
 		return WN_SPEC_NONE;
 	}
 
+	// More groups than the kernarg segment holds, in one launch (wavenet_launch.h).  Streams per workgroup: two share the staged weights,
+	// so a group with an odd stream count leaves half a workgroup idle -- with mostly one-stream groups (every stream its own model)
+	// the half-size workgroups waste nothing.
+	hipError_t LaunchWaveNetSpecTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream, WnLaunchTable& table)
+	{
+#ifdef NA_SP_QUICK
+		return hipErrorNotSupported;
+#else
+		if (numGroups <= WN_FRAME_MAX_GROUPS || n != 128 || !WaveNetSpecEnabled() || Tuning::Get().spSpb > 0) return hipErrorNotSupported;
+		const int arch = groups[0].model->spec_arch;
+		const bool lite = arch == WN_SPEC_LITE || arch == WN_SPEC_LITE16;
+		if (arch != WN_SPEC_STD && !lite) return hipErrorNotSupported;
+		bool packed = false;
+		long streams = 0, slots2 = 0;
+		for (int i = 0; i < numGroups; i++)
+		{
+			const int a = groups[i].model->spec_arch;
+			if (groups[i].numStreams <= 0 || (lite ? (a != WN_SPEC_LITE && a != WN_SPEC_LITE16) : a != WN_SPEC_STD)) return hipErrorNotSupported;
+			packed = packed || groups[i].pack > 1;
+			streams += groups[i].numStreams;
+			slots2 += (groups[i].numStreams + 1) / 2 * 2;
+		}
+		if (!lite && packed) return hipErrorNotSupported;
+		if (packed)
+			for (int i = 0; i < numGroups; i++)
+				if (groups[i].slots == nullptr) return hipErrorNotSupported;
+		if (!packed)
+			for (int i = 0; i < numGroups; i++)
+				if (groups[i].model->spec_arch == WN_SPEC_LITE16) return hipErrorNotSupported; // (16 / 16 only exists packed)
+		const int spb = (slots2 * 4 > streams * 5) ? 1 : 2; // more than a quarter of the full-size workgroups' stream slots would idle
+		if (!lite) return spb == 2 ? spk::LaunchTable<spk::FamStd, 128, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table)
+								   : spk::LaunchTable<spk::FamStd, 128, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
+		return spk::LaunchSpecLiteTable(groups, numGroups, in, out, inStride, outStride, spb, packed, stream, table);
+#endif
+	}
+
 	// Runs the launch on a specialised chain when every group is the SAME official architecture and the block is 128 / 64 / 32 frames;
 	// returns hipErrorNotSupported otherwise (the caller then uses the stage interpreter).
 	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,

@@ -18,5 +18,20 @@ namespace na
 			return LaunchNF<FamLite, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
 #endif
 		}
+
+		// the same families as table launches (wavenet_launch.h LaunchWaveNetSpecTable): 128-frame blocks
+		hipError_t LaunchSpecLiteTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int spb, bool packed,
+			hipStream_t stream, WnLaunchTable& table)
+		{
+#ifdef NA_SP_QUICK
+			return hipErrorNotSupported;
+#else
+			if (packed)
+				return spb >= 2 ? LaunchTable<FamLitePacked, 128, 2, true>(groups, numGroups, in, out, inStride, outStride, stream, table)
+								: LaunchTable<FamLitePacked, 128, 1, true>(groups, numGroups, in, out, inStride, outStride, stream, table);
+			return spb >= 2 ? LaunchTable<FamLite, 128, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table)
+							: LaunchTable<FamLite, 128, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
+#endif
+		}
 	}
 }

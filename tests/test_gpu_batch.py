@@ -893,3 +893,38 @@ def test_registered_host_blocks_are_processed_in_place(na, loader):
     assert np.array_equal(y_reg, y_copy)
     assert not np.any(y_reg[5])
     assert O.rms(y_reg[36] - O.oracle_from_file("BossWN-standard.nam").process(x[36])) < TOL_RMS
+
+
+@pytest.mark.parametrize("name,models,per", [("BossWN-standard.nam", 24, 3), ("BossWN-standard.nam", 40, 1), ("BossWN-nano.nam", 20, 5), ("BossWN-feather.nam", 12, 2)])
+def test_many_distinct_models_run_as_one_table_launch_and_match_one_model_batch(na, loader, name, models, per):
+    """A server's batch: many DIFFERENT model handles with a few streams each (here the same file loaded `models` times: as many model
+    groups).  More groups than a launch's kernarg segment holds run as ONE launch whose group table lives in device memory
+    (wavenet_spec_impl.h WaveNetSpecTableKernel) -- bit for bit what one model handle with all the streams computes, over a ragged
+    buffer sequence (128-frame blocks: table launches; the rest: launches of eight groups)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    handles = [loader.CreateFromFile(_path(name), doPrewarm=False) for _ in range(models)]
+    ts = torch.cuda.Stream(device=dev)
+    many, one = na.Batch(0, hip_stream=ts.cuda_stream), na.Batch(0, hip_stream=ts.cuda_stream)
+    for h in handles:
+        many.AddStreams(h, per)
+    one.AddStreams(handles[0], models * per)
+    S = models * per
+    g = torch.Generator(device="cpu").manual_seed(5)
+    lengths = [128, 128, 64, 128, 37, 256]
+    total = sum(lengths)
+    x = torch.clamp(0.3 * torch.randn(S, total, generator=g), -1.0, 1.0).to(dev)
+    want, got = torch.zeros_like(x), torch.zeros_like(x)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(ts):
+        for bb, y in ((one, want), (many, got)):
+            at = 0
+            for n in lengths:
+                bb.ProcessDevice(x[:, at:].data_ptr(), y[:, at:].data_ptr(), n, total, total)
+                at += n
+            bb.Synchronize()
+    assert torch.equal(want, got)
+    yo = O.oracle_from_file(name).process(x[S - 1].cpu().numpy())
+    assert O.rms(got[S - 1].cpu().numpy() - yo) < TOL_RMS
+    many.close()
+    one.close()
