@@ -52,8 +52,8 @@ namespace na
 		WnLaunchTable& operator=(const WnLaunchTable&) = delete;
 		~WnLaunchTable() { if (dev) (void)hipFree(dev); }
 	};
-	// A launch list of MORE than WN_FRAME_MAX_GROUPS groups of one A1 architecture family (all Standard; or lite-family groups, packed or
-	// not) as ONE launch of 128-frame blocks; hipErrorNotSupported otherwise (the caller then cuts the list into launches of eight).
+	// A launch list of MORE than WN_FRAME_MAX_GROUPS groups of one architecture family (all Standard; lite-family groups, packed or not;
+	// the A2 submodels) as ONE launch of 128-frame blocks; hipErrorNotSupported otherwise (the caller then cuts the list into launches of eight).
 	hipError_t LaunchWaveNetSpecTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream, WnLaunchTable& table);
 

@@ -15,5 +15,17 @@ namespace na
 			return LaunchNF<FamA2, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
 #endif
 		}
+
+		// ... as a table launch (wavenet_launch.h LaunchWaveNetSpecTable): 128-frame blocks
+		hipError_t LaunchSpecA2Table(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int spb, hipStream_t stream,
+			WnLaunchTable& table)
+		{
+#ifdef NA_SP_QUICK
+			return hipErrorNotSupported;
+#else
+			return spb >= 2 ? LaunchTable<FamA2, 128, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table)
+							: LaunchTable<FamA2, 128, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
+#endif
+		}
 	}
 }

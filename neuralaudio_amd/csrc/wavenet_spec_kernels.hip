@@ -51,17 +51,19 @@ namespace na
 #else
 		if (numGroups <= WN_FRAME_MAX_GROUPS || n != 128 || !WaveNetSpecEnabled() || Tuning::Get().spSpb > 0) return hipErrorNotSupported;
 		const int arch = groups[0].model->spec_arch;
-		const bool lite = arch == WN_SPEC_LITE || arch == WN_SPEC_LITE16;
-		if (arch != WN_SPEC_STD && !lite) return hipErrorNotSupported;
+		const bool lite = arch == WN_SPEC_LITE || arch == WN_SPEC_LITE16, a2 = arch == WN_SPEC_A2FULL || arch == WN_SPEC_A2LITE;
+		if (arch != WN_SPEC_STD && !lite && !a2) return hipErrorNotSupported;
 		bool packed = false;
 		long streams = 0, slots2 = 0;
 		for (int i = 0; i < numGroups; i++)
 		{
 			const int a = groups[i].model->spec_arch;
-			if (groups[i].numStreams <= 0 || (lite ? (a != WN_SPEC_LITE && a != WN_SPEC_LITE16) : a != WN_SPEC_STD)) return hipErrorNotSupported;
+			const bool same = lite ? (a == WN_SPEC_LITE || a == WN_SPEC_LITE16) : (a2 ? (a == WN_SPEC_A2FULL || a == WN_SPEC_A2LITE) : a == WN_SPEC_STD);
+			if (groups[i].numStreams <= 0 || !same) return hipErrorNotSupported;
 			packed = packed || groups[i].pack > 1;
+			const int per2 = a == WN_SPEC_A2LITE ? 4 : 2; // streams per full-size workgroup of this architecture
 			streams += groups[i].numStreams;
-			slots2 += (groups[i].numStreams + 1) / 2 * 2;
+			slots2 += (groups[i].numStreams + per2 - 1) / per2 * per2;
 		}
 		if (!lite && packed) return hipErrorNotSupported;
 		if (packed)
@@ -71,6 +73,7 @@ namespace na
 			for (int i = 0; i < numGroups; i++)
 				if (groups[i].model->spec_arch == WN_SPEC_LITE16) return hipErrorNotSupported; // (16 / 16 only exists packed)
 		const int spb = (slots2 * 4 > streams * 5) ? 1 : 2; // more than a quarter of the full-size workgroups' stream slots would idle
+		if (a2) return spk::LaunchSpecA2Table(groups, numGroups, in, out, inStride, outStride, spb, stream, table);
 		if (!lite) return spb == 2 ? spk::LaunchTable<spk::FamStd, 128, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table)
 								   : spk::LaunchTable<spk::FamStd, 128, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
 		return spk::LaunchSpecLiteTable(groups, numGroups, in, out, inStride, outStride, spb, packed, stream, table);

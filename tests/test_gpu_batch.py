@@ -895,7 +895,7 @@ def test_registered_host_blocks_are_processed_in_place(na, loader):
     assert O.rms(y_reg[36] - O.oracle_from_file("BossWN-standard.nam").process(x[36])) < TOL_RMS
 
 
-@pytest.mark.parametrize("name,models,per", [("BossWN-standard.nam", 24, 3), ("BossWN-standard.nam", 40, 1), ("BossWN-nano.nam", 20, 5), ("BossWN-feather.nam", 12, 2)])
+@pytest.mark.parametrize("name,models,per", [("BossWN-standard.nam", 24, 3), ("BossWN-standard.nam", 40, 1), ("BossWN-nano.nam", 20, 5), ("BossWN-feather.nam", 12, 2), ("BossWN-a2.nam", 22, 3)])
 def test_many_distinct_models_run_as_one_table_launch_and_match_one_model_batch(na, loader, name, models, per):
     """A server's batch: many DIFFERENT model handles with a few streams each (here the same file loaded `models` times: as many model
     groups).  More groups than a launch's kernarg segment holds run as ONE launch whose group table lives in device memory
@@ -906,9 +906,11 @@ def test_many_distinct_models_run_as_one_table_launch_and_match_one_model_batch(
     handles = [loader.CreateFromFile(_path(name), doPrewarm=False) for _ in range(models)]
     ts = torch.cuda.Stream(device=dev)
     many, one = na.Batch(0, hip_stream=ts.cuda_stream), na.Batch(0, hip_stream=ts.cuda_stream)
-    for h in handles:
-        many.AddStreams(h, per)
-    one.AddStreams(handles[0], models * per)
+    a2 = "a2" in name
+    for i, h in enumerate(handles):
+        many.AddStreams(h, per, quality=(1.0 if i % 2 else 0.2) if a2 else 1.0)  # (A2: both submodels of the container, model by model)
+    for i in range(models if a2 else 1):
+        one.AddStreams(handles[0], per if a2 else models * per, quality=(1.0 if i % 2 else 0.2) if a2 else 1.0)
     S = models * per
     g = torch.Generator(device="cpu").manual_seed(5)
     lengths = [128, 128, 64, 128, 37, 256]
@@ -924,7 +926,7 @@ def test_many_distinct_models_run_as_one_table_launch_and_match_one_model_batch(
                 at += n
             bb.Synchronize()
     assert torch.equal(want, got)
-    yo = O.oracle_from_file(name).process(x[S - 1].cpu().numpy())
+    yo = O.oracle_from_file(name, quality=1.0).process(x[S - 1].cpu().numpy())  # (the last handle runs at quality 1.0)
     assert O.rms(got[S - 1].cpu().numpy() - yo) < TOL_RMS
     many.close()
     one.close()
