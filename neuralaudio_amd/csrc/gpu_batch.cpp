@@ -539,6 +539,15 @@ namespace na
 			while (left > 0)
 			{
 				const int chunk = (int)std::min<size_t>(left, (size_t)LSTM_MAX_FRAMES);
+				if (fusedRec.size() > (size_t)RECURRENT_MAX_GROUPS)
+				{
+					// (many different recurrent models: one launch, the group table in device memory)
+					CheckHip(LaunchRecurrentDppTable(fusedRec.data(), (int)fusedRec.size(), dIn + offset, dOut + offset, inStride, outStride, chunk, s, wnTable[3]),
+						"RecurrentDppKernel (table launch)");
+					offset += (size_t)chunk;
+					left -= (size_t)chunk;
+					continue;
+				}
 				for (size_t first = 0; first < fusedRec.size(); first += RECURRENT_MAX_GROUPS)
 					CheckHip(LaunchRecurrentDpp(fusedRec.data() + first, (int)std::min<size_t>(fusedRec.size() - first, (size_t)RECURRENT_MAX_GROUPS),
 						dIn + offset, dOut + offset, inStride, outStride, chunk, s), "RecurrentDppKernel (fused)");

@@ -254,7 +254,7 @@ namespace na
 		// ring in pinned host memory -- for the batches the chains serve whose buffer is one launch of 128-frame A1 Standard blocks
 		struct ResidentState;
 		std::unique_ptr<ResidentState> residentState;
-		WnLaunchTable wnTable[3]; // device tables of launch lists with more groups than a launch's kernarg segment holds (gpu_batch.cpp launchWnList)
+		WnLaunchTable wnTable[4]; // device tables of launch lists with more groups than a launch's kernarg segment holds (gpu_batch.cpp launchWnList; [3]: the recurrent list)
 		bool lastStepResident = false;
 		bool residentWanted = Tuning::Get().residentOn;
 		bool TryResident(const float* dIn, float* dOut, size_t n, long inStride, long outStride);

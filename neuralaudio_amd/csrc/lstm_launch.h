@@ -36,6 +36,10 @@ namespace na
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err);
 	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream);
+	// ... any number of groups in one launch, the group table in device memory (`table`: the batch's cache of it; wavenet_launch.h)
+	struct WnLaunchTable;
+	hipError_t LaunchRecurrentDppTable(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream, WnLaunchTable& table);
 
 	// keras GRU (gru_kernels.hip): same state layout (only the h half of every layer is used), m.cell == LSTM_CELL_GRU
 	hipError_t LaunchGruBlock(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,

@@ -8,6 +8,8 @@
 // keras GRU = RTNeural's GRULayer (NeuralAudio/RTNeuralModel.h:300,417-421; third-party, parity unpinned -- see gru_kernels.hip).
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 #include <type_traits>
 
 #include <hip/hip_runtime.h>
@@ -16,6 +18,7 @@
 #include "tuning.h"
 #include "lstm_dev.h"
 #include "lstm_launch.h"
+#include "wavenet_launch.h"
 
 namespace na
 {
@@ -1086,15 +1089,9 @@ namespace na
 	long RecurrentQuadLaunches() { return gQuadLaunches.load(std::memory_order_relaxed); }
 
 	// grid = all streams of all groups, block = 64 (one wave per stream)
-	__global__ void __launch_bounds__(64) RecurrentDppKernel(const RecurrentLaunchArgs args, const float* __restrict__ in, float* __restrict__ out, long inStride,
-		long outStride, int n)
+	__device__ __forceinline__ void RecurrentDppRun(const RecurrentGroupArgs& ga, int noSkew, const float* __restrict__ in, float* __restrict__ out, long inStride,
+		long outStride, int n, float* xin, float* hout)
 	{
-		__shared__ __attribute__((aligned(16))) float xin[REC_XIN_FLOATS];
-		extern __shared__ __attribute__((aligned(16))) float hout[]; // REC_HOUT_FLOATS, or REC_HOUT32_FLOATS when a 32-unit-layout group is in the launch
-		int gi = 0;
-		for (int i = 1; i < args.numGroups; i++)
-			if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
-		const RecurrentGroupArgs& ga = args.g[gi];
 		const int idx = (int)blockIdx.x - ga.firstBlock;
 		const int slot = ga.slots ? ga.slots[idx] : ga.slot0 + idx;
 		const int row = ga.slots ? ga.rows[idx] : ga.row0 + idx;
@@ -1127,14 +1124,14 @@ namespace na
 		{
 			NA_REC_CASE(LSTM_CELL_LSTM, 8, 1, LstmDppBody)
 			case LSTM_CELL_LSTM * 100 + 8 * 4 + 2:
-				if (args.noSkew) LstmDppBody<8, 2>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+				if (noSkew) LstmDppBody<8, 2>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
 				else LstmDppSkewBody<false>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
 				break;
 			NA_REC_CASE(LSTM_CELL_LSTM, 16, 1, LstmDppBody)
 			NA_REC_CASE(LSTM_CELL_LSTM, 16, 2, LstmDppBody)
 			NA_REC_CASE(10 + LSTM_CELL_LSTM, 8, 1, LstmDppBodyStd)
 			case (10 + LSTM_CELL_LSTM) * 100 + 8 * 4 + 2:
-				if (args.noSkew) LstmDppBodyStd<8, 2>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
+				if (noSkew) LstmDppBodyStd<8, 2>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
 				else LstmDppSkewBody<true>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, xin, hout);
 				break;
 			NA_REC_CASE(10 + LSTM_CELL_LSTM, 16, 1, LstmDppBodyStd)
@@ -1148,6 +1145,46 @@ namespace na
 #undef NA_REC_CASE
 	}
 
+	__global__ void __launch_bounds__(64) RecurrentDppKernel(const RecurrentLaunchArgs args, const float* __restrict__ in, float* __restrict__ out, long inStride,
+		long outStride, int n)
+	{
+		__shared__ __attribute__((aligned(16))) float xin[REC_XIN_FLOATS];
+		extern __shared__ __attribute__((aligned(16))) float hout[]; // REC_HOUT_FLOATS, or REC_HOUT32_FLOATS when a 32-unit-layout group is in the launch
+		int gi = 0;
+		for (int i = 1; i < args.numGroups; i++)
+			if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
+		RecurrentDppRun(args.g[gi], args.noSkew, in, out, inStride, outStride, n, xin, hout);
+	}
+
+	// The same with the group table in device memory: any number of model groups in one launch (a batch in which every stream plays its
+	// own capture; the kernarg segment holds RECURRENT_MAX_GROUPS).  A wave finds its group by binary search over firstBlock and copies
+	// the entry out of the constant address space (scalar loads).  See wavenet_spec_impl.h WaveNetSpecTableKernel.
+	__global__ void __launch_bounds__(64) RecurrentDppTableKernel(const RecurrentGroupArgs* __restrict__ table, int numGroups, int noSkew, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n)
+	{
+		__shared__ __attribute__((aligned(16))) float xin[REC_XIN_FLOATS];
+		extern __shared__ __attribute__((aligned(16))) float hout[];
+		typedef const __attribute__((address_space(4))) RecurrentGroupArgs* TablePtr;
+		TablePtr tab = (TablePtr)(size_t)table;
+		int lo = 0, hi = numGroups - 1;
+		while (lo < hi)
+		{
+			const int mid = (lo + hi + 1) >> 1;
+			if (tab[mid].firstBlock <= (int)blockIdx.x) lo = mid;
+			else hi = mid - 1;
+		}
+		RecurrentGroupArgs ga;
+		{
+			static_assert(sizeof(RecurrentGroupArgs) % 4 == 0, "dword copy");
+			typedef const __attribute__((address_space(4))) unsigned* WordPtr;
+			WordPtr src = (WordPtr)(size_t)(table + lo);
+			unsigned* dst = reinterpret_cast<unsigned*>(&ga);
+#pragma unroll
+			for (int i = 0; i < (int)(sizeof(RecurrentGroupArgs) / 4); i++) dst[i] = src[i];
+		}
+		RecurrentDppRun(ga, noSkew, in, out, inStride, outStride, n, xin, hout);
+	}
+
 	bool RecurrentDppSupported(const LstmModelDev& m)
 	{
 		// hidden sizes below a layout (8 or 16 units per gate block) are padded into it: 12 (the reference's static 1x12 / 2x12) runs as 16
@@ -1156,6 +1193,53 @@ namespace na
 		if (m.tailLayers != 0) return false; // generic keras stacks run on the runtime-shaped kernels
 		if ((m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU) && m.numLayers == 1 && m.hidden > 16 && m.hidden <= 32) return !no32;
 		return m.hidden >= 1 && m.hidden <= 16 && (m.numLayers == 1 || m.numLayers == 2) && (m.cell == LSTM_CELL_LSTM || m.cell == LSTM_CELL_GRU);
+	}
+
+	hipError_t LaunchRecurrentDppTable(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
+		hipStream_t stream, WnLaunchTable& t)
+	{
+		if (n <= 0 || numGroups <= 0) return hipSuccess;
+		if (n > LSTM_MAX_FRAMES) return hipErrorInvalidValue;
+		std::vector<RecurrentGroupArgs> fresh((size_t)numGroups);
+		int blocks = 0;
+		bool any32 = false;
+		for (int i = 0; i < numGroups; i++)
+		{
+			if (!RecurrentDppSupported(groups[i].model) || groups[i].numStreams <= 0) return hipErrorInvalidValue;
+			fresh[(size_t)i] = {};
+			RecurrentGroupArgs& a = fresh[(size_t)i];
+			a.m = groups[i].model;
+			a.state = groups[i].state;
+			a.slots = groups[i].slots;
+			a.rows = groups[i].rows;
+			a.slot0 = groups[i].slot0;
+			a.row0 = groups[i].row0;
+			a.capacity = groups[i].capacity;
+			a.numStreams = groups[i].numStreams;
+			a.firstBlock = blocks;
+			blocks += groups[i].numStreams;
+			any32 |= groups[i].model.hidden > 16;
+		}
+		const size_t bytes = fresh.size() * sizeof(RecurrentGroupArgs);
+		if (t.dev == nullptr || t.devBytes < bytes)
+		{
+			if (t.dev) (void)hipFree(t.dev);
+			t.dev = nullptr;
+			t.host.clear();
+			const hipError_t me = hipMalloc(&t.dev, bytes + bytes / 2);
+			if (me != hipSuccess) return me;
+			t.devBytes = bytes + bytes / 2;
+		}
+		if (t.host.size() != bytes || memcmp(t.host.data(), fresh.data(), bytes) != 0)
+		{
+			t.host.assign(reinterpret_cast<const char*>(fresh.data()), reinterpret_cast<const char*>(fresh.data()) + bytes);
+			const hipError_t ce = hipMemcpyAsync(t.dev, t.host.data(), bytes, hipMemcpyHostToDevice, stream);
+			if (ce != hipSuccess) return ce;
+		}
+		const size_t lds = sizeof(float) * (size_t)(any32 ? REC_HOUT32_FLOATS : REC_HOUT_FLOATS);
+		hipLaunchKernelGGL(RecurrentDppTableKernel, dim3((unsigned)blocks), dim3(64), lds, stream, reinterpret_cast<const RecurrentGroupArgs*>(t.dev), numGroups,
+			Tuning::Get().recNoSkew ? 1 : 0, in, out, inStride, outStride, n);
+		return hipGetLastError();
 	}
 
 	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,

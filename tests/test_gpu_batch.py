@@ -895,7 +895,7 @@ def test_registered_host_blocks_are_processed_in_place(na, loader):
     assert O.rms(y_reg[36] - O.oracle_from_file("BossWN-standard.nam").process(x[36])) < TOL_RMS
 
 
-@pytest.mark.parametrize("name,models,per", [("BossWN-standard.nam", 24, 3), ("BossWN-standard.nam", 40, 1), ("BossWN-nano.nam", 20, 5), ("BossWN-feather.nam", 12, 2), ("BossWN-a2.nam", 22, 3)])
+@pytest.mark.parametrize("name,models,per", [("BossWN-standard.nam", 24, 3), ("BossWN-standard.nam", 40, 1), ("BossWN-nano.nam", 20, 5), ("BossWN-feather.nam", 12, 2), ("BossWN-a2.nam", 22, 3), ("BossLSTM-1x16.nam", 30, 2), ("BossLSTM-2x8.nam", 17, 3)])
 def test_many_distinct_models_run_as_one_table_launch_and_match_one_model_batch(na, loader, name, models, per):
     """A server's batch: many DIFFERENT model handles with a few streams each (here the same file loaded `models` times: as many model
     groups).  More groups than a launch's kernarg segment holds run as ONE launch whose group table lives in device memory
@@ -927,6 +927,6 @@ def test_many_distinct_models_run_as_one_table_launch_and_match_one_model_batch(
             bb.Synchronize()
     assert torch.equal(want, got)
     yo = O.oracle_from_file(name, quality=1.0).process(x[S - 1].cpu().numpy())  # (the last handle runs at quality 1.0)
-    assert O.rms(got[S - 1].cpu().numpy() - yo) < TOL_RMS
+    assert O.rms(got[S - 1].cpu().numpy() - yo) < (5e-6 if "LSTM" in name else TOL_RMS)
     many.close()
     one.close()
