@@ -1490,15 +1490,17 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 				if (tab[mid].firstBlock <= (int)blockIdx.x) lo = mid;
 				else hi = mid - 1;
 			}
-			// the entry, word by word out of the constant address space (scalar loads the compiler merges)
+			// the entry, field by field out of the constant address space: scalar loads into SGPRs, like kernel arguments (a word-wise copy of
+			// the struct kept it on the stack -- pointers in VGPRs, 19 - 30 spills in the chain)
 			GroupArgs ga;
 			{
-				static_assert(sizeof(GroupArgs) % 4 == 0, "dword copy");
-				typedef const __attribute__((address_space(4))) unsigned* WordPtr;
-				WordPtr src = (WordPtr)(size_t)(table + lo);
-				unsigned* dst = reinterpret_cast<unsigned*>(&ga);
-#pragma unroll
-				for (int i = 0; i < (int)(sizeof(GroupArgs) / 4); i++) dst[i] = src[i];
+				const auto& e = tab[lo];
+				ga.stages = e.stages; ga.wsplit = e.wsplit; ga.ringFrames = e.ringFrames; ga.state = e.state; ga.slots = e.slots; ga.rows = e.rows;
+				ga.nstages = e.nstages; ga.nrings = e.nrings; ga.stateF4 = e.stateF4; ga.wsplitQuads = e.wsplitQuads;
+				ga.headScale = e.headScale;
+				ga.numStreams = e.numStreams; ga.slot0 = e.slot0; ga.row0 = e.row0;
+				ga.maxG = e.maxG; ga.firstBlock = e.firstBlock; ga.pack = e.pack; ga.condLimit = e.condLimit; ga.arch = e.arch;
+				ga.gps0 = e.gps0; ga.gps1 = e.gps1; ga.saturate = e.saturate;
 			}
 			const int groupBlock = (int)blockIdx.x - ga.firstBlock;
 #ifdef NA_SP_TRACE

@@ -925,7 +925,12 @@ def test_many_distinct_models_run_as_one_table_launch_and_match_one_model_batch(
                 bb.ProcessDevice(x[:, at:].data_ptr(), y[:, at:].data_ptr(), n, total, total)
                 at += n
             bb.Synchronize()
-    assert torch.equal(want, got)
+    if "LSTM" in name and os.environ.get("NA_REC_QUAD_MIN"):
+        # (forced four-streams-per-wave runs, tests/test_gpu_families.py: the one-model batch is on that layout, the table launch on the
+        # one-stream layout -- another summation order)
+        assert float((want - got).abs().max()) < 2e-5
+    else:
+        assert torch.equal(want, got)
     yo = O.oracle_from_file(name, quality=1.0).process(x[S - 1].cpu().numpy())  # (the last handle runs at quality 1.0)
     assert O.rms(got[S - 1].cpu().numpy() - yo) < (5e-6 if "LSTM" in name else TOL_RMS)
     many.close()
