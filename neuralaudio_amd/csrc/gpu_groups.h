@@ -565,7 +565,10 @@ namespace na
 					if (which == WN_FAMILY_SPLIT)
 					{
 						const WnFrameGroup g = { &dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0, pack };
-						CheckHip(LaunchWaveNetSplitFused(&g, 1, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream), "WaveNetSplitKernel");
+						// (sharing 1; the state of this group's streams alone beyond the Infinity Cache: non-temporal ring traffic for the long dilations)
+						const bool beyondCache = !Tuning::Get().wnNtOff && (size_t)numActive * StateBytesPerStream() > WN_BEYOND_CACHE_BYTES;
+						CheckHip(LaunchWaveNetSplitFused(&g, 1, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream, 1 | (beyondCache ? WN_SHARING_BEYOND_CACHE : 0)),
+							"WaveNetSplitKernel");
 					}
 					else if (which == WN_FAMILY_GENERIC)
 						CheckHip(LaunchWaveNetGeneric(dPrewarm.Get(), (int)plan.prewarm.size(), dWeightsGen.Get(), dRingOff.Get(), dRingFrames.Get(), dRingG.Get(),

@@ -28,6 +28,7 @@ namespace na
 			if (const char* e = getenv("NA_WN_KERNEL")) t.wnKernel = !strcmp(e, "split") ? 1 : (!strcmp(e, "frame") ? 2 : (!strcmp(e, "generic") ? 3 : 0));
 			t.wnPack = Int("NA_WN_PACK", -1);
 			t.wnPadOff = IsZero("NA_WN_PAD");
+			t.wnNtOff = IsZero("NA_WN_NT");
 			t.wnDense = Int("NA_WN_DENSE", -1);
 			t.spT = Int("NA_SP_T", 0);
 			t.spSpb = Int("NA_SP_SPB", 0);

@@ -38,6 +38,12 @@ namespace na
 	// Same contract on the compile-time specialised layer chains of the official architectures (wavenet_spec_kernels.hip): blocks of
 	// exactly 128 / 64 / 32 frames, every group of the launch from one architecture family (WnModelDev::spec_arch); returns
 	// hipErrorNotSupported otherwise -- LaunchWaveNetSplitFused tries it first and falls back to its stage interpreter.
+	// `sharing` of the fused launches below: the number of launches that share the chip (free-running chains), OR-ed with this bit when the
+	// batch's stream state does not fit the 256 MB Infinity Cache (the chains then mark the long dilations' ring traffic non-temporal)
+	constexpr int WN_SHARING_BEYOND_CACHE = 1 << 16;
+	// ... from this much stream state on (measured, us per 1024 A1 Standard streams with / without the non-temporal bits: 1280 streams =
+	// 311 MB 40.4 / 39.2 -- part of the state still lives in the cache --, 2048 = 498 MB 37.6 / 39.2, 8192 = 2 GB 37.4 - 38.4 / 37.9 - 39.2)
+	constexpr size_t WN_BEYOND_CACHE_BYTES = (size_t)400 << 20;
 	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream, int sharing = 1);
 	// ---- table launches of the specialised chains (wavenet_spec_impl.h WaveNetSpecTableKernel): any number of model groups in one launch --

@@ -15,6 +15,7 @@
 
 #include "device_once.h"
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "tuning.h"
@@ -235,10 +236,14 @@ namespace na
 		// the streams into the workgroup, so every member of a family launches the same number of threads.
 		// COH_: the resident launch (WaveNetSpecResidentKernel) -- input rows are read and output rows written at system scope, because
 		// their producer / consumer runs while this launch is on the chip (no kernel boundary orders the caches)
-		template <class A_, int NF_, int SPB_, bool PK_, bool COH_ = false>
+		// NT_: the launch of a batch whose stream state does not fit the 256 MB Infinity Cache -- the ring traffic of the d >= 128 layers is
+		// marked non-temporal (nothing of it is read again before the whole state has passed through the cache: 38.9 -> 38.3 us per 1024
+		// streams with 8192 of them, profiles/r05_rotation_cache_policy.txt; inside the cache the same bits cost 2 - 3 us)
+		template <class A_, int NF_, int SPB_, bool PK_, bool COH_ = false, bool NT_ = false>
 		struct Cfg
 		{
 			static constexpr bool COH = COH_;
+			static constexpr bool NT = NT_;
 			typedef A_ A;
 			typedef Tab<A_> TB;
 			static constexpr int NF = NF_, T = A_::T, FW = 16 * T, WPS = NF_ / FW, SPB = SPB_ * T / 2, NTHREADS = 64 * WPS * SPB;
@@ -452,11 +457,12 @@ namespace na
 			if (base < 0) base += R;
 			if (base >= R) base -= R;
 			const int addr = RingWrap<GP, R>(laneRing, base);
-			constexpr bool LONG = RG < TB::NL && TB::Dil(RG < TB::NL ? RG : 0) >= NA_SPK_NT_DIL;
-			if constexpr (LONG && NA_SPK_NT_LD != 0)
+			constexpr int NT_LD = C::NT ? 2 : NA_SPK_NT_LD, NT_DIL = C::NT ? 128 : NA_SPK_NT_DIL;
+			constexpr bool LONG = RG < TB::NL && TB::Dil(RG < TB::NL ? RG : 0) >= NT_DIL;
+			if constexpr (LONG && NT_LD != 0)
 			{
-				if (cls == TAP_HIST) return RingLoadAux<NA_SPK_NT_LD>(cx.srsrc, addr, OFF * 16);
-				return RingLoadAux<NA_SPK_NT_LD>(cx.srsrc, (C::FW * cx.wave + 16 * P * i + fl < shift) ? addr : OOB, OFF * 16);
+				if (cls == TAP_HIST) return RingLoadAux<NT_LD>(cx.srsrc, addr, OFF * 16);
+				return RingLoadAux<NT_LD>(cx.srsrc, (C::FW * cx.wave + 16 * P * i + fl < shift) ? addr : OOB, OFF * 16);
 			}
 			if (cls == TAP_HIST) return RingLoad(cx.srsrc, addr, OFF * 16);
 			return RingLoad(cx.srsrc, (C::FW * cx.wave + 16 * P * i + fl < shift) ? addr : OOB, OFF * 16);
@@ -539,11 +545,12 @@ namespace na
 				if (base >= R) base -= R;
 			}
 			const int addr = RingWrap<GP, R>(ln.ring, base);
-			constexpr bool LONG = RG < TB::NL && TB::Dil(RG < TB::NL ? RG : 0) >= NA_SPK_NT_DIL;
-			if constexpr (LONG && NA_SPK_NT_ST != 0)
+			constexpr int NT_ST = C::NT ? 2 : NA_SPK_NT_ST, NT_DIL = C::NT ? 128 : NA_SPK_NT_DIL;
+			constexpr bool LONG = RG < TB::NL && TB::Dil(RG < TB::NL ? RG : 0) >= NT_DIL;
+			if constexpr (LONG && NT_ST != 0)
 			{
-				if (KEEP >= C::NF) RingStoreAux<NA_SPK_NT_ST>(cx.srsrc, v, addr, OFF * 16);
-				else RingStoreAux<NA_SPK_NT_ST>(cx.srsrc, v, (C::FW * cx.wave + 16 * P * i + ln.fl >= C::NF - KEEP) ? addr : OOB, OFF * 16);
+				if (KEEP >= C::NF) RingStoreAux<NT_ST>(cx.srsrc, v, addr, OFF * 16);
+				else RingStoreAux<NT_ST>(cx.srsrc, v, (C::FW * cx.wave + 16 * P * i + ln.fl >= C::NF - KEEP) ? addr : OOB, OFF * 16);
 				return;
 			}
 			if (KEEP >= C::NF) RingStore(cx.srsrc, v, addr, OFF * 16);
@@ -1214,7 +1221,7 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 		// (one tile per wave: launched with at most one workgroup per CU, i.e. half the waves per SIMD of the same thread count)
 		template <class F, int NF, int SPB>
 		constexpr int OccOf() { return F::A0::T == 1 ? (NA_SPK_OCC(NF, SPB) / 2 < 1 ? 1 : NA_SPK_OCC(NF, SPB) / 2) : NA_SPK_OCC(NF, SPB); }
-		template <class F, int NF, int SPB, bool PK>
+		template <class F, int NF, int SPB, bool PK, bool NT = false>
 		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(OccOf<F, NF, SPB>()))) WaveNetSpecKernel(const LaunchArgs args,
 			const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride
 #ifdef NA_SP_TRACE
@@ -1222,8 +1229,8 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 #endif
 			)
 		{
-			typedef Cfg<typename F::A0, NF, SPB, PK> C;
-			typedef Cfg<typename F::A1, NF, SPB, PK> C1;
+			typedef Cfg<typename F::A0, NF, SPB, PK, false, NT> C;
+			typedef Cfg<typename F::A1, NF, SPB, PK, false, NT> C1;
 			static_assert(C::NTHREADS == C1::NTHREADS, "members of a family launch the same workgroup");
 			extern __shared__ __attribute__((aligned(16))) char dynSmem[];
 			asm volatile("" : : "s"((unsigned)(size_t)(LdsPtr)dynSmem)); // the dynamic LDS segment is in use (and starts at 0)
@@ -1552,7 +1559,7 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 			return hipGetLastError();
 		}
 
-		template <class F, int NF, int SPB, bool PK>
+		template <class F, int NF, int SPB, bool PK, bool NT = false>
 		static hipError_t Launch(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, hipStream_t stream)
 		{
 			typedef Cfg<typename F::A0, NF, SPB, PK> C;
@@ -1565,10 +1572,10 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 			if (LDS_BYTES > 64 * 1024)
 			{
 				static PerDeviceOnce attr; // per instantiation and device
-				const hipError_t e = attr.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(WaveNetSpecKernel<F, NF, SPB, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); });
+				const hipError_t e = attr.Run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(WaveNetSpecKernel<F, NF, SPB, PK, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); });
 				if (e != hipSuccess) return e;
 			}
-			hipLaunchKernelGGL((WaveNetSpecKernel<F, NF, SPB, PK>), dim3((unsigned)blocks), dim3(C::NTHREADS), LDS_BYTES, stream, args, in, out, inStride, outStride
+			hipLaunchKernelGGL((WaveNetSpecKernel<F, NF, SPB, PK, NT>), dim3((unsigned)blocks), dim3(C::NTHREADS), LDS_BYTES, stream, args, in, out, inStride, outStride
 #ifdef NA_SP_TRACE
 				, GetWaveNetTraceBuffer(), Tuning::Get().traceBlock
 #endif
@@ -1621,12 +1628,17 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 		}
 
 		template <class F, bool PK>
-		static hipError_t LaunchNF(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream)
+		static hipError_t LaunchNF(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream,
+			bool beyondCache = false)
 		{
 #ifdef NA_SP_QUICK
-			(void)spb; (void)n;
+			(void)spb; (void)n; (void)beyondCache;
 			return Launch<F, 128, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream);
 #else
+			// (the non-temporal variant exists for full-size workgroups of 128-frame blocks of A1 Standard: the regime it is for -- more
+			// state than the Infinity Cache holds -- is thousands of such streams)
+			if constexpr (std::is_same<F, FamStd>::value && !PK)
+				if (beyondCache && n == 128 && spb >= 2) return Launch<F, 128, 2, PK, true>(groups, numGroups, in, out, inStride, outStride, stream);
 			if constexpr (F::A0::T == 1)
 			{
 				// one tile per wave: one stream per workgroup (SPB_ = 2 in units of four-wave streams), every block length

@@ -117,12 +117,14 @@ namespace na
 			const int per = groups[i].model->spec_arch == WN_SPEC_A2LITE ? 2 : 1;
 			halfGroups += (groups[i].numStreams + per - 1) / per;
 		}
+		const bool beyondCache = (sharing & WN_SHARING_BEYOND_CACHE) != 0; // (the batch's stream state does not fit the Infinity Cache)
+		sharing &= ~WN_SHARING_BEYOND_CACHE;
 		const int spb = spbEnv > 0 ? spbEnv : (halfGroups * std::max(sharing, 1) > residentHalf ? 2 : 1);
 #ifdef NA_SP_QUICK
 		if (arch != WN_SPEC_STD || packed) return hipErrorNotSupported;
 		return spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
 #else
-		if (fam == 0) return packed ? hipErrorNotSupported : spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
+		if (fam == 0) return packed ? hipErrorNotSupported : spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream, beyondCache);
 		if (fam == 2) return packed ? hipErrorNotSupported : spk::LaunchSpecA2(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
 		if (!packed && lite16) return hipErrorNotSupported; // (16 / 16 only exists packed)
 		// a launch of 16 / 16 virtual streams only (packed Nano) with at most one of them per CU: one tile per wave, eight waves per stream

@@ -935,3 +935,37 @@ def test_many_distinct_models_run_as_one_table_launch_and_match_one_model_batch(
     assert O.rms(got[S - 1].cpu().numpy() - yo) < (5e-6 if "LSTM" in name else TOL_RMS)
     many.close()
     one.close()
+
+
+def test_batches_beyond_the_infinity_cache_mark_their_ring_traffic_non_temporal_and_compute_the_same(na, loader):
+    """More A1 Standard state than the 256 MB Infinity Cache holds (1760 streams = 428 MB, beyond the 400 MB from which the variant is used): the chains of such a batch mark the ring traffic
+    of the d >= 128 layers non-temporal (Cfg::NT, wavenet_spec_impl.h) -- a cache-policy bit, so two batches of 880 streams (inside the
+    cache: the ordinary variant) must compute the same bits; both against the oracle on one stream."""
+    import torch
+    dev = torch.device("cuda", 0)
+    m = loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=False)
+    S, n, steps = 1760, 128, 5
+    big = na.Batch(0)
+    big.AddStreams(m, S)
+    assert big.StateBytes() > 400 * 1024 * 1024
+    halves = [na.Batch(0), na.Batch(0)]
+    for h in halves:
+        h.AddStreams(m, S // 2)
+        assert h.StateBytes() < 256 * 1024 * 1024
+    g = torch.Generator(device="cpu").manual_seed(31)
+    x = torch.clamp(0.3 * torch.randn(steps, S, n, generator=g), -1.0, 1.0).to(dev)
+    got, want = torch.zeros(steps, S, n, device=dev), torch.zeros(steps, S, n, device=dev)
+    torch.cuda.synchronize(dev)
+    for k in range(steps):
+        big.ProcessDevice(x[k].data_ptr(), got[k].data_ptr(), n)
+        for i, h in enumerate(halves):
+            h.ProcessDevice(x[k][i * (S // 2):].data_ptr(), want[k][i * (S // 2):].data_ptr(), n)
+    big.Synchronize()
+    for h in halves:
+        h.Synchronize()
+    assert torch.equal(got, want)
+    yo = O.oracle_from_file("BossWN-standard.nam").process(np.concatenate([x[k][S - 1].cpu().numpy() for k in range(steps)]))
+    assert O.rms(np.concatenate([got[k][S - 1].cpu().numpy() for k in range(steps)]) - yo) < TOL_RMS
+    big.close()
+    for h in halves:
+        h.close()
