@@ -951,7 +951,7 @@ def test_batches_beyond_the_infinity_cache_mark_their_ring_traffic_non_temporal_
     halves = [na.Batch(0), na.Batch(0)]
     for h in halves:
         h.AddStreams(m, S // 2)
-        assert h.StateBytes() < 256 * 1024 * 1024
+        assert h.StateBytes() < 400 * 1024 * 1024  # (below the threshold: the ordinary variant)
     g = torch.Generator(device="cpu").manual_seed(31)
     x = torch.clamp(0.3 * torch.randn(steps, S, n, generator=g), -1.0, 1.0).to(dev)
     got, want = torch.zeros(steps, S, n, device=dev), torch.zeros(steps, S, n, device=dev)
