@@ -7,12 +7,12 @@ namespace na
 {
 	namespace spk
 	{
-		hipError_t LaunchSpecA2(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream)
+		hipError_t LaunchSpecA2(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream, bool beyondCache)
 		{
 #ifdef NA_SP_QUICK
 			return hipErrorNotSupported;
 #else
-			return LaunchNF<FamA2, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
+			return LaunchNF<FamA2, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream, beyondCache);
 #endif
 		}
 

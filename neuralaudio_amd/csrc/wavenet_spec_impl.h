@@ -76,6 +76,7 @@ namespace na
 			static constexpr bool GUARDHIST = false;
 			static constexpr int SKEW = 0;
 			static constexpr bool COMPACT = true; // K <= 3 everywhere, dense heads: histories of <= 32 frames live in compact rings (wavenet_plan.cpp AddRing)
+			static constexpr int NT_DIL = 128;    // Cfg::NT: layers from this dilation on move their ring traffic non-temporally
 		};
 #ifndef NA_SPK_SKEW
 #define NA_SPK_SKEW 0
@@ -134,6 +135,7 @@ namespace na
 			static constexpr bool GUARDHIST = true;
 			static constexpr int SKEW = 0;
 			static constexpr bool COMPACT = false;
+			static constexpr int NT_DIL = 100;    // (d = 101 and 239)
 		};
 		struct ArchA2Full : ArchA2Base { static constexpr int CH[2] = { 8, 0 }; static constexpr int T = 2; };
 		struct ArchA2Lite : ArchA2Base { static constexpr int CH[2] = { 4, 0 }; static constexpr int T = 4; };
@@ -457,7 +459,7 @@ namespace na
 			if (base < 0) base += R;
 			if (base >= R) base -= R;
 			const int addr = RingWrap<GP, R>(laneRing, base);
-			constexpr int NT_LD = C::NT ? 2 : NA_SPK_NT_LD, NT_DIL = C::NT ? 128 : NA_SPK_NT_DIL;
+			constexpr int NT_LD = C::NT ? 2 : NA_SPK_NT_LD, NT_DIL = C::NT ? C::A::NT_DIL : NA_SPK_NT_DIL;
 			constexpr bool LONG = RG < TB::NL && TB::Dil(RG < TB::NL ? RG : 0) >= NT_DIL;
 			if constexpr (LONG && NT_LD != 0)
 			{
@@ -545,7 +547,7 @@ namespace na
 				if (base >= R) base -= R;
 			}
 			const int addr = RingWrap<GP, R>(ln.ring, base);
-			constexpr int NT_ST = C::NT ? 2 : NA_SPK_NT_ST, NT_DIL = C::NT ? 128 : NA_SPK_NT_DIL;
+			constexpr int NT_ST = C::NT ? 2 : NA_SPK_NT_ST, NT_DIL = C::NT ? C::A::NT_DIL : NA_SPK_NT_DIL;
 			constexpr bool LONG = RG < TB::NL && TB::Dil(RG < TB::NL ? RG : 0) >= NT_DIL;
 			if constexpr (LONG && NT_ST != 0)
 			{
@@ -1635,9 +1637,9 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 			(void)spb; (void)n; (void)beyondCache;
 			return Launch<F, 128, 2, PK>(groups, numGroups, in, out, inStride, outStride, stream);
 #else
-			// (the non-temporal variant exists for full-size workgroups of 128-frame blocks of A1 Standard: the regime it is for -- more
-			// state than the Infinity Cache holds -- is thousands of such streams)
-			if constexpr (std::is_same<F, FamStd>::value && !PK)
+			// (the non-temporal variant exists for full-size workgroups of 128-frame blocks: the regime it is for -- more state than the
+			// Infinity Cache holds -- is thousands of streams)
+			if constexpr (F::A0::T != 1)
 				if (beyondCache && n == 128 && spb >= 2) return Launch<F, 128, 2, PK, true>(groups, numGroups, in, out, inStride, outStride, stream);
 			if constexpr (F::A0::T == 1)
 			{
@@ -1659,8 +1661,9 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 
 		// (defined in the family's translation unit)
 		hipError_t LaunchSpecLite(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, bool packed,
-			hipStream_t stream, bool oneTilePerWave = false);
-		hipError_t LaunchSpecA2(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream);
+			hipStream_t stream, bool oneTilePerWave = false, bool beyondCache = false);
+		hipError_t LaunchSpecA2(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream,
+			bool beyondCache = false);
 		hipError_t LaunchSpecA2Table(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int spb, hipStream_t stream,
 			WnLaunchTable& table);
 		hipError_t LaunchSpecLiteTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int spb, bool packed,

@@ -125,7 +125,7 @@ namespace na
 		return spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
 #else
 		if (fam == 0) return packed ? hipErrorNotSupported : spk::LaunchNF<spk::FamStd, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream, beyondCache);
-		if (fam == 2) return packed ? hipErrorNotSupported : spk::LaunchSpecA2(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
+		if (fam == 2) return packed ? hipErrorNotSupported : spk::LaunchSpecA2(groups, numGroups, in, out, inStride, outStride, n, spb, stream, beyondCache);
 		if (!packed && lite16) return hipErrorNotSupported; // (16 / 16 only exists packed)
 		// a launch of 16 / 16 virtual streams only (packed Nano) with at most one of them per CU: one tile per wave, eight waves per stream
 		// (Nano x 1024 = 256 virtual streams: a chain of 23 short stages, bound by what its few waves can issue)
@@ -138,7 +138,7 @@ namespace na
 			virtualStreams += groups[i].numStreams;
 		}
 		const bool t1 = all16 && spbEnv == 0 && virtualStreams <= CurrentDeviceCUs();
-		return spk::LaunchSpecLite(groups, numGroups, in, out, inStride, outStride, n, spb, packed, stream, t1);
+		return spk::LaunchSpecLite(groups, numGroups, in, out, inStride, outStride, n, spb, packed, stream, t1, beyondCache);
 #endif
 	}
 }

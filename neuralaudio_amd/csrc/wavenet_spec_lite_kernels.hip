@@ -7,15 +7,15 @@ namespace na
 	namespace spk
 	{
 		hipError_t LaunchSpecLite(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, bool packed,
-			hipStream_t stream, bool oneTilePerWave)
+			hipStream_t stream, bool oneTilePerWave, bool beyondCache)
 		{
 #ifdef NA_SP_QUICK
 			return hipErrorNotSupported;
 #else
 			// (16 / 16 packed streams, at most one per CU: eight waves of one tile each, see ArchLite16T1)
 			if (packed && oneTilePerWave) return LaunchNF<FamLite16T1, true>(groups, numGroups, in, out, inStride, outStride, n, 2, stream);
-			if (packed) return LaunchNF<FamLitePacked, true>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
-			return LaunchNF<FamLite, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream);
+			if (packed) return LaunchNF<FamLitePacked, true>(groups, numGroups, in, out, inStride, outStride, n, spb, stream, beyondCache);
+			return LaunchNF<FamLite, false>(groups, numGroups, in, out, inStride, outStride, n, spb, stream, beyondCache);
 #endif
 		}
 
