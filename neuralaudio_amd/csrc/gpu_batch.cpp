@@ -528,7 +528,7 @@ namespace na
 					const int count = (int)std::min<size_t>(list.size() - first, (size_t)WN_FRAME_MAX_GROUPS);
 					CheckHip(which == 0 ? LaunchWaveNetFrameFused(list.data() + first, count, dIn + offset, dOut + offset, inStride, outStride, chunk, s)
 										: LaunchWaveNetSplitFused(list.data() + first, count, dIn + offset, dOut + offset, inStride, outStride, chunk, s,
-											1 | ((!Tuning::Get().wnNtOff && StateBytes() > WN_BEYOND_CACHE_BYTES) ? WN_SHARING_BEYOND_CACHE : 0)),
+											1 | ((!Tuning::Get().wnNtOff && StateBytes() > ((size_t)Tuning::Get().wnNtFromMB << 20)) ? WN_SHARING_BEYOND_CACHE : 0)),
 						"WaveNet kernel (fused)");
 				}
 				offset += (size_t)chunk;

@@ -363,7 +363,7 @@ namespace na
 			{
 				const int chunk = NextWaveNetChunk(left, halfLists->compact);
 				CheckHip(LaunchWaveNetSplitFused(part.data(), (int)part.size(), dIn + offset, dOut + offset, inStride, outStride, chunk, halfStream[h],
-					(hostRows ? 1 : numChains) | ((!Tuning::Get().wnNtOff && StateBytes() > WN_BEYOND_CACHE_BYTES) ? WN_SHARING_BEYOND_CACHE : 0)), "WaveNet kernel (half batch)");
+					(hostRows ? 1 : numChains) | ((!Tuning::Get().wnNtOff && StateBytes() > ((size_t)Tuning::Get().wnNtFromMB << 20)) ? WN_SHARING_BEYOND_CACHE : 0)), "WaveNet kernel (half batch)");
 				offset += (size_t)chunk;
 				left -= (size_t)chunk;
 			}

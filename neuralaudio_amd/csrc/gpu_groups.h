@@ -566,7 +566,7 @@ namespace na
 					{
 						const WnFrameGroup g = { &dev, state.Get(), contiguous ? nullptr : dSlots.Get(), dRows.Get(), numActive, contiguous ? hSlots[0] : 0, contiguous ? hRows[0] : 0, pack };
 						// (sharing 1; the state of this group's streams alone beyond the Infinity Cache: non-temporal ring traffic for the long dilations)
-						const bool beyondCache = !Tuning::Get().wnNtOff && (size_t)numActive * StateBytesPerStream() > WN_BEYOND_CACHE_BYTES;
+						const bool beyondCache = !Tuning::Get().wnNtOff && (size_t)numActive * StateBytesPerStream() > ((size_t)Tuning::Get().wnNtFromMB << 20);
 						CheckHip(LaunchWaveNetSplitFused(&g, 1, dIn + offset, dOut + offset, inStride, outStride, chunk, launchStream, 1 | (beyondCache ? WN_SHARING_BEYOND_CACHE : 0)),
 							"WaveNetSplitKernel");
 					}

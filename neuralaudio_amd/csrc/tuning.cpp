@@ -29,6 +29,7 @@ namespace na
 			t.wnPack = Int("NA_WN_PACK", -1);
 			t.wnPadOff = IsZero("NA_WN_PAD");
 			t.wnNtOff = IsZero("NA_WN_NT");
+			t.wnNtFromMB = Int("NA_WN_NT_MB", 400);
 			t.wnDense = Int("NA_WN_DENSE", -1);
 			t.spT = Int("NA_SP_T", 0);
 			t.spSpb = Int("NA_SP_SPB", 0);

@@ -12,6 +12,7 @@ namespace na
 		int wnKernel = 0;          // NA_WN_KERNEL=split|frame|generic -> 1 | 2 | 3; 0: per model (FamilyFor)
 		int wnPack = -1;           // NA_WN_PACK=0: no stream packing; -1: default
 		int wnDense = -1;          // NA_WN_DENSE=0: four Nano streams packed at 16 / 16 virtual channels (default: 16 / 8, two streams per channel group of the second array)
+		int wnNtFromMB = 400;      // NA_WN_NT_MB: stream state (MiB) from which a batch's long-dilation ring traffic is non-temporal (wavenet_launch.h WN_BEYOND_CACHE_BYTES)
 		bool wnNtOff = false;      // NA_WN_NT=0: no non-temporal ring traffic for batches whose state exceeds the Infinity Cache
 		bool wnPadOff = false;     // NA_WN_PAD=0: no padding of partly filled lane modes
 		bool wnSpecOff = false;    // NA_WN_SPEC=0 (implied by NA_SP_T / NA_SP_GEN): the stage interpreter for everything

@@ -76,7 +76,10 @@ namespace na
 			static constexpr bool GUARDHIST = false;
 			static constexpr int SKEW = 0;
 			static constexpr bool COMPACT = true; // K <= 3 everywhere, dense heads: histories of <= 32 frames live in compact rings (wavenet_plan.cpp AddRing)
-			static constexpr int NT_DIL = 128;    // Cfg::NT: layers from this dilation on move their ring traffic non-temporally
+#ifndef NA_A1_NT_DIL
+#define NA_A1_NT_DIL 128
+#endif
+			static constexpr int NT_DIL = NA_A1_NT_DIL; // Cfg::NT: layers from this dilation on move their ring traffic non-temporally
 		};
 #ifndef NA_SPK_SKEW
 #define NA_SPK_SKEW 0
