@@ -17,12 +17,15 @@ namespace na
 		}
 
 		// ... as a table launch (wavenet_launch.h LaunchWaveNetSpecTable): 128-frame blocks
-		hipError_t LaunchSpecA2Table(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int spb, hipStream_t stream,
+		hipError_t LaunchSpecA2Table(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream,
 			WnLaunchTable& table)
 		{
 #ifdef NA_SP_QUICK
 			return hipErrorNotSupported;
 #else
+			if (n == 64)
+				return spb >= 2 ? LaunchTable<FamA2, 64, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table)
+								: LaunchTable<FamA2, 64, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
 			return spb >= 2 ? LaunchTable<FamA2, 128, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table)
 							: LaunchTable<FamA2, 128, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
 #endif

@@ -1483,7 +1483,7 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 		// server sees) would be cut into launches of eight groups each, one after the other -- 1024 models x 1 stream: 128 launches, 2.9 ms
 		// per 128-frame buffer.  Here the group table lives in device memory (rebuilt and uploaded when the batch's topology changes): a
 		// workgroup finds its group by binary search over GroupArgs::firstBlock with scalar loads and copies the entry, the chain is the
-		// same code.  (Table kernels exist for 128-frame blocks of the A1 families; other lengths keep the launches of eight.)
+		// same code.  (Table kernels exist for 128- and 64-frame blocks; other lengths keep the launches of eight.)
 		template <class F, int NF, int SPB, bool PK>
 		__global__ void __launch_bounds__(64 * (NF / (16 * F::A0::T)) * (SPB * F::A0::T / 2)) __attribute__((amdgpu_waves_per_eu(OccOf<F, NF, SPB>()))) WaveNetSpecTableKernel(
 			const GroupArgs* __restrict__ table, int numGroups, const float* __restrict__ in, float* __restrict__ out, long inStride, long outStride)
@@ -1667,9 +1667,9 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 			hipStream_t stream, bool oneTilePerWave = false, bool beyondCache = false);
 		hipError_t LaunchSpecA2(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream,
 			bool beyondCache = false);
-		hipError_t LaunchSpecA2Table(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int spb, hipStream_t stream,
+		hipError_t LaunchSpecA2Table(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, hipStream_t stream,
 			WnLaunchTable& table);
-		hipError_t LaunchSpecLiteTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int spb, bool packed,
+		hipError_t LaunchSpecLiteTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, bool packed,
 			hipStream_t stream, WnLaunchTable& table);
 	}
 }

@@ -49,7 +49,7 @@ namespace na
 #ifdef NA_SP_QUICK
 		return hipErrorNotSupported;
 #else
-		if (numGroups <= WN_FRAME_MAX_GROUPS || n != 128 || !WaveNetSpecEnabled() || Tuning::Get().spSpb > 0) return hipErrorNotSupported;
+		if (numGroups <= WN_FRAME_MAX_GROUPS || (n != 128 && n != 64) || !WaveNetSpecEnabled() || Tuning::Get().spSpb > 0) return hipErrorNotSupported;
 		const int arch = groups[0].model->spec_arch;
 		const bool lite = arch == WN_SPEC_LITE || arch == WN_SPEC_LITE16, a2 = arch == WN_SPEC_A2FULL || arch == WN_SPEC_A2LITE;
 		if (arch != WN_SPEC_STD && !lite && !a2) return hipErrorNotSupported;
@@ -73,10 +73,15 @@ namespace na
 			for (int i = 0; i < numGroups; i++)
 				if (groups[i].model->spec_arch == WN_SPEC_LITE16) return hipErrorNotSupported; // (16 / 16 only exists packed)
 		const int spb = (slots2 * 4 > streams * 5) ? 1 : 2; // more than a quarter of the full-size workgroups' stream slots would idle
-		if (a2) return spk::LaunchSpecA2Table(groups, numGroups, in, out, inStride, outStride, spb, stream, table);
-		if (!lite) return spb == 2 ? spk::LaunchTable<spk::FamStd, 128, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table)
-								   : spk::LaunchTable<spk::FamStd, 128, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
-		return spk::LaunchSpecLiteTable(groups, numGroups, in, out, inStride, outStride, spb, packed, stream, table);
+		if (a2) return spk::LaunchSpecA2Table(groups, numGroups, in, out, inStride, outStride, n, spb, stream, table);
+		if (!lite)
+		{
+			if (n == 64) return spb == 2 ? spk::LaunchTable<spk::FamStd, 64, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table)
+										 : spk::LaunchTable<spk::FamStd, 64, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
+			return spb == 2 ? spk::LaunchTable<spk::FamStd, 128, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table)
+							: spk::LaunchTable<spk::FamStd, 128, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
+		}
+		return spk::LaunchSpecLiteTable(groups, numGroups, in, out, inStride, outStride, n, spb, packed, stream, table);
 #endif
 	}
 

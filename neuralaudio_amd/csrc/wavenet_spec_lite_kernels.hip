@@ -20,17 +20,21 @@ namespace na
 		}
 
 		// the same families as table launches (wavenet_launch.h LaunchWaveNetSpecTable): 128-frame blocks
-		hipError_t LaunchSpecLiteTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int spb, bool packed,
+		hipError_t LaunchSpecLiteTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n, int spb, bool packed,
 			hipStream_t stream, WnLaunchTable& table)
 		{
 #ifdef NA_SP_QUICK
 			return hipErrorNotSupported;
 #else
-			if (packed)
-				return spb >= 2 ? LaunchTable<FamLitePacked, 128, 2, true>(groups, numGroups, in, out, inStride, outStride, stream, table)
-								: LaunchTable<FamLitePacked, 128, 1, true>(groups, numGroups, in, out, inStride, outStride, stream, table);
-			return spb >= 2 ? LaunchTable<FamLite, 128, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table)
-							: LaunchTable<FamLite, 128, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
+#define NA_LITE_TABLE(NFR) \
+			if (packed) \
+				return spb >= 2 ? LaunchTable<FamLitePacked, NFR, 2, true>(groups, numGroups, in, out, inStride, outStride, stream, table) \
+								: LaunchTable<FamLitePacked, NFR, 1, true>(groups, numGroups, in, out, inStride, outStride, stream, table); \
+			return spb >= 2 ? LaunchTable<FamLite, NFR, 2, false>(groups, numGroups, in, out, inStride, outStride, stream, table) \
+							: LaunchTable<FamLite, NFR, 1, false>(groups, numGroups, in, out, inStride, outStride, stream, table);
+			if (n == 64) { NA_LITE_TABLE(64) }
+			NA_LITE_TABLE(128)
+#undef NA_LITE_TABLE
 #endif
 		}
 	}
