@@ -501,7 +501,8 @@ namespace na
 			fusedWn[list].push_back(a);
 			if (!wnOwner[list]) wnOwner[list] = j.second;
 		}
-		auto launchWnList = [&](int which, hipStream_t s) {
+		// prepareOnly: upload the group tables the list's launches will look up and launch nothing (the pass in front of a stream capture)
+		auto launchWnList = [&](int which, hipStream_t s, bool prepareOnly) {
 			const std::vector<WnFrameGroup>& list = fusedWn[which];
 			bool compact = false;
 			for (const WnFrameGroup& g : list) compact = compact || g.model->compact_rings != 0;
@@ -513,7 +514,9 @@ namespace na
 				// memory where the chains have one (128-frame blocks of the A1 families), else launches of eight groups each
 				if (which != 0 && list.size() > (size_t)WN_FRAME_MAX_GROUPS)
 				{
+					wnTable[which].prepareOnly = prepareOnly;
 					const hipError_t te = LaunchWaveNetSpecTable(list.data(), (int)list.size(), dIn + offset, dOut + offset, inStride, outStride, chunk, s, wnTable[which]);
+					wnTable[which].prepareOnly = false;
 					if (te == hipSuccess)
 					{
 						offset += (size_t)chunk;
@@ -522,6 +525,12 @@ namespace na
 					}
 					if (te != hipErrorNotSupported) CheckHip(te, "WaveNet kernel (table launch)");
 					(void)hipGetLastError();
+				}
+				if (prepareOnly)
+				{
+					offset += (size_t)chunk;
+					left -= (size_t)chunk;
+					continue;
 				}
 				for (size_t first = 0; first < list.size(); first += WN_FRAME_MAX_GROUPS)
 				{
@@ -535,7 +544,7 @@ namespace na
 				left -= (size_t)chunk;
 			}
 		};
-		auto launchRec = [&](hipStream_t s) {
+		auto launchRec = [&](hipStream_t s, bool prepareOnly) {
 			size_t offset = 0, left = n;
 			while (left > 0)
 			{
@@ -543,12 +552,15 @@ namespace na
 				if (fusedRec.size() > (size_t)RECURRENT_MAX_GROUPS)
 				{
 					// (many different recurrent models: one launch, the group table in device memory)
-					CheckHip(LaunchRecurrentDppTable(fusedRec.data(), (int)fusedRec.size(), dIn + offset, dOut + offset, inStride, outStride, chunk, s, wnTable[3]),
-						"RecurrentDppKernel (table launch)");
+					wnTable[3].prepareOnly = prepareOnly;
+					const hipError_t te = LaunchRecurrentDppTable(fusedRec.data(), (int)fusedRec.size(), dIn + offset, dOut + offset, inStride, outStride, chunk, s, wnTable[3]);
+					wnTable[3].prepareOnly = false;
+					CheckHip(te, "RecurrentDppKernel (table launch)");
 					offset += (size_t)chunk;
 					left -= (size_t)chunk;
 					continue;
 				}
+				if (prepareOnly) break;
 				for (size_t first = 0; first < fusedRec.size(); first += RECURRENT_MAX_GROUPS)
 					CheckHip(LaunchRecurrentDpp(fusedRec.data() + first, (int)std::min<size_t>(fusedRec.size() - first, (size_t)RECURRENT_MAX_GROUPS),
 						dIn + offset, dOut + offset, inStride, outStride, chunk, s), "RecurrentDppKernel (fused)");
@@ -556,6 +568,13 @@ namespace na
 				left -= (size_t)chunk;
 			}
 		};
+		// group tables of an earlier topology go (their graphs first)
+		if (!graphCache.empty() && graphCache.front().key.version != topologyVersion)
+		{
+			for (auto& e : graphCache) (void)hipGraphExecDestroy(e.exec);
+			graphCache.clear();
+		}
+		for (WnLaunchTable& t : wnTable) t.NewGeneration(topologyVersion);
 		size_t units = (fusedRec.empty() ? 0 : 1) + singles.size();
 		for (int l = 0; l < NUM_WN_LISTS; l++) units += fusedWn[l].empty() ? 0 : 1;
 		if (units == 1)
@@ -563,10 +582,10 @@ namespace na
 			for (int l = 0; l < NUM_WN_LISTS; l++)
 				if (!fusedWn[l].empty())
 				{
-					launchWnList(l, launch);
+					launchWnList(l, launch, false);
 					return;
 				}
-			if (!fusedRec.empty()) launchRec(launch);
+			if (!fusedRec.empty()) launchRec(launch, false);
 			else singles[0]->Process(dIn, dOut, inStride, outStride, n, launch);
 			return;
 		}
@@ -576,8 +595,8 @@ namespace na
 			if (serial)
 			{
 				for (int l = 0; l < NUM_WN_LISTS; l++)
-					if (!fusedWn[l].empty()) launchWnList(l, stream);
-				if (!fusedRec.empty()) launchRec(stream);
+					if (!fusedWn[l].empty()) launchWnList(l, stream, false);
+				if (!fusedRec.empty()) launchRec(stream, false);
 				for (ModelGroup* g : singles) g->Process(dIn, dOut, inStride, outStride, n, stream);
 				return;
 			}
@@ -586,11 +605,6 @@ namespace na
 		// costs ~5 HIP calls per unit, which would make a buffer host-bound, so the sequence is captured once into a hipGraph and
 		// replayed while the call signature (pointers, n, strides) and the active-stream lists stay the same -- the steady state of a
 		// real-time host.
-		if (!graphCache.empty() && graphCache.front().key.version != topologyVersion)
-		{
-			for (auto& e : graphCache) (void)hipGraphExecDestroy(e.exec);
-			graphCache.clear();
-		}
 		hipGraphExec_t graphExec = nullptr;
 		for (auto& e : graphCache)
 			if (e.key.dIn == dIn && e.key.dOut == dOut && e.key.n == n && e.key.inStride == inStride && e.key.outStride == outStride) graphExec = e.exec;
@@ -601,6 +615,10 @@ namespace na
 				(void)hipGraphExecDestroy(graphCache.front().exec);
 				graphCache.erase(graphCache.begin());
 			}
+			// the group tables of the table launches are uploaded here, in front of the capture (WnLaunchTable)
+			for (int l = 0; l < NUM_WN_LISTS; l++)
+				if (!fusedWn[l].empty()) launchWnList(l, stream, true);
+			if (!fusedRec.empty()) launchRec(stream, true);
 			hipGraph_t graph = nullptr;
 			CheckHip(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed), "hipStreamBeginCapture");
 			try
@@ -615,8 +633,8 @@ namespace na
 					CheckHip(hipStreamWaitEvent(stream, owner->DoneEvent(), 0), "hipStreamWaitEvent");
 				};
 				for (int l = 0; l < NUM_WN_LISTS; l++)
-					if (!fusedWn[l].empty()) branch(wnOwner[l], [&, l](hipStream_t s) { launchWnList(l, s); });
-				if (!fusedRec.empty()) branch(recOwner, launchRec);
+					if (!fusedWn[l].empty()) branch(wnOwner[l], [&, l](hipStream_t s) { launchWnList(l, s, false); });
+				if (!fusedRec.empty()) branch(recOwner, [&](hipStream_t s) { launchRec(s, false); });
 				for (ModelGroup* g : singles) branch(g, [&](hipStream_t s) { g->Process(dIn, dOut, inStride, outStride, n, s); });
 			}
 			catch (...)

@@ -7,6 +7,7 @@
 // single-stream NeuralModel (neural_model.cpp) is a GpuBatch with one stream.
 #pragma once
 
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <memory>
@@ -136,6 +137,24 @@ namespace na
 		size_t SlotFrames(int ticket) const { return (ticket >= 0 && ticket < kPipelineSlots) ? pipe[ticket].n : 0; } // frames per row of that submission
 		size_t SlotRows(int ticket) const { return (ticket >= 0 && ticket < kPipelineSlots) ? pipe[ticket].rows : 0; } // rows of that submission
 
+		// ---- bounded waits ------------------------------------------------------------------------------------------------------------
+		// Process is called from a real-time thread that must get its call back (NeuralAudio/NeuralModel.h:127, README "one thread per
+		// model"): every host-side wait of the processing paths -- stream and event waits, the polls of the resident launch's counters,
+		// the timing marks -- has a wall-clock limit (default 2000 ms: NA_WAIT_LIMIT_MS; <= 0: none).  A wait that runs into it marks the
+		// batch BROKEN and throws: the call returns (the C ABI: non-zero, NA_GetLastError(), output rows zeroed), and every later call on
+		// the batch fails at once without touching the device -- the stream states are no longer what the caller thinks they are.  A
+		// broken batch can only be destroyed; its destructor gives the device one more limit to come back and otherwise leaves the
+		// device allocations alone (a kernel may still be writing them) instead of hanging in hipFree.
+		void SetWaitLimitMs(double ms) { waitLimitMs = ms; }
+		double GetWaitLimitMs() const { return waitLimitMs; }
+		bool IsBroken() const { return broken; }
+		const std::string& BrokenReason() const { return brokenWhy; }
+		void WaitStreamBounded(hipStream_t s, const char* what); // hipStreamSynchronize with the limit
+		void WaitEventBounded(hipEvent_t e, const char* what);   // hipEventSynchronize with the limit
+		// test hook (NA_DebugStallDevice): a kernel that keeps the batch stream busy for `ms` milliseconds (at most 10 s), behind whatever
+		// the stream holds -- a wedged device as far as every wait on this batch can tell
+		void DebugStallDevice(double ms);
+
 		void Synchronize();
 		// every buffer handed to ProcessDevice so far has been processed (host-side wait).  Unlike Synchronize() it leaves the resident
 		// launch on the chip; on a caller's / observed stream it is a synchronisation of that stream.
@@ -193,6 +212,20 @@ namespace na
 		int device;
 		hipStream_t stream = nullptr;
 		bool ownsStream = true;
+		double waitLimitMs = DefaultWaitLimitMs();
+		bool broken = false;
+		std::string brokenWhy;
+		static double DefaultWaitLimitMs();
+		void CheckUsable() const; // throws when the batch is broken
+		[[noreturn]] void Stall(const char* what);
+		// a deadline of the current wait limit; Expired() is cheap enough for every turn of a poll loop
+		struct Deadline
+		{
+			std::chrono::steady_clock::time_point end;
+			bool limited;
+			explicit Deadline(double ms) : end(std::chrono::steady_clock::now() + std::chrono::microseconds((long long)(ms > 0 ? ms * 1000.0 : 0))), limited(ms > 0) {}
+			bool Expired() const { return limited && std::chrono::steady_clock::now() > end; }
+		};
 		hipEvent_t forkEvent = nullptr;
 
 		// cached hipGraph of the multi-group fork/launch/join sequence (see ProcessDevice)

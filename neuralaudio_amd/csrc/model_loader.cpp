@@ -665,7 +665,7 @@ namespace na
 		// reference's FastMathsProvider (RTNeuralModel.h:10-31): accurate tanh, sigmoid = (tanh(x/2)+1)/2 -- so an LSTM in such a
 		// stack runs with the StdMath policy.  Parity unpinned (RTNeural is an absent submodule): tests compare against a numpy
 		// restatement of the Keras definitions.  activation / batchnorm / prelu layers are lowered to dense layers (AppendKerasTailLayer);
-		// conv1d and softmax have no kernel: nullptr.
+		// conv1d layers make the tail a per-block evaluation (ConvTail); softmax runs across the units of its layer in both tail forms.
 		std::shared_ptr<ModelDesc> ReadKerasStack(const Json& modelJson)
 		{
 			const Json& layers = modelJson.At("layers");

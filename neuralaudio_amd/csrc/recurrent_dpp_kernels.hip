@@ -1220,24 +1220,12 @@ namespace na
 			blocks += groups[i].numStreams;
 			any32 |= groups[i].model.hidden > 16;
 		}
-		const size_t bytes = fresh.size() * sizeof(RecurrentGroupArgs);
-		if (t.dev == nullptr || t.devBytes < bytes)
-		{
-			if (t.dev) (void)hipFree(t.dev);
-			t.dev = nullptr;
-			t.host.clear();
-			const hipError_t me = hipMalloc(&t.dev, bytes + bytes / 2);
-			if (me != hipSuccess) return me;
-			t.devBytes = bytes + bytes / 2;
-		}
-		if (t.host.size() != bytes || memcmp(t.host.data(), fresh.data(), bytes) != 0)
-		{
-			t.host.assign(reinterpret_cast<const char*>(fresh.data()), reinterpret_cast<const char*>(fresh.data()) + bytes);
-			const hipError_t ce = hipMemcpyAsync(t.dev, t.host.data(), bytes, hipMemcpyHostToDevice, stream);
-			if (ce != hipSuccess) return ce;
-		}
+		const void* dev = nullptr;
+		const hipError_t ee = t.Ensure(fresh.data(), fresh.size() * sizeof(RecurrentGroupArgs), stream, &dev);
+		if (ee != hipSuccess) return ee;
+		if (t.prepareOnly) return hipSuccess;
 		const size_t lds = sizeof(float) * (size_t)(any32 ? REC_HOUT32_FLOATS : REC_HOUT_FLOATS);
-		hipLaunchKernelGGL(RecurrentDppTableKernel, dim3((unsigned)blocks), dim3(64), lds, stream, reinterpret_cast<const RecurrentGroupArgs*>(t.dev), numGroups,
+		hipLaunchKernelGGL(RecurrentDppTableKernel, dim3((unsigned)blocks), dim3(64), lds, stream, reinterpret_cast<const RecurrentGroupArgs*>(dev), numGroups,
 			Tuning::Get().recNoSkew ? 1 : 0, in, out, inStride, outStride, n);
 		return hipGetLastError();
 	}

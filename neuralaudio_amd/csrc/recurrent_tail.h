@@ -19,7 +19,7 @@ namespace na
 		case 2: return v > 0.0f ? v : 0.0f;
 		case 3: return GruSigmoid(v);
 		case 4: return v > 0.0f ? v : (__builtin_amdgcn_exp2f(v * 1.4426950408889634f) - 1.0f); // elu, alpha = 1
-		default: return v; // (5 = softmax: across the units of a layer, applied by the caller)
+		default: return v; // (5 = softmax: across the units of a layer, applied by the caller -- DenseTail / ConvTail below)
 		}
 	}
 
@@ -41,7 +41,21 @@ namespace na
 				if (curN == 0) acc += w[o] * x0;
 				else
 					for (int k = 0; k < in; k++) acc += w[(size_t)o * in + k] * cur[k * 64 + lane];
-				dst[o * 64 + lane] = DenseActivate(acc, act);
+				dst[o * 64 + lane] = act == 5 ? acc : DenseActivate(acc, act);
+			}
+			if (act == 5) // softmax across the units of the layer, this lane's stream (as ConvTail does per sample)
+			{
+				float mx = dst[lane];
+				for (int o = 1; o < out; o++) mx = fmaxf(mx, dst[o * 64 + lane]);
+				float sum = 0.0f;
+				for (int o = 0; o < out; o++)
+				{
+					const float e = __builtin_amdgcn_exp2f((dst[o * 64 + lane] - mx) * 1.4426950408889634f);
+					dst[o * 64 + lane] = e;
+					sum += e;
+				}
+				const float r = 1.0f / sum;
+				for (int o = 0; o < out; o++) dst[o * 64 + lane] *= r;
 			}
 			cur = dst;
 			curN = out;

@@ -1,6 +1,7 @@
 // wavenet_launch.h -- host-callable launchers of the WaveNet kernels (wavenet_split_kernels.hip, wavenet_frame_kernels.hip, wavenet_prewarm_kernels.hip)
 #pragma once
 
+#include <cstring>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -47,16 +48,65 @@ namespace na
 	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream, int sharing = 1);
 	// ---- table launches of the specialised chains (wavenet_spec_impl.h WaveNetSpecTableKernel): any number of model groups in one launch --
-	// The device copy of a launch's group table, owned by the batch (one per launch list); see LaunchWaveNetSpecTable.
+	// The device copies of a launch list's group tables, owned by the batch (one WnLaunchTable per launch list); see LaunchWaveNetSpecTable.
+	// An entry is IMMUTABLE once uploaded -- a table with other contents (another block length, other members) gets its own device
+	// buffer -- so a captured graph that replays a table launch keeps reading what it was captured with, and nothing is allocated,
+	// freed or copied inside a stream capture: the batch runs the launch list once with `prepareOnly` set before it begins the capture
+	// (gpu_batch.cpp ProcessDeviceOn), which uploads every table the captured launches will look up.  The upload is a blocking copy
+	// into a buffer no launch has seen yet.  Entries are dropped when the batch's topology changes (NewGeneration, after the graphs
+	// that point at them are gone; hipFree waits for the device).
 	struct WnLaunchTable
 	{
-		void* dev = nullptr;
-		size_t devBytes = 0;
-		std::vector<char> host; // what `dev` holds
+		struct Entry
+		{
+			void* dev = nullptr;
+			std::vector<char> host; // what `dev` holds
+		};
+		std::vector<Entry> entries;
+		unsigned long generation = 0;
+		bool prepareOnly = false; // the launch functions return after Ensure()
 		WnLaunchTable() = default;
 		WnLaunchTable(const WnLaunchTable&) = delete;
 		WnLaunchTable& operator=(const WnLaunchTable&) = delete;
-		~WnLaunchTable() { if (dev) (void)hipFree(dev); }
+		~WnLaunchTable() { Clear(); }
+		void Clear()
+		{
+			for (Entry& e : entries)
+				if (e.dev) (void)hipFree(e.dev);
+			entries.clear();
+		}
+		void NewGeneration(unsigned long g)
+		{
+			if (g != generation) Clear();
+			generation = g;
+		}
+		// the device copy of `bytes` bytes at `fresh`, uploaded now if no entry holds them
+		hipError_t Ensure(const void* fresh, size_t bytes, hipStream_t stream, const void** dev)
+		{
+			for (const Entry& e : entries)
+				if (e.host.size() == bytes && memcmp(e.host.data(), fresh, bytes) == 0)
+				{
+					*dev = e.dev;
+					return hipSuccess;
+				}
+			hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+			(void)hipStreamIsCapturing(stream, &capturing);
+			if (capturing != hipStreamCaptureStatusNone) return hipErrorStreamCaptureUnsupported; // (the prepare pass has not seen this table: a bug)
+			if (entries.size() >= 16) Clear(); // contents that change without a topology change: keep the table bounded
+			Entry e;
+			hipError_t err = hipMalloc(&e.dev, bytes);
+			if (err != hipSuccess) return err;
+			err = hipMemcpy(e.dev, fresh, bytes, hipMemcpyHostToDevice);
+			if (err != hipSuccess)
+			{
+				(void)hipFree(e.dev);
+				return err;
+			}
+			e.host.assign(static_cast<const char*>(fresh), static_cast<const char*>(fresh) + bytes);
+			*dev = e.dev;
+			entries.push_back(std::move(e));
+			return hipSuccess;
+		}
 	};
 	// A launch list of MORE than WN_FRAME_MAX_GROUPS groups of one architecture family (all Standard; lite-family groups, packed or not;
 	// the A2 submodels) as ONE launch of 128-frame blocks; hipErrorNotSupported otherwise (the caller then cuts the list into launches of eight).

@@ -1524,8 +1524,8 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 #endif
 		}
 
-		// host side of a table launch: the table is rebuilt into `t.host` every call (it is a few stores per group) and uploaded only
-		// when it differs from what the device holds
+		// host side of a table launch: the table is rebuilt every call (it is a few stores per group) and looked up among the device
+		// copies the batch holds (WnLaunchTable::Ensure uploads a new one -- never inside a stream capture)
 		template <class F, int NF, int SPB, bool PK>
 		static hipError_t LaunchTable(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, hipStream_t stream, WnLaunchTable& t)
 		{
@@ -1535,23 +1535,10 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 			int blocks = 0;
 			const hipError_t fe = FillGroupArgs<F, NF, SPB, PK>(groups, numGroups, fresh.data(), &blocks);
 			if (fe != hipSuccess) return fe;
-			const size_t bytes = fresh.size() * sizeof(GroupArgs);
-			if (t.dev == nullptr || t.devBytes < bytes)
-			{
-				if (t.dev) (void)hipFree(t.dev);
-				t.dev = nullptr;
-				t.host.clear();
-				const hipError_t me = hipMalloc(&t.dev, bytes + bytes / 2);
-				if (me != hipSuccess) return me;
-				t.devBytes = bytes + bytes / 2;
-			}
-			if (t.host.size() != bytes || memcmp(t.host.data(), fresh.data(), bytes) != 0)
-			{
-				// (pageable source: the copy is staged by the runtime before the call returns; ordered before the launch on `stream`)
-				t.host.assign(reinterpret_cast<const char*>(fresh.data()), reinterpret_cast<const char*>(fresh.data()) + bytes);
-				const hipError_t ce = hipMemcpyAsync(t.dev, t.host.data(), bytes, hipMemcpyHostToDevice, stream);
-				if (ce != hipSuccess) return ce;
-			}
+			const void* dev = nullptr;
+			const hipError_t ee = t.Ensure(fresh.data(), fresh.size() * sizeof(GroupArgs), stream, &dev);
+			if (ee != hipSuccess) return ee;
+			if (t.prepareOnly) return hipSuccess;
 			constexpr int LDS_BYTES = C::LDS_BYTES > C1::LDS_BYTES ? C::LDS_BYTES : C1::LDS_BYTES;
 			if (LDS_BYTES > 64 * 1024)
 			{
@@ -1560,7 +1547,7 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 				if (e != hipSuccess) return e;
 			}
 			hipLaunchKernelGGL((WaveNetSpecTableKernel<F, NF, SPB, PK>), dim3((unsigned)blocks), dim3(C::NTHREADS), LDS_BYTES, stream,
-				reinterpret_cast<const GroupArgs*>(t.dev), numGroups, in, out, inStride, outStride);
+				reinterpret_cast<const GroupArgs*>(dev), numGroups, in, out, inStride, outStride);
 			return hipGetLastError();
 		}
 

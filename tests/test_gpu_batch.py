@@ -937,6 +937,48 @@ def test_many_distinct_models_run_as_one_table_launch_and_match_one_model_batch(
     one.close()
 
 
+def test_table_launches_inside_a_captured_multi_unit_batch_replay_their_own_tables(na, loader):
+    """More than eight WaveNet model groups AND more than eight recurrent groups in ONE batch: several launch units, so the buffer is
+    captured into a hipGraph and replayed (gpu_batch.cpp ProcessDeviceOn) -- with table launches inside the capture.  The group tables
+    are uploaded in front of the capture, one immutable device copy per block length (wavenet_launch.h WnLaunchTable): a 192-frame
+    call is a 128- and a 64-frame table launch in the same graph, each replaying its own table.  Same call signature over and over
+    (replays), then other signatures (new captures), against one-model-handle batches of the same streams, bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    wn = [loader.CreateFromFile(_path("BossWN-standard.nam"), doPrewarm=False) for _ in range(11)]
+    nano = [loader.CreateFromFile(_path("BossWN-nano.nam"), doPrewarm=False) for _ in range(10)]
+    rec = [loader.CreateFromFile(_path("BossLSTM-1x16.nam"), doPrewarm=False) for _ in range(12)]
+    ts = torch.cuda.Stream(device=dev)
+    many, one = na.Batch(0, hip_stream=ts.cuda_stream), na.Batch(0, hip_stream=ts.cuda_stream)
+    per = 2
+    for h in wn + nano + rec:
+        many.AddStreams(h, per)
+    for hs in (wn, nano, rec):
+        one.AddStreams(hs[0], per * len(hs))
+    S = per * (len(wn) + len(nano) + len(rec))
+    lengths = [192] * 4 + [128] * 3 + [192] * 2 + [64, 100, 128]
+    total = max(lengths)
+    g = torch.Generator(device="cpu").manual_seed(17)
+    x = torch.clamp(0.3 * torch.randn(len(lengths), S, total, generator=g), -1.0, 1.0).to(dev)
+    want, got = torch.zeros_like(x), torch.zeros_like(x)
+    xin = torch.zeros(S, total, device=dev)      # one fixed pair of buffers, as a real-time host uses: the same call signature replays
+    yout = torch.zeros(S, total, device=dev)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(ts):
+        for bb, y in ((one, want), (many, got)):
+            for k, n in enumerate(lengths):
+                xin.copy_(x[k])
+                bb.ProcessDevice(xin.data_ptr(), yout.data_ptr(), n, total, total)
+                y[k, :, :n].copy_(yout[:, :n])
+            bb.Synchronize()
+    assert torch.equal(want, got)
+    xs = np.concatenate([x[k, 0, :n].cpu().numpy() for k, n in enumerate(lengths)])
+    ys = np.concatenate([got[k, 0, :n].cpu().numpy() for k, n in enumerate(lengths)])
+    assert O.rms(ys - O.oracle_from_file("BossWN-standard.nam").process(xs)) < TOL_RMS
+    many.close()
+    one.close()
+
+
 def test_batches_beyond_the_infinity_cache_mark_their_ring_traffic_non_temporal_and_compute_the_same(na, loader):
     """More A1 Standard state than the 256 MB Infinity Cache holds (1760 streams = 428 MB, beyond the 400 MB from which the variant is used): the chains of such a batch mark the ring traffic
     of the d >= 128 layers non-temporal (Cfg::NT, wavenet_spec_impl.h) -- a cache-policy bit, so two batches of 880 streams (inside the

@@ -4,31 +4,62 @@ By default a model runs on the family that is faster for it (FamilyFor() in gpu_
 models and padded A1 Lite, the f32 frame kernel for narrow / large-kernel ones, the runtime-shaped kernel for arrays wider than 16
 channels; large batches of narrow models run packed).
 NA_WN_KERNEL forces one family for all models it can run; it is read
-once per process, so each forced run is a subprocess of the same parity + fuzz + batch test files."""
+once per process, so each forced run is a subprocess.  Two tiers: four fallbacks over the direct parity file ride in `-m gpu`
+(seconds each); the full knob matrix over parity + fuzz + batch (245 tests per run) is a soak test behind `-m gpu_soak`.
+Every subprocess has its own limit below the per-test watchdog, so a stall is reported with the output it produced."""
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
-pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = os.path.join(ROOT, "tests")
+KNOBS = ("NA_WN_KERNEL", "NA_LSTM_NO_DPP", "NA_LSTM_LANE_KERNEL", "NA_REC_NOSKEW", "NA_WN_PACK", "NA_LSTM_NO_WAVE_RT", "NA_WN_SPEC", "NA_HOST_DIRECT",
+         "NA_REC_QUAD_MIN", "NA_HOST_HALVES", "NA_REC_RPL", "NA_WN_DENSE")
+
+SOAK = [{"NA_WN_SPEC": "0"}, {"NA_WN_KERNEL": "split"}, {"NA_WN_KERNEL": "split", "NA_SP_T": "4"}, {"NA_WN_KERNEL": "split", "NA_SP_GEN": "1"},
+        {"NA_WN_KERNEL": "frame"}, {"NA_WN_KERNEL": "frame", "NA_FR_PF": "2"}, {"NA_WN_KERNEL": "frame", "NA_FR_PF": "0"},
+        {"NA_WN_KERNEL": "frame", "NA_FR_SPB": "4"}, {"NA_WN_KERNEL": "generic"}, {"NA_WN_PACK": "1"}, {"NA_LSTM_NO_DPP": "1", "NA_GRU_NO_DPP": "1"},
+        {"NA_LSTM_LANE_KERNEL": "1"}, {"NA_REC_NOSKEW": "1", "NA_REC_NO_DPP32": "1"}, {"NA_LSTM_NO_WAVE_RT": "1"},
+        {"NA_HOST_DIRECT": "0"},    # host buffers through the copy engines instead of kernels on the pinned block
+        {"NA_REC_QUAD_MIN": "1"},   # every recurrent launch that can on the four-streams-per-wave layout, whatever its size
+        {"NA_HOST_HALVES": "0"},    # no free-running half-batch chains: every buffer as ordered launches on the batch stream
+        {"NA_WN_DENSE": "0"},       # four Nano streams at 16 / 16 virtual channels (default: 16 / 8, two streams per channel group)
+        {"NA_REC_RPL": "4"}]        # runtime-shaped recurrent kernel: four gate rows per lane (a quarter of the waves per stream)
+
+# the four fallbacks a deployment can actually land on, over the direct parity file only: part of -m gpu, a few seconds each
+SHORT = [{"NA_WN_KERNEL": "frame"}, {"NA_WN_SPEC": "0"}, {"NA_LSTM_NO_DPP": "1", "NA_GRU_NO_DPP": "1"}, {"NA_HOST_HALVES": "0"}]
 
 
-@pytest.mark.parametrize("env", [{"NA_WN_SPEC": "0"}, {"NA_WN_KERNEL": "split"}, {"NA_WN_KERNEL": "split", "NA_SP_T": "4"}, {"NA_WN_KERNEL": "split", "NA_SP_GEN": "1"},
-                                 {"NA_WN_KERNEL": "frame"}, {"NA_WN_KERNEL": "frame", "NA_FR_PF": "2"}, {"NA_WN_KERNEL": "frame", "NA_FR_PF": "0"},
-                                 {"NA_WN_KERNEL": "frame", "NA_FR_SPB": "4"}, {"NA_WN_KERNEL": "generic"}, {"NA_WN_PACK": "1"}, {"NA_LSTM_NO_DPP": "1", "NA_GRU_NO_DPP": "1"}, {"NA_LSTM_LANE_KERNEL": "1"}, {"NA_REC_NOSKEW": "1", "NA_REC_NO_DPP32": "1"}, {"NA_LSTM_NO_WAVE_RT": "1"},
-                                 {"NA_HOST_DIRECT": "0"},    # host buffers through the copy engines instead of kernels on the pinned block
-                                 {"NA_REC_QUAD_MIN": "1"},   # every recurrent launch that can on the four-streams-per-wave layout, whatever its size
-                                 {"NA_HOST_HALVES": "0"},    # no free-running half-batch chains: every buffer as ordered launches on the batch stream
-                                 {"NA_WN_DENSE": "0"},       # four Nano streams at 16 / 16 virtual channels (default: 16 / 8, two streams per channel group)
-                                 {"NA_REC_RPL": "4"}],       # runtime-shaped recurrent kernel: four gate rows per lane (a quarter of the waves per stream)
-                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
-def test_forced_family_passes_parity_fuzz_and_batch_suites(env):
-    if os.environ.get("NA_WN_KERNEL") or os.environ.get("NA_LSTM_NO_DPP") or os.environ.get("NA_LSTM_LANE_KERNEL") or os.environ.get("NA_REC_NOSKEW") or os.environ.get("NA_WN_PACK") or os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_WN_SPEC") or os.environ.get("NA_HOST_DIRECT") or os.environ.get("NA_REC_QUAD_MIN") or os.environ.get("NA_HOST_HALVES") or os.environ.get("NA_REC_RPL") or os.environ.get("NA_WN_DENSE"):
+def ident(e):
+    return ",".join("%s=%s" % kv for kv in e.items())
+
+
+def forced_run(env, files, limit):
+    if any(os.environ.get(k) for k in KNOBS):
         pytest.skip("already inside a forced run")
     e = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_fuzz.py"), os.path.join(ROOT, "tests", "test_gpu_batch.py")],
-                       env=e, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    t0 = time.monotonic()
+    try:    # --durations: a slow forced run names its slow tests in the failure text
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "--durations=8", "-p", "no:cacheprovider"] + files,
+                           env=e, capture_output=True, text=True, timeout=limit)
+    except subprocess.TimeoutExpired as ex:
+        out = ex.stdout.decode(errors="replace") if isinstance(ex.stdout, bytes) else (ex.stdout or "")
+        pytest.fail("forced run %s did not finish in %d s; output so far:\n%s" % (ident(env), limit, out[-3000:]))
+    assert r.returncode == 0, "%.0f s\n" % (time.monotonic() - t0) + r.stdout[-3000:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.watchdog(120)
+@pytest.mark.parametrize("env", SHORT, ids=ident)
+def test_forced_fallback_passes_the_parity_suite(env):
+    forced_run(env, [os.path.join(T, "test_gpu_parity.py")], 100)
+
+
+@pytest.mark.gpu_soak
+@pytest.mark.watchdog(330)
+@pytest.mark.parametrize("env", SOAK, ids=ident)
+def test_forced_family_passes_parity_fuzz_and_batch_suites(env):
+    forced_run(env, [os.path.join(T, "test_gpu_parity.py"), os.path.join(T, "test_gpu_fuzz.py"), os.path.join(T, "test_gpu_batch.py")], 300)

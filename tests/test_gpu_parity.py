@@ -209,7 +209,10 @@ def test_runtime_shaped_lstm_matches_oracle(na, loader, layers, hidden):
                                   [("lstm", 8), ("conv1d", 6, 5, 3), ("prelu", 6), ("batchnorm", 6), ("dense", 1, "tanh")],
                                   [("gru", 12), ("conv1d", 16, 4, 64, "elu"), ("dense", 5, "softmax"), ("dense", 1)],
                                   [("conv1d", 4, 12, 1), ("activation", 4, "softmax"), ("conv1d", 1, 2, 100, "sigmoid")],
-                                  [("dense", 6, "tanh"), ("conv1d", 3, 3, 170, "tanh"), ("conv1d", 1, 1, 1)]],
+                                  [("dense", 6, "tanh"), ("conv1d", 3, 3, 170, "tanh"), ("conv1d", 1, 1, 1)],
+                                  # softmax in tails WITHOUT a conv1d layer (the per-sample DenseTail; round 6 -- it was evaluated as linear there)
+                                  [("lstm", 8), ("dense", 4, "softmax"), ("dense", 1)], [("gru", 8), ("dense", 4, "softmax"), ("dense", 1)],
+                                  [("dense", 6, "softmax"), ("dense", 1)], [("gru", 6), ("dense", 5), ("activation", 5, "softmax"), ("dense", 2, "tanh")]],
                          ids=lambda s: "-".join("%s%d%s" % (l[0], l[1], "".join(str(v) for v in l[2:])) for l in s))
 def test_generic_keras_stack_matches_numpy_restatement(na, loader, spec):
     """Generic keras stacks (SURVEY 8 f3): the reference evaluates them with RTNeural, which is an absent submodule -- parity unpinned;
