@@ -117,6 +117,17 @@ NA_EXTERN int NA_BatchProcessDevice(NA_Batch* batch, const float* dIn, float* dO
 /* every buffer handed to NA_BatchProcessDevice so far has been processed: its output rows are valid (host-side wait; contract (b)) */
 NA_EXTERN int NA_BatchWaitOutputs(NA_Batch* batch);
 NA_EXTERN int NA_BatchSynchronize(NA_Batch* batch);
+/* Bounded waits.  Process is called from a real-time thread that must get its call back (NeuralAudio/NeuralModel.h:127): every host-side
+ * wait of the processing entry points -- NA_BatchProcess, NA_BatchCollect, NA_BatchWaitOutputs, NA_BatchSynchronize, the timing marks,
+ * the legacy Process / NA_ProcessChecked (a batch of one) -- gives up after a wall-clock limit: default 2000 ms, environment
+ * NA_WAIT_LIMIT_MS for every batch of the process, NA_BatchSetWaitLimitMs for one batch (<= 0: wait without a limit).  A wait that runs
+ * into the limit marks the batch BROKEN: the call returns non-zero with the reason in NA_GetLastError(), NA_BatchProcess / Process
+ * hand back silence (zeros), and every later call on the batch fails at once without touching the device (the stream states are no
+ * longer what the caller thinks they are).  A broken batch can only be destroyed; NA_BatchDestroy gives the device one more limit to
+ * come back and otherwise leaves the device allocations alone instead of waiting in hipFree.  NA_BatchIsBroken: 1 / 0. */
+NA_EXTERN int NA_BatchSetWaitLimitMs(NA_Batch* batch, double milliseconds);
+NA_EXTERN double NA_BatchGetWaitLimitMs(NA_Batch* batch);
+NA_EXTERN int NA_BatchIsBroken(NA_Batch* batch);
 /* The batch's HIP stream.  Fetching it switches a batch that created its own stream from contract (b) to contract (a) for good: the
    internal launches are joined, and from then on every launch is ordered on this stream. */
 NA_EXTERN void* NA_BatchGetHipStream(NA_Batch* batch);
@@ -210,6 +221,9 @@ NA_EXTERN long long NA_DebugRecurrentQuadLaunches(void);
  * byte over xGMI.  failSendAt > 0 makes the failSendAt-th ncclSend of the loopback table fail (fault injection), rendezvousMs > 0 is how
  * long a loopback rank waits for a peer that never posts.  Set it while no multi batch is being committed. */
 NA_EXTERN void NA_DebugSetRcclApi(int mode, int failSendAt, int rendezvousMs);
+/* Tests: a kernel that keeps the batch's streams busy for `milliseconds` (at most 10 000) behind whatever they hold -- a device that
+ * does not answer, as far as the waits of this batch can tell (tests/test_gpu_stall.py drives the wait limit with it). */
+NA_EXTERN int NA_DebugStallDevice(NA_Batch* batch, double milliseconds);
 /* tuning aid: device buffer (long long[stages*4*waves]) that workgroup 0 of the WaveNet kernel stamps with the shader clock; NULL = off */
 NA_EXTERN void NA_DebugSetTraceBuffer(void* deviceBuffer);
 

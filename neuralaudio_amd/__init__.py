@@ -317,6 +317,21 @@ class Batch:
         if self._lib.NA_BatchWaitOutputs(self._h) != 0:
             raise NeuralAudioError(capi.last_error())
 
+    def SetWaitLimitMs(self, ms):
+        """Wall-clock limit of every host-side wait of this batch (NA_BatchSetWaitLimitMs; <= 0: none).  A wait that runs into it breaks the batch."""
+        self._lib.NA_BatchSetWaitLimitMs(self._h, float(ms))
+
+    def GetWaitLimitMs(self):
+        return float(self._lib.NA_BatchGetWaitLimitMs(self._h))
+
+    def IsBroken(self):
+        return bool(self._lib.NA_BatchIsBroken(self._h))
+
+    def DebugStallDevice(self, ms):
+        """Test hook: keep the batch's streams busy for `ms` milliseconds (NA_DebugStallDevice)."""
+        if self._lib.NA_DebugStallDevice(self._h, float(ms)) != 0:
+            raise NeuralAudioError(capi.last_error())
+
     def SetResidentLaunch(self, on=True):
         """Opt in to (or out of) the resident launch for device-pointer buffers of this batch (NA_BatchSetResidentLaunch)."""
         if self._lib.NA_BatchSetResidentLaunch(self._h, 1 if on else 0) != 0:

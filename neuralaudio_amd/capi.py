@@ -30,6 +30,7 @@ NA_SYMBOLS = [
     "NA_BatchStateBytes", "NA_BatchStreamPackFactor", "NA_BatchStreamKernelName", "NA_DebugSetTraceBuffer", "NA_DebugSetWaveNetSpec", "NA_DebugSetRecurrentQuadMin", "NA_DebugRecurrentQuadLaunches", "NA_RegisterHostBuffer", "NA_UnregisterHostBuffer", "NA_BatchStreamInputLimit", "NA_BatchRemoveStreams", "NA_MultiCreate", "NA_MultiDestroy", "NA_MultiAddStreams", "NA_MultiCommit", "NA_MultiNumStreams", "NA_MultiNumShards", "NA_MultiShardRange", "NA_MultiProcess", "NA_MultiSubmit", "NA_MultiCollect", "NA_MultiSetQuality", "NA_ShardByCost", "NA_ModelStreamCost", "NA_BatchNumLiveStreams", "NA_BatchIsLive", "NA_SetWaveNetMathMode", "NA_SetLSTMMathMode", "NA_SetCompositeModelLoadMode",
     "NA_IsQualityChangeRealtimeSafe", "NA_ProcessChecked", "NA_BatchSubmit", "NA_BatchCollect", "NA_BatchNextInput", "NA_BatchOutputView", "NA_BatchIsQualityChangeRealtimeSafe", "NA_DebugClassifyNam", "NA_DebugPackedWeights", "NA_ModelKernelInfo", "NA_BatchStreamRangeEvents", "NA_MultiSetFanIn", "NA_MultiGatheredOutput", "NA_RcclAvailable",
     "NA_BatchMarkTime", "NA_BatchWaitMarks", "NA_BatchElapsedMs", "NA_BatchUsesHalfLaunches", "NA_DebugSetRcclApi", "NA_BatchWaitOutputs", "NA_BatchUsesResidentLaunch", "NA_BatchSetResidentLaunch",
+    "NA_BatchSetWaitLimitMs", "NA_BatchGetWaitLimitMs", "NA_BatchIsBroken", "NA_DebugStallDevice",
 ]
 
 _lib = None
@@ -95,6 +96,10 @@ def load_library():
         "NA_BatchUsesResidentLaunch": (C.c_int, [vp]),
         "NA_BatchSetResidentLaunch": (C.c_int, [vp, C.c_int]),
         "NA_BatchWaitOutputs": (C.c_int, [vp]),
+        "NA_BatchSetWaitLimitMs": (C.c_int, [vp, C.c_double]),
+        "NA_BatchGetWaitLimitMs": (C.c_double, [vp]),
+        "NA_BatchIsBroken": (C.c_int, [vp]),
+        "NA_DebugStallDevice": (C.c_int, [vp, C.c_double]),
         "NA_BatchAlgorithmicBytesPerSample": (C.c_double, [vp, C.c_int]),
         "NA_BatchMacsPerSample": (C.c_double, [vp]),
         "NA_BatchStateBytes": (C.c_double, [vp]),

@@ -427,8 +427,15 @@ int NA_BatchPrewarm(NA_Batch* batch, int stream)
 
 int NA_BatchProcess(NA_Batch* batch, const float* in, float* out, size_t n)
 {
-	if (!batch) return -1;
-	return Guard([&] { batch->batch->ProcessHost(in, out, n); });
+	if (!batch || !out)
+	{
+		SetError("NA_BatchProcess: null argument");
+		return -1;
+	}
+	const int rc = Guard([&] { batch->batch->ProcessHost(in, out, n); });
+	// (an audio host must never be handed stale or uninitialised rows: a failed buffer is silence, like the legacy Process)
+	if (rc != 0) memset(out, 0, (size_t)batch->batch->NumStreams() * n * sizeof(float));
+	return rc;
 }
 
 int NA_RegisterHostBuffer(void* ptr, size_t bytes)
@@ -481,6 +488,23 @@ int NA_BatchSynchronize(NA_Batch* batch)
 {
 	if (!batch) return -1;
 	return Guard([&] { batch->batch->Synchronize(); });
+}
+
+int NA_BatchSetWaitLimitMs(NA_Batch* batch, double milliseconds)
+{
+	if (!batch) return -1;
+	batch->batch->SetWaitLimitMs(milliseconds);
+	return 0;
+}
+
+double NA_BatchGetWaitLimitMs(NA_Batch* batch) { return batch ? batch->batch->GetWaitLimitMs() : 0.0; }
+
+int NA_BatchIsBroken(NA_Batch* batch) { return (batch && batch->batch->IsBroken()) ? 1 : 0; }
+
+int NA_DebugStallDevice(NA_Batch* batch, double milliseconds)
+{
+	if (!batch) return -1;
+	return Guard([&] { batch->batch->DebugStallDevice(milliseconds); });
 }
 
 void* NA_BatchGetHipStream(NA_Batch* batch) { return batch ? reinterpret_cast<void*>(batch->batch->GetStream()) : nullptr; }

@@ -114,18 +114,34 @@ namespace na
 	GpuBatch::~GpuBatch()
 	{
 		(void)hipSetDevice(device);
+		// everything this batch has in flight, under the wait limit (gpu_batch.h "bounded waits").  A device that does not come back keeps
+		// the allocations: a kernel that is still running may write them, and hipFree would wait for it without a limit.
+		bool idle = true;
 		try
 		{
-			DrainResident();
+			if (broken)
+			{
+				// (the resident launch of a broken batch: asked to leave, not waited for command by command)
+				if (residentState && residentState->ctrl) __atomic_store_n(&residentState->ctrl->exitAfter, 0ull, __ATOMIC_RELEASE);
+			}
+			else DrainResident();
+			for (PipeSlot& p : pipe)
+				if (p.own) WaitStreamBounded(p.own, "closing the batch");
+			for (hipStream_t hs : halfStream)
+				if (hs) WaitStreamBounded(hs, "closing the batch");
+			if (stream) WaitStreamBounded(stream, "closing the batch");
 		}
 		catch (...)
 		{
+			idle = false;
 		}
-		for (PipeSlot& p : pipe)
-			if (p.own) (void)hipStreamSynchronize(p.own);
-		for (hipStream_t hs : halfStream)
-			if (hs) (void)hipStreamSynchronize(hs);
-		if (stream) (void)hipStreamSynchronize(stream);
+		if (!idle)
+		{
+			for (auto& g : groups) (void)g.release();
+			(void)residentState.release();
+			for (WnLaunchTable& t : wnTable) t.entries.clear();
+			return;
+		}
 		residentState.reset();
 		groups.clear();
 		if (hostStage) (void)hipHostFree(hostStage);
@@ -195,6 +211,7 @@ namespace na
 
 	int GpuBatch::AddStreams(const std::shared_ptr<const LoadedModel>& model, float quality, int count, bool prewarm, bool onDemand)
 	{
+		CheckUsable();
 		if (!model || model->subModels.empty()) throw std::runtime_error("neuralaudio_amd: AddStream with an empty model");
 		if (count < 1) throw std::runtime_error("neuralaudio_amd: AddStreams with count < 1");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
@@ -293,6 +310,7 @@ namespace na
 
 	void GpuBatch::RemoveStreams(int first, int count)
 	{
+		CheckUsable();
 		if (count < 1 || first < 0 || (size_t)first + (size_t)count > streams.size()) throw std::runtime_error("neuralaudio_amd: RemoveStreams: id range outside the batch");
 		for (int i = 0; i < count; i++)
 			if (!streams[(size_t)(first + i)].live) throw std::runtime_error("neuralaudio_amd: RemoveStreams: stream was already removed");
@@ -327,6 +345,7 @@ namespace na
 
 	void GpuBatch::SetQuality(int s, float quality)
 	{
+		CheckUsable();
 		StreamRef& ref = streams.at((size_t)s);
 		if (!ref.live) throw std::runtime_error("neuralaudio_amd: stream was removed");
 		ref.quality = quality;
@@ -389,6 +408,7 @@ namespace na
 
 	void GpuBatch::Prewarm(int s)
 	{
+		CheckUsable();
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		DrainPipeline();
 		StreamRef& ref = streams.at((size_t)s);
@@ -404,6 +424,7 @@ namespace na
 
 	void GpuBatch::ProcessDevice(const float* dIn, float* dOut, size_t n, long inStride, long outStride)
 	{
+		CheckUsable();
 		if (n == 0 || streams.empty()) return;
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		// A batch on its own stream that nobody has seen: a buffer of one contiguous WaveNet group runs as two free-running half-batch
@@ -661,6 +682,7 @@ namespace na
 
 	void GpuBatch::WeightsArrived()
 	{
+		CheckUsable();
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		for (ModelGroup* g : awaitingWeights) g->WeightsArrived();
 		awaitingWeights.clear();
@@ -714,6 +736,7 @@ namespace na
 
 	int GpuBatch::StreamRangeEvents(int s)
 	{
+		CheckUsable();
 		const StreamRef& ref = streams.at((size_t)s);
 		if (!ref.live) return 0;
 		CheckHip(hipSetDevice(device), "hipSetDevice");

@@ -7,6 +7,7 @@
 // and the timing marks bench.py brackets its steps with.  Part of class GpuBatch (gpu_batch.h).
 #include "gpu_batch_internal.h"
 #include <immintrin.h>
+#include <thread>
 
 namespace na
 {
@@ -33,6 +34,93 @@ namespace na
 			__atomic_store_n(p, v, __ATOMIC_RELEASE);
 			_mm_sfence();
 		}
+	}
+
+	// ---- bounded waits (gpu_batch.h) --------------------------------------------------------------------------------------------------
+	double GpuBatch::DefaultWaitLimitMs()
+	{
+		static const double ms = [] {
+			const char* e = getenv("NA_WAIT_LIMIT_MS");
+			return (e && *e) ? atof(e) : 2000.0;
+		}();
+		return ms;
+	}
+
+	void GpuBatch::CheckUsable() const
+	{
+		if (broken) throw std::runtime_error("neuralaudio_amd: the batch is broken (" + brokenWhy + "); destroy it");
+	}
+
+	void GpuBatch::Stall(const char* what)
+	{
+		char text[256];
+		snprintf(text, sizeof text, "the device did not answer within %.0f ms: %s", waitLimitMs, what);
+		if (!broken) brokenWhy = text;
+		broken = true;
+		throw std::runtime_error(std::string("neuralaudio_amd: ") + text);
+	}
+
+	namespace
+	{
+		// one turn of a poll loop: busy for the first millisecond (a buffer takes 40 - 300 us), then 50 us naps
+		struct Poller
+		{
+			std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now();
+			void Turn()
+			{
+				if (std::chrono::steady_clock::now() - start < std::chrono::milliseconds(1)) _mm_pause();
+				else std::this_thread::sleep_for(std::chrono::microseconds(50));
+			}
+		};
+	}
+
+	void GpuBatch::WaitStreamBounded(hipStream_t s, const char* what)
+	{
+		if (waitLimitMs <= 0)
+		{
+			CheckHip(hipStreamSynchronize(s), what);
+			return;
+		}
+		const Deadline deadline(waitLimitMs);
+		Poller poll;
+		for (;;)
+		{
+			const hipError_t q = hipStreamQuery(s);
+			if (q == hipSuccess) return;
+			if (q != hipErrorNotReady) CheckHip(q, what);
+			if (deadline.Expired()) Stall(what);
+			poll.Turn();
+		}
+	}
+
+	void GpuBatch::WaitEventBounded(hipEvent_t e, const char* what)
+	{
+		if (waitLimitMs <= 0)
+		{
+			CheckHip(hipEventSynchronize(e), what);
+			return;
+		}
+		const Deadline deadline(waitLimitMs);
+		Poller poll;
+		for (;;)
+		{
+			const hipError_t q = hipEventQuery(e);
+			if (q == hipSuccess) return;
+			if (q != hipErrorNotReady) CheckHip(q, what);
+			if (deadline.Expired()) Stall(what);
+			poll.Turn();
+		}
+	}
+
+	void GpuBatch::DebugStallDevice(double ms)
+	{
+		CheckUsable();
+		CheckHip(hipSetDevice(device), "hipSetDevice");
+		DrainResident();
+		CheckHip(LaunchStallKernel(std::min(std::max(ms, 0.0), 10000.0), stream), "stall kernel");
+		if (halfChainsUsed)
+			for (hipStream_t hs : halfStream)
+				if (hs) CheckHip(LaunchStallKernel(std::min(std::max(ms, 0.0), 10000.0), hs), "stall kernel");
 	}
 
 	// (re)starts the launch of the current generation unless one is still on the stream
@@ -80,7 +168,7 @@ namespace na
 		if (active == 0 || active > WN_FRAME_MAX_GROUPS) return false;
 		// whatever else this batch has in flight comes first (state resets and prewarms on the batch stream, slot streams, the chains) ...
 		DrainPipeline();
-		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		WaitStreamBounded(stream, "hipStreamSynchronize");
 		for (const auto& g : groups)
 		{
 			if (g->NumActive() == 0) continue;
@@ -92,7 +180,7 @@ namespace na
 			r.list.push_back(a);
 		}
 		// ... and so do the index lists
-		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		WaitStreamBounded(stream, "hipStreamSynchronize");
 		if (total < 512) return false; // (a launch that does not fill the chip: nothing to gain)
 		const int grid = WaveNetSpecResidentGrid(r.list.data(), (int)r.list.size(), WN_MAX_FRAMES);
 		if (grid < 1) return false;
@@ -157,12 +245,12 @@ namespace na
 		if (!r.configured) return false;
 		if (pipelineUsed)
 			for (PipeSlot& p : pipe) // (buffers submitted through the pipelined host interface run on per-slot streams: behind them as well)
-				if (p.own) CheckHip(hipStreamSynchronize(p.own), "hipStreamSynchronize");
+				if (p.own) WaitStreamBounded(p.own, "hipStreamSynchronize");
 		if (halfChainsUsed)
 		{
 			// an earlier buffer of another length ran as half-batch launches on the chain streams: the command comes behind them
 			for (hipStream_t hs : halfStream)
-				if (hs) CheckHip(hipStreamSynchronize(hs), "hipStreamSynchronize");
+				if (hs) WaitStreamBounded(hs, "hipStreamSynchronize");
 			halfChainsUsed = false;
 		}
 		if (r.exitRequested) DrainResident(); // a closing mark asked the launch to leave: this command starts the next generation
@@ -170,7 +258,15 @@ namespace na
 		{
 			const unsigned long long seq = r.posted + 1;
 			// back-pressure: a slot (and its done counter) is free once the command RESIDENT_RING before it has completed
-			while (seq - HostLoad(&r.status->completed) >= (unsigned long long)RESIDENT_RING - 1) ResidentEnsureRunning();
+			if (seq - HostLoad(&r.status->completed) >= (unsigned long long)RESIDENT_RING - 1)
+			{
+				const Deadline deadline(waitLimitMs);
+				while (seq - HostLoad(&r.status->completed) >= (unsigned long long)RESIDENT_RING - 1)
+				{
+					ResidentEnsureRunning();
+					if (deadline.Expired()) Stall("resident launch: no free command slot");
+				}
+			}
 			// (write-only on this side: the block may be device memory behind the BAR)
 			ResidentCmd& c = r.ctrl->cmd[seq % RESIDENT_RING];
 			c.in = dIn + offset;
@@ -189,6 +285,7 @@ namespace na
 
 	void GpuBatch::SetResidentLaunch(bool on)
 	{
+		CheckUsable();
 		if (!on) DrainResident();
 		residentWanted = on;
 	}
@@ -201,11 +298,13 @@ namespace na
 		if (!r.launched && r.posted == r.base) return;
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		HostStore(&r.ctrl->exitAfter, r.posted);
+		const Deadline deadline(waitLimitMs);
 		for (;;)
 		{
-			if (r.launched) CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize (resident launch)");
+			if (r.launched) WaitStreamBounded(stream, "resident launch: leaving the chip");
 			r.launched = false;
 			if (HostLoad(&r.status->completed) >= r.posted) break;
+			if (deadline.Expired()) Stall("resident launch: posted commands not completed");
 			ResidentEnsureRunning(); // (it idled out, or left at an earlier exit mark, before it saw the last commands: once more)
 		}
 		HostStore(&r.ctrl->exitAfter, kNever);
@@ -216,18 +315,24 @@ namespace na
 
 	void GpuBatch::WaitOutputs()
 	{
+		CheckUsable();
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		if (residentState && (residentState->launched || residentState->posted != residentState->base))
 		{
 			// (the launch stays up: only its done count is awaited -- and it goes in again should it have idled out early)
 			ResidentState& r = *residentState;
-			while (HostLoad(&r.status->completed) < r.posted) ResidentEnsureRunning();
+			const Deadline deadline(waitLimitMs);
+			while (HostLoad(&r.status->completed) < r.posted)
+			{
+				ResidentEnsureRunning();
+				if (deadline.Expired()) Stall("resident launch: waiting for the outputs");
+			}
 			return;
 		}
 		if (halfChainsUsed)
 			for (hipStream_t hs : halfStream)
-				if (hs) CheckHip(hipStreamSynchronize(hs), "hipStreamSynchronize");
-		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+				if (hs) WaitStreamBounded(hs, "hipStreamSynchronize");
+		WaitStreamBounded(stream, "hipStreamSynchronize");
 	}
 
 	// closing timing mark: the launch leaves behind the last posted command, without waiting for it
@@ -245,9 +350,10 @@ namespace na
 	// the ONE helper behind every entry point that touches stream state, index lists or device allocations
 	void GpuBatch::Quiesce()
 	{
+		CheckUsable();
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		DrainPipeline(); // (resident launch, pipeline slots, half-batch chains)
-		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		WaitStreamBounded(stream, "hipStreamSynchronize");
 	}
 
 	void GpuBatch::JoinHalves()
@@ -255,7 +361,7 @@ namespace na
 		DrainResident();
 		if (!halfChainsUsed) return;
 		for (hipStream_t hs : halfStream)
-			if (hs) CheckHip(hipStreamSynchronize(hs), "hipStreamSynchronize");
+			if (hs) WaitStreamBounded(hs, "hipStreamSynchronize");
 		halfChainsUsed = false;
 	}
 
@@ -326,7 +432,7 @@ namespace na
 		{
 			// whatever the batch stream (state resets, prewarms of new streams, index lists) or a slot stream still has in flight comes first
 			DrainPipeline();
-			CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+			WaitStreamBounded(stream, "hipStreamSynchronize");
 			submitTopology = topologyVersion;
 		}
 		for (int h = 0; h < numChains; h++)
@@ -384,6 +490,7 @@ namespace na
 
 	void GpuBatch::MarkTime(int which)
 	{
+		CheckUsable();
 		if (which < 0 || which > 1) throw std::runtime_error("neuralaudio_amd: MarkTime(0 | 1)");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		// (a chain stream that does not exist yet is created by the first launch that needs it -- 13 ms, not inside a timed window if
@@ -405,10 +512,11 @@ namespace na
 	// polls the closing marks (a benchmark's closing wait should not pay the wake-up latency of a blocking synchronisation)
 	void GpuBatch::WaitMarks()
 	{
+		CheckUsable();
 		CheckHip(hipSetDevice(device), "hipSetDevice");
+		// (polled from the first turn on: WaitEventBounded)
 		for (int i = 0; i <= kMaxChains; i++)
-			if (marks[i][0] && marks[i][1])
-				while (hipEventQuery(marks[i][1]) == hipErrorNotReady) {}
+			if (marks[i][0] && marks[i][1]) WaitEventBounded(marks[i][1], "closing timing mark");
 		ResidentFinishMarked();
 	}
 
@@ -418,16 +526,19 @@ namespace na
 	{
 		if (!residentState || !residentState->exitRequested) return;
 		ResidentState& r = *residentState;
+		const Deadline deadline(waitLimitMs);
 		while (HostLoad(&r.status->completed) < r.markPosted)
 		{
+			if (deadline.Expired()) Stall("resident launch: marked commands not completed");
 			ResidentEnsureRunning();
 			if (marks[0][1]) CheckHip(hipEventRecord(marks[0][1], stream), "hipEventRecord");
-			while (hipEventQuery(r.gen) == hipErrorNotReady) {}
+			WaitEventBounded(r.gen, "resident launch: leaving the chip");
 		}
 	}
 
 	float GpuBatch::ElapsedMs()
 	{
+		CheckUsable();
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		WaitMarks();
 		float longest = 0.0f;
@@ -435,8 +546,7 @@ namespace na
 		{
 			if (!marks[i][0] || !marks[i][1]) continue;
 			// (polled: a benchmark's closing wait should not pay the wake-up latency of a blocking synchronisation -- ~25 us of a 20-step run)
-			while (hipEventQuery(marks[i][1]) == hipErrorNotReady) {}
-			CheckHip(hipEventSynchronize(marks[i][1]), "hipEventSynchronize");
+			WaitEventBounded(marks[i][1], "closing timing mark");
 			float ms = 0.0f;
 			CheckHip(hipEventElapsedTime(&ms, marks[i][0], marks[i][1]), "hipEventElapsedTime");
 			longest = std::max(longest, ms);

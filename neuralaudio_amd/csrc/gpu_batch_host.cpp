@@ -12,9 +12,9 @@ namespace na
 	{
 		DrainResident();
 		for (PipeSlot& p : pipe)
-			if (p.own) CheckHip(hipStreamSynchronize(p.own), "hipStreamSynchronize");
+			if (p.own) WaitStreamBounded(p.own, "hipStreamSynchronize");
 		for (hipStream_t hs : halfStream)
-			if (hs) CheckHip(hipStreamSynchronize(hs), "hipStreamSynchronize");
+			if (hs) WaitStreamBounded(hs, "hipStreamSynchronize");
 		halfChainsUsed = false; // (the next half-batch launches wait for the batch stream first: LaunchHalves)
 	}
 
@@ -97,6 +97,7 @@ namespace na
 	// event costs more than it hides -- 1024 x 128 frames: 114 us per call as one piece, 134 / 186 / 282 us in 2 / 4 / 8 chunks.)
 	void GpuBatch::ProcessHost(const float* in, float* out, size_t n)
 	{
+		CheckUsable();
 		if (n == 0 || streams.empty()) return;
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		const size_t total = streams.size() * n;
@@ -108,7 +109,7 @@ namespace na
 			if (dIn && dOut)
 			{
 				ProcessDeviceOrdered(dIn, dOut, n, (long)n, (long)n);
-				CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+				WaitStreamBounded(stream, "hipStreamSynchronize");
 				ZeroRetiredRows(out, n, streams.size());
 				return;
 			}
@@ -130,7 +131,7 @@ namespace na
 			}
 			for (int h = 0; h < numChains; h++)
 			{
-				CheckHip(hipStreamSynchronize(halfStream[h]), "hipStreamSynchronize");
+				WaitStreamBounded(halfStream[h], "hipStreamSynchronize");
 				for (const WnFrameGroup& g : halfLists->part[h])
 					memcpy(out + (size_t)g.row0 * n, hostStage + (size_t)g.row0 * n, (size_t)g.numStreams * n * sizeof(float));
 			}
@@ -149,18 +150,19 @@ namespace na
 			CheckHip(hipMemcpyAsync(hostStage, devStage, total * sizeof(float), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H");
 		}
 		JoinHalves();
-		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		WaitStreamBounded(stream, "hipStreamSynchronize");
 		memcpy(out, hostStage, total * sizeof(float));
 		ZeroRetiredRows(out, n, streams.size());
 	}
 
 	void GpuBatch::ProcessHostToDevice(const float* in, float* dOut, size_t n, long outStride)
 	{
+		CheckUsable();
 		if (n == 0 || streams.empty()) return;
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		const size_t total = streams.size() * n;
 		// the previous call's kernels may still be reading the pinned block
-		CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		WaitStreamBounded(stream, "hipStreamSynchronize");
 		EnsureStaging(total);
 		memcpy(hostStage, in, total * sizeof(float));
 		float* dStage = nullptr;
@@ -198,6 +200,7 @@ namespace na
 
 	int GpuBatch::Submit(const float* in, size_t n)
 	{
+		CheckUsable();
 		if (n == 0 || streams.empty()) throw std::runtime_error("neuralaudio_amd: Submit on an empty batch / buffer");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		const int ticket = nextSlot;
@@ -306,14 +309,15 @@ namespace na
 
 	void GpuBatch::Collect(int ticket, float* out)
 	{
+		CheckUsable();
 		if (ticket < 0 || ticket >= kPipelineSlots || !pipe[ticket].busy) throw std::runtime_error("neuralaudio_amd: Collect with an invalid ticket");
 		PipeSlot& p = pipe[ticket];
 		if (p.onHalfStreams)
 		{
-			for (int h = 0; h < numChains; h++) CheckHip(hipEventSynchronize(p.halfDone[h]), "hipEventSynchronize");
+			for (int h = 0; h < numChains; h++) WaitEventBounded(p.halfDone[h], "hipEventSynchronize");
 		}
-		else if (p.onOwnStream) CheckHip(hipStreamSynchronize(p.own), "hipStreamSynchronize"); // the download is the stream's last operation
-		else CheckHip(hipEventSynchronize(p.downloaded), "hipEventSynchronize");
+		else if (p.onOwnStream) WaitStreamBounded(p.own, "hipStreamSynchronize"); // the download is the stream's last operation
+		else WaitEventBounded(p.downloaded, "hipEventSynchronize");
 		// the slot holds the rows the batch had at Submit: ids retired since then are zeroed only inside that block
 		if (!retired.empty()) ZeroRetiredRows(p.hostOut, p.n, p.rows);
 		if (out) memcpy(out, p.hostOut, p.rows * p.n * sizeof(float)); // nullptr: the caller reads OutputView() in place
@@ -322,6 +326,7 @@ namespace na
 
 	float* GpuBatch::NextInput(size_t n)
 	{
+		CheckUsable();
 		if (n == 0 || streams.empty()) throw std::runtime_error("neuralaudio_amd: NextInput on an empty batch / buffer");
 		CheckHip(hipSetDevice(device), "hipSetDevice");
 		PipeSlot& p = pipe[nextSlot];

@@ -313,7 +313,7 @@ namespace na
 			const rccl::Result closed = nccl->GroupEnd(); // always: the peers' transfers of this group must not be left waiting
 			if (!failed.empty()) throw std::runtime_error(failed);
 			CheckNccl(nccl, closed, "ncclGroupEnd");
-			CheckHip(hipStreamSynchronize(st), "hipStreamSynchronize");
+			s.batch->WaitStreamBounded(st, "hipStreamSynchronize");
 			s.batch->WeightsArrived();
 		});
 	}
@@ -359,7 +359,7 @@ namespace na
 			if (!failed.empty()) throw std::runtime_error(failed);
 			CheckNccl(nccl, closed, "ncclGroupEnd");
 			if (s.rank == 0) CheckHip(hipMemcpyAsync(out, s.gathered, totalFloats * sizeof(float), hipMemcpyDeviceToHost, st), "hipMemcpyAsync D2H");
-			CheckHip(hipStreamSynchronize(st), "hipStreamSynchronize");
+			s.batch->WaitStreamBounded(st, "hipStreamSynchronize");
 		});
 		}
 		catch (const std::exception& e)

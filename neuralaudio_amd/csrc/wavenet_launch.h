@@ -47,6 +47,8 @@ namespace na
 	constexpr size_t WN_BEYOND_CACHE_BYTES = (size_t)400 << 20;
 	hipError_t LaunchWaveNetSpecFused(const WnFrameGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
 		hipStream_t stream, int sharing = 1);
+	// test hook (GpuBatch::DebugStallDevice): one wave that keeps `stream` busy for `ms` milliseconds (s_memrealtime, 100 MHz)
+	hipError_t LaunchStallKernel(double ms, hipStream_t stream);
 	// ---- table launches of the specialised chains (wavenet_spec_impl.h WaveNetSpecTableKernel): any number of model groups in one launch --
 	// The device copies of a launch list's group tables, owned by the batch (one WnLaunchTable per launch list); see LaunchWaveNetSpecTable.
 	// An entry is IMMUTABLE once uploaded -- a table with other contents (another block length, other members) gets its own device

@@ -175,4 +175,17 @@ namespace na
 			reinterpret_cast<f32x4*>(state), stateF4, slots, ringOffF4, ringFrames, ringG, cols, splitFormat ? 1 : 0, sub, pack, zero ? 1 : 0);
 		return hipGetLastError();
 	}
+
+	// ---- test hook: a stream that does not answer (GpuBatch::DebugStallDevice) ----
+	__global__ void __launch_bounds__(64) StallKernel(unsigned long long ticks)
+	{
+		const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+		while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+	}
+
+	hipError_t LaunchStallKernel(double ms, hipStream_t stream)
+	{
+		hipLaunchKernelGGL(StallKernel, dim3(1), dim3(64), 0, stream, (unsigned long long)(ms * 1.0e5));
+		return hipGetLastError();
+	}
 }
