@@ -686,7 +686,7 @@ def main():
             # PCIe-inclusive throughput (SURVEY 8d metric 1): host buffers in, host buffers out, through the pipelined entry points
             # (NA_BatchSubmit / NA_BatchCollect: upload of buffer k+1 and download of k-1 overlap the kernels of k), driven by a plain C++
             # host (tools/HostPipeBench: a Python loop around 48 us kernels measures the interpreter).  Never `value`.
-            hp = os.path.join(ROOT, "neuralaudio_amd", "HostPipeBench")
+            hp = os.path.join(ROOT, "tools", "bin", "HostPipeBench")
             model_path = os.path.join(mdir, files[0]) if args.workload in ("standard", "feather", "nano", "a2full", "lstm1x16", "lstm2x8") else None
             if os.path.exists(hp) and model_path is not None:
                 torch.cuda.synchronize(dev)

@@ -203,6 +203,10 @@ NA_EXTERN float NA_BatchStreamInputLimit(NA_Batch* batch, int stream);
  * (the stream recovers one receptive field later).  Always 0 for proven models and the f32 kernels.  Synchronises the batch stream: a
  * diagnostic, not for the audio path.  Negative on a bad argument. */
 NA_EXTERN int NA_BatchStreamRangeEvents(NA_Batch* batch, int stream);
+#ifndef NA_RELEASE
+/* ---- test / tuning hooks: exported by the test build only (csrc/Makefile default target; what tests/ loads).  The release library
+ * (make RELEASE=1 -> dist/libNeuralAudioCAPI.so: -DNA_RELEASE -DNA_NO_TUNING, no loopback RCCL table) has none of the NA_Debug* symbols
+ * and reads no tuning environment variable. ---- */
 /* NAMIsA2 (bit 0) / NAMIsA2Standard (bit 1) of a .nam document (NeuralModel.cpp:159-168, 188-317); negative on a parse error */
 NA_EXTERN int NA_DebugClassifyNam(const char* jsonText);
 /* stream packing, host side only: pack factor of the model in a large batch (1: none); flat weights of the packed virtual model into
@@ -226,6 +230,7 @@ NA_EXTERN void NA_DebugSetRcclApi(int mode, int failSendAt, int rendezvousMs);
 NA_EXTERN int NA_DebugStallDevice(NA_Batch* batch, double milliseconds);
 /* tuning aid: device buffer (long long[stages*4*waves]) that workgroup 0 of the WaveNet kernel stamps with the shader clock; NULL = off */
 NA_EXTERN void NA_DebugSetTraceBuffer(void* deviceBuffer);
+#endif /* NA_RELEASE */
 
 #ifdef __cplusplus
 }

@@ -261,6 +261,7 @@ int NA_IsQualityChangeRealtimeSafe(NeuralModel* model, float newQuality)
 }
 
 // bit 0: NAMIsA2(version), bit 1: NAMIsA2Standard(model) -- the reference's engine-selection predicates, exposed for tests
+#ifndef NA_RELEASE
 int NA_DebugClassifyNam(const char* jsonText)
 {
 	int r = -1;
@@ -271,9 +272,11 @@ int NA_DebugClassifyNam(const char* jsonText)
 	});
 	return r;
 }
+#endif
 
 // Stream packing, host side only (no GPU needed; tests): the pack factor the model would run with in a large batch (1: none) and, when
 // `out` is given, the flat weights of the packed virtual model (wavenet_plan.cpp PackWaveNetDesc); returns their count, -1 on failure.
+#ifndef NA_RELEASE
 int NA_DebugPackedWeights(NeuralModel* model, int* packFactor, float* out, int capacity)
 {
 	int r = -1;
@@ -306,6 +309,7 @@ int NA_DebugPackedWeights(NeuralModel* model, int* packFactor, float* out, int c
 	});
 	return r;
 }
+#endif
 
 void NA_SetDevice(NeuralModelLoader* loader, int device)
 {
@@ -501,11 +505,13 @@ double NA_BatchGetWaitLimitMs(NA_Batch* batch) { return batch ? batch->batch->Ge
 
 int NA_BatchIsBroken(NA_Batch* batch) { return (batch && batch->batch->IsBroken()) ? 1 : 0; }
 
+#ifndef NA_RELEASE
 int NA_DebugStallDevice(NA_Batch* batch, double milliseconds)
 {
 	if (!batch) return -1;
 	return Guard([&] { batch->batch->DebugStallDevice(milliseconds); });
 }
+#endif
 
 void* NA_BatchGetHipStream(NA_Batch* batch) { return batch ? reinterpret_cast<void*>(batch->batch->GetStream()) : nullptr; }
 
@@ -710,11 +716,13 @@ int NA_RcclAvailable(void)
 	return ok;
 }
 
+#ifndef NA_RELEASE
 void NA_DebugSetRcclApi(int mode, int failSendAt, int rendezvousMs)
 {
 	na::rccl::LoopbackConfigure(failSendAt, rendezvousMs);
 	na::rccl::SetOverride(mode == 1 ? na::rccl::LoopbackApi() : nullptr);
 }
+#endif
 
 int NA_MultiSetQuality(NA_MultiBatch* mb, int stream, float quality)
 {
@@ -722,13 +730,21 @@ int NA_MultiSetQuality(NA_MultiBatch* mb, int stream, float quality)
 	return Guard([&] { mb->multi->SetQuality(stream, quality); });
 }
 
+#ifndef NA_RELEASE
 void NA_DebugSetWaveNetSpec(int on) { na::SetWaveNetSpecEnabled(on != 0); }
+#endif
 
+#ifndef NA_RELEASE
 int NA_DebugSetRecurrentQuadMin(int streams) { return na::SetRecurrentQuadMinStreams(streams); }
+#endif
 
+#ifndef NA_RELEASE
 long long NA_DebugRecurrentQuadLaunches(void) { return (long long)na::RecurrentQuadLaunches(); }
+#endif
 
+#ifndef NA_RELEASE
 void NA_DebugSetTraceBuffer(void* deviceBuffer) { na::SetWaveNetTraceBuffer(reinterpret_cast<long long*>(deviceBuffer)); }
+#endif
 
 double NA_BatchStateBytes(NA_Batch* batch) { return batch ? (double)batch->batch->StateBytes() : 0.0; }
 

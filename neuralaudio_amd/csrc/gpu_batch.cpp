@@ -227,6 +227,7 @@ namespace na
 		// members it created are removed again, the ids go back to `retired` (rows appended by AllocateIds leave the arrays).
 		int built = 0; // rows [first, first + built) are complete StreamRefs
 		std::vector<std::pair<ModelGroup*, int>> partial; // members of the row under construction
+		const size_t pendingBefore = pendingPrewarm.size(); // (deferred prewarms this call files: dropped again if it fails)
 		try
 		{
 			for (int i = 0; i < count; i++)
@@ -267,6 +268,7 @@ namespace na
 		}
 		catch (...)
 		{
+			pendingPrewarm.resize(pendingBefore); // (WeightsArrived must not prewarm member slots that are gone or recycled)
 			for (auto& gm : partial) gm.first->RemoveMember(gm.second);
 			for (int i = 0; i < count; i++)
 			{

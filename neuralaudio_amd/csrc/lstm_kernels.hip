@@ -628,7 +628,8 @@ namespace na
 	bool LaunchRecurrentWaveRt(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err)
 	{
-		const bool off = Tuning::Get().lstmNoWaveRt; // tuning knob / tests: the lane = stream kernels for every shape
+		// tuning knob / tests: the lane = stream kernels for every shape -- except tails with conv1d layers, which only this kernel evaluates
+		const bool off = Tuning::Get().lstmNoWaveRt && !(m.tailLayers > 0 && m.tailHistMax > 0);
 		if (off || m.hidden > RECURRENT_WAVE_MAX_HIDDEN || m.numLayers < 0 || (m.numLayers == 0 && m.tailLayers == 0)) return false;
 		size_t ldsBytes = RecurrentWaveRtLdsFloats(m) * sizeof(float);
 		// weights larger than the LDS (LSTM 2x64: 197 KB): streamed from L2, transposed for coalesced reads (NA_REC_L2W=1 forces the mode)
@@ -795,7 +796,7 @@ namespace na
 		if (numStreams <= 0 || n <= 0) return hipSuccess;
 		if (n > LSTM_MAX_FRAMES) return hipErrorInvalidValue;
 		{
-			const bool forceLaneKernel = Tuning::Get().lstmLaneKernel; // tuning knob
+			const bool forceLaneKernel = Tuning::Get().lstmLaneKernel && !(m.tailLayers > 0 && m.tailHistMax > 0); // tuning knob (conv1d tails: the wave kernel only)
 			hipError_t err = hipSuccess;
 			if (!forceLaneKernel && m.tailLayers == 0 && LaunchLstmWave(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;
 			if (!forceLaneKernel && LaunchRecurrentWaveRt(m, state, capacity, slots, rows, numStreams, in, out, inStride, outStride, n, stream, err)) return err;

@@ -1325,13 +1325,15 @@ hn[sn] = Mfma(WOp<C>(cx, s, 0, 4 * u), hs[so], hn[sn]);
 						unsigned long long cSeq = word(&cmd->seq), cChk = word(&cmd->check);
 						if (finished)
 						{
-							const unsigned before = __hip_atomic_fetch_add(&r.doneCount[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							// release: this workgroup's output rows (every wave's stores are out -- the closing wait + barrier) are ordered before
+							// the count; acquire: the last arriver has every other workgroup's rows behind it when it publishes `completed`
+							const unsigned before = __hip_atomic_fetch_add(&r.doneCount[slot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 							if (before == gridDim.x - 1)
 							{
 								// the last workgroup of command k: the slot's counter is free again (the host does not reuse the slot before it
 								// has seen `completed`), and the host may read the output rows
 								__hip_atomic_store(&r.doneCount[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-								__hip_atomic_store(&r.status->completed, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+								__hip_atomic_store(&r.status->completed, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // (the host loads it with acquire)
 							}
 						}
 						const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();

@@ -11,7 +11,7 @@ import na_oracle as O
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "neuralaudio_amd", "ModelTest")
+EXE = os.path.join(ROOT, "tools", "bin", "ModelTest")
 
 
 @pytest.fixture(scope="module")

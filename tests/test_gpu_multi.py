@@ -59,7 +59,7 @@ def test_sharded_host_matches_one_batch_with_the_same_global_list(na, shards):
 
 
 def test_hostpipebench_multi_gpu_mode_two_threads_on_one_gpu():
-    exe = os.path.join(ROOT, "neuralaudio_amd", "HostPipeBench")
+    exe = os.path.join(ROOT, "tools", "bin", "HostPipeBench")
     r = subprocess.run([exe, _path("BossWN-standard.nam"), "512", "128", "200", "--devices", "0,0", "--mix", _path("BossLSTM-1x16.nam")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -222,8 +222,6 @@ def test_generic_keras_stack_matches_numpy_restatement(na, loader, spec):
     import ref_np as R
     if (os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_LSTM_LANE_KERNEL")) and max(l[1] for l in spec if l[0] != "lstm" and l[0] != "gru") > 64:
         pytest.skip("dense layers wider than 64 units are beyond the lane = stream kernels' LDS bound")
-    if (os.environ.get("NA_LSTM_NO_WAVE_RT") or os.environ.get("NA_LSTM_LANE_KERNEL")) and any(l[0] == "conv1d" for l in spec):
-        pytest.skip("conv1d layers run on the runtime-shaped wave kernel only")
     mj = R.synth_keras_stack(spec, seed=40 + len(spec))
     m = loader.CreateFromString(json.dumps(mj), ".json")
     assert m is not None

@@ -179,12 +179,34 @@ def test_rccl_is_bound_at_run_time_and_the_library_does_not_link_it(na):
 def test_modeltest_host_builds_and_reports_a_missing_gpu(na):
     """tools/ModelTest (the reference's Utils/ModelTest counterpart) is a C++ host of the exported API; without a device it must say so."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "tools", "ModelTest")], check=True, capture_output=True)
-    exe = os.path.join(ROOT, "neuralaudio_amd", "ModelTest")
+    exe = os.path.join(ROOT, "tools", "bin", "ModelTest")
     assert subprocess.run([exe, "--bogus"], capture_output=True).returncode == 1
     if na.device_count() > 0:
         pytest.skip("a GPU is present: tests/test_gpu_modeltest.py runs it for real")
     r = subprocess.run([exe, "-b", "128", os.path.join(O.MODELS_DIR, "BossLSTM-1x16.nam")], capture_output=True, text=True)
     assert r.returncode == 2 and "no HIP device" in r.stdout and "Block size: 128  Quality Scale: 1" in r.stdout
+
+
+def test_release_library_exports_the_documented_surface_and_nothing_else(na):
+    """make release -> dist/libNeuralAudioCAPI.so (-DNA_RELEASE -DNA_NO_TUNING, no loopback RCCL table): its dynamic symbol table is the 15
+    legacy symbols of the reference's NeuralAudioCApi.h:18-46 plus the NA_* set include/neuralaudio_amd.h declares outside its
+    `#ifndef NA_RELEASE` block -- no NA_Debug* hook, no loopback table, no tuning environment reader."""
+    import re
+    from neuralaudio_amd import capi
+    subprocess.run(["make", "-C", os.path.join(ROOT, "neuralaudio_amd", "csrc"), "-j8", "release"], check=True, capture_output=True)
+    lib = os.path.join(ROOT, "dist", "libNeuralAudioCAPI.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], check=True, capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "TWBDRV" and not l.split()[-1].startswith("_")}
+    header = open(os.path.join(ROOT, "include", "neuralaudio_amd.h")).read()
+    public, hooks = header.split("#ifndef NA_RELEASE")[0], header.split("#ifndef NA_RELEASE")[1].split("#endif /* NA_RELEASE */")[0]
+    declared = set(re.findall(r"NA_EXTERN[^;(]*?\b(NA_[A-Za-z0-9]+)\(", public))
+    debug = set(re.findall(r"NA_EXTERN[^;(]*?\b(NA_[A-Za-z0-9]+)\(", hooks))
+    assert debug and all(n.startswith("NA_Debug") for n in debug)
+    assert set(capi.NA_SYMBOLS) == declared | debug  # (the Python binding list and the header agree)
+    assert exported == set(capi.LEGACY_SYMBOLS) | declared, (sorted(exported - set(capi.LEGACY_SYMBOLS) - declared), sorted((set(capi.LEGACY_SYMBOLS) | declared) - exported))
+    data = open(lib, "rb").read()
+    assert b"NA_WN_KERNEL" not in data and b"NA_LSTM_LANE_KERNEL" not in data  # no tuning knob is read
+    assert b"gfx950" in data and b"WaveNetSpecKernel" in data
 
 
 def test_library_embeds_gfx950_code_object(na):
