@@ -57,6 +57,9 @@ def usable_cores():
 
 PORT_NOTE = ("kind 'port' = oracle/na_oracle.c, a scalar C restatement built -O3 -march=native: it has none of the reference's Eigen "
              "vectorisation / MULTIFRAME_8X8 conv tiling, so it understates the reference's CPU path")
+SIMD_NOTE = ("kind 'port' = oracle/na_oracle_simd.c built -O3 -march=native: the oracle's WaveNet path with frames as the vector axis and "
+             "8-frame x 8-channel register tiles (the idea of the reference's MULTIFRAME_8X8_CONVOLUTION, WaveNet.h:144-239, without Eigen), "
+             "validated <= 1e-6 RMS against the scalar restatement (tests/test_oracle.py); `scalar` beside it is oracle/na_oracle.c")
 
 
 def _timed_cpu_run(run, label, seconds_target):
@@ -139,7 +142,17 @@ def cpu_baseline(workload="standard", seconds_target=12.0):
 
         def run(blocks, threads):
             return lib.na_oracle_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, blocks, threads)
-    return _timed_cpu_run(run, files[workload], seconds_target)
+    scalar = _timed_cpu_run(run, files[workload], seconds_target if j["architecture"] == "LSTM" else seconds_target / 2)
+    if j["architecture"] == "LSTM" or BLOCK % 8 != 0 or not hasattr(lib, "na_oracle_simd_wavenet_bench"):
+        return scalar
+    # WaveNets: the vectorised variant is the headline CPU figure (the fairer stand-in for the reference's Eigen path), the scalar port rides along
+    def run_simd(blocks, threads):
+        return lib.na_oracle_simd_wavenet_bench(len(arrays), cfgs, wp, w.size, BLOCK, blocks, threads)
+    simd = _timed_cpu_run(run_simd, files[workload], seconds_target / 2)
+    simd["sample"] = simd["sample"].replace(PORT_NOTE, SIMD_NOTE)
+    simd["port_simd"] = {"value": simd["value"], "unit": simd["unit"], "cores": simd["cores"]}
+    simd["port_scalar"] = {"value": scalar["value"], "unit": scalar["unit"], "cores": scalar["cores"], "sample": scalar["sample"]}
+    return simd
 
 
 def synthetic_lite_nam():
@@ -309,7 +322,7 @@ def spawn_ranks(n):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and "--share-device" not in sys.argv:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n, have))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -348,6 +361,11 @@ def main():
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the same-box run of the exact-f32 kernel (NA_WN_KERNEL=frame) that is reported beside `dtype`")
     ap.add_argument("--ramp-ms", type=float, default=400.0, help="untimed sustained load before warm-up so the shader clock reaches steady state")
+    ap.add_argument("--share-device", action="store_true",
+                    help="REHEARSAL of the multi-rank path on a box with one GPU: the N ranks of --gpus N all use device 0 and rendezvous over "
+                         "gloo (RCCL refuses two ranks on one device).  Everything else is the N-GPU path: spawn_ranks, the rank-count check, "
+                         "cost sharding of the mixed workloads, barrier + max-over-ranks, the rank-0 line.  The numbers say nothing about scaling "
+                         "(the ranks share one chip) and the line says so: \"share_device\": true.")
     ap.add_argument("--workload", default="standard",
                     help="standard (default = the BASELINE metric's config) | lite | feather | nano | a2full | a2lite | lstm1x16 | lstm2x8 | "
                          "config3 (Lite+Feather+Nano, 4096 streams) | config4 (LSTM 2x16 + GRU) | config5 (A2 quality sweep, 2048 streams) "
@@ -368,16 +386,19 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.share_device:
+        local_rank = 0  # every rank on device 0 (rehearsal of the multi-rank path on a one-GPU box)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    reduce_dev = "cpu" if args.share_device else dev  # where the timing all-reduce lives: gloo has no device tensors
     import neuralaudio_amd as na
     from neuralaudio_amd import dist as nd
 
     rccl_ranks = 1
     if distributed:
-        nd.init(backend="nccl", device=dev)  # nccl == RCCL on ROCm; one rank per GPU
+        nd.init(backend="gloo" if args.share_device else "nccl", device=dev)  # nccl == RCCL on ROCm; one rank per GPU
         import torch.distributed as tdist
-        ones = torch.ones(1, device=dev)
+        ones = torch.ones(1, device=reduce_dev)
         tdist.all_reduce(ones)  # every rank adds 1 over RCCL: proves N ranks on N GPUs are really in the job
         rccl_ranks = int(ones.item())
         if rccl_ranks != world or world != args.gpus:
@@ -511,7 +532,7 @@ def main():
     if world > 1:
         nd.barrier()
         torch.cuda.synchronize(dev)
-    elapsed = nd.max_over_ranks(time.perf_counter() - t0, device=dev)
+    elapsed = nd.max_over_ranks(time.perf_counter() - t0, device=reduce_dev)
     marks_ms = batch.ElapsedMs()
     batch.Synchronize()  # (outside the timed region: the batch's own bookkeeping of its chains)
     kernel_ms_avg = marks_ms / args.steps  # per STEP (one or two launches)
@@ -586,6 +607,8 @@ def main():
             "unit": "Msamples/s",
             "n_gpus": world,
             "rccl_ranks": rccl_ranks,
+            **({"share_device": True, "share_device_note": "rehearsal: %d ranks on ONE device over gloo -- exercises the multi-rank code path; "
+                "not a scaling measurement" % world} if args.share_device else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

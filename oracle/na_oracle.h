@@ -122,6 +122,17 @@ double na_oracle_lstm_bench(int num_layers, int hidden_size, const float* weight
 double na_oracle_gru_bench(int num_layers, int hidden_size, const float* const* kernels, const float* const* recurrents,
 	const float* const* biases, const float* head_weights, float head_bias, int block_size, int num_blocks, int threads);
 
+/* ---- na_oracle_simd.c: a vectorised variant of the WaveNet path (frames as the vector axis, 8-frame x 8-channel register tiles --
+ * the idea of the reference's MULTIFRAME_8X8_CONVOLUTION, WaveNet.h:144-239), for bench.py's cpu_baseline leg only.  Validated against
+ * the scalar restatement above (tests/test_oracle.py); it is NOT the parity checker.  condition_size == 1; num_samples a multiple of
+ * 8 (process returns -1 otherwise); FastMath; a created model is prewarmed. */
+typedef struct na_oracle_simd_wavenet na_oracle_simd_wavenet;
+na_oracle_simd_wavenet* na_oracle_simd_wavenet_create(int num_arrays, const na_oracle_wn_array_cfg* cfgs, const float* weights, size_t num_weights);
+void na_oracle_simd_wavenet_free(na_oracle_simd_wavenet* m);
+int na_oracle_simd_wavenet_process(na_oracle_simd_wavenet* m, const float* in, float* out, size_t num_samples);
+double na_oracle_simd_wavenet_bench(int num_arrays, const na_oracle_wn_array_cfg* cfgs, const float* weights, size_t num_weights,
+	int block_size, int num_blocks, int threads);
+
 #ifdef __cplusplus
 }
 #endif

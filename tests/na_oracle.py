@@ -81,6 +81,14 @@ def _bind(lib):
     lib.na_oracle_wavenet_bench.argtypes = [C.c_int, C.POINTER(WnArrayCfg), fp, C.c_size_t, C.c_int, C.c_int, C.c_int]
     lib.na_oracle_lstm_bench.restype = C.c_double
     lib.na_oracle_lstm_bench.argtypes = [C.c_int, C.c_int, fp, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    # na_oracle_simd.c: the vectorised bench-only variant of the WaveNet path
+    lib.na_oracle_simd_wavenet_create.restype = C.c_void_p
+    lib.na_oracle_simd_wavenet_create.argtypes = [C.c_int, C.POINTER(WnArrayCfg), fp, C.c_size_t]
+    lib.na_oracle_simd_wavenet_free.argtypes = [C.c_void_p]
+    lib.na_oracle_simd_wavenet_process.restype = C.c_int
+    lib.na_oracle_simd_wavenet_process.argtypes = [C.c_void_p, fp, fp, C.c_size_t]
+    lib.na_oracle_simd_wavenet_bench.restype = C.c_double
+    lib.na_oracle_simd_wavenet_bench.argtypes = [C.c_int, C.POINTER(WnArrayCfg), fp, C.c_size_t, C.c_int, C.c_int, C.c_int]
     return lib
 
 
@@ -225,6 +233,29 @@ class OracleWaveNet:
     def __del__(self):
         if getattr(self, "_h", None):
             lib().na_oracle_wavenet_free(self._h)
+            self._h = None
+
+
+class OracleWaveNetSimd:
+    """oracle/na_oracle_simd.c: the vectorised variant timed by bench.py's cpu_baseline leg (not the checker); always prewarmed."""
+    def __init__(self, arrays, weights, native=False):
+        self._lib = load_native_lib() if native else lib()
+        self.weights = np.ascontiguousarray(weights, dtype=np.float32)
+        self._cfgs = _cfgs(arrays)
+        self._h = self._lib.na_oracle_simd_wavenet_create(len(arrays), self._cfgs, _fptr(self.weights), self.weights.size)
+        if not self._h:
+            raise ValueError("Wrong number of weights")
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty_like(x)
+        if self._lib.na_oracle_simd_wavenet_process(self._h, _fptr(x), _fptr(y), x.size) != 0:
+            raise ValueError("the vectorised variant takes multiples of 8 samples")
+        return y
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.na_oracle_simd_wavenet_free(self._h)
             self._h = None
 
 

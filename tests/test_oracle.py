@@ -304,3 +304,21 @@ def test_generic_keras_stack_restatement_matches_committed_torch_vectors():
             j = json.load(f)
         y = R.keras_stack_forward(j, d["input"])
         assert O.rms(y - d[name]) < 1e-6, (name, O.rms(y - d[name]))
+
+
+@pytest.mark.parametrize("name,q", [("BossWN-standard.nam", 1.0), ("BossWN-feather.nam", 1.0), ("BossWN-nano.nam", 1.0), ("BossWN-a2.nam", 1.0), ("BossWN-a2.nam", 0.0)])
+def test_vectorised_bench_variant_matches_the_scalar_oracle(name, q):
+    """oracle/na_oracle_simd.c (frames as the vector axis, 8 x 8 register tiles: what bench.py's cpu_baseline times as `port_simd`) computes
+    what the scalar restatement computes -- same values, another summation order: <= 1e-6 RMS on every official WaveNet architecture,
+    sine and noise, from the prewarmed state."""
+    j = O.load_json(name)
+    if j["architecture"] == "SlimmableContainer":
+        j = j["config"]["submodels"][O.quality_to_submodel(j, q)]["model"]
+    arrays = O.wavenet_arrays_from_nam(j)
+    for x in (O.signal_sine(6400), O.signal_noise(6400, 11)):
+        ref = O.OracleWaveNet(arrays, j["weights"]).process(x)
+        got = O.OracleWaveNetSimd(arrays, j["weights"]).process(x)
+        assert O.rms(ref) > 1e-3 and O.rms(got - ref) < 1e-6, (name, q, O.rms(got - ref))
+    with pytest.raises(ValueError):
+        O.OracleWaveNetSimd(arrays, j["weights"]).process(np.zeros(13, np.float32))
+

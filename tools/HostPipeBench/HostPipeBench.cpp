@@ -1,7 +1,7 @@
 // HostPipeBench: PCIe-inclusive throughput of the batched engine from a plain C++ host, through the C ABI only
 // (include/neuralaudio_amd.h): host buffers in, host buffers out, pipelined with NA_BatchSubmit / NA_BatchCollect.
 //   HostPipeBench <model file> [streams=1024] [frames=128] [buffers=2000]
-//   HostPipeBench <model file> [streams] [frames] [buffers] --gpus N [--devices 0,0,...] [--fan-in rccl]
+//   HostPipeBench <model file> [streams] [frames] [buffers] --gpus N [--devices 0,0,...] [--fan-in rccl] [--loopback]
 //       the multi-GPU host (NA_Multi*: one batch + one host thread + one HIP stream per device, the global stream list sharded by
 //       cost): `streams` is the GLOBAL count; --devices names the device of every shard explicitly (an index may repeat, e.g. 0,0 runs
 //       two shards on one GPU -- the plumbing test on a single-GPU box).  A second model file may follow --mix: the global list is then
@@ -102,7 +102,7 @@ static int RunMulti(NeuralModelLoader* loader, NeuralModel* model, const char* m
 
 int main(int argc, char** argv)
 {
-	if (argc < 2) { std::fprintf(stderr, "usage: HostPipeBench <model> [streams] [frames] [buffers] [--gpus N] [--devices a,b,...] [--mix <model 2>] [--fan-in rccl]\n"); return 2; }
+	if (argc < 2) { std::fprintf(stderr, "usage: HostPipeBench <model> [streams] [frames] [buffers] [--gpus N] [--devices a,b,...] [--mix <model 2>] [--fan-in rccl] [--loopback]\n"); return 2; }
 	std::vector<const char*> pos;
 	std::vector<int> devices;
 	int gpus = 0;
@@ -113,6 +113,12 @@ int main(int argc, char** argv)
 		if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = std::atoi(argv[++i]);
 		else if (!std::strcmp(argv[i], "--fan-in") && i + 1 < argc) rcclFanIn = !std::strcmp(argv[++i], "rccl");
 		else if (!std::strcmp(argv[i], "--mix") && i + 1 < argc) mixFile = argv[++i];
+		else if (!std::strcmp(argv[i], "--loopback"))
+		{
+			// rehearsal on a one-GPU box: the multi-GPU host bound to the library's loopback RCCL table (test build only), so that
+			// `--devices 0,0 --fan-in rccl` runs the communicator set-up, the weight fan-out and the gathered fan-in with two ranks
+			NA_DebugSetRcclApi(1, 0, 0);
+		}
 		else if (!std::strcmp(argv[i], "--devices") && i + 1 < argc)
 		{
 			for (const char* p = argv[++i]; *p;)
