@@ -6,6 +6,7 @@
 //
 // Reference arithmetic: LSTMModelT/LSTMLayerT::Process (NeuralAudio/LSTM.h:164-191, 87-100), FastMath (Activation.h:83-96);
 // keras GRU = RTNeural's GRULayer (NeuralAudio/RTNeuralModel.h:300,417-421; third-party, parity unpinned -- see gru_kernels.hip).
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -152,7 +153,7 @@ namespace na
 	{
 		static_assert(H == 8 || H == 16, "a 16-lane DPP row must hold the units a whole number of times");
 		constexpr int HP = H + 1;
-		const int lane = threadIdx.x;
+		const int lane = (int)threadIdx.x & 63; // (the two-wave kernel runs these bodies on the waves of a 256-thread workgroup)
 		const int unit = lane % H;
 		const int gate = (lane / H) & 3;
 		// H is the lane layout (8 or 16 units per gate block); the model's hidden size hr may be smaller (12 on the 16 layout, 4 .. 7 on
@@ -288,7 +289,7 @@ namespace na
 		constexpr int H = 8, HP = H + 1;
 		constexpr int HREGION = (LSTM_MAX_FRAMES + 2) * HP; // per layer: the h before every tick and after the last
 		static_assert(2 * HREGION <= REC_HOUT_FLOATS, "");
-		const int lane = threadIdx.x;
+		const int lane = (int)threadIdx.x & 63; // (the two-wave kernel runs these bodies on the waves of a 256-thread workgroup)
 		const int unit = lane % H;
 		const int gate = (lane / H) & 3;
 		const int layer = lane >> 5; // 0: lanes 0..31, 1: lanes 32..63
@@ -373,6 +374,144 @@ namespace na
 		}
 	}
 
+	// H = 16 layout, two layers (LSTM 2x16 / 2x12: BASELINE config 4): TWO WAVES PER STREAM, one per layer, a few samples apart.
+	// A lone wave issues an instruction every ~5 cycles while its SIMD could take one every ~2 (tools/microbench: lone_wave_issue vs
+	// valu_rate_saturated), and a batch of <= 1024 streams is one wave per SIMD: half the VALU issue slots of the chip are idle and the
+	// step time is the dependent chain of ONE wave -- 3 dots + 2 cell updates per sample (LstmDppBodyM<16, 2>: 112 instructions, 37 us
+	// per 128-sample block).  The two layers of a stream depend on each other in ONE direction only (layer 1 of sample t needs h0(t),
+	// LSTM.h:170-180), so they run as a pipeline: wave 0 owns layer 0 and runs ahead freely, writing h0 of every sample into LDS and a
+	// progress word every four samples; wave 1 owns layer 1, follows a group behind and takes its input from there (four ds_reads per
+	// group, issued together).  Nobody waits for a round trip: the chain per sample is max(1 dot + 1 update, 2 dots + 1 update) = 63
+	// instructions instead of 112, on a chip that now carries two waves per SIMD.  Same lane layout, same weights, same order of
+	// floating-point operations as LstmDppBodyM<16, 2>: bit-identical results (tests/test_gpu_batch.py, NA_REC_NOPIPE=1 selects the
+	// one-wave body).  LDS: h0[n + 2][17] | h1[n + 2][17] | progress.
+	constexpr int REC_PIPE_HP = 17;
+	constexpr int REC_PIPE_REGION = (LSTM_MAX_FRAMES + 2) * REC_PIPE_HP;
+	constexpr int REC_PIPE_FLOATS = 2 * REC_PIPE_REGION + 16;
+
+	__device__ __forceinline__ bool RecurrentPipeGroup(const LstmModelDev& m)
+	{
+		return m.cell == LSTM_CELL_LSTM && m.numLayers == 2 && m.hidden > 8 && m.hidden <= 16 && m.tailLayers == 0;
+	}
+
+	template <bool STD>
+	__device__ __forceinline__ void LstmDppPipeBody(const LstmModelDev& m, float* __restrict__ state, int capacity, int slot, int row, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n, int layer, float* xin, float* lds)
+	{
+		// layer (wave-uniform): which of the stream's two waves this is; xin: the layer-0 wave's input samples; lds: the pair's region
+		constexpr int H = 16, HP = REC_PIPE_HP;
+		const int lane = (int)threadIdx.x & 63;
+		const int unit = lane % H;
+		const int gate = lane / H;
+		const int hr = m.hidden; // 9 .. 16: surplus units carry zero weights and zero state (see LstmDppBodyM)
+		const bool real = unit < hr;
+		const int r = gate * hr + unit;
+		auto col = [&](int k) { return (unit - k + H) % H; };
+		const float* inRow = in + (size_t)row * inStride;
+		float* outRow = out + (size_t)row * outStride;
+		const GateK<STD> K = MakeGateK<STD>(gate == 2);
+		const float gs = GateRowScale<STD>(gate == 2);
+		float* hb0 = lds;
+		float* hb1 = lds + REC_PIPE_REGION;
+		int* prog = reinterpret_cast<int*>(lds + 2 * REC_PIPE_REGION);
+
+		// layer 0: W row-major [4H][1 + H], bias[4H]; layer 1: W [4H][H + H] (input = layer-0 h, then own h), bias[4H] (LSTM.h:42-56).
+		// wa: the weights of the layer input's h part (layer 0: its own h), wb: layer 1's own h; rotated by `unit` for the DPP walk
+		const float* w0 = m.w + m.layerOff[0];
+		const float* w1 = m.w + m.layerOff[1];
+		const float wx = gs * LoadIf(w0, (size_t)r * (1 + hr), layer == 0 && real);
+		float wa[H], wb[H];
+#pragma unroll
+		for (int k = 0; k < H; k++)
+		{
+			const bool on = real && col(k) < hr;
+			wa[k] = gs * LoadIf(layer == 0 ? w0 : w1, layer == 0 ? (size_t)r * (1 + hr) + 1 + col(k) : (size_t)r * (2 * hr) + col(k), on);
+			wb[k] = gs * LoadIf(w1, (size_t)r * (2 * hr) + hr + col(k), layer == 1 && on);
+		}
+		const float b = gs * LoadIf(layer == 0 ? w0 : w1, layer == 0 ? (size_t)4 * hr * (1 + hr) + r : (size_t)4 * hr * (2 * hr) + r, real);
+		if (layer == 0)
+			for (int f = lane; f < n + 4; f += 64) xin[f] = f < n ? inRow[f] : 0.0f;
+		float h = LoadIf(state, (size_t)(layer * 2 * hr + unit) * capacity + slot, real);
+		float c = LoadIf(state, (size_t)(layer * 2 * hr + hr + unit) * capacity + slot, real);
+		if (layer == 0) __hip_atomic_store(prog, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__syncthreads(); // (all live waves of the workgroup: pairs whose stream does not exist have left and do not count)
+
+		if (layer == 0)
+		{
+			// entry t of hb0 = h0 BEFORE sample t (stored right after the first dot of sample t: see LstmDppBodyM), entry n = after the last
+			float* hw = hb0 + unit;
+			auto step = [&](float x, float* dst) {
+				float acc;
+				DppDotFrom<H>(acc, wx, x, b, wa, h); // LSTM.h:168 -- column 0 is the input sample
+				*dst = h;
+				h = DppCellUpdate<H, STD>(acc, K, c);
+			};
+			int f = 0;
+			for (; f + 4 <= n; f += 4)
+			{
+				const float4 xv = *reinterpret_cast<const float4*>(xin + f);
+				step(xv.x, hw + (f + 0) * HP);
+				step(xv.y, hw + (f + 1) * HP);
+				step(xv.z, hw + (f + 2) * HP);
+				step(xv.w, hw + (f + 3) * HP);
+				// entries 0 .. f + 3 are complete (LDS operations of a wave retire in order; the release orders the compiler)
+				__hip_atomic_store(prog, f + 4, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+			for (; f < n; f++) step(xin[f], hw + f * HP);
+			hw[n * HP] = h;
+			__hip_atomic_store(prog, n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (lane < hr)
+			{
+				state[(size_t)lane * capacity + slot] = h;
+				state[(size_t)(hr + lane) * capacity + slot] = c;
+			}
+			return;
+		}
+
+		// layer 1: sample t takes h0 after sample t = entry t + 1 of hb0
+		const float* hr0 = hb0 + unit;
+		float* hw = hb1 + unit;
+		auto step = [&](float hin, float* dst) {
+			float acc;
+			DppDotFrom2<H>(acc, b, wa, hin, wb[0], h); // LSTM.h:170-180
+			DppDotTail<H>(acc, wb, h);
+			*dst = h;
+			h = DppCellUpdate<H, STD>(acc, K, c);
+		};
+		auto waitFor = [&](int entries) {
+			while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < entries) __builtin_amdgcn_s_sleep(1);
+		};
+		int f = 0;
+		for (; f + 4 <= n; f += 4)
+		{
+			waitFor(f + 5);
+			const float i0 = hr0[(f + 1) * HP], i1 = hr0[(f + 2) * HP], i2 = hr0[(f + 3) * HP], i3 = hr0[(f + 4) * HP];
+			step(i0, hw + (f + 0) * HP);
+			step(i1, hw + (f + 1) * HP);
+			step(i2, hw + (f + 2) * HP);
+			step(i3, hw + (f + 3) * HP);
+		}
+		if (f < n) waitFor(n + 1);
+		for (; f < n; f++) step(hr0[(f + 1) * HP], hw + f * HP);
+		hw[n * HP] = h;
+		RecurrentWaveSync();
+
+		// dense head for the whole block, lane = sample (LSTM.h:182-189)
+		const float* headW = m.w + m.headOff;
+		for (int s = lane; s < n; s += 64)
+		{
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < H; k++) acc += LoadIf(headW, (size_t)k, k < hr) * hb1[(s + 1) * HP + k];
+			outRow[s] = acc + headW[hr];
+		}
+		if (lane < hr)
+		{
+			state[(size_t)(2 * hr + lane) * capacity + slot] = h;
+			state[(size_t)(2 * hr + hr + lane) * capacity + slot] = c;
+		}
+	}
+
 	// One layer, hidden 17 .. 32 (the reference's static 1x24, NeuralModel.cpp:35): the 32-unit layout.  A 16-lane row still walks 16
 	// units with row_ror, so the state lives as TWO vectors replicated in every row (a = h[0..15], b = h[16..31]) and a gate row sum is two
 	// DPP walks; every lane owns unit 16 r + j (r = row & 1) and TWO gates of it: rows 0-1 (pair A) the i and g gates, rows 2-3 (pair B)
@@ -384,7 +523,7 @@ namespace na
 		float* __restrict__ out, long inStride, long outStride, int n, float* xin, float* hout)
 	{
 		constexpr int HP = 33;
-		const int lane = threadIdx.x;
+		const int lane = (int)threadIdx.x & 63; // (the two-wave kernel runs these bodies on the waves of a 256-thread workgroup)
 		const int j = lane & 15, rho = lane >> 4, r = rho & 1, pair = rho >> 1; // pair 0 = A (i, g), 1 = B (f, o)
 		const int hr = m.hidden, unit = 16 * r + j;
 		const bool real = unit < hr;
@@ -546,7 +685,7 @@ namespace na
 	{
 		static_assert(H == 8 || H == 16, "a 16-lane DPP row must hold the units a whole number of times");
 		constexpr int HP = H + 1;
-		const int lane = threadIdx.x;
+		const int lane = (int)threadIdx.x & 63; // (the two-wave kernel runs these bodies on the waves of a 256-thread workgroup)
 		const int unit = lane % H;
 		const int gate = min((lane / H) & 3, 2); // rows z, r, c, c
 		const bool isC = gate == 2;
@@ -645,7 +784,7 @@ namespace na
 	{
 		constexpr int HP = 33;
 		constexpr int NB = B8 ? 8 : 16;
-		const int lane = threadIdx.x;
+		const int lane = (int)threadIdx.x & 63; // (the two-wave kernel runs these bodies on the waves of a 256-thread workgroup)
 		const int j = lane & 15, rho = lane >> 4, r = rho & 1, pair = rho >> 1; // pair 0 = A (z), 1 = B (r, c)
 		const int hr = m.hidden, unit = 16 * r + j;
 		const bool real = unit < hr, isB = pair == 1;
@@ -742,6 +881,7 @@ namespace na
 		RecurrentGroupArgs g[RECURRENT_MAX_GROUPS];
 		int numGroups;
 		int noSkew; // tuning / tests (NA_REC_NOSKEW): two-layer H = 8 LSTMs on the sequential body
+		int houtWave; // four-wave workgroups (RecurrentDppKernel<true>): floats of dynamic LDS per wave
 	};
 
 	// ------------------------------------------------------------------------------------------------------------
@@ -1089,10 +1229,9 @@ namespace na
 	long RecurrentQuadLaunches() { return gQuadLaunches.load(std::memory_order_relaxed); }
 
 	// grid = all streams of all groups, block = 64 (one wave per stream)
-	__device__ __forceinline__ void RecurrentDppRun(const RecurrentGroupArgs& ga, int noSkew, const float* __restrict__ in, float* __restrict__ out, long inStride,
+	__device__ __forceinline__ void RecurrentDppRun(const RecurrentGroupArgs& ga, int idx, int noSkew, const float* __restrict__ in, float* __restrict__ out, long inStride,
 		long outStride, int n, float* xin, float* hout)
 	{
-		const int idx = (int)blockIdx.x - ga.firstBlock;
 		const int slot = ga.slots ? ga.slots[idx] : ga.slot0 + idx;
 		const int row = ga.slots ? ga.rows[idx] : ga.row0 + idx;
 		if (ga.m.hidden > 16 && ga.m.cell == LSTM_CELL_GRU) // one-layer GRUs of 17 .. 32 units
@@ -1145,24 +1284,61 @@ namespace na
 #undef NA_REC_CASE
 	}
 
-	__global__ void __launch_bounds__(64) RecurrentDppKernel(const RecurrentLaunchArgs args, const float* __restrict__ in, float* __restrict__ out, long inStride,
+	// PIPE: workgroups of FOUR waves (one per SIMD of the CU).  A group that pipelines its two layers (RecurrentPipeGroup) puts two streams
+	// into a workgroup, waves [A0 B0 B1 A1] (A: layer 0, B: layer 1); every other group four streams, one per wave, on its one-wave body.
+	// firstBlock counts these workgroups (host: PipeBlocksOf).  Measured (profiles/r06_cfg4_pipeline.txt, us per 128-sample step, two waves
+	// per stream / one): LSTM 2x16 x 256 streams 27.7 / 35.1, x 512: 28.0 / 36.1, BASELINE config 4 (512 LSTM 2x16 + 512 GRU) 33.0 / 37.1;
+	// x 1024: 41.1 / 38.0 -- with two waves on every SIMD a layer-0 wave no longer stays ahead of its layer-1 wave (which then spins), so
+	// launches of more than recPipeMax waves keep one wave per stream (UsePipe).  Swapping the A / B order between workgroups that share a
+	// CU (five patterns tried) changes nothing.
+	constexpr int REC_PIPE_WG_WAVES = 4;
+	template <bool PIPE>
+	__device__ __forceinline__ void RecurrentDppDispatch(const RecurrentGroupArgs& ga, int noSkew, const float* __restrict__ in, float* __restrict__ out, long inStride,
+		long outStride, int n, float* xinAll, float* houtAll, int houtWave)
+	{
+		if constexpr (PIPE)
+		{
+			const int wave = (int)threadIdx.x >> 6, blk = (int)blockIdx.x - ga.firstBlock;
+			if (RecurrentPipeGroup(ga.m))
+			{
+				const int pair = wave >> 1, idx = blk * 2 + pair;
+				if (idx >= ga.numStreams) return;
+				const int layer = ((wave + 1) >> 1) & 1; // waves 0 1 2 3 -> layers 0 1 1 0
+				const int slot = ga.slots ? ga.slots[idx] : ga.slot0 + idx;
+				const int row = ga.slots ? ga.rows[idx] : ga.row0 + idx;
+				float* xin = xinAll + pair * REC_XIN_FLOATS;
+				float* lds = houtAll + (size_t)pair * 2 * houtWave;
+				if (ga.m.math == LSTM_MATH_STD) LstmDppPipeBody<true>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, layer, xin, lds);
+				else LstmDppPipeBody<false>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, layer, xin, lds);
+				return;
+			}
+			const int idx = blk * REC_PIPE_WG_WAVES + wave;
+			if (idx >= ga.numStreams) return;
+			RecurrentDppRun(ga, idx, noSkew, in, out, inStride, outStride, n, xinAll + wave * REC_XIN_FLOATS, houtAll + (size_t)wave * houtWave);
+		}
+		else RecurrentDppRun(ga, (int)blockIdx.x - ga.firstBlock, noSkew, in, out, inStride, outStride, n, xinAll, houtAll);
+	}
+
+	template <bool PIPE>
+	__global__ void __launch_bounds__(PIPE ? 256 : 64) RecurrentDppKernel(const RecurrentLaunchArgs args, const float* __restrict__ in, float* __restrict__ out, long inStride,
 		long outStride, int n)
 	{
-		__shared__ __attribute__((aligned(16))) float xin[REC_XIN_FLOATS];
-		extern __shared__ __attribute__((aligned(16))) float hout[]; // REC_HOUT_FLOATS, or REC_HOUT32_FLOATS when a 32-unit-layout group is in the launch
+		__shared__ __attribute__((aligned(16))) float xin[(PIPE ? REC_PIPE_WG_WAVES : 1) * REC_XIN_FLOATS];
+		extern __shared__ __attribute__((aligned(16))) float hout[]; // REC_HOUT_FLOATS; REC_HOUT32_FLOATS when a 32-unit-layout group is in the launch; REC_PIPE_FLOATS with a pipelined one
 		int gi = 0;
 		for (int i = 1; i < args.numGroups; i++)
 			if ((int)blockIdx.x >= args.g[i].firstBlock) gi = i;
-		RecurrentDppRun(args.g[gi], args.noSkew, in, out, inStride, outStride, n, xin, hout);
+		RecurrentDppDispatch<PIPE>(args.g[gi], args.noSkew, in, out, inStride, outStride, n, xin, hout, args.houtWave);
 	}
 
 	// The same with the group table in device memory: any number of model groups in one launch (a batch in which every stream plays its
 	// own capture; the kernarg segment holds RECURRENT_MAX_GROUPS).  A wave finds its group by binary search over firstBlock and copies
 	// the entry out of the constant address space (scalar loads).  See wavenet_spec_impl.h WaveNetSpecTableKernel.
-	__global__ void __launch_bounds__(64) RecurrentDppTableKernel(const RecurrentGroupArgs* __restrict__ table, int numGroups, int noSkew, const float* __restrict__ in,
-		float* __restrict__ out, long inStride, long outStride, int n)
+	template <bool PIPE>
+	__global__ void __launch_bounds__(PIPE ? 256 : 64) RecurrentDppTableKernel(const RecurrentGroupArgs* __restrict__ table, int numGroups, int noSkew, const float* __restrict__ in,
+		float* __restrict__ out, long inStride, long outStride, int n, int houtWave)
 	{
-		__shared__ __attribute__((aligned(16))) float xin[REC_XIN_FLOATS];
+		__shared__ __attribute__((aligned(16))) float xin[(PIPE ? REC_PIPE_WG_WAVES : 1) * REC_XIN_FLOATS];
 		extern __shared__ __attribute__((aligned(16))) float hout[];
 		typedef const __attribute__((address_space(4))) RecurrentGroupArgs* TablePtr;
 		TablePtr tab = (TablePtr)(size_t)table;
@@ -1182,7 +1358,29 @@ namespace na
 #pragma unroll
 			for (int i = 0; i < (int)(sizeof(RecurrentGroupArgs) / 4); i++) dst[i] = src[i];
 		}
-		RecurrentDppRun(ga, noSkew, in, out, inStride, outStride, n, xin, hout);
+		RecurrentDppDispatch<PIPE>(ga, noSkew, in, out, inStride, outStride, n, xin, hout, houtWave);
+	}
+
+	// two waves per stream for the launch?  Some group must pipeline, and the launch must leave the SIMDs room for the second waves: at
+	// most recPipeMax waves in all (1536 = one and a half per SIMD; see RecurrentDppDispatch for the measurements)
+	static bool HostPipeGroup(const LstmModelDev& m)
+	{
+		return m.cell == LSTM_CELL_LSTM && m.numLayers == 2 && m.hidden > 8 && m.hidden <= 16 && m.tailLayers == 0;
+	}
+	static int PipeBlocksOf(const RecurrentGroup& g) { const int spb = HostPipeGroup(g.model) ? 2 : REC_PIPE_WG_WAVES; return (g.numStreams + spb - 1) / spb; }
+	static_assert(2 * REC_HOUT_FLOATS >= REC_PIPE_FLOATS, "a pair of waves' LDS regions hold the pipelined body's two h arrays");
+	static bool UsePipe(const RecurrentGroup* groups, int numGroups, int)
+	{
+		if (Tuning::Get().recNoPipe) return false;
+		long waves = 0;
+		bool any = false;
+		for (int i = 0; i < numGroups; i++)
+		{
+			const bool p = HostPipeGroup(groups[i].model);
+			any = any || p;
+			waves += (long)groups[i].numStreams * (p ? 2 : 1);
+		}
+		return any && waves <= (long)Tuning::Get().recPipeMax;
 	}
 
 	bool RecurrentDppSupported(const LstmModelDev& m)
@@ -1220,13 +1418,30 @@ namespace na
 			blocks += groups[i].numStreams;
 			any32 |= groups[i].model.hidden > 16;
 		}
+		if (!any32 && UsePipe(groups, numGroups, blocks))
+		{
+			// four-wave workgroups: two streams of a pipelining group, four of any other (RecurrentDppDispatch)
+			blocks = 0;
+			for (int i = 0; i < numGroups; i++)
+			{
+				fresh[(size_t)i].firstBlock = blocks;
+				blocks += PipeBlocksOf(groups[i]);
+			}
+			const void* devp = nullptr;
+			const hipError_t ep = t.Ensure(fresh.data(), fresh.size() * sizeof(RecurrentGroupArgs), stream, &devp);
+			if (ep != hipSuccess) return ep;
+			if (t.prepareOnly) return hipSuccess;
+			hipLaunchKernelGGL(RecurrentDppTableKernel<true>, dim3((unsigned)blocks), dim3(64 * REC_PIPE_WG_WAVES), sizeof(float) * (size_t)REC_PIPE_WG_WAVES * REC_HOUT_FLOATS, stream,
+				reinterpret_cast<const RecurrentGroupArgs*>(devp), numGroups, Tuning::Get().recNoSkew ? 1 : 0, in, out, inStride, outStride, n, REC_HOUT_FLOATS);
+			return hipGetLastError();
+		}
 		const void* dev = nullptr;
 		const hipError_t ee = t.Ensure(fresh.data(), fresh.size() * sizeof(RecurrentGroupArgs), stream, &dev);
 		if (ee != hipSuccess) return ee;
 		if (t.prepareOnly) return hipSuccess;
 		const size_t lds = sizeof(float) * (size_t)(any32 ? REC_HOUT32_FLOATS : REC_HOUT_FLOATS);
-		hipLaunchKernelGGL(RecurrentDppTableKernel, dim3((unsigned)blocks), dim3(64), lds, stream, reinterpret_cast<const RecurrentGroupArgs*>(dev), numGroups,
-			Tuning::Get().recNoSkew ? 1 : 0, in, out, inStride, outStride, n);
+		hipLaunchKernelGGL(RecurrentDppTableKernel<false>, dim3((unsigned)blocks), dim3(64), lds, stream, reinterpret_cast<const RecurrentGroupArgs*>(dev), numGroups,
+			Tuning::Get().recNoSkew ? 1 : 0, in, out, inStride, outStride, n, 0);
 		return hipGetLastError();
 	}
 
@@ -1277,8 +1492,21 @@ namespace na
 		}
 		bool any32 = false;
 		for (int i = 0; i < numGroups; i++) any32 |= groups[i].model.hidden > 16;
+		if (!any32 && UsePipe(groups, numGroups, blocks))
+		{
+			blocks = 0;
+			for (int i = 0; i < numGroups; i++)
+			{
+				args.g[i].firstBlock = blocks;
+				blocks += PipeBlocksOf(groups[i]);
+			}
+			args.houtWave = REC_HOUT_FLOATS;
+			hipLaunchKernelGGL(RecurrentDppKernel<true>, dim3((unsigned)blocks), dim3(64 * REC_PIPE_WG_WAVES), sizeof(float) * (size_t)REC_PIPE_WG_WAVES * REC_HOUT_FLOATS, stream, args, in, out,
+				inStride, outStride, n);
+			return hipGetLastError();
+		}
 		const size_t lds = sizeof(float) * (size_t)(any32 ? REC_HOUT32_FLOATS : REC_HOUT_FLOATS);
-		hipLaunchKernelGGL(RecurrentDppKernel, dim3((unsigned)blocks), dim3(64), lds, stream, args, in, out, inStride, outStride, n);
+		hipLaunchKernelGGL(RecurrentDppKernel<false>, dim3((unsigned)blocks), dim3(64), lds, stream, args, in, out, inStride, outStride, n);
 		return hipGetLastError();
 	}
 }

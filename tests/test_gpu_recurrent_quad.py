@@ -144,3 +144,41 @@ def test_quad_kernel_runs_keras_gru_layers(na, quad, hidden):
     assert np.max(np.abs(yq - y1)) < 3e-6
     for s in (0, 3, 1700, S - 2, S - 1):
         assert O.rms(yq[s] - O.OracleGRU(gj).process(x[s])) < 5e-6, s
+
+
+@pytest.mark.parametrize("hidden,std", [(16, False), (12, False), (16, True), (9, False)])
+def test_two_layer_lstm_on_one_wave_per_layer_is_bit_identical_to_the_one_wave_body(na, quad, hidden, std):
+    """LSTM 2x16 (BASELINE config 4; 2x12 is the reference's other static two-layer shape on this layout): launches of up to 1536 waves
+    run TWO waves per stream, one per layer, a few samples apart through LDS (recurrent_dpp_kernels.hip LstmDppPipeBody); larger ones
+    keep one wave per stream (LstmDppBodyM).  Same lanes, same weights, same order of operations: the two must agree bit for bit --
+    the same streams inside a batch of 2100 (one wave each; below the four-streams-per-wave threshold) and in a batch of 75, over
+    ragged block lengths (a tail that is not a multiple of four, a block above the 128-sample chunk) -- and match the oracle."""
+    ld = na.NeuralModelLoader()
+    if std:
+        ld.SetLSTMMathMode(na.EMathMode.StdMath)
+    w = O.synth_lstm_weights(2, hidden, seed=900 + hidden)
+    m = ld.CreateFromString(O.nam_json_lstm(2, hidden, w), ".nam", doPrewarm=True)
+    sizes = [128, 37, 128, 3, 300, 64]
+    S_small, S_big = 75, 2100
+    x = _inputs(S_big, sum(sizes))
+    quad.NA_DebugSetRecurrentQuadMin(0)  # (never the four-streams-per-wave kernel here)
+
+    def run(S):
+        b = na.Batch(0)
+        b.AddStreams(m, S)
+        out, pos = [], 0
+        for n in sizes:
+            out.append(b.Process(np.ascontiguousarray(x[:S, pos:pos + n])))
+            pos += n
+        b.close()
+        return np.concatenate(out, axis=1)
+
+    try:
+        small, big = run(S_small), run(S_big)
+    finally:
+        quad.NA_DebugSetRecurrentQuadMin(3072)
+    assert np.array_equal(small, big[:S_small])
+    for s in (0, 1, 63, 64, S_small - 1):
+        want = O.OracleLSTM.from_nam(2, hidden, w, math_mode=O.MATH_STD if std else O.MATH_FAST).process(x[s])
+        assert O.rms(small[s] - want) < 5e-6, (s, O.rms(small[s] - want))
+
