@@ -52,6 +52,29 @@ def pytest_collection_modifyitems(config, items):
             config.hook.pytest_deselected(items=soak)
             ordered = [item for item in ordered if not item.get_closest_marker("gpu_soak")]
     items[:] = ordered
+    if any(item.get_closest_marker("gpu") or item.get_closest_marker("gpu_soak") for item in ordered):
+        _warm_imports()
+
+
+def _warm_imports():
+    """The first `import torch` on a fresh GPU box pages ~2 GB of libraries in from cold storage: seconds on a good day, minutes on a bad one
+    (r06 soak run: 301 s, 238 s and 135 s for the first three sub-processes of a session whose parent had not imported torch; the r05
+    driver run lost its 1200 s window to the same thing).  That cost belongs to no test: it is paid here, once, in front of the first
+    test and outside the per-test watchdog -- and with the libraries in the page cache every forced-run sub-process starts warm."""
+    t0 = time.monotonic()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda").item()
+    except Exception:
+        pass  # (a box without torch / without a GPU: the tests say so themselves)
+    dt = time.monotonic() - t0
+    if dt > 10.0:
+        try:
+            os.write(2, ("\n[conftest] importing torch and opening the device took %.0f s (cold box)\n" % dt).encode())
+        except OSError:
+            pass
 
 
 class _Watchdog:

@@ -971,7 +971,14 @@ def test_table_launches_inside_a_captured_multi_unit_batch_replay_their_own_tabl
                 bb.ProcessDevice(xin.data_ptr(), yout.data_ptr(), n, total, total)
                 y[k, :, :n].copy_(yout[:, :n])
             bb.Synchronize()
-    assert torch.equal(want, got)
+    nwn = per * (len(wn) + len(nano))
+    assert torch.equal(want[:, :nwn], got[:, :nwn])
+    if os.environ.get("NA_REC_QUAD_MIN"):
+        # (forced four-streams-per-wave runs, tests/test_gpu_families.py: the one-model batch is on that layout, the table launch on the
+        # one-stream layout -- another summation order)
+        assert float((want[:, nwn:] - got[:, nwn:]).abs().max()) < 2e-5
+    else:
+        assert torch.equal(want[:, nwn:], got[:, nwn:])
     xs = np.concatenate([x[k, 0, :n].cpu().numpy() for k, n in enumerate(lengths)])
     ys = np.concatenate([got[k, 0, :n].cpu().numpy() for k, n in enumerate(lengths)])
     assert O.rms(ys - O.oracle_from_file("BossWN-standard.nam").process(xs)) < TOL_RMS

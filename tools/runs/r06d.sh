@@ -8,6 +8,6 @@ d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['kernel_ms_avg'], d['r
 done
 for v in "" "NA_REC_NOPIPE=1"; do
   echo "== lstm 2x16 only, 1024 / 512 / 2048 streams $v" >> gpurun_out/r06d/cfg4.log
-  env $v python tools/r06d_lstm.py >> gpurun_out/r06d/cfg4.log 2>&1
+  env $v python tools/runs/r06d_lstm.py >> gpurun_out/r06d/cfg4.log 2>&1
 done
 tail -n 8 gpurun_out/r06d/tests.log; cat gpurun_out/r06d/cfg4.log

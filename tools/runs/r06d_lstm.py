@@ -1,6 +1,6 @@
 """LSTM 2x16 alone at several batch sizes: us per 128-sample step (HIP-event marks of the batch)."""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import neuralaudio_amd as na
