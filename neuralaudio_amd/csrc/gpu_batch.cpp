@@ -628,6 +628,33 @@ namespace na
 		// costs ~5 HIP calls per unit, which would make a buffer host-bound, so the sequence is captured once into a hipGraph and
 		// replayed while the call signature (pointers, n, strides) and the active-stream lists stay the same -- the steady state of a
 		// real-time host.
+		// The runtime this process actually runs on may be OLDER than the ROCm 7.2 this library is built against: a host that loads
+		// PyTorch first gets PyTorch's bundled libamdhip64 (HIP 7.0.51831 with torch 2.10+rocm7.0) for the whole process, and that
+		// runtime's graph replay crashes after other graphs of the process were destroyed (hip::Graph::UpdateStreams under
+		// hipGraphLaunch; seen in tests/test_gpu_multi.py behind any other test file, never on 7.2: profiles/r06_gputest_timing.txt).  On a
+		// runtime older than the one it was built for the sequence is therefore issued directly, every buffer: ~5 HIP calls per launch
+		// unit of host time, the same streams, events and results.
+		static const bool graphsTrusted = [] {
+			int v = 0;
+			return hipRuntimeGetVersion(&v) == hipSuccess && v >= 70200000 && !Tuning::Get().batchNoGraph;
+		}();
+		if (!graphsTrusted)
+		{
+			if (!forkEvent) CheckHip(hipEventCreateWithFlags(&forkEvent, hipEventDisableTiming), "hipEventCreate");
+			CheckHip(hipEventRecord(forkEvent, stream), "hipEventRecord");
+			auto direct = [&](ModelGroup* owner, const std::function<void(hipStream_t)>& work) {
+				hipStream_t side = owner->SideStream();
+				CheckHip(hipStreamWaitEvent(side, forkEvent, 0), "hipStreamWaitEvent");
+				work(side);
+				CheckHip(hipEventRecord(owner->DoneEvent(), side), "hipEventRecord");
+				CheckHip(hipStreamWaitEvent(stream, owner->DoneEvent(), 0), "hipStreamWaitEvent");
+			};
+			for (int l = 0; l < NUM_WN_LISTS; l++)
+				if (!fusedWn[l].empty()) direct(wnOwner[l], [&, l](hipStream_t s) { launchWnList(l, s, false); });
+			if (!fusedRec.empty()) direct(recOwner, [&](hipStream_t s) { launchRec(s, false); });
+			for (ModelGroup* g : singles) direct(g, [&](hipStream_t s) { g->Process(dIn, dOut, inStride, outStride, n, s); });
+			return;
+		}
 		hipGraphExec_t graphExec = nullptr;
 		for (auto& e : graphCache)
 			if (e.key.dIn == dIn && e.key.dOut == dOut && e.key.n == n && e.key.inStride == inStride && e.key.outStride == outStride) graphExec = e.exec;

@@ -56,6 +56,7 @@ namespace na
 			t.hostHalvesOff = IsZero("NA_HOST_HALVES");
 			t.hostDirect = !IsZero("NA_HOST_DIRECT");
 			t.batchSerial = Has("NA_BATCH_SERIAL");
+			t.batchNoGraph = Has("NA_BATCH_NO_GRAPH");
 			t.residentOn = Int("NA_RESIDENT", 0) != 0;
 			t.residentHostRing = Int("NA_RESIDENT_HOST_RING", 0) != 0;
 			t.residentDelayUs = Int("NA_RESIDENT_DELAY_US", 0);

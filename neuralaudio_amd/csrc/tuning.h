@@ -42,6 +42,7 @@ namespace na
 		bool hostHalvesOff = false; // NA_HOST_HALVES=0
 		bool hostDirect = true;    // NA_HOST_DIRECT=0: copy engines instead of kernels on the pinned block
 		bool batchSerial = false;  // NA_BATCH_SERIAL
+		bool batchNoGraph = false; // NA_BATCH_NO_GRAPH: multi-unit batches issue their fork / join sequence directly every buffer instead of replaying a captured hipGraph
 		bool residentOn = false;   // NA_RESIDENT=1: batches start with the resident launch enabled (NA_BatchSetResidentLaunch; default: free-running chains)
 		bool residentHostRing = false; // NA_RESIDENT_HOST_RING=1: the command ring in pinned host memory even where the BAR maps device memory
 		int residentDelayUs = 0;   // NA_RESIDENT_DELAY_US: start offset of the second workgroup of every CU inside the resident launch

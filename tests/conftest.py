@@ -52,7 +52,7 @@ def pytest_collection_modifyitems(config, items):
             config.hook.pytest_deselected(items=soak)
             ordered = [item for item in ordered if not item.get_closest_marker("gpu_soak")]
     items[:] = ordered
-    if any(item.get_closest_marker("gpu") or item.get_closest_marker("gpu_soak") for item in ordered):
+    if not os.environ.get("NA_TEST_NO_WARM") and any(item.get_closest_marker("gpu") or item.get_closest_marker("gpu_soak") for item in ordered):
         _warm_imports()
 
 
@@ -63,6 +63,11 @@ def _warm_imports():
     test and outside the per-test watchdog -- and with the libraries in the page cache every forced-run sub-process starts warm."""
     t0 = time.monotonic()
     try:
+        # the product library FIRST: the process then runs on the ROCm runtime the library was built against (/opt/rocm, 7.2) and torch
+        # joins it; the other way round everything runs on torch's bundled HIP 7.0 runtime (NA_TEST_TORCH_FIRST=1 tests that order)
+        if not os.environ.get("NA_TEST_TORCH_FIRST"):
+            from neuralaudio_amd import capi
+            capi.load_library()
         import torch
         if torch.cuda.is_available():
             torch.cuda.init()

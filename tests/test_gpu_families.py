@@ -17,7 +17,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 T = os.path.join(ROOT, "tests")
 KNOBS = ("NA_WN_KERNEL", "NA_LSTM_NO_DPP", "NA_LSTM_LANE_KERNEL", "NA_REC_NOSKEW", "NA_WN_PACK", "NA_LSTM_NO_WAVE_RT", "NA_WN_SPEC", "NA_HOST_DIRECT",
-         "NA_REC_QUAD_MIN", "NA_HOST_HALVES", "NA_REC_RPL", "NA_WN_DENSE")
+         "NA_REC_QUAD_MIN", "NA_HOST_HALVES", "NA_REC_RPL", "NA_WN_DENSE", "NA_BATCH_NO_GRAPH", "NA_REC_NOPIPE")
 
 SOAK = [{"NA_WN_SPEC": "0"}, {"NA_WN_KERNEL": "split"}, {"NA_WN_KERNEL": "split", "NA_SP_T": "4"}, {"NA_WN_KERNEL": "split", "NA_SP_GEN": "1"},
         {"NA_WN_KERNEL": "frame"}, {"NA_WN_KERNEL": "frame", "NA_FR_PF": "2"}, {"NA_WN_KERNEL": "frame", "NA_FR_PF": "0"},
@@ -27,7 +27,9 @@ SOAK = [{"NA_WN_SPEC": "0"}, {"NA_WN_KERNEL": "split"}, {"NA_WN_KERNEL": "split"
         {"NA_REC_QUAD_MIN": "1"},   # every recurrent launch that can on the four-streams-per-wave layout, whatever its size
         {"NA_HOST_HALVES": "0"},    # no free-running half-batch chains: every buffer as ordered launches on the batch stream
         {"NA_WN_DENSE": "0"},       # four Nano streams at 16 / 16 virtual channels (default: 16 / 8, two streams per channel group)
-        {"NA_REC_RPL": "4"}]        # runtime-shaped recurrent kernel: four gate rows per lane (a quarter of the waves per stream)
+        {"NA_REC_RPL": "4"},        # runtime-shaped recurrent kernel: four gate rows per lane (a quarter of the waves per stream)
+        {"NA_BATCH_NO_GRAPH": "1"}, # multi-unit batches: fork / join issued directly every buffer (the path of a runtime older than the build's)
+        {"NA_REC_NOPIPE": "1"}]     # two-layer 16-unit LSTMs on one wave per stream (default: one wave per layer below 1536 waves)
 
 # the four fallbacks a deployment can actually land on, over the direct parity file only: part of -m gpu, a few seconds each
 SHORT = [{"NA_WN_KERNEL": "frame"}, {"NA_WN_SPEC": "0"}, {"NA_LSTM_NO_DPP": "1", "NA_GRU_NO_DPP": "1"}, {"NA_HOST_HALVES": "0"}]
