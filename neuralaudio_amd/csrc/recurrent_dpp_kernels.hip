@@ -897,14 +897,35 @@ namespace na
 	// Row sums run over the columns in the reference's order (input, then h[0 .. hr - 1]; LSTM.h:87-100), not rotated by the unit as in
 	// the one-stream layout: the two layouts agree to rounding (~1e-7), not bit for bit.  Hidden sizes below 16 are zero-padded.
 	// ------------------------------------------------------------------------------------------------------------
+	// NA_QUAD_NOPK (tuning builds): the pairs as two scalars -- no v_pk_*_f32 in the kernel (10 - 17 % slower: 8192 x LSTM 1x16 58.9 -> 64.9 us).
+	// Kept because of an UNEXPLAINED fault (profiles/r06_quad_race.txt): as ONE UNIT OF A MULTI-UNIT BATCH, beside the f16-split WaveNet
+	// kernel in its one-stream-per-workgroup flavour, the packed kernel was occasionally wrong in the fourth stream of a wave (lanes 48 ..
+	// 63) from some sample of a block on; never alone, never beside a separate batch, never with scalar pairs.  LaunchRecurrentDpp
+	// therefore takes `allowQuad`: a multi-unit batch runs its recurrent unit on the one-stream-per-wave kernel.
+#ifndef NA_QUAD_NOPK
+#define NA_QUAD_NOPK 0
+#endif
+#if NA_QUAD_NOPK
+	struct quad_f2
+	{
+		float x, y;
+	};
+	__device__ __forceinline__ quad_f2 operator*(quad_f2 a, quad_f2 b) { return quad_f2{ a.x * b.x, a.y * b.y }; }
+	__device__ __forceinline__ quad_f2 operator+(quad_f2 a, quad_f2 b) { return quad_f2{ a.x + b.x, a.y + b.y }; }
+#else
 	typedef float quad_f2 __attribute__((ext_vector_type(2)));
+#endif
 	constexpr int QUAD_CHUNK = 16;                      // samples between two head passes (bounds the LDS of a wave)
 	constexpr int QUAD_XROW = LSTM_MAX_FRAMES + 4;      // input samples of one stream in LDS (+4: the float4 reads may run past the block)
 	constexpr int QUAD_HP = 20;                         // floats per h entry: 16 units + padding (16-byte aligned rows, spread over the banks)
 	constexpr int QUAD_HROW = (QUAD_CHUNK + 1) * QUAD_HP; // output-layer h of one stream: the state before the chunk, then after each of its samples
 	constexpr int QUAD_LDS_FLOATS = 4 * QUAD_XROW + 4 * QUAD_HROW;
 
+#if NA_QUAD_NOPK
+	__device__ __forceinline__ quad_f2 QuadFma(quad_f2 a, quad_f2 b, quad_f2 c) { return quad_f2{ __builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y) }; }
+#else
 	__device__ __forceinline__ quad_f2 QuadFma(quad_f2 a, quad_f2 b, quad_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
 	__device__ __forceinline__ quad_f2 QuadSplat(float v) { return quad_f2{ v, v }; }
 
 	// GateAct on a pair of gate rows: component 0 / 1 take the constants of their own gate (sigmoid or tanh)
@@ -1446,7 +1467,7 @@ namespace na
 	}
 
 	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
-		hipStream_t stream)
+		hipStream_t stream, bool allowQuad)
 	{
 		if (n <= 0 || numGroups <= 0) return hipSuccess;
 		if (n > LSTM_MAX_FRAMES || numGroups > RECURRENT_MAX_GROUPS) return hipErrorInvalidValue;
@@ -1476,7 +1497,7 @@ namespace na
 		bool allGru = true;
 		for (int i = 0; i < numGroups; i++) allGru = allGru && groups[i].model.cell == LSTM_CELL_GRU;
 		const int quadMin = allGru ? RecurrentQuadMinStreams() * 2 / 3 : RecurrentQuadMinStreams();
-		bool quad = RecurrentQuadMinStreams() > 0 && blocks >= quadMin;
+		bool quad = allowQuad && RecurrentQuadMinStreams() > 0 && blocks >= quadMin;
 		for (int i = 0; i < numGroups; i++) quad = quad && RecurrentQuadSupported(groups[i].model);
 		if (quad)
 		{

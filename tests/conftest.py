@@ -4,7 +4,7 @@ Order (`-m gpu`): the evidence first -- committed goldens, direct parity / known
 then the kernel-specific files, the fuzz, and last the short forced-knob runs.  The long forced-knob matrix is a soak test behind
 its own marker (`-m gpu_soak`) and is not part of `-m gpu`.
 
-Watchdog: every test has a wall-clock limit (120 s unless `@pytest.mark.watchdog(seconds)` says otherwise).  A hang inside native
+Watchdog: every test has a wall-clock limit (180 s unless `@pytest.mark.watchdog(seconds)` says otherwise).  A hang inside native
 code never returns to the interpreter, so the limit is enforced by a daemon thread: it writes the test id and every thread's Python
 stack to the real stderr (behind pytest's capture) and to gpurun_out/watchdog.log, then ends the process with exit code 3 -- a stall
 names itself inside the driver's window instead of running into it."""
@@ -21,7 +21,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-DEFAULT_LIMIT_S = float(os.environ.get("NA_TEST_WATCHDOG_S", "120"))
+DEFAULT_LIMIT_S = float(os.environ.get("NA_TEST_WATCHDOG_S", "180"))
 
 GPU_FILE_ORDER = ["test_gpu_fixtures.py", "test_gpu_parity.py", "test_gpu_modeltest.py", "test_gpu_batch.py", "test_gpu_spec.py",
                   "test_gpu_recurrent_quad.py", "test_gpu_resident.py", "test_gpu_stall.py", "test_gpu_multi.py", "test_gpu_scale.py",

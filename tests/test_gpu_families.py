@@ -54,10 +54,12 @@ def forced_run(env, files, limit):
 
 
 @pytest.mark.gpu
-@pytest.mark.watchdog(120)
+@pytest.mark.watchdog(260)
 @pytest.mark.parametrize("env", SHORT, ids=ident)
 def test_forced_fallback_passes_the_parity_suite(env):
-    forced_run(env, [os.path.join(T, "test_gpu_parity.py")], 100)
+    # (the parity file needs no torch: the child skips the warm import -- 16 s on a good box; one r06 run on a box with slow storage
+    # spent more than 100 s before the child's first test, hence the generous limit)
+    forced_run(dict(env, NA_TEST_NO_WARM="1"), [os.path.join(T, "test_gpu_parity.py")], 240)
 
 
 @pytest.mark.gpu_soak

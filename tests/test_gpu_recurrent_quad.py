@@ -182,3 +182,82 @@ def test_two_layer_lstm_on_one_wave_per_layer_is_bit_identical_to_the_one_wave_b
         want = O.OracleLSTM.from_nam(2, hidden, w, math_mode=O.MATH_STD if std else O.MATH_FAST).process(x[s])
         assert O.rms(small[s] - want) < 5e-6, (s, O.rms(small[s] - want))
 
+
+def test_many_two_layer_lstm_models_in_one_table_launch_use_the_layer_pipeline_too(na, quad):
+    """More model groups than a launch's kernarg segment holds run as one table launch (RecurrentDppTableKernel); with two-layer 16-unit
+    LSTMs among them that launch, too, is four-wave workgroups with one wave per layer -- 11 handles of the same LSTM 2x16 (3 streams each)
+    next to 10 handles of an LSTM 1x16 (one wave per stream inside the same workgroups), against one handle each with all the streams:
+    bit for bit, ragged blocks."""
+    ld = na.NeuralModelLoader()
+    w2, w1 = O.synth_lstm_weights(2, 16, seed=77), O.synth_lstm_weights(1, 16, seed=78)
+    two = [ld.CreateFromString(O.nam_json_lstm(2, 16, w2), ".nam", doPrewarm=True) for _ in range(11)]
+    one = [ld.CreateFromString(O.nam_json_lstm(1, 16, w1), ".nam", doPrewarm=True) for _ in range(10)]
+    per = 3
+    S = per * (len(two) + len(one))
+    sizes = [128, 50, 128, 7]
+    x = _inputs(S, sum(sizes))
+    quad.NA_DebugSetRecurrentQuadMin(0)
+
+    def run(many):
+        b = na.Batch(0)
+        if many:
+            for h in two + one:
+                b.AddStreams(h, per)
+        else:
+            b.AddStreams(two[0], per * len(two))
+            b.AddStreams(one[0], per * len(one))
+        out, pos = [], 0
+        for n in sizes:
+            out.append(b.Process(np.ascontiguousarray(x[:, pos:pos + n])))
+            pos += n
+        b.close()
+        return np.concatenate(out, axis=1)
+
+    try:
+        ym, y1 = run(True), run(False)
+    finally:
+        quad.NA_DebugSetRecurrentQuadMin(3072)
+    assert np.array_equal(ym, y1)
+    assert O.rms(ym[1] - O.OracleLSTM.from_nam(2, 16, w2).process(x[1])) < 5e-6
+    assert O.rms(ym[S - 1] - O.OracleLSTM.from_nam(1, 16, w1).process(x[S - 1])) < 5e-6
+
+
+def test_a_recurrent_unit_of_a_mixed_batch_stays_on_the_one_stream_kernel(na, quad):
+    """Round 6 found the four-streams-per-wave kernel occasionally wrong in the fourth stream of a wave (lanes 48 .. 63, from some sample
+    of a block on) when it ran as ONE UNIT OF A MULTI-UNIT BATCH beside the f16-split WaveNet kernel -- never alone, never beside a
+    separate batch, never with its packed pairs evaluated as scalars (profiles/r06_quad_race.txt; unexplained).  A multi-unit batch
+    therefore runs its recurrent unit on the one-stream-per-wave kernel whatever the stream count: no launch of the other kernel, and
+    the LSTM rows of the mixed batch equal an LSTM-only batch on that kernel bit for bit over 120 buffers."""
+    import os
+    import torch
+    ld = na.NeuralModelLoader()
+    std = ld.CreateFromFile(os.path.join(O.MODELS_DIR, "BossWN-standard.nam"), doPrewarm=False)
+    lstm = ld.CreateFromFile(os.path.join(O.MODELS_DIR, "BossLSTM-1x16.nam"), doPrewarm=False)
+    dev = torch.device("cuda", 0)
+    nstd, nl, n, steps = 22, 64, 128, 120
+    quad.NA_DebugSetRecurrentQuadMin(0)  # (both batches prewarm their LSTM streams on the one-stream kernel: the same start state, bit for bit)
+    ts = torch.cuda.Stream(device=dev)
+    mixed = na.Batch(0, hip_stream=ts.cuda_stream)
+    mixed.AddStreams(std, nstd)
+    mixed.AddStreams(lstm, nl)
+    tr = torch.cuda.Stream(device=dev)
+    ref = na.Batch(0, hip_stream=tr.cuda_stream)
+    ref.AddStreams(lstm, nl)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    launches = quad.NA_DebugRecurrentQuadLaunches()
+    for k in range(steps):
+        x = torch.clamp(0.3 * torch.randn(nstd + nl, n, generator=g), -1, 1).to(dev)
+        ym, yr = torch.zeros(nstd + nl, n, device=dev), torch.zeros(nl, n, device=dev)
+        torch.cuda.synchronize(dev)
+        quad.NA_DebugSetRecurrentQuadMin(1)  # every launch that may use the four-streams-per-wave kernel does
+        with torch.cuda.stream(ts):
+            mixed.ProcessDevice(x.data_ptr(), ym.data_ptr(), n, n, n)
+        quad.NA_DebugSetRecurrentQuadMin(0)
+        with torch.cuda.stream(tr):
+            ref.ProcessDevice(x[nstd:].data_ptr(), yr.data_ptr(), n, n, n)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(ym[nstd:], yr), k
+    assert quad.NA_DebugRecurrentQuadLaunches() == launches
+    mixed.close()
+    ref.close()
+
