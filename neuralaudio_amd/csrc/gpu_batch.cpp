@@ -567,7 +567,7 @@ namespace na
 				left -= (size_t)chunk;
 			}
 		};
-		auto launchRec = [&](hipStream_t s, bool prepareOnly, bool allowQuad) {
+		auto launchRec = [&](hipStream_t s, bool prepareOnly) {
 			size_t offset = 0, left = n;
 			while (left > 0)
 			{
@@ -586,7 +586,7 @@ namespace na
 				if (prepareOnly) break;
 				for (size_t first = 0; first < fusedRec.size(); first += RECURRENT_MAX_GROUPS)
 					CheckHip(LaunchRecurrentDpp(fusedRec.data() + first, (int)std::min<size_t>(fusedRec.size() - first, (size_t)RECURRENT_MAX_GROUPS),
-						dIn + offset, dOut + offset, inStride, outStride, chunk, s, allowQuad), "RecurrentDppKernel (fused)");
+						dIn + offset, dOut + offset, inStride, outStride, chunk, s), "RecurrentDppKernel (fused)");
 				offset += (size_t)chunk;
 				left -= (size_t)chunk;
 			}
@@ -608,7 +608,7 @@ namespace na
 					launchWnList(l, launch, false);
 					return;
 				}
-			if (!fusedRec.empty()) launchRec(launch, false, true);
+			if (!fusedRec.empty()) launchRec(launch, false);
 			else singles[0]->Process(dIn, dOut, inStride, outStride, n, launch);
 			return;
 		}
@@ -619,7 +619,7 @@ namespace na
 			{
 				for (int l = 0; l < NUM_WN_LISTS; l++)
 					if (!fusedWn[l].empty()) launchWnList(l, stream, false);
-				if (!fusedRec.empty()) launchRec(stream, false, false);
+				if (!fusedRec.empty()) launchRec(stream, false);
 				for (ModelGroup* g : singles) g->Process(dIn, dOut, inStride, outStride, n, stream);
 				return;
 			}
@@ -651,7 +651,7 @@ namespace na
 			};
 			for (int l = 0; l < NUM_WN_LISTS; l++)
 				if (!fusedWn[l].empty()) direct(wnOwner[l], [&, l](hipStream_t s) { launchWnList(l, s, false); });
-			if (!fusedRec.empty()) direct(recOwner, [&](hipStream_t s) { launchRec(s, false, false); });
+			if (!fusedRec.empty()) direct(recOwner, [&](hipStream_t s) { launchRec(s, false); });
 			for (ModelGroup* g : singles) direct(g, [&](hipStream_t s) { g->Process(dIn, dOut, inStride, outStride, n, s); });
 			return;
 		}
@@ -668,7 +668,7 @@ namespace na
 			// the group tables of the table launches are uploaded here, in front of the capture (WnLaunchTable)
 			for (int l = 0; l < NUM_WN_LISTS; l++)
 				if (!fusedWn[l].empty()) launchWnList(l, stream, true);
-			if (!fusedRec.empty()) launchRec(stream, true, false);
+			if (!fusedRec.empty()) launchRec(stream, true);
 			hipGraph_t graph = nullptr;
 			CheckHip(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed), "hipStreamBeginCapture");
 			try
@@ -684,7 +684,7 @@ namespace na
 				};
 				for (int l = 0; l < NUM_WN_LISTS; l++)
 					if (!fusedWn[l].empty()) branch(wnOwner[l], [&, l](hipStream_t s) { launchWnList(l, s, false); });
-				if (!fusedRec.empty()) branch(recOwner, [&](hipStream_t s) { launchRec(s, false, false); });
+				if (!fusedRec.empty()) branch(recOwner, [&](hipStream_t s) { launchRec(s, false); });
 				for (ModelGroup* g : singles) branch(g, [&](hipStream_t s) { g->Process(dIn, dOut, inStride, outStride, n, s); });
 			}
 			catch (...)

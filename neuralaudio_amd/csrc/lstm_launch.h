@@ -34,9 +34,8 @@ namespace na
 	// dense chain, as long as the weights of all layers fit the LDS.  false: not launched (the lane = stream kernels take the model).
 	bool LaunchRecurrentWaveRt(const LstmModelDev& m, float* state, int capacity, const int* slots, const int* rows, int numStreams,
 		const float* in, float* out, long inStride, long outStride, int n, hipStream_t stream, hipError_t& err);
-	// allowQuad = false: never the four-streams-per-wave kernel (a recurrent unit of a multi-unit batch: see NA_QUAD_NOPK in recurrent_dpp_kernels.hip)
 	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
-		hipStream_t stream, bool allowQuad = true);
+		hipStream_t stream);
 	// ... any number of groups in one launch, the group table in device memory (`table`: the batch's cache of it; wavenet_launch.h)
 	struct WnLaunchTable;
 	hipError_t LaunchRecurrentDppTable(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,

@@ -890,18 +890,15 @@ namespace na
 	// as two packed pairs (i, f) and (g, o): a row sum is v_pk_fma_f32 over the 16 state values of the lane's stream -- 2 x 17 packed
 	// instructions per sample for four streams, where the one-stream layout spends 17 (and its DPP terms cost ~6 cycles each, measured,
 	// against ~4.3 for a plain or packed VALU instruction).  The state reaches the lanes through LDS: every lane writes the h of its unit
-	// (the entry the dense head reads afterwards anyway) and reads the 16 values of its stream back as four 16-byte broadcasts.  The gates
+	// (the entry the dense head reads afterwards anyway) and reads the 16 values of its stream back as 16-byte broadcasts (of {h, h} pairs: see QUAD_HP).  The gates
 	// of a unit meet in one lane (no lane swaps), the activations run on packed pairs with the gate's identity in per-component constants,
 	// tanh(c) on full lanes.  ~80 instructions per sample for four streams against 52 per stream.  The dependent chain of a wave is
 	// longer, so the one-stream layout stays the choice for batches that leave SIMDs idle (LaunchRecurrentDpp picks by the stream count).
 	// Row sums run over the columns in the reference's order (input, then h[0 .. hr - 1]; LSTM.h:87-100), not rotated by the unit as in
 	// the one-stream layout: the two layouts agree to rounding (~1e-7), not bit for bit.  Hidden sizes below 16 are zero-padded.
 	// ------------------------------------------------------------------------------------------------------------
-	// NA_QUAD_NOPK (tuning builds): the pairs as two scalars -- no v_pk_*_f32 in the kernel (10 - 17 % slower: 8192 x LSTM 1x16 58.9 -> 64.9 us).
-	// Kept because of an UNEXPLAINED fault (profiles/r06_quad_race.txt): as ONE UNIT OF A MULTI-UNIT BATCH, beside the f16-split WaveNet
-	// kernel in its one-stream-per-workgroup flavour, the packed kernel was occasionally wrong in the fourth stream of a wave (lanes 48 ..
-	// 63) from some sample of a block on; never alone, never beside a separate batch, never with scalar pairs.  LaunchRecurrentDpp
-	// therefore takes `allowQuad`: a multi-unit batch runs its recurrent unit on the one-stream-per-wave kernel.
+	// NA_QUAD_NOPK (tuning builds): the pairs as two scalars -- no v_pk_*_f32 in the kernel (10 - 17 % slower).  How the op_sel hazard of
+	// QUAD_HP below was cornered (profiles/r06_quad_race.txt): this build was the first variant that did not show it.
 #ifndef NA_QUAD_NOPK
 #define NA_QUAD_NOPK 0
 #endif
@@ -917,9 +914,22 @@ namespace na
 #endif
 	constexpr int QUAD_CHUNK = 16;                      // samples between two head passes (bounds the LDS of a wave)
 	constexpr int QUAD_XROW = LSTM_MAX_FRAMES + 4;      // input samples of one stream in LDS (+4: the float4 reads may run past the block)
-	constexpr int QUAD_HP = 20;                         // floats per h entry: 16 units + padding (16-byte aligned rows, spread over the banks)
+	// An h entry holds every unit TWICE, {h[k], h[k]} pairs: the row sums are packed FMAs against such a pair, and the pair has to come out of
+	// LDS as it is.  Rounds 3 - 5 kept one copy and let the FMA spread it (op_sel / op_sel_hi on the operand the ds_read_b128 had just
+	// delivered): v_pk_fma_f32 with a non-default op_sel on an LDS-DELIVERED register computes garbage in lanes 48 .. 63 every now and then
+	// while waves of another kernel issue f16 MFMAs on the same SIMD (tools/microbench/pk_lds_opsel.hip: 0.7 - 1.5 M mismatches per run beside
+	// MFMA waves, none beside anything else, none with pairs out of LDS, none with copies, none with VALU-born operands;
+	// profiles/r06_quad_race.txt) -- the fourth stream of a wave went wrong beside the f16-split WaveNet kernels.
+	constexpr int QUAD_HP = 40;                         // floats per h entry: 16 pairs + padding (16-byte aligned rows, spread over the banks)
 	constexpr int QUAD_HROW = (QUAD_CHUNK + 1) * QUAD_HP; // output-layer h of one stream: the state before the chunk, then after each of its samples
 	constexpr int QUAD_LDS_FLOATS = 4 * QUAD_XROW + 4 * QUAD_HROW;
+	// an input sample out of LDS, through a VALU copy (it is broadcast with op_sel below: see QUAD_HP)
+	__device__ __forceinline__ float QuadCopy(float v)
+	{
+		float r;
+		asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+		return r;
+	}
 
 #if NA_QUAD_NOPK
 	__device__ __forceinline__ quad_f2 QuadFma(quad_f2 a, quad_f2 b, quad_f2 c) { return quad_f2{ __builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y) }; }
@@ -1021,20 +1031,19 @@ namespace na
 		}
 		float h = LoadIf(state, (size_t)unit * capacity + slot, real);
 		float c = LoadIf(state, (size_t)(hr + unit) * capacity + slot, real);
-		float* hw = hout + sub * QUAD_HROW + unit;        // this lane's word of an entry of h
-		const float* hrd = hout + sub * QUAD_HROW;        // the 16 values of an entry
-		hw[0] = h;
+		quad_f2* hw = reinterpret_cast<quad_f2*>(hout + sub * QUAD_HROW + 2 * unit); // this lane's pair of an entry of h
+		const float* hrd = hout + sub * QUAD_HROW;                                  // the 16 pairs of an entry
+		constexpr int HPP = HP / 2;                                                 // entry stride in pairs
+		hw[0] = quad_f2{ h, h };
 		RecurrentWaveSync();
 
-		auto read16 = [&](const float* p, float (&v)[H]) {
+		auto read16 = [&](const float* p, quad_f2 (&v)[H]) {
 #pragma unroll
-			for (int q = 0; q < 4; q++)
+			for (int q = 0; q < 8; q++)
 			{
 				const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
-				v[4 * q + 0] = t.x;
-				v[4 * q + 1] = t.y;
-				v[4 * q + 2] = t.z;
-				v[4 * q + 3] = t.w;
+				v[2 * q + 0] = quad_f2{ t.x, t.y };
+				v[2 * q + 1] = quad_f2{ t.z, t.w };
 			}
 		};
 		auto cell = [&](quad_f2 aIF, quad_f2 aGO, float& cc) {
@@ -1042,7 +1051,7 @@ namespace na
 			cc = __builtin_fmaf(gIF.y, cc, gIF.x * gGO.x);
 			return gGO.y * (STD ? StdTanh(cc) : LstmRcpTanh(cc));
 		};
-		float hv0[H]; // h, all units of this lane's stream
+		quad_f2 hv0[H]; // h, all units of this lane's stream, as {h[k], h[k]}
 		read16(hrd, hv0);
 		// one sample: entry e of hout = h after sample e - 1 of the chunk
 		auto step = [&](float x, int e) {
@@ -1050,11 +1059,11 @@ namespace na
 #pragma unroll
 			for (int k = 0; k < H; k++)
 			{
-				aIF = QuadFma(wh0IF[k], QuadSplat(hv0[k]), aIF);
-				aGO = QuadFma(wh0GO[k], QuadSplat(hv0[k]), aGO);
+				aIF = QuadFma(wh0IF[k], hv0[k], aIF);
+				aGO = QuadFma(wh0GO[k], hv0[k], aGO);
 			}
 			h = cell(aIF, aGO, c);
-			hw[(e + 1) * HP] = h;
+			hw[(e + 1) * HPP] = quad_f2{ h, h };
 			RecurrentWaveSync();
 			read16(hrd + (e + 1) * HP, hv0);
 		};
@@ -1068,24 +1077,24 @@ namespace na
 			for (; f + 4 <= cn; f += 4)
 			{
 				const float4 xv = *reinterpret_cast<const float4*>(xs + f0 + f);
-				step(xv.x, f + 0);
-				step(xv.y, f + 1);
-				step(xv.z, f + 2);
-				step(xv.w, f + 3);
+				step(QuadCopy(xv.x), f + 0);
+				step(QuadCopy(xv.y), f + 1);
+				step(QuadCopy(xv.z), f + 2);
+				step(QuadCopy(xv.w), f + 3);
 			}
-			for (; f < cn; f++) step(xs[f0 + f], f);
+			for (; f < cn; f++) step(QuadCopy(xs[f0 + f]), f);
 			// dense head of the chunk (LSTM.h:182-189): output o = QUAD_CHUNK * stream + sample, one per lane
 			{
 				const int s = lane / QUAD_CHUNK, ff = lane % QUAD_CHUNK;
 				const float* hs = hout + s * QUAD_HROW + (ff + 1) * HP;
 				float acc = 0.0f;
 #pragma unroll
-				for (int k = 0; k < H; k++) acc += LoadIf(headW, (size_t)k, k < hr) * hs[k];
+				for (int k = 0; k < H; k++) acc += LoadIf(headW, (size_t)k, k < hr) * hs[2 * k];
 				const int orow = __builtin_amdgcn_ds_bpermute(4 * (16 * s), row);
 				if (ff < cn && idx0 + s < ga.numStreams) out[(size_t)orow * outStride + f0 + ff] = acc + headW[hr];
 			}
 			RecurrentWaveSync();
-			hw[0] = h; // entry 0 of the next chunk
+			hw[0] = quad_f2{ h, h }; // entry 0 of the next chunk
 			RecurrentWaveSync();
 		}
 		if (real && live)
@@ -1138,15 +1147,16 @@ namespace na
 			for (int f = lane; f < n + 4; f += 64) xin[s * QUAD_XROW + f] = f < n ? inRow[f] : 0.0f;
 		}
 		float h = LoadIf(state, (size_t)unit * capacity + slot, real);
-		float* hw = hout + sub * QUAD_HROW + unit;
+		quad_f2* hw = reinterpret_cast<quad_f2*>(hout + sub * QUAD_HROW + 2 * unit); // this lane's {h, h} pair of an entry (see QUAD_HP)
 		const float* hrd = hout + sub * QUAD_HROW;
-		hw[0] = h;
+		constexpr int HPP = HP / 2;
+		hw[0] = quad_f2{ h, h };
 		RecurrentWaveSync();
 
-		quad_f2 hv[H / 2]; // (h[2k], h[2k + 1]) of this lane's stream
+		quad_f2 hv[H]; // {h[k], h[k]} of this lane's stream
 		auto read16 = [&](const float* p) {
 #pragma unroll
-			for (int q = 0; q < 4; q++)
+			for (int q = 0; q < 8; q++)
 			{
 				const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
 				hv[2 * q] = quad_f2{ t.x, t.y };
@@ -1160,15 +1170,17 @@ namespace na
 #pragma unroll
 			for (int k = 0; k < H / 2; k++)
 			{
-				aZR = QuadFma(whZR[2 * k], QuadSplat(hv[k].x), aZR);
-				aZR = QuadFma(whZR[2 * k + 1], QuadSplat(hv[k].y), aZR);
-				aC = QuadFma(whC[k], hv[k], aC);
+				aZR = QuadFma(whZR[2 * k], hv[2 * k], aZR);
+				aZR = QuadFma(whZR[2 * k + 1], hv[2 * k + 1], aZR);
+				// the candidate row as (even terms, odd terms) like before, but with scalar FMAs: its operand pair (h[2k], h[2k + 1]) does not exist
+				// in the duplicated layout, and scalar instructions may read delivered registers any way they like
+				aC = quad_f2{ __builtin_fmaf(whC[k].x, hv[2 * k].x, aC.x), __builtin_fmaf(whC[k].y, hv[2 * k + 1].x, aC.y) };
 			}
 			const quad_f2 e2 = aZR * QuadSplat(-1.4426950408889634f);
 			const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(e2.x)), r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(e2.y));
 			const float c = StdTanh(__builtin_fmaf(r, aC.x + aC.y, __builtin_fmaf(wxC, x, biC)));
 			h = __builtin_fmaf(z, h - c, c); // (1 - z) c + z h
-			hw[(e + 1) * HP] = h;
+			hw[(e + 1) * HPP] = quad_f2{ h, h };
 			RecurrentWaveSync();
 			read16(hrd + (e + 1) * HP);
 		};
@@ -1182,23 +1194,23 @@ namespace na
 			for (; f + 4 <= cn; f += 4)
 			{
 				const float4 xv = *reinterpret_cast<const float4*>(xs + f0 + f);
-				step(xv.x, f + 0);
-				step(xv.y, f + 1);
-				step(xv.z, f + 2);
-				step(xv.w, f + 3);
+				step(QuadCopy(xv.x), f + 0);
+				step(QuadCopy(xv.y), f + 1);
+				step(QuadCopy(xv.z), f + 2);
+				step(QuadCopy(xv.w), f + 3);
 			}
-			for (; f < cn; f++) step(xs[f0 + f], f);
+			for (; f < cn; f++) step(QuadCopy(xs[f0 + f]), f);
 			{
 				const int s = lane / QUAD_CHUNK, ff = lane % QUAD_CHUNK;
 				const float* hs = hout + s * QUAD_HROW + (ff + 1) * HP;
 				float acc = 0.0f;
 #pragma unroll
-				for (int k = 0; k < H; k++) acc += LoadIf(headW, (size_t)k, k < hr) * hs[k];
+				for (int k = 0; k < H; k++) acc += LoadIf(headW, (size_t)k, k < hr) * hs[2 * k];
 				const int orow = __builtin_amdgcn_ds_bpermute(4 * (16 * s), row);
 				if (ff < cn && idx0 + s < ga.numStreams) out[(size_t)orow * outStride + f0 + ff] = acc + headW[hr];
 			}
 			RecurrentWaveSync();
-			hw[0] = h;
+			hw[0] = quad_f2{ h, h };
 			RecurrentWaveSync();
 			read16(hrd); // (the same values: keeps the entry the next chunk starts from and the registers in one place)
 		}
@@ -1467,7 +1479,7 @@ namespace na
 	}
 
 	hipError_t LaunchRecurrentDpp(const RecurrentGroup* groups, int numGroups, const float* in, float* out, long inStride, long outStride, int n,
-		hipStream_t stream, bool allowQuad)
+		hipStream_t stream)
 	{
 		if (n <= 0 || numGroups <= 0) return hipSuccess;
 		if (n > LSTM_MAX_FRAMES || numGroups > RECURRENT_MAX_GROUPS) return hipErrorInvalidValue;
@@ -1497,7 +1509,7 @@ namespace na
 		bool allGru = true;
 		for (int i = 0; i < numGroups; i++) allGru = allGru && groups[i].model.cell == LSTM_CELL_GRU;
 		const int quadMin = allGru ? RecurrentQuadMinStreams() * 2 / 3 : RecurrentQuadMinStreams();
-		bool quad = allowQuad && RecurrentQuadMinStreams() > 0 && blocks >= quadMin;
+		bool quad = RecurrentQuadMinStreams() > 0 && blocks >= quadMin;
 		for (int i = 0; i < numGroups; i++) quad = quad && RecurrentQuadSupported(groups[i].model);
 		if (quad)
 		{

@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for suf in _ldsfix "" _ldsfix _ldsfix; do echo "== variant '$suf'"; for i in 1 2; do NA_LIB_SUFFIX=$suf python tools/runs/r06n_quadrace.py std 64 400 128 2>&1 | grep "^mix" | cut -c1-200; done; done
+python tools/runs/r06u_victims.py quad 2>&1 | grep -v amdgpu.ids
+python tools/runs/r06p_quadrace2.py 64 own 2 2>&1 | grep "^separate" | cut -c1-200
+timeout 300 python -m pytest tests/test_gpu_recurrent_quad.py -x -q -m gpu 2>&1 | tail -3
+python tools/runs/r06q_quadperf.py 2>&1 | grep streams

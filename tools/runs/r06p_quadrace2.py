@@ -14,13 +14,15 @@ std = ld.CreateFromFile(P("BossWN-standard.nam"), doPrewarm=False)
 lstm = ld.CreateFromFile(P("BossLSTM-1x16.nam"), doPrewarm=False)
 dev = torch.device("cuda", 0)
 nstd = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+OWN = len(sys.argv) > 2 and sys.argv[2] == "own"   # the batches on streams of their own (HIP's, not torch's)
+REP = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # Standard steps per LSTM step (more overlap)
 nl, steps, n = 64, 400, 128
 def lstm_batch(quad):
     lib.NA_DebugSetRecurrentQuadMin(1 if quad else 0)
-    ts = torch.cuda.Stream(device=dev); b = na.Batch(0, hip_stream=ts.cuda_stream); b.AddStreams(lstm, nl); return ts, b
+    ts = torch.cuda.Stream(device=dev); b = (na.Batch(0) if OWN else na.Batch(0, hip_stream=ts.cuda_stream)); b.AddStreams(lstm, nl); return ts, b
 tsq, bq = lstm_batch(True)
 tsd, bd = lstm_batch(False)
-tss = torch.cuda.Stream(device=dev); bs = na.Batch(0, hip_stream=tss.cuda_stream)
+tss = torch.cuda.Stream(device=dev); bs = (na.Batch(0) if OWN else na.Batch(0, hip_stream=tss.cuda_stream))
 if nstd: bs.AddStreams(std, nstd)
 g = torch.Generator(device="cpu").manual_seed(3)
 xs = torch.clamp(0.3 * torch.randn(max(nstd, 1), n, generator=g), -1, 1).to(dev); ys = torch.zeros_like(xs)
@@ -31,15 +33,17 @@ for k in range(steps):
     torch.cuda.synchronize()
     if nstd:
         with torch.cuda.stream(tss):
-            bs.ProcessDevice(xs.data_ptr(), ys.data_ptr(), n, n, n)
+            for _ in range(REP): bs.ProcessDevice(xs.data_ptr(), ys.data_ptr(), n, n, n)
     lib.NA_DebugSetRecurrentQuadMin(1)
     with torch.cuda.stream(tsq):
         bq.ProcessDevice(x.data_ptr(), yq.data_ptr(), n, n, n)
     lib.NA_DebugSetRecurrentQuadMin(0)
     with torch.cuda.stream(tsd):
         bd.ProcessDevice(x.data_ptr(), yd.data_ptr(), n, n, n)
+    if OWN:
+        bs.Synchronize(); bq.Synchronize(); bd.Synchronize()
     torch.cuda.synchronize()
     d = (yq - yd).abs().amax(dim=1)
     for r in torch.nonzero(d > 1e-4).flatten().tolist():
         bad.setdefault(r, []).append(k)
-print("separate batches: std streams", nstd, "-> bad rows:", {r: v[:3] for r, v in sorted(bad.items())})
+print("separate batches:", "own streams" if OWN else "torch streams", "x%d" % REP, "std streams", nstd, "-> bad rows:", {r: v[:3] for r, v in sorted(bad.items())})
