@@ -209,6 +209,25 @@ def test_release_library_exports_the_documented_surface_and_nothing_else(na):
     assert b"gfx950" in data and b"WaveNetSpecKernel" in data
 
 
+def test_no_kernel_feeds_a_loaded_register_to_a_packed_f32_instruction_through_op_sel(na):
+    """gfx950 (profiles/r06_quad_race.txt, tools/microbench/pk_lds_opsel.hip): v_pk_fma_f32 with a non-default op_sel / op_sel_hi on a register
+    that a 128-bit load (ds_read_b128, global_load_dwordx4) has just delivered is wrong in lanes 48 .. 63 now and then while another wave
+    issues MFMAs on the SIMD.  The library's kernels have thousands of packed-f32 operands with op_sel -- on ALU / MFMA results -- and must
+    have none on a loaded register: the hand-written ones go through pairs or copies, the compiler's own pairing (SLP) is off for the
+    recurrent files (csrc/Makefile).  A scan of the disassembly of every code object in the built library."""
+    import importlib.util
+    from neuralaudio_amd import capi
+    spec = importlib.util.spec_from_file_location("pk_opsel_sources", os.path.join(ROOT, "tools", "analysis", "pk_opsel_sources.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    if not os.path.exists(scan.OBJDUMP):
+        pytest.skip("no llvm-objdump under /opt/rocm")
+    n, total, found = scan.scan_library(capi.LIB_PATH)
+    assert n >= 10 and sum(total.values()) > 1000  # (the scan saw the kernels and their packed instructions)
+    assert any("RecurrentQuadKernel" in k for k in total)
+    assert not found, sorted(found.items())
+
+
 def test_library_embeds_gfx950_code_object(na):
     from neuralaudio_amd import capi
     data = open(capi.LIB_PATH, "rb").read()

@@ -22,7 +22,10 @@ __device__ __forceinline__ void WaveSync()
 // VARIANT 0: the values come from the LDS broadcast and are spread over the pair by op_sel (the kernel's form).  1: same values, but every
 // broadcast pair {x, x} is built in registers first (two v_mov: the packed FMA runs with default op_sel).  2: no LDS at all -- the 16
 // values come from VALU arithmetic -- with the op_sel broadcast.  3: the LDS holds every value TWICE ({x, x} pairs, eight ds_read_b128): the
-// packed FMA reads the delivered pair as it is, default op_sel, no copy.
+// packed FMA reads the delivered pair as it is, default op_sel, no copy.  4: as 0, but the values arrive by sixteen ds_read_b32 (what the
+// compiler's own pairing of scalar code produces: lstm_kernels.hip's runtime-shaped kernel had 200 such sites).  5: the values arrive by
+// global_load_dwordx4 (from gsrc, L2-resident).  6: as 0 with ds_read_b64.
+__device__ const float* g_src;
 template <int VARIANT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) Checker(unsigned* hist, int iters, float seed)
 {
@@ -70,6 +73,38 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) Ch
 		{
 #pragma unroll
 			for (int k = 0; k < 16; k++) hv[k] = __builtin_fmaf(h, 0.37f + 0.01f * k, 0.05f * (float)(k - 8)); // (register-born values)
+		}
+		if (VARIANT == 4 || VARIANT == 6)
+		{
+			const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(hrd + (e + 1) * 20);
+			if (VARIANT == 4)
+			{
+#pragma unroll
+				for (int k = 0; k < 16; k++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(hv[k]) : "v"(a), "n"(4 * k));
+			}
+			else
+			{
+#pragma unroll
+				for (int k = 0; k < 8; k++)
+				{
+					f2 t;
+					asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t) : "v"(a), "n"(8 * k));
+					hv[2 * k] = t.x; hv[2 * k + 1] = t.y;
+				}
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]), "+v"(hv[4]), "+v"(hv[5]), "+v"(hv[6]), "+v"(hv[7]), "+v"(hv[8]),
+				"+v"(hv[9]), "+v"(hv[10]), "+v"(hv[11]), "+v"(hv[12]), "+v"(hv[13]), "+v"(hv[14]), "+v"(hv[15]));
+		}
+		if (VARIANT == 5)
+		{
+			typedef float gf4 __attribute__((ext_vector_type(4)));
+			const __attribute__((address_space(1))) gf4* gp = (const __attribute__((address_space(1))) gf4*)(g_src + ((i & 63) * 64 + sub * 16));
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+			{
+				const gf4 t = gp[q];
+				hv[4 * q + 0] = t.x; hv[4 * q + 1] = t.y; hv[4 * q + 2] = t.z; hv[4 * q + 3] = t.w;
+			}
 		}
 #pragma unroll
 		for (int k = 0; k < 16; k++)
@@ -209,8 +244,17 @@ int main(int argc, char** argv)
 			printf("beside %-28s mismatches in lanes 0-15 / 16-31 / 32-47 / 48-63: %lu / %lu / %lu / %lu\n", names[mode], q[0], q[1], q[2], q[3]);
 		}
 		// what in the victim matters: the three variants beside the MFMA waves
-		const char* vn[4] = { "LDS values, op_sel broadcast", "LDS values, pairs built in registers", "VALU values, op_sel broadcast", "LDS PAIRS, default op_sel" };
-		for (int v = 0; v < 4; v++)
+		const char* vn[7] = { "LDS values, op_sel broadcast", "LDS values, pairs built in registers", "VALU values, op_sel broadcast", "LDS PAIRS, default op_sel",
+			"ds_read_b32 values, op_sel", "global_load_dwordx4 values, op_sel", "ds_read_b64 values, op_sel" };
+		{
+			std::vector<float> pat(64 * 64);
+			for (size_t k = 0; k < pat.size(); k++) pat[k] = 0.05f * (float)((k * 37) % 23) - 0.5f;
+			float* gs;
+			CHECK(hipMalloc(&gs, pat.size() * sizeof(float)));
+			CHECK(hipMemcpy(gs, pat.data(), pat.size() * sizeof(float), hipMemcpyHostToDevice));
+			CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_src), &gs, sizeof(gs)));
+		}
+		for (int v = 0; v < 7; v++)
 		{
 			CHECK(hipMemset(hist, 0, 64 * sizeof(unsigned)));
 			for (int r = 0; r < rounds; r++)
@@ -222,6 +266,9 @@ int main(int argc, char** argv)
 					if (v == 1) hipLaunchKernelGGL(Checker<1>, dim3(cus * 4), dim3(64), 0, sa, hist, 40000, 0.2f + 0.003f * (4 * r + q));
 					if (v == 2) hipLaunchKernelGGL(Checker<2>, dim3(cus * 4), dim3(64), 0, sa, hist, 40000, 0.2f + 0.003f * (4 * r + q));
 					if (v == 3) hipLaunchKernelGGL(Checker<3>, dim3(cus * 4), dim3(64), 0, sa, hist, 40000, 0.2f + 0.003f * (4 * r + q));
+					if (v == 4) hipLaunchKernelGGL(Checker<4>, dim3(cus * 4), dim3(64), 0, sa, hist, 40000, 0.2f + 0.003f * (4 * r + q));
+					if (v == 5) hipLaunchKernelGGL(Checker<5>, dim3(cus * 4), dim3(64), 0, sa, hist, 40000, 0.2f + 0.003f * (4 * r + q));
+					if (v == 6) hipLaunchKernelGGL(Checker<6>, dim3(cus * 4), dim3(64), 0, sa, hist, 40000, 0.2f + 0.003f * (4 * r + q));
 				}
 				CHECK(hipStreamSynchronize(sa));
 				CHECK(hipStreamSynchronize(sb));

@@ -22,6 +22,11 @@ victims = {
     "lstm2x16 x64 (pipe)": (lambda: lstm(2, 16), 64, 0),
     "lstm1x24 x64 (32-unit layout)": (lambda: lstm(1, 24), 64, 0),
     "lstm2x40 x32 (wave rt)": (lambda: lstm(2, 40), 32, 0),
+    "lstm1x18 x512 (rt)": (lambda: lstm(1, 18), 512, 0),
+    "lstm3x16 x256 (rt)": (lambda: lstm(3, 16), 256, 0),
+    "lstm2x40 x256 (rt)": (lambda: lstm(2, 40), 256, 0),
+    "lstm1x200 x64 (rt, waves share a stream)": (lambda: lstm(1, 200), 64, 0),
+    "keras stack gru12+dense x512 (rt)": (lambda: ld.CreateFromFile(os.path.join(ROOT, "tests", "golden", "models", "synthetic_stack_gru12_dense5relu_dense3sigmoid_dense1.json"), doPrewarm=False), 512, 0),
     "gru1x16 x64": (lambda: ld.CreateFromFile(os.path.join(ROOT, "tests", "golden", "models", "synthetic_gru_1x16.json"), doPrewarm=False), 64, 0),
     "gru1x16 x64 (quad)": (lambda: ld.CreateFromFile(os.path.join(ROOT, "tests", "golden", "models", "synthetic_gru_1x16.json"), doPrewarm=False), 64, 1),
     "keras stack gru12+dense": (lambda: ld.CreateFromFile(os.path.join(ROOT, "tests", "golden", "models", "synthetic_stack_gru12_dense5relu_dense3sigmoid_dense1.json"), doPrewarm=False), 64, 0),
