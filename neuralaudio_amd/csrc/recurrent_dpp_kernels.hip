@@ -385,6 +385,9 @@ namespace na
 	// instructions instead of 112, on a chip that now carries two waves per SIMD.  Same lane layout, same weights, same order of
 	// floating-point operations as LstmDppBodyM<16, 2>: bit-identical results (tests/test_gpu_batch.py, NA_REC_NOPIPE=1 selects the
 	// one-wave body).  LDS: h0[n + 2][17] | h1[n + 2][17] | progress.
+#ifndef NA_PIPE_PUBLISH_LATE
+#define NA_PIPE_PUBLISH_LATE 0 // (A/B: the layer-0 wave publishes at the end of a group instead of after its first step)
+#endif
 	constexpr int REC_PIPE_HP = 17;
 	constexpr int REC_PIPE_REGION = (LSTM_MAX_FRAMES + 2) * REC_PIPE_HP;
 	constexpr int REC_PIPE_FLOATS = 2 * REC_PIPE_REGION + 16;
@@ -451,11 +454,17 @@ namespace na
 			{
 				const float4 xv = *reinterpret_cast<const float4*>(xin + f);
 				step(xv.x, hw + (f + 0) * HP);
+				// entries 0 .. f are complete (LDS operations of a wave retire in order; the release orders the compiler): the group
+				// f - 4 .. f - 1 of the layer-1 wave, which ends with entry f, may start
+#if !NA_PIPE_PUBLISH_LATE
+				__hip_atomic_store(prog, f + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 				step(xv.y, hw + (f + 1) * HP);
 				step(xv.z, hw + (f + 2) * HP);
 				step(xv.w, hw + (f + 3) * HP);
-				// entries 0 .. f + 3 are complete (LDS operations of a wave retire in order; the release orders the compiler)
+#if NA_PIPE_PUBLISH_LATE
 				__hip_atomic_store(prog, f + 4, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 			}
 			for (; f < n; f++) step(xin[f], hw + f * HP);
 			hw[n * HP] = h;
@@ -481,6 +490,10 @@ namespace na
 		auto waitFor = [&](int entries) {
 			while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < entries) __builtin_amdgcn_s_sleep(1);
 		};
+		// (The look at the progress word and the four reads of a group are two LDS round trips in front of its steps.  Requesting both in
+		// front of the PREVIOUS group's steps -- a seen-progress counter, four more registers -- was built and measured: LSTM 2x16 x 256
+		// 26.1 us either way, config 4 33.6 against 32.7 us.  The wave is bound by the instructions it issues, the other wave of the SIMD
+		// fills the round trips, and the bookkeeping costs more than it hides: profiles/r06_cfg4_pipeline.txt.)
 		int f = 0;
 		for (; f + 4 <= n; f += 4)
 		{
