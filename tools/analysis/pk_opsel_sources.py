@@ -3,7 +3,8 @@ whose LAST WRITER (scanning the disassembly backwards, same kernel) is a memory 
 rather than a VALU instruction.  Linear scan, no control-flow graph: a report is a place to look at, not a proof; no report for a kernel
 means every such operand was last written by ALU / MFMA / accumulator-read instructions on the straight-line path in front of it.
 The probe (tools/microbench/pk_lds_opsel.hip) shows the hazard for registers delivered by ds_read_b128 and global_load_dwordx4, not for
-ds_read_b32 / b64; the scan reports every memory-delivered operand all the same -- the library has none (tests/test_host_cpu.py).
+ds_read_b32 / b64, and not for v_fma_mix_f32 (the other op_sel user of the library, which IS fed loaded registers: probed clean); the scan
+reports every memory-delivered packed-f32 operand all the same -- the library has none (tests/test_host_cpu.py).
 usage: python tools/analysis/pk_opsel_sources.py <libNeuralAudioCAPI.so | disassembly.s> ...   (.s: llvm-objdump -d of a gfx950 code object)"""
 import glob
 import os

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef float f2 __attribute__((ext_vector_type(2)));
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -147,6 +148,75 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) Ch
 	if (bad) atomicAdd(&hist[lane], bad);
 }
 
+// ---- the same question for v_fma_mix_f32, the other instruction of the library that selects register halves with op_sel (the split kernels
+// read f16 halves of 128-bit loads with it: tools/analysis found 369 sites behind ds_read_b128, 384 behind global / flat dwordx4 loads) ----
+// SRC 0: sixteen packed-f16 words out of LDS by four ds_read_b128; 1: out of global memory by four global_load_dwordx4.  Checked against the
+// same sum from v_mov copies of the words, halves widened with v_cvt_f32_f16 (v_fma_mix converts exactly and fuses: bit-identical).
+__device__ const unsigned* g_src16;
+template <int SRC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) MixChecker(unsigned* hist, int iters, float seed)
+{
+	__shared__ __attribute__((aligned(16))) unsigned lds[4 * 340];
+	const int lane = threadIdx.x, unit = lane & 15, sub = lane >> 4;
+	unsigned* hw = lds + sub * 340 + unit;
+	const unsigned* hrd = lds + sub * 340;
+	float w[16];
+	for (int k = 0; k < 16; k++) w[k] = 0.02f * (float)((unit + 3 * k) % 16) - 0.15f;
+	float h = seed + 0.01f * lane;
+	unsigned bad = 0;
+	for (int i = 0; i < iters; i++)
+	{
+		const int e = i & 15;
+		typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+		const h2 ph = { (_Float16)h, (_Float16)(0.5f * h + 0.125f) };
+		hw[(e + 1) * 20] = __builtin_bit_cast(unsigned, ph);
+		WaveSync();
+		unsigned q[16];
+		if (SRC == 0)
+		{
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				const uint4 t = *reinterpret_cast<const uint4*>(hrd + (e + 1) * 20 + 4 * j);
+				q[4 * j + 0] = t.x; q[4 * j + 1] = t.y; q[4 * j + 2] = t.z; q[4 * j + 3] = t.w;
+			}
+		}
+		else
+		{
+			typedef unsigned gu4 __attribute__((ext_vector_type(4)));
+			const __attribute__((address_space(1))) gu4* gp = (const __attribute__((address_space(1))) gu4*)(g_src16 + ((i & 63) * 64 + sub * 16));
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				const gu4 t = gp[j];
+				q[4 * j + 0] = t.x; q[4 * j + 1] = t.y; q[4 * j + 2] = t.z; q[4 * j + 3] = t.w;
+			}
+		}
+		float mHi = 0.1f, mLo = -0.1f;
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+		{
+			asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(mHi) : "v"(q[k]), "v"(w[k]));
+			asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(mLo) : "v"(q[k]), "v"(w[k]));
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		float rHi = 0.1f, rLo = -0.1f;
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+		{
+			unsigned c;
+			asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(q[k]));
+			const h2 hh = __builtin_bit_cast(h2, c);
+			rLo = __builtin_fmaf((float)hh.x, w[k], rLo);
+			rHi = __builtin_fmaf((float)hh.y, w[k], rHi);
+		}
+		if (__builtin_bit_cast(unsigned, mHi) != __builtin_bit_cast(unsigned, rHi) || __builtin_bit_cast(unsigned, mLo) != __builtin_bit_cast(unsigned, rLo)) bad++;
+		h = 0.5f * rHi - 0.25f * rLo + 1e-3f * (float)(i & 7);
+		h = h > 4.0f ? 4.0f : (h < -4.0f ? -4.0f : h);
+	}
+	if (bad) atomicAdd(&hist[lane], bad);
+}
+
 // ---- built-in aggressors (another stream of this process): what in the split kernel does it? ----
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -278,6 +348,43 @@ int main(int argc, char** argv)
 			unsigned long q[4] = { 0, 0, 0, 0 };
 			for (int l = 0; l < 64; l++) q[l / 16] += h[l];
 			printf("beside MFMA waves, victim = %-38s mismatches in lanes 0-15 / 16-31 / 32-47 / 48-63: %lu / %lu / %lu / %lu\n", vn[v], q[0], q[1], q[2], q[3]);
+		}
+		// v_fma_mix_f32 with op_sel as the victim
+		{
+			std::vector<unsigned> pat(64 * 64);
+			for (size_t k = 0; k < pat.size(); k++)
+			{
+				const _Float16 lo = (_Float16)(0.05f * (float)((k * 37) % 23) - 0.5f), hi = (_Float16)(0.03f * (float)((k * 11) % 29) - 0.4f);
+				unsigned short ul, uh;
+				memcpy(&ul, &lo, 2); memcpy(&uh, &hi, 2);
+				pat[k] = (unsigned)ul | ((unsigned)uh << 16);
+			}
+			unsigned* gs;
+			CHECK(hipMalloc(&gs, pat.size() * sizeof(unsigned)));
+			CHECK(hipMemcpy(gs, pat.data(), pat.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+			CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_src16), &gs, sizeof(gs)));
+			const char* mn[2] = { "ds_read_b128 words", "global_load_dwordx4 words" };
+			for (int beside = 0; beside < 2; beside++)
+				for (int v = 0; v < 2; v++)
+				{
+					CHECK(hipMemset(hist, 0, 64 * sizeof(unsigned)));
+					for (int r = 0; r < rounds; r++)
+					{
+						if (beside) hipLaunchKernelGGL(Burner, dim3(cus * 4), dim3(256), 0, sb, src, sink, its[1], 1);
+						for (int q = 0; q < 4; q++)
+						{
+							if (v == 0) hipLaunchKernelGGL(MixChecker<0>, dim3(cus * 4), dim3(64), 0, sa, hist, 40000, 0.2f + 0.003f * (4 * r + q));
+							else hipLaunchKernelGGL(MixChecker<1>, dim3(cus * 4), dim3(64), 0, sa, hist, 40000, 0.2f + 0.003f * (4 * r + q));
+						}
+						CHECK(hipStreamSynchronize(sa));
+						CHECK(hipStreamSynchronize(sb));
+					}
+					std::vector<unsigned> hh(64);
+					CHECK(hipMemcpy(hh.data(), hist, 64 * sizeof(unsigned), hipMemcpyDeviceToHost));
+					unsigned long qq[4] = { 0, 0, 0, 0 };
+					for (int l = 0; l < 64; l++) qq[l / 16] += hh[l];
+					printf("beside %-10s victim = v_fma_mix_f32 op_sel on %-26s mismatches in lanes 0-15 / 16-31 / 32-47 / 48-63: %lu / %lu / %lu / %lu\n", beside ? "MFMA waves," : "nothing,", mn[v], qq[0], qq[1], qq[2], qq[3]);
+				}
 		}
 		return 0;
 	}
