@@ -178,7 +178,8 @@ NA_EXTERN int NA_MultiSetQuality(NA_MultiBatch* multi, int stream, float quality
  * buffer on the shard's GPU (valid until the next NA_MultiProcess).  The kernels' data path has no collective either way. */
 NA_EXTERN int NA_MultiSetFanIn(NA_MultiBatch* multi, int mode);
 NA_EXTERN const float* NA_MultiGatheredOutput(NA_MultiBatch* multi, int shard);
-/* 1 when librccl.so loads and exports every entry point this library binds (no GPU needed), else 0 with NA_GetLastError() */
+/* 1 when librccl.so loads and exports every entry point this library binds (no GPU needed), else 0 with NA_GetLastError().  The first
+ * call is the dlopen (seconds on a cold page cache: measured 4.9 s): a set-up call, never one for the audio thread. */
 NA_EXTERN int NA_RcclAvailable(void);
 /* the partition itself: bounds[0 .. parts] of contiguous ranges of items [0, n) with near-equal total cost (every range keeps at least
  * one item while items remain).  One-process-per-GPU hosts (bench.py over torch.distributed / RCCL) call it with their rank. */
