@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dpp_recurrent.h"
+#include "device_once.h"
 #include "tuning.h"
 #include "lstm_dev.h"
 #include "lstm_launch.h"
@@ -1335,7 +1336,7 @@ namespace na
 	// firstBlock counts these workgroups (host: PipeBlocksOf).  Measured (profiles/r06_cfg4_pipeline.txt, us per 128-sample step, two waves
 	// per stream / one): LSTM 2x16 x 256 streams 27.7 / 35.1, x 512: 28.0 / 36.1, BASELINE config 4 (512 LSTM 2x16 + 512 GRU) 33.0 / 37.1;
 	// x 1024: 41.1 / 38.0 -- with two waves on every SIMD a layer-0 wave no longer stays ahead of its layer-1 wave (which then spins), so
-	// launches of more than recPipeMax waves keep one wave per stream (UsePipe).  Swapping the A / B order between workgroups that share a
+	// such launches keep one wave per stream (UsePipe has the rule and the measurements over the batch size).  Swapping the A / B order between workgroups that share a
 	// CU (five patterns tried) changes nothing.
 	constexpr int REC_PIPE_WG_WAVES = 4;
 	template <bool PIPE>
@@ -1407,26 +1408,32 @@ namespace na
 		RecurrentDppDispatch<PIPE>(ga, noSkew, in, out, inStride, outStride, n, xin, hout, houtWave);
 	}
 
-	// two waves per stream for the launch?  Some group must pipeline, and the launch must leave the SIMDs room for the second waves: at
-	// most recPipeMax waves in all (1536 = one and a half per SIMD; see RecurrentDppDispatch for the measurements)
+	// two waves per stream for the launch?  Some group must pipeline, and the second waves must find SIMDs with room (UsePipe)
 	static bool HostPipeGroup(const LstmModelDev& m)
 	{
 		return m.cell == LSTM_CELL_LSTM && m.numLayers == 2 && m.hidden > 8 && m.hidden <= 16 && m.tailLayers == 0;
 	}
 	static int PipeBlocksOf(const RecurrentGroup& g) { const int spb = HostPipeGroup(g.model) ? 2 : REC_PIPE_WG_WAVES; return (g.numStreams + spb - 1) / spb; }
 	static_assert(2 * REC_HOUT_FLOATS >= REC_PIPE_FLOATS, "a pair of waves' LDS regions hold the pipelined body's two h arrays");
+	// Measured (tools/runs/r06ag_pipesizes.py, LSTM 2x16 alone, us per 128-sample step, 1024 SIMDs):
+	//   streams        384   512   640   768   896  1024  1152  1280  1536  1792  2048  2304  2560  3072
+	//   one wave      35.9  36.1  37.0  37.1  37.9  38.0  59.9  60.0  60.7  61.1  61.5  86.0  86.3  86.8    a step per wave a SIMD holds
+	//   two waves     27.4  27.6  40.1  40.2  40.3  40.3  52.1  52.2  52.4  63.0  63.1  75.5  75.7  88.9    half a step per wave
+	// -- the pipeline wins whenever its 2 S waves fill an ODD number of waves per SIMD (the one-wave layout then pays a whole step for a
+	// round that is at most half full), and loses by ~5 % otherwise.  Launches that also hold other recurrent groups (BASELINE config 4:
+	// 512 LSTM 2x16 + 512 GRU = 1536 waves, 33.0 against 37.1 us) pipeline up to one and a half waves per SIMD, as measured there.
+	// NA_REC_PIPE_MAX = a plain wave-count threshold for every launch (tuning), NA_REC_NOPIPE = never.
 	static bool UsePipe(const RecurrentGroup* groups, int numGroups, int)
 	{
-		if (Tuning::Get().recNoPipe) return false;
-		long waves = 0;
-		bool any = false;
-		for (int i = 0; i < numGroups; i++)
-		{
-			const bool p = HostPipeGroup(groups[i].model);
-			any = any || p;
-			waves += (long)groups[i].numStreams * (p ? 2 : 1);
-		}
-		return any && waves <= (long)Tuning::Get().recPipeMax;
+		const Tuning& t = Tuning::Get();
+		if (t.recNoPipe) return false;
+		long piped = 0, others = 0;
+		for (int i = 0; i < numGroups; i++) (HostPipeGroup(groups[i].model) ? piped : others) += groups[i].numStreams;
+		if (piped == 0) return false;
+		const long waves = 2 * piped + others, simds = 4L * CurrentDeviceCUs();
+		if (t.recPipeMax > 0) return waves <= (long)t.recPipeMax;
+		if (others != 0) return 2 * waves <= 3 * simds;
+		return (((waves + simds - 1) / simds) & 1) != 0;
 	}
 
 	bool RecurrentDppSupported(const LstmModelDev& m)

@@ -50,7 +50,7 @@ namespace na
 			t.recNoDpp32 = Has("NA_REC_NO_DPP32");
 			t.recNoSkew = Has("NA_REC_NOSKEW");
 			t.recNoPipe = Has("NA_REC_NOPIPE");
-			t.recPipeMax = Int("NA_REC_PIPE_MAX", 1536);
+			t.recPipeMax = Int("NA_REC_PIPE_MAX", 0);
 			t.recRpl = Int("NA_REC_RPL", 1);
 			t.hostChains = Int("NA_HOST_CHAINS", 2);
 			t.hostHalvesOff = IsZero("NA_HOST_HALVES");

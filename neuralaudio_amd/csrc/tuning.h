@@ -35,7 +35,7 @@ namespace na
 		bool recNoDpp32 = false;   // NA_REC_NO_DPP32
 		bool recNoSkew = false;    // NA_REC_NOSKEW
 		bool recNoPipe = false;    // NA_REC_NOPIPE: two-layer 16-unit LSTMs on the one-wave body instead of one wave per layer (recurrent_dpp_kernels.hip LstmDppPipeBody)
-		int recPipeMax = 1536;     // NA_REC_PIPE_MAX: launches of more waves than this (two per pipelined stream, one per other) keep one wave per stream
+		int recPipeMax = 0;        // NA_REC_PIPE_MAX: > 0 = launches of more waves than this (two per pipelined stream, one per other) keep one wave per stream; 0 = UsePipe's rule
 		int recRpl = 1;            // NA_REC_RPL=1|2|4|8
 		// host side
 		int hostChains = 2;        // NA_HOST_CHAINS=2..4

@@ -148,10 +148,11 @@ def test_quad_kernel_runs_keras_gru_layers(na, quad, hidden):
 
 @pytest.mark.parametrize("hidden,std", [(16, False), (12, False), (16, True), (9, False)])
 def test_two_layer_lstm_on_one_wave_per_layer_is_bit_identical_to_the_one_wave_body(na, quad, hidden, std):
-    """LSTM 2x16 (BASELINE config 4; 2x12 is the reference's other static two-layer shape on this layout): launches of up to 1536 waves
-    run TWO waves per stream, one per layer, a few samples apart through LDS (recurrent_dpp_kernels.hip LstmDppPipeBody); larger ones
-    keep one wave per stream (LstmDppBodyM).  Same lanes, same weights, same order of operations: the two must agree bit for bit --
-    the same streams inside a batch of 2100 (one wave each; below the four-streams-per-wave threshold) and in a batch of 75, over
+    """LSTM 2x16 (BASELINE config 4; 2x12 is the reference's other static two-layer shape on this layout): launches whose second waves find
+    half-empty SIMDs run TWO waves per stream, one per layer, a few samples apart through LDS (recurrent_dpp_kernels.hip LstmDppPipeBody,
+    UsePipe: 2 S waves an odd number of times the 1024 SIMDs); the others keep one wave per stream (LstmDppBodyM).  Same lanes, same
+    weights, same order of operations: the two must agree bit for bit -- the same streams inside a batch of 1900 (3800 waves would be
+    the fourth wave of most SIMDs: one wave each; below the four-streams-per-wave threshold) and in a batch of 75 (pipelined), over
     ragged block lengths (a tail that is not a multiple of four, a block above the 128-sample chunk) -- and match the oracle."""
     ld = na.NeuralModelLoader()
     if std:
@@ -159,7 +160,7 @@ def test_two_layer_lstm_on_one_wave_per_layer_is_bit_identical_to_the_one_wave_b
     w = O.synth_lstm_weights(2, hidden, seed=900 + hidden)
     m = ld.CreateFromString(O.nam_json_lstm(2, hidden, w), ".nam", doPrewarm=True)
     sizes = [128, 37, 128, 3, 300, 64]
-    S_small, S_big = 75, 2100
+    S_small, S_big = 75, 1900
     x = _inputs(S_big, sum(sizes))
     quad.NA_DebugSetRecurrentQuadMin(0)  # (never the four-streams-per-wave kernel here)
 
