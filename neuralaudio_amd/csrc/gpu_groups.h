@@ -904,7 +904,7 @@ namespace na
 				// their total, this name on the group's own count)
 				if (RecurrentDppSupported(dev))
 					return (RecurrentQuadSupported(dev) && RecurrentQuadMinStreams() > 0 &&
-						NumActive() >= (dev.cell == LSTM_CELL_GRU ? RecurrentQuadMinStreams() * 2 / 3 : RecurrentQuadMinStreams())) ? "RecurrentQuadKernel" : "RecurrentDppKernel";
+						NumActive() >= RecurrentQuadMinStreams()) ? "RecurrentQuadKernel" : "RecurrentDppKernel";
 				return dev.cell == LSTM_CELL_GRU ? "GruWaveKernel / RecurrentWaveRtKernel / GruGenericKernel" : "LstmWaveKernel / RecurrentWaveRtKernel / LstmBlockKernel / LstmGenericKernel";
 			}
 

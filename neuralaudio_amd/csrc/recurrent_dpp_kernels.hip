@@ -1262,7 +1262,13 @@ namespace na
 		int v = gQuadMin.load(std::memory_order_relaxed);
 		if (v < 0)
 		{
+			// default: from the first stream that would be a THIRD wave on some SIMD of the one-stream layout (2049 on MI355X) -- measured
+			// (tools/runs/r06ah_quadsizes.py, us per 128-sample step, one stream per wave / four):
+			//   streams     1024  1536  2048  2560  3072  3584  4096  5120  6144
+			//   LSTM 1x16   19.6  29.4  30.1  41.1  40.8  51.2  51.1  61.6  72.0  /  32.1  33.8  34.2  35.6  36.0  37.8  39.5  54.9  57.8
+			//   GRU 1x16    19.6  27.3  27.3  37.0  37.1  45.9  45.9  55.0  64.1  /  26.9  28.3  28.3  29.9  29.8  31.2  32.5  42.0  43.5
 			v = Tuning::Get().recQuadMin;
+			if (v < 0) v = 2 * 4 * CurrentDeviceCUs() + 1;
 			gQuadMin.store(v, std::memory_order_relaxed);
 		}
 		return v;
@@ -1524,11 +1530,7 @@ namespace na
 			blocks += groups[i].numStreams;
 		}
 		// a batch with more waves than the chip can hold at three per SIMD: four streams per wave (all groups must have the layout)
-		// (the GRU body is the shorter one: a lone wave of it takes 27 us per block against 37 for the LSTM body, and it overtakes the
-		// one-stream layout from ~2000 streams instead of ~2800 -- a launch of GRUs only switches at two thirds of the stream count)
-		bool allGru = true;
-		for (int i = 0; i < numGroups; i++) allGru = allGru && groups[i].model.cell == LSTM_CELL_GRU;
-		const int quadMin = allGru ? RecurrentQuadMinStreams() * 2 / 3 : RecurrentQuadMinStreams();
+		const int quadMin = RecurrentQuadMinStreams();
 		bool quad = RecurrentQuadMinStreams() > 0 && blocks >= quadMin;
 		for (int i = 0; i < numGroups; i++) quad = quad && RecurrentQuadSupported(groups[i].model);
 		if (quad)

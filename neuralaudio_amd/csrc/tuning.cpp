@@ -46,7 +46,7 @@ namespace na
 			t.lstmLaneKernel = Has("NA_LSTM_LANE_KERNEL");
 			t.lstmNoWaveRt = Has("NA_LSTM_NO_WAVE_RT");
 			t.recL2w = Int("NA_REC_L2W", 0) != 0;
-			t.recQuadMin = Int("NA_REC_QUAD_MIN", 3072);
+			t.recQuadMin = Int("NA_REC_QUAD_MIN", -1);
 			t.recNoDpp32 = Has("NA_REC_NO_DPP32");
 			t.recNoSkew = Has("NA_REC_NOSKEW");
 			t.recNoPipe = Has("NA_REC_NOPIPE");

@@ -31,7 +31,7 @@ namespace na
 		bool lstmLaneKernel = false; // NA_LSTM_LANE_KERNEL
 		bool lstmNoWaveRt = false; // NA_LSTM_NO_WAVE_RT
 		bool recL2w = false;       // NA_REC_L2W=1
-		int recQuadMin = 3072;     // NA_REC_QUAD_MIN
+		int recQuadMin = -1;       // NA_REC_QUAD_MIN (streams of a launch from which one-layer recurrent models run four streams per wave; -1: two waves per SIMD + 1, 0: never)
 		bool recNoDpp32 = false;   // NA_REC_NO_DPP32
 		bool recNoSkew = false;    // NA_REC_NOSKEW
 		bool recNoPipe = false;    // NA_REC_NOPIPE: two-layer 16-unit LSTMs on the one-wave body instead of one wave per layer (recurrent_dpp_kernels.hip LstmDppPipeBody)

@@ -191,7 +191,7 @@ def test_default_kernel_family_and_pack_factor_of_every_official_architecture(na
         b.AddStreams(m, streams, doPrewarm=False)
         got = (b.StreamKernelName(0), b.StreamPackFactor(0))
         want = expect[name]
-        if name == "lstm1x16" and streams >= 3072:
+        if name == "lstm1x16" and streams > 2048:
             want = ("RecurrentQuadKernel", 1)  # one-layer LSTMs in launches of thousands of streams: four streams per wave
         assert got == want, (name, streams, got)
         assert (b.StreamKernelName(streams - 1), b.StreamPackFactor(streams - 1)) == got
