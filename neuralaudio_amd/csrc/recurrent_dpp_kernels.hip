@@ -1338,7 +1338,7 @@ namespace na
 	}
 
 	// PIPE: workgroups of FOUR waves (one per SIMD of the CU).  A group that pipelines its two layers (RecurrentPipeGroup) puts two streams
-	// into a workgroup, waves [A0 B0 B1 A1] (A: layer 0, B: layer 1); every other group four streams, one per wave, on its one-wave body.
+	// into a workgroup, waves [A0 B0 B1 A1] (A: layer 0, B: layer 1); every other group two streams as well (waves 0 and 3), on its one-wave body.
 	// firstBlock counts these workgroups (host: PipeBlocksOf).  Measured (profiles/r06_cfg4_pipeline.txt, us per 128-sample step, two waves
 	// per stream / one): LSTM 2x16 x 256 streams 27.7 / 35.1, x 512: 28.0 / 36.1, BASELINE config 4 (512 LSTM 2x16 + 512 GRU) 33.0 / 37.1;
 	// x 1024: 41.1 / 38.0 -- with two waves on every SIMD a layer-0 wave no longer stays ahead of its layer-1 wave (which then spins), so
@@ -1365,7 +1365,11 @@ namespace na
 				else LstmDppPipeBody<false>(ga.m, ga.state, ga.capacity, slot, row, in, out, inStride, outStride, n, layer, xin, lds);
 				return;
 			}
-			const int idx = blk * REC_PIPE_WG_WAVES + wave;
+			// a one-wave group of such a launch: TWO streams per workgroup as well, on waves 0 and 3 (1 and 2 leave at once).  Four per
+			// workgroup put eight waves on the CUs that get a second workgroup and four on the others (config 4: 384 workgroups on 256 CUs);
+			// with two, the GRU half of config 4 is one workgroup of two waves on EVERY CU: 32.9 -> 32.4 us (which two waves: no difference)
+			if (wave == 1 || wave == 2) return;
+			const int idx = blk * 2 + (wave == 3 ? 1 : 0);
 			if (idx >= ga.numStreams) return;
 			RecurrentDppRun(ga, idx, noSkew, in, out, inStride, outStride, n, xinAll + wave * REC_XIN_FLOATS, houtAll + (size_t)wave * houtWave);
 		}
@@ -1419,7 +1423,7 @@ namespace na
 	{
 		return m.cell == LSTM_CELL_LSTM && m.numLayers == 2 && m.hidden > 8 && m.hidden <= 16 && m.tailLayers == 0;
 	}
-	static int PipeBlocksOf(const RecurrentGroup& g) { const int spb = HostPipeGroup(g.model) ? 2 : REC_PIPE_WG_WAVES; return (g.numStreams + spb - 1) / spb; }
+	static int PipeBlocksOf(const RecurrentGroup& g) { return (g.numStreams + 1) / 2; } // (two streams per four-wave workgroup, pipelined or not)
 	static_assert(2 * REC_HOUT_FLOATS >= REC_PIPE_FLOATS, "a pair of waves' LDS regions hold the pipelined body's two h arrays");
 	// Measured (tools/runs/r06ag_pipesizes.py, LSTM 2x16 alone, us per 128-sample step, 1024 SIMDs):
 	//   streams        384   512   640   768   896  1024  1152  1280  1536  1792  2048  2304  2560  3072
@@ -1479,7 +1483,7 @@ namespace na
 		}
 		if (!any32 && UsePipe(groups, numGroups, blocks))
 		{
-			// four-wave workgroups: two streams of a pipelining group, four of any other (RecurrentDppDispatch)
+			// four-wave workgroups of two streams each (RecurrentDppDispatch)
 			blocks = 0;
 			for (int i = 0; i < numGroups; i++)
 			{
